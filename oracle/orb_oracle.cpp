@@ -1,0 +1,862 @@
+/*
+ * orb_oracle.cpp — CPU restatement of the reference ORB front-end (parity oracle + timed CPU baseline).
+ *
+ * TEST INFRASTRUCTURE ONLY: loaded by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as
+ * the checker / baseline; the product never calls into it.
+ *
+ * PARITY STATUS: "parity unpinned" for image-dependent stages (the reference's tests pin no numbers on
+ * this path and the reference needs OpenCV >= 4.4, absent here — see orb_oracle.h and DESIGN.md).
+ *
+ * Every function cites the reference file:line it follows (paths relative to the reference repo root).
+ * OpenCV internals follow OpenCV 4.5.0 (the version recorded in the reference's ExecMean.txt:2), plain
+ * C++ code paths (no IPP), as catalogued in SURVEY.md Appendix A.
+ *
+ * Build: g++ -O3 -std=c++17 -ffp-contract=off (no -march=native: the reference builds with plain -O3,
+ * CMakeLists.txt:105-107, so x*b + y*a is an unfused multiply-add).
+ */
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../include/orbx_synth.h"
+#include "pattern_table.inc"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// OpenCV scalar helpers: cvRound = round-half-to-even (SSE cvtss2si / lrint),
+// cvFloor / cvCeil as in opencv2/core/fast_math.hpp.
+// ---------------------------------------------------------------------------------------------------
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+inline int cvFloorD(double v) { int i = (int)v; return i - (i > v); }
+inline int cvCeilD(double v) { int i = (int)v; return i + (i < v); }
+inline uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+inline short satShort(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+const int PATCH_SIZE = 31;        // reference src/ORBextractor.cc:99
+const int HALF_PATCH_SIZE = 15;   // :100
+const int EDGE_THRESHOLD = 19;    // :101
+
+struct Image {
+    int w = 0, h = 0;
+    std::vector<uint8_t> px;  // tight, row-major
+    const uint8_t *row(int y) const { return px.data() + (size_t)y * w; }
+    uint8_t *row(int y) { return px.data() + (size_t)y * w; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// cv::resize(src, dst, sz, 0, 0, INTER_LINEAR) for CV_8UC1 — SURVEY App. A.1.
+// Call site: reference src/ORBextractor.cc:1320.
+// ---------------------------------------------------------------------------------------------------
+void resizeLinear8u(const uint8_t *src, int sw, int sh, ptrdiff_t sstride, uint8_t *dst, int dw, int dh,
+                    ptrdiff_t dstride)
+{
+    const int COEF_BITS = 11, COEF_SCALE = 1 << COEF_BITS;
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> ialpha(dw * 2), ibeta(dh * 2);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvFloorF(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[dx * 2] = satShort(cvRoundF((1.f - fx) * COEF_SCALE));
+        ialpha[dx * 2 + 1] = satShort(cvRoundF(fx * COEF_SCALE));
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cvFloorF(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[dy * 2] = satShort(cvRoundF((1.f - fy) * COEF_SCALE));
+        ibeta[dy * 2 + 1] = satShort(cvRoundF(fy * COEF_SCALE));
+    }
+    auto clipRow = [&](int y) { return y < 0 ? 0 : (y >= sh ? sh - 1 : y); };
+
+    std::vector<int> h0(dw), h1(dw);
+    auto hresize = [&](int sy, std::vector<int> &out) {
+        const uint8_t *S = src + (ptrdiff_t)sy * sstride;
+        for (int dx = 0; dx < dw; ++dx) {
+            int sx = xofs[dx];
+            int s1 = sx + 1 < sw ? sx + 1 : sw - 1;  // second tap replicated at the right edge (its weight is 0)
+            out[dx] = S[sx] * ialpha[dx * 2] + S[s1] * ialpha[dx * 2 + 1];
+        }
+    };
+    int cached0 = -1, cached1 = -1;
+    for (int dy = 0; dy < dh; ++dy) {
+        int sy0 = clipRow(yofs[dy]), sy1 = clipRow(yofs[dy] + 1);
+        if (sy0 == cached1) { std::swap(h0, h1); std::swap(cached0, cached1); }
+        if (sy0 != cached0) { hresize(sy0, h0); cached0 = sy0; }
+        if (sy1 == cached0) { h1 = h0; cached1 = sy1; }
+        else if (sy1 != cached1) { hresize(sy1, h1); cached1 = sy1; }
+        const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+        uint8_t *D = dst + (ptrdiff_t)dy * dstride;
+        for (int x = 0; x < dw; ++x)
+            D[x] = (uint8_t)((((b0 * (h0[x] >> 4)) >> 16) + ((b1 * (h1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cv::GaussianBlur(8U, Size(7,7), 2, 2, BORDER_REFLECT_101) — SURVEY App. A.2 (fixed-point 8.8 taps,
+// exact 16-bit horizontal sums, (sum + 32768) >> 16 vertically, saturated).
+// Call site: reference src/ORBextractor.cc:1270-1273 (on an isolated clone of the level).
+// ---------------------------------------------------------------------------------------------------
+const int kBlurTaps450[7] = {18, 34, 49, 55, 49, 34, 18};  // round(k*256), OpenCV 4.5.0 (sum 257)
+const int kBlurTaps451[7] = {18, 34, 48, 56, 48, 34, 18};  // error-diffused, OpenCV >= 4.5.1 (sum 256)
+
+inline int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+void gaussianBlur7(const uint8_t *src, int w, int h, ptrdiff_t sstride, uint8_t *dst, ptrdiff_t dstride,
+                   const int taps[7])
+{
+    std::vector<uint16_t> tmp((size_t)w * h);
+    std::vector<int> xi((size_t)w + 6);
+    for (int x = -3; x < w + 3; ++x) xi[x + 3] = reflect101(x, w);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t *S = src + (ptrdiff_t)y * sstride;
+        uint16_t *T = tmp.data() + (size_t)y * w;
+        for (int x = 0; x < w; ++x) {
+            unsigned acc = 0;
+            for (int k = 0; k < 7; ++k) acc += (unsigned)taps[k] * S[xi[x + k]];
+            T[x] = (uint16_t)(acc > 65535u ? 65535u : acc);  // ufixedpoint16 saturating add (never hit: 257*255 = 65535)
+        }
+    }
+    for (int y = 0; y < h; ++y) {
+        const uint16_t *R[7];
+        for (int k = 0; k < 7; ++k) R[k] = tmp.data() + (size_t)reflect101(y + k - 3, h) * w;
+        uint8_t *D = dst + (ptrdiff_t)y * dstride;
+        for (int x = 0; x < w; ++x) {
+            uint32_t acc = 0;
+            for (int k = 0; k < 7; ++k) acc += (uint32_t)taps[k] * R[k][x];
+            D[x] = sat8((int)((acc + 32768u) >> 16));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cv::FAST(roi, kps, threshold, nonmaxSuppression=true), TYPE_9_16 — SURVEY App. A.3.
+// Call sites: reference src/ORBextractor.cc:908, 925.
+// ---------------------------------------------------------------------------------------------------
+const int kRing[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                          {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+// cornerScore<16>: largest threshold for which the pixel is still a FAST-9 corner.
+int fastCornerScore(const uint8_t *p, const int pixel[25], int threshold)
+{
+    const int K = 8, N = K * 3 + 1;
+    int v = p[0];
+    int d[N];
+    for (int k = 0; k < N; ++k) d[k] = v - p[pixel[k]];
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = std::min(d[k + 1], d[k + 2]);
+        a = std::min(a, d[k + 3]);
+        if (a <= a0) continue;
+        a = std::min(a, d[k + 4]);
+        a = std::min(a, d[k + 5]);
+        a = std::min(a, d[k + 6]);
+        a = std::min(a, d[k + 7]);
+        a = std::min(a, d[k + 8]);
+        a0 = std::max(a0, std::min(a, d[k]));
+        a0 = std::max(a0, std::min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = std::max(d[k + 1], d[k + 2]);
+        b = std::max(b, d[k + 3]);
+        b = std::max(b, d[k + 4]);
+        b = std::max(b, d[k + 5]);
+        if (b >= b0) continue;
+        b = std::max(b, d[k + 6]);
+        b = std::max(b, d[k + 7]);
+        b = std::max(b, d[k + 8]);
+        b0 = std::min(b0, std::max(b, d[k]));
+        b0 = std::min(b0, std::max(b, d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+struct FastPt { int x, y, score; };
+
+void fast9_16(const uint8_t *img, int cols, int rows, ptrdiff_t step, int threshold, std::vector<FastPt> &out)
+{
+    out.clear();
+    const int K = 8, N = 25;
+    int pixel[25];
+    for (int k = 0; k < 16; ++k) pixel[k] = kRing[k][0] + kRing[k][1] * (int)step;
+    for (int k = 16; k < 25; ++k) pixel[k] = pixel[k - 16];
+    threshold = std::min(std::max(threshold, 0), 255);
+    if (cols < 7 || rows < 7) return;
+
+    std::vector<uint8_t> bufmem((size_t)cols * 3, 0);
+    std::vector<int> cpmem(((size_t)cols + 1) * 3, 0);
+    uint8_t *buf[3] = {bufmem.data(), bufmem.data() + cols, bufmem.data() + 2 * cols};
+    int *cpbuf[3] = {cpmem.data(), cpmem.data() + cols + 1, cpmem.data() + 2 * (cols + 1)};
+
+    for (int i = 3; i < rows - 2; ++i) {
+        const uint8_t *ptr = img + (ptrdiff_t)i * step + 3;
+        uint8_t *curr = buf[(i - 3) % 3];
+        int *cornerpos = cpbuf[(i - 3) % 3] + 1;
+        memset(curr, 0, cols);
+        int ncorners = 0;
+        if (i < rows - 3) {
+            for (int j = 3; j < cols - 3; ++j, ++ptr) {
+                int v = ptr[0];
+                // contiguous-arc test, both polarities (a pixel cannot pass both: 9 + 9 > 16)
+                bool corner = false;
+                {
+                    int vt = v - threshold, count = 0;
+                    for (int k = 0; k < N; ++k) {
+                        if (ptr[pixel[k]] < vt) { if (++count > K) { corner = true; break; } }
+                        else count = 0;
+                    }
+                }
+                if (!corner) {
+                    int vt = v + threshold, count = 0;
+                    for (int k = 0; k < N; ++k) {
+                        if (ptr[pixel[k]] > vt) { if (++count > K) { corner = true; break; } }
+                        else count = 0;
+                    }
+                }
+                if (corner) {
+                    cornerpos[ncorners++] = j;
+                    curr[j] = (uint8_t)fastCornerScore(ptr, pixel, threshold);
+                }
+            }
+        }
+        cornerpos[-1] = ncorners;
+        if (i == 3) continue;
+        const uint8_t *prev = buf[(i - 4 + 3) % 3];
+        const uint8_t *pprev = buf[(i - 5 + 3) % 3];
+        cornerpos = cpbuf[(i - 4 + 3) % 3] + 1;
+        ncorners = cornerpos[-1];
+        for (int k = 0; k < ncorners; ++k) {
+            int j = cornerpos[k];
+            int score = prev[j];
+            if (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] &&
+                score > pprev[j + 1] && score > curr[j - 1] && score > curr[j] && score > curr[j + 1])
+                out.push_back({j, i - 1, score});
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cv::fastAtan2 (degrees) — SURVEY App. A.4.  Imported by the reference at src/ORBextractor.cc:85.
+// ---------------------------------------------------------------------------------------------------
+float fastAtan2Deg(float y, float x)
+{
+    static const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    static const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    static const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    static const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float eps = (float)2.2204460492503131e-16;  // (float)DBL_EPSILON
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Quadtree (reference src/ORBextractor.cc:515-582 DivideNode / compareNodes, 584-774 DistributeOctTree;
+// step specification in SURVEY App. D).  Keys are held as indices into the candidate arrays.
+// ---------------------------------------------------------------------------------------------------
+struct Cand { float x, y, response; };
+
+struct QNode {
+    std::vector<int> keys;
+    int ulx = 0, uly = 0, urx = 0, bry = 0;  // UL.x, UL.y, UR.x, BR.y (BL/BR.x follow)
+    std::list<QNode>::iterator self;
+    bool noMore = false;
+};
+
+void divideNode(const QNode &n, const std::vector<Cand> &c, QNode out[4])
+{
+    const int halfX = (int)std::ceil(static_cast<float>(n.urx - n.ulx) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(n.bry - n.uly) / 2);
+    const int mx = n.ulx + halfX, my = n.uly + halfY;
+    out[0].ulx = n.ulx; out[0].urx = mx;    out[0].uly = n.uly; out[0].bry = my;     // n1: upper-left
+    out[1].ulx = mx;    out[1].urx = n.urx; out[1].uly = n.uly; out[1].bry = my;     // n2: upper-right
+    out[2].ulx = n.ulx; out[2].urx = mx;    out[2].uly = my;    out[2].bry = n.bry;  // n3: bottom-left
+    out[3].ulx = mx;    out[3].urx = n.urx; out[3].uly = my;    out[3].bry = n.bry;  // n4: bottom-right
+    for (int q = 0; q < 4; ++q) out[q].keys.reserve(n.keys.size());
+    for (int k : n.keys) {
+        const Cand &kp = c[k];
+        if (kp.x < (float)mx) {
+            if (kp.y < (float)my) out[0].keys.push_back(k);
+            else out[2].keys.push_back(k);
+        } else if (kp.y < (float)my) out[1].keys.push_back(k);
+        else out[3].keys.push_back(k);
+    }
+    for (int q = 0; q < 4; ++q)
+        if (out[q].keys.size() == 1) out[q].noMore = true;
+}
+
+typedef std::pair<int, QNode *> SizedNode;
+bool compareNodes(const SizedNode &e1, const SizedNode &e2)
+{
+    if (e1.first < e2.first) return true;
+    if (e1.first > e2.first) return false;
+    return e1.second->ulx < e2.second->ulx;
+}
+
+std::vector<int> distributeOctTree(const std::vector<Cand> &c, int minX, int maxX, int minY, int maxY, int N)
+{
+    const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+    const float hX = static_cast<float>(maxX - minX) / nIni;
+    std::list<QNode> nodes;
+    std::vector<QNode *> roots(nIni);
+    for (int i = 0; i < nIni; ++i) {
+        QNode ni;
+        ni.ulx = (int)(hX * static_cast<float>(i));
+        ni.urx = (int)(hX * static_cast<float>(i + 1));
+        ni.uly = 0;
+        ni.bry = maxY - minY;
+        nodes.push_back(ni);
+        roots[i] = &nodes.back();
+    }
+    for (size_t i = 0; i < c.size(); ++i) roots[(int)(c[i].x / hX)]->keys.push_back((int)i);
+
+    for (auto it = nodes.begin(); it != nodes.end();) {
+        if (it->keys.size() == 1) { it->noMore = true; ++it; }
+        else if (it->keys.empty()) it = nodes.erase(it);
+        else ++it;
+    }
+
+    bool finish = false;
+    std::vector<SizedNode> sized;
+    sized.reserve(nodes.size() * 4);
+    auto pushChildren = [&](QNode ch[4], int *nToExpand) {
+        for (int q = 0; q < 4; ++q) {
+            if (ch[q].keys.empty()) continue;
+            nodes.push_front(ch[q]);
+            if (ch[q].keys.size() > 1) {
+                if (nToExpand) ++*nToExpand;
+                sized.push_back(std::make_pair((int)ch[q].keys.size(), &nodes.front()));
+                nodes.front().self = nodes.begin();
+            }
+        }
+    };
+    while (!finish) {
+        int prevSize = (int)nodes.size();
+        int nToExpand = 0;
+        sized.clear();
+        for (auto it = nodes.begin(); it != nodes.end();) {
+            if (it->noMore) { ++it; continue; }
+            QNode ch[4];
+            divideNode(*it, c, ch);
+            pushChildren(ch, &nToExpand);
+            it = nodes.erase(it);
+        }
+        if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) {
+            finish = true;
+        } else if ((int)nodes.size() + nToExpand * 3 > N) {
+            while (!finish) {
+                prevSize = (int)nodes.size();
+                std::vector<SizedNode> prev = sized;
+                sized.clear();
+                std::sort(prev.begin(), prev.end(), compareNodes);  // libstdc++ introsort: tie order is observable
+                for (int j = (int)prev.size() - 1; j >= 0; --j) {
+                    QNode ch[4];
+                    divideNode(*prev[j].second, c, ch);
+                    pushChildren(ch, nullptr);
+                    nodes.erase(prev[j].second->self);
+                    if ((int)nodes.size() >= N) break;
+                }
+                if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) finish = true;
+            }
+        }
+    }
+    std::vector<int> result;
+    result.reserve(nodes.size());
+    for (auto &n : nodes) {
+        int best = n.keys[0];
+        float maxResponse = c[best].response;
+        for (size_t k = 1; k < n.keys.size(); ++k)
+            if (c[n.keys[k]].response > maxResponse) { best = n.keys[k]; maxResponse = c[best].response; }
+        result.push_back(best);
+    }
+    return result;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// The extractor object (reference include/ORBextractor.h:52-113, src/ORBextractor.cc:410-468).
+// ---------------------------------------------------------------------------------------------------
+struct oracle_handle {
+    int nfeatures, nlevels, iniTh, minTh, blurVariant, angleMode;
+    float scaleFactor;
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> featuresPerLevel, umax;
+    // state of the last extract
+    std::vector<Image> pyr, blurred;
+    std::vector<std::vector<FastPt>> cands;             // per level, relative to the 16-px border
+    std::vector<std::vector<oracle_keypoint>> levelKps;  // per level, level coordinates, with angle
+
+    oracle_handle(int nf, float sf, int nl, int ini, int mn, int bv, int am)
+        : nfeatures(nf), nlevels(nl), iniTh(ini), minTh(mn), blurVariant(bv), angleMode(am), scaleFactor(sf)
+    {
+        scale.resize(nl); sigma2.resize(nl); invScale.resize(nl); invSigma2.resize(nl);
+        scale[0] = 1.0f; sigma2[0] = 1.0f;
+        for (int i = 1; i < nl; ++i) {
+            scale[i] = scale[i - 1] * scaleFactor;
+            sigma2[i] = scale[i] * scale[i];
+        }
+        for (int i = 0; i < nl; ++i) {
+            invScale[i] = 1.0f / scale[i];
+            invSigma2[i] = 1.0f / sigma2[i];
+        }
+        featuresPerLevel.resize(nl);
+        float factor = 1.0f / scaleFactor;
+        float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int level = 0; level < nl - 1; ++level) {
+            featuresPerLevel[level] = cvRoundF(nDesired);
+            sum += featuresPerLevel[level];
+            nDesired *= factor;
+        }
+        featuresPerLevel[nl - 1] = std::max(nfeatures - sum, 0);
+
+        umax.resize(HALF_PATCH_SIZE + 1);
+        int v, v0, vmax = cvFloorF(HALF_PATCH_SIZE * std::sqrt(2.f) / 2 + 1);
+        int vmin = cvCeilD(HALF_PATCH_SIZE * std::sqrt(2.f) / 2);
+        const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+        for (v = 0; v <= vmax; ++v) umax[v] = cvRoundD(std::sqrt(hp2 - v * v));
+        for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+    }
+
+    const int *taps() const { return blurVariant ? kBlurTaps451 : kBlurTaps450; }
+
+    // ORBextractor::ComputePyramid — reference src/ORBextractor.cc:1309-1329.  The 19-px REFLECT_101
+    // padding of mvImagePyramid is never read by any extractor stage and is not built.
+    void computePyramid(const uint8_t *img, int w, int h, ptrdiff_t stride)
+    {
+        pyr.assign(nlevels, Image());
+        for (int level = 0; level < nlevels; ++level) {
+            float s = invScale[level];
+            int sw = cvRoundF((float)w * s), sh = cvRoundF((float)h * s);
+            Image &L = pyr[level];
+            L.w = sw; L.h = sh; L.px.resize((size_t)sw * sh);
+            if (level == 0) {
+                for (int y = 0; y < h; ++y) memcpy(L.row(y), img + (ptrdiff_t)y * stride, w);
+            } else {
+                const Image &P = pyr[level - 1];
+                resizeLinear8u(P.px.data(), P.w, P.h, P.w, L.px.data(), sw, sh, sw);
+            }
+        }
+    }
+
+    // tileCalcKeypoints — reference src/ORBextractor.cc:867-950 (the CPU algorithm of record for FAST).
+    void tileCalcKeypoints(const Image &img, std::vector<FastPt> &out) const
+    {
+        out.clear();
+        const int border = EDGE_THRESHOLD - 3;
+        const int minBorderX = border, minBorderY = border;
+        const float W = 35;
+        const int maxBorderX = img.w - EDGE_THRESHOLD + 3;
+        const int maxBorderY = img.h - EDGE_THRESHOLD + 3;
+        const float width = (float)(maxBorderX - minBorderX);
+        const float height = (float)(maxBorderY - minBorderY);
+        const int nCols = (int)(width / W);
+        const int nRows = (int)(height / W);
+        if (nCols < 1 || nRows < 1) return;  // image too small for the reference (division by zero there)
+        const int wCell = (int)std::ceil(width / nCols);
+        const int hCell = (int)std::ceil(height / nRows);
+        std::vector<FastPt> cell;
+        for (int i = 0; i < nRows; ++i) {
+            const float iniY = (float)(minBorderY + i * hCell);
+            float maxY = iniY + hCell + 6;
+            if (iniY >= maxBorderY - 3) continue;
+            if (maxY > maxBorderY) maxY = (float)maxBorderY;
+            for (int j = 0; j < nCols; ++j) {
+                const float iniX = (float)(minBorderX + j * wCell);
+                float maxX = iniX + wCell + 6;
+                if (iniX >= maxBorderX - 6) continue;
+                if (maxX > maxBorderX) maxX = (float)maxBorderX;
+                const int y0 = (int)iniY, y1 = (int)maxY, x0 = (int)iniX, x1 = (int)maxX;
+                const uint8_t *roi = img.row(y0) + x0;
+                fast9_16(roi, x1 - x0, y1 - y0, img.w, iniTh, cell);
+                if (cell.empty()) fast9_16(roi, x1 - x0, y1 - y0, img.w, minTh, cell);
+                for (const FastPt &p : cell) out.push_back({p.x + j * wCell, p.y + i * hCell, p.score});
+            }
+        }
+    }
+
+    // IC_Angle: upstream ORB-SLAM3 CPU function (removed from this fork; moment definition preserved in
+    // reference src/OpenCL/Kernel/Angle.cl:24-60, umax at :3) + cv::fastAtan2.
+    float icAngle(const Image &img, int cx, int cy) const
+    {
+        int m_01 = 0, m_10 = 0;
+        const uint8_t *center = img.row(cy) + cx;
+        const int step = img.w;
+        for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+        for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+            int v_sum = 0;
+            int d = umax[v];
+            for (int u = -d; u <= d; ++u) {
+                int val_plus = center[u + v * step], val_minus = center[u - v * step];
+                v_sum += (val_plus - val_minus);
+                m_10 += u * (val_plus + val_minus);
+            }
+            m_01 += v * v_sum;
+        }
+        if (angleMode == 1) {
+            // fork's OpenCL kernel arithmetic (Angle.cl:56-58)
+            float kp_dir = atan2f((float)m_01, (float)m_10);
+            kp_dir += (kp_dir < 0) * (2.0f * 3.141592f);
+            kp_dir *= 180.0f / 3.141592f;
+            return kp_dir;
+        }
+        return fastAtan2Deg((float)m_01, (float)m_10);
+    }
+
+    // computeOrbDescriptor — reference src/ORBextractor.cc:105-149.
+    void orbDescriptor(const oracle_keypoint &kpt, const Image &img, uint8_t *desc) const
+    {
+        const float factorPI = (float)(M_PI / 180.f);
+        float angle = (float)kpt.angle * factorPI;
+        float a = (float)cos((double)angle), b = (float)sin((double)angle);
+        const uint8_t *center = img.row(cvRoundF(kpt.y)) + cvRoundF(kpt.x);
+        const int step = img.w;
+        const signed char *pat = kOraclePattern31;
+        for (int i = 0; i < 32; ++i, pat += 32) {
+            int val = 0;
+            for (int k = 0; k < 8; ++k) {
+                const signed char *p = pat + 4 * k;
+                float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+                int t0 = center[cvRoundF(x0 * b + y0 * a) * step + cvRoundF(x0 * a - y0 * b)];
+                int t1 = center[cvRoundF(x1 * b + y1 * a) * step + cvRoundF(x1 * a - y1 * b)];
+                val |= (t0 < t1) << k;
+            }
+            desc[i] = (uint8_t)val;
+        }
+    }
+
+    // ComputeKeyPointsOctTree — reference src/ORBextractor.cc:958-1027, with the CPU candidate path
+    // (tileCalcKeypoints, :990-994) and the CPU border/octave/size loop preserved as a comment at :1004-1012.
+    void computeKeyPointsOctTree()
+    {
+        const int border = EDGE_THRESHOLD - 3;
+        cands.assign(nlevels, {});
+        levelKps.assign(nlevels, {});
+        for (int level = 0; level < nlevels; ++level) {
+            const Image &img = pyr[level];
+            const int maxBorderX = img.w - EDGE_THRESHOLD + 3;
+            const int maxBorderY = img.h - EDGE_THRESHOLD + 3;
+            tileCalcKeypoints(img, cands[level]);
+            std::vector<Cand> c(cands[level].size());
+            for (size_t i = 0; i < c.size(); ++i)
+                c[i] = {(float)cands[level][i].x, (float)cands[level][i].y, (float)cands[level][i].score};
+            std::vector<int> sel;
+            if (!c.empty()) sel = distributeOctTree(c, border, maxBorderX, border, maxBorderY, featuresPerLevel[level]);
+            const int scaledPatchSize = (int)(PATCH_SIZE * scale[level]);
+            std::vector<oracle_keypoint> &out = levelKps[level];
+            out.resize(sel.size());
+            for (size_t i = 0; i < sel.size(); ++i) {
+                oracle_keypoint &k = out[i];
+                k.x = c[sel[i]].x + (float)border;
+                k.y = c[sel[i]].y + (float)border;
+                k.size = (float)scaledPatchSize;
+                k.response = c[sel[i]].response;
+                k.octave = level;
+                k.class_id = -1;
+                k.angle = icAngle(img, cvRoundF(k.x), cvRoundF(k.y));
+            }
+        }
+    }
+
+    // ORBextractor::operator() — reference src/ORBextractor.cc:1227-1307.
+    int extract(const uint8_t *img, int w, int h, ptrdiff_t stride, int lap0, int lap1, oracle_keypoint *kps,
+                uint8_t *desc, int *n_out)
+    {
+        if (!img || w <= 0 || h <= 0) { if (n_out) *n_out = 0; return -1; }
+        computePyramid(img, w, h, stride);
+        computeKeyPointsOctTree();
+        int nkeypoints = 0;
+        for (int level = 0; level < nlevels; ++level) nkeypoints += (int)levelKps[level].size();
+        if (n_out) *n_out = nkeypoints;
+        blurred.assign(nlevels, Image());
+        int monoIndex = 0, stereoIndex = nkeypoints - 1;
+        uint8_t d[32];
+        for (int level = 0; level < nlevels; ++level) {
+            std::vector<oracle_keypoint> &keypoints = levelKps[level];
+            // the reference skips the blur for empty levels (:1266-1267); the accessor then returns zeros
+            Image &B = blurred[level];
+            B.w = pyr[level].w; B.h = pyr[level].h;
+            if (keypoints.empty()) continue;
+            B.px.resize(pyr[level].px.size());
+            gaussianBlur7(pyr[level].px.data(), B.w, B.h, B.w, B.px.data(), B.w, taps());
+            float s = scale[level];
+            for (const oracle_keypoint &kp0 : keypoints) {
+                orbDescriptor(kp0, B, d);
+                oracle_keypoint kp = kp0;
+                if (level != 0) { kp.x *= s; kp.y *= s; }
+                int pos;
+                if (kp.x >= (float)lap0 && kp.x <= (float)lap1) pos = stereoIndex--;
+                else pos = monoIndex++;
+                if (kps) kps[pos] = kp;
+                if (desc) memcpy(desc + (size_t)pos * 32, d, 32);
+            }
+        }
+        return monoIndex;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+oracle_handle *oracle_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int blur_variant,
+                             int angle_mode)
+{
+    if (nfeatures <= 0 || nlevels <= 0 || nlevels > 32 || !(scale_factor > 1.0f)) return nullptr;
+    return new oracle_handle(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, angle_mode);
+}
+void oracle_destroy(oracle_handle *h) { delete h; }
+
+int oracle_get_tables(const oracle_handle *h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                      int32_t *fpl, int32_t *umax16)
+{
+    for (int i = 0; i < h->nlevels; ++i) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->invScale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->invSigma2[i];
+        if (fpl) fpl[i] = h->featuresPerLevel[i];
+    }
+    if (umax16) for (int i = 0; i < 16; ++i) umax16[i] = h->umax[i];
+    return h->nlevels;
+}
+int oracle_max_keypoints(const oracle_handle *h)
+{
+    int s = 0;
+    for (int v : h->featuresPerLevel) s += v + 3;
+    return s;
+}
+int oracle_extract(oracle_handle *h, const uint8_t *img, int w, int h_, ptrdiff_t stride, int lap0, int lap1,
+                   oracle_keypoint *kps, uint8_t *desc, int *n_out)
+{
+    return h->extract(img, w, h_, stride, lap0, lap1, kps, desc, n_out);
+}
+int oracle_level_size(const oracle_handle *h, int level, int *w, int *hh)
+{
+    if (level < 0 || level >= (int)h->pyr.size()) return -1;
+    *w = h->pyr[level].w; *hh = h->pyr[level].h;
+    return 0;
+}
+int oracle_get_level(const oracle_handle *h, int level, int blurred, uint8_t *out)
+{
+    const std::vector<Image> &v = blurred ? h->blurred : h->pyr;
+    if (level < 0 || level >= (int)v.size()) return -1;
+    if (v[level].px.empty()) { memset(out, 0, (size_t)v[level].w * v[level].h); return 1; }
+    memcpy(out, v[level].px.data(), v[level].px.size());
+    return 0;
+}
+int oracle_get_candidates(const oracle_handle *h, int level, uint32_t *out, int cap)
+{
+    if (level < 0 || level >= (int)h->cands.size()) return -1;
+    const auto &c = h->cands[level];
+    for (int i = 0; i < (int)c.size() && i < cap; ++i)
+        out[i] = (uint32_t)c[i].x | ((uint32_t)c[i].y << 12) | ((uint32_t)c[i].score << 24);
+    return (int)c.size();
+}
+int oracle_get_level_keypoints(const oracle_handle *h, int level, oracle_keypoint *out, int cap)
+{
+    if (level < 0 || level >= (int)h->levelKps.size()) return -1;
+    const auto &k = h->levelKps[level];
+    for (int i = 0; i < (int)k.size() && i < cap; ++i) out[i] = k[i];
+    return (int)k.size();
+}
+
+int oracle_extract_batch(oracle_handle *h, const uint8_t *imgs, int n, int w, int hh, ptrdiff_t stride, int lap0,
+                         int lap1, int threads, int32_t *counts, int32_t *mono, oracle_keypoint *kps, uint8_t *desc,
+                         int cap)
+{
+    if (threads < 1) threads = 1;
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+        oracle_handle local(h->nfeatures, h->scaleFactor, h->nlevels, h->iniTh, h->minTh, h->blurVariant, h->angleMode);
+        std::vector<oracle_keypoint> k(oracle_max_keypoints(&local));
+        std::vector<uint8_t> d((size_t)k.size() * 32);
+        for (;;) {
+            int f = next.fetch_add(1);
+            if (f >= n) break;
+            int cnt = 0;
+            int m = local.extract(imgs + (size_t)f * hh * stride, w, hh, stride, lap0, lap1, k.data(), d.data(), &cnt);
+            if (counts) counts[f] = cnt;
+            if (mono) mono[f] = m;
+            int c = std::min(cnt, cap);
+            if (kps) memcpy(kps + (size_t)f * cap, k.data(), (size_t)c * sizeof(oracle_keypoint));
+            if (desc) memcpy(desc + (size_t)f * cap * 32, d.data(), (size_t)c * 32);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    return 0;
+}
+
+int oracle_resize_linear(const uint8_t *src, int sw, int sh, ptrdiff_t sstride, uint8_t *dst, int dw, int dh,
+                         ptrdiff_t dstride)
+{
+    resizeLinear8u(src, sw, sh, sstride, dst, dw, dh, dstride);
+    return 0;
+}
+int oracle_gaussian_blur7(const uint8_t *src, int w, int h, ptrdiff_t sstride, uint8_t *dst, ptrdiff_t dstride,
+                          int blur_variant)
+{
+    gaussianBlur7(src, w, h, sstride, dst, dstride, blur_variant ? kBlurTaps451 : kBlurTaps450);
+    return 0;
+}
+int oracle_fast_roi(const uint8_t *roi, int cols, int rows, ptrdiff_t stride, int threshold, uint32_t *out, int cap)
+{
+    std::vector<FastPt> v;
+    fast9_16(roi, cols, rows, stride, threshold, v);
+    for (int i = 0; i < (int)v.size() && i < cap; ++i)
+        out[i] = (uint32_t)v[i].x | ((uint32_t)v[i].y << 12) | ((uint32_t)v[i].score << 24);
+    return (int)v.size();
+}
+float oracle_fast_atan2(float y, float x) { return fastAtan2Deg(y, x); }
+
+int oracle_distribute(const uint32_t *cand, int ncand, int W, int H, int N, int32_t *out_idx, int cap)
+{
+    std::vector<Cand> c(ncand);
+    for (int i = 0; i < ncand; ++i)
+        c[i] = {(float)(cand[i] & 0xFFF), (float)((cand[i] >> 12) & 0xFFF), (float)(cand[i] >> 24)};
+    if (c.empty()) return 0;
+    std::vector<int> r = distributeOctTree(c, 0, W, 0, H, N);
+    for (int i = 0; i < (int)r.size() && i < cap; ++i) out_idx[i] = r[i];
+    return (int)r.size();
+}
+
+int oracle_sort_pairs(const int32_t *count, const int32_t *ulx, int n, int32_t *order)
+{
+    std::vector<QNode> nodes(n);
+    std::vector<SizedNode> v(n);
+    for (int i = 0; i < n; ++i) { nodes[i].ulx = ulx[i]; v[i] = std::make_pair((int)count[i], &nodes[i]); }
+    std::sort(v.begin(), v.end(), compareNodes);
+    for (int i = 0; i < n; ++i) order[i] = (int32_t)(v[i].second - nodes.data());
+    return 0;
+}
+
+// ORBmatcher::DescriptorDistance — reference src/ORBmatcher3.cc:637-653 (SWAR popcount of 8 xor-ed words).
+int oracle_hamming256(const void *a, const void *b)
+{
+    uint32_t pa[8], pb[8];
+    memcpy(pa, a, 32); memcpy(pb, b, 32);
+    int dist = 0;
+    for (int i = 0; i < 8; ++i) {
+        unsigned int v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2) — SURVEY App. A.7; call site reference src/Frame.cc:1174.
+int oracle_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
+{
+    const int K = 2;
+    for (int i = 0; i < nq; ++i) {
+        int32_t *di = dist + (size_t)i * K, *ni = idx + (size_t)i * K;
+        for (int k = 0; k < K; ++k) { di[k] = INT_MAX; ni[k] = -1; }
+        for (int j = 0; j < nt; ++j) {
+            int d = oracle_hamming256(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < di[K - 1]) {
+                int k;
+                for (k = K - 2; k >= 0 && di[k] > d; --k) { ni[k + 1] = ni[k]; di[k + 1] = di[k]; }
+                ni[k + 1] = j;
+                di[k + 1] = d;
+            }
+        }
+    }
+    return 0;
+}
+
+// Frame::ComputeStereoMatches, Hamming stage — reference src/Frame.cc:841-925 (TH_HIGH = 100,
+// src/ORBmatcher1.cc:37).
+int oracle_stereo_rows(const oracle_keypoint *kl, const uint8_t *dl, int nl, const oracle_keypoint *kr,
+                       const uint8_t *dr, int nr, int n_rows, const float *sf, float min_d, float max_d,
+                       int32_t *best_idx, int32_t *best_dist)
+{
+    const int TH_HIGH = 100;
+    std::vector<std::vector<int>> rowIdx(n_rows);
+    for (int iR = 0; iR < nr; ++iR) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * sf[kr[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; ++yi)
+            if (yi >= 0 && yi < n_rows) rowIdx[yi].push_back(iR);  // the reference would index out of range here
+    }
+    for (int iL = 0; iL < nl; ++iL) {
+        best_idx[iL] = -1;
+        best_dist[iL] = TH_HIGH;
+        const int levelL = kl[iL].octave;
+        const float vL = kl[iL].y, uL = kl[iL].x;
+        int row = (int)vL;
+        if (row < 0 || row >= n_rows) continue;
+        const std::vector<int> &cands = rowIdx[row];
+        if (cands.empty()) continue;
+        const float minU = uL - max_d, maxU = uL - min_d;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH, bestIdx = -1;
+        for (int iR : cands) {
+            if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+            const float uR = kr[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                int d = oracle_hamming256(dl + (size_t)iL * 32, dr + (size_t)iR * 32);
+                if (d < bestDist) { bestDist = d; bestIdx = iR; }
+            }
+        }
+        best_idx[iL] = bestIdx;
+        best_dist[iL] = bestDist;
+    }
+    return 0;
+}
+
+void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride)
+{
+    orbx_synth_frame_impl(seed, w, h, out, stride);
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+/*
+ * orb_oracle.h — C ABI of the CPU parity oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the timed CPU baseline.  The product (liborbx.so) never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" for every image-dependent stage — the reference's own tests hold no
+ * numeric golden vectors for this path and the reference cannot be built here
+ * (OpenCV >= 4.4 absent).  What IS pinned against the reference text: umax (Angle.cl:3), the
+ * 256-pair sampling pattern (SHA-256), per-level quotas / level sizes / scale tables (App. C),
+ * DescriptorDistance identities.  OpenCV internals (resize, FAST, GaussianBlur, fastAtan2,
+ * BFMatcher) are restated from OpenCV 4.5.0 semantics as documented in SURVEY.md App. A.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_handle oracle_handle;
+
+/* 28-byte record, identical field order to cv::KeyPoint / key_point_t
+ * (reference include/OpenCL/Kernel/key_point.hpp). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} oracle_keypoint;
+
+/* blur_variant: 0 = OpenCV 4.5.0 taps {18,34,49,55,49,34,18}; 1 = OpenCV >= 4.5.1 taps
+ * {18,34,48,56,48,34,18}.  angle_mode: 0 = cv::fastAtan2 polynomial; 1 = libm atan2f (fork kernel). */
+oracle_handle *oracle_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
+                             int blur_variant, int angle_mode);
+void oracle_destroy(oracle_handle *);
+
+/* constructor tables (reference src/ORBextractor.cc:410-468) */
+int oracle_get_tables(const oracle_handle *, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                      int32_t *features_per_level, int32_t *umax16);
+int oracle_max_keypoints(const oracle_handle *); /* sum(N_l + 3) */
+
+/* ORBextractor::operator() (reference src/ORBextractor.cc:1227-1307).  Returns monoIndex, or -1 on an
+ * empty image.  kps/desc must hold oracle_max_keypoints() entries. */
+int oracle_extract(oracle_handle *, const uint8_t *img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+                   oracle_keypoint *kps, uint8_t *desc, int *n_out);
+
+/* stage accessors for the last oracle_extract() on this handle */
+int oracle_level_size(const oracle_handle *, int level, int *w, int *h);
+int oracle_get_level(const oracle_handle *, int level, int blurred, uint8_t *out /* w*h, tight */);
+/* FAST candidates (A5) of a level: packed x | y<<12 | score<<24, coordinates relative to the 16-px border */
+int oracle_get_candidates(const oracle_handle *, int level, uint32_t *out, int cap);
+/* per-level keypoints after DistributeOctTree + border + orientation (level coordinates) */
+int oracle_get_level_keypoints(const oracle_handle *, int level, oracle_keypoint *out, int cap);
+
+/* Batch runner used for the CPU baseline: frames are contiguous [n][h][stride]; `threads` workers each
+ * with a private extractor; fills counts[n] (and kps/desc when non-NULL, cap entries per frame). */
+int oracle_extract_batch(oracle_handle *, const uint8_t *imgs, int n, int w, int h, ptrdiff_t stride,
+                         int lap0, int lap1, int threads, int32_t *counts, int32_t *mono,
+                         oracle_keypoint *kps, uint8_t *desc, int cap);
+
+/* stand-alone stages, for stage-level parity tests */
+int oracle_resize_linear(const uint8_t *src, int sw, int sh, ptrdiff_t sstride, uint8_t *dst, int dw, int dh,
+                         ptrdiff_t dstride);
+int oracle_gaussian_blur7(const uint8_t *src, int w, int h, ptrdiff_t sstride, uint8_t *dst, ptrdiff_t dstride,
+                          int blur_variant);
+/* cv::FAST(roi, th, nms=true) on a ROI; out = packed x | y<<12 | score<<24 in emission order */
+int oracle_fast_roi(const uint8_t *roi, int cols, int rows, ptrdiff_t stride, int threshold, uint32_t *out,
+                    int cap);
+float oracle_fast_atan2(float y, float x);
+/* DistributeOctTree on packed candidates (x | y<<12 | score<<24), region W x H (= maxX-minX, maxY-minY),
+ * quota N; out_idx = indices into cand[] in result order.  Returns count. */
+int oracle_distribute(const uint32_t *cand, int ncand, int W, int H, int N, int32_t *out_idx, int cap);
+/* std::sort(pairs, compareNodes) permutation probe: keys (count, ulx); writes the sorted order of
+ * original indices.  Used to pin the device introsort emulation. */
+int oracle_sort_pairs(const int32_t *count, const int32_t *ulx, int n, int32_t *order);
+
+/* matcher leafs */
+int oracle_hamming256(const void *a, const void *b); /* ORBmatcher::DescriptorDistance, ORBmatcher3.cc:637-653 */
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) (reference src/Frame.cc:1174); idx = -1 / dist = INT_MAX when absent */
+int oracle_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx /*nq*2*/, int32_t *dist /*nq*2*/);
+/* Hamming stage of Frame::ComputeStereoMatches (reference src/Frame.cc:841-925).  best_idx[i] = right index
+ * or -1, best_dist[i] = distance (TH_HIGH when none). */
+int oracle_stereo_rows(const oracle_keypoint *kl, const uint8_t *dl, int nl, const oracle_keypoint *kr,
+                       const uint8_t *dr, int nr, int n_rows, const float *scale_factors, float min_d, float max_d,
+                       int32_t *best_idx, int32_t *best_dist);
+
+/* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
+ * here so the oracle library is self-contained for CPU-only tests). */
+void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
