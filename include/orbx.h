@@ -1,0 +1,208 @@
+/*
+ * orbx.h — C ABI of the MI355X-native ORB front-end (liborbx.so).
+ *
+ * Drop-in boundary for the ORB hot path of kpmrozowski/wut-cuda-orb-slam3.  Plain
+ * pointers and sizes only; no C++/torch types cross this boundary.  Every entry point names the
+ * reference interface it replaces (file:line relative to the reference repository root).
+ *
+ * Error model (reference: `return -1` on an empty image, src/ORBextractor.cc:1231-1232; exceptions /
+ * exit(1) elsewhere, src/OpenCL/Manager.cpp:13-20): functions return an orbx_status (0 = OK, negative =
+ * error) unless documented otherwise; orbx_last_error() returns a thread-local message.  The library
+ * never exits the process and never throws across this boundary.  There is NO CPU fallback: without a
+ * HIP device every compute entry point fails with ORBX_ERR_NO_DEVICE.
+ *
+ * Threading (reference: operator() of two different extractor objects runs in two std::threads,
+ * src/Frame.cc:124-127): handles are independent and may be used concurrently from different threads;
+ * one handle must not be entered concurrently.  Each handle owns one HIP stream.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_VERSION 100
+
+typedef enum {
+    ORBX_OK = 0,
+    ORBX_ERR_INVALID_ARG = -1,
+    ORBX_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init */
+    ORBX_ERR_HIP = -3,         /* a HIP call or kernel launch failed (reference: throw std::runtime_error, ORBextractor.cc:499,862,974,1213) */
+    ORBX_ERR_CAPACITY = -4,    /* image, batch or output capacity exceeds what the handle was created for */
+    ORBX_ERR_TOO_SMALL = -5,   /* a pyramid level is too small for the 35-px FAST cell grid (the reference divides by zero there) */
+    ORBX_ERR_OUT_OF_MEMORY = -6
+} orbx_status;
+
+/* 28-byte keypoint record == cv::KeyPoint == key_point_t (reference include/OpenCL/Manager.hpp:11-24,
+ * include/OpenCL/Kernel/key_point.hpp): a C++ adaptor can memcpy into std::vector<cv::KeyPoint>. */
+typedef struct {
+    float x, y;       /* pt, level-0 image coordinates */
+    float size;       /* (int)(31 * scaleFactor[octave]) */
+    float angle;      /* degrees in [0, 360) */
+    float response;   /* FAST score */
+    int32_t octave;   /* pyramid level */
+    int32_t class_id; /* -1 */
+} orbx_keypoint;
+
+/* GaussianBlur fixed-point tap table: the 8-bit taps depend on the OpenCV version. */
+typedef enum {
+    ORBX_BLUR_OPENCV_450 = 0, /* {18,34,49,55,49,34,18} — OpenCV <= 4.5.0 (the version in the reference's ExecMean.txt:2) */
+    ORBX_BLUR_OPENCV_451 = 1  /* {18,34,48,56,48,34,18} — OpenCV >= 4.5.1 / 3.4.13 (sum forced to 256) */
+} orbx_blur_variant;
+
+typedef enum {
+    ORBX_ANGLE_FASTATAN2 = 0, /* upstream CPU IC_Angle: cv::fastAtan2 (reference src/ORBextractor.cc:85) */
+    ORBX_ANGLE_ATAN2F = 1     /* fork's OpenCL kernel: atan2 + 3.141592f constants (src/OpenCL/Kernel/Angle.cl:56-58) */
+} orbx_angle_mode;
+
+/* Constructor arguments of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:58-59) plus the
+ * device-side sizing the reference re-derives on every call (src/ORBextractor.cc:1315). */
+typedef struct {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t device;      /* HIP device ordinal */
+    int32_t max_width;   /* largest image the handle will see */
+    int32_t max_height;
+    int32_t max_batch;   /* frames per orbx_extract_batch call */
+    int32_t blur_variant; /* orbx_blur_variant */
+    int32_t angle_mode;   /* orbx_angle_mode */
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;
+
+/* Fills *p with the reference defaults (nfeatures 1000, 1.2, 8 levels, 20/7, 640x480, batch 1). */
+void orbx_default_params(orbx_params *p);
+
+/* ORBextractor::ORBextractor — reference src/ORBextractor.cc:410-468.  Allocates all device memory and
+ * pinned staging once; no allocation happens on the extraction path afterwards. */
+int orbx_create(const orbx_params *p, orbx_extractor **out);
+void orbx_destroy(orbx_extractor *ex);
+
+/* Thread-local description of the last error on the calling thread. */
+const char *orbx_last_error(void);
+
+/* Getters — reference include/ORBextractor.h:70-90 (GetLevels, GetScaleFactor, GetScaleFactors,
+ * GetInverseScaleFactors, GetScaleSigmaSquares, GetInverseScaleSigmaSquares).  Arrays hold nlevels entries. */
+int orbx_get_levels(const orbx_extractor *ex);
+float orbx_get_scale_factor(const orbx_extractor *ex);
+int orbx_get_scale_factors(const orbx_extractor *ex, float *out);
+int orbx_get_inverse_scale_factors(const orbx_extractor *ex, float *out);
+int orbx_get_scale_sigma_squares(const orbx_extractor *ex, float *out);
+int orbx_get_inverse_scale_sigma_squares(const orbx_extractor *ex, float *out);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:436-447) and umax[16] (:455-467) */
+int orbx_get_features_per_level(const orbx_extractor *ex, int32_t *out);
+int orbx_get_umax(const orbx_extractor *ex, int32_t *out16);
+/* Output capacity a caller must provide per frame: sum over levels of (quota + 3) — DistributeOctTree can
+ * overshoot its quota by up to 3 (src/ORBextractor.cc:697). */
+int orbx_max_keypoints(const orbx_extractor *ex);
+
+/* ORBextractor::operator()(image, mask (ignored), keypoints, descriptors, vLappingArea) —
+ * reference include/ORBextractor.h:66-68, src/ORBextractor.cc:1227-1307, invoked through
+ * Frame::ExtractORB (src/Frame.cc:430-455).
+ * img: host pointer, 8-bit single channel, `stride` bytes per row.  Keypoints with pt.x in [lap0, lap1] are
+ * written from the back of the output in reverse order, the rest from the front (:1293-1301).
+ * Returns monoIndex (>= 0), or -1 for an empty image (img == NULL or w/h <= 0) exactly like the reference;
+ * library errors are kept apart from that -1 by returning (orbx_status - 100), i.e. values <= -101. */
+int orbx_extract(orbx_extractor *ex, const uint8_t *img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+                 orbx_keypoint *kps, uint8_t *desc /* capacity x 32, row-major */, int capacity, int *n_out);
+
+/* Batch form for the multi-frame configurations: nframes images, frame f at imgs + f*frame_stride.
+ * Per frame f: n_out[f] keypoints, mono_out[f] = monoIndex; kps/desc rows of frame f start at f*capacity.
+ * Host pointers in, host pointers out (H2D and D2H included).  Returns ORBX_OK or an orbx_status. */
+int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
+                       ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
+                       int32_t *n_out, int32_t *mono_out);
+
+/* Device-resident batch: d_imgs is a device pointer (frames already in HBM); results stay in HBM in the
+ * handle's own output buffers, retrievable with orbx_device_outputs().  Launches asynchronously on the
+ * handle's stream; orbx_sync() waits.  This is the path bench.py times. */
+int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride,
+                              ptrdiff_t frame_stride, int lap0, int lap1);
+int orbx_sync(orbx_extractor *ex);
+/* Device pointers of the last batch's outputs: kps [max_batch][capacity], desc [max_batch][capacity][32],
+ * n [max_batch], mono [max_batch]; capacity = orbx_max_keypoints(). */
+int orbx_device_outputs(orbx_extractor *ex, void **d_kps, void **d_desc, void **d_n, void **d_mono);
+/* Copies the last batch's outputs to host arrays laid out as in orbx_extract_batch. */
+int orbx_download_outputs(orbx_extractor *ex, int nframes, orbx_keypoint *kps, uint8_t *desc, int capacity,
+                          int32_t *n_out, int32_t *mono_out);
+/* The HIP stream (hipStream_t) the handle launches on — for event timing by the caller. */
+void *orbx_stream(orbx_extractor *ex);
+
+/* mvImagePyramid[level] — public member read by Frame::ComputeStereoMatches (reference
+ * include/ORBextractor.h:92, src/Frame.cc:848,938-953).  Copies the interior (un-padded) level image of
+ * frame `frame` of the last batch to `out` (w*h bytes, tight).  blurred != 0 returns the GaussianBlur-ed
+ * working image (src/ORBextractor.cc:1270-1273) instead. */
+int orbx_get_level_size(const orbx_extractor *ex, int level, int *w, int *h);
+int orbx_get_pyramid_level(orbx_extractor *ex, int frame, int level, int blurred, uint8_t *out);
+
+/* Stage taps for parity tests (no reference counterpart): FAST candidates of a level in
+ * tileCalcKeypoints order (src/ORBextractor.cc:867-950), packed x | y<<12 | score<<24 relative to the 16-px
+ * border; and the per-level DistributeOctTree output in list order (same packing). Return the count. */
+int orbx_debug_get_candidates(orbx_extractor *ex, int frame, int level, uint32_t *out, int cap);
+int orbx_debug_get_selected(orbx_extractor *ex, int frame, int level, uint32_t *out, int cap);
+
+/* ---- matcher leafs ------------------------------------------------------------------------------ */
+
+/* ORBmatcher::DescriptorDistance(a, b) — reference include/ORBmatcher.h:43, src/ORBmatcher3.cc:637-653
+ * (duplicate: Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101).  Host inline; a, b point to 32 bytes. */
+static inline int orbx_hamming256(const void *a, const void *b)
+{
+    const uint64_t *pa = (const uint64_t *)a, *pb = (const uint64_t *)b;
+    int d = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint64_t v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x5555555555555555ull);
+        v = (v & 0x3333333333333333ull) + ((v >> 2) & 0x3333333333333333ull);
+        d += (int)((((v + (v >> 4)) & 0x0F0F0F0F0F0F0F0Full) * 0x0101010101010101ull) >> 56);
+    }
+    return d;
+}
+
+typedef struct orbx_matcher orbx_matcher;
+/* Matcher context: device ordinal + capacities (max query / train rows). */
+int orbx_matcher_create(int device, int max_query, int max_train, orbx_matcher **out);
+void orbx_matcher_destroy(orbx_matcher *m);
+
+/* All-pairs distance matrix dist[nq][nt] (int32) — the loop body every ORBmatcher search routine runs
+ * (18 call sites of DescriptorDistance).  Host pointers. */
+int orbx_hamming_matrix(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *dist);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, matches, 2) — reference src/Frame.cc:45,1174.  Per query the
+ * two smallest distances, ties ranked by lower train index; idx = -1 and dist = INT32_MAX when fewer than
+ * k train rows exist.  Host pointers; idx/dist are [nq][2]. */
+int orbx_match_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx,
+                    int32_t *dist);
+/* Same with device pointers (descriptors straight from orbx_device_outputs), asynchronous on the
+ * matcher's stream; orbx_matcher_sync() waits. */
+int orbx_match_knn2_device(orbx_matcher *m, const void *d_q, int nq, const void *d_t, int nt, void *d_idx,
+                           void *d_dist);
+int orbx_matcher_sync(orbx_matcher *m);
+
+/* Hamming stage of Frame::ComputeStereoMatches — reference src/Frame.cc:841-925: for each left keypoint
+ * the best right keypoint whose row band [floor(y-r), ceil(y+r)], r = 2*scale[octave], contains the left
+ * row, with |octave difference| <= 1 and uR in [uL-max_d, uL-min_d]; best_dist starts at TH_HIGH = 100
+ * (src/ORBmatcher1.cc:37).  best_idx = -1 when none. Host pointers. */
+int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int nl,
+                           const orbx_keypoint *kr, const uint8_t *dr, int nr, int n_rows, const float *scale_factors,
+                           int nlevels, float min_d, float max_d, int32_t *best_idx, int32_t *best_dist);
+
+/* ---- utilities ---------------------------------------------------------------------------------- */
+
+/* Number of HIP devices (reference: Eden_resources::get_gpus_count, src/HipEdenResources/Ngpus_Ncpus.cpp). */
+int orbx_device_count(void);
+/* Deterministic synthetic frame (include/orbx_synth.h): host buffer. */
+void orbx_synth_frame(uint64_t frame_index, int w, int h, uint8_t *out, ptrdiff_t stride);
+/* Per-level geometry for a w x h image: sizes out[level] (reference src/ORBextractor.cc:1313). */
+int orbx_level_sizes(const orbx_extractor *ex, int w, int h, int32_t *lw, int32_t *lh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,206 @@
+"""ctypes wrapper of the CPU parity oracle (oracle/liborb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the
+checker / timed CPU baseline.  The product never imports it.  Parity status: see orb_oracle.h ("parity unpinned"
+for image-dependent stages; constructor tables, umax, sampling pattern and Hamming identities are pinned
+against the reference text).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_float, c_int, c_ssize_t, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing — run `make -C oracle`")
+        L = ctypes.CDLL(LIB_PATH)
+        L.oracle_create.restype = c_void_p
+        L.oracle_create.argtypes = [c_int, c_float, c_int, c_int, c_int, c_int, c_int]
+        L.oracle_destroy.argtypes = [c_void_p]
+        L.oracle_destroy.restype = None
+        L.oracle_get_tables.argtypes = [c_void_p] + [c_void_p] * 6
+        L.oracle_max_keypoints.argtypes = [c_void_p]
+        L.oracle_extract.argtypes = [c_void_p, c_void_p, c_int, c_int, c_ssize_t, c_int, c_int, c_void_p, c_void_p, POINTER(c_int)]
+        L.oracle_level_size.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]
+        L.oracle_get_level.argtypes = [c_void_p, c_int, c_int, c_void_p]
+        L.oracle_get_candidates.argtypes = [c_void_p, c_int, c_void_p, c_int]
+        L.oracle_get_level_keypoints.argtypes = [c_void_p, c_int, c_void_p, c_int]
+        L.oracle_extract_batch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_ssize_t, c_int, c_int, c_int, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_int]
+        L.oracle_resize_linear.argtypes = [c_void_p, c_int, c_int, c_ssize_t, c_void_p, c_int, c_int, c_ssize_t]
+        L.oracle_gaussian_blur7.argtypes = [c_void_p, c_int, c_int, c_ssize_t, c_void_p, c_ssize_t, c_int]
+        L.oracle_fast_roi.argtypes = [c_void_p, c_int, c_int, c_ssize_t, c_int, c_void_p, c_int]
+        L.oracle_fast_atan2.argtypes = [c_float, c_float]
+        L.oracle_fast_atan2.restype = c_float
+        L.oracle_distribute.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]
+        L.oracle_sort_pairs.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+        L.oracle_hamming256.argtypes = [c_void_p, c_void_p]
+        L.oracle_knn2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
+        L.oracle_stereo_rows.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float,
+                                         c_void_p, c_void_p]
+        L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
+        L.oracle_synth_frame.restype = None
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0, angle_mode=0):
+        self.L = lib()
+        self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, angle_mode)
+        if not self.h:
+            raise ValueError("oracle_create rejected the parameters")
+        self.nlevels = nlevels
+        self.capacity = self.L.oracle_max_keypoints(self.h)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self.h:
+                self.L.oracle_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.oracle_get_tables(self.h, sc.ctypes.data, isc.ctypes.data, s2.ctypes.data, is2.ctypes.data, fpl.ctypes.data, um.ctypes.data)
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, features_per_level=fpl, umax=um)
+
+    def extract(self, img: np.ndarray, lap=(0, 0)):
+        if img is None or img.size == 0:
+            return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = max(self.capacity, 64) + 64
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = c_int()
+        mono = self.L.oracle_extract(self.h, img.ctypes.data, w, h, img.strides[0], int(lap[0]), int(lap[1]), kps.ctypes.data,
+                                     desc.ctypes.data, byref(n))
+        return mono, kps[: n.value].copy(), desc[: n.value].copy()
+
+    def level_size(self, level):
+        w, h = c_int(), c_int()
+        self.L.oracle_level_size(self.h, level, byref(w), byref(h))
+        return w.value, h.value
+
+    def level(self, level, blurred=False):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        self.L.oracle_get_level(self.h, level, int(blurred), out.ctypes.data)
+        return out
+
+    def candidates(self, level, cap=1 << 20):
+        out = np.zeros(cap, np.uint32)
+        n = self.L.oracle_get_candidates(self.h, level, out.ctypes.data, cap)
+        return out[:n].copy()
+
+    def level_keypoints(self, level):
+        out = np.zeros(self.capacity + 64, KEYPOINT_DTYPE)
+        n = self.L.oracle_get_level_keypoints(self.h, level, out.ctypes.data, len(out))
+        return out[:n].copy()
+
+    def extract_batch(self, imgs: np.ndarray, lap=(0, 0), threads=1, want_outputs=False):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        b, h, w = imgs.shape
+        counts = np.zeros(b, np.int32)
+        mono = np.zeros(b, np.int32)
+        cap = self.capacity
+        kps = np.zeros((b, cap), KEYPOINT_DTYPE) if want_outputs else None
+        desc = np.zeros((b, cap, 32), np.uint8) if want_outputs else None
+        self.L.oracle_extract_batch(self.h, imgs.ctypes.data, b, w, h, imgs.strides[1], int(lap[0]), int(lap[1]), threads,
+                                    counts.ctypes.data, mono.ctypes.data, kps.ctypes.data if want_outputs else None,
+                                    desc.ctypes.data if want_outputs else None, cap)
+        return counts, mono, kps, desc
+
+
+def synth_frame(frame_index, w=640, h=480):
+    img = np.empty((h, w), np.uint8)
+    lib().oracle_synth_frame(frame_index, w, h, img.ctypes.data, w)
+    return img
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oracle_resize_linear(src.ctypes.data, src.shape[1], src.shape[0], src.strides[0], dst.ctypes.data, dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src: np.ndarray, blur_variant=0) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().oracle_gaussian_blur7(src.ctypes.data, src.shape[1], src.shape[0], src.strides[0], dst.ctypes.data, dst.strides[0], blur_variant)
+    return dst
+
+
+def fast_roi(roi: np.ndarray, threshold: int) -> np.ndarray:
+    roi = np.ascontiguousarray(roi, np.uint8)
+    out = np.zeros(roi.size, np.uint32)
+    n = lib().oracle_fast_roi(roi.ctypes.data, roi.shape[1], roi.shape[0], roi.strides[0], threshold, out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+def fast_atan2(y: float, x: float) -> float:
+    return float(lib().oracle_fast_atan2(y, x))
+
+
+def distribute(cand: np.ndarray, W: int, H: int, N: int) -> np.ndarray:
+    cand = np.ascontiguousarray(cand, np.uint32)
+    out = np.zeros(N + 64, np.int32)
+    n = lib().oracle_distribute(cand.ctypes.data, len(cand), W, H, N, out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+def sort_pairs(count: np.ndarray, ulx: np.ndarray) -> np.ndarray:
+    count = np.ascontiguousarray(count, np.int32)
+    ulx = np.ascontiguousarray(ulx, np.int32)
+    order = np.zeros(len(count), np.int32)
+    lib().oracle_sort_pairs(count.ctypes.data, ulx.ctypes.data, len(count), order.ctypes.data)
+    return order
+
+
+def hamming256(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().oracle_hamming256(a.ctypes.data, b.ctypes.data))
+
+
+def knn2(q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(q), 2), np.int32)
+    dist = np.zeros((len(q), 2), np.int32)
+    lib().oracle_knn2(q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data, dist.ctypes.data)
+    return idx, dist
+
+
+def stereo_rows(kl, dl, kr, dr, n_rows, scale_factors, min_d, max_d):
+    kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)
+    kr = np.ascontiguousarray(kr, KEYPOINT_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32)
+    dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    bi = np.zeros(len(kl), np.int32)
+    bd = np.zeros(len(kl), np.int32)
+    lib().oracle_stereo_rows(kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data, len(kr), n_rows,
+                             sf.ctypes.data, min_d, max_d, bi.ctypes.data, bd.ctypes.data)
+    return bi, bd

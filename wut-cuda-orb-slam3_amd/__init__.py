@@ -1,0 +1,329 @@
+"""wut-cuda-orb-slam3_amd — MI355X-native ORB front-end (ctypes binding over the C ABI in include/orbx.h).
+
+The product is ``liborbx.so`` (hand-written gfx950 HIP kernels + C ABI, sources in ``csrc/``).  This module is a
+thin host-side mirror of the reference's operator interface for tests and benchmarks:
+
+* :class:`ORBextractor` mirrors ``ORB_SLAM3::ORBextractor`` (reference include/ORBextractor.h:52-113):
+  same constructor arguments, ``__call__(image, mask, lapping_area)`` returning
+  ``(monoIndex, keypoints, descriptors)``, the ``Get*`` getters.
+* :class:`ORBmatcher` mirrors the Hamming leafs of ``ORBmatcher`` / ``cv::BFMatcher``
+  (reference src/ORBmatcher3.cc:637-653, src/Frame.cc:1174, 841-925).
+
+There is no CPU fallback: importing works anywhere, but every compute call raises if ``liborbx.so`` is not
+built or no HIP device exists.  Because the directory name contains hyphens, load this package with
+``__graft_entry__.load_package()`` (importlib) — it registers itself as ``wut_cuda_orb_slam3_amd``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_ssize_t, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+assert KEYPOINT_DTYPE.itemsize == 28
+
+TH_HIGH = 100  # reference src/ORBmatcher1.cc:37
+TH_LOW = 50  # reference src/ORBmatcher1.cc:38
+HISTO_LENGTH = 30  # reference src/ORBmatcher1.cc:39
+
+ORBX_BLUR_OPENCV_450 = 0
+ORBX_BLUR_OPENCV_451 = 1
+
+
+class OrbxError(RuntimeError):
+    pass
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [
+        ("nfeatures", c_int32), ("scale_factor", c_float), ("nlevels", c_int32), ("ini_th_fast", c_int32),
+        ("min_th_fast", c_int32), ("device", c_int32), ("max_width", c_int32), ("max_height", c_int32),
+        ("max_batch", c_int32), ("blur_variant", c_int32), ("angle_mode", c_int32),
+    ]
+
+
+# every symbol include/orbx.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
+    "orbx_get_scale_factors", "orbx_get_inverse_scale_factors", "orbx_get_scale_sigma_squares",
+    "orbx_get_inverse_scale_sigma_squares", "orbx_get_features_per_level", "orbx_get_umax", "orbx_max_keypoints",
+    "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
+    "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
+    "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
+    "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
+    "orbx_level_sizes",
+]
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen liborbx.so; raises OrbxError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbxError(f"{LIB_PATH} is missing — run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.orbx_last_error.restype = c_char_p
+    lib.orbx_create.argtypes = [POINTER(_Params), POINTER(c_void_p)]
+    lib.orbx_destroy.argtypes = [c_void_p]
+    lib.orbx_destroy.restype = None
+    lib.orbx_default_params.argtypes = [POINTER(_Params)]
+    lib.orbx_default_params.restype = None
+    lib.orbx_get_levels.argtypes = [c_void_p]
+    lib.orbx_get_scale_factor.argtypes = [c_void_p]
+    lib.orbx_get_scale_factor.restype = c_float
+    for name in ("orbx_get_scale_factors", "orbx_get_inverse_scale_factors", "orbx_get_scale_sigma_squares",
+                 "orbx_get_inverse_scale_sigma_squares", "orbx_get_features_per_level", "orbx_get_umax"):
+        getattr(lib, name).argtypes = [c_void_p, c_void_p]
+    lib.orbx_max_keypoints.argtypes = [c_void_p]
+    lib.orbx_extract.argtypes = [c_void_p, c_void_p, c_int, c_int, c_ssize_t, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]
+    lib.orbx_extract_batch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int, c_void_p,
+                                       c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_extract_batch_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int]
+    lib.orbx_sync.argtypes = [c_void_p]
+    lib.orbx_device_outputs.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]
+    lib.orbx_download_outputs.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_stream.argtypes = [c_void_p]
+    lib.orbx_stream.restype = c_void_p
+    lib.orbx_get_level_size.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]
+    lib.orbx_get_pyramid_level.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.orbx_debug_get_candidates.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int]
+    lib.orbx_debug_get_selected.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int]
+    lib.orbx_matcher_create.argtypes = [c_int, c_int, c_int, POINTER(c_void_p)]
+    lib.orbx_matcher_destroy.argtypes = [c_void_p]
+    lib.orbx_matcher_destroy.restype = None
+    lib.orbx_matcher_sync.argtypes = [c_void_p]
+    lib.orbx_hamming_matrix.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]
+    lib.orbx_match_knn2.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_match_knn2_device.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_match_stereo_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                           c_int, c_float, c_float, c_void_p, c_void_p]
+    lib.orbx_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
+    lib.orbx_synth_frame.restype = None
+    lib.orbx_level_sizes.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().orbx_last_error()
+        raise OrbxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def synth_frame(frame_index: int, w: int = 640, h: int = 480) -> np.ndarray:
+    """Deterministic synthetic mono frame (include/orbx_synth.h)."""
+    img = np.empty((h, w), np.uint8)
+    load_library().orbx_synth_frame(frame_index, w, h, img.ctypes.data, w)
+    return img
+
+
+def device_count() -> int:
+    return int(load_library().orbx_device_count())
+
+
+class ORBextractor:
+    """Mirror of ``ORB_SLAM3::ORBextractor`` (reference include/ORBextractor.h:58-92)."""
+
+    def __init__(self, nfeatures: int, scaleFactor: float, nlevels: int, iniThFAST: int, minThFAST: int, *, device: int = 0,
+                 max_width: int = 640, max_height: int = 480, max_batch: int = 1, blur_variant: int = ORBX_BLUR_OPENCV_450,
+                 angle_mode: int = 0):
+        self._lib = load_library()
+        p = _Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, max_width, max_height, max_batch,
+                    blur_variant, angle_mode)
+        h = c_void_p()
+        _check(self._lib.orbx_create(byref(p), byref(h)), "orbx_create")
+        self._h = h
+        self.nlevels = nlevels
+        self.max_batch = max_batch
+        self.capacity = int(self._lib.orbx_max_keypoints(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orbx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- getters (reference include/ORBextractor.h:70-90) --------------------------------------------------
+    def GetLevels(self) -> int:
+        return int(self._lib.orbx_get_levels(self._h))
+
+    def GetScaleFactor(self) -> float:
+        return float(self._lib.orbx_get_scale_factor(self._h))
+
+    def _table(self, fn: str, dtype, n=None) -> np.ndarray:
+        out = np.zeros(n or self.nlevels, dtype)
+        getattr(self._lib, fn)(self._h, out.ctypes.data)
+        return out
+
+    def GetScaleFactors(self):
+        return self._table("orbx_get_scale_factors", np.float32)
+
+    def GetInverseScaleFactors(self):
+        return self._table("orbx_get_inverse_scale_factors", np.float32)
+
+    def GetScaleSigmaSquares(self):
+        return self._table("orbx_get_scale_sigma_squares", np.float32)
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._table("orbx_get_inverse_scale_sigma_squares", np.float32)
+
+    def features_per_level(self):
+        return self._table("orbx_get_features_per_level", np.int32)
+
+    def umax(self):
+        return self._table("orbx_get_umax", np.int32, 16)
+
+    # -- operator() (reference src/ORBextractor.cc:1227-1307) --------------------------------------------
+    def __call__(self, image, mask=None, vLappingArea=(0, 0)):
+        """Returns (monoIndex, keypoints[n] (KEYPOINT_DTYPE), descriptors[n, 32]); monoIndex == -1 on an empty image."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        image = np.ascontiguousarray(image, np.uint8)
+        assert image.ndim == 2
+        h, w = image.shape
+        kps = np.zeros(self.capacity, KEYPOINT_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = c_int()
+        mono = self._lib.orbx_extract(self._h, image.ctypes.data, w, h, image.strides[0], int(vLappingArea[0]),
+                                      int(vLappingArea[1]), kps.ctypes.data, desc.ctypes.data, self.capacity, byref(n))
+        if mono <= -101:
+            _check(mono + 100, "orbx_extract")
+        return int(mono), kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_batch(self, images: np.ndarray, vLappingArea=(0, 0)):
+        """images: [B, H, W] uint8 host array -> (n[B], mono[B], kps[B, cap], desc[B, cap, 32])."""
+        images = np.ascontiguousarray(images, np.uint8)
+        b, h, w = images.shape
+        kps = np.zeros((b, self.capacity), KEYPOINT_DTYPE)
+        desc = np.zeros((b, self.capacity, 32), np.uint8)
+        n = np.zeros(b, np.int32)
+        mono = np.zeros(b, np.int32)
+        _check(self._lib.orbx_extract_batch(self._h, images.ctypes.data, b, w, h, images.strides[1], images.strides[0],
+                                            int(vLappingArea[0]), int(vLappingArea[1]), kps.ctypes.data, desc.ctypes.data,
+                                            self.capacity, n.ctypes.data, mono.ctypes.data), "orbx_extract_batch")
+        return n, mono, kps, desc
+
+    def extract_batch_device(self, d_ptr: int, nframes: int, w: int, h: int, stride: int, frame_stride: int, vLappingArea=(0, 0)):
+        """Asynchronous device-resident batch (the path bench.py times); d_ptr is a raw device address."""
+        _check(self._lib.orbx_extract_batch_device(self._h, c_void_p(d_ptr), nframes, w, h, stride, frame_stride,
+                                                   int(vLappingArea[0]), int(vLappingArea[1])), "orbx_extract_batch_device")
+
+    def sync(self) -> None:
+        _check(self._lib.orbx_sync(self._h), "orbx_sync")
+
+    def stream(self) -> int:
+        return int(self._lib.orbx_stream(self._h) or 0)
+
+    def device_outputs(self):
+        k, d, n, m = c_void_p(), c_void_p(), c_void_p(), c_void_p()
+        _check(self._lib.orbx_device_outputs(self._h, byref(k), byref(d), byref(n), byref(m)), "orbx_device_outputs")
+        return k.value, d.value, n.value, m.value
+
+    def download_outputs(self, nframes: int):
+        kps = np.zeros((nframes, self.capacity), KEYPOINT_DTYPE)
+        desc = np.zeros((nframes, self.capacity, 32), np.uint8)
+        n = np.zeros(nframes, np.int32)
+        mono = np.zeros(nframes, np.int32)
+        _check(self._lib.orbx_download_outputs(self._h, nframes, kps.ctypes.data, desc.ctypes.data, self.capacity,
+                                               n.ctypes.data, mono.ctypes.data), "orbx_download_outputs")
+        return n, mono, kps, desc
+
+    # -- mvImagePyramid + stage taps -------------------------------------------------------------------
+    def level_size(self, level: int):
+        w, h = c_int(), c_int()
+        _check(self._lib.orbx_get_level_size(self._h, level, byref(w), byref(h)), "orbx_get_level_size")
+        return w.value, h.value
+
+    def pyramid_level(self, frame: int, level: int, blurred: bool = False) -> np.ndarray:
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        _check(self._lib.orbx_get_pyramid_level(self._h, frame, level, int(blurred), out.ctypes.data), "orbx_get_pyramid_level")
+        return out
+
+    def debug_candidates(self, frame: int, level: int, cap: int = 1 << 20) -> np.ndarray:
+        out = np.zeros(cap, np.uint32)
+        n = self._lib.orbx_debug_get_candidates(self._h, frame, level, out.ctypes.data, cap)
+        if n < 0:
+            _check(n, "orbx_debug_get_candidates")
+        return out[:n].copy()
+
+    def debug_selected(self, frame: int, level: int, cap: int = 1 << 16) -> np.ndarray:
+        out = np.zeros(cap, np.uint32)
+        n = self._lib.orbx_debug_get_selected(self._h, frame, level, out.ctypes.data, cap)
+        if n < 0:
+            _check(n, "orbx_debug_get_selected")
+        return out[:n].copy()
+
+
+class ORBmatcher:
+    """Hamming leafs of the reference matcher on the GPU (include/orbx.h matcher section)."""
+
+    TH_HIGH = TH_HIGH
+    TH_LOW = TH_LOW
+    HISTO_LENGTH = HISTO_LENGTH
+
+    def __init__(self, max_query: int = 8192, max_train: int = 8192, device: int = 0):
+        self._lib = load_library()
+        h = c_void_p()
+        _check(self._lib.orbx_matcher_create(device, max_query, max_train, byref(h)), "orbx_matcher_create")
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orbx_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def DescriptorDistance(a: np.ndarray, b: np.ndarray) -> int:
+        """ORBmatcher::DescriptorDistance (reference src/ORBmatcher3.cc:637-653) — host leaf."""
+        return int(np.unpackbits(np.bitwise_xor(np.asarray(a, np.uint8), np.asarray(b, np.uint8))).sum())
+
+    def hamming_matrix(self, q: np.ndarray, t: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(q), len(t)), np.int32)
+        _check(self._lib.orbx_hamming_matrix(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), out.ctypes.data), "orbx_hamming_matrix")
+        return out
+
+    def knnMatch(self, q: np.ndarray, t: np.ndarray):
+        """cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, k=2) -> (idx[nq, 2], dist[nq, 2])."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.full((len(q), 2), -1, np.int32)
+        dist = np.full((len(q), 2), np.iinfo(np.int32).max, np.int32)
+        _check(self._lib.orbx_match_knn2(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data, dist.ctypes.data), "orbx_match_knn2")
+        return idx, dist
+
+    def stereo_rows(self, kl, dl, kr, dr, n_rows: int, scale_factors, min_d: float, max_d: float):
+        kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)
+        kr = np.ascontiguousarray(kr, KEYPOINT_DTYPE)
+        dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32)
+        dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        bi = np.full(len(kl), -1, np.int32)
+        bd = np.full(len(kl), TH_HIGH, np.int32)
+        _check(self._lib.orbx_match_stereo_rows(self._h, kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data,
+                                                len(kr), n_rows, sf.ctypes.data, len(sf), min_d, max_d, bi.ctypes.data, bd.ctypes.data),
+               "orbx_match_stereo_rows")
+        return bi, bd

@@ -1,0 +1,759 @@
+// orbx_api.cpp — C ABI (include/orbx.h) and host orchestration of the gfx950 ORB front-end.
+//
+// Host side of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:52-113, src/ORBextractor.cc:410-468,
+// 1227-1329): constructor tables, per-image-size geometry (level sizes, FAST cell grid, cv::resize coefficient
+// tables), device buffer ownership and the launch sequence.  All pixel work is in orbx_kernels.hip; there is
+// no CPU fallback — every compute entry point fails if HIP is unavailable.
+#include "../../include/orbx.h"
+#include "../../include/orbx_synth.h"
+#include "orbx_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+static thread_local std::string g_lastError;
+
+static int setError(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_lastError = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return setError(ORBX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *orbx_last_error(void) { return g_lastError.c_str(); }
+
+// OpenCV scalar helpers
+static inline int cvRoundF(float v) { return (int)lrintf(v); }
+static inline int cvRoundD(double v) { return (int)lrint(v); }
+static inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+static inline int cvCeilD(double v) { int i = (int)v; return i + (i < v); }
+static inline short satShort(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+static inline size_t roundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T) + 256);
+        if (e != hipSuccess) return setError(ORBX_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+        n = count;
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct orbx_extractor {
+    orbx_params prm;
+    // constructor tables (reference src/ORBextractor.cc:418-467)
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> quota, umax, levelCap;
+    int maxKeypoints = 0, maxQuota = 0;
+    int taps[7];
+    hipStream_t stream = nullptr;
+
+    // geometry of the current image size
+    int curW = 0, curH = 0;
+    std::vector<OrbxLevelGeom> geom;
+    long long candFrameStride = 0;
+    int tilesPerFrame = 0, selFrameStride = 0;
+    std::vector<int> tabOffsets;  // per level transition: offsets into d_tabs for xofs,xab,yofs,yab,rowBeg,colBeg
+
+    // device memory
+    DevBuf<uint8_t> d_in;                       // staging for host-pointer input (level 0)
+    int inPitch = 0; long long inFrameStride = 0;
+    std::vector<DevBuf<uint8_t>> d_raw, d_blur; // per level [max_batch][h][pitch]
+    DevBuf<int> d_tabs;
+    DevBuf<OrbxLevelGeom> d_geom;
+    DevBuf<uint32_t> d_cand, d_scratchA, d_scratchB, d_sel, d_workKey;
+    DevBuf<int> d_tileCount, d_selCount, d_workPos, d_n, d_mono;
+    DevBuf<orbx_keypoint> d_kps;
+    DevBuf<uint8_t> d_desc;
+
+    // level-0 source of the last batch (for orbx_get_pyramid_level)
+    const uint8_t *lastSrc = nullptr; int lastSrcPitch = 0; long long lastSrcFrameStride = 0; int lastFrames = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------------------------------------
+extern "C" void orbx_default_params(orbx_params *p)
+{
+    if (!p) return;
+    p->nfeatures = 1000; p->scale_factor = 1.2f; p->nlevels = 8; p->ini_th_fast = 20; p->min_th_fast = 7;
+    p->device = 0; p->max_width = 640; p->max_height = 480; p->max_batch = 1;
+    p->blur_variant = ORBX_BLUR_OPENCV_450; p->angle_mode = ORBX_ANGLE_FASTATAN2;
+}
+
+extern "C" int orbx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int computeGeometry(orbx_extractor *ex, int w, int h);
+static int ensureBuffers(orbx_extractor *ex);
+
+extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
+{
+    if (!p || !out) return setError(ORBX_ERR_INVALID_ARG, "orbx_create: null argument");
+    *out = nullptr;
+    if (p->nfeatures <= 0 || p->nlevels <= 0 || p->nlevels > ORBX_MAX_LEVELS || !(p->scale_factor > 1.0f))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_create: nfeatures>0, 1<=nlevels<=%d, scale_factor>1 required", ORBX_MAX_LEVELS);
+    if (p->max_width <= 0 || p->max_height <= 0 || p->max_batch <= 0 || p->max_width > 4096 || p->max_height > 4096)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_create: image size must be within 1..4096, max_batch >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return setError(ORBX_ERR_NO_DEVICE, "orbx_create: no HIP device available (this library has no CPU fallback)");
+    if (p->device < 0 || p->device >= ndev) return setError(ORBX_ERR_INVALID_ARG, "orbx_create: device %d out of range (%d devices)", p->device, ndev);
+    HIP_TRY(hipSetDevice(p->device));
+
+    orbx_extractor *ex = new (std::nothrow) orbx_extractor();
+    if (!ex) return setError(ORBX_ERR_OUT_OF_MEMORY, "orbx_create: host allocation failed");
+    ex->prm = *p;
+    const int nl = p->nlevels;
+    // scale tables — reference src/ORBextractor.cc:418-432 (float arithmetic)
+    ex->scale.resize(nl); ex->sigma2.resize(nl); ex->invScale.resize(nl); ex->invSigma2.resize(nl);
+    ex->scale[0] = 1.0f; ex->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; ++i) {
+        ex->scale[i] = ex->scale[i - 1] * p->scale_factor;
+        ex->sigma2[i] = ex->scale[i] * ex->scale[i];
+    }
+    for (int i = 0; i < nl; ++i) {
+        ex->invScale[i] = 1.0f / ex->scale[i];
+        ex->invSigma2[i] = 1.0f / ex->sigma2[i];
+    }
+    // per-level quotas — :436-447
+    ex->quota.resize(nl);
+    float factor = 1.0f / p->scale_factor;
+    float nDesired = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int level = 0; level < nl - 1; ++level) {
+        ex->quota[level] = cvRoundF(nDesired);
+        sum += ex->quota[level];
+        nDesired *= factor;
+    }
+    ex->quota[nl - 1] = std::max(p->nfeatures - sum, 0);
+    // umax — :455-467
+    ex->umax.assign(16, 0);
+    {
+        int v, v0, vmax = cvFloorF(ORBX_HALF_PATCH * std::sqrt(2.f) / 2 + 1);
+        int vmin = cvCeilD(ORBX_HALF_PATCH * std::sqrt(2.f) / 2);
+        const double hp2 = ORBX_HALF_PATCH * ORBX_HALF_PATCH;
+        for (v = 0; v <= vmax; ++v) ex->umax[v] = cvRoundD(std::sqrt(hp2 - v * v));
+        for (v = ORBX_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+            while (ex->umax[v0] == ex->umax[v0 + 1]) ++v0;
+            ex->umax[v] = v0;
+            ++v0;
+        }
+    }
+    // DistributeOctTree may overshoot a quota by up to 3 (:697); tiny quotas are floored at 16 slots so that
+    // the up-to-4-per-root first split always fits.
+    ex->levelCap.resize(nl);
+    ex->maxKeypoints = 0; ex->maxQuota = 0;
+    for (int l = 0; l < nl; ++l) {
+        ex->levelCap[l] = std::max(ex->quota[l] + 3, 16);
+        ex->maxKeypoints += ex->levelCap[l];
+        ex->maxQuota = std::max(ex->maxQuota, ex->quota[l]);
+    }
+    static const int t450[7] = {18, 34, 49, 55, 49, 34, 18}, t451[7] = {18, 34, 48, 56, 48, 34, 18};
+    memcpy(ex->taps, p->blur_variant == ORBX_BLUR_OPENCV_451 ? t451 : t450, sizeof ex->taps);
+
+    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ex; return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    ex->d_raw.resize(nl); ex->d_blur.resize(nl);
+    int rc = computeGeometry(ex, p->max_width, p->max_height);
+    if (rc == ORBX_OK) rc = ensureBuffers(ex);
+    if (rc != ORBX_OK) { orbx_destroy(ex); return rc; }
+    *out = ex;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_destroy(orbx_extractor *ex)
+{
+    if (!ex) return;
+    (void)hipSetDevice(ex->prm.device);
+    if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
+    ex->d_in.release();
+    for (auto &b : ex->d_raw) b.release();
+    for (auto &b : ex->d_blur) b.release();
+    ex->d_tabs.release(); ex->d_geom.release(); ex->d_cand.release(); ex->d_scratchA.release(); ex->d_scratchB.release();
+    ex->d_sel.release(); ex->d_workKey.release(); ex->d_tileCount.release(); ex->d_selCount.release();
+    ex->d_workPos.release(); ex->d_n.release(); ex->d_mono.release(); ex->d_kps.release(); ex->d_desc.release();
+    delete ex;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// getters (reference include/ORBextractor.h:70-90)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orbx_get_levels(const orbx_extractor *ex) { return ex ? ex->prm.nlevels : 0; }
+extern "C" float orbx_get_scale_factor(const orbx_extractor *ex) { return ex ? ex->prm.scale_factor : 0.f; }
+#define ORBX_COPY_TABLE(fn, type, member)                                          \
+    extern "C" int fn(const orbx_extractor *ex, type *out)                          \
+    {                                                                               \
+        if (!ex || !out) return setError(ORBX_ERR_INVALID_ARG, #fn ": null argument"); \
+        for (size_t i = 0; i < ex->member.size(); ++i) out[i] = ex->member[i];      \
+        return (int)ex->member.size();                                              \
+    }
+ORBX_COPY_TABLE(orbx_get_scale_factors, float, scale)
+ORBX_COPY_TABLE(orbx_get_inverse_scale_factors, float, invScale)
+ORBX_COPY_TABLE(orbx_get_scale_sigma_squares, float, sigma2)
+ORBX_COPY_TABLE(orbx_get_inverse_scale_sigma_squares, float, invSigma2)
+ORBX_COPY_TABLE(orbx_get_features_per_level, int32_t, quota)
+ORBX_COPY_TABLE(orbx_get_umax, int32_t, umax)
+extern "C" int orbx_max_keypoints(const orbx_extractor *ex) { return ex ? ex->maxKeypoints : 0; }
+extern "C" void *orbx_stream(orbx_extractor *ex) { return ex ? (void *)ex->stream : nullptr; }
+
+extern "C" int orbx_level_sizes(const orbx_extractor *ex, int w, int h, int32_t *lw, int32_t *lh)
+{
+    if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_level_sizes: null handle");
+    for (int l = 0; l < ex->prm.nlevels; ++l) {
+        if (lw) lw[l] = cvRoundF((float)w * ex->invScale[l]);
+        if (lh) lh[l] = cvRoundF((float)h * ex->invScale[l]);
+    }
+    return ex->prm.nlevels;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// geometry: level sizes (:1313), FAST cell grid (:870-886), tiles, cv::resize tables
+// ---------------------------------------------------------------------------------------------------------
+static int computeGeometry(orbx_extractor *ex, int w, int h)
+{
+    if (w == ex->curW && h == ex->curH && !ex->geom.empty()) return ORBX_OK;
+    const int nl = ex->prm.nlevels;
+    std::vector<OrbxLevelGeom> geom(nl);
+    long long candOff = 0;
+    int tileOff = 0, selOff = 0;
+    for (int l = 0; l < nl; ++l) {
+        OrbxLevelGeom &g = geom[l];
+        memset(&g, 0, sizeof g);
+        g.w = cvRoundF((float)w * ex->invScale[l]);
+        g.h = cvRoundF((float)h * ex->invScale[l]);
+        g.pitch = (int)roundUp(g.w, 64);
+        g.frameStride = (long long)roundUp((size_t)g.pitch * g.h, 256);
+        const int minB = ORBX_BORDER, maxBX = g.w - ORBX_EDGE + 3, maxBY = g.h - ORBX_EDGE + 3;
+        const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+        const int nCols = (int)(width / 35.f), nRows = (int)(height / 35.f);
+        if (nCols < 1 || nRows < 1 || g.w < 2 * ORBX_FAST_MARGIN + 1 || g.h < 2 * ORBX_FAST_MARGIN + 1)
+            return setError(ORBX_ERR_TOO_SMALL, "pyramid level %d (%dx%d) is smaller than one 35-px FAST cell", l, g.w, g.h);
+        g.wCell = (int)std::ceil(width / nCols);
+        g.hCell = (int)std::ceil(height / nRows);
+        const int iw = g.w - 2 * ORBX_FAST_MARGIN, ih = g.h - 2 * ORBX_FAST_MARGIN;  // corner-capable interior
+        g.ncx = std::min(nCols, (iw + g.wCell - 1) / g.wCell);
+        g.ncy = std::min(nRows, (ih + g.hCell - 1) / g.hCell);
+        int gmax = std::max(1, 288 / g.wCell);
+        g.nGroups = (g.ncx + gmax - 1) / gmax;
+        g.groupCells = (g.ncx + g.nGroups - 1) / g.nGroups;
+        g.nGroups = (g.ncx + g.groupCells - 1) / g.groupCells;
+        if (g.groupCells > 32) return setError(ORBX_ERR_CAPACITY, "level %d: %d cells per tile group exceeds 32", l, g.groupCells);
+        g.nTiles = g.nGroups * g.ncy;
+        g.slotCap = g.groupCells * ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2);
+        g.candBase = candOff; candOff += (long long)g.nTiles * g.slotCap;
+        g.tileBase = tileOff; tileOff += g.nTiles;
+        g.quota = ex->quota[l];
+        g.selBase = selOff; selOff += ex->levelCap[l];
+        // LDS layout of k_pyr_fast
+        int maxRows = 0;
+        for (int c = 0; c < g.ncy; ++c) {
+            int ty0 = ORBX_FAST_MARGIN + c * g.hCell, ty1 = std::min(ty0 + g.hCell, g.h - ORBX_FAST_MARGIN);
+            int ly0 = c == 0 ? 0 : ty0 - 3, ly1 = c == g.ncy - 1 ? g.h : ty1 + 3;
+            maxRows = std::max(maxRows, ly1 - ly0);
+        }
+        int maxCols = 0;
+        for (int gi = 0; gi < g.nGroups; ++gi) {
+            int c0 = gi * g.groupCells, c1 = std::min(c0 + g.groupCells, g.ncx);
+            int tx0 = ORBX_FAST_MARGIN + c0 * g.wCell, tx1 = std::min(ORBX_FAST_MARGIN + c1 * g.wCell, g.w - ORBX_FAST_MARGIN);
+            int lx0 = gi == 0 ? 0 : tx0 - 3, lx1 = gi == g.nGroups - 1 ? g.w : tx1 + 3;
+            maxCols = std::max(maxCols, lx1 - (lx0 & ~3));
+        }
+        g.tileRows = maxRows;
+        g.tilePitch = (int)roundUp(maxCols + 4, 16);
+        g.scorePitch = (int)roundUp(g.groupCells * g.wCell + 2, 16);
+        int maskW = (g.groupCells * g.wCell + 63) >> 6;
+        size_t lds = (size_t)g.tileRows * g.tilePitch + (size_t)(g.hCell + 2) * g.scorePitch +
+                     (size_t)g.hCell * maskW * 8 + roundUp(g.groupCells * g.wCell, 16);
+        g.ldsBytes = (int)roundUp(lds, 16);
+        if (g.ldsBytes > 64 * 1024)
+            return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
+    }
+    // resize coefficient tables + tile ownership of destination rows / columns, per level transition
+    std::vector<int> tabs;
+    std::vector<int> offs((size_t)nl * 6, 0);
+    for (int l = 0; l + 1 < nl; ++l) {
+        const OrbxLevelGeom &s = geom[l], &d = geom[l + 1];
+        const int COEF = 2048;
+        const double scale_x = 1. / ((double)d.w / s.w), scale_y = 1. / ((double)d.h / s.h);
+        std::vector<int> xofs(d.w), xab(d.w), yofs(d.h), yab(d.h), rowBeg(s.ncy + 1), colBeg(s.nGroups + 1);
+        for (int dx = 0; dx < d.w; ++dx) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = cvFloorF(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= s.w - 1) { fx = 0; sx = s.w - 1; }
+            xofs[dx] = sx;
+            int a0 = satShort(cvRoundF((1.f - fx) * COEF)), a1 = satShort(cvRoundF(fx * COEF));
+            xab[dx] = (a0 & 0xFFFF) | (a1 << 16);
+        }
+        for (int dy = 0; dy < d.h; ++dy) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = cvFloorF(fy);
+            fy -= sy;
+            yofs[dy] = sy;
+            int b0 = satShort(cvRoundF((1.f - fy) * COEF)), b1 = satShort(cvRoundF(fy * COEF));
+            yab[dy] = (b0 & 0xFFFF) | (b1 << 16);
+        }
+        // destination row dy is produced by the source cell-row that owns source row clamp(yofs[dy])
+        auto rowOwner = [&](int sy) {
+            sy = std::min(std::max(sy, 0), s.h - 1);
+            int c = (sy - ORBX_FAST_MARGIN) / s.hCell;
+            if (sy < ORBX_FAST_MARGIN) c = 0;
+            return std::min(c, s.ncy - 1);
+        };
+        auto colOwner = [&](int sx) {
+            int c = sx < ORBX_FAST_MARGIN ? 0 : (sx - ORBX_FAST_MARGIN) / s.wCell;
+            c = std::min(c, s.ncx - 1);
+            return c / s.groupCells;
+        };
+        {
+            int dy = 0;
+            for (int c = 0; c < s.ncy; ++c) {
+                rowBeg[c] = dy;
+                while (dy < d.h && rowOwner(yofs[dy]) == c) ++dy;
+            }
+            rowBeg[s.ncy] = dy;
+            if (dy != d.h) return setError(ORBX_ERR_INVALID_ARG, "internal: resize row ownership is not monotone (level %d)", l);
+            int dx = 0;
+            for (int gi = 0; gi < s.nGroups; ++gi) {
+                colBeg[gi] = dx;
+                while (dx < d.w && colOwner(xofs[dx]) == gi) ++dx;
+            }
+            colBeg[s.nGroups] = dx;
+            if (dx != d.w) return setError(ORBX_ERR_INVALID_ARG, "internal: resize column ownership is not monotone (level %d)", l);
+        }
+        std::vector<int> *parts[6] = {&xofs, &xab, &yofs, &yab, &rowBeg, &colBeg};
+        for (int k = 0; k < 6; ++k) {
+            offs[(size_t)l * 6 + k] = (int)tabs.size();
+            tabs.insert(tabs.end(), parts[k]->begin(), parts[k]->end());
+        }
+    }
+    if (tabs.empty()) tabs.push_back(0);
+    (void)hipSetDevice(ex->prm.device);
+    int rc = ex->d_tabs.ensure(tabs.size());
+    if (rc != ORBX_OK) return rc;
+    rc = ex->d_geom.ensure(nl);
+    if (rc != ORBX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    HIP_TRY(hipMemcpy(ex->d_tabs.p, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ex->d_geom.p, geom.data(), nl * sizeof(OrbxLevelGeom), hipMemcpyHostToDevice));
+    ex->geom.swap(geom);
+    ex->tabOffsets.swap(offs);
+    ex->candFrameStride = candOff;
+    ex->tilesPerFrame = tileOff;
+    ex->selFrameStride = selOff;
+    ex->curW = w; ex->curH = h;
+    return ORBX_OK;
+}
+
+static int ensureBuffers(orbx_extractor *ex)
+{
+    const int nl = ex->prm.nlevels;
+    const size_t B = (size_t)ex->prm.max_batch;
+    int rc;
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        if (l > 0 && (rc = ex->d_raw[l].ensure(B * g.frameStride + 64)) != ORBX_OK) return rc;
+        if ((rc = ex->d_blur[l].ensure(B * g.frameStride + 64)) != ORBX_OK) return rc;
+    }
+    ex->inPitch = ex->geom[0].pitch;
+    ex->inFrameStride = ex->geom[0].frameStride;
+    if ((rc = ex->d_in.ensure(B * ex->inFrameStride + 64)) != ORBX_OK) return rc;
+    if ((rc = ex->d_cand.ensure(B * ex->candFrameStride)) != ORBX_OK) return rc;
+    if ((rc = ex->d_scratchA.ensure(B * ex->candFrameStride)) != ORBX_OK) return rc;
+    if ((rc = ex->d_scratchB.ensure(B * ex->candFrameStride)) != ORBX_OK) return rc;
+    if ((rc = ex->d_tileCount.ensure(B * ex->tilesPerFrame)) != ORBX_OK) return rc;
+    if ((rc = ex->d_sel.ensure(B * ex->selFrameStride)) != ORBX_OK) return rc;
+    if ((rc = ex->d_selCount.ensure(B * nl)) != ORBX_OK) return rc;
+    const size_t cap = (size_t)ex->maxKeypoints;
+    if ((rc = ex->d_workKey.ensure(B * cap)) != ORBX_OK) return rc;
+    if ((rc = ex->d_workPos.ensure(B * cap)) != ORBX_OK) return rc;
+    if ((rc = ex->d_kps.ensure(B * cap)) != ORBX_OK) return rc;
+    if ((rc = ex->d_desc.ensure(B * cap * 32)) != ORBX_OK) return rc;
+    if ((rc = ex->d_n.ensure(B)) != ORBX_OK) return rc;
+    if ((rc = ex->d_mono.ensure(B)) != ORBX_OK) return rc;
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// extraction
+// ---------------------------------------------------------------------------------------------------------
+static OrbxTables makeTables(const orbx_extractor *ex)
+{
+    OrbxTables t;
+    memset(&t, 0, sizeof t);
+    t.nlevels = ex->prm.nlevels;
+    t.angleMode = ex->prm.angle_mode;
+    for (int l = 0; l < t.nlevels; ++l) {
+        t.scale[l] = ex->scale[l];
+        t.quota[l] = ex->quota[l];
+        t.selBase[l] = ex->geom[l].selBase;
+        t.patchSize[l] = (int)(31 * ex->scale[l]);  // const int scaledPatchSize = PATCH_SIZE * mvScaleFactor[level], :1017
+    }
+    for (int i = 0; i < 16; ++i) t.umax[i] = ex->umax[i];
+    for (int i = 0; i < 7; ++i) t.taps[i] = ex->taps[i];
+    return t;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride,
+                                         ptrdiff_t frame_stride, int lap0, int lap1)
+{
+    if (!ex || !d_imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: null argument");
+    if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: bad shape");
+    if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
+    if (w > 4096 || h > 4096) return setError(ORBX_ERR_CAPACITY, "image %dx%d exceeds 4096", w, h);
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    int rc = computeGeometry(ex, w, h);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = ensureBuffers(ex)) != ORBX_OK) return rc;
+    const int nl = ex->prm.nlevels;
+    hipStream_t st = ex->stream;
+    const uint8_t *src0 = (const uint8_t *)d_imgs;
+    ex->lastSrc = src0; ex->lastSrcPitch = (int)stride; ex->lastSrcFrameStride = (long long)frame_stride; ex->lastFrames = nframes;
+
+    // fused pyramid + FAST, one launch per level over all frames
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
+        const int srcPitch = l == 0 ? (int)stride : g.pitch;
+        const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
+        uint8_t *dst = nullptr; int dw = 0, dh = 0, dPitch = 0; long long dFS = 0;
+        OrbxResizeTabs tabs;
+        memset(&tabs, 0, sizeof tabs);
+        if (l + 1 < nl) {
+            const OrbxLevelGeom &d = ex->geom[l + 1];
+            dst = ex->d_raw[l + 1].p; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;
+            const int *o = &ex->tabOffsets[(size_t)l * 6];
+            tabs.xofs = ex->d_tabs.p + o[0]; tabs.xab = ex->d_tabs.p + o[1]; tabs.yofs = ex->d_tabs.p + o[2];
+            tabs.yab = ex->d_tabs.p + o[3]; tabs.rowBeg = ex->d_tabs.p + o[4]; tabs.colBeg = ex->d_tabs.p + o[5];
+        }
+        HIP_TRY(orbxLaunchPyrFast(st, nframes, g, src, srcPitch, srcFS, dst, dw, dh, dPitch, dFS, tabs, ex->d_cand.p,
+                                  ex->candFrameStride, ex->d_tileCount.p, ex->tilesPerFrame, ex->prm.ini_th_fast,
+                                  ex->prm.min_th_fast));
+    }
+    HIP_TRY(orbxLaunchQuadtree(st, nframes, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p, ex->candFrameStride,
+                               ex->d_tileCount.p, ex->tilesPerFrame, ex->d_scratchA.p, ex->d_scratchB.p, ex->d_sel.p,
+                               ex->selFrameStride, ex->d_selCount.p, ex->maxQuota));
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
+        const int srcPitch = l == 0 ? (int)stride : g.pitch;
+        const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
+        HIP_TRY(orbxLaunchBlur(st, nframes, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p, g.pitch, g.frameStride, ex->taps));
+    }
+    OrbxTables tb = makeTables(ex);
+    HIP_TRY(orbxLaunchPack(st, nframes, tb, ex->d_sel.p, ex->selFrameStride, ex->d_selCount.p, lap0, lap1, ex->d_kps.p,
+                           ex->maxKeypoints, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_mono.p));
+    OrbxLevelPtrs lv;
+    memset(&lv, 0, sizeof lv);
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        lv.raw[l] = l == 0 ? src0 : ex->d_raw[l].p;
+        lv.rawPitch[l] = l == 0 ? (int)stride : g.pitch;
+        lv.rawFrameStride[l] = l == 0 ? (long long)frame_stride : g.frameStride;
+        lv.blur[l] = ex->d_blur[l].p; lv.blurPitch[l] = g.pitch; lv.blurFrameStride[l] = g.frameStride;
+        lv.w[l] = g.w; lv.h[l] = g.h;
+    }
+    HIP_TRY(orbxLaunchOrientDesc(st, nframes, tb, lv, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_kps.p,
+                                 ex->d_desc.p, ex->maxKeypoints));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_sync(orbx_extractor *ex)
+{
+    if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_sync: null handle");
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_device_outputs(orbx_extractor *ex, void **d_kps, void **d_desc, void **d_n, void **d_mono)
+{
+    if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_device_outputs: null handle");
+    if (d_kps) *d_kps = ex->d_kps.p;
+    if (d_desc) *d_desc = ex->d_desc.p;
+    if (d_n) *d_n = ex->d_n.p;
+    if (d_mono) *d_mono = ex->d_mono.p;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_download_outputs(orbx_extractor *ex, int nframes, orbx_keypoint *kps, uint8_t *desc, int capacity,
+                                     int32_t *n_out, int32_t *mono_out)
+{
+    if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_download_outputs: null handle");
+    if (nframes <= 0 || nframes > ex->prm.max_batch) return setError(ORBX_ERR_INVALID_ARG, "orbx_download_outputs: bad nframes");
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    std::vector<int32_t> n(nframes), mono(nframes);
+    HIP_TRY(hipMemcpyAsync(n.data(), ex->d_n.p, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(mono.data(), ex->d_mono.p, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    const int cap = ex->maxKeypoints;
+    for (int f = 0; f < nframes; ++f) {
+        if (n[f] > capacity) return setError(ORBX_ERR_CAPACITY, "frame %d has %d keypoints, output capacity is %d", f, n[f], capacity);
+        if (kps && n[f] > 0)
+            HIP_TRY(hipMemcpyAsync(kps + (size_t)f * capacity, ex->d_kps.p + (size_t)f * cap, (size_t)n[f] * sizeof(orbx_keypoint),
+                                   hipMemcpyDeviceToHost, ex->stream));
+        if (desc && n[f] > 0)
+            HIP_TRY(hipMemcpyAsync(desc + (size_t)f * capacity * 32, ex->d_desc.p + (size_t)f * cap * 32, (size_t)n[f] * 32,
+                                   hipMemcpyDeviceToHost, ex->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    for (int f = 0; f < nframes; ++f) {
+        if (n_out) n_out[f] = n[f];
+        if (mono_out) mono_out[f] = mono[f];
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
+                                  ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
+                                  int32_t *n_out, int32_t *mono_out)
+{
+    if (!ex || !imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: null argument");
+    if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: bad shape");
+    if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    int rc = computeGeometry(ex, w, h);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = ensureBuffers(ex)) != ORBX_OK) return rc;
+    for (int f = 0; f < nframes; ++f)
+        HIP_TRY(hipMemcpy2DAsync(ex->d_in.p + (size_t)f * ex->inFrameStride, ex->inPitch, imgs + (size_t)f * frame_stride, stride, w, h,
+                                 hipMemcpyHostToDevice, ex->stream));
+    rc = orbx_extract_batch_device(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1);
+    if (rc != ORBX_OK) return rc;
+    return orbx_download_outputs(ex, nframes, kps, desc, capacity, n_out, mono_out);
+}
+
+extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+                            orbx_keypoint *kps, uint8_t *desc, int capacity, int *n_out)
+{
+    if (n_out) *n_out = 0;
+    if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract: null handle") - 100;
+    if (!img || w <= 0 || h <= 0) return -1;  // `if (_image.empty()) return -1;` (reference src/ORBextractor.cc:1231-1232)
+    int32_t n = 0, mono = 0;
+    int rc = orbx_extract_batch(ex, img, 1, w, h, stride, (ptrdiff_t)stride * h, lap0, lap1, kps, desc, capacity, &n, &mono);
+    if (rc != ORBX_OK) return rc - 100;
+    if (n_out) *n_out = n;
+    return mono;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pyramid access + stage taps
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orbx_get_level_size(const orbx_extractor *ex, int level, int *w, int *h)
+{
+    if (!ex || level < 0 || level >= ex->prm.nlevels || ex->geom.empty()) return setError(ORBX_ERR_INVALID_ARG, "orbx_get_level_size: bad argument");
+    if (w) *w = ex->geom[level].w;
+    if (h) *h = ex->geom[level].h;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_get_pyramid_level(orbx_extractor *ex, int frame, int level, int blurred, uint8_t *out)
+{
+    if (!ex || !out || level < 0 || level >= ex->prm.nlevels || frame < 0 || frame >= ex->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_get_pyramid_level: bad argument");
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    const OrbxLevelGeom &g = ex->geom[level];
+    const uint8_t *src; int pitch; long long fs;
+    if (blurred) { src = ex->d_blur[level].p; pitch = g.pitch; fs = g.frameStride; }
+    else if (level == 0) { src = ex->lastSrc; pitch = ex->lastSrcPitch; fs = ex->lastSrcFrameStride; }
+    else { src = ex->d_raw[level].p; pitch = g.pitch; fs = g.frameStride; }
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    HIP_TRY(hipMemcpy2D(out, g.w, src + (size_t)frame * fs, pitch, g.w, g.h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_get_candidates(orbx_extractor *ex, int frame, int level, uint32_t *out, int cap)
+{
+    if (!ex || level < 0 || level >= ex->prm.nlevels || frame < 0 || frame >= ex->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_debug_get_candidates: bad argument");
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    const OrbxLevelGeom &g = ex->geom[level];
+    std::vector<int> tc(g.nTiles);
+    HIP_TRY(hipMemcpy(tc.data(), ex->d_tileCount.p + (size_t)frame * ex->tilesPerFrame + g.tileBase, g.nTiles * sizeof(int), hipMemcpyDeviceToHost));
+    int total = 0;
+    for (int t = 0; t < g.nTiles; ++t) {
+        int n = tc[t];
+        if (n < 0 || n > g.slotCap) return setError(ORBX_ERR_HIP, "tile %d count %d out of range", t, n);
+        int ncopy = std::min(n, std::max(0, cap - total));
+        if (ncopy > 0 && out)
+            HIP_TRY(hipMemcpy(out + total, ex->d_cand.p + (size_t)frame * ex->candFrameStride + g.candBase + (size_t)t * g.slotCap,
+                              ncopy * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        total += n;
+    }
+    return total;
+}
+
+extern "C" int orbx_debug_get_selected(orbx_extractor *ex, int frame, int level, uint32_t *out, int cap)
+{
+    if (!ex || level < 0 || level >= ex->prm.nlevels || frame < 0 || frame >= ex->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_debug_get_selected: bad argument");
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    int n = 0;
+    HIP_TRY(hipMemcpy(&n, ex->d_selCount.p + (size_t)frame * ex->prm.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    int ncopy = std::min(n, cap);
+    if (ncopy > 0 && out)
+        HIP_TRY(hipMemcpy(out, ex->d_sel.p + (size_t)frame * ex->selFrameStride + ex->geom[level].selBase, ncopy * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" void orbx_synth_frame(uint64_t frame_index, int w, int h, uint8_t *out, ptrdiff_t stride)
+{
+    orbx_synth_frame_impl(frame_index, w, h, out, stride);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// matcher
+// ---------------------------------------------------------------------------------------------------------
+struct orbx_matcher {
+    int device = 0, maxQ = 0, maxT = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<uint8_t> d_q, d_t;
+    DevBuf<int> d_idx, d_dist, d_mat;
+    DevBuf<orbx_keypoint> d_kl, d_kr;
+    DevBuf<float> d_scale;
+};
+
+extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orbx_matcher **out)
+{
+    if (!out || max_query <= 0 || max_train <= 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_create: bad argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return setError(ORBX_ERR_NO_DEVICE, "orbx_matcher_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_create: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    orbx_matcher *m = new (std::nothrow) orbx_matcher();
+    if (!m) return setError(ORBX_ERR_OUT_OF_MEMORY, "orbx_matcher_create: host allocation failed");
+    m->device = device; m->maxQ = max_query; m->maxT = max_train;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete m; return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    int rc;
+    if ((rc = m->d_q.ensure((size_t)max_query * 32)) != ORBX_OK || (rc = m->d_t.ensure((size_t)max_train * 32)) != ORBX_OK ||
+        (rc = m->d_idx.ensure((size_t)max_query * 2)) != ORBX_OK || (rc = m->d_dist.ensure((size_t)max_query * 2)) != ORBX_OK ||
+        (rc = m->d_kl.ensure(max_query)) != ORBX_OK || (rc = m->d_kr.ensure(max_train)) != ORBX_OK ||
+        (rc = m->d_scale.ensure(ORBX_MAX_LEVELS)) != ORBX_OK) {
+        orbx_matcher_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_matcher_destroy(orbx_matcher *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release();
+    m->d_kl.release(); m->d_kr.release(); m->d_scale.release();
+    delete m;
+}
+
+extern "C" int orbx_matcher_sync(orbx_matcher *m)
+{
+    if (!m) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_sync: null handle");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+static int uploadQT(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt)
+{
+    if (nq > m->maxQ || nt > m->maxT) return setError(ORBX_ERR_CAPACITY, "matcher capacity (%d x %d) exceeded by %d x %d", m->maxQ, m->maxT, nq, nt);
+    if (nq > 0) HIP_TRY(hipMemcpyAsync(m->d_q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    if (nt > 0) HIP_TRY(hipMemcpyAsync(m->d_t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_hamming_matrix(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *dist)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || !dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_hamming_matrix: bad argument");
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = uploadQT(m, q, nq, t, nt);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = m->d_mat.ensure((size_t)nq * nt)) != ORBX_OK) return rc;
+    HIP_TRY(orbxLaunchHammingMatrix(m->stream, m->d_q.p, nq, m->d_t.p, nt, m->d_mat.p));
+    HIP_TRY(hipMemcpyAsync(dist, m->d_mat.p, (size_t)nq * nt * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_match_knn2_device(orbx_matcher *m, const void *d_q, int nq, const void *d_t, int nt, void *d_idx, void *d_dist)
+{
+    if (!m || nq < 0 || nt < 0 || !d_idx || !d_dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_device: bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(orbxLaunchKnn2(m->stream, (const uint8_t *)d_q, nq, (const uint8_t *)d_t, nt, (int *)d_idx, (int *)d_dist));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_match_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
+{
+    if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || !idx || !dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2: bad argument");
+    if (nq == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = uploadQT(m, q, nq, t, nt);
+    if (rc != ORBX_OK) return rc;
+    HIP_TRY(orbxLaunchKnn2(m->stream, m->d_q.p, nq, m->d_t.p, nt, m->d_idx.p, m->d_dist.p));
+    HIP_TRY(hipMemcpyAsync(idx, m->d_idx.p, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(dist, m->d_dist.p, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr,
+                                      const uint8_t *dr, int nr, int n_rows, const float *scale_factors, int nlevels, float min_d,
+                                      float max_d, int32_t *best_idx, int32_t *best_dist)
+{
+    if (!m || nl < 0 || nr < 0 || (nl > 0 && (!kl || !dl)) || (nr > 0 && (!kr || !dr)) || !scale_factors || nlevels <= 0 ||
+        nlevels > ORBX_MAX_LEVELS || !best_idx || !best_dist)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_match_stereo_rows: bad argument");
+    if (nl == 0) return ORBX_OK;
+    for (int i = 0; i < nr; ++i)
+        if (kr[i].octave < 0 || kr[i].octave >= nlevels) return setError(ORBX_ERR_INVALID_ARG, "right keypoint %d has octave %d outside [0,%d)", i, kr[i].octave, nlevels);
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = uploadQT(m, dl, nl, dr, nr);
+    if (rc != ORBX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, n_rows, m->d_scale.p, min_d, max_d,
+                                 m->d_idx.p, m->d_dist.p));
+    HIP_TRY(hipMemcpyAsync(best_idx, m->d_idx.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(best_dist, m->d_dist.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}

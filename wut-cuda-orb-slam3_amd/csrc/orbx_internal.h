@@ -1,0 +1,98 @@
+// orbx_internal.h — structures shared between the host orchestration (orbx_api.cpp) and the gfx950
+// kernels (orbx_kernels.hip).  Not part of the public ABI (include/orbx.h).
+#ifndef ORBX_INTERNAL_H
+#define ORBX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE 19          // EDGE_THRESHOLD, reference src/ORBextractor.cc:101
+#define ORBX_BORDER 16        // EDGE_THRESHOLD - 3 (FAST ROI origin), :960
+#define ORBX_FAST_MARGIN 19   // first pixel that can be a corner: border + 3
+#define ORBX_HALF_PATCH 15    // :100
+
+// Candidate / selected-keypoint packing: x | y << 12 | score << 24, coordinates relative to the 16-px border.
+#define ORBX_PACK(x, y, s) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(s) << 24))
+
+// Geometry of one pyramid level for the current image size (host computes; kernels take it by value).
+struct OrbxLevelGeom {
+    int w, h;              // level size (reference src/ORBextractor.cc:1313)
+    int pitch;             // bytes per row in the handle's level buffers (multiple of 64)
+    long long frameStride; // bytes between consecutive frames in the level buffers
+    // FAST cell grid (reference tileCalcKeypoints, src/ORBextractor.cc:870-886)
+    int wCell, hCell;
+    int ncx, ncy;          // cells with a non-empty interior
+    // tiles of the fused pyramid+FAST kernel: one cell-row x one group of cells
+    int groupCells, nGroups, nTiles;
+    int slotCap;           // u32 entries per tile candidate slot
+    long long candBase;    // offset (entries) of this level's slots inside a frame's candidate area
+    int tileBase;          // offset of this level's tiles inside a frame's tile-count array
+    int quota;             // mnFeaturesPerLevel[level]
+    int selBase;           // offset of this level's selected keypoints inside a frame's selection area
+    // LDS layout of the fused kernel
+    int tilePitch;         // bytes per LDS tile row
+    int tileRows;          // max rows held in LDS
+    int scorePitch;        // bytes per row of the LDS score tile (interior + 1-px zero ring)
+    int ldsBytes;
+};
+
+// Bilinear-resize coefficient tables for producing level l+1 from level l (OpenCV fixed point,
+// SURVEY App. A.1).  Device arrays; one set per level transition.
+struct OrbxResizeTabs {
+    const int *xofs;   // [dw] source column of the left tap (clamped)
+    const int *xab;    // [dw] a0 | a1 << 16 (int16 each, 11-bit weights)
+    const int *yofs;   // [dh] unclipped source row of the top tap
+    const int *yab;    // [dh] b0 | b1 << 16
+    const int *rowBeg; // [ncy + 1] first dst row owned by each cell-row of the source level
+    const int *colBeg; // [nGroups + 1] first dst column owned by each column group
+};
+
+struct OrbxLevelPtrs {
+    const uint8_t *raw[ORBX_MAX_LEVELS];
+    const uint8_t *blur[ORBX_MAX_LEVELS];
+    int rawPitch[ORBX_MAX_LEVELS];
+    long long rawFrameStride[ORBX_MAX_LEVELS];
+    int blurPitch[ORBX_MAX_LEVELS];
+    long long blurFrameStride[ORBX_MAX_LEVELS];
+    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS];
+};
+
+struct OrbxTables {
+    float scale[ORBX_MAX_LEVELS];
+    int quota[ORBX_MAX_LEVELS];
+    int selBase[ORBX_MAX_LEVELS];
+    int patchSize[ORBX_MAX_LEVELS];  // (int)(31 * scale)
+    int umax[16];
+    int taps[7];
+    int nlevels;
+    int angleMode;
+};
+
+// ---- kernel launchers (orbx_kernels.hip) -------------------------------------------------------------
+hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch,
+                             long long srcFrameStride, uint8_t *dst, int dw, int dh, int dstPitch,
+                             long long dstFrameStride, OrbxResizeTabs tabs, uint32_t *cand, long long candFrameStride,
+                             int *tileCount, int tilesPerFrame, int iniTh, int minTh);
+hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8_t *src, int srcPitch,
+                          long long srcFrameStride, uint8_t *dst, int dstPitch, long long dstFrameStride,
+                          const int taps[7]);
+hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const OrbxLevelGeom *geomsHost,
+                              const OrbxLevelGeom *geomsDev, const uint32_t *cand, long long candFrameStride,
+                              const int *tileCount, int tilesPerFrame, uint32_t *scratchA, uint32_t *scratchB,
+                              uint32_t *sel, int selFrameStride, int *selCount, int maxQuota);
+hipError_t orbxLaunchPack(hipStream_t st, int nframes, OrbxTables tabs, const uint32_t *sel, int selFrameStride,
+                          const int *selCount, int lap0, int lap1, void *kps, int cap, uint32_t *workKey,
+                          int *workPos, int *nOut, int *monoOut);
+hipError_t orbxLaunchOrientDesc(hipStream_t st, int nframes, OrbxTables tabs, OrbxLevelPtrs lv, const uint32_t *workKey,
+                                const int *workPos, const int *nOut, void *kps, uint8_t *desc, int cap);
+
+// matcher (orbx_match.hip)
+hipError_t orbxLaunchHammingMatrix(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int *dist);
+hipError_t orbxLaunchKnn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist);
+hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *dl, int nl, const void *kr,
+                                const uint8_t *dr, int nr, int nRows, const float *scaleDev, float minD, float maxD,
+                                int *bestIdx, int *bestDist);
+
+#endif
