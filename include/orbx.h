@@ -135,6 +135,17 @@ int orbx_download_outputs(orbx_extractor *ex, int nframes, orbx_keypoint *kps, u
 /* The HIP stream (hipStream_t) the handle launches on — for event timing by the caller. */
 void *orbx_stream(orbx_extractor *ex);
 
+/* Stage timing with HIP events recorded on the handle's own stream (the reference's counterpart is the
+ * orb::benchmark MEASURE_* wrappers around the same stages, include/orb/Benchmark.h:83-92; reference
+ * src/ORBextractor.cc:969,998,1238,1241,1273,1278).  When enabled, every batch records events around each
+ * stage; orbx_get_stage_times() synchronises the stream and returns the mean milliseconds per batch of the
+ * batches recorded since the last call (at most the 32 most recent), then resets.  Stage order:
+ * 0 = fused pyramid+FAST (all per-level launches), 1 = quadtree, 2 = GaussianBlur (all levels),
+ * 3 = pack, 4 = orientation+descriptor.  Returns the number of batches averaged (0 if none). */
+#define ORBX_NUM_STAGES 5
+int orbx_set_profiling(orbx_extractor *ex, int enable);
+int orbx_get_stage_times(orbx_extractor *ex, float *ms /* ORBX_NUM_STAGES */);
+
 /* mvImagePyramid[level] — public member read by Frame::ComputeStereoMatches (reference
  * include/ORBextractor.h:92, src/Frame.cc:848,938-953).  Copies the interior (un-padded) level image of
  * frame `frame` of the last batch to `out` (w*h bytes, tight).  blurred != 0 returns the GaussianBlur-ed

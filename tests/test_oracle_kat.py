@@ -1,0 +1,148 @@
+"""Known-answer tests that pin the CPU oracle against the reference TEXT: constructor
+tables, umax literal, sampling-pattern hash, Hamming identities, packing rule, OpenCV-semantics spot checks."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# SURVEY.md App. C (derived from reference src/ORBextractor.cc:418-447)
+SCALE = [1, 1.2000000477, 1.4400000572, 1.7280001640, 2.0736002922, 2.4883203506, 2.9859845638, 3.5831816196]
+QUOTAS = {1000: [217, 181, 151, 126, 105, 87, 73, 60], 1200: [261, 217, 181, 151, 126, 105, 87, 72],
+          1500: [326, 271, 226, 189, 157, 131, 109, 91], 4000: [869, 724, 603, 503, 419, 349, 291, 242]}
+UMAX = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]  # literal at reference src/OpenCL/Kernel/Angle.cl:3
+PATTERN_SHA256 = "3f202c09967ef499081baca510075490fe60c9626ed8e748ff8e94378229a598"
+LEVEL_SIZES = {
+    (640, 480): [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)],
+    (752, 480): [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)],
+    (1920, 1080): [(1920, 1080), (1600, 900), (1333, 750), (1111, 625), (926, 521), (772, 434), (643, 362), (536, 301)],
+}
+
+
+@pytest.mark.parametrize("nf", sorted(QUOTAS))
+def test_constructor_tables(orc, nf):
+    t = orc.Oracle(nf, 1.2, 8, 20, 7).tables()
+    assert list(t["features_per_level"]) == QUOTAS[nf]
+    assert np.allclose(t["scale"], np.array(SCALE, np.float32), rtol=0, atol=1e-9 * 4)
+    assert list(t["umax"]) == UMAX
+    assert np.array_equal(t["inv_scale"], (np.float32(1) / t["scale"]).astype(np.float32))
+    assert np.array_equal(t["sigma2"], (t["scale"] * t["scale"]).astype(np.float32))
+
+
+def _pattern_values(path):
+    body = open(path).read()
+    body = body[body.index("{") + 1: body.rindex("}")]
+    return [int(v) for v in re.findall(r"-?\d+", body)]
+
+
+@pytest.mark.parametrize("rel", ["oracle/pattern_table.inc", "wut-cuda-orb-slam3_amd/csrc/orbx_pattern.inc"])
+def test_pattern_hash(rel):
+    vals = _pattern_values(os.path.join(ROOT, rel))
+    assert len(vals) == 1024 and min(vals) == -13 and max(vals) == 12
+    assert hashlib.sha256(bytes((v + 128) & 255 for v in vals)).hexdigest() == PATTERN_SHA256
+
+
+def test_hamming_identities(orc):
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, 32, dtype=np.uint8)
+    b = rng.integers(0, 256, 32, dtype=np.uint8)
+    assert orc.hamming256(a, a) == 0
+    assert orc.hamming256(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+    assert orc.hamming256(a, b) == orc.hamming256(b, a) == int(np.unpackbits(a ^ b).sum())
+
+
+def test_level_sizes_and_mono_packing_rule(orc):
+    img = orc.synth_frame(3, 640, 480)
+    o = orc.Oracle(1000, 1.2, 8, 20, 7)
+    mono, kps, desc = o.extract(img, (0, 1000))  # Frame.cc:313 mono call: every keypoint is "lapping"
+    assert mono == 0 and len(kps) >= 1000
+    assert [o.level_size(l) for l in range(8)] == LEVEL_SIZES[(640, 480)]
+    # fully reversed level-major order: octaves non-increasing
+    assert np.all(np.diff(kps["octave"]) <= 0)
+    mono2, kps2, desc2 = o.extract(img, (2000, 3000))  # no keypoint is lapping -> plain level-major order
+    assert mono2 == len(kps2) == len(kps)
+    assert kps2[::-1].tobytes() == kps.tobytes() and desc2[::-1].tobytes() == desc.tobytes()
+    # split: lapping ones at the tail in reverse order
+    mono3, kps3, _ = o.extract(img, (300, 400))
+    inlap = (kps2["x"] >= 300) & (kps2["x"] <= 400)
+    assert mono3 == int((~inlap).sum())
+    assert kps3[:mono3].tobytes() == kps2[~inlap].tobytes()
+    assert kps3[mono3:].tobytes() == kps2[inlap][::-1].tobytes()
+
+
+def test_empty_image(orc):
+    o = orc.Oracle()
+    mono, kps, desc = o.extract(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(kps) == 0
+
+
+@pytest.mark.parametrize("size", sorted(LEVEL_SIZES))
+def test_level_sizes(orc, size):
+    w, h = size
+    o = orc.Oracle(1200, 1.2, 8, 20, 7)
+    o.extract(orc.synth_frame(0, w, h), (0, 0))
+    assert [o.level_size(l) for l in range(8)] == LEVEL_SIZES[size]
+
+
+def test_fast_atan2_known_values(orc):
+    # exact axis values of cv::fastAtan2: polynomial gives 0 at c=0; 90-0, 180-0, 360-90
+    assert orc.fast_atan2(0.0, 1.0) == 0.0
+    assert orc.fast_atan2(1.0, 0.0) == 90.0
+    assert orc.fast_atan2(0.0, -1.0) == 180.0
+    assert orc.fast_atan2(-1.0, 0.0) == 270.0
+    for y, x in [(1, 1), (3, -2), (-5, -7), (-1, 9)]:
+        want = np.degrees(np.arctan2(y, x)) % 360
+        assert abs(orc.fast_atan2(float(y), float(x)) - want) < 0.02  # documented accuracy ~0.01 deg
+
+
+def test_resize_identity_and_constant(orc):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (40, 60), dtype=np.uint8)
+    assert np.array_equal(orc.resize_linear(img, 60, 40), img)  # scale 1: weights (2048, 0)
+    flat = np.full((48, 64), 137, np.uint8)
+    assert np.all(orc.resize_linear(flat, 53, 40) == 137)
+
+
+def test_blur_constant_and_taps(orc):
+    flat = np.full((30, 30), 200, np.uint8)
+    # OpenCV 4.5.0 taps sum to 257/256: 200 * (257/256)^2 = 201.57 -> 202 ; >= 4.5.1 taps sum to 1
+    assert np.all(orc.gaussian_blur7(flat, 0) == 202)
+    assert np.all(orc.gaussian_blur7(flat, 1) == 200)
+    imp = np.zeros((15, 15), np.uint8)
+    imp[7, 7] = 255
+    out = orc.gaussian_blur7(imp, 1)
+    taps = np.array([18, 34, 48, 56, 48, 34, 18])
+    want = ((np.outer(taps, taps) * 255 + 32768) >> 16).astype(np.uint8)
+    assert np.array_equal(out[4:11, 4:11], want)
+
+
+def test_fast_roi_synthetic_corner(orc):
+    # a bright 90-degree wedge, brightest at its tip, on a dark background: the tip is the unique NMS survivor
+    # (a flat wedge gives a plateau of equal scores, which strict `>` NMS suppresses entirely)
+    img = np.full((21, 21), 10, np.uint8)
+    yy, xx = np.mgrid[10:21, 10:21]
+    img[10:, 10:] = (200 - (xx - 10) - (yy - 10)).astype(np.uint8)
+    kp = orc.fast_roi(img, 20)
+    xs, ys, sc = kp & 0xFFF, (kp >> 12) & 0xFFF, kp >> 24
+    assert list(zip(xs.tolist(), ys.tolist(), sc.tolist())) == [(10, 10, 189)]  # |200 - 10| - 1
+    flat = np.full((21, 21), 10, np.uint8)
+    flat[10:, 10:] = 200
+    assert len(orc.fast_roi(flat, 20)) == 0
+    assert len(orc.fast_roi(np.full((21, 21), 77, np.uint8), 7)) == 0
+
+
+def test_distribute_keeps_best_and_quota(orc):
+    rng = np.random.default_rng(9)
+    W, H = 608, 448
+    pts = set()
+    while len(pts) < 3000:
+        pts.add((int(rng.integers(3, W - 3)), int(rng.integers(3, H - 3))))
+    pts = sorted(pts, key=lambda p: (p[1], p[0]))
+    cand = np.array([x | (y << 12) | (int(rng.integers(7, 255)) << 24) for x, y in pts], np.uint32)
+    sel = orc.distribute(cand, W, H, 217)
+    assert 217 <= len(sel) <= 220 and len(set(sel.tolist())) == len(sel)
+    one = orc.distribute(cand[:1], W, H, 217)
+    assert list(one) == [0]

@@ -1,0 +1,233 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Bar: bit-exact keypoints (all 7 fields incl. float angle), octaves, order and 32-byte descriptors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [  # w, h, nfeatures — BASELINE.json configs 1-5 geometries
+    (640, 480, 1000),
+    (752, 480, 1200),
+    (512, 512, 1500),
+    (1920, 1080, 4000),
+]
+
+
+def _pack_level_kps(k):
+    return ((k["x"].astype(np.int64) - 16) | ((k["y"].astype(np.int64) - 16) << 12) | (k["response"].astype(np.int64) << 24)).astype(np.uint32)
+
+
+def _assert_same(pkg, kps, desc, rk, rd, what):
+    assert len(kps) == len(rk), f"{what}: count {len(kps)} vs {len(rk)}"
+    for name in kps.dtype.names:
+        a, b = kps[name].view(np.uint32), rk[name].view(np.uint32)
+        if not np.array_equal(a, b):
+            i = int(np.nonzero(a != b)[0][0])
+            raise AssertionError(f"{what}: field {name} differs at {i}: {kps[name][i]!r} vs {rk[name][i]!r}")
+    assert np.array_equal(desc, rd), f"{what}: descriptors differ at rows {np.nonzero((desc != rd).any(axis=1))[0][:5]}"
+
+
+@pytest.mark.parametrize("w,h,nf", CONFIGS)
+def test_stagewise_and_end_to_end(pkg, orc, w, h, nf):
+    nframes = 2 if w < 1000 else 1
+    imgs = np.stack([pkg.synth_frame(100 + i, w, h) for i in range(nframes)])
+    ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=nframes)
+    lap = (0, 1000)
+    n, mono, kps, desc = ex.extract_batch(imgs, lap)
+    for f in range(nframes):
+        ref = orc.Oracle(nf, 1.2, 8, 20, 7)
+        rmono, rk, rd = ref.extract(imgs[f], lap)
+        for l in range(8):
+            assert ex.level_size(l) == ref.level_size(l)
+            assert np.array_equal(ex.pyramid_level(f, l), ref.level(l)), f"pyramid level {l}"
+            assert np.array_equal(ex.debug_candidates(f, l), ref.candidates(l)), f"FAST candidates level {l}"
+            assert np.array_equal(ex.debug_selected(f, l), _pack_level_kps(ref.level_keypoints(l))), f"quadtree level {l}"
+            assert np.array_equal(ex.pyramid_level(f, l, True), ref.level(l, True)), f"blur level {l}"
+        assert mono[f] == rmono
+        _assert_same(pkg, kps[f][: n[f]], desc[f][: n[f]], rk, rd, f"{w}x{h} frame {f}")
+        assert n[f] >= nf  # quotas saturate on the synthetic frames
+    ex.close()
+
+
+@pytest.mark.parametrize("lap", [(0, 1000), (0, 0), (250, 400), (639, 5000), (-5, 18)])
+def test_lapping_split(pkg, orc, lap):
+    img = pkg.synth_frame(21, 640, 480)
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    mono, kps, desc = ex(img, None, lap)
+    rmono, rk, rd = orc.Oracle(1000, 1.2, 8, 20, 7).extract(img, lap)
+    assert mono == rmono
+    _assert_same(pkg, kps, desc, rk, rd, f"lap {lap}")
+    ex.close()
+
+
+@pytest.mark.parametrize("nf,scale,nlevels,ini,mn", [(500, 1.2, 8, 20, 7), (2000, 1.2, 8, 12, 5), (1000, 1.5, 4, 20, 7),
+                                                     (300, 1.1, 6, 30, 30), (1000, 1.2, 1, 20, 7), (7500, 1.2, 8, 20, 7),
+                                                     (40, 1.2, 8, 20, 7), (1000, 1.2, 8, 20, 0), (1000, 1.2, 8, 300, 7)])
+def test_parameter_space(pkg, orc, nf, scale, nlevels, ini, mn):
+    img = pkg.synth_frame(33, 640, 480)
+    ex = pkg.ORBextractor(nf, scale, nlevels, ini, mn)
+    ref = orc.Oracle(nf, scale, nlevels, ini, mn)
+    assert np.array_equal(ex.features_per_level(), ref.tables()["features_per_level"])
+    assert np.array_equal(ex.GetScaleFactors(), ref.tables()["scale"])
+    assert np.array_equal(ex.GetInverseScaleFactors(), ref.tables()["inv_scale"])
+    assert np.array_equal(ex.GetScaleSigmaSquares(), ref.tables()["sigma2"])
+    assert np.array_equal(ex.GetInverseScaleSigmaSquares(), ref.tables()["inv_sigma2"])
+    assert np.array_equal(ex.umax(), ref.tables()["umax"])
+    assert ex.GetLevels() == nlevels and abs(ex.GetScaleFactor() - scale) < 1e-6
+    mono, kps, desc = ex(img, None, (0, 1000))
+    rmono, rk, rd = ref.extract(img, (0, 1000))
+    assert mono == rmono
+    _assert_same(pkg, kps, desc, rk, rd, f"params {(nf, scale, nlevels, ini, mn)}")
+    ex.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_blur_variants(pkg, orc, variant):
+    img = pkg.synth_frame(2, 640, 480)
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, blur_variant=variant)
+    mono, kps, desc = ex(img, None, (0, 1000))
+    rmono, rk, rd = orc.Oracle(1000, 1.2, 8, 20, 7, blur_variant=variant).extract(img, (0, 1000))
+    _assert_same(pkg, kps, desc, rk, rd, f"blur variant {variant}")
+    ex.close()
+
+
+def test_image_content_edge_cases(pkg, orc):
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    ref = orc.Oracle(1000, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(4)
+    cases = {
+        "flat": np.full((480, 640), 128, np.uint8),                       # no corners at all -> n == 0
+        "noise": rng.integers(0, 256, (480, 640), dtype=np.uint8),        # corners everywhere, heavy quadtree
+        "weak": (128 + rng.integers(-6, 7, (480, 640))).astype(np.uint8),  # only minThFAST corners
+        "saturated": np.where(rng.random((480, 640)) < 0.5, 0, 255).astype(np.uint8),
+        "one_corner": np.pad(np.full((100, 100), 255, np.uint8), ((190, 190), (270, 270))),
+        "checker": (((np.indices((480, 640)).sum(axis=0) // 17) % 2) * 200 + 20).astype(np.uint8),
+    }
+    for name, img in cases.items():
+        mono, kps, desc = ex(img, None, (0, 1000))
+        rmono, rk, rd = ref.extract(img, (0, 1000))
+        assert mono == rmono, name
+        _assert_same(pkg, kps, desc, rk, rd, name)
+    assert len(ex(cases["flat"], None, (0, 0))[1]) == 0
+    ex.close()
+
+
+def test_empty_and_error_paths(pkg):
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=2)
+    mono, kps, desc = ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(kps) == 0  # reference: `return -1` on an empty image (ORBextractor.cc:1231-1232)
+    lib = pkg.load_library()
+    n = __import__("ctypes").c_int(7)
+    assert lib.orbx_extract(ex._h, None, 640, 480, 640, 0, 0, None, None, 0, __import__("ctypes").byref(n)) == -1 and n.value == 0
+    with pytest.raises(pkg.OrbxError, match="smaller than one 35-px FAST cell"):
+        ex(np.zeros((100, 100), np.uint8))
+    with pytest.raises(pkg.OrbxError, match="max_batch"):
+        ex.extract_batch(np.zeros((3, 480, 640), np.uint8))
+    img = pkg.synth_frame(1, 640, 480)
+    # an extraction still works after the errors, and a smaller image re-derives the geometry
+    assert len(ex(img, None, (0, 0))[1]) >= 1000
+    assert len(ex(img[:300, :400], None, (0, 0))[1]) > 0
+    ex.close()
+
+
+def test_strided_and_unaligned_input(pkg, orc):
+    base = np.zeros((480, 643 + 5), np.uint8)
+    img = pkg.synth_frame(8, 640, 480)
+    base[:, 3:643] = img
+    view = base[:, 3:643]  # row stride 648, start address offset by 3 -> byte-granular staging path
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7)
+    lib = pkg.load_library()
+    import ctypes
+    kps = np.zeros(ex.capacity, pkg.KEYPOINT_DTYPE)
+    desc = np.zeros((ex.capacity, 32), np.uint8)
+    n = ctypes.c_int()
+    mono = lib.orbx_extract(ex._h, view.ctypes.data, 640, 480, view.strides[0], 0, 1000, kps.ctypes.data, desc.ctypes.data,
+                            ex.capacity, ctypes.byref(n))
+    rmono, rk, rd = orc.Oracle(1000, 1.2, 8, 20, 7).extract(img, (0, 1000))
+    assert mono == rmono
+    _assert_same(pkg, kps[: n.value], desc[: n.value], rk, rd, "strided input")
+    ex.close()
+
+
+def test_odd_sizes(pkg, orc):
+    for (w, h) in [(641, 479), (333, 257), (1241, 376), (1024, 768)]:
+        img = pkg.synth_frame(50, w, h)
+        ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h)
+        mono, kps, desc = ex(img, None, (0, 1000))
+        rmono, rk, rd = orc.Oracle(1000, 1.2, 8, 20, 7).extract(img, (0, 1000))
+        assert mono == rmono
+        _assert_same(pkg, kps, desc, rk, rd, f"{w}x{h}")
+        ex.close()
+
+
+def test_batch_parity_and_composition_independence(pkg, orc):
+    B = 48
+    imgs = np.stack([pkg.synth_frame(1000 + i, 640, 480) for i in range(B)])
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    n, mono, kps, desc = ex.extract_batch(imgs, (0, 1000))
+    rc, rmono, rk, rd = orc.Oracle(1000, 1.2, 8, 20, 7).extract_batch(imgs, (0, 1000), threads=8, want_outputs=True)
+    assert np.array_equal(n, rc) and np.array_equal(mono, rmono)
+    for f in range(B):
+        assert kps[f][: n[f]].tobytes() == rk[f][: n[f]].tobytes(), f"frame {f}"
+        assert desc[f][: n[f]].tobytes() == rd[f][: n[f]].tobytes(), f"frame {f}"
+    # a frame's result does not depend on its batch slot, nor on the previous batch's contents
+    perm = np.random.default_rng(0).permutation(B)
+    n2, mono2, kps2, desc2 = ex.extract_batch(imgs[perm], (0, 1000))
+    for i, f in enumerate(perm):
+        assert n2[i] == n[f] and kps2[i][: n2[i]].tobytes() == kps[f][: n[f]].tobytes()
+        assert desc2[i][: n2[i]].tobytes() == desc[f][: n[f]].tobytes()
+    ex.close()
+
+
+def test_full_size_batch_properties(pkg, orc):
+    """BASELINE configs[1] at full size (1024 frames, device-resident): size-independent properties."""
+    import torch
+    B = 1024
+    base = np.stack([pkg.synth_frame(i, 640, 480) for i in range(64)])
+    host = np.concatenate([base] * (B // 64))  # frame f == base[f % 64]
+    dev = torch.from_numpy(host).cuda()
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    ex.extract_batch_device(dev.data_ptr(), B, 640, 480, 640, 640 * 480, (0, 1000))
+    n, mono, kps, desc = ex.download_outputs(B)
+    ex.extract_batch_device(dev.data_ptr(), B, 640, 480, 640, 640 * 480, (0, 1000))
+    n2, mono2, kps2, desc2 = ex.download_outputs(B)
+    assert np.array_equal(n, n2) and kps.tobytes() == kps2.tobytes() and desc.tobytes() == desc2.tobytes()  # idempotent
+    assert np.all(n >= 1000) and np.all(n <= ex.capacity) and np.all(mono == 0)
+    for f in range(64, B):  # periodic input -> periodic output (no cross-frame leakage at full occupancy)
+        assert n[f] == n[f % 64]
+    assert kps[64:128].tobytes() == kps[:64].tobytes() and desc[960:].tobytes() == desc[:64].tobytes()
+    rc, _, rk, rd = orc.Oracle(1000, 1.2, 8, 20, 7).extract_batch(base[:16], (0, 1000), threads=8, want_outputs=True)
+    for f in range(16):
+        assert n[f + 512] == rc[f]
+        assert kps[f + 512][: rc[f]].tobytes() == rk[f][: rc[f]].tobytes()
+        assert desc[f + 512][: rc[f]].tobytes() == rd[f][: rc[f]].tobytes()
+    # keypoint invariants: inside the image margin, octave/size consistent, angle range, level-major reversed order
+    k = kps[0][: n[0]]
+    sf = ex.GetScaleFactors()
+    assert np.all((k["octave"] >= 0) & (k["octave"] < 8)) and np.all(k["class_id"] == -1)
+    assert np.all((k["angle"] >= 0) & (k["angle"] <= 360))
+    assert np.array_equal(k["size"], np.floor(31 * sf[k["octave"]]).astype(np.float32))
+    assert np.all(k["x"] >= 19) and np.all(k["x"] <= 640) and np.all(k["y"] >= 19) and np.all(k["y"] <= 480)
+    assert np.all(np.diff(k["octave"]) <= 0)
+    ex.close()
+
+
+def test_two_handles_concurrently(pkg, orc):
+    """Reference runs left/right extractors in two threads (src/Frame.cc:124-127): handles are independent."""
+    import threading
+    imgs = [pkg.synth_frame(60, 752, 480), pkg.synth_frame(61, 752, 480)]
+    exs = [pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_width=752, max_height=480) for _ in range(2)]
+    out = [None, None]
+
+    def work(i):
+        for _ in range(5):
+            out[i] = exs[i](imgs[i], None, (0, 0))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        rmono, rk, rd = orc.Oracle(1200, 1.2, 8, 20, 7).extract(imgs[i], (0, 0))
+        assert out[i][0] == rmono
+        _assert_same(pkg, out[i][1], out[i][2], rk, rd, f"handle {i}")
+    [e.close() for e in exs]

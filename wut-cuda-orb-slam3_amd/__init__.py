@@ -58,8 +58,9 @@ ABI_SYMBOLS = [
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
-    "orbx_level_sizes",
+    "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times",
 ]
+STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
 _lib = None
 
@@ -110,6 +111,8 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
     lib.orbx_synth_frame.restype = None
     lib.orbx_level_sizes.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
+    lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
     return lib
 
@@ -228,6 +231,17 @@ class ORBextractor:
 
     def stream(self) -> int:
         return int(self._lib.orbx_stream(self._h) or 0)
+
+    def set_profiling(self, enable: bool) -> None:
+        _check(self._lib.orbx_set_profiling(self._h, int(enable)), "orbx_set_profiling")
+
+    def stage_times(self):
+        """(mean ms per batch for each of STAGE_NAMES, batches averaged) since the previous call."""
+        ms = np.zeros(len(STAGE_NAMES), np.float32)
+        nb = self._lib.orbx_get_stage_times(self._h, ms.ctypes.data)
+        if nb < 0:
+            _check(nb, "orbx_get_stage_times")
+        return ms, nb
 
     def device_outputs(self):
         k, d, n, m = c_void_p(), c_void_p(), c_void_p(), c_void_p()

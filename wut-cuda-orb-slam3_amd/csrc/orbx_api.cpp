@@ -91,6 +91,11 @@ struct orbx_extractor {
     DevBuf<orbx_keypoint> d_kps;
     DevBuf<uint8_t> d_desc;
 
+    // stage profiling: ring of event sets recorded on `stream`
+    bool profiling = false;
+    std::vector<hipEvent_t> events;  // [PROF_RING][ORBX_NUM_STAGES + 1]
+    int profCount = 0;
+
     // level-0 source of the last batch (for orbx_get_pyramid_level)
     const uint8_t *lastSrc = nullptr; int lastSrcPitch = 0; long long lastSrcFrameStride = 0; int lastFrames = 0;
 };
@@ -196,6 +201,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     if (!ex) return;
     (void)hipSetDevice(ex->prm.device);
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
+    for (auto &e : ex->events) (void)hipEventDestroy(e);
     ex->d_in.release();
     for (auto &b : ex->d_raw) b.release();
     for (auto &b : ex->d_blur) b.release();
@@ -406,6 +412,50 @@ static int ensureBuffers(orbx_extractor *ex)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// stage profiling (HIP events on the handle's stream)
+// ---------------------------------------------------------------------------------------------------------
+static const int PROF_RING = 32;
+
+extern "C" int orbx_set_profiling(orbx_extractor *ex, int enable)
+{
+    if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_set_profiling: null handle");
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    if (enable && ex->events.empty()) {
+        ex->events.resize((size_t)PROF_RING * (ORBX_NUM_STAGES + 1));
+        for (auto &e : ex->events) HIP_TRY(hipEventCreate(&e));
+    }
+    ex->profiling = enable != 0;
+    ex->profCount = 0;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_get_stage_times(orbx_extractor *ex, float *ms)
+{
+    if (!ex || !ms) return setError(ORBX_ERR_INVALID_ARG, "orbx_get_stage_times: null argument");
+    for (int s = 0; s < ORBX_NUM_STAGES; ++s) ms[s] = 0.f;
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    const int nb = std::min(ex->profCount, PROF_RING);
+    for (int b = 0; b < nb; ++b) {
+        const int slot = (ex->profCount - 1 - b) % PROF_RING;
+        hipEvent_t *ev = &ex->events[(size_t)slot * (ORBX_NUM_STAGES + 1)];
+        for (int s = 0; s < ORBX_NUM_STAGES; ++s) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, ev[s], ev[s + 1]));
+            ms[s] += t;
+        }
+    }
+    for (int s = 0; s < ORBX_NUM_STAGES && nb > 0; ++s) ms[s] /= (float)nb;
+    ex->profCount = 0;
+    return nb;
+}
+
+#define PROF_MARK(i)                                                                                     \
+    do {                                                                                                 \
+        if (prof) HIP_TRY(hipEventRecord(prof[i], st));                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
 // extraction
 // ---------------------------------------------------------------------------------------------------------
 static OrbxTables makeTables(const orbx_extractor *ex)
@@ -441,6 +491,8 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     const uint8_t *src0 = (const uint8_t *)d_imgs;
     ex->lastSrc = src0; ex->lastSrcPitch = (int)stride; ex->lastSrcFrameStride = (long long)frame_stride; ex->lastFrames = nframes;
 
+    hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * (ORBX_NUM_STAGES + 1)] : nullptr;
+    PROF_MARK(0);
     // fused pyramid + FAST, one launch per level over all frames
     for (int l = 0; l < nl; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
@@ -461,9 +513,11 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
                                   ex->candFrameStride, ex->d_tileCount.p, ex->tilesPerFrame, ex->prm.ini_th_fast,
                                   ex->prm.min_th_fast));
     }
+    PROF_MARK(1);
     HIP_TRY(orbxLaunchQuadtree(st, nframes, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p, ex->candFrameStride,
                                ex->d_tileCount.p, ex->tilesPerFrame, ex->d_scratchA.p, ex->d_scratchB.p, ex->d_sel.p,
                                ex->selFrameStride, ex->d_selCount.p, ex->maxQuota));
+    PROF_MARK(2);
     for (int l = 0; l < nl; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
         const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
@@ -471,6 +525,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
         const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
         HIP_TRY(orbxLaunchBlur(st, nframes, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p, g.pitch, g.frameStride, ex->taps));
     }
+    PROF_MARK(3);
     OrbxTables tb = makeTables(ex);
     HIP_TRY(orbxLaunchPack(st, nframes, tb, ex->d_sel.p, ex->selFrameStride, ex->d_selCount.p, lap0, lap1, ex->d_kps.p,
                            ex->maxKeypoints, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_mono.p));
@@ -484,8 +539,11 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
         lv.blur[l] = ex->d_blur[l].p; lv.blurPitch[l] = g.pitch; lv.blurFrameStride[l] = g.frameStride;
         lv.w[l] = g.w; lv.h[l] = g.h;
     }
+    PROF_MARK(4);
     HIP_TRY(orbxLaunchOrientDesc(st, nframes, tb, lv, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_kps.p,
                                  ex->d_desc.p, ex->maxKeypoints));
+    PROF_MARK(5);
+    if (prof) ++ex->profCount;
     return ORBX_OK;
 }
 
