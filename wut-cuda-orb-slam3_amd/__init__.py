@@ -72,6 +72,13 @@ def load_library() -> ctypes.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise OrbxError(f"{LIB_PATH} is missing — run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 (SONAME libamdhip64.so.7, the
+    # same as /opt/rocm's).  If liborbx.so pulled in the system copy first, a later `import torch` would bring up a
+    # second runtime that cannot see the GPU.  Importing torch first makes liborbx.so bind to the copy torch uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.orbx_last_error.restype = c_char_p
     lib.orbx_create.argtypes = [POINTER(_Params), POINTER(c_void_p)]
