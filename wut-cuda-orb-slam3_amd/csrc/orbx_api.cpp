@@ -292,17 +292,13 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
             int c0 = gi * g.groupCells, c1 = std::min(c0 + g.groupCells, g.ncx);
             int tx0 = ORBX_FAST_MARGIN + c0 * g.wCell, tx1 = std::min(ORBX_FAST_MARGIN + c1 * g.wCell, g.w - ORBX_FAST_MARGIN);
             int lx0 = gi == 0 ? 0 : tx0 - 3, lx1 = gi == g.nGroups - 1 ? g.w : tx1 + 3;
-            maxCols = std::max(maxCols, lx1 - (lx0 & ~3));
+            maxCols = std::max(maxCols, lx1 - (lx0 & ~15));
         }
         g.tileRows = maxRows;
-        g.tilePitch = (int)roundUp(maxCols + 4, 16);
-        g.scorePitch = (int)roundUp(g.groupCells * g.wCell + 2, 16);
-        int maskW = (g.groupCells * g.wCell + 63) >> 6;
-        size_t lds = (size_t)g.tileRows * g.tilePitch + (size_t)(g.hCell + 2) * g.scorePitch +
-                     (size_t)g.hCell * maskW * 8 + roundUp(g.groupCells * g.wCell, 16);
-        g.ldsBytes = (int)roundUp(lds, 16);
-        if (g.ldsBytes > 64 * 1024)
-            return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
+        // LDS column 16 holds image column ax0; strip windows / 16-byte loads may overshoot by up to 16 bytes
+        g.tilePitch = (int)roundUp(maxCols + 16 + 32, 16);
+        g.wpc = (g.wCell + 31) / 32;
+        g.rsMaxDx = g.rsMaxDy = 0;  // filled in with the resize tables below
     }
     // resize coefficient tables + tile ownership of destination rows / columns, per level transition
     std::vector<int> tabs;
@@ -358,11 +354,24 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
             colBeg[s.nGroups] = dx;
             if (dx != d.w) return setError(ORBX_ERR_INVALID_ARG, "internal: resize column ownership is not monotone (level %d)", l);
         }
+        for (int c = 0; c < s.ncy; ++c) geom[l].rsMaxDy = std::max(geom[l].rsMaxDy, rowBeg[c + 1] - rowBeg[c]);
+        for (int gi = 0; gi < s.nGroups; ++gi) geom[l].rsMaxDx = std::max(geom[l].rsMaxDx, colBeg[gi + 1] - colBeg[gi]);
         std::vector<int> *parts[6] = {&xofs, &xab, &yofs, &yab, &rowBeg, &colBeg};
         for (int k = 0; k < 6; ++k) {
             offs[(size_t)l * 6 + k] = (int)tabs.size();
             tabs.insert(tabs.end(), parts[k]->begin(), parts[k]->end());
         }
+    }
+    for (int l = 0; l < nl; ++l) {
+        OrbxLevelGeom &g = geom[l];
+        g.rsMaxDx = (int)roundUp(g.rsMaxDx + 1, 2);
+        g.rsMaxDy = (int)roundUp(g.rsMaxDy + 1, 2);
+        size_t lds = (size_t)g.tileRows * g.tilePitch + (size_t)(g.hCell + 2) * g.tilePitch +
+                     roundUp((size_t)g.hCell * (g.tilePitch / 8), 16) + (size_t)2 * g.groupCells * g.hCell * g.wpc * 4 +
+                     (size_t)(g.rsMaxDx + g.rsMaxDy) * 8 + 4096 * 2 + roundUp(g.groupCells * g.wCell, 16);
+        g.ldsBytes = (int)roundUp(lds, 16);
+        if (g.ldsBytes > 64 * 1024)
+            return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
     }
     if (tabs.empty()) tabs.push_back(0);
     (void)hipSetDevice(ex->prm.device);

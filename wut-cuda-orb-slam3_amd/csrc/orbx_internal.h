@@ -32,9 +32,10 @@ struct OrbxLevelGeom {
     int quota;             // mnFeaturesPerLevel[level]
     int selBase;           // offset of this level's selected keypoints inside a frame's selection area
     // LDS layout of the fused kernel
-    int tilePitch;         // bytes per LDS tile row
+    int tilePitch;         // bytes per LDS tile row (multiple of 16; shared by the pixel and the score tile)
     int tileRows;          // max rows held in LDS
-    int scorePitch;        // bytes per row of the LDS score tile (interior + 1-px zero ring)
+    int wpc;               // 32-bit words per cell row in the NMS bitmaps
+    int rsMaxDx, rsMaxDy;  // max destination columns / rows of the next level produced by one tile
     int ldsBytes;
 };
 

@@ -19,6 +19,7 @@
 #include "orbx_internal.h"
 #include "libstdcxx_sort.h"
 #include "orbx_pattern.inc"
+#include <cstdlib>
 
 #define WAVE 64
 
@@ -32,40 +33,28 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 // FAST-9/16 (cv::FAST TYPE_9_16)
 // =====================================================================================================
 
-// true iff the 16-bit circular mask has >= 9 contiguous set bits
-__device__ __forceinline__ bool ring_has9(unsigned m)
+// non-zero iff the 16-bit circular mask has >= 9 contiguous set bits
+__device__ __forceinline__ unsigned ring_run9(unsigned m)
 {
     m |= m << 16;
     unsigned r = m & (m >> 1);
     r &= r >> 2;
     r &= r >> 4;
     r &= m >> 8;
-    return r != 0;
+    return r;
 }
 
-// Returns the FAST corner score (cornerScore<16>: largest threshold for which the pixel is still a corner,
-// = max over the 16 arcs of 9 of min |diff| on one polarity, minus 1) if the pixel is a corner at
-// threshold `th`, else 0.  `c` points at the centre pixel inside an LDS tile with row pitch `tp`.
-__device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp, int th)
+// FAST corner score (cornerScore<16>: largest threshold for which the pixel is still a corner = max over the
+// 16 arcs of 9 of the minimum one-sided difference, minus 1).  `c` points at the centre pixel inside an LDS tile
+// with row pitch `tp`.  Only called for pixels that passed the ring test (sparse), so byte reads are fine here.
+__device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp)
 {
     const int v = c[0];
-    int p[16];
-    p[0] = c[3 * tp];       p[1] = c[3 * tp + 1];   p[2] = c[2 * tp + 2];   p[3] = c[tp + 3];
-    p[4] = c[3];            p[5] = c[-tp + 3];      p[6] = c[-2 * tp + 2];  p[7] = c[-3 * tp + 1];
-    p[8] = c[-3 * tp];      p[9] = c[-3 * tp - 1];  p[10] = c[-2 * tp - 2]; p[11] = c[-tp - 3];
-    p[12] = c[-3];          p[13] = c[tp - 3];      p[14] = c[2 * tp - 2];  p[15] = c[3 * tp - 1];
-    const int lo = v - th, hi = v + th;
-    unsigned dark = 0, bright = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        dark |= (unsigned)(p[k] < lo) << k;
-        bright |= (unsigned)(p[k] > hi) << k;
-    }
-    if (!(ring_has9(dark) || ring_has9(bright))) return 0;
-
     int d[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - p[k];
+    d[0] = v - c[3 * tp];       d[1] = v - c[3 * tp + 1];   d[2] = v - c[2 * tp + 2];   d[3] = v - c[tp + 3];
+    d[4] = v - c[3];            d[5] = v - c[-tp + 3];      d[6] = v - c[-2 * tp + 2];  d[7] = v - c[-3 * tp + 1];
+    d[8] = v - c[-3 * tp];      d[9] = v - c[-3 * tp - 1];  d[10] = v - c[-2 * tp - 2]; d[11] = v - c[-tp - 3];
+    d[12] = v - c[-3];          d[13] = v - c[tp - 3];      d[14] = v - c[2 * tp - 2];  d[15] = v - c[3 * tp - 1];
     int mn3[16], mx3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -83,17 +72,89 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp, int t
     return max(a, -b) - 1;
 }
 
+// Ring test for the 8 pixels of one strip.  w[j] holds 16 consecutive tile bytes of row (y - 3 + j); strip pixel
+// i is byte 4 + i of the centre row.  Returns the 8-bit mask of pixels with >= 9 contiguous ring pixels darker
+// than v - th or brighter than v + th.  The per-lane 16-bit ring masks are built with one subtract (sign bit =
+// comparison) and one v_alignbit (mask = mask << 1 | sign) per ring pixel and polarity.
+#define WBYTE(j, idx) ((w[j][(idx) >> 2] >> (((idx) & 3) * 8)) & 0xFFu)
+__device__ __forceinline__ unsigned fast_strip_mask(const uint32_t (&w)[7][4], int th)
+{
+    unsigned out = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int v = (int)WBYTE(3, 4 + i);
+        const int lo = v - th, hi = v + th;
+        unsigned dark = 0, bright = 0;
+#define RING(dx, dy)                                                                              \
+        {                                                                                         \
+            const int p = (int)WBYTE(3 + (dy), 4 + i + (dx));                                     \
+            dark = __builtin_amdgcn_alignbit(dark, (unsigned)(p - lo), 31);                       \
+            bright = __builtin_amdgcn_alignbit(bright, (unsigned)(hi - p), 31);                   \
+        }
+        RING(0, 3) RING(1, 3) RING(2, 2) RING(3, 1) RING(3, 0) RING(3, -1) RING(2, -2) RING(1, -3)
+        RING(0, -3) RING(-1, -3) RING(-2, -2) RING(-3, -1) RING(-3, 0) RING(-3, 1) RING(-2, 2) RING(-1, 3)
+#undef RING
+        // branch-free on purpose: both polarities are always evaluated so the 16 chains of a strip interleave
+        out |= (unsigned)((ring_run9(dark) | ring_run9(bright)) != 0) << i;
+    }
+    return out;
+}
+#undef WBYTE
+
+__device__ __forceinline__ int wave_excl_scan(int v, int &total)
+{
+    const int lane = threadIdx.x & 63;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
 struct PyrFastArgs {
     OrbxLevelGeom g;
-    const uint8_t *src; int srcPitch; long long srcFrameStride; int srcAligned4;
+    const uint8_t *src; int srcPitch; long long srcFrameStride; int srcAlign;  // 16, 4 or 1
     uint8_t *dst; int dw, dh, dstPitch; long long dstFrameStride;
     OrbxResizeTabs tabs;
     uint32_t *cand; long long candFrameStride;
     int *tileCount; int tilesPerFrame;
     int iniTh, minTh;
+    int phases;  // debug/ablation mask (ORBX_PF_PHASES): 1 resize, 2 ring test+score, 4 NMS, 8 count+emit
 };
 
 #define PF_MAX_GROUP_CELLS 32
+#define PF_XO 16      // LDS column of image column ax0 (keeps every strip window inside the tile row)
+#define PF_QCAP 4096  // corner queue entries (u16: row << 9 | interior column)
+
+// score + cell-local NMS of one ring-test survivor at tile row r, LDS column c
+__device__ __forceinline__ void pf_score_one(const uint8_t *tile, uint8_t *score, int tp, int rowOff, int r, int c, int minEff)
+{
+    const int sc = fast_corner_score(tile + (rowOff + r) * tp + c, tp);
+    score[(r + 1) * tp + c] = (uint8_t)(sc >= minEff ? sc : 0);
+}
+__device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *colInfo, uint32_t *bitsAll, uint32_t *bitsIni,
+                                           int tp, int r, int c, int cInt0, int wCell, int hCell, int wpc, int iniEff)
+{
+    const uint8_t *s1p = score + (r + 1) * tp + c, *s0p = s1p - tp, *s2p = s1p + tp;
+    const int sc = s1p[0];
+    if (sc > 0) {
+        const int xi = c - cInt0;
+        const int ci = colInfo[xi];
+        int mx = max(s0p[0], s2p[0]);
+        if (!(ci & 0x80)) mx = max(mx, max(s0p[-1], max(s1p[-1], s2p[-1])));
+        if (!(ci & 0x40)) mx = max(mx, max(s0p[1], max(s1p[1], s2p[1])));
+        if (sc > mx) {
+            const int cell = ci & 0x3F;
+            const int cx = xi - cell * wCell;
+            const int wi = (cell * hCell + r) * wpc + (cx >> 5);
+            atomicOr(&bitsAll[wi], 1u << (cx & 31));
+            if (sc >= iniEff) atomicOr(&bitsIni[wi], 1u << (cx & 31));
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
 {
@@ -106,6 +167,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
     const int ty0 = ORBX_FAST_MARGIN + crow * g.hCell;
     const int ty1 = min(ty0 + g.hCell, g.h - ORBX_FAST_MARGIN);
     const int c0 = grp * g.groupCells, c1 = min(c0 + g.groupCells, g.ncx);
+    const int nCells = c1 - c0;
     const int tx0 = ORBX_FAST_MARGIN + c0 * g.wCell;
     const int tx1 = min(ORBX_FAST_MARGIN + c1 * g.wCell, g.w - ORBX_FAST_MARGIN);
     const int THi = ty1 - ty0, TWi = tx1 - tx0;
@@ -113,112 +175,225 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
     // tile also owns the source pixels of the next pyramid level there
     const int ly0 = crow == 0 ? 0 : ty0 - 3, ly1 = crow == g.ncy - 1 ? g.h : ty1 + 3;
     const int lx0 = grp == 0 ? 0 : tx0 - 3, lx1 = grp == g.nGroups - 1 ? g.w : tx1 + 3;
-    const int ax0 = lx0 & ~3;
-    const int tp = g.tilePitch, sp = g.scorePitch;
+    const int ax0 = lx0 & ~15;
+    const int tp = g.tilePitch;
+    const int colOf0 = PF_XO - ax0;             // LDS column of image column x is x + colOf0
+    const int cInt0 = tx0 + colOf0, cInt1 = tx1 + colOf0;
 
-    uint8_t *tile = lds;
-    uint8_t *score = lds + (size_t)g.tileRows * tp;                      // (hCell + 2) x sp
-    unsigned long long *maxMask = (unsigned long long *)(score + (size_t)(g.hCell + 2) * sp);  // hCell x maskW
-    const int maskW = (g.groupCells * g.wCell + 63) >> 6;
-    uint8_t *colInfo = (uint8_t *)(maxMask + (size_t)g.hCell * maskW);   // per interior column: cell | edge flags
+    uint8_t *tile = lds;                                              // tileRows x tp
+    uint8_t *score = tile + (size_t)g.tileRows * tp;                  // (hCell + 2) x tp, same column indexing
+    uint8_t *cmask = score + (size_t)(g.hCell + 2) * tp;              // hCell x (tp / 8): ring-test mask per strip
+    const int nsPitch = tp >> 3;
+    uint32_t *bitsAll = (uint32_t *)(cmask + (((size_t)g.hCell * nsPitch + 15) & ~(size_t)15));  // [cell][row][wpc]
+    const int wpc = g.wpc;
+    const int cellWords = g.hCell * wpc;
+    uint32_t *bitsIni = bitsAll + (size_t)g.groupCells * cellWords;   // ... with score >= iniThFAST
+    int2 *xt = (int2 *)(bitsIni + (size_t)g.groupCells * cellWords);  // resize x table of this tile's dst columns
+    int2 *yt = xt + g.rsMaxDx;                                        // resize y table of this tile's dst rows
+    uint16_t *queue = (uint16_t *)(yt + g.rsMaxDy);                   // ring-test survivors
+    uint8_t *colInfo = (uint8_t *)(queue + PF_QCAP);                  // per interior column
     __shared__ int cntAll[PF_MAX_GROUP_CELLS], cntIni[PF_MAX_GROUP_CELLS], cellOff[PF_MAX_GROUP_CELLS + 1];
+    __shared__ unsigned qCount;
 
-    // ---- stage the tile: coalesced dword loads of row-major image rows into LDS ------------------------
+    // ---- stage the tile: coalesced 16-byte loads of row-major image rows into LDS ------------------------
     const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
     const int nRowsL = ly1 - ly0;
-    if (a.srcAligned4) {
+    if (a.srcAlign == 16) {
+        const int nV = (lx1 - ax0 + 15) >> 4;
+        const float invNV = 1.0f / (float)nV;
+        const int n = nRowsL * nV;
+        for (int it = tid; it < n; it += 256) {
+            const int r = (int)(((float)it + 0.5f) * invNV);
+            const int c = it - r * nV;
+            const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+            *(uint4 *)(tile + r * tp + PF_XO + c * 16) = v;
+        }
+    } else if (a.srcAlign == 4) {
         const int nDw = (lx1 - ax0 + 3) >> 2;
         for (int r = wave; r < nRowsL; r += 4) {
             const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0);
-            uint32_t *trow = (uint32_t *)(tile + r * tp);
+            uint32_t *trow = (uint32_t *)(tile + r * tp + PF_XO);
             for (int c = lane; c < nDw; c += 64) trow[c] = srow[c];
         }
     } else {
         const int nB = lx1 - ax0;
         for (int r = wave; r < nRowsL; r += 4) {
             const uint8_t *srow = srcF + (size_t)(ly0 + r) * a.srcPitch + ax0;
-            uint8_t *trow = tile + r * tp;
+            uint8_t *trow = tile + r * tp + PF_XO;
             for (int c = lane; c < nB; c += 64) trow[c] = srow[c];
         }
     }
-    if (tid < PF_MAX_GROUP_CELLS) { cntAll[tid] = 0; cntIni[tid] = 0; }
-    // per-column cell index + cell-edge flags (bit7: first column of its cell, bit6: last column)
+    // zero the score tile and the per-cell NMS bitmaps (16-byte stores)
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *zs = (uint4 *)score;
+        const int nz = ((g.hCell + 2) * tp) >> 4;
+        for (int i = tid; i < nz; i += 256) zs[i] = z;
+        uint32_t *zb = bitsAll;
+        const int nb = 2 * g.groupCells * cellWords;
+        for (int i = tid; i < nb; i += 256) zb[i] = 0;
+    }
+    if (tid == 0) qCount = 0;
+    // per interior column: cell index | bit7 first column of its cell | bit6 last column
     for (int x = tid; x < TWi; x += 256) {
-        int rel = x;  // relative to tx0, which is a cell boundary
-        int cell = rel / g.wCell, cx = rel - cell * g.wCell;
+        int cell = x / g.wCell, cx = x - cell * g.wCell;
         int cw = min(g.wCell, TWi - cell * g.wCell);
         colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
     }
-    // zero ring of the score tile
-    for (int i = tid; i < TWi + 2; i += 256) { score[i] = 0; score[(THi + 1) * sp + i] = 0; }
-    for (int i = tid; i < THi + 2; i += 256) { score[i * sp] = 0; score[i * sp + TWi + 1] = 0; }
+    // resize coefficient tables of this tile's destination rows / columns -> LDS
+    int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
+    const bool doResize = a.dst && (a.phases & 1);
+    if (doResize) {
+        dy0 = a.tabs.rowBeg[crow]; dy1 = a.tabs.rowBeg[crow + 1];
+        dx0 = a.tabs.colBeg[grp]; dx1 = a.tabs.colBeg[grp + 1];
+        for (int i = tid; i < dx1 - dx0; i += 256) {
+            const int sx0 = a.tabs.xofs[dx0 + i];
+            xt[i] = make_int2((sx0 + colOf0) | ((min(sx0 + 1, g.w - 1) + colOf0) << 16), a.tabs.xab[dx0 + i]);
+        }
+        for (int i = tid; i < dy1 - dy0; i += 256) {
+            const int sy = a.tabs.yofs[dy0 + i];
+            const int sy0 = min(max(sy, 0), g.h - 1) - ly0, sy1 = min(max(sy + 1, 0), g.h - 1) - ly0;
+            yt[i] = make_int2(sy0 | (sy1 << 16), a.tabs.yab[dy0 + i]);
+        }
+    }
     __syncthreads();
 
-    // ---- next pyramid level: cv::resize INTER_LINEAR fixed point ---------------------
-    if (a.dst) {
-        const int dy0 = a.tabs.rowBeg[crow], dy1 = a.tabs.rowBeg[crow + 1];
-        const int dx0 = a.tabs.colBeg[grp], dx1 = a.tabs.colBeg[grp + 1];
+    // ---- next pyramid level: cv::resize INTER_LINEAR fixed point; 4 px per lane -------
+    if (doResize) {
         uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
-        for (int dy = dy0 + wave; dy < dy1; dy += 4) {
-            const int sy = a.tabs.yofs[dy];
-            const int sy0 = min(max(sy, 0), g.h - 1), sy1 = min(max(sy + 1, 0), g.h - 1);
-            const int yab = a.tabs.yab[dy];
-            const int b0 = (short)(yab & 0xFFFF), b1 = yab >> 16;
-            const uint8_t *r0 = tile + (sy0 - ly0) * tp - ax0;
-            const uint8_t *r1 = tile + (sy1 - ly0) * tp - ax0;
-            uint8_t *drow = dstF + (size_t)dy * a.dstPitch;
-            for (int dx = dx0 + lane; dx < dx1; dx += 64) {
-                const int sx0 = a.tabs.xofs[dx];
-                const int sx1 = min(sx0 + 1, g.w - 1);
-                const int xab = a.tabs.xab[dx];
-                const int a0 = (short)(xab & 0xFFFF), a1 = xab >> 16;
-                const int h0 = r0[sx0] * a0 + r0[sx1] * a1;
-                const int h1 = r1[sx0] * a0 + r1[sx1] * a1;
-                drow[dx] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        const int q0 = dx0 >> 2, q1 = (dx1 + 3) >> 2;
+        for (int q = q0 + lane; q < q1; q += 64) {
+            int ca[4], cb[4], wa[4], wb[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dx = q * 4 + j;
+                ok[j] = dx >= dx0 && dx < dx1;
+                const int2 e = xt[min(max(dx, dx0), dx1 - 1) - dx0];
+                ca[j] = e.x & 0xFFFF;
+                cb[j] = e.x >> 16;
+                wa[j] = (short)(e.y & 0xFFFF);
+                wb[j] = e.y >> 16;
             }
-        }
-    }
-
-    // ---- FAST score map at minThFAST into LDS ---------------------------------------------------------
-    const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
-    const int minEff = max(minTh, 1), iniEff = max(iniTh, 1);
-    for (int y = wave; y < THi; y += 4) {
-        const uint8_t *trow = tile + (ty0 + y - ly0) * tp + (tx0 - ax0);
-        uint8_t *srow = score + (y + 1) * sp + 1;
-        for (int x = lane; x < TWi; x += 64) {
-            int s = fast_corner_score(trow + x, tp, minTh);
-            srow[x] = (uint8_t)(s >= minEff ? s : 0);
-        }
-    }
-    __syncthreads();
-
-    // ---- cell-local 3x3 non-max suppression; per-cell counts at both thresholds -------------------------
-    for (int y = wave; y < THi; y += 4) {
-        const uint8_t *s0 = score + y * sp + 1, *s1 = s0 + sp, *s2 = s1 + sp;
-        for (int xb = 0; xb < TWi; xb += 64) {
-            const int x = xb + lane;
-            bool ismax = false;
-            if (x < TWi) {
-                const int s = s1[x];
-                if (s > 0) {
-                    const int ci = colInfo[x];
-                    const bool le = ci & 0x80, re = ci & 0x40;
-                    int m = max(s0[x], s2[x]);
-                    if (!le) m = max(m, max(s0[x - 1], max(s1[x - 1], s2[x - 1])));
-                    if (!re) m = max(m, max(s0[x + 1], max(s1[x + 1], s2[x + 1])));
-                    if (s > m) {
-                        ismax = true;
-                        atomicAdd(&cntAll[ci & 0x3F], 1);
-                        if (s >= iniEff) atomicAdd(&cntIni[ci & 0x3F], 1);
-                    }
+            const bool full = ok[0] && ok[3];
+            for (int dy = dy0 + wave; dy < dy1; dy += 4) {
+                const int2 ye = yt[dy - dy0];
+                const int b0 = (short)(ye.y & 0xFFFF), b1 = ye.y >> 16;
+                const uint8_t *r0 = tile + (ye.x & 0xFFFF) * tp;
+                const uint8_t *r1 = tile + (ye.x >> 16) * tp;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int h0 = r0[ca[j]] * wa[j] + r0[cb[j]] * wb[j];
+                    const int h1 = r1[ca[j]] * wa[j] + r1[cb[j]] * wb[j];
+                    const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
+                    packed |= v << (8 * j);
+                }
+                uint8_t *drow = dstF + (size_t)dy * a.dstPitch + q * 4;
+                if (full) *(uint32_t *)drow = packed;
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ok[j]) drow[j] = (uint8_t)(packed >> (8 * j));
                 }
             }
-            unsigned long long mk = __ballot(ismax);
-            if (lane == 0) maxMask[y * maskW + (xb >> 6)] = mk;
+        }
+    }
+
+    // ---- FAST-9/16 ring test on 8-pixel strips; survivors go to a dense LDS queue ----------------------
+    const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
+    const int minEff = max(minTh, 1), iniEff = max(iniTh, 1);
+    const int s0 = (cInt0 - 4) >> 3, s1 = (cInt1 - 1 - 4) >> 3;  // strips cover LDS columns [8s + 4, 8s + 12)
+    const int NS = s1 - s0 + 1;
+    const float invNS = 1.0f / (float)NS;
+    const int nItems = NS * THi;
+    const int nItemsPad = nItems;
+    const int rowOff = ty0 - ly0;
+    if (a.phases & 2)
+    for (int it = tid; it < nItemsPad; it += 256) {
+        unsigned m = 0;
+        int r = 0, cbase = 0;
+        if (it < nItems) {
+            r = (int)(((float)it + 0.5f) * invNS);
+            const int s = s0 + (it - r * NS);
+            const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * s;
+            uint32_t w[7][4];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const uint2 lo = *(const uint2 *)(wp + j * tp);
+                const uint2 hi = *(const uint2 *)(wp + j * tp + 8);
+                w[j][0] = lo.x; w[j][1] = lo.y; w[j][2] = hi.x; w[j][3] = hi.y;
+            }
+            m = fast_strip_mask(w, minTh);
+            cbase = 8 * s + 4;
+            const int lo = max(cInt0 - cbase, 0), hi = min(cInt1 - cbase, 8);
+            m &= (0xFFu >> (8 - hi)) & (0xFFu << lo);  // interior pixels only
+            cmask[r * nsPitch + s] = (uint8_t)m;
+        }
+        if (m) {
+            unsigned pos = atomicAdd(&qCount, (unsigned)__popc(m));  // queue order is irrelevant (bitmaps order the output)
+            while (m) {
+                const int i = __ffs(m) - 1;
+                m &= m - 1;
+                if (pos < PF_QCAP) queue[pos] = (uint16_t)((r << 9) | (cbase + i - cInt0));
+                ++pos;
+            }
         }
     }
     __syncthreads();
-    const int nCells = c1 - c0;
+    const unsigned qn = qCount;
+    if (qn <= PF_QCAP) {
+        // dense: one queue entry per lane — score, then cell-local 3x3 NMS into the per-cell row bitmaps
+        for (unsigned i = tid; i < qn; i += 256) {
+            const unsigned e = queue[i];
+            pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, minEff);
+        }
+        __syncthreads();
+        if (a.phases & 4)
+        for (unsigned i = tid; i < qn; i += 256) {
+            const unsigned e = queue[i];
+            pf_nms_one(score, colInfo, bitsAll, bitsIni, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc, iniEff);
+        }
+    } else {
+        // queue overflow (pathological corner density): per-strip loops over the ring-test masks
+        for (int it = tid; it < nItems; it += 256) {
+            const int r = (int)(((float)it + 0.5f) * invNS);
+            const int s = s0 + (it - r * NS);
+            unsigned m = cmask[r * nsPitch + s];
+            while (m) {
+                const int i = __ffs(m) - 1;
+                m &= m - 1;
+                pf_score_one(tile, score, tp, rowOff, r, 8 * s + 4 + i, minEff);
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < nItems; it += 256) {
+            const int r = (int)(((float)it + 0.5f) * invNS);
+            const int s = s0 + (it - r * NS);
+            unsigned m = cmask[r * nsPitch + s];
+            while (m) {
+                const int i = __ffs(m) - 1;
+                m &= m - 1;
+                pf_nms_one(score, colInfo, bitsAll, bitsIni, tp, r, 8 * s + 4 + i, cInt0, g.wCell, g.hCell, wpc, iniEff);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- per-cell counts at both thresholds (wave per cell, lane per row) ------------------------------
+    if (!(a.phases & 8)) return;
+    for (int c = wave; c < nCells; c += 4) {
+        int nA = 0, nI = 0;
+        for (int r = lane; r < THi; r += 64)
+            for (int k = 0; k < wpc; ++k) {
+                nA += __popc(bitsAll[(c * g.hCell + r) * wpc + k]);
+                nI += __popc(bitsIni[(c * g.hCell + r) * wpc + k]);
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { nA += __shfl_xor(nA, o); nI += __shfl_xor(nI, o); }
+        if (lane == 0) { cntAll[c] = nA; cntIni[c] = nI; }
+    }
+    __syncthreads();
     if (tid == 0) {
         int off = 0;
         for (int c = 0; c < nCells; ++c) {
@@ -230,33 +405,32 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
     }
     __syncthreads();
 
-    // ---- ordered compaction: cells in order, raster inside a cell (== tileCalcKeypoints emission order) --
+    // ---- ordered emission: cells in order, raster inside a cell (== tileCalcKeypoints emission order) ----
     uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + g.candBase +
                      (size_t)(crow * g.nGroups + grp) * g.slotCap;
-    const unsigned long long lt = lanemask_lt();
     for (int c = wave; c < nCells; c += 4) {
-        const int cx0 = c * g.wCell;
-        const int cw = min(g.wCell, TWi - cx0);
-        const int thr = cntIni[c] > 0 ? iniEff : minEff;
-        int off = cellOff[c];
-        const int total = cw * THi;
-        for (int base = 0; base < total; base += 64) {
-            const int p = base + lane;
-            bool keep = false;
-            int xt = 0, r = 0, s = 0;
-            if (p < total) {
-                r = p / cw;
-                xt = cx0 + (p - r * cw);
-                if ((maxMask[r * maskW + (xt >> 6)] >> (xt & 63)) & 1ull) {
-                    s = score[(r + 1) * sp + xt + 1];
-                    keep = s >= thr;
+        const uint32_t *bits = (cntIni[c] > 0 ? bitsIni : bitsAll) + (size_t)c * cellWords;
+        int base = cellOff[c];
+        const int cellC0 = cInt0 + c * g.wCell;
+        for (int rb = 0; rb < THi; rb += 64) {
+            const int r = rb + lane;
+            int n = 0;
+            if (r < THi)
+                for (int k = 0; k < wpc; ++k) n += __popc(bits[r * wpc + k]);
+            int total;
+            int o = base + wave_excl_scan(n, total);
+            if (r < THi) {
+                for (int k = 0; k < wpc; ++k) {
+                    uint32_t wd = bits[r * wpc + k];
+                    while (wd) {
+                        const int b = __ffs(wd) - 1;
+                        wd &= wd - 1;
+                        const int cc = cellC0 + k * 32 + b;
+                        slot[o++] = ORBX_PACK(cc - colOf0 - ORBX_BORDER, ty0 + r - ORBX_BORDER, score[(r + 1) * tp + cc]);
+                    }
                 }
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep)
-                slot[off + __popcll(m & lt)] =
-                    ORBX_PACK(tx0 + xt - ORBX_BORDER, ty0 + r - ORBX_BORDER, s);
-            off += __popcll(m);
+            base += total;
         }
     }
 }
@@ -269,12 +443,20 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
     PyrFastArgs a;
     a.g = g;
     a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride;
-    a.srcAligned4 = (((uintptr_t)src & 3) == 0 && (srcPitch & 3) == 0 && (srcFrameStride & 3) == 0) ? 1 : 0;
+    {
+        const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride;
+        a.srcAlign = (bits & 15) == 0 ? 16 : ((bits & 3) == 0 ? 4 : 1);
+    }
     a.dst = dst; a.dw = dw; a.dh = dh; a.dstPitch = dstPitch; a.dstFrameStride = dstFrameStride;
     a.tabs = tabs;
     a.cand = cand; a.candFrameStride = candFrameStride;
     a.tileCount = tileCount; a.tilesPerFrame = tilesPerFrame;
     a.iniTh = iniTh; a.minTh = minTh;
+    {
+        static int phases = -1;
+        if (phases < 0) { const char *e = getenv("ORBX_PF_PHASES"); phases = e ? atoi(e) : 15; }
+        a.phases = phases;
+    }
     if (g.groupCells > PF_MAX_GROUP_CELLS) return hipErrorInvalidValue;
     dim3 grid(g.nGroups, g.ncy, nframes);
     hipLaunchKernelGGL(k_pyr_fast, grid, dim3(256), g.ldsBytes, st, a);
@@ -336,6 +518,89 @@ __global__ __launch_bounds__(256) void k_blur(BlurArgs a)
     }
 }
 
+// ---- v2: SWAR blur.  Tile = 128 px x 64 rows per workgroup.
+// Horizontal pass: one lane = 4 adjacent output pixels; the 10 source bytes come from three aligned dwords of
+// the global row; byte pairs (s[j], s[j+2]) are isolated with one v_alignbyte + one AND and multiplied as packed
+// 2 x u16 lanes (sums stay below 2^16, so one 32-bit multiply-add serves two pixels); symmetric taps are folded.
+// Vertical pass: one lane = the same 4-pixel column for 8 output rows, 14 rows of 16-bit sums in registers.
+#define BL2_GW 32   // 4-px groups per tile row (128 px)
+#define BL2_TH 64   // output rows per tile
+#define BL2_RT 8    // output rows per lane in the vertical pass
+
+__device__ __forceinline__ uint32_t bl_alignbyte(uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+
+__global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
+{
+    __shared__ uint2 T[BL2_TH + 6][BL2_GW];
+    const int x0 = blockIdx.x * (BL2_GW * 4), y0 = blockIdx.y * BL2_TH, f = blockIdx.z;
+    const int tid = threadIdx.x;
+    const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
+    const uint32_t k0 = a.taps[0], k1 = a.taps[1], k2 = a.taps[2], k3 = a.taps[3];
+    const int rowsNeeded = min(BL2_TH, a.h - y0) + 6;
+
+    for (int it = tid; it < rowsNeeded * BL2_GW; it += 256) {
+        const int r = it >> 5, g = it & 31;
+        const int x = x0 + 4 * g;
+        uint32_t oe = 0, oo = 0;
+        if (x < a.w) {
+            const int gy = reflect101(y0 + r - 3, a.h);
+            const uint8_t *row = srcF + (size_t)gy * a.srcPitch;
+            if (x >= 4 && x + 7 < a.w) {
+                const uint32_t *p = (const uint32_t *)(row + x);
+                const uint32_t w0 = p[-1], w1 = p[0], w2 = p[1];
+                const uint32_t M = 0x00FF00FFu;
+                const uint32_t em3 = bl_alignbyte(w1, w0, 1) & M, em2 = bl_alignbyte(w1, w0, 2) & M, em1 = bl_alignbyte(w1, w0, 3) & M;
+                const uint32_t e0 = w1 & M, e1 = bl_alignbyte(w2, w1, 1) & M, e2 = bl_alignbyte(w2, w1, 2) & M;
+                const uint32_t e3 = bl_alignbyte(w2, w1, 3) & M, e4 = w2 & M;
+                oe = k0 * (em3 + e3) + k1 * (em2 + e2) + k2 * (em1 + e1) + k3 * e0;
+                oo = k0 * (em2 + e4) + k1 * (em1 + e3) + k2 * (e0 + e2) + k3 * e1;
+            } else {
+                // image border: REFLECT_101 per byte
+                uint32_t s[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) s[j] = row[reflect101(x - 3 + j, a.w)];
+                uint32_t t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    t[i] = k0 * (s[i] + s[i + 6]) + k1 * (s[i + 1] + s[i + 5]) + k2 * (s[i + 2] + s[i + 4]) + k3 * s[i + 3];
+                oe = t[0] | (t[2] << 16);
+                oo = t[1] | (t[3] << 16);
+            }
+        }
+        T[r][g] = make_uint2(oe, oo);
+    }
+    __syncthreads();
+
+    const int g = tid & 31, rb = tid >> 5;
+    const int x = x0 + 4 * g;
+    const int r0 = rb * BL2_RT;
+    if (x >= a.w || y0 + r0 >= a.h) return;
+    uint32_t t[BL2_RT + 6][4];
+#pragma unroll
+    for (int j = 0; j < BL2_RT + 6; ++j) {
+        const uint2 v = T[min(r0 + j, rowsNeeded - 1)][g];
+        t[j][0] = v.x & 0xFFFFu; t[j][2] = v.x >> 16; t[j][1] = v.y & 0xFFFFu; t[j][3] = v.y >> 16;
+    }
+    uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
+    const bool fullw = x + 3 < a.w;
+#pragma unroll
+    for (int i = 0; i < BL2_RT; ++i) {
+        const int gy = y0 + r0 + i;
+        if (gy < a.h) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t acc = k0 * (t[i][c] + t[i + 6][c]) + k1 * (t[i + 1][c] + t[i + 5][c]) + k2 * (t[i + 2][c] + t[i + 4][c]) + k3 * t[i + 3][c];
+                packed |= min((acc + 32768u) >> 16, 255u) << (8 * c);
+            }
+            uint8_t *d = dstF + (size_t)gy * a.dstPitch + x;
+            if (fullw) *(uint32_t *)d = packed;
+            else
+                for (int c = 0; c < 4 && x + c < a.w; ++c) d[c] = (uint8_t)(packed >> (8 * c));
+        }
+    }
+}
+
 hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8_t *src, int srcPitch,
                           long long srcFrameStride, uint8_t *dst, int dstPitch, long long dstFrameStride,
                           const int taps[7])
@@ -345,8 +610,17 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
     a.dst = dst; a.dstPitch = dstPitch; a.dstFrameStride = dstFrameStride;
     a.w = w; a.h = h;
     for (int k = 0; k < 7; ++k) a.taps[k] = taps[k];
-    dim3 grid((w + BL_TW - 1) / BL_TW, (h + BL_TH - 1) / BL_TH, nframes);
-    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, st, a);
+    const bool symmetric = taps[0] == taps[6] && taps[1] == taps[5] && taps[2] == taps[4];
+    const bool small = (taps[0] + taps[1] + taps[2]) * 2 + taps[3] <= 257;  // packed 16-bit horizontal sums cannot overflow
+    const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride | (uintptr_t)dst | (uintptr_t)dstPitch |
+                           (uintptr_t)dstFrameStride;
+    if (symmetric && small && (bits & 3) == 0) {
+        dim3 grid((w + BL2_GW * 4 - 1) / (BL2_GW * 4), (h + BL2_TH - 1) / BL2_TH, nframes);
+        hipLaunchKernelGGL(k_blur2, grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((w + BL_TW - 1) / BL_TW, (h + BL_TH - 1) / BL_TH, nframes);
+        hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 
