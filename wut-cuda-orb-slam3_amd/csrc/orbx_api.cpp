@@ -72,6 +72,8 @@ struct orbx_extractor {
     int maxKeypoints = 0, maxQuota = 0;
     int taps[7];
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // GaussianBlur runs here, concurrently with the quadtree on `stream`
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
 
     // geometry of the current image size
     int curW = 0, curH = 0;
@@ -187,7 +189,10 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     memcpy(ex->taps, p->blur_variant == ORBX_BLUR_OPENCV_451 ? t451 : t450, sizeof ex->taps);
 
     hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete ex; return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evJoin, hipEventDisableTiming);
+    if (e != hipSuccess) { orbx_destroy(ex); return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ex->d_raw.resize(nl); ex->d_blur.resize(nl);
     int rc = computeGeometry(ex, p->max_width, p->max_height);
     if (rc == ORBX_OK) rc = ensureBuffers(ex);
@@ -200,7 +205,10 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
 {
     if (!ex) return;
     (void)hipSetDevice(ex->prm.device);
+    if (ex->stream2) { (void)hipStreamSynchronize(ex->stream2); (void)hipStreamDestroy(ex->stream2); }
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
+    if (ex->evFork) (void)hipEventDestroy(ex->evFork);
+    if (ex->evJoin) (void)hipEventDestroy(ex->evJoin);
     for (auto &e : ex->events) (void)hipEventDestroy(e);
     ex->d_in.release();
     for (auto &b : ex->d_raw) b.release();
@@ -479,7 +487,7 @@ static OrbxTables makeTables(const orbx_extractor *ex)
         t.selBase[l] = ex->geom[l].selBase;
         t.patchSize[l] = (int)(31 * ex->scale[l]);  // const int scaledPatchSize = PATCH_SIZE * mvScaleFactor[level], :1017
     }
-    for (int i = 0; i < 16; ++i) t.umax[i] = ex->umax[i];
+    for (int i = 0; i < 16; ++i) { t.umax[i] = ex->umax[i]; t.umaxPacked |= (unsigned long long)(ex->umax[i] & 15) << (4 * i); }
     for (int i = 0; i < 7; ++i) t.taps[i] = ex->taps[i];
     return t;
 }
@@ -523,17 +531,22 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
                                   ex->prm.min_th_fast));
     }
     PROF_MARK(1);
-    HIP_TRY(orbxLaunchQuadtree(st, nframes, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p, ex->candFrameStride,
-                               ex->d_tileCount.p, ex->tilesPerFrame, ex->d_scratchA.p, ex->d_scratchB.p, ex->d_sel.p,
-                               ex->selFrameStride, ex->d_selCount.p, ex->maxQuota));
-    PROF_MARK(2);
+    // fork: GaussianBlur of every level on stream2 (needs only the pyramid), concurrently with the
+    // latency-bound quadtree + pack on the main stream; joined before orientation + descriptors
+    HIP_TRY(hipEventRecord(ex->evFork, st));
+    HIP_TRY(hipStreamWaitEvent(ex->stream2, ex->evFork, 0));
     for (int l = 0; l < nl; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
         const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
         const int srcPitch = l == 0 ? (int)stride : g.pitch;
         const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
-        HIP_TRY(orbxLaunchBlur(st, nframes, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p, g.pitch, g.frameStride, ex->taps));
+        HIP_TRY(orbxLaunchBlur(ex->stream2, nframes, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p, g.pitch, g.frameStride, ex->taps));
     }
+    HIP_TRY(hipEventRecord(ex->evJoin, ex->stream2));
+    HIP_TRY(orbxLaunchQuadtree(st, nframes, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p, ex->candFrameStride,
+                               ex->d_tileCount.p, ex->tilesPerFrame, ex->d_scratchA.p, ex->d_scratchB.p, ex->d_sel.p,
+                               ex->selFrameStride, ex->d_selCount.p, ex->maxQuota));
+    PROF_MARK(2);
     PROF_MARK(3);
     OrbxTables tb = makeTables(ex);
     HIP_TRY(orbxLaunchPack(st, nframes, tb, ex->d_sel.p, ex->selFrameStride, ex->d_selCount.p, lap0, lap1, ex->d_kps.p,
@@ -548,6 +561,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
         lv.blur[l] = ex->d_blur[l].p; lv.blurPitch[l] = g.pitch; lv.blurFrameStride[l] = g.frameStride;
         lv.w[l] = g.w; lv.h[l] = g.h;
     }
+    HIP_TRY(hipStreamWaitEvent(st, ex->evJoin, 0));
     PROF_MARK(4);
     HIP_TRY(orbxLaunchOrientDesc(st, nframes, tb, lv, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_kps.p,
                                  ex->d_desc.p, ex->maxKeypoints));

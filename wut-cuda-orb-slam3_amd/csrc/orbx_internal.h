@@ -66,6 +66,7 @@ struct OrbxTables {
     int selBase[ORBX_MAX_LEVELS];
     int patchSize[ORBX_MAX_LEVELS];  // (int)(31 * scale)
     int umax[16];
+    unsigned long long umaxPacked;  // umax[v] in nibble v
     int taps[7];
     int nlevels;
     int angleMode;

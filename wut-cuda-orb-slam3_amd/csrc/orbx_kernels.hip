@@ -72,34 +72,76 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp)
     return max(a, -b) - 1;
 }
 
-// Ring test for the 8 pixels of one strip.  w[j] holds 16 consecutive tile bytes of row (y - 3 + j); strip pixel
-// i is byte 4 + i of the centre row.  Returns the 8-bit mask of pixels with >= 9 contiguous ring pixels darker
-// than v - th or brighter than v + th.  The per-lane 16-bit ring masks are built with one subtract (sign bit =
-// comparison) and one v_alignbit (mask = mask << 1 | sign) per ring pixel and polarity.
-#define WBYTE(j, idx) ((w[j][(idx) >> 2] >> (((idx) & 3) * 8)) & 0xFFu)
+// Ring test for the 8 pixels of one strip — byte-SWAR, 4 pixels per 32-bit operation.
+//
+// Measured on gfx950 (profiles/r01_valu_microbench.txt): v_and/v_or/v_add/v_sub/v_bitop3/shifts issue at 2
+// cycles per wave64, while SDWA forms, v_alignbit, min/max, v_pk_*, v_perm, v_bfi and v_mad issue at 4.  So the
+// test is phrased in full-rate ops only (plus one v_alignbyte per ring position to fetch 4 unaligned bytes):
+//   * w[j] holds 16 consecutive tile bytes of row (y - 3 + j); strip pixel i is byte 4 + i of the centre row;
+//     a group = 4 adjacent pixels = one dword V of centres; ring position k of the group = the dword P_k at byte
+//     offset (dx_k, dy_k) from it.
+//   * per byte "P < LO" (dark) and "P > HI" (bright) with LO = v - th, HI = v + th use the borrow-free 7+1-bit
+//     compare: t = (Pl + (0x80 - LOl)) has bit 7 = [Pl >= LOl]; flag = (~P7 & LO7) | (~(P7 ^ LO7) & ~t7).
+//     LO / HI wrap modulo 256; pixels whose v - th < 0 (v + th > 255) cannot have dark (bright) ring pixels and
+//     are masked once at the end.
+//   * the flags stay transposed (one word per ring position, bit 7 of each byte = one pixel); ">= 9 contiguous"
+//     = OR over the 16 arcs of the AND of 9 consecutive words, with 3-input ANDs (v_bitop3).
+// Returns the 8-bit corner mask of the strip.
+#define SW_H 0x80808080u
+#define SW_L 0x7F7F7F7Fu
+
+template <int GRP>
+__device__ __forceinline__ uint32_t fast_group_flags(const uint32_t (&w)[7][4], uint32_t T4, uint32_t C4)
+{
+    const uint32_t V = w[3][1 + GRP];
+    const uint32_t Vl = V & SW_L;
+    // LO = V - th, HI = V + th (per byte, wrapping) and their validity
+    const uint32_t tS = (V | SW_H) - (T4 & SW_L);                                  // bit7 = [Vl >= Tl]
+    const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
+    const uint32_t ltVT = (~V & T4) | (~(V ^ T4) & ~tS);                           // bit7 = [V < th]
+    const uint32_t HI = (Vl + (T4 & SW_L)) ^ ((V ^ T4) & SW_H);
+    const uint32_t tC = (C4 | SW_H) - Vl;                                          // C = 255 - th
+    const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);                           // bit7 = [255 - th < V]
+    const uint32_t Kd = SW_H - (LO & SW_L);
+    const uint32_t HIh = HI | SW_H;
+    uint32_t D[16], B[16];
+#define RING(k, dx, dy)                                                                            \
+    {                                                                                              \
+        constexpr int o = 4 + 4 * GRP + (dx);                                                      \
+        const uint32_t P = (o & 3) == 0 ? w[3 + (dy)][o >> 2]                                      \
+                                        : __builtin_amdgcn_alignbyte(w[3 + (dy)][(o >> 2) + 1], w[3 + (dy)][o >> 2], o & 3); \
+        const uint32_t Pl = P & SW_L;                                                              \
+        const uint32_t td = Pl + Kd;                                                               \
+        const uint32_t tb = HIh - Pl;                                                              \
+        D[k] = (~P & LO) | (~(P ^ LO) & ~td);                                                      \
+        B[k] = (~HI & P) | (~(HI ^ P) & ~tb);                                                      \
+    }
+    RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+    RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2) RING(15, -1, 3)
+#undef RING
+    uint32_t d3[16], b3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        d3[k] = D[k] & D[(k + 1) & 15] & D[(k + 2) & 15];
+        b3[k] = B[k] & B[(k + 1) & 15] & B[(k + 2) & 15];
+    }
+    uint32_t rd = 0, rb = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        rd |= d3[k] & d3[(k + 3) & 15] & d3[(k + 6) & 15];
+        rb |= b3[k] & b3[(k + 3) & 15] & b3[(k + 6) & 15];
+    }
+    return ((rd & ~ltVT) | (rb & ~ltCV)) & SW_H;
+}
+
 __device__ __forceinline__ unsigned fast_strip_mask(const uint32_t (&w)[7][4], int th)
 {
-    unsigned out = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int v = (int)WBYTE(3, 4 + i);
-        const int lo = v - th, hi = v + th;
-        unsigned dark = 0, bright = 0;
-#define RING(dx, dy)                                                                              \
-        {                                                                                         \
-            const int p = (int)WBYTE(3 + (dy), 4 + i + (dx));                                     \
-            dark = __builtin_amdgcn_alignbit(dark, (unsigned)(p - lo), 31);                       \
-            bright = __builtin_amdgcn_alignbit(bright, (unsigned)(hi - p), 31);                   \
-        }
-        RING(0, 3) RING(1, 3) RING(2, 2) RING(3, 1) RING(3, 0) RING(3, -1) RING(2, -2) RING(1, -3)
-        RING(0, -3) RING(-1, -3) RING(-2, -2) RING(-3, -1) RING(-3, 0) RING(-3, 1) RING(-2, 2) RING(-1, 3)
-#undef RING
-        // branch-free on purpose: both polarities are always evaluated so the 16 chains of a strip interleave
-        out |= (unsigned)((ring_run9(dark) | ring_run9(bright)) != 0) << i;
-    }
-    return out;
+    const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
+    const uint32_t f0 = fast_group_flags<0>(w, T4, C4);
+    const uint32_t f1 = fast_group_flags<1>(w, T4, C4);
+    // gather bits 7/15/23/31 of each group into a nibble
+    return ((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4);
 }
-#undef WBYTE
 
 __device__ __forceinline__ int wave_excl_scan(int v, int &total)
 {
@@ -1024,66 +1066,116 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+#define OD_KPW 32  // keypoints per wave
+
+// sum over the 64 lanes: 4 DPP steps give every lane its 16-lane row total, the 4 row totals are added as scalars
+__device__ __forceinline__ int wave_sum_i32(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);  // row_mirror
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+           __builtin_amdgcn_readlane(x, 48);
+}
+
+// One wave = OD_KPW keypoints of one frame:
+//   pass 1  per keypoint, wave-cooperative: IC_Angle moments over the radius-15 patch (16 byte loads in flight per
+//           lane, DPP row reduction); lane k keeps the moments of keypoint k
+//   pass 2  per lane: fastAtan2 + (float)cos/sin((double)angle) for all keypoints of the wave at once
+//   pass 3  per keypoint, wave-cooperative: 256 steered-BRIEF tests, 64 per ballot
 __global__ __launch_bounds__(256) void k_orient_desc(OrbxTables tb, OrbxLevelPtrs lv, const uint32_t *workKey,
                                                      const int *workPos, const int *nOut, OrbxKp *kps, uint8_t *desc,
                                                      int cap)
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gi = blockIdx.x * 4 + wave;
-    if (gi >= nOut[f]) return;
-    const uint32_t key = workKey[(size_t)f * cap + gi];
-    const int pos = workPos[(size_t)f * cap + gi];
-    const int l = key >> 24, xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
+    const int n = nOut[f];
+    const int base = (blockIdx.x * 4 + wave) * OD_KPW;
+    if (base >= n) return;
+    const int cnt = min(OD_KPW, n - base);
+    uint32_t myKey = 0;
+    int myPos = 0;
+    if (lane < cnt) {
+        myKey = workKey[(size_t)f * cap + base + lane];
+        myPos = workPos[(size_t)f * cap + base + lane];
+    }
+    // this lane's 4 test pairs (pairs lane, lane + 64, lane + 128, lane + 192) as floats
+    float px0[4], py0[4], px1[4], py1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int v = *(const int *)(c_pattern + (r * 64 + lane) * 4);
+        px0[r] = (float)(signed char)(v & 0xFF);
+        py0[r] = (float)(signed char)((v >> 8) & 0xFF);
+        px1[r] = (float)(signed char)((v >> 16) & 0xFF);
+        py1[r] = (float)(signed char)((v >> 24) & 0xFF);
+    }
 
-    // ---- IC_Angle: m10 = sum u*I, m01 = sum v*I over the radius-15 circular patch of the un-blurred level
-    const int rp = lv.rawPitch[l];
-    const uint8_t *center = lv.raw[l] + (size_t)f * lv.rawFrameStride[l] + (size_t)yl * rp + xl;
-    int m10 = 0, m01 = 0;
+    // ---- pass 1: moments ------------------------------------------------------------------------------------
     const int u = (lane & 31) - 15;
-    for (int it = 0; it < 16; ++it) {
-        const int v = it * 2 + (lane >> 5) - 15;
-        if (v <= 15) {
-            const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-            if (au <= tb.umax[av]) {
+    const int au = u < 0 ? -u : u;
+    int myM01 = 0, myM10 = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const uint32_t key = __builtin_amdgcn_readlane(myKey, k);
+        const int l = key >> 24, xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
+        const int rp = lv.rawPitch[l];
+        const uint8_t *center = lv.raw[l] + (size_t)f * lv.rawFrameStride[l] + (size_t)yl * rp + xl;
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int v = it * 2 + (lane >> 5) - 15;
+            const int av = v < 0 ? -v : v;
+            const int um = (int)((tb.umaxPacked >> (4 * (av & 15))) & 15);
+            if (v <= 15 && au <= um) {
                 const int I = center[v * rp + u];
                 m10 += u * I;
                 m01 += v * I;
             }
         }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
+        if (lane == k) { myM10 = m10; myM01 = m01; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
+
+    // ---- pass 2: orientation + rotation, one keypoint per lane ---------------------------------------------------
     float angle;
     if (tb.angleMode == 1) {
-        angle = atan2f((float)m01, (float)m10);
+        angle = atan2f((float)myM01, (float)myM10);
         angle = __fadd_rn(angle, (angle < 0) ? __fmul_rn(2.0f, 3.141592f) : 0.f);
         angle = __fmul_rn(angle, __fdiv_rn(180.0f, 3.141592f));
     } else {
-        angle = fast_atan2_deg((float)m01, (float)m10);
+        angle = fast_atan2_deg((float)myM01, (float)myM10);
     }
-    if (lane == 0) kps[(size_t)f * cap + pos].angle = angle;
-
-    // ---- steered BRIEF on the blurred level; 64 test pairs per ballot ---------------------------------
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)ar), b = (float)sin((double)ar);
-    const int bp = lv.blurPitch[l];
-    const uint8_t *bc = lv.blur[l] + (size_t)f * lv.blurFrameStride[l] + (size_t)yl * bp + xl;
-    uint8_t *dout = desc + ((size_t)f * cap + pos) * 32;
+    const float myA = (float)cos((double)ar), myB = (float)sin((double)ar);
+    if (lane < cnt) kps[(size_t)f * cap + myPos].angle = angle;
+
+    // ---- pass 3: descriptors --------------------------------------------------------------------------------
+    for (int k = 0; k < cnt; ++k) {
+        const uint32_t key = __builtin_amdgcn_readlane(myKey, k);
+        const int pos = __builtin_amdgcn_readlane(myPos, k);
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myA), k));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myB), k));
+        const int l = key >> 24, xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
+        const int bp = lv.blurPitch[l];
+        const uint8_t *bc = lv.blur[l] + (size_t)f * lv.blurFrameStride[l] + (size_t)yl * bp + xl;
+        int t0[4], t1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const signed char *pt = c_pattern + (r * 64 + lane) * 4;
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[iy0 * bp + ix0], t1 = bc[iy1 * bp + ix1];
-        const unsigned long long bits = __ballot(t0 < t1);
-        if (lane == 0) *(unsigned long long *)(dout + r * 8) = bits;
+        for (int r = 0; r < 4; ++r) {
+            const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)));
+            const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
+            const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
+            const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
+            t0[r] = bc[iy0 * bp + ix0];
+            t1[r] = bc[iy1 * bp + ix1];
+        }
+        unsigned long long word = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long bits = __ballot(t0[r] < t1[r]);
+            if (lane == r) word = bits;
+        }
+        if (lane < 4) *(unsigned long long *)(desc + ((size_t)f * cap + pos) * 32 + lane * 8) = word;
     }
 }
 
@@ -1098,7 +1190,7 @@ hipError_t orbxLaunchOrientDesc(hipStream_t st, int nframes, OrbxTables tabs, Or
         if (e != hipSuccess) return e;
         patternLoaded[dev] = true;
     }
-    dim3 grid((cap + 3) / 4, nframes);
+    dim3 grid((cap + 4 * OD_KPW - 1) / (4 * OD_KPW), nframes);
     hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, st, tabs, lv, workKey, workPos, nOut, (OrbxKp *)kps, desc, cap);
     return hipGetLastError();
 }
