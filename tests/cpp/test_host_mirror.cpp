@@ -1,0 +1,108 @@
+// C++ parity test of the host-side mirror (wut-cuda-orb-slam3_amd/host/ORBextractor.hpp) against the CPU oracle.
+// Reads like the reference's own tests (test/src/OpenCLTest.cpp: build an extractor, run one stage, check the
+// result) — but asserts numeric equality instead of "the kernel started".  Needs a GPU; built and run by
+// tests/test_host_mirror_gpu.py.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/orbx_synth.h"
+#include "../../oracle/orb_oracle.h"
+#include "../../wut-cuda-orb-slam3_amd/host/ORBextractor.hpp"
+
+#define ASSERT_TRUE(c)                                                          \
+    do {                                                                        \
+        if (!(c)) { printf("ASSERT_TRUE failed: %s (line %d)\n", #c, __LINE__); return 1; } \
+    } while (0)
+#define ASSERT_EQ(a, b) ASSERT_TRUE((a) == (b))
+
+static int runExtractAndCompare(int w, int h, int nfeatures, std::vector<int> lap)
+{
+    std::vector<uint8_t> img((size_t)w * h);
+    orbx_synth_frame_impl(42, w, h, img.data(), w);
+
+    orbx::ORBextractor extractor(nfeatures, 1.2f, 8, 20, 7, 0, w, h);
+    std::vector<orbx::KeyPoint> keypoints;
+    orbx::Descriptors descriptors;
+    int mono = extractor(orbx::Image(img.data(), w, h), orbx::Image(), keypoints, descriptors, lap);
+
+    oracle_handle *ref = oracle_create(nfeatures, 1.2f, 8, 20, 7, 0, 0);
+    std::vector<oracle_keypoint> rk(oracle_max_keypoints(ref) + 64);
+    std::vector<uint8_t> rd(rk.size() * 32);
+    int rn = 0;
+    int rmono = oracle_extract(ref, img.data(), w, h, w, lap[0], lap[1], rk.data(), rd.data(), &rn);
+
+    ASSERT_EQ(mono, rmono);
+    ASSERT_EQ((int)keypoints.size(), rn);
+    ASSERT_EQ(descriptors.rows, rn);
+    ASSERT_TRUE(rn >= nfeatures);
+    ASSERT_TRUE(memcmp(keypoints.data(), rk.data(), (size_t)rn * 28) == 0);
+    ASSERT_TRUE(memcmp(descriptors.data.data(), rd.data(), (size_t)rn * 32) == 0);
+
+    // getters (reference include/ORBextractor.h:70-90)
+    float sc[8], isc[8], s2[8], is2[8];
+    int32_t fpl[8], um[16];
+    oracle_get_tables(ref, sc, isc, s2, is2, fpl, um);
+    ASSERT_EQ(extractor.GetLevels(), 8);
+    ASSERT_TRUE(memcmp(extractor.GetScaleFactors().data(), sc, sizeof sc) == 0);
+    ASSERT_TRUE(memcmp(extractor.GetInverseScaleFactors().data(), isc, sizeof isc) == 0);
+    ASSERT_TRUE(memcmp(extractor.GetScaleSigmaSquares().data(), s2, sizeof s2) == 0);
+    ASSERT_TRUE(memcmp(extractor.GetInverseScaleSigmaSquares().data(), is2, sizeof is2) == 0);
+
+    // mvImagePyramid
+    for (int level = 0; level < 8; ++level) {
+        int lw, lh, ow, oh;
+        std::vector<uint8_t> lv = extractor.ImagePyramidLevel(level, lw, lh);
+        oracle_level_size(ref, level, &ow, &oh);
+        ASSERT_EQ(lw, ow);
+        ASSERT_EQ(lh, oh);
+        std::vector<uint8_t> rl((size_t)ow * oh);
+        oracle_get_level(ref, level, 0, rl.data());
+        ASSERT_TRUE(lv == rl);
+    }
+
+    // DescriptorDistance + knnMatch on the descriptors just produced
+    ASSERT_EQ(orbx::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(0)), 0);
+    ASSERT_EQ(orbx::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)),
+              oracle_hamming256(descriptors.row(0), descriptors.row(1)));
+    orbx::BFMatcher BFmatcher(8192, 8192);
+    std::vector<std::vector<orbx::DMatch>> matches;
+    orbx::Descriptors train = descriptors;
+    BFmatcher.knnMatch(descriptors, train, matches, 2);
+    std::vector<int32_t> ridx((size_t)rn * 2), rdist((size_t)rn * 2);
+    oracle_knn2(descriptors.data.data(), rn, train.data.data(), rn, ridx.data(), rdist.data());
+    ASSERT_EQ((int)matches.size(), rn);
+    for (int i = 0; i < rn; ++i) {
+        ASSERT_EQ((int)matches[i].size(), 2);
+        for (int j = 0; j < 2; ++j) {
+            ASSERT_EQ(matches[i][j].trainIdx, ridx[i * 2 + j]);
+            ASSERT_EQ(matches[i][j].distance, (float)rdist[i * 2 + j]);
+        }
+        ASSERT_EQ(matches[i][0].distance, 0.0f);  // self-match
+    }
+    oracle_destroy(ref);
+    return 0;
+}
+
+int main()
+{
+    // empty image -> -1 (reference src/ORBextractor.cc:1231-1232)
+    {
+        orbx::ORBextractor extractor(1000, 1.2f, 8, 20, 7, 0, 640, 480);
+        std::vector<orbx::KeyPoint> kps;
+        orbx::Descriptors d;
+        std::vector<int> lap = {0, 0};
+        ASSERT_EQ(extractor(orbx::Image(), orbx::Image(), kps, d, lap), -1);
+        // too small for the FAST cell grid -> std::runtime_error, like the fork's failed launches
+        std::vector<uint8_t> tiny(64 * 64, 0);
+        bool thrown = false;
+        try { extractor(orbx::Image(tiny.data(), 64, 64), orbx::Image(), kps, d, lap); } catch (const std::runtime_error &) { thrown = true; }
+        ASSERT_TRUE(thrown);
+    }
+    if (runExtractAndCompare(640, 480, 1000, {0, 1000})) return 1;   // mono call of Frame.cc:313
+    if (runExtractAndCompare(752, 480, 1200, {0, 0})) return 1;      // EuRoC geometry
+    if (runExtractAndCompare(512, 512, 1500, {100, 300})) return 1;  // TUM-VI geometry with a lapping band
+    printf("OK host mirror\n");
+    return 0;
+}

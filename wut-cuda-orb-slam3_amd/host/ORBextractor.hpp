@@ -1,0 +1,198 @@
+// ORBextractor.hpp — C++ host-side mirror of the reference's operator interface over the C ABI (include/orbx.h).
+//
+// Same names, argument meaning and error behaviour as the reference for this path:
+//   ORB_SLAM3::ORBextractor            reference include/ORBextractor.h:52-113, src/ORBextractor.cc:410-468, 1227-1307
+//   ORB_SLAM3::ORBmatcher::DescriptorDistance + TH_LOW/TH_HIGH/HISTO_LENGTH
+//                                      reference include/ORBmatcher.h:43, src/ORBmatcher3.cc:637-653, src/ORBmatcher1.cc:37-39
+//   cv::BFMatcher(NORM_HAMMING).knnMatch  reference src/Frame.cc:45, 1174
+// Header-only; links against liborbx.so.  OpenCV is NOT required: images are passed as orbx::Image views and
+// keypoints as orbx::KeyPoint, which is layout-identical to cv::KeyPoint (28 bytes).  When OpenCV headers are
+// present (the reference's build), the cv:: overloads at the bottom make this class a drop-in for the
+// reference's call site `(*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors, vLapping)` (src/Frame.cc:420-428).
+//
+// Errors: like the fork (throw std::runtime_error on a failed launch, src/ORBextractor.cc:499,862,974,1213)
+// library errors are rethrown as std::runtime_error; an empty image returns -1 (src/ORBextractor.cc:1231-1232).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+namespace orbx {
+
+struct Point2f { float x, y; };
+
+// == cv::KeyPoint (pt, size, angle, response, octave, class_id)
+struct KeyPoint {
+    Point2f pt;
+    float size;
+    float angle;
+    float response;
+    int octave;
+    int class_id;
+};
+static_assert(sizeof(KeyPoint) == 28 && sizeof(KeyPoint) == sizeof(orbx_keypoint), "KeyPoint must match cv::KeyPoint");
+
+// 8-bit single-channel image view (== cv::Mat of type CV_8UC1: data / cols / rows / step)
+struct Image {
+    const uint8_t *data = nullptr;
+    int cols = 0, rows = 0;
+    ptrdiff_t step = 0;
+    Image() = default;
+    Image(const uint8_t *d, int c, int r, ptrdiff_t s = 0) : data(d), cols(c), rows(r), step(s ? s : c) {}
+    bool empty() const { return !data || cols <= 0 || rows <= 0; }
+};
+
+// n x 32 CV_8U descriptor matrix
+struct Descriptors {
+    int rows = 0;
+    std::vector<uint8_t> data;
+    void create(int n) { rows = n; data.assign((size_t)n * 32, 0); }
+    void release() { rows = 0; data.clear(); }
+    const uint8_t *row(int i) const { return data.data() + (size_t)i * 32; }
+    uint8_t *row(int i) { return data.data() + (size_t)i * 32; }
+    bool empty() const { return rows == 0; }
+};
+
+struct DMatch {
+    int queryIdx, trainIdx, imgIdx;
+    float distance;
+};
+
+inline void check(int rc, const char *what)
+{
+    if (rc != ORBX_OK) throw std::runtime_error(std::string(what) + ": " + orbx_last_error());
+}
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0, int maxWidth = 1920,
+                 int maxHeight = 1080, int blurVariant = ORBX_BLUR_OPENCV_450)
+    {
+        orbx_params p;
+        orbx_default_params(&p);
+        p.nfeatures = nfeatures; p.scale_factor = scaleFactor; p.nlevels = nlevels;
+        p.ini_th_fast = iniThFAST; p.min_th_fast = minThFAST;
+        p.device = device; p.max_width = maxWidth; p.max_height = maxHeight; p.max_batch = 1;
+        p.blur_variant = blurVariant;
+        check(orbx_create(&p, &h_), "ORBextractor");
+    }
+    ~ORBextractor() { orbx_destroy(h_); }
+    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor &operator=(const ORBextractor &) = delete;
+
+    // Compute the ORB features and descriptors on an image; mask is ignored (as in the reference).
+    int operator()(const Image &image, const Image & /*mask*/, std::vector<KeyPoint> &keypoints, Descriptors &descriptors,
+                   std::vector<int> &vLappingArea)
+    {
+        if (image.empty()) return -1;
+        const int cap = orbx_max_keypoints(h_);
+        keypoints.resize(cap);
+        descriptors.create(cap);
+        int n = 0;
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        int mono = orbx_extract(h_, image.data, image.cols, image.rows, image.step, lap0, lap1,
+                                reinterpret_cast<orbx_keypoint *>(keypoints.data()), descriptors.data.data(), cap, &n);
+        if (mono <= -101) throw std::runtime_error(std::string("ORBextractor::operator(): ") + orbx_last_error());
+        keypoints.resize(n);
+        if (n == 0) descriptors.release();
+        else { descriptors.rows = n; descriptors.data.resize((size_t)n * 32); }
+        return mono;
+    }
+
+    int GetLevels() { return orbx_get_levels(h_); }
+    float GetScaleFactor() { return orbx_get_scale_factor(h_); }
+    std::vector<float> GetScaleFactors() { return table(orbx_get_scale_factors); }
+    std::vector<float> GetInverseScaleFactors() { return table(orbx_get_inverse_scale_factors); }
+    std::vector<float> GetScaleSigmaSquares() { return table(orbx_get_scale_sigma_squares); }
+    std::vector<float> GetInverseScaleSigmaSquares() { return table(orbx_get_inverse_scale_sigma_squares); }
+
+    // mvImagePyramid[level] of the last call (interior, tight rows) — reference include/ORBextractor.h:92
+    std::vector<uint8_t> ImagePyramidLevel(int level, int &cols, int &rows)
+    {
+        check(orbx_get_level_size(h_, level, &cols, &rows), "ImagePyramidLevel");
+        std::vector<uint8_t> out((size_t)cols * rows);
+        check(orbx_get_pyramid_level(h_, 0, level, 0, out.data()), "ImagePyramidLevel");
+        return out;
+    }
+    orbx_extractor *handle() { return h_; }
+
+private:
+    std::vector<float> table(int (*fn)(const orbx_extractor *, float *))
+    {
+        std::vector<float> v(orbx_get_levels(h_));
+        fn(h_, v.data());
+        return v;
+    }
+    orbx_extractor *h_ = nullptr;
+};
+
+class ORBmatcher {
+public:
+    static const int TH_LOW = 50;      // reference src/ORBmatcher1.cc:38
+    static const int TH_HIGH = 100;    // :37
+    static const int HISTO_LENGTH = 30;  // :39
+    // Computes the Hamming distance between two ORB descriptors (rows of 32 bytes)
+    static int DescriptorDistance(const uint8_t *a, const uint8_t *b) { return orbx_hamming256(a, b); }
+};
+
+// cv::BFMatcher(cv::NORM_HAMMING) for k = 2 (the only use in the reference, src/Frame.cc:1174)
+class BFMatcher {
+public:
+    explicit BFMatcher(int maxQuery = 8192, int maxTrain = 8192, int device = 0) { check(orbx_matcher_create(device, maxQuery, maxTrain, &m_), "BFMatcher"); }
+    ~BFMatcher() { orbx_matcher_destroy(m_); }
+    BFMatcher(const BFMatcher &) = delete;
+    BFMatcher &operator=(const BFMatcher &) = delete;
+
+    void knnMatch(const Descriptors &query, const Descriptors &train, std::vector<std::vector<DMatch>> &matches, int k = 2)
+    {
+        if (k != 2) throw std::runtime_error("BFMatcher::knnMatch: only k == 2 is provided (reference src/Frame.cc:1174)");
+        std::vector<int32_t> idx((size_t)query.rows * 2), dist((size_t)query.rows * 2);
+        check(orbx_match_knn2(m_, query.data.data(), query.rows, train.data.data(), train.rows, idx.data(), dist.data()), "knnMatch");
+        matches.assign(query.rows, {});
+        for (int i = 0; i < query.rows; ++i)
+            for (int j = 0; j < 2 && idx[i * 2 + j] >= 0; ++j)
+                matches[i].push_back(DMatch{i, idx[i * 2 + j], 0, (float)dist[i * 2 + j]});
+    }
+    orbx_matcher *handle() { return m_; }
+
+private:
+    orbx_matcher *m_ = nullptr;
+};
+
+}  // namespace orbx
+
+// ---- OpenCV adaptor (compiled only inside the reference's build, where OpenCV >= 4.4 exists) ----------------
+#if defined(ORBX_WITH_OPENCV) && __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+namespace orbx {
+// Drop-in for `int ORB_SLAM3::ORBextractor::operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&,
+// cv::OutputArray, std::vector<int>&)` (reference include/ORBextractor.h:66-68).
+inline int extract(ORBextractor &ex, cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints,
+                   cv::OutputArray _descriptors, std::vector<int> &vLappingArea)
+{
+    static_assert(sizeof(cv::KeyPoint) == sizeof(KeyPoint), "cv::KeyPoint layout");
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    CV_Assert(image.type() == CV_8UC1);
+    std::vector<KeyPoint> kps;
+    Descriptors d;
+    int mono = ex(Image(image.data, image.cols, image.rows, (ptrdiff_t)image.step), Image(), kps, d, vLappingArea);
+    _keypoints.resize(kps.size());
+    if (!kps.empty()) std::memcpy((void *)_keypoints.data(), kps.data(), kps.size() * sizeof(KeyPoint));
+    if (kps.empty()) _descriptors.release();
+    else {
+        _descriptors.create((int)kps.size(), 32, CV_8U);
+        std::memcpy(_descriptors.getMat().data, d.data.data(), d.data.size());
+    }
+    return mono;
+}
+}  // namespace orbx
+#endif
