@@ -23,6 +23,22 @@
 
 #define WAVE 64
 
+// XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs in linear block order, and each XCD has
+// its own 4 MiB L2.  A 1-D grid of 8 * ceil(nframes / 8) * unitsPerFrame blocks is decoded so that block b works on
+// frame (b % 8) + 8 * (b / (8 * units)) and unit (b / 8) % units: eight frames are in flight, one per XCD, and
+// every unit (tile / keypoint chunk) of a frame runs on the same XCD back to back, so halo rows, overlapping
+// keypoint patches and the level written by the previous launch are re-read from that XCD's L2, not from HBM.
+__device__ __forceinline__ bool xcd_decode(int nframes, int units, int &frame, int &unit)
+{
+    const unsigned b = blockIdx.x;
+    const unsigned per = 8u * (unsigned)units;
+    const unsigned chunk = b / per, rem = b - chunk * per;
+    frame = (int)(chunk * 8u + (rem & 7u));
+    unit = (int)(rem >> 3);
+    return frame < nframes;
+}
+static inline unsigned xcd_grid(int nframes, int units) { return (unsigned)((nframes + 7) / 8) * 8u * (unsigned)units; }
+
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {
     const unsigned lane = threadIdx.x & 63;
@@ -164,10 +180,13 @@ struct PyrFastArgs {
     uint32_t *cand; long long candFrameStride;
     int *tileCount; int tilesPerFrame;
     int iniTh, minTh;
+    int nframes;
     int phases;  // debug/ablation mask (ORBX_PF_PHASES): 1 resize, 2 ring test+score, 4 NMS, 8 count+emit
 };
 
 #define PF_MAX_GROUP_CELLS 32
+#define PF_NT 256           // threads per workgroup (512 measured no faster: the kernel is VALU-issue bound, not latency bound)
+#define PF_NW (PF_NT / 64)
 #define PF_XO 16      // LDS column of image column ax0 (keeps every strip window inside the tile row)
 #define PF_QCAP 4096  // corner queue entries (u16: row << 9 | interior column)
 
@@ -198,11 +217,13 @@ __device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *
     }
 }
 
-__global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
+__global__ __launch_bounds__(PF_NT) void k_pyr_fast(PyrFastArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const OrbxLevelGeom &g = a.g;
-    const int grp = blockIdx.x, crow = blockIdx.y, f = blockIdx.z;
+    int f, tileId;
+    if (!xcd_decode(a.nframes, g.nTiles, f, tileId)) return;
+    const int crow = tileId / g.nGroups, grp = tileId - crow * g.nGroups;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // interior (corner-capable) pixel ranges of this tile
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
         const int nV = (lx1 - ax0 + 15) >> 4;
         const float invNV = 1.0f / (float)nV;
         const int n = nRowsL * nV;
-        for (int it = tid; it < n; it += 256) {
+        for (int it = tid; it < n; it += PF_NT) {
             const int r = (int)(((float)it + 0.5f) * invNV);
             const int c = it - r * nV;
             const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
@@ -252,14 +273,14 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
         }
     } else if (a.srcAlign == 4) {
         const int nDw = (lx1 - ax0 + 3) >> 2;
-        for (int r = wave; r < nRowsL; r += 4) {
+        for (int r = wave; r < nRowsL; r += PF_NW) {
             const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0);
             uint32_t *trow = (uint32_t *)(tile + r * tp + PF_XO);
             for (int c = lane; c < nDw; c += 64) trow[c] = srow[c];
         }
     } else {
         const int nB = lx1 - ax0;
-        for (int r = wave; r < nRowsL; r += 4) {
+        for (int r = wave; r < nRowsL; r += PF_NW) {
             const uint8_t *srow = srcF + (size_t)(ly0 + r) * a.srcPitch + ax0;
             uint8_t *trow = tile + r * tp + PF_XO;
             for (int c = lane; c < nB; c += 64) trow[c] = srow[c];
@@ -270,14 +291,14 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
         uint4 z = make_uint4(0, 0, 0, 0);
         uint4 *zs = (uint4 *)score;
         const int nz = ((g.hCell + 2) * tp) >> 4;
-        for (int i = tid; i < nz; i += 256) zs[i] = z;
+        for (int i = tid; i < nz; i += PF_NT) zs[i] = z;
         uint32_t *zb = bitsAll;
         const int nb = 2 * g.groupCells * cellWords;
-        for (int i = tid; i < nb; i += 256) zb[i] = 0;
+        for (int i = tid; i < nb; i += PF_NT) zb[i] = 0;
     }
     if (tid == 0) qCount = 0;
     // per interior column: cell index | bit7 first column of its cell | bit6 last column
-    for (int x = tid; x < TWi; x += 256) {
+    for (int x = tid; x < TWi; x += PF_NT) {
         int cell = x / g.wCell, cx = x - cell * g.wCell;
         int cw = min(g.wCell, TWi - cell * g.wCell);
         colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
@@ -288,11 +309,11 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
     if (doResize) {
         dy0 = a.tabs.rowBeg[crow]; dy1 = a.tabs.rowBeg[crow + 1];
         dx0 = a.tabs.colBeg[grp]; dx1 = a.tabs.colBeg[grp + 1];
-        for (int i = tid; i < dx1 - dx0; i += 256) {
+        for (int i = tid; i < dx1 - dx0; i += PF_NT) {
             const int sx0 = a.tabs.xofs[dx0 + i];
             xt[i] = make_int2((sx0 + colOf0) | ((min(sx0 + 1, g.w - 1) + colOf0) << 16), a.tabs.xab[dx0 + i]);
         }
-        for (int i = tid; i < dy1 - dy0; i += 256) {
+        for (int i = tid; i < dy1 - dy0; i += PF_NT) {
             const int sy = a.tabs.yofs[dy0 + i];
             const int sy0 = min(max(sy, 0), g.h - 1) - ly0, sy1 = min(max(sy + 1, 0), g.h - 1) - ly0;
             yt[i] = make_int2(sy0 | (sy1 << 16), a.tabs.yab[dy0 + i]);
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
                 wb[j] = e.y >> 16;
             }
             const bool full = ok[0] && ok[3];
-            for (int dy = dy0 + wave; dy < dy1; dy += 4) {
+            for (int dy = dy0 + wave; dy < dy1; dy += PF_NW) {
                 const int2 ye = yt[dy - dy0];
                 const int b0 = (short)(ye.y & 0xFFFF), b1 = ye.y >> 16;
                 const uint8_t *r0 = tile + (ye.x & 0xFFFF) * tp;
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
     const int nItemsPad = nItems;
     const int rowOff = ty0 - ly0;
     if (a.phases & 2)
-    for (int it = tid; it < nItemsPad; it += 256) {
+    for (int it = tid; it < nItemsPad; it += PF_NT) {
         unsigned m = 0;
         int r = 0, cbase = 0;
         if (it < nItems) {
@@ -372,7 +393,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
             m &= (0xFFu >> (8 - hi)) & (0xFFu << lo);  // interior pixels only
             cmask[r * nsPitch + s] = (uint8_t)m;
         }
-        if (m) {
+        if (m && !(a.phases & 32)) {
             unsigned pos = atomicAdd(&qCount, (unsigned)__popc(m));  // queue order is irrelevant (bitmaps order the output)
             while (m) {
                 const int i = __ffs(m) - 1;
@@ -386,19 +407,20 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
     const unsigned qn = qCount;
     if (qn <= PF_QCAP) {
         // dense: one queue entry per lane — score, then cell-local 3x3 NMS into the per-cell row bitmaps
-        for (unsigned i = tid; i < qn; i += 256) {
+        if (!(a.phases & 16))
+        for (unsigned i = tid; i < qn; i += PF_NT) {
             const unsigned e = queue[i];
             pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, minEff);
         }
         __syncthreads();
         if (a.phases & 4)
-        for (unsigned i = tid; i < qn; i += 256) {
+        for (unsigned i = tid; i < qn; i += PF_NT) {
             const unsigned e = queue[i];
             pf_nms_one(score, colInfo, bitsAll, bitsIni, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc, iniEff);
         }
     } else {
         // queue overflow (pathological corner density): per-strip loops over the ring-test masks
-        for (int it = tid; it < nItems; it += 256) {
+        for (int it = tid; it < nItems; it += PF_NT) {
             const int r = (int)(((float)it + 0.5f) * invNS);
             const int s = s0 + (it - r * NS);
             unsigned m = cmask[r * nsPitch + s];
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
             }
         }
         __syncthreads();
-        for (int it = tid; it < nItems; it += 256) {
+        for (int it = tid; it < nItems; it += PF_NT) {
             const int r = (int)(((float)it + 0.5f) * invNS);
             const int s = s0 + (it - r * NS);
             unsigned m = cmask[r * nsPitch + s];
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
 
     // ---- per-cell counts at both thresholds (wave per cell, lane per row) ------------------------------
     if (!(a.phases & 8)) return;
-    for (int c = wave; c < nCells; c += 4) {
+    for (int c = wave; c < nCells; c += PF_NW) {
         int nA = 0, nI = 0;
         for (int r = lane; r < THi; r += 64)
             for (int k = 0; k < wpc; ++k) {
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(256) void k_pyr_fast(PyrFastArgs a)
     // ---- ordered emission: cells in order, raster inside a cell (== tileCalcKeypoints emission order) ----
     uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + g.candBase +
                      (size_t)(crow * g.nGroups + grp) * g.slotCap;
-    for (int c = wave; c < nCells; c += 4) {
+    for (int c = wave; c < nCells; c += PF_NW) {
         const uint32_t *bits = (cntIni[c] > 0 ? bitsIni : bitsAll) + (size_t)c * cellWords;
         int base = cellOff[c];
         const int cellC0 = cInt0 + c * g.wCell;
@@ -494,14 +516,15 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
     a.cand = cand; a.candFrameStride = candFrameStride;
     a.tileCount = tileCount; a.tilesPerFrame = tilesPerFrame;
     a.iniTh = iniTh; a.minTh = minTh;
+    a.nframes = nframes;
     {
         static int phases = -1;
         if (phases < 0) { const char *e = getenv("ORBX_PF_PHASES"); phases = e ? atoi(e) : 15; }
         a.phases = phases;
     }
     if (g.groupCells > PF_MAX_GROUP_CELLS) return hipErrorInvalidValue;
-    dim3 grid(g.nGroups, g.ncy, nframes);
-    hipLaunchKernelGGL(k_pyr_fast, grid, dim3(256), g.ldsBytes, st, a);
+    dim3 grid(xcd_grid(nframes, g.nTiles));
+    hipLaunchKernelGGL(k_pyr_fast, grid, dim3(PF_NT), g.ldsBytes, st, a);
     return hipGetLastError();
 }
 
@@ -523,13 +546,16 @@ struct BlurArgs {
     uint8_t *dst; int dstPitch; long long dstFrameStride;
     int w, h;
     int taps[7];
+    int nframes, tilesX, tilesY;
 };
 
 __global__ __launch_bounds__(256) void k_blur(BlurArgs a)
 {
     __shared__ uint8_t in[BL_TH + 6][BL_TW + 8];
     __shared__ uint16_t hs[BL_TH + 6][BL_TW];
-    const int x0 = blockIdx.x * BL_TW, y0 = blockIdx.y * BL_TH, f = blockIdx.z;
+    int f, tileIdx;
+    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, tileIdx)) return;
+    const int x0 = (tileIdx % a.tilesX) * BL_TW, y0 = (tileIdx / a.tilesX) * BL_TH;
     const int tid = threadIdx.x;
     const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
     for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
@@ -574,7 +600,9 @@ __device__ __forceinline__ uint32_t bl_alignbyte(uint32_t hi, uint32_t lo, int s
 __global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
 {
     __shared__ uint2 T[BL2_TH + 6][BL2_GW];
-    const int x0 = blockIdx.x * (BL2_GW * 4), y0 = blockIdx.y * BL2_TH, f = blockIdx.z;
+    int f, tileIdx;
+    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, tileIdx)) return;
+    const int x0 = (tileIdx % a.tilesX) * (BL2_GW * 4), y0 = (tileIdx / a.tilesX) * BL2_TH;
     const int tid = threadIdx.x;
     const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
     const uint32_t k0 = a.taps[0], k1 = a.taps[1], k2 = a.taps[2], k3 = a.taps[3];
@@ -657,11 +685,11 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
     const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride | (uintptr_t)dst | (uintptr_t)dstPitch |
                            (uintptr_t)dstFrameStride;
     if (symmetric && small && (bits & 3) == 0) {
-        dim3 grid((w + BL2_GW * 4 - 1) / (BL2_GW * 4), (h + BL2_TH - 1) / BL2_TH, nframes);
-        hipLaunchKernelGGL(k_blur2, grid, dim3(256), 0, st, a);
+        a.nframes = nframes; a.tilesX = (w + BL2_GW * 4 - 1) / (BL2_GW * 4); a.tilesY = (h + BL2_TH - 1) / BL2_TH;
+        hipLaunchKernelGGL(k_blur2, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
     } else {
-        dim3 grid((w + BL_TW - 1) / BL_TW, (h + BL_TH - 1) / BL_TH, nframes);
-        hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, st, a);
+        a.nframes = nframes; a.tilesX = (w + BL_TW - 1) / BL_TW; a.tilesY = (h + BL_TH - 1) / BL_TH;
+        hipLaunchKernelGGL(k_blur, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
     }
     return hipGetLastError();
 }
@@ -692,7 +720,7 @@ struct QtArgs {
     uint32_t *scratchA, *scratchB;  // [nframes][candFrameStride] spill space for levels with > QT_LDS_KEYS candidates
     uint32_t *sel; int selFrameStride;
     int *selCount;
-    int nlevels;
+    int nlevels, nframes;
     int pool;  // node pool size P
 };
 
@@ -807,7 +835,9 @@ __device__ void qt_divide(QtState &S, int node)
 __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
-    const int level = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    int f, level;
+    if (!xcd_decode(a.nframes, a.nlevels, f, level)) return;
+    const int lane = threadIdx.x;
     const OrbxLevelGeom g = a.geoms[level];
     const int P = a.pool;
     QtState S;
@@ -954,7 +984,7 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     a.tileCount = tileCount; a.tilesPerFrame = tilesPerFrame;
     a.scratchA = scratchA; a.scratchB = scratchB;
     a.sel = sel; a.selFrameStride = selFrameStride; a.selCount = selCount;
-    a.nlevels = nlevels;
+    a.nlevels = nlevels; a.nframes = nframes;
     a.pool = maxQuota + 24;
     size_t lds = qtLdsBytes(a.pool);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -963,8 +993,7 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
         (void)hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
     }
-    dim3 grid(nlevels, nframes);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(64), lds, st, a);
+    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(nframes, nlevels)), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 
@@ -1067,6 +1096,18 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 #define OD_KPW 32  // keypoints per wave
+#define OD_PROWS 37    // blurred patch rows staged per keypoint (sample reach is +-18)
+#define OD_PPITCH 64   // 4 x 16-byte chunks per row: covers [x - 18 - 15, x + 18] for any alignment
+
+// Waves of one workgroup use disjoint LDS slices here, so ordering only has to hold inside a wave: wait for this
+// wave's own LDS traffic and stop the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void __syncthreads_lds_wave()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // sum over the 64 lanes: 4 DPP steps give every lane its 16-lane row total, the 4 row totals are added as scalars
 __device__ __forceinline__ int wave_sum_i32(int x)
@@ -1086,11 +1127,13 @@ __device__ __forceinline__ int wave_sum_i32(int x)
 //   pass 3  per keypoint, wave-cooperative: 256 steered-BRIEF tests, 64 per ballot
 __global__ __launch_bounds__(256) void k_orient_desc(OrbxTables tb, OrbxLevelPtrs lv, const uint32_t *workKey,
                                                      const int *workPos, const int *nOut, OrbxKp *kps, uint8_t *desc,
-                                                     int cap)
+                                                     int cap, int nframes, int chunks)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int f, chunk;
+    if (!xcd_decode(nframes, chunks, f, chunk)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = nOut[f];
-    const int base = (blockIdx.x * 4 + wave) * OD_KPW;
+    const int base = (chunk * 4 + wave) * OD_KPW;
     if (base >= n) return;
     const int cnt = min(OD_KPW, n - base);
     uint32_t myKey = 0;
@@ -1151,6 +1194,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbxTables tb, OrbxLevelPtr
     if (lane < cnt) kps[(size_t)f * cap + myPos].angle = angle;
 
     // ---- pass 3: descriptors --------------------------------------------------------------------------------
+    // The 512 sample points of a keypoint lie within +-18 px of it.  Instead of 8 wave-wide 64-way divergent byte
+    // gathers from global memory (texture-address bound), the 37 x 37 blurred patch is staged into this wave's LDS
+    // slice with coalesced 16-byte-per-lane loads (37 rows x 4 chunks = 148 loads = 3 wave instructions) and the
+    // samples are gathered from LDS.
+    __shared__ __attribute__((aligned(16))) uint8_t patchLds[4][OD_PROWS * OD_PPITCH];
+    uint8_t *patch = patchLds[wave];
     for (int k = 0; k < cnt; ++k) {
         const uint32_t key = __builtin_amdgcn_readlane(myKey, k);
         const int pos = __builtin_amdgcn_readlane(myPos, k);
@@ -1158,7 +1207,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbxTables tb, OrbxLevelPtr
         const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myB), k));
         const int l = key >> 24, xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
         const int bp = lv.blurPitch[l];
-        const uint8_t *bc = lv.blur[l] + (size_t)f * lv.blurFrameStride[l] + (size_t)yl * bp + xl;
+        const uint8_t *bimg = lv.blur[l] + (size_t)f * lv.blurFrameStride[l];
+        const int cx0 = (xl - 18) & ~15;                 // 16-byte aligned first column of the staged patch
+        const uint8_t *src = bimg + (size_t)(yl - 18) * bp + cx0;
+        __syncthreads_lds_wave();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < OD_PROWS * 4) {
+                const int r = idx >> 2, c = idx & 3;
+                *(uint4 *)(patch + r * OD_PPITCH + c * 16) = *(const uint4 *)(src + (size_t)r * bp + c * 16);
+            }
+        }
+        __syncthreads_lds_wave();
+        const uint8_t *bc = patch + 18 * OD_PPITCH + (xl - cx0);
         int t0[4], t1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1166,8 +1228,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbxTables tb, OrbxLevelPtr
             const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
             const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
             const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
-            t0[r] = bc[iy0 * bp + ix0];
-            t1[r] = bc[iy1 * bp + ix1];
+            t0[r] = bc[iy0 * OD_PPITCH + ix0];
+            t1[r] = bc[iy1 * OD_PPITCH + ix1];
         }
         unsigned long long word = 0;
 #pragma unroll
@@ -1190,7 +1252,8 @@ hipError_t orbxLaunchOrientDesc(hipStream_t st, int nframes, OrbxTables tabs, Or
         if (e != hipSuccess) return e;
         patternLoaded[dev] = true;
     }
-    dim3 grid((cap + 4 * OD_KPW - 1) / (4 * OD_KPW), nframes);
-    hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, st, tabs, lv, workKey, workPos, nOut, (OrbxKp *)kps, desc, cap);
+    const int chunks = (cap + 4 * OD_KPW - 1) / (4 * OD_KPW);
+    hipLaunchKernelGGL(k_orient_desc, dim3(xcd_grid(nframes, chunks)), dim3(256), 0, st, tabs, lv, workKey, workPos, nOut, (OrbxKp *)kps, desc, cap,
+                       nframes, chunks);
     return hipGetLastError();
 }
