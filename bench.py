@@ -53,7 +53,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (default: the metric's 1024)")
     ap.add_argument("--gather", action="store_true", help="all-gather result records over RCCL inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=384, help="frames in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=768, help="frames in the CPU-baseline sample")
+    ap.add_argument("--pcie", action="store_true", help="also time the host-pointer API (H2D + D2H included); reported separately")
     args = ap.parse_args()
 
     import torch
@@ -87,17 +88,24 @@ def main() -> None:
     d_kps, d_desc, d_n, d_mono = ex.device_outputs()
     cap = ex.capacity
 
+    class _DevView:  # zero-copy torch view of a liborbx device buffer (for the RCCL gather)
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
     gather_bufs = None
     if args.gather and world > 1:
-        rec_bytes = B * cap * (28 + 32)
-        local = torch.empty(rec_bytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        gather_bufs = (local, torch.empty(world * rec_bytes, dtype=torch.uint8, device=f"cuda:{local_rank}"))
+        views = [torch.as_tensor(_DevView(d_kps, B * cap * 28), device=f"cuda:{local_rank}"),
+                 torch.as_tensor(_DevView(d_desc, B * cap * 32), device=f"cuda:{local_rank}"),
+                 torch.as_tensor(_DevView(d_n, B * 4), device=f"cuda:{local_rank}"),
+                 torch.as_tensor(_DevView(d_mono, B * 4), device=f"cuda:{local_rank}")]
+        gather_bufs = [(v, torch.empty(world * v.numel(), dtype=torch.uint8, device=f"cuda:{local_rank}")) for v in views]
 
     def step():
         ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, (0, 1000))
         if gather_bufs is not None:
-            ex.sync()
-            dist.all_gather_into_tensor(gather_bufs[1], gather_bufs[0])
+            ex.sync()  # results of this rank are complete; gather the fixed-capacity records over RCCL / xGMI
+            for local, full in gather_bufs:
+                dist.all_gather_into_tensor(full, local)
 
     def fence():
         if world > 1:
@@ -123,11 +131,29 @@ def main() -> None:
     n, mono, _, _ = ex.download_outputs(B)
     total_kps = int(n.sum())
 
+    pcie_fps = None
+    if args.pcie and rank == 0:
+        ex.extract_batch(host, (0, 1000))
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ex.extract_batch(host, (0, 1000))
+        pcie_fps = 3 * B / (time.perf_counter() - t1)
+
     if rank == 0:
         frames_total = world * B * args.steps
         fps = frames_total / dt
         pyr_ms = float(stage_ms[0])
         achieved = ALGO_BYTES_PYR_FAST_PER_FRAME * B / (pyr_ms * 1e-3) / 1e9 if pyr_ms > 0 else 0.0
+        # HBM bytes of the same launch set from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE and
+        # WRITE_SIZE in separate rocprofv3 runs; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        if os.path.exists(tpath) and B == BATCH:
+            try:
+                t = json.load(open(tpath))["k_pyr_fast"]
+                traffic = int(2 * t["FETCH_SIZE_bytes_per_batch"] + t["WRITE_SIZE_bytes_per_batch"])
+            except Exception:
+                traffic = None
         out = {
             "metric": "ORB extract throughput (640x480, 1000 feat, 8 levels)",
             "value": round(fps, 1),
@@ -148,10 +174,12 @@ def main() -> None:
             "stages_ms": {name: round(float(ms), 4) for name, ms in zip(pkg.STAGE_NAMES, stage_ms)},
             "roofline": {"bound": "hbm", "kernel": "k_pyr_fast (8 per-level launches = one pyramid+FAST pass)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch_set": ALGO_BYTES_PYR_FAST_PER_FRAME * B,
                          "avg_duration_ms": round(pyr_ms, 4), "batches_timed": int(nb)},
         }
+        if pcie_fps is not None:
+            out["pcie_inclusive_frames_per_s"] = round(pcie_fps, 1)
         if not args.no_cpu_baseline:
             orc = graft.load_oracle()
             threads = min(os.cpu_count() or 1, 16)
