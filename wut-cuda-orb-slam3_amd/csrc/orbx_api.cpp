@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -535,7 +536,8 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     // latency-bound quadtree + pack on the main stream; joined before orientation + descriptors
     HIP_TRY(hipEventRecord(ex->evFork, st));
     HIP_TRY(hipStreamWaitEvent(ex->stream2, ex->evFork, 0));
-    for (int l = 0; l < nl; ++l) {
+    static const bool noBlur = getenv("ORBX_NO_BLUR") != nullptr;  // timing experiments only
+    for (int l = 0; l < nl && !noBlur; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
         const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
         const int srcPitch = l == 0 ? (int)stride : g.pitch;

@@ -60,9 +60,25 @@ __device__ __forceinline__ unsigned ring_run9(unsigned m)
     return r;
 }
 
+// 3-input min / max (v_min3_i32 / v_max3_i32: one half-rate op instead of two; the compiler does not form them
+// from nested min()/max() here)
+__device__ __forceinline__ int min3i(int a, int b, int c)
+{
+    int r;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int max3i(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // FAST corner score (cornerScore<16>: largest threshold for which the pixel is still a corner = max over the
 // 16 arcs of 9 of the minimum one-sided difference, minus 1).  `c` points at the centre pixel inside an LDS tile
 // with row pitch `tp`.  Only called for pixels that passed the ring test (sparse), so byte reads are fine here.
+// min over 9 consecutive = min3 of three min3's: 16 + 16 ops per polarity, then a max3 tree.
 __device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp)
 {
     const int v = c[0];
@@ -74,17 +90,23 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp)
     int mn3[16], mx3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        mn3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
-        mx3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
+        mn3[k] = min3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        mx3[k] = max3i(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
     }
-    int a = -256, b = 256;
+    int m9[16], M9[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        int m9 = min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
-        int M9 = max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
-        a = max(a, m9);
-        b = min(b, M9);
+        m9[k] = min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+        M9[k] = max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
     }
+    int a5[5], b5[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        a5[k] = max3i(m9[3 * k], m9[3 * k + 1], m9[3 * k + 2]);
+        b5[k] = min3i(M9[3 * k], M9[3 * k + 1], M9[3 * k + 2]);
+    }
+    const int a = max3i(max3i(a5[0], a5[1], a5[2]), max3i(a5[3], a5[4], m9[15]), -256);
+    const int b = min3i(min3i(b5[0], b5[1], b5[2]), min3i(b5[3], b5[4], M9[15]), 256);
     return max(a, -b) - 1;
 }
 
@@ -721,6 +743,7 @@ struct QtArgs {
     uint32_t *sel; int selFrameStride;
     int *selCount;
     int nlevels, nframes;
+    int stop;  // debug (ORBX_QT_STOP): 1 return after the gather, 2 after the roots, 3 skip the inner (sorted) loop, 4 skip the sort only
     int pool;  // node pool size P
 };
 
@@ -872,6 +895,7 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
         }
     }
     __syncthreads();
+    if (a.stop == 1) { if (lane == 0) *selCnt = 0; return; }
 
     // ---- roots (:589-626) -----------------------------------------------------------------------------
     const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
@@ -916,6 +940,7 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
     }
     __syncthreads();
 
+    if (a.stop == 2) { if (lane == 0) *selCnt = 0; return; }
     // ---- subdivision (:630-752) -----------------------------------------------------------------------
     bool finish = false;
     while (!finish) {
@@ -930,13 +955,14 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
         if (S.size >= N || S.size == prevSize) {
             finish = true;
         } else if (S.size + S.nToExpand * 3 > N) {
+            if (a.stop == 3) break;
             while (!finish) {
                 const int prevSize2 = S.size;
                 const int nPrev = S.nSized;
                 for (int i = lane; i < nPrev; i += WAVE) prevArr[i] = S.sized[i];
                 S.nSized = 0;
                 __syncthreads();
-                if (lane == 0) orbx_sort::sort(prevArr, nPrev, QtSizedLess());
+                if (lane == 0 && a.stop != 4) orbx_sort::sort(prevArr, nPrev, QtSizedLess());
                 __syncthreads();
                 for (int j = nPrev - 1; j >= 0; --j) {
                     qt_divide(S, prevArr[j].id);
@@ -985,6 +1011,7 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     a.scratchA = scratchA; a.scratchB = scratchB;
     a.sel = sel; a.selFrameStride = selFrameStride; a.selCount = selCount;
     a.nlevels = nlevels; a.nframes = nframes;
+    { static int stop = -1; if (stop < 0) { const char *e = getenv("ORBX_QT_STOP"); stop = e ? atoi(e) : 0; } a.stop = stop; }
     a.pool = maxQuota + 24;
     size_t lds = qtLdsBytes(a.pool);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -1154,29 +1181,61 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbxTables tb, OrbxLevelPtr
     }
 
     // ---- pass 1: moments ------------------------------------------------------------------------------------
+    // Lane k first resolves the level tables of keypoint k (raw / blurred patch pointers, pitches), so the
+    // per-keypoint loops below only broadcast registers (v_readlane) and never wait on a dependent table load.
+    unsigned long long myRaw = 0, myBlur = 0;
+    int myRp = 0, myBp = 0;
+    if (lane < cnt) {
+        const int l = myKey >> 24, xl = myKey & 0xFFF, yl = (myKey >> 12) & 0xFFF;
+        myRp = lv.rawPitch[l];
+        myBp = lv.blurPitch[l];
+        myRaw = (unsigned long long)(lv.raw[l] + (size_t)f * lv.rawFrameStride[l] + (size_t)yl * myRp + xl);
+        const int cx0 = (xl - 18) & ~15;  // 16-byte aligned first column of the staged blurred patch
+        myBlur = (unsigned long long)(lv.blur[l] + (size_t)f * lv.blurFrameStride[l] + (size_t)(yl - 18) * myBp + cx0);
+    }
     const int u = (lane & 31) - 15;
     const int au = u < 0 ? -u : u;
+    // this lane's 16 (row, column) patch samples: row v = 2 * it + (lane >> 5) - 15, column u; a sample outside the
+    // circular patch (|u| > umax[|v|], or the 32nd row / column) gets weight 0 — loads stay unconditional (every
+    // address is inside the image: keypoints keep a 19-px margin) and the loop is branch-free
+    int wu[16], wv[16], vrow[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int v = it * 2 + (lane >> 5) - 15;
+        const int av = v < 0 ? -v : v;
+        const int um = (int)((tb.umaxPacked >> (4 * (av & 15))) & 15);
+        const bool in = v <= 15 && au <= um;
+        wu[it] = in ? u : 0;
+        wv[it] = in ? v : 0;
+        vrow[it] = v;
+    }
+    typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
     int myM01 = 0, myM10 = 0;
-    for (int k = 0; k < cnt; ++k) {
-        const uint32_t key = __builtin_amdgcn_readlane(myKey, k);
-        const int l = key >> 24, xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
-        const int rp = lv.rawPitch[l];
-        const uint8_t *center = lv.raw[l] + (size_t)f * lv.rawFrameStride[l] + (size_t)yl * rp + xl;
-        int m10 = 0, m01 = 0;
+    // two keypoints per iteration: 32 independent byte loads in flight per lane before the first reduction
+    for (int k = 0; k < cnt; k += 2) {
+        const bool two = k + 1 < cnt;
+        const int k1 = two ? k + 1 : k;
+        const gptr_t c0 = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myRaw >> 32), k) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)myRaw, k));
+        const gptr_t c1 = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myRaw >> 32), k1) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)myRaw, k1));
+        const int rp0 = __builtin_amdgcn_readlane(myRp, k), rp1 = __builtin_amdgcn_readlane(myRp, k1);
+        int I0[16], I1[16];
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const int v = it * 2 + (lane >> 5) - 15;
-            const int av = v < 0 ? -v : v;
-            const int um = (int)((tb.umaxPacked >> (4 * (av & 15))) & 15);
-            if (v <= 15 && au <= um) {
-                const int I = center[v * rp + u];
-                m10 += u * I;
-                m01 += v * I;
-            }
+            I0[it] = c0[vrow[it] * rp0 + u];
+            I1[it] = c1[vrow[it] * rp1 + u];
         }
-        m10 = wave_sum_i32(m10);
-        m01 = wave_sum_i32(m01);
-        if (lane == k) { myM10 = m10; myM01 = m01; }
+        int a10 = 0, a01 = 0, b10 = 0, b01 = 0;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            a10 += wu[it] * I0[it]; a01 += wv[it] * I0[it];
+            b10 += wu[it] * I1[it]; b01 += wv[it] * I1[it];
+        }
+        a10 = wave_sum_i32(a10); a01 = wave_sum_i32(a01);
+        b10 = wave_sum_i32(b10); b01 = wave_sum_i32(b01);
+        if (lane == k) { myM10 = a10; myM01 = a01; }
+        if (two && lane == k1) { myM10 = b10; myM01 = b01; }
     }
 
     // ---- pass 2: orientation + rotation, one keypoint per lane ---------------------------------------------------
@@ -1200,25 +1259,35 @@ __global__ __launch_bounds__(256) void k_orient_desc(OrbxTables tb, OrbxLevelPtr
     // samples are gathered from LDS.
     __shared__ __attribute__((aligned(16))) uint8_t patchLds[4][OD_PROWS * OD_PPITCH];
     uint8_t *patch = patchLds[wave];
+    // staging loads of keypoint k + 1 are issued before the samples of keypoint k are consumed
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 nxt[3];
+    auto issue = [&](int kk) {
+        typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
+        const gptr_t src = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myBlur >> 32), kk) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)myBlur, kk));
+        const int bp = __builtin_amdgcn_readlane(myBp, kk);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < OD_PROWS * 4) nxt[i] = *(const __attribute__((address_space(1))) u32x4 *)(src + (idx >> 2) * bp + (idx & 3) * 16);
+        }
+    };
+    issue(0);
     for (int k = 0; k < cnt; ++k) {
         const uint32_t key = __builtin_amdgcn_readlane(myKey, k);
         const int pos = __builtin_amdgcn_readlane(myPos, k);
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myA), k));
         const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myB), k));
-        const int l = key >> 24, xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
-        const int bp = lv.blurPitch[l];
-        const uint8_t *bimg = lv.blur[l] + (size_t)f * lv.blurFrameStride[l];
-        const int cx0 = (xl - 18) & ~15;                 // 16-byte aligned first column of the staged patch
-        const uint8_t *src = bimg + (size_t)(yl - 18) * bp + cx0;
+        const int xl = key & 0xFFF;
+        const int cx0 = (xl - 18) & ~15;
         __syncthreads_lds_wave();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int idx = lane + 64 * i;
-            if (idx < OD_PROWS * 4) {
-                const int r = idx >> 2, c = idx & 3;
-                *(uint4 *)(patch + r * OD_PPITCH + c * 16) = *(const uint4 *)(src + (size_t)r * bp + c * 16);
-            }
+            if (idx < OD_PROWS * 4) *(u32x4 *)(patch + (idx >> 2) * OD_PPITCH + (idx & 3) * 16) = nxt[i];
         }
+        if (k + 1 < cnt) issue(k + 1);
         __syncthreads_lds_wave();
         const uint8_t *bc = patch + 18 * OD_PPITCH + (xl - cx0);
         int t0[4], t1[4];
