@@ -139,9 +139,10 @@ void *orbx_stream(orbx_extractor *ex);
  * orb::benchmark MEASURE_* wrappers around the same stages, include/orb/Benchmark.h:83-92; reference
  * src/ORBextractor.cc:969,998,1238,1241,1273,1278).  When enabled, every batch records events around each
  * stage; orbx_get_stage_times() synchronises the stream and returns the mean milliseconds per batch of the
- * batches recorded since the last call (at most the 32 most recent), then resets.  Stage order:
- * 0 = fused pyramid+FAST (all per-level launches), 1 = quadtree (the GaussianBlur launches run concurrently on a
- * second stream and are joined before stage 4), 2 = (empty marker), 3 = pack + wait for the blur stream,
+ * batches recorded since the last call (at most the 32 most recent), then resets.  A batch is software-pipelined
+ * in sub-batches over three streams, so stage times are sums over the sub-batches, measured on the stream the
+ * stage runs on, and they overlap in time (they do not add up to the batch time).  Stage order:
+ * 0 = fused pyramid+FAST (all per-level launches), 1 = quadtree, 2 = GaussianBlur (all levels), 3 = pack,
  * 4 = orientation+descriptor.  Returns the number of batches averaged (0 if none). */
 #define ORBX_NUM_STAGES 5
 int orbx_set_profiling(orbx_extractor *ex, int enable);

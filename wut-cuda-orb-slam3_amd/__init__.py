@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times",
 ]
-STAGE_NAMES = ["pyramid+FAST", "quadtree||blur", "-", "pack+join", "orient+desc"]
+STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
 _lib = None
 

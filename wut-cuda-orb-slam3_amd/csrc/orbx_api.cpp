@@ -73,8 +73,10 @@ struct orbx_extractor {
     int maxKeypoints = 0, maxQuota = 0;
     int taps[7];
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // GaussianBlur runs here, concurrently with the quadtree on `stream`
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t stream2 = nullptr;          // blur stream
+    hipStream_t stream3 = nullptr;          // back stream: quadtree -> pack -> orientation + descriptors
+    hipEvent_t evJoin = nullptr;
+    hipEvent_t evFront[8] = {}, evBlur[8] = {};  // per sub-batch hand-offs between the streams
 
     // geometry of the current image size
     int curW = 0, curH = 0;
@@ -96,7 +98,8 @@ struct orbx_extractor {
 
     // stage profiling: ring of event sets recorded on `stream`
     bool profiling = false;
-    std::vector<hipEvent_t> events;  // [PROF_RING][ORBX_NUM_STAGES + 1]
+    std::vector<hipEvent_t> events;  // [PROF_RING][sub-batch][stage][begin, end]
+    std::vector<int> profSubs;       // sub-batches recorded in each ring slot
     int profCount = 0;
 
     // level-0 source of the last batch (for orbx_get_pyramid_level)
@@ -191,8 +194,12 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
 
     hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evFork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->stream3, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evJoin, hipEventDisableTiming);
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&ex->evFront[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBlur[i], hipEventDisableTiming);
+    }
     if (e != hipSuccess) { orbx_destroy(ex); return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ex->d_raw.resize(nl); ex->d_blur.resize(nl);
     int rc = computeGeometry(ex, p->max_width, p->max_height);
@@ -206,10 +213,14 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
 {
     if (!ex) return;
     (void)hipSetDevice(ex->prm.device);
+    if (ex->stream3) { (void)hipStreamSynchronize(ex->stream3); (void)hipStreamDestroy(ex->stream3); }
     if (ex->stream2) { (void)hipStreamSynchronize(ex->stream2); (void)hipStreamDestroy(ex->stream2); }
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
-    if (ex->evFork) (void)hipEventDestroy(ex->evFork);
     if (ex->evJoin) (void)hipEventDestroy(ex->evJoin);
+    for (int i = 0; i < 8; ++i) {
+        if (ex->evFront[i]) (void)hipEventDestroy(ex->evFront[i]);
+        if (ex->evBlur[i]) (void)hipEventDestroy(ex->evBlur[i]);
+    }
     for (auto &e : ex->events) (void)hipEventDestroy(e);
     ex->d_in.release();
     for (auto &b : ex->d_raw) b.release();
@@ -278,7 +289,8 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         const int iw = g.w - 2 * ORBX_FAST_MARGIN, ih = g.h - 2 * ORBX_FAST_MARGIN;  // corner-capable interior
         g.ncx = std::min(nCols, (iw + g.wCell - 1) / g.wCell);
         g.ncy = std::min(nRows, (ih + g.hCell - 1) / g.hCell);
-        int gmax = std::max(1, 288 / g.wCell);
+        static const int tileW = [] { const char *e = getenv("ORBX_TILE_W"); return e ? atoi(e) : 288; }();  // target interior width of a tile
+        int gmax = std::max(1, tileW / g.wCell);
         g.nGroups = (g.ncx + gmax - 1) / gmax;
         g.groupCells = (g.ncx + g.nGroups - 1) / g.nGroups;
         g.nGroups = (g.ncx + g.groupCells - 1) / g.groupCells;
@@ -375,9 +387,11 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         OrbxLevelGeom &g = geom[l];
         g.rsMaxDx = (int)roundUp(g.rsMaxDx + 1, 2);
         g.rsMaxDy = (int)roundUp(g.rsMaxDy + 1, 2);
+        // strips cover [8s + 4, 8s + 12): at most (interior width + 7) / 8 + 1 strips per row, 2 groups each
+        g.gqCap = (int)roundUp((size_t)2 * ((g.groupCells * g.wCell + 7) / 8 + 1) * g.hCell, 8);
         size_t lds = (size_t)g.tileRows * g.tilePitch + (size_t)(g.hCell + 2) * g.tilePitch +
-                     roundUp((size_t)g.hCell * (g.tilePitch / 8), 16) + (size_t)2 * g.groupCells * g.hCell * g.wpc * 4 +
-                     (size_t)(g.rsMaxDx + g.rsMaxDy) * 8 + 4096 * 2 + roundUp(g.groupCells * g.wCell, 16);
+                     (size_t)g.groupCells * g.hCell * g.wpc * 4 + 8 + (size_t)(g.rsMaxDx + g.rsMaxDy) * 8 +
+                     (size_t)g.gqCap * 2 + 1024 * 2 + (size_t)g.gqCap + roundUp(g.groupCells * g.wCell, 16);
         g.ldsBytes = (int)roundUp(lds, 16);
         if (g.ldsBytes > 64 * 1024)
             return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
@@ -433,13 +447,16 @@ static int ensureBuffers(orbx_extractor *ex)
 // stage profiling (HIP events on the handle's stream)
 // ---------------------------------------------------------------------------------------------------------
 static const int PROF_RING = 32;
+#define ORBX_MAX_SUB 8
+static const int PROF_EVENTS = ORBX_MAX_SUB * ORBX_NUM_STAGES * 2;  // [sub-batch][stage][begin, end]
 
 extern "C" int orbx_set_profiling(orbx_extractor *ex, int enable)
 {
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_set_profiling: null handle");
     HIP_TRY(hipSetDevice(ex->prm.device));
     if (enable && ex->events.empty()) {
-        ex->events.resize((size_t)PROF_RING * (ORBX_NUM_STAGES + 1));
+        ex->events.resize((size_t)PROF_RING * PROF_EVENTS);
+        ex->profSubs.assign(PROF_RING, 0);
         for (auto &e : ex->events) HIP_TRY(hipEventCreate(&e));
     }
     ex->profiling = enable != 0;
@@ -456,22 +473,18 @@ extern "C" int orbx_get_stage_times(orbx_extractor *ex, float *ms)
     const int nb = std::min(ex->profCount, PROF_RING);
     for (int b = 0; b < nb; ++b) {
         const int slot = (ex->profCount - 1 - b) % PROF_RING;
-        hipEvent_t *ev = &ex->events[(size_t)slot * (ORBX_NUM_STAGES + 1)];
-        for (int s = 0; s < ORBX_NUM_STAGES; ++s) {
-            float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, ev[s], ev[s + 1]));
-            ms[s] += t;
-        }
+        hipEvent_t *ev = &ex->events[(size_t)slot * PROF_EVENTS];
+        for (int sb = 0; sb < ex->profSubs[slot]; ++sb)
+            for (int s = 0; s < ORBX_NUM_STAGES; ++s) {
+                float t = 0.f;
+                HIP_TRY(hipEventElapsedTime(&t, ev[(sb * ORBX_NUM_STAGES + s) * 2], ev[(sb * ORBX_NUM_STAGES + s) * 2 + 1]));
+                ms[s] += t;
+            }
     }
     for (int s = 0; s < ORBX_NUM_STAGES && nb > 0; ++s) ms[s] /= (float)nb;
     ex->profCount = 0;
     return nb;
 }
-
-#define PROF_MARK(i)                                                                                     \
-    do {                                                                                                 \
-        if (prof) HIP_TRY(hipEventRecord(prof[i], st));                                                  \
-    } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // extraction
@@ -493,6 +506,14 @@ static OrbxTables makeTables(const orbx_extractor *ex)
     return t;
 }
 
+// Launch sequence of one batch.  Frames are independent, so the batch can be cut into up to ORBX_MAX_SUB sub-batches
+// (env ORBX_SUBBATCHES; default 1 — measured on MI355X: 1 -> 6.73 ms, 2 -> 6.69 ms, 4 -> 6.94 ms, 8 -> 7.60 ms per
+// 1024-frame batch: the stages are throughput-bound in aggregate, so deeper pipelining only adds contention) and
+// software-pipelined over three streams: the VALU-bound fused pyramid+FAST launches of sub-batch s+1 (front stream)
+// overlap the GaussianBlur (blur stream) and the latency-bound quadtree -> pack -> orientation+descriptor chain (back
+// stream) of sub-batch s.  No buffer is shared between sub-batches (everything is indexed by frame), so no double
+// buffering is needed.  The front stream finally waits for the back stream: orbx_sync() and the next batch order
+// themselves after all work of this batch.
 extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride,
                                          ptrdiff_t frame_stride, int lap0, int lap1)
 {
@@ -505,70 +526,95 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     if (rc != ORBX_OK) return rc;
     if ((rc = ensureBuffers(ex)) != ORBX_OK) return rc;
     const int nl = ex->prm.nlevels;
-    hipStream_t st = ex->stream;
     const uint8_t *src0 = (const uint8_t *)d_imgs;
     ex->lastSrc = src0; ex->lastSrcPitch = (int)stride; ex->lastSrcFrameStride = (long long)frame_stride; ex->lastFrames = nframes;
+    hipStream_t sFront = ex->stream, sBlur = ex->stream2, sBack = ex->stream3;
+    const OrbxTables tb = makeTables(ex);
+    const int cap = ex->maxKeypoints;
 
-    hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * (ORBX_NUM_STAGES + 1)] : nullptr;
-    PROF_MARK(0);
-    // fused pyramid + FAST, one launch per level over all frames
-    for (int l = 0; l < nl; ++l) {
-        const OrbxLevelGeom &g = ex->geom[l];
-        const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
-        const int srcPitch = l == 0 ? (int)stride : g.pitch;
-        const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
-        uint8_t *dst = nullptr; int dw = 0, dh = 0, dPitch = 0; long long dFS = 0;
-        OrbxResizeTabs tabs;
-        memset(&tabs, 0, sizeof tabs);
-        if (l + 1 < nl) {
-            const OrbxLevelGeom &d = ex->geom[l + 1];
-            dst = ex->d_raw[l + 1].p; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;
-            const int *o = &ex->tabOffsets[(size_t)l * 6];
-            tabs.xofs = ex->d_tabs.p + o[0]; tabs.xab = ex->d_tabs.p + o[1]; tabs.yofs = ex->d_tabs.p + o[2];
-            tabs.yab = ex->d_tabs.p + o[3]; tabs.rowBeg = ex->d_tabs.p + o[4]; tabs.colBeg = ex->d_tabs.p + o[5];
+    // sub-batch size: a multiple of 8 frames (one frame per XCD in flight), at least 64 frames
+    static const int maxSub = [] { const char *e = getenv("ORBX_SUBBATCHES"); int v = e ? atoi(e) : 1; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
+    int nsub = std::min(maxSub, std::max(1, nframes / 64));
+    const int subSize = ((nframes + nsub - 1) / nsub + 7) / 8 * 8;
+    nsub = (nframes + subSize - 1) / subSize;
+
+    hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * PROF_EVENTS] : nullptr;
+    for (int sb = 0; sb < nsub; ++sb) {
+        const int f0 = sb * subSize, nf = std::min(subSize, nframes - f0);
+        // ---- front: fused pyramid + FAST, one launch per level -----------------------------------------------
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 0) * 2], sFront));
+        for (int l = 0; l < nl; ++l) {
+            const OrbxLevelGeom &g = ex->geom[l];
+            const uint8_t *src = l == 0 ? src0 + (size_t)f0 * frame_stride : ex->d_raw[l].p + (size_t)f0 * g.frameStride;
+            const int srcPitch = l == 0 ? (int)stride : g.pitch;
+            const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
+            uint8_t *dst = nullptr; int dw = 0, dh = 0, dPitch = 0; long long dFS = 0;
+            OrbxResizeTabs tabs;
+            memset(&tabs, 0, sizeof tabs);
+            if (l + 1 < nl) {
+                const OrbxLevelGeom &d = ex->geom[l + 1];
+                dst = ex->d_raw[l + 1].p + (size_t)f0 * d.frameStride; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;
+                const int *o = &ex->tabOffsets[(size_t)l * 6];
+                tabs.xofs = ex->d_tabs.p + o[0]; tabs.xab = ex->d_tabs.p + o[1]; tabs.yofs = ex->d_tabs.p + o[2];
+                tabs.yab = ex->d_tabs.p + o[3]; tabs.rowBeg = ex->d_tabs.p + o[4]; tabs.colBeg = ex->d_tabs.p + o[5];
+            }
+            HIP_TRY(orbxLaunchPyrFast(sFront, nf, g, src, srcPitch, srcFS, dst, dw, dh, dPitch, dFS, tabs,
+                                      ex->d_cand.p + (size_t)f0 * ex->candFrameStride, ex->candFrameStride,
+                                      ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame, ex->prm.ini_th_fast,
+                                      ex->prm.min_th_fast));
         }
-        HIP_TRY(orbxLaunchPyrFast(st, nframes, g, src, srcPitch, srcFS, dst, dw, dh, dPitch, dFS, tabs, ex->d_cand.p,
-                                  ex->candFrameStride, ex->d_tileCount.p, ex->tilesPerFrame, ex->prm.ini_th_fast,
-                                  ex->prm.min_th_fast));
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 0) * 2 + 1], sFront));
+        HIP_TRY(hipEventRecord(ex->evFront[sb], sFront));
+
+        // ---- blur stream: GaussianBlur of every level (needs only the pyramid) ---------------------------------
+        HIP_TRY(hipStreamWaitEvent(sBlur, ex->evFront[sb], 0));
+        static const bool noBlur = getenv("ORBX_NO_BLUR") != nullptr;  // timing experiments only
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 2) * 2], sBlur));
+        for (int l = 0; l < nl && !noBlur; ++l) {
+            const OrbxLevelGeom &g = ex->geom[l];
+            const uint8_t *src = l == 0 ? src0 + (size_t)f0 * frame_stride : ex->d_raw[l].p + (size_t)f0 * g.frameStride;
+            const int srcPitch = l == 0 ? (int)stride : g.pitch;
+            const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
+            HIP_TRY(orbxLaunchBlur(sBlur, nf, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p + (size_t)f0 * g.frameStride, g.pitch,
+                                   g.frameStride, ex->taps));
+        }
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 2) * 2 + 1], sBlur));
+        HIP_TRY(hipEventRecord(ex->evBlur[sb], sBlur));
+
+        // ---- back stream: quadtree -> pack -> (join blur) -> orientation + descriptors -----------------------------
+        HIP_TRY(hipStreamWaitEvent(sBack, ex->evFront[sb], 0));
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2], sBack));
+        HIP_TRY(orbxLaunchQuadtree(sBack, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
+                                   ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
+                                   ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
+                                   ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
+                                   ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota));
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2 + 1], sBack));
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 3) * 2], sBack));
+        HIP_TRY(orbxLaunchPack(sBack, nf, tb, ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
+                               ex->d_selCount.p + (size_t)f0 * nl, lap0, lap1, ex->d_kps.p + (size_t)f0 * cap, cap,
+                               ex->d_workKey.p + (size_t)f0 * cap, ex->d_workPos.p + (size_t)f0 * cap, ex->d_n.p + f0, ex->d_mono.p + f0));
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 3) * 2 + 1], sBack));
+        HIP_TRY(hipStreamWaitEvent(sBack, ex->evBlur[sb], 0));
+        OrbxLevelPtrs lv;
+        memset(&lv, 0, sizeof lv);
+        for (int l = 0; l < nl; ++l) {
+            const OrbxLevelGeom &g = ex->geom[l];
+            lv.raw[l] = l == 0 ? src0 + (size_t)f0 * frame_stride : ex->d_raw[l].p + (size_t)f0 * g.frameStride;
+            lv.rawPitch[l] = l == 0 ? (int)stride : g.pitch;
+            lv.rawFrameStride[l] = l == 0 ? (long long)frame_stride : g.frameStride;
+            lv.blur[l] = ex->d_blur[l].p + (size_t)f0 * g.frameStride; lv.blurPitch[l] = g.pitch; lv.blurFrameStride[l] = g.frameStride;
+            lv.w[l] = g.w; lv.h[l] = g.h;
+        }
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 4) * 2], sBack));
+        HIP_TRY(orbxLaunchOrientDesc(sBack, nf, tb, lv, ex->d_workKey.p + (size_t)f0 * cap, ex->d_workPos.p + (size_t)f0 * cap,
+                                     ex->d_n.p + f0, ex->d_kps.p + (size_t)f0 * cap, ex->d_desc.p + (size_t)f0 * cap * 32, cap));
+        if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 4) * 2 + 1], sBack));
     }
-    PROF_MARK(1);
-    // fork: GaussianBlur of every level on stream2 (needs only the pyramid), concurrently with the
-    // latency-bound quadtree + pack on the main stream; joined before orientation + descriptors
-    HIP_TRY(hipEventRecord(ex->evFork, st));
-    HIP_TRY(hipStreamWaitEvent(ex->stream2, ex->evFork, 0));
-    static const bool noBlur = getenv("ORBX_NO_BLUR") != nullptr;  // timing experiments only
-    for (int l = 0; l < nl && !noBlur; ++l) {
-        const OrbxLevelGeom &g = ex->geom[l];
-        const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
-        const int srcPitch = l == 0 ? (int)stride : g.pitch;
-        const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
-        HIP_TRY(orbxLaunchBlur(ex->stream2, nframes, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p, g.pitch, g.frameStride, ex->taps));
-    }
-    HIP_TRY(hipEventRecord(ex->evJoin, ex->stream2));
-    HIP_TRY(orbxLaunchQuadtree(st, nframes, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p, ex->candFrameStride,
-                               ex->d_tileCount.p, ex->tilesPerFrame, ex->d_scratchA.p, ex->d_scratchB.p, ex->d_sel.p,
-                               ex->selFrameStride, ex->d_selCount.p, ex->maxQuota));
-    PROF_MARK(2);
-    PROF_MARK(3);
-    OrbxTables tb = makeTables(ex);
-    HIP_TRY(orbxLaunchPack(st, nframes, tb, ex->d_sel.p, ex->selFrameStride, ex->d_selCount.p, lap0, lap1, ex->d_kps.p,
-                           ex->maxKeypoints, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_mono.p));
-    OrbxLevelPtrs lv;
-    memset(&lv, 0, sizeof lv);
-    for (int l = 0; l < nl; ++l) {
-        const OrbxLevelGeom &g = ex->geom[l];
-        lv.raw[l] = l == 0 ? src0 : ex->d_raw[l].p;
-        lv.rawPitch[l] = l == 0 ? (int)stride : g.pitch;
-        lv.rawFrameStride[l] = l == 0 ? (long long)frame_stride : g.frameStride;
-        lv.blur[l] = ex->d_blur[l].p; lv.blurPitch[l] = g.pitch; lv.blurFrameStride[l] = g.frameStride;
-        lv.w[l] = g.w; lv.h[l] = g.h;
-    }
-    HIP_TRY(hipStreamWaitEvent(st, ex->evJoin, 0));
-    PROF_MARK(4);
-    HIP_TRY(orbxLaunchOrientDesc(st, nframes, tb, lv, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_kps.p,
-                                 ex->d_desc.p, ex->maxKeypoints));
-    PROF_MARK(5);
-    if (prof) ++ex->profCount;
+    // join: everything of this batch is ordered before whatever follows on the front stream
+    HIP_TRY(hipEventRecord(ex->evJoin, sBack));
+    HIP_TRY(hipStreamWaitEvent(sFront, ex->evJoin, 0));
+    if (prof) { ex->profSubs[ex->profCount % PROF_RING] = nsub; ++ex->profCount; }
     return ORBX_OK;
 }
 

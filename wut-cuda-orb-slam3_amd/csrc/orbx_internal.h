@@ -36,6 +36,7 @@ struct OrbxLevelGeom {
     int tileRows;          // max rows held in LDS
     int wpc;               // 32-bit words per cell row in the NMS bitmaps
     int rsMaxDx, rsMaxDy;  // max destination columns / rows of the next level produced by one tile
+    int gqCap;             // capacity of the pre-test group queue (2 groups per strip, all strips of the tile)
     int ldsBytes;
 };
 

@@ -19,6 +19,7 @@
 #include "orbx_internal.h"
 #include "libstdcxx_sort.h"
 #include "orbx_pattern.inc"
+#include <cstdio>
 #include <cstdlib>
 
 #define WAVE 64
@@ -181,6 +182,40 @@ __device__ __forceinline__ unsigned fast_strip_mask(const uint32_t (&w)[7][4], i
     return ((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4);
 }
 
+// Cheap necessary condition for the ring test of one 4-pixel group: a contiguous arc of 9 ring pixels contains two
+// adjacent compass points, i.e. (k0 | k8) & (k4 | k12) must hold for one polarity (the first two of OpenCV's
+// opposite-pair checks).  Needs only the rows y-3, y, y+3 of the strip window (w0, w3, w6).  On the benchmark
+// frames 11-22 % of the groups pass at iniThFAST; only those go through the full 16-position test.
+template <int GRP>
+__device__ __forceinline__ uint32_t fast_group_pretest(const uint32_t (&w0)[4], const uint32_t (&w3)[4], const uint32_t (&w6)[4],
+                                                       uint32_t T4, uint32_t C4)
+{
+    const uint32_t V = w3[1 + GRP];
+    const uint32_t Vl = V & SW_L;
+    const uint32_t tS = (V | SW_H) - (T4 & SW_L);
+    const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
+    const uint32_t ltVT = (~V & T4) | (~(V ^ T4) & ~tS);
+    const uint32_t HI = (Vl + (T4 & SW_L)) ^ ((V ^ T4) & SW_H);
+    const uint32_t tC = (C4 | SW_H) - Vl;
+    const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);
+    const uint32_t Kd = SW_H - (LO & SW_L);
+    const uint32_t HIh = HI | SW_H;
+    uint32_t D[4], B[4];
+    const uint32_t P[4] = {w6[1 + GRP], __builtin_amdgcn_alignbyte(w3[2 + GRP], w3[1 + GRP], 3), w0[1 + GRP],
+                           __builtin_amdgcn_alignbyte(w3[1 + GRP], w3[GRP], 1)};  // k = 0, 4, 8, 12
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t Pl = P[j] & SW_L;
+        const uint32_t td = Pl + Kd;
+        const uint32_t tb = HIh - Pl;
+        D[j] = (~P[j] & LO) | (~(P[j] ^ LO) & ~td);
+        B[j] = (~HI & P[j]) | (~(HI ^ P[j]) & ~tb);
+    }
+    const uint32_t d = (D[0] | D[2]) & (D[1] | D[3]);
+    const uint32_t b = (B[0] | B[2]) & (B[1] | B[3]);
+    return ((d & ~ltVT) | (b & ~ltCV)) & SW_H;
+}
+
 __device__ __forceinline__ int wave_excl_scan(int v, int &total)
 {
     const int lane = threadIdx.x & 63;
@@ -207,10 +242,11 @@ struct PyrFastArgs {
 };
 
 #define PF_MAX_GROUP_CELLS 32
-#define PF_NT 256           // threads per workgroup (512 measured no faster: the kernel is VALU-issue bound, not latency bound)
+#define PF_NT 512           // threads per workgroup: 8 waves x 3 workgroups/CU (LDS-limited); with the queue-based two-round
+                            // FAST the kernel is barrier/latency-bound and 512 threads measured 3.79 -> 3.14 ms per batch
 #define PF_NW (PF_NT / 64)
 #define PF_XO 16      // LDS column of image column ax0 (keeps every strip window inside the tile row)
-#define PF_QCAP 4096  // corner queue entries (u16: row << 9 | interior column)
+#define PF_QCAP 1024  // corner queue entries (u16: row << 9 | interior column)
 
 // score + cell-local NMS of one ring-test survivor at tile row r, LDS column c
 __device__ __forceinline__ void pf_score_one(const uint8_t *tile, uint8_t *score, int tp, int rowOff, int r, int c, int minEff)
@@ -218,8 +254,8 @@ __device__ __forceinline__ void pf_score_one(const uint8_t *tile, uint8_t *score
     const int sc = fast_corner_score(tile + (rowOff + r) * tp + c, tp);
     score[(r + 1) * tp + c] = (uint8_t)(sc >= minEff ? sc : 0);
 }
-__device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *colInfo, uint32_t *bitsAll, uint32_t *bitsIni,
-                                           int tp, int r, int c, int cInt0, int wCell, int hCell, int wpc, int iniEff)
+__device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *colInfo, uint32_t *bits, int tp, int r, int c,
+                                           int cInt0, int wCell, int hCell, int wpc)
 {
     const uint8_t *s1p = score + (r + 1) * tp + c, *s0p = s1p - tp, *s2p = s1p + tp;
     const int sc = s1p[0];
@@ -232,9 +268,7 @@ __device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *
         if (sc > mx) {
             const int cell = ci & 0x3F;
             const int cx = xi - cell * wCell;
-            const int wi = (cell * hCell + r) * wpc + (cx >> 5);
-            atomicOr(&bitsAll[wi], 1u << (cx & 31));
-            if (sc >= iniEff) atomicOr(&bitsIni[wi], 1u << (cx & 31));
+            atomicOr(&bits[(cell * hCell + r) * wpc + (cx >> 5)], 1u << (cx & 31));
         }
     }
 }
@@ -267,18 +301,18 @@ __global__ __launch_bounds__(PF_NT) void k_pyr_fast(PyrFastArgs a)
 
     uint8_t *tile = lds;                                              // tileRows x tp
     uint8_t *score = tile + (size_t)g.tileRows * tp;                  // (hCell + 2) x tp, same column indexing
-    uint8_t *cmask = score + (size_t)(g.hCell + 2) * tp;              // hCell x (tp / 8): ring-test mask per strip
-    const int nsPitch = tp >> 3;
-    uint32_t *bitsAll = (uint32_t *)(cmask + (((size_t)g.hCell * nsPitch + 15) & ~(size_t)15));  // [cell][row][wpc]
+    uint32_t *bits = (uint32_t *)(score + (size_t)(g.hCell + 2) * tp); // [cell][row][wpc] NMS survivors
     const int wpc = g.wpc;
     const int cellWords = g.hCell * wpc;
-    uint32_t *bitsIni = bitsAll + (size_t)g.groupCells * cellWords;   // ... with score >= iniThFAST
-    int2 *xt = (int2 *)(bitsIni + (size_t)g.groupCells * cellWords);  // resize x table of this tile's dst columns
+    int2 *xt = (int2 *)(bits + (((size_t)g.groupCells * cellWords + 1) & ~(size_t)1));  // resize x table of this tile's dst columns
     int2 *yt = xt + g.rsMaxDx;                                        // resize y table of this tile's dst rows
-    uint16_t *queue = (uint16_t *)(yt + g.rsMaxDy);                   // ring-test survivors
-    uint8_t *colInfo = (uint8_t *)(queue + PF_QCAP);                  // per interior column
-    __shared__ int cntAll[PF_MAX_GROUP_CELLS], cntIni[PF_MAX_GROUP_CELLS], cellOff[PF_MAX_GROUP_CELLS + 1];
-    __shared__ unsigned qCount;
+    uint16_t *gq = (uint16_t *)(yt + g.rsMaxDy);                      // groups that passed the pre-test: row << 9 | 2 * strip + grp
+    uint16_t *cq = gq + g.gqCap;                                      // ring-test survivors: row << 9 | interior column
+    uint8_t *gqm = (uint8_t *)(cq + PF_QCAP);                         // corner mask of each queued group (overflow path)
+    uint8_t *colInfo = gqm + g.gqCap;                                 // per interior column
+    __shared__ int cnt[PF_MAX_GROUP_CELLS], cellOff[PF_MAX_GROUP_CELLS + 1];
+    __shared__ unsigned char cellEmpty[PF_MAX_GROUP_CELLS];
+    __shared__ unsigned gqCount, cqCount, anyEmpty;
 
     // ---- stage the tile: coalesced 16-byte loads of row-major image rows into LDS ------------------------
     const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
@@ -314,11 +348,10 @@ __global__ __launch_bounds__(PF_NT) void k_pyr_fast(PyrFastArgs a)
         uint4 *zs = (uint4 *)score;
         const int nz = ((g.hCell + 2) * tp) >> 4;
         for (int i = tid; i < nz; i += PF_NT) zs[i] = z;
-        uint32_t *zb = bitsAll;
-        const int nb = 2 * g.groupCells * cellWords;
-        for (int i = tid; i < nb; i += PF_NT) zb[i] = 0;
+        const int nb = g.groupCells * cellWords;
+        for (int i = tid; i < nb; i += PF_NT) bits[i] = 0;
     }
-    if (tid == 0) qCount = 0;
+    if (tid < PF_MAX_GROUP_CELLS) cellEmpty[tid] = 1;
     // per interior column: cell index | bit7 first column of its cell | bit6 last column
     for (int x = tid; x < TWi; x += PF_NT) {
         int cell = x / g.wCell, cx = x - cell * g.wCell;
@@ -385,106 +418,159 @@ __global__ __launch_bounds__(PF_NT) void k_pyr_fast(PyrFastArgs a)
         }
     }
 
-    // ---- FAST-9/16 ring test on 8-pixel strips; survivors go to a dense LDS queue ----------------------
+    // ---- FAST-9/16 + cell-local NMS, in the reference's two rounds -----------------------------------------------
+    // round 0: threshold iniThFAST everywhere; round 1: threshold minThFAST, only in cells that produced no keypoint
+    // in round 0 (tileCalcKeypoints :908-925).  Each round: (A) 4-point pre-test on 8-pixel strips -> LDS queue of
+    // 4-pixel groups; (B) dense full 16-position SWAR ring test, one queued group per lane -> LDS queue of corners;
+    // (C) dense corner score; (D) dense cell-local strict 3x3 NMS -> per-cell row bitmaps; (E) per-cell counts.
     const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
-    const int minEff = max(minTh, 1), iniEff = max(iniTh, 1);
     const int s0 = (cInt0 - 4) >> 3, s1 = (cInt1 - 1 - 4) >> 3;  // strips cover LDS columns [8s + 4, 8s + 12)
     const int NS = s1 - s0 + 1;
     const float invNS = 1.0f / (float)NS;
     const int nItems = NS * THi;
-    const int nItemsPad = nItems;
     const int rowOff = ty0 - ly0;
-    if (a.phases & 2)
-    for (int it = tid; it < nItemsPad; it += PF_NT) {
-        unsigned m = 0;
-        int r = 0, cbase = 0;
-        if (it < nItems) {
-            r = (int)(((float)it + 0.5f) * invNS);
-            const int s = s0 + (it - r * NS);
+    for (int round = 0; round < 2; ++round) {
+        const int th = round == 0 ? iniTh : minTh;
+        const int thEff = max(th, 1);
+        if (round == 1 && (minTh >= iniTh || anyEmpty == 0)) break;   // uniform: LDS flag written before the last barrier
+        const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
+        if (tid == 0) { gqCount = 0; cqCount = 0; }
+        __syncthreads();
+
+        // (A) pre-test
+        if (a.phases & 2)
+        for (int it = tid; it < nItems; it += PF_NT) {
+            const int r = (int)(((float)it + 0.5f) * invNS);
+            const int sI = it - r * NS, s = s0 + sI;
+            const int cbase = 8 * s + 4;
+            const int plo = max(cInt0 - cbase, 0), phi = min(cInt1 - cbase, 8);
+            unsigned valid = (0xFFu >> (8 - phi)) & (0xFFu << plo);          // interior pixels of the strip
+            if (round == 1) {                                                // ... that lie in a still-empty cell
+                unsigned keep = 0;
+                for (int i = plo; i < phi; ++i) keep |= (unsigned)cellEmpty[colInfo[cbase + i - cInt0] & 0x3F] << i;
+                valid &= keep;
+            }
+            if (!valid) continue;
             const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * s;
+            uint32_t w0[4], w3[4], w6[4];
+            {
+                const uint2 a0 = *(const uint2 *)(wp), a1 = *(const uint2 *)(wp + 8);
+                const uint2 b0 = *(const uint2 *)(wp + 3 * tp), b1 = *(const uint2 *)(wp + 3 * tp + 8);
+                const uint2 c0 = *(const uint2 *)(wp + 6 * tp), c1 = *(const uint2 *)(wp + 6 * tp + 8);
+                w0[0] = a0.x; w0[1] = a0.y; w0[2] = a1.x; w0[3] = a1.y;
+                w3[0] = b0.x; w3[1] = b0.y; w3[2] = b1.x; w3[3] = b1.y;
+                w6[0] = c0.x; w6[1] = c0.y; w6[2] = c1.x; w6[3] = c1.y;
+            }
+            const uint32_t f0 = fast_group_pretest<0>(w0, w3, w6, T4, C4);
+            const uint32_t f1 = fast_group_pretest<1>(w0, w3, w6, T4, C4);
+            const unsigned m = (((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4)) & valid;
+            const unsigned g0 = (m & 0x0F) != 0, g1 = (m & 0xF0) != 0;
+            if (g0 | g1) {
+                unsigned pos = atomicAdd(&gqCount, g0 + g1);
+                const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
+                if (g0) gq[pos++] = (uint16_t)e;
+                if (g1) gq[pos] = (uint16_t)(e | 1u);
+            }
+        }
+        __syncthreads();
+
+        // (B) full ring test of the queued groups
+        const unsigned gn = gqCount;
+        for (unsigned i = tid; i < gn; i += PF_NT) {
+            const unsigned e = gq[i];
+            const int r = e >> 9, sg = e & 511;
+            const int cb = 8 * s0 + 4 * sg;                       // window start: the group's pixels are bytes 4..7
+            const uint8_t *wp = tile + (rowOff + r - 3) * tp + cb;
             uint32_t w[7][4];
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const uint2 lo = *(const uint2 *)(wp + j * tp);
-                const uint2 hi = *(const uint2 *)(wp + j * tp + 8);
-                w[j][0] = lo.x; w[j][1] = lo.y; w[j][2] = hi.x; w[j][3] = hi.y;
+                const uint32_t *q = (const uint32_t *)(wp + j * tp);
+                w[j][0] = q[0]; w[j][1] = q[1]; w[j][2] = q[2]; w[j][3] = q[3];
             }
-            m = fast_strip_mask(w, minTh);
-            cbase = 8 * s + 4;
-            const int lo = max(cInt0 - cbase, 0), hi = min(cInt1 - cbase, 8);
-            m &= (0xFFu >> (8 - hi)) & (0xFFu << lo);  // interior pixels only
-            cmask[r * nsPitch + s] = (uint8_t)m;
-        }
-        if (m && !(a.phases & 32)) {
-            unsigned pos = atomicAdd(&qCount, (unsigned)__popc(m));  // queue order is irrelevant (bitmaps order the output)
-            while (m) {
-                const int i = __ffs(m) - 1;
-                m &= m - 1;
-                if (pos < PF_QCAP) queue[pos] = (uint16_t)((r << 9) | (cbase + i - cInt0));
-                ++pos;
+            const uint32_t fl = fast_group_flags<0>(w, T4, C4);
+            const int c4 = cb + 4;
+            const int plo = max(cInt0 - c4, 0), phi = min(cInt1 - c4, 4);
+            unsigned m = ((fl * 0x00204081u) >> 28) & (0xFu >> (4 - phi)) & (0xFu << plo);
+            if (round == 1 && m) {
+                unsigned keep = 0;
+                for (int k = plo; k < phi; ++k) keep |= (unsigned)cellEmpty[colInfo[c4 + k - cInt0] & 0x3F] << k;
+                m &= keep;
             }
-        }
-    }
-    __syncthreads();
-    const unsigned qn = qCount;
-    if (qn <= PF_QCAP) {
-        // dense: one queue entry per lane — score, then cell-local 3x3 NMS into the per-cell row bitmaps
-        if (!(a.phases & 16))
-        for (unsigned i = tid; i < qn; i += PF_NT) {
-            const unsigned e = queue[i];
-            pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, minEff);
-        }
-        __syncthreads();
-        if (a.phases & 4)
-        for (unsigned i = tid; i < qn; i += PF_NT) {
-            const unsigned e = queue[i];
-            pf_nms_one(score, colInfo, bitsAll, bitsIni, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc, iniEff);
-        }
-    } else {
-        // queue overflow (pathological corner density): per-strip loops over the ring-test masks
-        for (int it = tid; it < nItems; it += PF_NT) {
-            const int r = (int)(((float)it + 0.5f) * invNS);
-            const int s = s0 + (it - r * NS);
-            unsigned m = cmask[r * nsPitch + s];
-            while (m) {
-                const int i = __ffs(m) - 1;
-                m &= m - 1;
-                pf_score_one(tile, score, tp, rowOff, r, 8 * s + 4 + i, minEff);
+            gqm[i] = (uint8_t)m;
+            if (m) {
+                unsigned pos = atomicAdd(&cqCount, (unsigned)__popc(m));
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
+                    ++pos;
+                }
             }
         }
         __syncthreads();
-        for (int it = tid; it < nItems; it += PF_NT) {
-            const int r = (int)(((float)it + 0.5f) * invNS);
-            const int s = s0 + (it - r * NS);
-            unsigned m = cmask[r * nsPitch + s];
-            while (m) {
-                const int i = __ffs(m) - 1;
-                m &= m - 1;
-                pf_nms_one(score, colInfo, bitsAll, bitsIni, tp, r, 8 * s + 4 + i, cInt0, g.wCell, g.hCell, wpc, iniEff);
-            }
-        }
-    }
-    __syncthreads();
 
-    // ---- per-cell counts at both thresholds (wave per cell, lane per row) ------------------------------
-    if (!(a.phases & 8)) return;
-    for (int c = wave; c < nCells; c += PF_NW) {
-        int nA = 0, nI = 0;
-        for (int r = lane; r < THi; r += 64)
-            for (int k = 0; k < wpc; ++k) {
-                nA += __popc(bitsAll[(c * g.hCell + r) * wpc + k]);
-                nI += __popc(bitsIni[(c * g.hCell + r) * wpc + k]);
+        // (C) score, (D) NMS
+        const unsigned qn = cqCount;
+        if (qn <= PF_QCAP) {
+            if (!(a.phases & 16))
+            for (unsigned i = tid; i < qn; i += PF_NT) {
+                const unsigned e = cq[i];
+                pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
             }
+            __syncthreads();
+            if (a.phases & 4)
+            for (unsigned i = tid; i < qn; i += PF_NT) {
+                const unsigned e = cq[i];
+                pf_nms_one(score, colInfo, bits, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc);
+            }
+        } else {
+            // corner queue overflow (pathological corner density): per-group loops over the ring-test masks
+            for (unsigned i = tid; i < gn; i += PF_NT) {
+                const unsigned e = gq[i];
+                const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
+                unsigned m = gqm[i];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    pf_score_one(tile, score, tp, rowOff, r, c4 + k, thEff);
+                }
+            }
+            __syncthreads();
+            for (unsigned i = tid; i < gn; i += PF_NT) {
+                const unsigned e = gq[i];
+                const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
+                unsigned m = gqm[i];
+                while (m) {
+                    const int k = __ffs(m) - 1;
+                    m &= m - 1;
+                    pf_nms_one(score, colInfo, bits, tp, r, c4 + k, cInt0, g.wCell, g.hCell, wpc);
+                }
+            }
+        }
+        if (tid == 0) anyEmpty = 0;
+        __syncthreads();
+
+        // (E) keypoints per cell (wave per cell, lane per row)
+        for (int c = wave; c < nCells; c += PF_NW) {
+            int n = 0;
+            for (int r = lane; r < THi; r += 64)
+                for (int k = 0; k < wpc; ++k) n += __popc(bits[(c * g.hCell + r) * wpc + k]);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { nA += __shfl_xor(nA, o); nI += __shfl_xor(nI, o); }
-        if (lane == 0) { cntAll[c] = nA; cntIni[c] = nI; }
+            for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+            if (lane == 0) {
+                cnt[c] = n;
+                cellEmpty[c] = n == 0;
+                if (n == 0) anyEmpty = 1;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    if (!(a.phases & 8)) return;
     if (tid == 0) {
         int off = 0;
         for (int c = 0; c < nCells; ++c) {
             cellOff[c] = off;
-            off += cntIni[c] > 0 ? cntIni[c] : cntAll[c];
+            off += cnt[c];
         }
         cellOff[nCells] = off;
         a.tileCount[(size_t)f * a.tilesPerFrame + g.tileBase + crow * g.nGroups + grp] = off;
@@ -495,19 +581,19 @@ __global__ __launch_bounds__(PF_NT) void k_pyr_fast(PyrFastArgs a)
     uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + g.candBase +
                      (size_t)(crow * g.nGroups + grp) * g.slotCap;
     for (int c = wave; c < nCells; c += PF_NW) {
-        const uint32_t *bits = (cntIni[c] > 0 ? bitsIni : bitsAll) + (size_t)c * cellWords;
+        const uint32_t *cbits = bits + (size_t)c * cellWords;
         int base = cellOff[c];
         const int cellC0 = cInt0 + c * g.wCell;
         for (int rb = 0; rb < THi; rb += 64) {
             const int r = rb + lane;
             int n = 0;
             if (r < THi)
-                for (int k = 0; k < wpc; ++k) n += __popc(bits[r * wpc + k]);
+                for (int k = 0; k < wpc; ++k) n += __popc(cbits[r * wpc + k]);
             int total;
             int o = base + wave_excl_scan(n, total);
             if (r < THi) {
                 for (int k = 0; k < wpc; ++k) {
-                    uint32_t wd = bits[r * wpc + k];
+                    uint32_t wd = cbits[r * wpc + k];
                     while (wd) {
                         const int b = __ffs(wd) - 1;
                         wd &= wd - 1;
@@ -545,6 +631,12 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
         a.phases = phases;
     }
     if (g.groupCells > PF_MAX_GROUP_CELLS) return hipErrorInvalidValue;
+    if (getenv("ORBX_DEBUG")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pyr_fast, PF_NT, g.ldsBytes);
+        fprintf(stderr, "[orbx] k_pyr_fast level %dx%d: tiles/frame %d (%d groups x %d rows, %d cells/group), LDS %d B, %d threads, %d blocks/CU\n", g.w, g.h,
+                g.nTiles, g.nGroups, g.ncy, g.groupCells, g.ldsBytes, PF_NT, nb);
+    }
     dim3 grid(xcd_grid(nframes, g.nTiles));
     hipLaunchKernelGGL(k_pyr_fast, grid, dim3(PF_NT), g.ldsBytes, st, a);
     return hipGetLastError();
