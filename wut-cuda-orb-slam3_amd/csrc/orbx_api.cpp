@@ -317,7 +317,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         }
         g.tileRows = maxRows;
         // LDS column 16 holds image column ax0; strip windows / 16-byte loads may overshoot by up to 16 bytes
-        g.tilePitch = (int)roundUp(maxCols + 16 + 32, 16);
+        g.tilePitch = (int)roundUp(maxCols + 32, 16);  // XO (16) + widest overshoot of strip windows (24) / 16-byte loads (31 - 16)
         g.wpc = (g.wCell + 31) / 32;
         g.rsMaxDx = g.rsMaxDy = 0;  // filled in with the resize tables below
     }

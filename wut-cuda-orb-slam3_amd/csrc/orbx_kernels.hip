@@ -273,7 +273,7 @@ __device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *
     }
 }
 
-__global__ __launch_bounds__(PF_NT) void k_pyr_fast(PyrFastArgs a)
+__global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const OrbxLevelGeom &g = a.g;
