@@ -173,6 +173,51 @@ __device__ __forceinline__ uint32_t fast_group_flags(const uint32_t (&w)[7][4], 
     return ((rd & ~ltVT) | (rb & ~ltCV)) & SW_H;
 }
 
+// Same test for ONE 4-pixel group whose pixels are bytes 4..7 of a 16-byte LDS window starting at `wp` (row y-3;
+// 4-byte aligned), fetching each ring dword pair from LDS on demand instead of holding the 7 x 16-byte window in
+// registers: ~50 VGPRs instead of ~75, so the kernel reaches 8 waves/SIMD without scratch spills.
+__device__ __forceinline__ uint32_t fast_group_flags_lds(const uint8_t *wp, int tp, uint32_t T4, uint32_t C4)
+{
+    const uint32_t V = *(const uint32_t *)(wp + 3 * tp + 4);
+    const uint32_t Vl = V & SW_L;
+    const uint32_t tS = (V | SW_H) - (T4 & SW_L);
+    const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
+    const uint32_t ltVT = (~V & T4) | (~(V ^ T4) & ~tS);
+    const uint32_t HI = (Vl + (T4 & SW_L)) ^ ((V ^ T4) & SW_H);
+    const uint32_t tC = (C4 | SW_H) - Vl;
+    const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);
+    const uint32_t Kd = SW_H - (LO & SW_L);
+    const uint32_t HIh = HI | SW_H;
+    uint32_t D[16], B[16];
+#define RING(k, dx, dy)                                                                            \
+    {                                                                                              \
+        constexpr int o = 4 + (dx);                                                                \
+        const uint32_t *q = (const uint32_t *)(wp + (3 + (dy)) * tp + (o & ~3));                   \
+        const uint32_t P = (o & 3) == 0 ? q[0] : __builtin_amdgcn_alignbyte(q[1], q[0], o & 3);    \
+        const uint32_t Pl = P & SW_L;                                                              \
+        const uint32_t td = Pl + Kd;                                                               \
+        const uint32_t tb = HIh - Pl;                                                              \
+        D[k] = (~P & LO) | (~(P ^ LO) & ~td);                                                      \
+        B[k] = (~HI & P) | (~(HI ^ P) & ~tb);                                                      \
+    }
+    RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+    RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2) RING(15, -1, 3)
+#undef RING
+    uint32_t d3[16], b3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        d3[k] = D[k] & D[(k + 1) & 15] & D[(k + 2) & 15];
+        b3[k] = B[k] & B[(k + 1) & 15] & B[(k + 2) & 15];
+    }
+    uint32_t rd = 0, rb = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        rd |= d3[k] & d3[(k + 3) & 15] & d3[(k + 6) & 15];
+        rb |= b3[k] & b3[(k + 3) & 15] & b3[(k + 6) & 15];
+    }
+    return ((rd & ~ltVT) | (rb & ~ltCV)) & SW_H;
+}
+
 __device__ __forceinline__ unsigned fast_strip_mask(const uint32_t (&w)[7][4], int th)
 {
     const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
@@ -281,6 +326,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
     if (!xcd_decode(a.nframes, g.nTiles, f, tileId)) return;
     const int crow = tileId / g.nGroups, grp = tileId - crow * g.nGroups;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // opaque copy of the thread index: stops the compiler from hoisting every phase's per-lane address arithmetic into the
+    // kernel prologue, where it was being spilled to scratch at the 64-VGPR budget needed for 4 workgroups per CU
+    auto otid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
 
     // interior (corner-capable) pixel ranges of this tile
     const int ty0 = ORBX_FAST_MARGIN + crow * g.hCell;
@@ -321,7 +369,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         const int nV = (lx1 - ax0 + 15) >> 4;
         const float invNV = 1.0f / (float)nV;
         const int n = nRowsL * nV;
-        for (int it = tid; it < n; it += PF_NT) {
+        for (int it = otid(); it < n; it += PF_NT) {
             const int r = (int)(((float)it + 0.5f) * invNV);
             const int c = it - r * nV;
             const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
@@ -347,13 +395,13 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         uint4 z = make_uint4(0, 0, 0, 0);
         uint4 *zs = (uint4 *)score;
         const int nz = ((g.hCell + 2) * tp) >> 4;
-        for (int i = tid; i < nz; i += PF_NT) zs[i] = z;
+        for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
         const int nb = g.groupCells * cellWords;
-        for (int i = tid; i < nb; i += PF_NT) bits[i] = 0;
+        for (int i = otid(); i < nb; i += PF_NT) bits[i] = 0;
     }
     if (tid < PF_MAX_GROUP_CELLS) cellEmpty[tid] = 1;
     // per interior column: cell index | bit7 first column of its cell | bit6 last column
-    for (int x = tid; x < TWi; x += PF_NT) {
+    for (int x = otid(); x < TWi; x += PF_NT) {
         int cell = x / g.wCell, cx = x - cell * g.wCell;
         int cw = min(g.wCell, TWi - cell * g.wCell);
         colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
@@ -364,11 +412,11 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
     if (doResize) {
         dy0 = a.tabs.rowBeg[crow]; dy1 = a.tabs.rowBeg[crow + 1];
         dx0 = a.tabs.colBeg[grp]; dx1 = a.tabs.colBeg[grp + 1];
-        for (int i = tid; i < dx1 - dx0; i += PF_NT) {
+        for (int i = otid(); i < dx1 - dx0; i += PF_NT) {
             const int sx0 = a.tabs.xofs[dx0 + i];
             xt[i] = make_int2((sx0 + colOf0) | ((min(sx0 + 1, g.w - 1) + colOf0) << 16), a.tabs.xab[dx0 + i]);
         }
-        for (int i = tid; i < dy1 - dy0; i += PF_NT) {
+        for (int i = otid(); i < dy1 - dy0; i += PF_NT) {
             const int sy = a.tabs.yofs[dy0 + i];
             const int sy0 = min(max(sy, 0), g.h - 1) - ly0, sy1 = min(max(sy + 1, 0), g.h - 1) - ly0;
             yt[i] = make_int2(sy0 | (sy1 << 16), a.tabs.yab[dy0 + i]);
@@ -438,8 +486,10 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         __syncthreads();
 
         // (A) pre-test
+        int tidA = tid;
+        asm volatile("" : "+v"(tidA));  // keep per-lane address arithmetic local to the phase (no hoisting -> no spills)
         if (a.phases & 2)
-        for (int it = tid; it < nItems; it += PF_NT) {
+        for (int it = tidA; it < nItems; it += PF_NT) {
             const int r = (int)(((float)it + 0.5f) * invNS);
             const int sI = it - r * NS, s = s0 + sI;
             const int cbase = 8 * s + 4;
@@ -476,18 +526,13 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
 
         // (B) full ring test of the queued groups
         const unsigned gn = gqCount;
-        for (unsigned i = tid; i < gn; i += PF_NT) {
+        int tidB = tid;
+        asm volatile("" : "+v"(tidB));
+        for (unsigned i = tidB; i < gn; i += PF_NT) {
             const unsigned e = gq[i];
             const int r = e >> 9, sg = e & 511;
             const int cb = 8 * s0 + 4 * sg;                       // window start: the group's pixels are bytes 4..7
-            const uint8_t *wp = tile + (rowOff + r - 3) * tp + cb;
-            uint32_t w[7][4];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const uint32_t *q = (const uint32_t *)(wp + j * tp);
-                w[j][0] = q[0]; w[j][1] = q[1]; w[j][2] = q[2]; w[j][3] = q[3];
-            }
-            const uint32_t fl = fast_group_flags<0>(w, T4, C4);
+            const uint32_t fl = fast_group_flags_lds(tile + (rowOff + r - 3) * tp + cb, tp, T4, C4);
             const int c4 = cb + 4;
             const int plo = max(cInt0 - c4, 0), phi = min(cInt1 - c4, 4);
             unsigned m = ((fl * 0x00204081u) >> 28) & (0xFu >> (4 - phi)) & (0xFu << plo);
@@ -513,19 +558,19 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         const unsigned qn = cqCount;
         if (qn <= PF_QCAP) {
             if (!(a.phases & 16))
-            for (unsigned i = tid; i < qn; i += PF_NT) {
+            for (unsigned i = otid(); i < qn; i += PF_NT) {
                 const unsigned e = cq[i];
                 pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
             }
             __syncthreads();
             if (a.phases & 4)
-            for (unsigned i = tid; i < qn; i += PF_NT) {
+            for (unsigned i = otid(); i < qn; i += PF_NT) {
                 const unsigned e = cq[i];
                 pf_nms_one(score, colInfo, bits, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc);
             }
         } else {
             // corner queue overflow (pathological corner density): per-group loops over the ring-test masks
-            for (unsigned i = tid; i < gn; i += PF_NT) {
+            for (unsigned i = otid(); i < gn; i += PF_NT) {
                 const unsigned e = gq[i];
                 const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
                 unsigned m = gqm[i];
@@ -536,7 +581,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
                 }
             }
             __syncthreads();
-            for (unsigned i = tid; i < gn; i += PF_NT) {
+            for (unsigned i = otid(); i < gn; i += PF_NT) {
                 const unsigned e = gq[i];
                 const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
                 unsigned m = gqm[i];
