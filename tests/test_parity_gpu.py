@@ -231,3 +231,17 @@ def test_two_handles_concurrently(pkg, orc):
         assert out[i][0] == rmono
         _assert_same(pkg, out[i][1], out[i][2], rk, rd, f"handle {i}")
     [e.close() for e in exs]
+
+
+def test_quadtree_pool_compaction_path(pkg):
+    """The quadtree recycles node ids by compacting its tombstoned list when the node pool runs low.  With the
+    default pool (2 * quota + 64) that path is rare; force a tiny pool in a subprocess and check full parity."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBX_QT_POOL_SLACK="12")
+    for args in (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py")] + args, env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert out.returncode == 0 and "ALL STAGES BIT-IDENTICAL" in out.stdout, out.stdout[-2000:]

@@ -8,6 +8,11 @@
 // order observable in the final keypoint set.  The quadtree kernel therefore
 // reproduces the exact permutation instead of "a" sorted order.  No recursion: an explicit stack of
 // sub-ranges (the sub-ranges are disjoint, so processing order does not change the result).
+//
+// The algorithm is written against an accessor (get(i) / set(i, v)) so that the device can keep the elements
+// in lane registers (v_readlane / v_writelane with scalar indices: the whole sort then runs at scalar-ALU
+// latency instead of one dependent LDS round trip per element access) while the host tests and the LDS
+// fallback use a plain pointer accessor.  The sequence of comparisons and moves is identical for every accessor.
 #ifndef ORBX_LIBSTDCXX_SORT_H
 #define ORBX_LIBSTDCXX_SORT_H
 
@@ -19,46 +24,57 @@
 
 namespace orbx_sort {
 
-template <class T, class Less>
-ORBX_HD void push_heap(T *first, int holeIndex, int topIndex, T value, Less less)
+template <class T>
+struct PtrAccessor {
+    T *p;
+    ORBX_HD T get(int i) const { return p[i]; }
+    ORBX_HD void set(int i, const T &v) const { p[i] = v; }
+};
+
+template <class A, class T, class Less>
+ORBX_HD void push_heap(A &a, int first, int holeIndex, int topIndex, T value, Less less)
 {
     int parent = (holeIndex - 1) / 2;
-    while (holeIndex > topIndex && less(first[parent], value)) {
-        first[holeIndex] = first[parent];
+    while (holeIndex > topIndex) {
+        const T pv = a.get(first + parent);
+        if (!less(pv, value)) break;
+        a.set(first + holeIndex, pv);
         holeIndex = parent;
         parent = (holeIndex - 1) / 2;
     }
-    first[holeIndex] = value;
+    a.set(first + holeIndex, value);
 }
 
-template <class T, class Less>
-ORBX_HD void adjust_heap(T *first, int holeIndex, int len, T value, Less less)
+template <class A, class T, class Less>
+ORBX_HD void adjust_heap(A &a, int first, int holeIndex, int len, T value, Less less)
 {
     const int topIndex = holeIndex;
     int secondChild = holeIndex;
     while (secondChild < (len - 1) / 2) {
         secondChild = 2 * (secondChild + 1);
-        if (less(first[secondChild], first[secondChild - 1])) secondChild--;
-        first[holeIndex] = first[secondChild];
+        T c1 = a.get(first + secondChild);
+        const T c0 = a.get(first + secondChild - 1);
+        if (less(c1, c0)) { secondChild--; c1 = c0; }
+        a.set(first + holeIndex, c1);
         holeIndex = secondChild;
     }
     if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
         secondChild = 2 * (secondChild + 1);
-        first[holeIndex] = first[secondChild - 1];
+        a.set(first + holeIndex, a.get(first + secondChild - 1));
         holeIndex = secondChild - 1;
     }
-    push_heap(first, holeIndex, topIndex, value, less);
+    push_heap(a, first, holeIndex, topIndex, value, less);
 }
 
 // std::__partial_sort(first, last, last): make_heap + sort_heap (the heap_select loop over [middle,last) is empty)
-template <class T, class Less>
-ORBX_HD void heap_sort(T *first, int len, Less less)
+template <class T, class A, class Less>
+ORBX_HD void heap_sort_acc(A &a, int first, int len, Less less)
 {
     if (len >= 2) {
         int parent = (len - 2) / 2;
         for (;;) {
-            T value = first[parent];
-            adjust_heap(first, parent, len, value, less);
+            const T value = a.get(first + parent);
+            adjust_heap(a, first, parent, len, value, less);
             if (parent == 0) break;
             parent--;
         }
@@ -66,58 +82,54 @@ ORBX_HD void heap_sort(T *first, int len, Less less)
     int last = len;
     while (last > 1) {
         --last;
-        T value = first[last];
-        first[last] = first[0];
-        adjust_heap(first, 0, last, value, less);
+        const T value = a.get(first + last);
+        a.set(first + last, a.get(first));
+        adjust_heap(a, first, 0, last, value, less);
     }
 }
 
-template <class T>
-ORBX_HD void swap_elems(T &a, T &b)
+template <class T, class A, class Less>
+ORBX_HD void unguarded_linear_insert(A &a, int last, Less less)
 {
-    T t = a;
-    a = b;
-    b = t;
-}
-
-template <class T, class Less>
-ORBX_HD void unguarded_linear_insert(T *a, int last, Less less)
-{
-    T val = a[last];
+    const T val = a.get(last);
     int next = last - 1;
-    while (less(val, a[next])) {
-        a[last] = a[next];
+    for (;;) {
+        const T nv = a.get(next);
+        if (!less(val, nv)) break;
+        a.set(last, nv);
         last = next;
         --next;
     }
-    a[last] = val;
+    a.set(last, val);
 }
 
-template <class T, class Less>
-ORBX_HD void insertion_sort(T *a, int first, int last, Less less)
+template <class T, class A, class Less>
+ORBX_HD void insertion_sort(A &a, int first, int last, Less less)
 {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-        if (less(a[i], a[first])) {
-            T val = a[i];
-            for (int k = i; k > first; --k) a[k] = a[k - 1];
-            a[first] = val;
+        const T vi = a.get(i);
+        if (less(vi, a.get(first))) {
+            for (int k = i; k > first; --k) a.set(k, a.get(k - 1));
+            a.set(first, vi);
         } else {
-            unguarded_linear_insert(a, i, less);
+            unguarded_linear_insert<T>(a, i, less);
         }
     }
 }
 
-// std::sort(a, a + n, less) — result (including the order of equivalent elements) identical to libstdc++.
-template <class T, class Less>
-ORBX_HD void sort(T *a, int n, Less less)
+// std::sort over elements [0, n) of the accessor — result (including the order of equivalent elements) identical to libstdc++.
+// `stack` = caller-provided storage for 3 * 72 ints (the explicit recursion stack); on the device it lives in LDS so
+// that no dynamically indexed private array (scratch memory) sits in the middle of the latency chain.
+template <class T, class A, class Less>
+ORBX_HD void sort_acc(A &a, int n, Less less, int *stack)
 {
     if (n <= 1) return;
     const int kThreshold = 16;
     int lg = 0;
     for (unsigned v = (unsigned)n; v > 1; v >>= 1) ++lg;  // std::__lg
     // explicit stack of (first, last, depth_limit); depth <= 2*lg + 1 entries
-    int stFirst[72], stLast[72], stDepth[72];
+    int *stFirst = stack, *stLast = stack + 72, *stDepth = stack + 144;
     int sp = 0;
     stFirst[0] = 0; stLast[0] = n; stDepth[0] = lg * 2; sp = 1;
     while (sp > 0) {
@@ -125,31 +137,39 @@ ORBX_HD void sort(T *a, int n, Less less)
         int first = stFirst[sp], last = stLast[sp], depth = stDepth[sp];
         while (last - first > kThreshold) {
             if (depth == 0) {
-                heap_sort(a + first, last - first, less);
+                heap_sort_acc<T>(a, first, last - first, less);
                 break;
             }
             --depth;
             // __unguarded_partition_pivot: median of (first+1, mid, last-1) moved to first
-            int mid = first + (last - first) / 2;
-            int ia = first + 1, ib = mid, ic = last - 1;
-            if (less(a[ia], a[ib])) {
-                if (less(a[ib], a[ic])) swap_elems(a[first], a[ib]);
-                else if (less(a[ia], a[ic])) swap_elems(a[first], a[ic]);
-                else swap_elems(a[first], a[ia]);
-            } else if (less(a[ia], a[ic])) swap_elems(a[first], a[ia]);
-            else if (less(a[ib], a[ic])) swap_elems(a[first], a[ic]);
-            else swap_elems(a[first], a[ib]);
-            // __unguarded_partition(first + 1, last, pivot = first)
+            const int mid = first + (last - first) / 2;
+            const int ia = first + 1, ib = mid, ic = last - 1;
+            const T vf = a.get(first), va = a.get(ia), vb = a.get(ib), vc = a.get(ic);
+            int im;  // index whose element is swapped with *first
+            if (less(va, vb)) {
+                if (less(vb, vc)) im = ib;
+                else if (less(va, vc)) im = ic;
+                else im = ia;
+            } else if (less(va, vc)) im = ia;
+            else if (less(vb, vc)) im = ic;
+            else im = ib;
+            const T pivot = im == ia ? va : (im == ib ? vb : vc);
+            a.set(im, vf);
+            a.set(first, pivot);
+            // __unguarded_partition(first + 1, last, pivot = *first); *first is not touched inside the loop
             int lo = first + 1, hi = last;
             for (;;) {
-                while (less(a[lo], a[first])) ++lo;
+                T vlo = a.get(lo);
+                while (less(vlo, pivot)) { ++lo; vlo = a.get(lo); }
                 --hi;
-                while (less(a[first], a[hi])) --hi;
+                T vhi = a.get(hi);
+                while (less(pivot, vhi)) { --hi; vhi = a.get(hi); }
                 if (!(lo < hi)) break;
-                swap_elems(a[lo], a[hi]);
+                a.set(lo, vhi);
+                a.set(hi, vlo);
                 ++lo;
             }
-            int cut = lo;
+            const int cut = lo;
             // recurse on [cut, last) with the decremented depth, loop on [first, cut)
             stFirst[sp] = cut; stLast[sp] = last; stDepth[sp] = depth; ++sp;
             last = cut;
@@ -157,11 +177,31 @@ ORBX_HD void sort(T *a, int n, Less less)
     }
     // __final_insertion_sort
     if (n > kThreshold) {
-        insertion_sort(a, 0, kThreshold, less);
-        for (int i = kThreshold; i != n; ++i) unguarded_linear_insert(a, i, less);
+        insertion_sort<T>(a, 0, kThreshold, less);
+        for (int i = kThreshold; i != n; ++i) unguarded_linear_insert<T>(a, i, less);
     } else {
-        insertion_sort(a, 0, n, less);
+        insertion_sort<T>(a, 0, n, less);
     }
+}
+
+// pointer convenience wrappers (host tests, LDS fallback)
+template <class T, class Less>
+ORBX_HD void sort(T *p, int n, Less less, int *stack)
+{
+    PtrAccessor<T> a{p};
+    sort_acc<T>(a, n, less, stack);
+}
+template <class T, class Less>
+inline void sort(T *p, int n, Less less)  // host convenience
+{
+    int stack[216];
+    sort(p, n, less, stack);
+}
+template <class T, class Less>
+ORBX_HD void heap_sort(T *p, int n, Less less)
+{
+    PtrAccessor<T> a{p};
+    heap_sort_acc<T>(a, 0, n, less);
 }
 
 }  // namespace orbx_sort

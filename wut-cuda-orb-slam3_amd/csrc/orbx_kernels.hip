@@ -861,16 +861,10 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
 // the FAST candidates and the per-node arg-max.  List order (push_front / erase) is kept exactly with a
 // doubly linked list in LDS; the std::sort tie order with the libstdc++ introsort emulation.
 // =====================================================================================================
-#define QT_LDS_KEYS 2048
-#define QT_NIL (-1)
+#define QT_LDS_KEYS 2048   // candidates of one (frame, level) held in LDS (two buffers); larger sets use global scratch
+#define QT_SORT_REGS 4     // std::sort emulation in lane registers for up to 64 * QT_SORT_REGS elements
 
-struct QtSized { int cnt, ulx, id; };
-struct QtSizedLess {
-    __device__ __forceinline__ bool operator()(const QtSized &a, const QtSized &b) const
-    {
-        return a.cnt < b.cnt || (a.cnt == b.cnt && a.ulx < b.ulx);
-    }
-};
+typedef unsigned long long qt_u64;
 
 struct QtArgs {
     const OrbxLevelGeom *geoms;  // device array [nlevels]
@@ -880,54 +874,91 @@ struct QtArgs {
     uint32_t *sel; int selFrameStride;
     int *selCount;
     int nlevels, nframes;
-    int stop;  // debug (ORBX_QT_STOP): 1 return after the gather, 2 after the roots, 3 skip the inner (sorted) loop, 4 skip the sort only
-    int pool;  // node pool size P
+    int pool;     // node pool size P
+    int listCap;  // capacity of list-sized arrays (max quota + 8)
+    int stop;     // debug (ORBX_QT_STOP): 1 return after the gather, 2 after the roots, 3 skip the sorted phase, 4 skip the sort only
 };
 
-struct QtState {
-    int *gx, *gy, *begin, *count;
-    short *next, *prev, *noMore, *freeList;
-    QtSized *sized;
-    uint32_t *A, *B;
-    int head, size, freeTop, bump, nSized, nToExpand;
+// (count, UL.x, node id) of an expandable node packed as count << 32 | ulx << 16 | id; compareNodes (:569-582)
+// orders by (count, UL.x) only = key >> 16
+struct QtSizedLess {
+    __host__ __device__ __forceinline__ bool operator()(qt_u64 a, qt_u64 b) const { return (a >> 16) < (b >> 16); }
 };
 
-__device__ __forceinline__ int qt_alloc(QtState &S)
+// up to 64 * QT_SORT_REGS elements spread over the lanes of the wave: element i = lane (i & 63), register (i >> 6).
+// Indices are wave-uniform, so get is v_readlane and the sort's control flow is scalar.  Plain scalar members (no
+// arrays) so that the accessor stays in VGPRs after inlining instead of being demoted to scratch memory.
+struct QtLaneArr {
+    int lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3;
+    __device__ __forceinline__ qt_u64 get(int i) const
+    {
+        const int l = i & 63, r = i >> 6;
+        const int vl = r == 0 ? lo0 : (r == 1 ? lo1 : (r == 2 ? lo2 : lo3));
+        const int vh = r == 0 ? hi0 : (r == 1 ? hi1 : (r == 2 ? hi2 : hi3));
+        const int a = __builtin_amdgcn_readlane(vl, l), b = __builtin_amdgcn_readlane(vh, l);
+        return ((qt_u64)(unsigned)b << 32) | (unsigned)a;
+    }
+    // v_writelane with two scalar operands exceeds gfx9's one-SGPR constant-bus limit (it would need M0); a compare +
+    // select on the lane id is just as good here
+    __device__ __forceinline__ void set(int i, qt_u64 v)
+    {
+        const int r = i >> 6;
+        const bool me = (int)(threadIdx.x & 63) == (i & 63);
+        const int a = (int)(unsigned)v, b = (int)(unsigned)(v >> 32);
+        lo0 = (me && r == 0) ? a : lo0; hi0 = (me && r == 0) ? b : hi0;
+        lo1 = (me && r == 1) ? a : lo1; hi1 = (me && r == 1) ? b : hi1;
+        lo2 = (me && r == 2) ? a : lo2; hi2 = (me && r == 2) ? b : hi2;
+        lo3 = (me && r == 3) ? a : lo3; hi3 = (me && r == 3) ? b : hi3;
+    }
+};
+
+// the workgroup is a single wave: ordering only has to hold inside the wave
+template <bool LDSK>
+__device__ __forceinline__ void qt_sync()
 {
-    if (S.freeTop > 0) return S.freeList[--S.freeTop];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (LDSK) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+#define QT_F_NOMORE 1
+#define QT_F_ALIVE 2
+
+struct QtCtx {
+    int *gx, *gy, *beg, *cnt;           // node data [P]: UL.x | UR.x << 16, UL.y | BR.y << 16, key range
+    unsigned short *fl;                 // [P] QT_F_*
+    short *front, *freeL;               // [P] children pushed to the list front in the sorted phase; free node ids
+    short *order, *tmpC, *tmpK;         // [L] list order; children / kept nodes of the running pass
+    int *sortStack;                     // [216] explicit recursion stack of the std::sort emulation
+    qt_u64 *sized, *prev;               // [L] expandable nodes of the running / previous pass
+    int size, freeTop, bump, nSized, nFront, nC, nK, P;
+};
+
+__device__ __forceinline__ int qt_alloc(QtCtx &S)
+{
+    if (S.freeTop > 0) return S.freeL[--S.freeTop];
     return S.bump++;
 }
-__device__ __forceinline__ void qt_push_front(QtState &S, int id)
-{
-    S.prev[id] = QT_NIL;
-    S.next[id] = (short)S.head;
-    if (S.head != QT_NIL) S.prev[S.head] = (short)id;
-    S.head = id;
-    ++S.size;
-}
-__device__ __forceinline__ void qt_erase(QtState &S, int id)
-{
-    const int p = S.prev[id], n = S.next[id];
-    if (p != QT_NIL) S.next[p] = (short)n; else S.head = n;
-    if (n != QT_NIL) S.prev[n] = (short)p;
-    S.freeList[S.freeTop++] = (short)id;
-    --S.size;
-}
 
-// ExtractorNode::DivideNode + the "add childs if they contain points" blocks (:653-688 / :717-741) + erase.
-__device__ void qt_divide(QtState &S, int node)
+// ExtractorNode::DivideNode (:515-567) + "add childs if they contain points" (:653-688 / :717-741) + erase.
+// mode 0 = list walk of an outer pass (children collected in tmpC, the parent's id is recycled at once);
+// mode 1 = sorted phase (children pushed on the front stack, the parent becomes a tombstone).
+template <bool LDSK, class KP>
+__device__ __forceinline__ void qt_divide(QtCtx &S, KP A, KP B, int node, int mode)
 {
     const int lane = threadIdx.x;
     const unsigned long long lt = lanemask_lt();
     const int gx = S.gx[node], gy = S.gy[node];
     const int ulx = gx & 0xFFFF, urx = gx >> 16, uly = gy & 0xFFFF, bry = gy >> 16;
-    const int begin = S.begin[node], cnt = S.count[node];
+    const int begin = S.beg[node], cnt = S.cnt[node];
     const int mx = ulx + ((urx - ulx + 1) >> 1);  // UL.x + ceil((UR.x - UL.x) / 2)
     const int my = uly + ((bry - uly + 1) >> 1);
     int c[4] = {0, 0, 0, 0};
     if (cnt <= WAVE) {
         const bool act = lane < cnt;
-        const uint32_t key = act ? S.A[begin + lane] : 0u;
+        const uint32_t key = act ? A[begin + lane] : 0u;
         const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
         const int q = x < mx ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
         unsigned long long m[4];
@@ -936,12 +967,12 @@ __device__ void qt_divide(QtState &S, int node)
         const int o1 = c[0], o2 = o1 + c[1], o3 = o2 + c[2];
         const int offq = q == 0 ? 0 : (q == 1 ? o1 : (q == 2 ? o2 : o3));
         const unsigned long long mq = q == 0 ? m[0] : (q == 1 ? m[1] : (q == 2 ? m[2] : m[3]));
-        __syncthreads();
-        if (act) S.A[begin + offq + __popcll(mq & lt)] = key;
+        qt_sync<LDSK>();
+        if (act) A[begin + offq + __popcll(mq & lt)] = key;
     } else {
         for (int base = 0; base < cnt; base += WAVE) {
             const bool act = base + lane < cnt;
-            const uint32_t key = act ? S.A[begin + base + lane] : 0u;
+            const uint32_t key = act ? A[begin + base + lane] : 0u;
             const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
             const int q = x < mx ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
 #pragma unroll
@@ -950,7 +981,7 @@ __device__ void qt_divide(QtState &S, int node)
         int run[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
         for (int base = 0; base < cnt; base += WAVE) {
             const bool act = base + lane < cnt;
-            const uint32_t key = act ? S.A[begin + base + lane] : 0u;
+            const uint32_t key = act ? A[begin + base + lane] : 0u;
             const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
             const int q = x < mx ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
             unsigned long long m[4];
@@ -958,16 +989,18 @@ __device__ void qt_divide(QtState &S, int node)
             for (int k = 0; k < 4; ++k) m[k] = __ballot(act && q == k);
             const int rq = q == 0 ? run[0] : (q == 1 ? run[1] : (q == 2 ? run[2] : run[3]));
             const unsigned long long mq = q == 0 ? m[0] : (q == 1 ? m[1] : (q == 2 ? m[2] : m[3]));
-            if (act) S.B[begin + rq + __popcll(mq & lt)] = key;
+            if (act) B[begin + rq + __popcll(mq & lt)] = key;
 #pragma unroll
             for (int k = 0; k < 4; ++k) run[k] += __popcll(m[k]);
         }
-        __syncthreads();
-        for (int i = lane; i < cnt; i += WAVE) S.A[begin + i] = S.B[begin + i];
+        qt_sync<LDSK>();
+        for (int i = lane; i < cnt; i += WAVE) A[begin + i] = B[begin + i];
     }
-    __syncthreads();
-    // children n1 (UL), n2 (UR), n3 (BL), n4 (BR) pushed to the list front in that order
-    int off = begin;
+    // the parent's id is free for its own children in an outer pass (nothing refers to it any more)
+    if (mode == 0) S.freeL[S.freeTop++] = (short)node;
+    else S.fl[node] = 0;
+    // children n1 (UL), n2 (UR), n3 (BL), n4 (BR) in push order
+    int off = begin, nonEmpty = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (c[k] > 0) {
@@ -976,20 +1009,236 @@ __device__ void qt_divide(QtState &S, int node)
             const int cuy = (k & 2) ? my : uly, cby = (k & 2) ? bry : my;
             S.gx[id] = cul | (cur << 16);
             S.gy[id] = cuy | (cby << 16);
-            S.begin[id] = off;
-            S.count[id] = c[k];
-            S.noMore[id] = (short)(c[k] == 1);
-            qt_push_front(S, id);
-            if (c[k] > 1) {
-                ++S.nToExpand;
-                QtSized e; e.cnt = c[k]; e.ulx = cul; e.id = id;
-                S.sized[S.nSized++] = e;
-            }
+            S.beg[id] = off;
+            S.cnt[id] = c[k];
+            S.fl[id] = (unsigned short)(QT_F_ALIVE | (c[k] == 1 ? QT_F_NOMORE : 0));
+            if (mode == 0) S.tmpC[S.nC++] = (short)id;
+            else S.front[S.nFront++] = (short)id;
+            if (c[k] > 1) S.sized[S.nSized++] = ((qt_u64)(unsigned)c[k] << 32) | ((qt_u64)(unsigned)cul << 16) | (unsigned)id;
             off += c[k];
+            ++nonEmpty;
         }
     }
-    qt_erase(S, node);
-    __syncthreads();
+    S.size += nonEmpty - 1;
+    qt_sync<LDSK>();
+}
+
+// final list order = front stack reversed (alive entries) followed by the base order (alive entries) -> dst[0 .. size)
+template <bool LDSK>
+__device__ __forceinline__ int qt_flatten(QtCtx &S, int nOrder, short *dst)
+{
+    const int lane = threadIdx.x;
+    const unsigned long long lt = lanemask_lt();
+    int out = 0;
+    for (int base = 0; base < S.nFront; base += WAVE) {
+        const int j = S.nFront - 1 - (base + lane);
+        const int id = j >= 0 ? S.front[j] : 0;
+        const bool alive = j >= 0 && (S.fl[id] & QT_F_ALIVE);
+        const unsigned long long m = __ballot(alive);
+        if (alive) dst[out + __popcll(m & lt)] = (short)id;
+        out += __popcll(m);
+    }
+    for (int base = 0; base < nOrder; base += WAVE) {
+        const int j = base + lane;
+        const int id = j < nOrder ? S.order[j] : 0;
+        const bool alive = j < nOrder && (S.fl[id] & QT_F_ALIVE);
+        const unsigned long long m = __ballot(alive);
+        if (alive) dst[out + __popcll(m & lt)] = (short)id;
+        out += __popcll(m);
+    }
+    qt_sync<LDSK>();
+    return out;
+}
+
+template <bool LDSK, class KP>
+__device__ void qt_body(const QtArgs &a, const OrbxLevelGeom &g, int f, int level, uint8_t *qlds, KP A, KP B, int M,
+                        const int *tc, uint32_t *selOut, int *selCnt)
+{
+    const int lane = threadIdx.x;
+    const int P = a.pool, L = a.listCap;
+    QtCtx S;
+    S.gx = (int *)qlds; S.gy = S.gx + P; S.beg = S.gy + P; S.cnt = S.beg + P;
+    S.sized = (qt_u64 *)(S.cnt + P); S.prev = S.sized + L;
+    S.fl = (unsigned short *)(S.prev + L);
+    S.front = (short *)(S.fl + P); S.freeL = S.front + P;
+    S.order = S.freeL + P; S.tmpC = S.order + L; S.tmpK = S.tmpC + L;
+    S.sortStack = (int *)(S.tmpK + L);
+    S.P = P;
+
+    // ---- ordered gather of the FAST candidates (tile slots in cell-row-major order) --------------------
+    // flattened over the M candidates: lane e finds its tile by binary search in the prefix of the tile counts (LDS),
+    // so all slot loads are independent and stay in flight together
+    {
+        int *tileOff = (int *)S.prev;  // nTiles + 1 prefix offsets; `prev` is free until the sorted phase
+        int base = 0;
+        for (int tb = 0; tb < g.nTiles; tb += WAVE) {
+            const int t = tb + lane;
+            const int myN = t < g.nTiles ? tc[t] : 0;
+            int total;
+            const int myOff = wave_excl_scan(myN, total);
+            if (t < g.nTiles) tileOff[t] = base + myOff;
+            base += total;
+        }
+        if (lane == 0) tileOff[g.nTiles] = base;
+        qt_sync<true>();
+        const uint32_t *slots = a.cand + (size_t)f * a.candFrameStride + g.candBase;
+        for (int e = lane; e < M; e += WAVE) {
+            int lo = 0, hi = g.nTiles;  // largest t with tileOff[t] <= e
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (tileOff[mid] <= e) lo = mid; else hi = mid;
+            }
+            A[e] = slots[(size_t)lo * g.slotCap + (e - tileOff[lo])];
+        }
+    }
+    qt_sync<LDSK>();
+    if (a.stop == 1) { if (lane == 0) *selCnt = 0; return; }
+
+    // ---- roots (:589-626) -----------------------------------------------------------------------------
+    const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
+    const int N = g.quota;
+    const int nIni = (int)roundf(__fdiv_rn((float)W, (float)H));
+    const float hX = __fdiv_rn((float)W, (float)nIni);
+    S.size = 0; S.freeTop = 0; S.bump = 0; S.nSized = 0; S.nFront = 0; S.nC = 0; S.nK = 0;
+    int nOrder = 0;
+    {
+        int off = 0;
+        for (int r = 0; r < nIni; ++r) {
+            int cnt;
+            if (nIni == 1) cnt = M;
+            else {
+                cnt = 0;  // stable compaction of the keys whose root is r, appended to B
+                for (int base = 0; base < M; base += WAVE) {
+                    const bool act = base + lane < M;
+                    const uint32_t key = act ? A[base + lane] : 0u;
+                    const bool mine = act && (int)__fdiv_rn((float)(key & 0xFFF), hX) == r;
+                    const unsigned long long m = __ballot(mine);
+                    if (mine) B[off + cnt + __popcll(m & lanemask_lt())] = key;
+                    cnt += __popcll(m);
+                }
+            }
+            if (cnt > 0) {
+                const int id = S.bump++;
+                S.gx[id] = (int)__fmul_rn(hX, (float)r) | ((int)__fmul_rn(hX, (float)(r + 1)) << 16);
+                S.gy[id] = 0 | (H << 16);
+                S.beg[id] = off; S.cnt[id] = cnt;
+                S.fl[id] = (unsigned short)(QT_F_ALIVE | (cnt == 1 ? QT_F_NOMORE : 0));
+                S.order[nOrder++] = (short)id;  // push_back
+                ++S.size;
+            }
+            off += cnt;
+        }
+        if (nIni > 1) {
+            qt_sync<LDSK>();
+            for (int i = lane; i < M; i += WAVE) A[i] = B[i];
+        }
+    }
+    qt_sync<LDSK>();
+
+    if (a.stop == 2) { if (lane == 0) *selCnt = 0; return; }
+    // ---- subdivision (:630-752) -----------------------------------------------------------------------
+    bool finish = false;
+    while (!finish) {
+        // one walk over the list: every node with more than one key is divided; its children go to the list front
+        // in creation order, so the new list is reverse(children) followed by the untouched nodes
+        const int prevSize = S.size;
+        S.nSized = 0; S.nC = 0; S.nK = 0;
+        // 64 list entries per step: the nodes that are final (one key) are appended to tmpK in bulk, the others are
+        // divided one after the other in list order (their ids broadcast from the lanes' registers)
+        for (int base = 0; base < nOrder; base += WAVE) {
+            const int i = base + lane;
+            const int node = i < nOrder ? S.order[i] : 0;
+            const bool valid = i < nOrder;
+            const bool noMore = valid && (S.fl[node] & QT_F_NOMORE);
+            const unsigned long long mKeep = __ballot(noMore);
+            unsigned long long mDiv = __ballot(valid && !noMore);
+            if (noMore) S.tmpK[S.nK + __popcll(mKeep & lanemask_lt())] = (short)node;
+            S.nK += __popcll(mKeep);
+            while (mDiv) {
+                const int b = __ffsll((long long)mDiv) - 1;
+                mDiv &= mDiv - 1;
+                qt_divide<LDSK>(S, A, B, __builtin_amdgcn_readlane(node, b), 0);
+            }
+        }
+        qt_sync<LDSK>();
+        for (int j = lane; j < S.nC; j += WAVE) S.order[j] = S.tmpC[S.nC - 1 - j];
+        for (int j = lane; j < S.nK; j += WAVE) S.order[S.nC + j] = S.tmpK[j];
+        nOrder = S.nC + S.nK;
+        qt_sync<LDSK>();
+        const int nToExpand = S.nSized;
+        if (S.size >= N || S.size == prevSize) {
+            finish = true;
+        } else if (S.size + nToExpand * 3 > N) {
+            // sorted phase: divide the largest nodes first until the quota is reached (:701-751)
+            if (a.stop == 3) break;
+            while (!finish) {
+                const int prevSize2 = S.size;
+                const int nPrev = S.nSized;
+                S.nSized = 0;
+                if (false && nPrev <= 64 * QT_SORT_REGS) {  // lane-register sort measured 4x slower than the LDS sort (readlane hazards)
+                    QtLaneArr arr;
+                    {
+                        const qt_u64 v0 = lane < nPrev ? S.sized[lane] : 0ull, v1 = 64 + lane < nPrev ? S.sized[64 + lane] : 0ull;
+                        const qt_u64 v2 = 128 + lane < nPrev ? S.sized[128 + lane] : 0ull, v3 = 192 + lane < nPrev ? S.sized[192 + lane] : 0ull;
+                        arr.lo0 = (int)(unsigned)v0; arr.hi0 = (int)(unsigned)(v0 >> 32);
+                        arr.lo1 = (int)(unsigned)v1; arr.hi1 = (int)(unsigned)(v1 >> 32);
+                        arr.lo2 = (int)(unsigned)v2; arr.hi2 = (int)(unsigned)(v2 >> 32);
+                        arr.lo3 = (int)(unsigned)v3; arr.hi3 = (int)(unsigned)(v3 >> 32);
+                    }
+                    if (a.stop != 4) orbx_sort::sort_acc<qt_u64>(arr, nPrev, QtSizedLess(), S.sortStack);
+                    if (lane < nPrev) S.prev[lane] = ((qt_u64)(unsigned)arr.hi0 << 32) | (unsigned)arr.lo0;
+                    if (64 + lane < nPrev) S.prev[64 + lane] = ((qt_u64)(unsigned)arr.hi1 << 32) | (unsigned)arr.lo1;
+                    if (128 + lane < nPrev) S.prev[128 + lane] = ((qt_u64)(unsigned)arr.hi2 << 32) | (unsigned)arr.lo2;
+                    if (192 + lane < nPrev) S.prev[192 + lane] = ((qt_u64)(unsigned)arr.hi3 << 32) | (unsigned)arr.lo3;
+                } else {
+                    for (int i = lane; i < nPrev; i += WAVE) S.prev[i] = S.sized[i];
+                    qt_sync<LDSK>();
+                    if (lane == 0 && a.stop != 4) orbx_sort::sort(S.prev, nPrev, QtSizedLess(), S.sortStack);
+                }
+                qt_sync<LDSK>();
+                for (int j = nPrev - 1; j >= 0; --j) {
+                    // node ids are only recycled by a flatten: make room for 4 children first if the pool is nearly used up
+                    if (S.P - S.bump + S.freeTop < 4) {
+                        nOrder = qt_flatten<LDSK>(S, nOrder, S.tmpC);
+                        for (int i = lane; i < nOrder; i += WAVE) S.order[i] = S.tmpC[i];
+                        S.nFront = 0;
+                        S.freeTop = 0;
+                        for (int base = 0; base < S.bump; base += WAVE) {
+                            const int id = base + lane;
+                            const bool dead = id < S.bump && !(S.fl[id] & QT_F_ALIVE);
+                            const unsigned long long m = __ballot(dead);
+                            if (dead) S.freeL[S.freeTop + __popcll(m & lanemask_lt())] = (short)id;
+                            S.freeTop += __popcll(m);
+                        }
+                        qt_sync<LDSK>();
+                    }
+                    qt_divide<LDSK>(S, A, B, (int)(S.prev[j] & 0xFFFF), 1);
+                    if (S.size >= N) break;
+                }
+                if (S.size >= N || S.size == prevSize2) finish = true;
+            }
+        }
+    }
+
+    // ---- retain the best (first strictly greatest response) key of every node, in list order (:755-771) --
+    const int nFinal = qt_flatten<LDSK>(S, nOrder, S.tmpC);
+    for (int k = lane; k < nFinal; k += WAVE) {
+        const int node = S.tmpC[k];
+        const int b = S.beg[node], n = S.cnt[node];
+        uint32_t best = A[b];
+        for (int i = 1; i < n; ++i) {
+            const uint32_t key = A[b + i];
+            if ((key >> 24) > (best >> 24)) best = key;
+        }
+        selOut[k] = best;
+    }
+    if (lane == 0) *selCnt = nFinal;
+}
+
+static size_t qtNodeBytes(int P, int L)
+{
+    // gx, gy, beg, cnt (16 B) + fl, front, freeL (6 B) per pool entry; sized, prev (16 B) + order, tmpC, tmpK (6 B) per list entry
+    return (((size_t)P * 22 + (size_t)L * 22 + 216 * 4) + 15) & ~(size_t)15;
 }
 
 __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
@@ -999,140 +1248,27 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
     if (!xcd_decode(a.nframes, a.nlevels, f, level)) return;
     const int lane = threadIdx.x;
     const OrbxLevelGeom g = a.geoms[level];
-    const int P = a.pool;
-    QtState S;
-    S.gx = (int *)qlds; S.gy = S.gx + P; S.begin = S.gy + P; S.count = S.begin + P;
-    S.sized = (QtSized *)(S.count + P);
-    QtSized *prevArr = S.sized + P;
-    S.next = (short *)(prevArr + P); S.prev = S.next + P; S.noMore = S.prev + P; S.freeList = S.noMore + P;
-    short *ord = S.freeList + P;
-    uint32_t *ldsKeys = (uint32_t *)(qlds + (((size_t)P * (16 + 24 + 10)) + 15 & ~(size_t)15));
-
     uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
     int *selCnt = a.selCount + (size_t)f * a.nlevels + level;
-
-    // ---- ordered gather of the FAST candidates (tile slots in cell-row-major order) --------------------
     const int *tc = a.tileCount + (size_t)f * a.tilesPerFrame + g.tileBase;
     int M = 0;
-    for (int t = 0; t < g.nTiles; ++t) M += tc[t];
+    for (int tb = 0; tb < g.nTiles; tb += WAVE) {
+        int v = tb + lane < g.nTiles ? tc[tb + lane] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        M += v;
+    }
     if (M == 0) { if (lane == 0) *selCnt = 0; return; }
-    if (M <= QT_LDS_KEYS) { S.A = ldsKeys; S.B = ldsKeys + QT_LDS_KEYS; }
-    else {
-        S.A = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
-        S.B = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
+    // node / list arrays first (8-byte aligned: the 64-bit `sized` array follows 4 * P ints), keys after them
+    uint8_t *keysBase = qlds + ((((size_t)a.pool * 22 + (size_t)a.listCap * 22 + 216 * 4) + 15) & ~(size_t)15);
+    if (M <= QT_LDS_KEYS) {
+        uint32_t *A = (uint32_t *)keysBase, *B = A + QT_LDS_KEYS;
+        qt_body<true>(a, g, f, level, qlds, A, B, M, tc, selOut, selCnt);
+    } else {
+        uint32_t *A = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
+        uint32_t *B = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
+        qt_body<false>(a, g, f, level, qlds, A, B, M, tc, selOut, selCnt);
     }
-    {
-        const uint32_t *slots = a.cand + (size_t)f * a.candFrameStride + g.candBase;
-        int off = 0;
-        for (int t = 0; t < g.nTiles; ++t) {
-            const int n = tc[t];
-            const uint32_t *s = slots + (size_t)t * g.slotCap;
-            for (int i = lane; i < n; i += WAVE) S.A[off + i] = s[i];
-            off += n;
-        }
-    }
-    __syncthreads();
-    if (a.stop == 1) { if (lane == 0) *selCnt = 0; return; }
-
-    // ---- roots (:589-626) -----------------------------------------------------------------------------
-    const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
-    const int N = g.quota;
-    const int nIni = (int)roundf(__fdiv_rn((float)W, (float)H));
-    const float hX = __fdiv_rn((float)W, (float)nIni);
-    S.head = QT_NIL; S.size = 0; S.freeTop = 0; S.bump = 0; S.nSized = 0; S.nToExpand = 0;
-    {
-        int tail = QT_NIL, off = 0;
-        for (int r = 0; r < nIni; ++r) {
-            int cnt;
-            if (nIni == 1) cnt = M;
-            else {
-                // stable compaction of the keys whose root is r, appended to B
-                cnt = 0;
-                for (int base = 0; base < M; base += WAVE) {
-                    const bool act = base + lane < M;
-                    const uint32_t key = act ? S.A[base + lane] : 0u;
-                    const bool mine = act && (int)__fdiv_rn((float)(key & 0xFFF), hX) == r;
-                    const unsigned long long m = __ballot(mine);
-                    if (mine) S.B[off + cnt + __popcll(m & lanemask_lt())] = key;
-                    cnt += __popcll(m);
-                }
-            }
-            if (cnt > 0) {
-                const int id = S.bump++;
-                S.gx[id] = (int)__fmul_rn(hX, (float)r) | ((int)__fmul_rn(hX, (float)(r + 1)) << 16);
-                S.gy[id] = 0 | (H << 16);
-                S.begin[id] = off; S.count[id] = cnt; S.noMore[id] = (short)(cnt == 1);
-                // push_back
-                S.prev[id] = (short)tail; S.next[id] = QT_NIL;
-                if (tail != QT_NIL) S.next[tail] = (short)id; else S.head = id;
-                tail = id;
-                ++S.size;
-            }
-            off += cnt;
-        }
-        if (nIni > 1) {
-            __syncthreads();
-            for (int i = lane; i < M; i += WAVE) S.A[i] = S.B[i];
-        }
-    }
-    __syncthreads();
-
-    if (a.stop == 2) { if (lane == 0) *selCnt = 0; return; }
-    // ---- subdivision (:630-752) -----------------------------------------------------------------------
-    bool finish = false;
-    while (!finish) {
-        const int prevSize = S.size;
-        S.nToExpand = 0; S.nSized = 0;
-        int cur = S.head;
-        while (cur != QT_NIL) {
-            const int nxt = S.next[cur];
-            if (!S.noMore[cur]) qt_divide(S, cur);
-            cur = nxt;
-        }
-        if (S.size >= N || S.size == prevSize) {
-            finish = true;
-        } else if (S.size + S.nToExpand * 3 > N) {
-            if (a.stop == 3) break;
-            while (!finish) {
-                const int prevSize2 = S.size;
-                const int nPrev = S.nSized;
-                for (int i = lane; i < nPrev; i += WAVE) prevArr[i] = S.sized[i];
-                S.nSized = 0;
-                __syncthreads();
-                if (lane == 0 && a.stop != 4) orbx_sort::sort(prevArr, nPrev, QtSizedLess());
-                __syncthreads();
-                for (int j = nPrev - 1; j >= 0; --j) {
-                    qt_divide(S, prevArr[j].id);
-                    if (S.size >= N) break;
-                }
-                if (S.size >= N || S.size == prevSize2) finish = true;
-            }
-        }
-    }
-
-    // ---- retain the best (first strictly greatest response) key of every node, in list order (:755-771) --
-    {
-        int k = 0;
-        for (int cur = S.head; cur != QT_NIL; cur = S.next[cur]) ord[k++] = (short)cur;
-    }
-    __syncthreads();
-    for (int k = lane; k < S.size; k += WAVE) {
-        const int node = ord[k];
-        const int b = S.begin[node], n = S.count[node];
-        uint32_t best = S.A[b];
-        for (int i = 1; i < n; ++i) {
-            const uint32_t key = S.A[b + i];
-            if ((key >> 24) > (best >> 24)) best = key;
-        }
-        selOut[k] = best;
-    }
-    if (lane == 0) *selCnt = S.size;
-}
-
-static size_t qtLdsBytes(int P)
-{
-    size_t nodeBytes = ((size_t)P * (16 + 24 + 10) + 15) & ~(size_t)15;
-    return nodeBytes + (size_t)QT_LDS_KEYS * 2 * sizeof(uint32_t);
 }
 
 hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const OrbxLevelGeom *geomsHost,
@@ -1149,13 +1285,25 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     a.sel = sel; a.selFrameStride = selFrameStride; a.selCount = selCount;
     a.nlevels = nlevels; a.nframes = nframes;
     { static int stop = -1; if (stop < 0) { const char *e = getenv("ORBX_QT_STOP"); stop = e ? atoi(e) : 0; } a.stop = stop; }
-    a.pool = maxQuota + 24;
-    size_t lds = qtLdsBytes(a.pool);
+    a.listCap = (maxQuota + 16 + 3) & ~3;
+    a.pool = (2 * maxQuota + 64 + 3) & ~3;
+    {   // test hook: ORBX_QT_POOL_SLACK=k shrinks the pool to quota + k so that the tombstone compaction path runs
+        static int slack = -2;
+        if (slack == -2) { const char *e = getenv("ORBX_QT_POOL_SLACK"); slack = e ? atoi(e) : -1; }
+        if (slack >= 8) a.pool = (maxQuota + slack + 3) & ~3;
+    }
+    if (a.pool > 32767) return hipErrorInvalidValue;  // node ids are 15-bit
+    size_t lds = qtNodeBytes(a.pool, a.listCap) + (size_t)QT_LDS_KEYS * 2 * sizeof(uint32_t);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attrSet = false;
     if (!attrSet && lds > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
+    }
+    if (getenv("ORBX_DEBUG")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
+        fprintf(stderr, "[orbx] k_quadtree: pool %d, list %d, LDS %zu B, %d blocks/CU\n", a.pool, a.listCap, lds, nb);
     }
     hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(nframes, nlevels)), dim3(64), lds, st, a);
     return hipGetLastError();
