@@ -77,6 +77,7 @@ struct orbx_extractor {
     hipStream_t stream3 = nullptr;          // back stream: quadtree -> pack -> orientation + descriptors
     hipEvent_t evJoin = nullptr;
     hipEvent_t evFront[8] = {}, evBlur[8] = {};  // per sub-batch hand-offs between the streams
+    hipEvent_t evLevel[ORBX_MAX_LEVELS] = {};    // level l of the pyramid is complete (recorded after pyr_fast(l-1))
 
     // geometry of the current image size
     int curW = 0, curH = 0;
@@ -200,6 +201,7 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
         e = hipEventCreateWithFlags(&ex->evFront[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBlur[i], hipEventDisableTiming);
     }
+    for (int i = 0; i < ORBX_MAX_LEVELS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ex->evLevel[i], hipEventDisableTiming);
     if (e != hipSuccess) { orbx_destroy(ex); return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ex->d_raw.resize(nl); ex->d_blur.resize(nl);
     int rc = computeGeometry(ex, p->max_width, p->max_height);
@@ -221,6 +223,8 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
         if (ex->evFront[i]) (void)hipEventDestroy(ex->evFront[i]);
         if (ex->evBlur[i]) (void)hipEventDestroy(ex->evBlur[i]);
     }
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i)
+        if (ex->evLevel[i]) (void)hipEventDestroy(ex->evLevel[i]);
     for (auto &e : ex->events) (void)hipEventDestroy(e);
     ex->d_in.release();
     for (auto &b : ex->d_raw) b.release();
@@ -538,7 +542,13 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     const int subSize = ((nframes + nsub - 1) / nsub + 7) / 8 * 8;
     nsub = (nframes + subSize - 1) / subSize;
 
+    static const bool earlyBlur = [] { const char *e = getenv("ORBX_EARLY_BLUR"); return e ? atoi(e) != 0 : false; }();  // measured: 6.37 ms with early blur vs 6.02 ms with blur || quadtree
     hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * PROF_EVENTS] : nullptr;
+    if (earlyBlur) {
+        // the blur stream must not start on this batch's level 0 before the previous batch is done with the blur buffers
+        HIP_TRY(hipEventRecord(ex->evJoin, sFront));
+        HIP_TRY(hipStreamWaitEvent(sBlur, ex->evJoin, 0));
+    }
     for (int sb = 0; sb < nsub; ++sb) {
         const int f0 = sb * subSize, nf = std::min(subSize, nframes - f0);
         // ---- front: fused pyramid + FAST, one launch per level -----------------------------------------------
@@ -562,12 +572,17 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
                                       ex->d_cand.p + (size_t)f0 * ex->candFrameStride, ex->candFrameStride,
                                       ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame, ex->prm.ini_th_fast,
                                       ex->prm.min_th_fast));
+            if (l + 1 < nl && earlyBlur) {
+                // level l + 1 now exists: its GaussianBlur may start on the blur stream while the front stream goes on
+                // with pyr_fast(l + 1) (the fused kernel is barrier-bound, the blur fills its idle issue slots)
+                HIP_TRY(hipEventRecord(ex->evLevel[l + 1], sFront));
+            }
         }
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 0) * 2 + 1], sFront));
         HIP_TRY(hipEventRecord(ex->evFront[sb], sFront));
 
         // ---- blur stream: GaussianBlur of every level (needs only the pyramid) ---------------------------------
-        HIP_TRY(hipStreamWaitEvent(sBlur, ex->evFront[sb], 0));
+        if (!earlyBlur) HIP_TRY(hipStreamWaitEvent(sBlur, ex->evFront[sb], 0));
         static const bool noBlur = getenv("ORBX_NO_BLUR") != nullptr;  // timing experiments only
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 2) * 2], sBlur));
         for (int l = 0; l < nl && !noBlur; ++l) {
@@ -575,6 +590,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
             const uint8_t *src = l == 0 ? src0 + (size_t)f0 * frame_stride : ex->d_raw[l].p + (size_t)f0 * g.frameStride;
             const int srcPitch = l == 0 ? (int)stride : g.pitch;
             const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
+            if (earlyBlur && l > 0) HIP_TRY(hipStreamWaitEvent(sBlur, ex->evLevel[l], 0));
             HIP_TRY(orbxLaunchBlur(sBlur, nf, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p + (size_t)f0 * g.frameStride, g.pitch,
                                    g.frameStride, ex->taps));
         }
