@@ -206,6 +206,16 @@ int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, const uint8
                            const orbx_keypoint *kr, const uint8_t *dr, int nr, int n_rows, const float *scale_factors,
                            int nlevels, float min_d, float max_d, int32_t *best_idx, int32_t *best_dist);
 
+/* Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011: the row-band Hamming
+ * stage above, then for every accepted left keypoint the 11x11 L1 sliding-window refinement (+-5 px) on
+ * mvImagePyramid[octave] of the left / right extractor (the device-resident pyramids of frame `frame_left` /
+ * `frame_right` of each handle's last batch: no pyramid leaves the GPU), parabola fit, re-scaling, the disparity test
+ * with minD = 0, maxD = mbf / mb, and the median-based outlier rejection.  u_right[nl] / depth[nl] receive mvuRight /
+ * mvDepth (-1 where no match).  Keypoints / descriptors are the host arrays the extractors returned. */
+int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left, int frame_left, orbx_extractor *right, int frame_right,
+                                const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr, const uint8_t *dr, int nr,
+                                float mb, float mbf, float *u_right, float *depth);
+
 /* ---- utilities ---------------------------------------------------------------------------------- */
 
 /* Number of HIP devices (reference: Eden_resources::get_gpus_count, src/HipEdenResources/Ngpus_Ncpus.cpp). */

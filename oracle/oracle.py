@@ -53,6 +53,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_knn2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
         L.oracle_stereo_rows.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float,
                                          c_void_p, c_void_p]
+        L.oracle_stereo_matches.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float,
+                                            c_void_p, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -204,3 +206,16 @@ def stereo_rows(kl, dl, kr, dr, n_rows, scale_factors, min_d, max_d):
     lib().oracle_stereo_rows(kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data, len(kr), n_rows,
                              sf.ctypes.data, min_d, max_d, bi.ctypes.data, bd.ctypes.data)
     return bi, bd
+
+
+def stereo_matches(left: Oracle, right: Oracle, kl, dl, kr, dr, mb: float, mbf: float):
+    """Frame::ComputeStereoMatches on the pyramids of the two oracles' last extract(); returns (uRight, depth, n_valid_before_outlier_cut)."""
+    kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)
+    kr = np.ascontiguousarray(kr, KEYPOINT_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32)
+    dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+    ur = np.zeros(len(kl), np.float32)
+    dp = np.zeros(len(kl), np.float32)
+    n = lib().oracle_stereo_matches(left.h, right.h, kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data, len(kr),
+                                    mb, mbf, ur.ctypes.data, dp.ctypes.data)
+    return ur, dp, n

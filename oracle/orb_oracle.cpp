@@ -854,6 +854,97 @@ int oracle_stereo_rows(const oracle_keypoint *kl, const uint8_t *dl, int nl, con
     return 0;
 }
 
+// Frame::ComputeStereoMatches — reference src/Frame.cc:841-1011 (thOrbDist = (TH_HIGH + TH_LOW) / 2, :846).
+int oracle_stereo_matches(const oracle_handle *L, const oracle_handle *R, const oracle_keypoint *kl, const uint8_t *dl, int nl,
+                          const oracle_keypoint *kr, const uint8_t *dr, int nr, float mb, float mbf, float *uRightOut, float *depthOut)
+{
+    const int TH_HIGH = 100, TH_LOW = 50;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = L->pyr[0].h;
+    for (int i = 0; i < nl; ++i) { uRightOut[i] = -1.0f; depthOut[i] = -1.0f; }
+    std::vector<std::vector<int>> rowIdx(nRows);
+    for (int iR = 0; iR < nr; ++iR) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * L->scale[kr[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; ++yi)
+            if (yi >= 0 && yi < nRows) rowIdx[yi].push_back(iR);
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < nl; ++iL) {
+        const oracle_keypoint &kpL = kl[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        const int row = (int)vL;
+        if (row < 0 || row >= nRows) continue;
+        const std::vector<int> &cands = rowIdx[row];
+        if (cands.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        for (int iR : cands) {
+            const oracle_keypoint &kpR = kr[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = oracle_hamming256(dl + (size_t)iL * 32, dr + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = L->invScale[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5;
+            const Image &imL = L->pyr[kpL.octave], &imR = R->pyr[kpL.octave];
+            int bestDistS = INT_MAX, bestincR = 0;
+            const int Ls = 5;
+            float vDists[11];
+            const float iniu = scaleduR0 + Ls - w;
+            const float endu = scaleduR0 + Ls + w + 1;
+            if (iniu < 0 || endu >= imR.w) continue;
+            const int y0 = (int)(scaledvL - w), xL0 = (int)(scaleduL - w);
+            for (int incR = -Ls; incR <= +Ls; ++incR) {
+                const int xR0 = (int)(scaleduR0 + incR - w);
+                int sad = 0;
+                for (int yy = 0; yy < 2 * w + 1; ++yy)
+                    for (int xx = 0; xx < 2 * w + 1; ++xx)
+                        sad += std::abs((int)imL.row(y0 + yy)[xL0 + xx] - (int)imR.row(y0 + yy)[xR0 + xx]);
+                const float dist = (float)sad;  // cv::norm(IL, IR, NORM_L1)
+                if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[Ls + incR] = dist;
+            }
+            if (bestincR == -Ls || bestincR == Ls) continue;
+            const float dist1 = vDists[Ls + bestincR - 1], dist2 = vDists[Ls + bestincR], dist3 = vDists[Ls + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = L->scale[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }  // double literals, as in the reference (:985-986)
+                depthOut[iL] = mbf / disparity;
+                uRightOut[iL] = bestuR;
+                vDistIdx.push_back(std::make_pair(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0;  // the reference would index an empty vector here
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; --i) {
+        if (vDistIdx[i].first < thDist) break;
+        uRightOut[vDistIdx[i].second] = -1;
+        depthOut[vDistIdx[i].second] = -1;
+    }
+    return (int)vDistIdx.size();
+}
+
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride)
 {
     orbx_synth_frame_impl(seed, w, h, out, stride);

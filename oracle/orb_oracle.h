@@ -86,6 +86,13 @@ int oracle_stereo_rows(const oracle_keypoint *kl, const uint8_t *dl, int nl, con
                        const uint8_t *dr, int nr, int n_rows, const float *scale_factors, float min_d, float max_d,
                        int32_t *best_idx, int32_t *best_dist);
 
+/* Frame::ComputeStereoMatches, complete (reference src/Frame.cc:841-1011): row-band Hamming stage, 11x11 SAD
+ * sliding-window refinement on the pyramids of the two extractors' last oracle_extract(), parabola fit, disparity
+ * check and the median-based outlier rejection.  u_right[nl] / depth[nl] = -1 where no match (mvuRight / mvDepth). */
+int oracle_stereo_matches(const oracle_handle *left, const oracle_handle *right, const oracle_keypoint *kl, const uint8_t *dl,
+                          int nl, const oracle_keypoint *kr, const uint8_t *dr, int nr, float mb, float mbf, float *u_right,
+                          float *depth);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

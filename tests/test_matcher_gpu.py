@@ -85,3 +85,34 @@ def test_stereo_row_band_matcher(pkg, orc):
     assert np.all(bi == -1) and np.all(bd == pkg.TH_HIGH)
     ex.close()
     m.close()
+
+
+@pytest.mark.parametrize("shift,mb,mbf", [(20, 0.11, 47.9), (7, 0.11, 47.9), (35, 0.5373, 386.1448)])
+def test_compute_stereo_matches_full(pkg, orc, shift, mb, mbf):
+    """Frame::ComputeStereoMatches end to end (reference src/Frame.cc:841-1011): Hamming row-band stage + 11x11 SAD
+    refinement on the device-resident pyramids + parabola fit + median outlier cut, bit-exact floats vs the oracle."""
+    rng = np.random.default_rng(shift)
+    left = pkg.synth_frame(200 + shift, 752, 480)
+    right = np.roll(left, -shift, axis=1).copy()
+    right = np.clip(right.astype(np.int16) + rng.integers(-2, 3, right.shape), 0, 255).astype(np.uint8)  # not a pure copy
+    exL = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_width=752, max_height=480)
+    exR = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_width=752, max_height=480)
+    _, kl, dl = exL(left, None, (0, 0))
+    _, kr, dr = exR(right, None, (0, 0))
+    oL, oR = orc.Oracle(1200, 1.2, 8, 20, 7), orc.Oracle(1200, 1.2, 8, 20, 7)
+    _, rkl, rdl = oL.extract(left, (0, 0))
+    _, rkr, rdr = oR.extract(right, (0, 0))
+    assert kl.tobytes() == rkl.tobytes() and kr.tobytes() == rkr.tobytes()
+    m = pkg.ORBmatcher(2048, 2048)
+    ur, dp = m.ComputeStereoMatches(exL, exR, kl, dl, kr, dr, mb, mbf)
+    rur, rdp, nacc = orc.stereo_matches(oL, oR, rkl, rdl, rkr, rdr, mb, mbf)
+    assert np.array_equal(ur.view(np.uint32), rur.view(np.uint32))
+    assert np.array_equal(dp.view(np.uint32), rdp.view(np.uint32))
+    ok = ur >= 0
+    if mbf / mb > shift + 2:
+        assert ok.sum() > 200
+        assert np.median(kl["x"][ok] - ur[ok]) == pytest.approx(shift, abs=0.6)
+    # no right keypoints at all -> nothing matched
+    ur0, dp0 = m.ComputeStereoMatches(exL, exR, kl, dl, kr[:0], dr[:0], mb, mbf)
+    assert np.all(ur0 == -1) and np.all(dp0 == -1)
+    exL.close(); exR.close(); m.close()

@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
-    "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times",
+    "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -118,6 +118,8 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
     lib.orbx_synth_frame.restype = None
     lib.orbx_level_sizes.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_compute_stereo_matches.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                                c_float, c_float, c_void_p, c_void_p]
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -348,3 +350,17 @@ class ORBmatcher:
                                                 len(kr), n_rows, sf.ctypes.data, len(sf), min_d, max_d, bi.ctypes.data, bd.ctypes.data),
                "orbx_match_stereo_rows")
         return bi, bd
+
+    def ComputeStereoMatches(self, left: "ORBextractor", right: "ORBextractor", kl, dl, kr, dr, mb: float, mbf: float, frame_left: int = 0,
+                             frame_right: int = 0):
+        """Frame::ComputeStereoMatches (reference src/Frame.cc:841-1011) -> (mvuRight, mvDepth)."""
+        kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)
+        kr = np.ascontiguousarray(kr, KEYPOINT_DTYPE)
+        dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32)
+        dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+        ur = np.full(len(kl), -1, np.float32)
+        dp = np.full(len(kl), -1, np.float32)
+        _check(self._lib.orbx_compute_stereo_matches(self._h, left._h, frame_left, right._h, frame_right, kl.ctypes.data, dl.ctypes.data,
+                                                     len(kl), kr.ctypes.data, dr.ctypes.data, len(kr), mb, mbf, ur.ctypes.data,
+                                                     dp.ctypes.data), "orbx_compute_stereo_matches")
+        return ur, dp

@@ -788,7 +788,8 @@ struct orbx_matcher {
     DevBuf<uint8_t> d_q, d_t;
     DevBuf<int> d_idx, d_dist, d_mat;
     DevBuf<orbx_keypoint> d_kl, d_kr;
-    DevBuf<float> d_scale;
+    DevBuf<float> d_scale, d_uRight, d_depth;
+    DevBuf<int> d_sad;
 };
 
 extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orbx_matcher **out)
@@ -823,7 +824,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release();
-    m->d_kl.release(); m->d_kr.release(); m->d_scale.release();
+    m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
     delete m;
 }
 
@@ -899,6 +900,60 @@ extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, 
                                  m->d_idx.p, m->d_dist.p));
     HIP_TRY(hipMemcpyAsync(best_idx, m->d_idx.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(best_dist, m->d_dist.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+// Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011.
+extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left, int frame_left, orbx_extractor *right, int frame_right,
+                                           const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr, const uint8_t *dr,
+                                           int nr, float mb, float mbf, float *u_right, float *depth)
+{
+    if (!m || !left || !right || nl < 0 || nr < 0 || (nl > 0 && (!kl || !dl)) || (nr > 0 && (!kr || !dr)) || !u_right || !depth)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches: bad argument");
+    if (frame_left < 0 || frame_left >= left->lastFrames || frame_right < 0 || frame_right >= right->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches: frame index outside the extractors' last batch");
+    if (left->prm.device != m->device || right->prm.device != m->device)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches: matcher and extractors must live on the same device");
+    if (left->prm.nlevels != right->prm.nlevels || left->curW != right->curW || left->curH != right->curH)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches: left / right extractors differ in geometry");
+    if (nl == 0) return ORBX_OK;
+    const int nlev = left->prm.nlevels;
+    for (int i = 0; i < nl; ++i)
+        if (kl[i].octave < 0 || kl[i].octave >= nlev) return setError(ORBX_ERR_INVALID_ARG, "left keypoint %d has octave %d", i, kl[i].octave);
+    for (int i = 0; i < nr; ++i)
+        if (kr[i].octave < 0 || kr[i].octave >= nlev) return setError(ORBX_ERR_INVALID_ARG, "right keypoint %d has octave %d", i, kr[i].octave);
+    HIP_TRY(hipSetDevice(m->device));
+    // the pyramids must be complete before the matcher stream reads them
+    HIP_TRY(hipStreamSynchronize(left->stream));
+    HIP_TRY(hipStreamSynchronize(right->stream));
+    int rc = uploadQT(m, dl, nl, dr, nr);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = m->d_uRight.ensure(m->maxQ)) != ORBX_OK || (rc = m->d_depth.ensure(m->maxQ)) != ORBX_OK || (rc = m->d_sad.ensure(m->maxQ)) != ORBX_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p, left->scale.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const float minZ = mb, minD = 0.f, maxD = mbf / minZ;
+    const int nRows = left->geom[0].h;  // mvImagePyramid[0].rows (:848)
+    HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, nRows, m->d_scale.p, minD, maxD,
+                                 m->d_idx.p, m->d_dist.p));
+    OrbxStereoLevels lv;
+    memset(&lv, 0, sizeof lv);
+    for (int l = 0; l < nlev; ++l) {
+        const OrbxLevelGeom &g = left->geom[l];
+        lv.left[l] = l == 0 ? left->lastSrc + (size_t)frame_left * left->lastSrcFrameStride : left->d_raw[l].p + (size_t)frame_left * g.frameStride;
+        lv.right[l] = l == 0 ? right->lastSrc + (size_t)frame_right * right->lastSrcFrameStride : right->d_raw[l].p + (size_t)frame_right * g.frameStride;
+        lv.pitchL[l] = l == 0 ? left->lastSrcPitch : g.pitch;
+        lv.pitchR[l] = l == 0 ? right->lastSrcPitch : g.pitch;
+        lv.colsR[l] = g.w;
+        lv.scale[l] = left->scale[l];
+        lv.invScale[l] = left->invScale[l];
+    }
+    HIP_TRY(orbxLaunchStereoRefine(m->stream, &lv, m->d_kl.p, nl, m->d_kr.p, m->d_idx.p, m->d_dist.p, mbf, minD, maxD, m->d_uRight.p,
+                                   m->d_depth.p, m->d_sad.p));
+    HIP_TRY(hipMemcpyAsync(u_right, m->d_uRight.p, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(depth, m->d_depth.p, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }

@@ -98,4 +98,14 @@ hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *d
                                 const uint8_t *dr, int nr, int nRows, const float *scaleDev, float minD, float maxD,
                                 int *bestIdx, int *bestDist);
 
+// stereo refinement (orbx_match.hip); `levels` points to a host StereoLevelsHost with the layout below
+struct OrbxStereoLevels {
+    const uint8_t *left[ORBX_MAX_LEVELS], *right[ORBX_MAX_LEVELS];
+    int pitchL[ORBX_MAX_LEVELS], pitchR[ORBX_MAX_LEVELS];
+    int colsR[ORBX_MAX_LEVELS];
+    float scale[ORBX_MAX_LEVELS], invScale[ORBX_MAX_LEVELS];
+};
+hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void *kl, int nl, const void *kr, const int *bestIdx,
+                                  const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist);
+
 #endif

@@ -156,3 +156,143 @@ hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *d
                        dr, nr, nRows, scaleDev, minD, maxD, bestIdx, bestDist);
     return hipGetLastError();
 }
+
+// =====================================================================================================
+// Sub-pixel stereo refinement — Frame::ComputeStereoMatches, reference src/Frame.cc:926-1011
+// (the step right after the row-band Hamming stage; it reads mvImagePyramid of both extractors,
+// which stays on the device here).  One wave per left keypoint: 11x11 L1 (cv::norm NORM_L1) between the left patch and
+// 11 shifted right patches, parabola fit through the best three, re-scale, disparity test.
+// =====================================================================================================
+struct StereoLevels {
+    const uint8_t *left[ORBX_MAX_LEVELS], *right[ORBX_MAX_LEVELS];
+    int pitchL[ORBX_MAX_LEVELS], pitchR[ORBX_MAX_LEVELS];
+    int colsR[ORBX_MAX_LEVELS];
+    float scale[ORBX_MAX_LEVELS], invScale[ORBX_MAX_LEVELS];
+};
+
+__device__ __forceinline__ int mt_wave_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);
+    return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+           __builtin_amdgcn_readlane(x, 48);
+}
+
+__global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp *kl, int nl, const MtKp *kr, const int *bestIdx,
+                                                    const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth,
+                                                    int *sadDist)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nl) return;
+    float outU = -1.0f, outD = -1.0f;
+    int outS = -1;
+    const int bi = bestIdx[i], bd = bestDist[i];
+    if (bi >= 0 && bd < (100 + 50) / 2) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2  (:846, :927)
+        const MtKp kpL = kl[i];
+        const int oct = kpL.octave;
+        const float uL = kpL.x;
+        const float uR0 = kr[bi].x;
+        const float sf = lv.invScale[oct];
+        const float scaleduL = roundf(__fmul_rn(kpL.x, sf));
+        const float scaledvL = roundf(__fmul_rn(kpL.y, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const int w = 5, L = 5;
+        const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)L), (float)w);
+        const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)L), (float)w), 1.0f);
+        if (!(iniu < 0 || endu >= (float)lv.colsR[oct])) {
+            const int y0 = (int)__fsub_rn(scaledvL, (float)w), xL0 = (int)__fsub_rn(scaleduL, (float)w);
+            const int xRb = (int)scaleduR0 - w;  // first column of the unshifted right patch
+            const uint8_t *pl = lv.left[oct] + (size_t)y0 * lv.pitchL[oct] + xL0;
+            const uint8_t *pr = lv.right[oct] + (size_t)y0 * lv.pitchR[oct] + xRb;
+            // lane handles patch pixels p0 = lane and p1 = lane + 64 (121 pixels)
+            const int p0 = lane, p1 = lane + 64;
+            const int y0p = p0 / 11, x0p = p0 - y0p * 11, y1p = p1 / 11, x1p = p1 - y1p * 11;
+            const bool has1 = p1 < 121;
+            const int a0 = pl[y0p * lv.pitchL[oct] + x0p];
+            const int a1 = has1 ? pl[y1p * lv.pitchL[oct] + x1p] : 0;
+            int sad[11];
+#pragma unroll
+            for (int inc = 0; inc < 11; ++inc) {
+                const int b0 = pr[y0p * lv.pitchR[oct] + x0p + inc - L];
+                const int b1 = has1 ? pr[y1p * lv.pitchR[oct] + x1p + inc - L] : 0;
+                const int d0 = a0 - b0, d1 = a1 - b1;
+                sad[inc] = (d0 < 0 ? -d0 : d0) + (has1 ? (d1 < 0 ? -d1 : d1) : 0);
+            }
+            int best = INT_MAX, bestInc = 0;
+            int tot[11];
+#pragma unroll
+            for (int inc = 0; inc < 11; ++inc) {
+                tot[inc] = mt_wave_sum(sad[inc]);
+                if (tot[inc] < best) { best = tot[inc]; bestInc = inc - L; }
+            }
+            if (!(bestInc == -L || bestInc == L)) {
+                float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
+#pragma unroll
+                for (int inc = 1; inc < 10; ++inc)
+                    if (inc - L == bestInc) { dist1 = (float)tot[inc - 1]; dist2 = (float)tot[inc]; dist3 = (float)tot[inc + 1]; }
+                const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = __fmul_rn(lv.scale[oct], __fadd_rn(__fadd_rn(scaleduR0, (float)bestInc), deltaR));
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = (float)0.01;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        outD = __fdiv_rn(mbf, disparity);
+                        outU = bestuR;
+                        outS = best;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) { uRight[i] = outU; depth[i] = outD; sadDist[i] = outS; }
+}
+
+// median-based outlier rejection (:996-1010): median = SAD at rank size/2 of the accepted matches (a k-th order
+// statistic, no sort needed), thDist = 1.5f * 1.4f * median; every match with SAD >= thDist is dropped.
+__global__ __launch_bounds__(256) void k_stereo_outliers(int nl, float *uRight, float *depth, const int *sadDist)
+{
+    __shared__ int red[4];
+    __shared__ int total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto blockCount = [&](int thr) {  // number of accepted matches with SAD <= thr
+        int c = 0;
+        for (int i = tid; i < nl; i += 256) { const int s = sadDist[i]; c += (s >= 0 && s <= thr); }
+        c = mt_wave_sum(c);
+        __syncthreads();
+        if (lane == 0) red[wave] = c;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    const int valid = blockCount(INT_MAX);
+    if (valid == 0) return;
+    const int k = valid / 2;  // rank of vDistIdx[size / 2]
+    int lo = 0, hi = 121 * 255;
+    while (lo < hi) {  // smallest v with count(SAD <= v) >= k + 1
+        const int mid = (lo + hi) >> 1;
+        if (blockCount(mid) >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    const float thDist = __fmul_rn(1.5f * 1.4f, (float)lo);
+    for (int i = tid; i < nl; i += 256) {
+        const int s = sadDist[i];
+        if (s >= 0 && !((float)s < thDist)) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    }
+    (void)total;
+}
+
+hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void *kl, int nl, const void *kr, const int *bestIdx,
+                                  const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist)
+{
+    if (nl <= 0) return hipSuccess;
+    const StereoLevels &lv = *(const StereoLevels *)levels;
+    hipLaunchKernelGGL(k_stereo_sad, dim3((nl + 3) / 4), dim3(256), 0, st, lv, (const MtKp *)kl, nl, (const MtKp *)kr, bestIdx, bestDist,
+                       mbf, minD, maxD, uRight, depth, sadDist);
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(256), 0, st, nl, uRight, depth, sadDist);
+    return hipGetLastError();
+}
