@@ -429,7 +429,7 @@ static int ensureBuffers(orbx_extractor *ex)
         if ((rc = ex->d_blur[l].ensure(B * g.frameStride + 64)) != ORBX_OK) return rc;
     }
     ex->inPitch = ex->geom[0].pitch;
-    ex->inFrameStride = ex->geom[0].frameStride;
+    ex->inFrameStride = (long long)ex->inPitch * ex->geom[0].h;  // rows of consecutive frames are contiguous: one bulk H2D copy per batch
     if ((rc = ex->d_in.ensure(B * ex->inFrameStride + 64)) != ORBX_OK) return rc;
     if ((rc = ex->d_cand.ensure(B * ex->candFrameStride)) != ORBX_OK) return rc;
     if ((rc = ex->d_scratchA.ensure(B * ex->candFrameStride)) != ORBX_OK) return rc;
@@ -663,14 +663,21 @@ extern "C" int orbx_download_outputs(orbx_extractor *ex, int nframes, orbx_keypo
     HIP_TRY(hipMemcpyAsync(mono.data(), ex->d_mono.p, nframes * sizeof(int32_t), hipMemcpyDeviceToHost, ex->stream));
     HIP_TRY(hipStreamSynchronize(ex->stream));
     const int cap = ex->maxKeypoints;
-    for (int f = 0; f < nframes; ++f) {
+    for (int f = 0; f < nframes; ++f)
         if (n[f] > capacity) return setError(ORBX_ERR_CAPACITY, "frame %d has %d keypoints, output capacity is %d", f, n[f], capacity);
-        if (kps && n[f] > 0)
-            HIP_TRY(hipMemcpyAsync(kps + (size_t)f * capacity, ex->d_kps.p + (size_t)f * cap, (size_t)n[f] * sizeof(orbx_keypoint),
-                                   hipMemcpyDeviceToHost, ex->stream));
-        if (desc && n[f] > 0)
-            HIP_TRY(hipMemcpyAsync(desc + (size_t)f * capacity * 32, ex->d_desc.p + (size_t)f * cap * 32, (size_t)n[f] * 32,
-                                   hipMemcpyDeviceToHost, ex->stream));
+    if (capacity == cap && nframes > 1) {
+        // same per-frame capacity on both sides: two bulk copies (rows beyond n[f] are unspecified)
+        if (kps) HIP_TRY(hipMemcpyAsync(kps, ex->d_kps.p, (size_t)nframes * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->stream));
+        if (desc) HIP_TRY(hipMemcpyAsync(desc, ex->d_desc.p, (size_t)nframes * cap * 32, hipMemcpyDeviceToHost, ex->stream));
+    } else {
+        for (int f = 0; f < nframes; ++f) {
+            if (kps && n[f] > 0)
+                HIP_TRY(hipMemcpyAsync(kps + (size_t)f * capacity, ex->d_kps.p + (size_t)f * cap, (size_t)n[f] * sizeof(orbx_keypoint),
+                                       hipMemcpyDeviceToHost, ex->stream));
+            if (desc && n[f] > 0)
+                HIP_TRY(hipMemcpyAsync(desc + (size_t)f * capacity * 32, ex->d_desc.p + (size_t)f * cap * 32, (size_t)n[f] * 32,
+                                       hipMemcpyDeviceToHost, ex->stream));
+        }
     }
     HIP_TRY(hipStreamSynchronize(ex->stream));
     for (int f = 0; f < nframes; ++f) {
@@ -691,9 +698,15 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
     int rc = computeGeometry(ex, w, h);
     if (rc != ORBX_OK) return rc;
     if ((rc = ensureBuffers(ex)) != ORBX_OK) return rc;
-    for (int f = 0; f < nframes; ++f)
-        HIP_TRY(hipMemcpy2DAsync(ex->d_in.p + (size_t)f * ex->inFrameStride, ex->inPitch, imgs + (size_t)f * frame_stride, stride, w, h,
-                                 hipMemcpyHostToDevice, ex->stream));
+    // H2D staging: one 2-D copy for the whole batch when the frames are row-contiguous (rows of all frames form one
+    // [nframes * h] x w matrix with a constant row pitch on both sides), else one 2-D copy per frame
+    if (frame_stride == (ptrdiff_t)stride * h && ex->inFrameStride == (long long)ex->inPitch * h) {
+        HIP_TRY(hipMemcpy2DAsync(ex->d_in.p, ex->inPitch, imgs, stride, w, (size_t)h * nframes, hipMemcpyHostToDevice, ex->stream));
+    } else {
+        for (int f = 0; f < nframes; ++f)
+            HIP_TRY(hipMemcpy2DAsync(ex->d_in.p + (size_t)f * ex->inFrameStride, ex->inPitch, imgs + (size_t)f * frame_stride, stride, w, h,
+                                     hipMemcpyHostToDevice, ex->stream));
+    }
     rc = orbx_extract_batch_device(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1);
     if (rc != ORBX_OK) return rc;
     return orbx_download_outputs(ex, nframes, kps, desc, capacity, n_out, mono_out);
