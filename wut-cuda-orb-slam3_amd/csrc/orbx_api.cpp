@@ -194,8 +194,15 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     memcpy(ex->taps, p->blur_variant == ORBX_BLUR_OPENCV_451 ? t451 : t450, sizeof ex->taps);
 
     hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->stream3, hipStreamNonBlocking);
+    {
+        // blur stream above / back (quadtree) stream below the front stream: the quadtree's single-wave, LDS-heavy
+        // workgroups are long-lived, so the throughput kernels should get free CU resources first
+        int prLo = 0, prHi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);  // lo = numerically largest = lowest priority
+        static const int mode = [] { const char *q = getenv("ORBX_STREAM_PRIO"); return q ? atoi(q) : 0; }();  // measured: no gain (6.03 vs 5.98 ms)
+        if (e == hipSuccess) e = mode ? hipStreamCreateWithPriority(&ex->stream2, hipStreamNonBlocking, prHi) : hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = mode ? hipStreamCreateWithPriority(&ex->stream3, hipStreamNonBlocking, prLo) : hipStreamCreateWithFlags(&ex->stream3, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evJoin, hipEventDisableTiming);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&ex->evFront[i], hipEventDisableTiming);

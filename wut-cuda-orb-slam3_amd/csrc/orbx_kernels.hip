@@ -993,7 +993,7 @@ __device__ __forceinline__ void qt_divide(QtCtx &S, KP A, KP B, int node, int mo
 #pragma unroll
             for (int k = 0; k < 4; ++k) run[k] += __popcll(m[k]);
         }
-        qt_sync<LDSK>();
+        qt_sync<false>();  // B is global scratch: wait for the stores (vmcnt) before other lanes read them back
         for (int i = lane; i < cnt; i += WAVE) A[begin + i] = B[begin + i];
     }
     // the parent's id is free for its own children in an outer pass (nothing refers to it any more)
@@ -1129,7 +1129,7 @@ __device__ void qt_body(const QtArgs &a, const OrbxLevelGeom &g, int f, int leve
             off += cnt;
         }
         if (nIni > 1) {
-            qt_sync<LDSK>();
+            qt_sync<false>();
             for (int i = lane; i < M; i += WAVE) A[i] = B[i];
         }
     }
@@ -1261,12 +1261,14 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
     if (M == 0) { if (lane == 0) *selCnt = 0; return; }
     // node / list arrays first (8-byte aligned: the 64-bit `sized` array follows 4 * P ints), keys after them
     uint8_t *keysBase = qlds + ((((size_t)a.pool * 22 + (size_t)a.listCap * 22 + 216 * 4) + 15) & ~(size_t)15);
+    // second key buffer: only used while a node still holds more than 64 keys (the first few divides), so it lives in
+    // global scratch and the LDS footprint of an instance stays at ~25 KB (6 instances per CU)
+    uint32_t *B = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
     if (M <= QT_LDS_KEYS) {
-        uint32_t *A = (uint32_t *)keysBase, *B = A + QT_LDS_KEYS;
+        uint32_t *A = (uint32_t *)keysBase;
         qt_body<true>(a, g, f, level, qlds, A, B, M, tc, selOut, selCnt);
     } else {
         uint32_t *A = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
-        uint32_t *B = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
         qt_body<false>(a, g, f, level, qlds, A, B, M, tc, selOut, selCnt);
     }
 }
@@ -1293,7 +1295,7 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
         if (slack >= 8) a.pool = (maxQuota + slack + 3) & ~3;
     }
     if (a.pool > 32767) return hipErrorInvalidValue;  // node ids are 15-bit
-    size_t lds = qtNodeBytes(a.pool, a.listCap) + (size_t)QT_LDS_KEYS * 2 * sizeof(uint32_t);
+    size_t lds = qtNodeBytes(a.pool, a.listCap) + (size_t)QT_LDS_KEYS * sizeof(uint32_t);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attrSet = false;
     if (!attrSet && lds > 48 * 1024) {
