@@ -299,7 +299,7 @@ __device__ __forceinline__ void pf_score_one(const uint8_t *tile, uint8_t *score
     const int sc = fast_corner_score(tile + (rowOff + r) * tp + c, tp);
     score[(r + 1) * tp + c] = (uint8_t)(sc >= minEff ? sc : 0);
 }
-__device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *colInfo, uint32_t *bits, int tp, int r, int c,
+__device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *colInfo, uint32_t *bits, int *cnt, int tp, int r, int c,
                                            int cInt0, int wCell, int hCell, int wpc)
 {
     const uint8_t *s1p = score + (r + 1) * tp + c, *s0p = s1p - tp, *s2p = s1p + tp;
@@ -313,7 +313,9 @@ __device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *
         if (sc > mx) {
             const int cell = ci & 0x3F;
             const int cx = xi - cell * wCell;
-            atomicOr(&bits[(cell * hCell + r) * wpc + (cx >> 5)], 1u << (cx & 31));
+            const uint32_t bit = 1u << (cx & 31);
+            const uint32_t old = atomicOr(&bits[(cell * hCell + r) * wpc + (cx >> 5)], bit);
+            if (!(old & bit)) atomicAdd(&cnt[cell], 1);  // the overflow path may visit a pixel twice: count a bit once
         }
     }
 }
@@ -358,9 +360,8 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
     uint16_t *cq = gq + g.gqCap;                                      // ring-test survivors: row << 9 | interior column
     uint8_t *gqm = (uint8_t *)(cq + PF_QCAP);                         // corner mask of each queued group (overflow path)
     uint8_t *colInfo = gqm + g.gqCap;                                 // per interior column
-    __shared__ int cnt[PF_MAX_GROUP_CELLS], cellOff[PF_MAX_GROUP_CELLS + 1];
-    __shared__ unsigned char cellEmpty[PF_MAX_GROUP_CELLS];
-    __shared__ unsigned gqCount, cqCount, anyEmpty;
+    __shared__ int cnt[PF_MAX_GROUP_CELLS];                 // keypoints per cell (LDS atomics in the NMS phase)
+    __shared__ unsigned gqCountR[2], cqCountR[2];           // queue fill counters, one pair per round (no reset barrier)
 
     // ---- stage the tile: coalesced 16-byte loads of row-major image rows into LDS ------------------------
     const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
@@ -399,7 +400,8 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         const int nb = g.groupCells * cellWords;
         for (int i = otid(); i < nb; i += PF_NT) bits[i] = 0;
     }
-    if (tid < PF_MAX_GROUP_CELLS) cellEmpty[tid] = 1;
+    if (tid < PF_MAX_GROUP_CELLS) cnt[tid] = 0;
+    if (tid < 2) { gqCountR[tid] = 0; cqCountR[tid] = 0; }
     // per interior column: cell index | bit7 first column of its cell | bit6 last column
     for (int x = otid(); x < TWi; x += PF_NT) {
         int cell = x / g.wCell, cx = x - cell * g.wCell;
@@ -480,16 +482,17 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
     for (int round = 0; round < 2; ++round) {
         const int th = round == 0 ? iniTh : minTh;
         const int thEff = max(th, 1);
-        if (round == 1 && (minTh >= iniTh || anyEmpty == 0)) break;   // uniform: LDS flag written before the last barrier
+        if (round == 1) {
+            // cells without a keypoint after round 0 (cnt is complete: barrier at the end of the NMS phase)
+            bool anyEmpty = false;
+            for (int c = 0; c < nCells; ++c) anyEmpty |= cnt[c] == 0;
+            if (minTh >= iniTh || !anyEmpty) break;  // uniform
+        }
         const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
-        if (tid == 0) { gqCount = 0; cqCount = 0; }
-        __syncthreads();
 
         // (A) pre-test
-        int tidA = tid;
-        asm volatile("" : "+v"(tidA));  // keep per-lane address arithmetic local to the phase (no hoisting -> no spills)
         if (a.phases & 2)
-        for (int it = tidA; it < nItems; it += PF_NT) {
+        for (int it = otid(); it < nItems; it += PF_NT) {
             const int r = (int)(((float)it + 0.5f) * invNS);
             const int sI = it - r * NS, s = s0 + sI;
             const int cbase = 8 * s + 4;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
             unsigned valid = (0xFFu >> (8 - phi)) & (0xFFu << plo);          // interior pixels of the strip
             if (round == 1) {                                                // ... that lie in a still-empty cell
                 unsigned keep = 0;
-                for (int i = plo; i < phi; ++i) keep |= (unsigned)cellEmpty[colInfo[cbase + i - cInt0] & 0x3F] << i;
+                for (int i = plo; i < phi; ++i) keep |= (unsigned)(cnt[colInfo[cbase + i - cInt0] & 0x3F] == 0) << i;
                 valid &= keep;
             }
             if (!valid) continue;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
             const unsigned m = (((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4)) & valid;
             const unsigned g0 = (m & 0x0F) != 0, g1 = (m & 0xF0) != 0;
             if (g0 | g1) {
-                unsigned pos = atomicAdd(&gqCount, g0 + g1);
+                unsigned pos = atomicAdd(&gqCountR[round], g0 + g1);
                 const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
                 if (g0) gq[pos++] = (uint16_t)e;
                 if (g1) gq[pos] = (uint16_t)(e | 1u);
@@ -524,11 +527,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         }
         __syncthreads();
 
-        // (B) full ring test of the queued groups
-        const unsigned gn = gqCount;
-        int tidB = tid;
-        asm volatile("" : "+v"(tidB));
-        for (unsigned i = tidB; i < gn; i += PF_NT) {
+        // (B) full ring test of the queued groups -> corner queue
+        const unsigned gn = gqCountR[round];
+        for (unsigned i = otid(); i < gn; i += PF_NT) {
             const unsigned e = gq[i];
             const int r = e >> 9, sg = e & 511;
             const int cb = 8 * s0 + 4 * sg;                       // window start: the group's pixels are bytes 4..7
@@ -538,96 +539,63 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
             unsigned m = ((fl * 0x00204081u) >> 28) & (0xFu >> (4 - phi)) & (0xFu << plo);
             if (round == 1 && m) {
                 unsigned keep = 0;
-                for (int k = plo; k < phi; ++k) keep |= (unsigned)cellEmpty[colInfo[c4 + k - cInt0] & 0x3F] << k;
+                for (int k = plo; k < phi; ++k) keep |= (unsigned)(cnt[colInfo[c4 + k - cInt0] & 0x3F] == 0) << k;
                 m &= keep;
             }
-            gqm[i] = (uint8_t)m;
             if (m) {
-                unsigned pos = atomicAdd(&cqCount, (unsigned)__popc(m));
+                unsigned pos = atomicAdd(&cqCountR[round], (unsigned)__popc(m));
                 while (m) {
                     const int k = __ffs(m) - 1;
                     m &= m - 1;
                     if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
+                    else pf_score_one(tile, score, tp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
                     ++pos;
                 }
             }
         }
         __syncthreads();
 
-        // (C) score, (D) NMS
-        const unsigned qn = cqCount;
+        // (C) dense corner score (merging it into (B) measured slower: 3.26 vs 3.0 ms — divergent scoring loops)
+        const unsigned qn = cqCountR[round];
+        for (unsigned i = otid(); i < min(qn, (unsigned)PF_QCAP); i += PF_NT) {
+            const unsigned e = cq[i];
+            pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
+        }
+        __syncthreads();
+
+        // (D) cell-local NMS -> bitmaps; (E) per-cell counts by LDS atomics
         if (qn <= PF_QCAP) {
-            if (!(a.phases & 16))
-            for (unsigned i = otid(); i < qn; i += PF_NT) {
-                const unsigned e = cq[i];
-                pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
-            }
-            __syncthreads();
             if (a.phases & 4)
             for (unsigned i = otid(); i < qn; i += PF_NT) {
                 const unsigned e = cq[i];
-                pf_nms_one(score, colInfo, bits, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc);
+                pf_nms_one(score, colInfo, bits, cnt, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc);
             }
         } else {
-            // corner queue overflow (pathological corner density): per-group loops over the ring-test masks
+            // corner queue overflow (pathological corner density): NMS over every scored pixel of the queued groups
             for (unsigned i = otid(); i < gn; i += PF_NT) {
                 const unsigned e = gq[i];
                 const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
-                unsigned m = gqm[i];
-                while (m) {
-                    const int k = __ffs(m) - 1;
-                    m &= m - 1;
-                    pf_score_one(tile, score, tp, rowOff, r, c4 + k, thEff);
-                }
-            }
-            __syncthreads();
-            for (unsigned i = otid(); i < gn; i += PF_NT) {
-                const unsigned e = gq[i];
-                const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
-                unsigned m = gqm[i];
-                while (m) {
-                    const int k = __ffs(m) - 1;
-                    m &= m - 1;
-                    pf_nms_one(score, colInfo, bits, tp, r, c4 + k, cInt0, g.wCell, g.hCell, wpc);
-                }
-            }
-        }
-        if (tid == 0) anyEmpty = 0;
-        __syncthreads();
-
-        // (E) keypoints per cell (wave per cell, lane per row)
-        for (int c = wave; c < nCells; c += PF_NW) {
-            int n = 0;
-            for (int r = lane; r < THi; r += 64)
-                for (int k = 0; k < wpc; ++k) n += __popc(bits[(c * g.hCell + r) * wpc + k]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
-            if (lane == 0) {
-                cnt[c] = n;
-                cellEmpty[c] = n == 0;
-                if (n == 0) anyEmpty = 1;
+                for (int k = 0; k < 4; ++k)
+                    if (c4 + k >= cInt0 && c4 + k < cInt1)
+                        pf_nms_one(score, colInfo, bits, cnt, tp, r, c4 + k, cInt0, g.wCell, g.hCell, wpc);
             }
         }
         __syncthreads();
     }
     if (!(a.phases & 8)) return;
-    if (tid == 0) {
-        int off = 0;
-        for (int c = 0; c < nCells; ++c) {
-            cellOff[c] = off;
-            off += cnt[c];
-        }
-        cellOff[nCells] = off;
-        a.tileCount[(size_t)f * a.tilesPerFrame + g.tileBase + crow * g.nGroups + grp] = off;
-    }
-    __syncthreads();
 
     // ---- ordered emission: cells in order, raster inside a cell (== tileCalcKeypoints emission order) ----
     uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + g.candBase +
                      (size_t)(crow * g.nGroups + grp) * g.slotCap;
+    if (tid == 0) {
+        int tot = 0;
+        for (int c = 0; c < nCells; ++c) tot += cnt[c];
+        a.tileCount[(size_t)f * a.tilesPerFrame + g.tileBase + crow * g.nGroups + grp] = tot;
+    }
     for (int c = wave; c < nCells; c += PF_NW) {
         const uint32_t *cbits = bits + (size_t)c * cellWords;
-        int base = cellOff[c];
+        int base = 0;
+        for (int q = 0; q < c; ++q) base += cnt[q];
         const int cellC0 = cInt0 + c * g.wCell;
         for (int rb = 0; rb < THi; rb += 64) {
             const int r = rb + lane;
@@ -767,36 +735,55 @@ __global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
     const uint32_t k0 = a.taps[0], k1 = a.taps[1], k2 = a.taps[2], k3 = a.taps[3];
     const int rowsNeeded = min(BL2_TH, a.h - y0) + 6;
 
-    for (int it = tid; it < rowsNeeded * BL2_GW; it += 256) {
-        const int r = it >> 5, g = it & 31;
-        const int x = x0 + 4 * g;
-        uint32_t oe = 0, oo = 0;
+    // horizontal pass: one item = 8 adjacent output pixels (two 4-px groups sharing four aligned source dwords)
+    auto group4 = [&](const uint8_t *row, int x, uint32_t &oe, uint32_t &oo) {  // generic 4-px group (image borders)
+        if (x >= 4 && x + 7 < a.w) {
+            const uint32_t *p = (const uint32_t *)(row + x);
+            const uint32_t w0 = p[-1], w1 = p[0], w2 = p[1];
+            const uint32_t M = 0x00FF00FFu;
+            const uint32_t em3 = bl_alignbyte(w1, w0, 1) & M, em2 = bl_alignbyte(w1, w0, 2) & M, em1 = bl_alignbyte(w1, w0, 3) & M;
+            const uint32_t e0 = w1 & M, e1 = bl_alignbyte(w2, w1, 1) & M, e2 = bl_alignbyte(w2, w1, 2) & M;
+            const uint32_t e3 = bl_alignbyte(w2, w1, 3) & M, e4 = w2 & M;
+            oe = k0 * (em3 + e3) + k1 * (em2 + e2) + k2 * (em1 + e1) + k3 * e0;
+            oo = k0 * (em2 + e4) + k1 * (em1 + e3) + k2 * (e0 + e2) + k3 * e1;
+        } else {
+            uint32_t sv[10];  // REFLECT_101 per byte
+#pragma unroll
+            for (int j = 0; j < 10; ++j) sv[j] = row[reflect101(x - 3 + j, a.w)];
+            uint32_t t4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                t4[i] = k0 * (sv[i] + sv[i + 6]) + k1 * (sv[i + 1] + sv[i + 5]) + k2 * (sv[i + 2] + sv[i + 4]) + k3 * sv[i + 3];
+            oe = t4[0] | (t4[2] << 16);
+            oo = t4[1] | (t4[3] << 16);
+        }
+    };
+    for (int it = tid; it < rowsNeeded * (BL2_GW / 2); it += 256) {
+        const int r = it >> 4, gp = it & 15;
+        const int x = x0 + 8 * gp;
+        uint32_t oeA = 0, ooA = 0, oeB = 0, ooB = 0;
         if (x < a.w) {
             const int gy = reflect101(y0 + r - 3, a.h);
             const uint8_t *row = srcF + (size_t)gy * a.srcPitch;
-            if (x >= 4 && x + 7 < a.w) {
+            if (x >= 4 && x + 11 < a.w) {
                 const uint32_t *p = (const uint32_t *)(row + x);
-                const uint32_t w0 = p[-1], w1 = p[0], w2 = p[1];
+                const uint32_t w0 = p[-1], w1 = p[0], w2 = p[1], w3 = p[2];
                 const uint32_t M = 0x00FF00FFu;
                 const uint32_t em3 = bl_alignbyte(w1, w0, 1) & M, em2 = bl_alignbyte(w1, w0, 2) & M, em1 = bl_alignbyte(w1, w0, 3) & M;
-                const uint32_t e0 = w1 & M, e1 = bl_alignbyte(w2, w1, 1) & M, e2 = bl_alignbyte(w2, w1, 2) & M;
-                const uint32_t e3 = bl_alignbyte(w2, w1, 3) & M, e4 = w2 & M;
-                oe = k0 * (em3 + e3) + k1 * (em2 + e2) + k2 * (em1 + e1) + k3 * e0;
-                oo = k0 * (em2 + e4) + k1 * (em1 + e3) + k2 * (e0 + e2) + k3 * e1;
+                const uint32_t e0 = w1 & M, e1 = bl_alignbyte(w2, w1, 1) & M, e2 = bl_alignbyte(w2, w1, 2) & M, e3 = bl_alignbyte(w2, w1, 3) & M;
+                const uint32_t e4 = w2 & M, e5 = bl_alignbyte(w3, w2, 1) & M, e6 = bl_alignbyte(w3, w2, 2) & M, e7 = bl_alignbyte(w3, w2, 3) & M;
+                const uint32_t e8 = w3 & M;
+                oeA = k0 * (em3 + e3) + k1 * (em2 + e2) + k2 * (em1 + e1) + k3 * e0;
+                ooA = k0 * (em2 + e4) + k1 * (em1 + e3) + k2 * (e0 + e2) + k3 * e1;
+                oeB = k0 * (e1 + e7) + k1 * (e2 + e6) + k2 * (e3 + e5) + k3 * e4;
+                ooB = k0 * (e2 + e8) + k1 * (e3 + e7) + k2 * (e4 + e6) + k3 * e5;
             } else {
-                // image border: REFLECT_101 per byte
-                uint32_t s[10];
-#pragma unroll
-                for (int j = 0; j < 10; ++j) s[j] = row[reflect101(x - 3 + j, a.w)];
-                uint32_t t[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    t[i] = k0 * (s[i] + s[i + 6]) + k1 * (s[i + 1] + s[i + 5]) + k2 * (s[i + 2] + s[i + 4]) + k3 * s[i + 3];
-                oe = t[0] | (t[2] << 16);
-                oo = t[1] | (t[3] << 16);
+                group4(row, x, oeA, ooA);
+                if (x + 4 < a.w) group4(row, x + 4, oeB, ooB);
             }
         }
-        T[r][g] = make_uint2(oe, oo);
+        T[r][2 * gp] = make_uint2(oeA, ooA);
+        T[r][2 * gp + 1] = make_uint2(oeB, ooB);
     }
     __syncthreads();
 
