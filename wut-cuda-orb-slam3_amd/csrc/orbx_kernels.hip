@@ -111,71 +111,26 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp)
     return max(a, -b) - 1;
 }
 
-// Ring test for the 8 pixels of one strip — byte-SWAR, 4 pixels per 32-bit operation.
+// FAST-9/16 ring test — byte-SWAR, 4 pixels (one "group") per 32-bit operation.
 //
 // Measured on gfx950 (profiles/r01_valu_microbench.txt): v_and/v_or/v_add/v_sub/v_bitop3/shifts issue at 2
 // cycles per wave64, while SDWA forms, v_alignbit, min/max, v_pk_*, v_perm, v_bfi and v_mad issue at 4.  So the
 // test is phrased in full-rate ops only (plus one v_alignbyte per ring position to fetch 4 unaligned bytes):
-//   * w[j] holds 16 consecutive tile bytes of row (y - 3 + j); strip pixel i is byte 4 + i of the centre row;
-//     a group = 4 adjacent pixels = one dword V of centres; ring position k of the group = the dword P_k at byte
-//     offset (dx_k, dy_k) from it.
+//   * a group = 4 adjacent pixels = one dword V of centres; ring position k of the group = the (unaligned) dword
+//     P_k at byte offset (dx_k, dy_k) from it, fetched from the LDS tile as two aligned dwords + one v_alignbyte.
 //   * per byte "P < LO" (dark) and "P > HI" (bright) with LO = v - th, HI = v + th use the borrow-free 7+1-bit
 //     compare: t = (Pl + (0x80 - LOl)) has bit 7 = [Pl >= LOl]; flag = (~P7 & LO7) | (~(P7 ^ LO7) & ~t7).
 //     LO / HI wrap modulo 256; pixels whose v - th < 0 (v + th > 255) cannot have dark (bright) ring pixels and
 //     are masked once at the end.
 //   * the flags stay transposed (one word per ring position, bit 7 of each byte = one pixel); ">= 9 contiguous"
 //     = OR over the 16 arcs of the AND of 9 consecutive words, with 3-input ANDs (v_bitop3).
-// Returns the 8-bit corner mask of the strip.
+// Returns the flags of the 4 pixels in bit 7 of each byte.
 #define SW_H 0x80808080u
 #define SW_L 0x7F7F7F7Fu
 
-template <int GRP>
-__device__ __forceinline__ uint32_t fast_group_flags(const uint32_t (&w)[7][4], uint32_t T4, uint32_t C4)
-{
-    const uint32_t V = w[3][1 + GRP];
-    const uint32_t Vl = V & SW_L;
-    // LO = V - th, HI = V + th (per byte, wrapping) and their validity
-    const uint32_t tS = (V | SW_H) - (T4 & SW_L);                                  // bit7 = [Vl >= Tl]
-    const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
-    const uint32_t ltVT = (~V & T4) | (~(V ^ T4) & ~tS);                           // bit7 = [V < th]
-    const uint32_t HI = (Vl + (T4 & SW_L)) ^ ((V ^ T4) & SW_H);
-    const uint32_t tC = (C4 | SW_H) - Vl;                                          // C = 255 - th
-    const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);                           // bit7 = [255 - th < V]
-    const uint32_t Kd = SW_H - (LO & SW_L);
-    const uint32_t HIh = HI | SW_H;
-    uint32_t D[16], B[16];
-#define RING(k, dx, dy)                                                                            \
-    {                                                                                              \
-        constexpr int o = 4 + 4 * GRP + (dx);                                                      \
-        const uint32_t P = (o & 3) == 0 ? w[3 + (dy)][o >> 2]                                      \
-                                        : __builtin_amdgcn_alignbyte(w[3 + (dy)][(o >> 2) + 1], w[3 + (dy)][o >> 2], o & 3); \
-        const uint32_t Pl = P & SW_L;                                                              \
-        const uint32_t td = Pl + Kd;                                                               \
-        const uint32_t tb = HIh - Pl;                                                              \
-        D[k] = (~P & LO) | (~(P ^ LO) & ~td);                                                      \
-        B[k] = (~HI & P) | (~(HI ^ P) & ~tb);                                                      \
-    }
-    RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
-    RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2) RING(15, -1, 3)
-#undef RING
-    uint32_t d3[16], b3[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        d3[k] = D[k] & D[(k + 1) & 15] & D[(k + 2) & 15];
-        b3[k] = B[k] & B[(k + 1) & 15] & B[(k + 2) & 15];
-    }
-    uint32_t rd = 0, rb = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        rd |= d3[k] & d3[(k + 3) & 15] & d3[(k + 6) & 15];
-        rb |= b3[k] & b3[(k + 3) & 15] & b3[(k + 6) & 15];
-    }
-    return ((rd & ~ltVT) | (rb & ~ltCV)) & SW_H;
-}
-
-// Same test for ONE 4-pixel group whose pixels are bytes 4..7 of a 16-byte LDS window starting at `wp` (row y-3;
-// 4-byte aligned), fetching each ring dword pair from LDS on demand instead of holding the 7 x 16-byte window in
-// registers: ~50 VGPRs instead of ~75, so the kernel reaches 8 waves/SIMD without scratch spills.
+// The group's pixels are bytes 4..7 of a 16-byte LDS window starting at `wp` (row y-3; 4-byte aligned).  Each ring dword
+// pair is fetched from LDS on demand instead of holding a 7 x 16-byte window in registers: ~50 VGPRs instead of ~75,
+// so the kernel reaches 8 waves/SIMD without scratch spills.
 __device__ __forceinline__ uint32_t fast_group_flags_lds(const uint8_t *wp, int tp, uint32_t T4, uint32_t C4)
 {
     const uint32_t V = *(const uint32_t *)(wp + 3 * tp + 4);
@@ -216,15 +171,6 @@ __device__ __forceinline__ uint32_t fast_group_flags_lds(const uint8_t *wp, int 
         rb |= b3[k] & b3[(k + 3) & 15] & b3[(k + 6) & 15];
     }
     return ((rd & ~ltVT) | (rb & ~ltCV)) & SW_H;
-}
-
-__device__ __forceinline__ unsigned fast_strip_mask(const uint32_t (&w)[7][4], int th)
-{
-    const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
-    const uint32_t f0 = fast_group_flags<0>(w, T4, C4);
-    const uint32_t f1 = fast_group_flags<1>(w, T4, C4);
-    // gather bits 7/15/23/31 of each group into a nibble
-    return ((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4);
 }
 
 // Cheap necessary condition for the ring test of one 4-pixel group: a contiguous arc of 9 ring pixels contains two
@@ -283,7 +229,9 @@ struct PyrFastArgs {
     int *tileCount; int tilesPerFrame;
     int iniTh, minTh;
     int nframes;
-    int phases;  // debug/ablation mask (ORBX_PF_PHASES): 1 resize, 2 ring test+score, 4 NMS, 8 count+emit
+    int phases;  // debug/ablation mask (ORBX_PF_PHASES): 1 resize, 2 ring test+score, 4 NMS, 8 count+emit;
+                 // bits 4..7 = stop point for instruction-count profiles (tools/pmc_phases.sh): return after 1 tile load,
+                 // 2 LDS setup, 3 resize, 4 pre-test, 5 ring test, 6 score, 7 NMS (round 0)
 };
 
 #define PF_MAX_GROUP_CELLS 32
@@ -320,10 +268,15 @@ __device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *
     }
 }
 
-__global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
+__global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const OrbxLevelGeom &g = a.g;
+    // The argument block is read in place from the kernarg segment (constant address space), field by field where it is
+    // used: as a by-value parameter all ~60 dwords are loaded in the prologue and then live (spilled to VGPR lanes at the
+    // 80-SGPR budget that 8 waves/SIMD allows) for the whole kernel.
+    typedef const __attribute__((address_space(4))) PyrFastArgs KArgs;
+    KArgs &a = *(KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) OrbxLevelGeom &g = a.g;
     int f, tileId;
     if (!xcd_decode(a.nframes, g.nTiles, f, tileId)) return;
     const int crow = tileId / g.nGroups, grp = tileId - crow * g.nGroups;
@@ -368,7 +321,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
     const int nRowsL = ly1 - ly0;
     if (a.srcAlign == 16) {
         const int nV = (lx1 - ax0 + 15) >> 4;
-        const float invNV = 1.0f / (float)nV;
+        const float invNV = __builtin_amdgcn_rcpf((float)nV);  // 1-ulp reciprocal: the quotients below sit >= 0.5/n from an integer
         const int n = nRowsL * nV;
         for (int it = otid(); it < n; it += PF_NT) {
             const int r = (int)(((float)it + 0.5f) * invNV);
@@ -378,33 +331,42 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         }
     } else if (a.srcAlign == 4) {
         const int nDw = (lx1 - ax0 + 3) >> 2;
+#pragma nounroll
         for (int r = wave; r < nRowsL; r += PF_NW) {
             const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0);
             uint32_t *trow = (uint32_t *)(tile + r * tp + PF_XO);
-            for (int c = lane; c < nDw; c += 64) trow[c] = srow[c];
+#pragma nounroll
+            for (int c = otid() & 63; c < nDw; c += 64) trow[c] = srow[c];
         }
     } else {
         const int nB = lx1 - ax0;
+#pragma nounroll
         for (int r = wave; r < nRowsL; r += PF_NW) {
             const uint8_t *srow = srcF + (size_t)(ly0 + r) * a.srcPitch + ax0;
             uint8_t *trow = tile + r * tp + PF_XO;
-            for (int c = lane; c < nB; c += 64) trow[c] = srow[c];
+#pragma nounroll
+            for (int c = otid() & 63; c < nB; c += 64) trow[c] = srow[c];
         }
     }
+    if ((a.phases >> 4) == 1) return;
     // zero the score tile and the per-cell NMS bitmaps (16-byte stores)
     {
         uint4 z = make_uint4(0, 0, 0, 0);
         uint4 *zs = (uint4 *)score;
         const int nz = ((g.hCell + 2) * tp) >> 4;
+#pragma nounroll
         for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
         const int nb = g.groupCells * cellWords;
+#pragma nounroll
         for (int i = otid(); i < nb; i += PF_NT) bits[i] = 0;
     }
     if (tid < PF_MAX_GROUP_CELLS) cnt[tid] = 0;
     if (tid < 2) { gqCountR[tid] = 0; cqCountR[tid] = 0; }
     // per interior column: cell index | bit7 first column of its cell | bit6 last column
+    const float invWC = __builtin_amdgcn_rcpf((float)g.wCell);
+#pragma nounroll
     for (int x = otid(); x < TWi; x += PF_NT) {
-        int cell = x / g.wCell, cx = x - cell * g.wCell;
+        int cell = (int)(((float)x + 0.5f) * invWC), cx = x - cell * g.wCell;
         int cw = min(g.wCell, TWi - cell * g.wCell);
         colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
     }
@@ -414,47 +376,52 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
     if (doResize) {
         dy0 = a.tabs.rowBeg[crow]; dy1 = a.tabs.rowBeg[crow + 1];
         dx0 = a.tabs.colBeg[grp]; dx1 = a.tabs.colBeg[grp + 1];
+#pragma nounroll
         for (int i = otid(); i < dx1 - dx0; i += PF_NT) {
-            const int sx0 = a.tabs.xofs[dx0 + i];
-            xt[i] = make_int2((sx0 + colOf0) | ((min(sx0 + 1, g.w - 1) + colOf0) << 16), a.tabs.xab[dx0 + i]);
+            // the right tap is always the next LDS column: where cv::resize clamps sx to w - 1 its weight is 0
+            xt[i] = make_int2(a.tabs.xofs[dx0 + i] + colOf0, a.tabs.xab[dx0 + i]);
         }
+#pragma nounroll
         for (int i = otid(); i < dy1 - dy0; i += PF_NT) {
             const int sy = a.tabs.yofs[dy0 + i];
             const int sy0 = min(max(sy, 0), g.h - 1) - ly0, sy1 = min(max(sy + 1, 0), g.h - 1) - ly0;
-            yt[i] = make_int2(sy0 | (sy1 << 16), a.tabs.yab[dy0 + i]);
+            yt[i] = make_int2((sy0 * tp) | ((sy1 * tp) << 16), a.tabs.yab[dy0 + i]);  // LDS byte offsets of the two source rows
         }
     }
     __syncthreads();
+    if ((a.phases >> 4) == 2) return;
 
     // ---- next pyramid level: cv::resize INTER_LINEAR fixed point; 4 px per lane -------
     if (doResize) {
         uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
         const int q0 = dx0 >> 2, q1 = (dx1 + 3) >> 2;
+        const int waveU = __builtin_amdgcn_readfirstlane(wave);  // rows are wave-uniform: row entry and weights in SGPRs
         for (int q = q0 + lane; q < q1; q += 64) {
-            int ca[4], cb[4], wa[4], wb[4];
+            int ca[4], wa[4], wb[4];
             bool ok[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int dx = q * 4 + j;
                 ok[j] = dx >= dx0 && dx < dx1;
                 const int2 e = xt[min(max(dx, dx0), dx1 - 1) - dx0];
-                ca[j] = e.x & 0xFFFF;
-                cb[j] = e.x >> 16;
+                ca[j] = e.x;
                 wa[j] = (short)(e.y & 0xFFFF);
                 wb[j] = e.y >> 16;
             }
             const bool full = ok[0] && ok[3];
-            for (int dy = dy0 + wave; dy < dy1; dy += PF_NW) {
+            for (int dy = dy0 + waveU; dy < dy1; dy += PF_NW) {
                 const int2 ye = yt[dy - dy0];
-                const int b0 = (short)(ye.y & 0xFFFF), b1 = ye.y >> 16;
-                const uint8_t *r0 = tile + (ye.x & 0xFFFF) * tp;
-                const uint8_t *r1 = tile + (ye.x >> 16) * tp;
+                const int yo = __builtin_amdgcn_readfirstlane(ye.x), yw = __builtin_amdgcn_readfirstlane(ye.y);
+                const int b0 = yw & 0xFFFF, b1 = (unsigned)yw >> 16;  // weights are in [0, 2048]
+                const uint8_t *r0 = tile + (yo & 0xFFFF);
+                const uint8_t *r1 = tile + ((unsigned)yo >> 16);
                 uint32_t packed = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int h0 = r0[ca[j]] * wa[j] + r0[cb[j]] * wb[j];
-                    const int h1 = r1[ca[j]] * wa[j] + r1[cb[j]] * wb[j];
-                    const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
+                    const int h0 = r0[ca[j]] * wa[j] + r0[ca[j] + 1] * wb[j];
+                    const int h1 = r1[ca[j]] * wa[j] + r1[ca[j] + 1] * wb[j];
+                    // <= 255: the weights of each axis sum to 2048
+                    const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
                     packed |= v << (8 * j);
                 }
                 uint8_t *drow = dstF + (size_t)dy * a.dstPitch + q * 4;
@@ -468,6 +435,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
         }
     }
 
+    if ((a.phases >> 4) == 3) return;
     // ---- FAST-9/16 + cell-local NMS, in the reference's two rounds -----------------------------------------------
     // round 0: threshold iniThFAST everywhere; round 1: threshold minThFAST, only in cells that produced no keypoint
     // in round 0 (tileCalcKeypoints :908-925).  Each round: (A) 4-point pre-test on 8-pixel strips -> LDS queue of
@@ -476,35 +444,23 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
     const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
     const int s0 = (cInt0 - 4) >> 3, s1 = (cInt1 - 1 - 4) >> 3;  // strips cover LDS columns [8s + 4, 8s + 12)
     const int NS = s1 - s0 + 1;
-    const float invNS = 1.0f / (float)NS;
+    const float invNS = __builtin_amdgcn_rcpf((float)NS);
     const int nItems = NS * THi;
     const int rowOff = ty0 - ly0;
     for (int round = 0; round < 2; ++round) {
         const int th = round == 0 ? iniTh : minTh;
         const int thEff = max(th, 1);
+        unsigned eMask = 0;  // round 1: cells without a keypoint after round 0 (cnt is complete: barrier at the end of the NMS phase)
         if (round == 1) {
-            // cells without a keypoint after round 0 (cnt is complete: barrier at the end of the NMS phase)
-            bool anyEmpty = false;
-            for (int c = 0; c < nCells; ++c) anyEmpty |= cnt[c] == 0;
-            if (minTh >= iniTh || !anyEmpty) break;  // uniform
+            for (int c = 0; c < nCells; ++c) eMask |= (unsigned)(cnt[c] == 0) << c;
+            eMask = __builtin_amdgcn_readfirstlane(eMask);
+            if (minTh >= iniTh || !eMask) break;  // uniform
         }
         const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
 
-        // (A) pre-test
-        if (a.phases & 2)
-        for (int it = otid(); it < nItems; it += PF_NT) {
-            const int r = (int)(((float)it + 0.5f) * invNS);
-            const int sI = it - r * NS, s = s0 + sI;
-            const int cbase = 8 * s + 4;
-            const int plo = max(cInt0 - cbase, 0), phi = min(cInt1 - cbase, 8);
-            unsigned valid = (0xFFu >> (8 - phi)) & (0xFFu << plo);          // interior pixels of the strip
-            if (round == 1) {                                                // ... that lie in a still-empty cell
-                unsigned keep = 0;
-                for (int i = plo; i < phi; ++i) keep |= (unsigned)(cnt[colInfo[cbase + i - cInt0] & 0x3F] == 0) << i;
-                valid &= keep;
-            }
-            if (!valid) continue;
-            const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * s;
+        // (A) pre-test of one 8-pixel strip (row r, strip sI of the tile, `valid` = its candidate pixels)
+        auto preTest = [&](int r, int sI, unsigned valid) {
+            const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * (s0 + sI);
             uint32_t w0[4], w3[4], w6[4];
             {
                 const uint2 a0 = *(const uint2 *)(wp), a1 = *(const uint2 *)(wp + 8);
@@ -524,8 +480,43 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
                 if (g0) gq[pos++] = (uint16_t)e;
                 if (g1) gq[pos] = (uint16_t)(e | 1u);
             }
+        };
+        if (!(a.phases & 2)) {
+        } else if (round == 0) {
+            for (int it = otid(); it < nItems; it += PF_NT) {
+                const int r = (int)(((float)it + 0.5f) * invNS);
+                const int sI = it - r * NS;
+                const int cbase = 8 * (s0 + sI) + 4;
+                const int plo = max(cInt0 - cbase, 0), phi = min(cInt1 - cbase, 8);
+                preTest(r, sI, (0xFFu >> (8 - phi)) & (0xFFu << plo));          // interior pixels of the strip
+            }
+        } else {
+            // only the strips of still-empty cells, one cell at a time (cell geometry in SGPRs).  A strip that straddles two
+            // empty cells is tested once, with the left one.
+            int visit = 0;
+            for (unsigned em = eMask; em; em &= em - 1, ++visit) {
+                const int c = __ffs(em) - 1;
+                const bool prevEmpty = c > 0 && ((eMask >> (c - 1)) & 1u), nextEmpty = ((eMask >> 1) >> c) & 1u;
+                const int cc0 = cInt0 + c * g.wCell, cc1 = min(cc0 + g.wCell, cInt1);
+                int sF = (cc0 - 4) >> 3;
+                const int sL = (cc1 - 1 - 4) >> 3;
+                if (prevEmpty && 8 * sF + 4 < cc0) ++sF;
+                const int vhi = nextEmpty ? min(cc1 + g.wCell, cInt1) : cc1;
+                const int nS = sL - sF + 1;
+                if (nS <= 0) continue;
+                const float invS = __builtin_amdgcn_rcpf((float)nS);
+                // alternate the half of the workgroup that takes a cell's (usually < 256) strips
+                for (int it = (otid() + visit * (PF_NT / 2)) & (PF_NT - 1); it < nS * THi; it += PF_NT) {
+                    const int r = (int)(((float)it + 0.5f) * invS);
+                    const int s = sF + (it - r * nS);
+                    const int cbase = 8 * s + 4;
+                    const int plo = max(cc0 - cbase, 0), phi = min(vhi - cbase, 8);
+                    preTest(r, s - s0, (0xFFu >> (8 - phi)) & (0xFFu << plo));
+                }
+            }
         }
         __syncthreads();
+        if ((a.phases >> 4) == 4) return;
 
         // (B) full ring test of the queued groups -> corner queue
         const unsigned gn = gqCountR[round];
@@ -538,9 +529,13 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
             const int plo = max(cInt0 - c4, 0), phi = min(cInt1 - c4, 4);
             unsigned m = ((fl * 0x00204081u) >> 28) & (0xFu >> (4 - phi)) & (0xFu << plo);
             if (round == 1 && m) {
-                unsigned keep = 0;
-                for (int k = plo; k < phi; ++k) keep |= (unsigned)(cnt[colInfo[c4 + k - cInt0] & 0x3F] == 0) << k;
-                m &= keep;
+                // keep the pixels that lie in a still-empty cell; a group overlaps at most two cells (cells are >= 35 px wide)
+                const int x0 = c4 + plo - cInt0, n = phi - plo;
+                const int cl = colInfo[x0] & 0x3F, ch = colInfo[x0 + n - 1] & 0x3F;
+                const int b = min(max(ch * g.wCell - x0, 0), n);  // first pixel of cell ch (0 when cl == ch)
+                const unsigned all = (1u << n) - 1u, lo = (1u << b) - 1u;
+                const unsigned keep = (((eMask >> cl) & 1u) ? lo : 0u) | (((eMask >> ch) & 1u) ? all & ~lo : 0u);
+                m &= keep << plo;
             }
             if (m) {
                 unsigned pos = atomicAdd(&cqCountR[round], (unsigned)__popc(m));
@@ -554,6 +549,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
             }
         }
         __syncthreads();
+        if ((a.phases >> 4) == 5) return;
 
         // (C) dense corner score (merging it into (B) measured slower: 3.26 vs 3.0 ms — divergent scoring loops)
         const unsigned qn = cqCountR[round];
@@ -562,6 +558,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
             pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
         }
         __syncthreads();
+        if ((a.phases >> 4) == 6) return;
 
         // (D) cell-local NMS -> bitmaps; (E) per-cell counts by LDS atomics
         if (qn <= PF_QCAP) {
@@ -581,6 +578,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs a)
             }
         }
         __syncthreads();
+        if ((a.phases >> 4) == 7) return;
     }
     if (!(a.phases & 8)) return;
 
@@ -849,7 +847,6 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
 // doubly linked list in LDS; the std::sort tie order with the libstdc++ introsort emulation.
 // =====================================================================================================
 #define QT_LDS_KEYS 2048   // candidates of one (frame, level) held in LDS (two buffers); larger sets use global scratch
-#define QT_SORT_REGS 4     // std::sort emulation in lane registers for up to 64 * QT_SORT_REGS elements
 
 typedef unsigned long long qt_u64;
 
@@ -870,33 +867,6 @@ struct QtArgs {
 // orders by (count, UL.x) only = key >> 16
 struct QtSizedLess {
     __host__ __device__ __forceinline__ bool operator()(qt_u64 a, qt_u64 b) const { return (a >> 16) < (b >> 16); }
-};
-
-// up to 64 * QT_SORT_REGS elements spread over the lanes of the wave: element i = lane (i & 63), register (i >> 6).
-// Indices are wave-uniform, so get is v_readlane and the sort's control flow is scalar.  Plain scalar members (no
-// arrays) so that the accessor stays in VGPRs after inlining instead of being demoted to scratch memory.
-struct QtLaneArr {
-    int lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3;
-    __device__ __forceinline__ qt_u64 get(int i) const
-    {
-        const int l = i & 63, r = i >> 6;
-        const int vl = r == 0 ? lo0 : (r == 1 ? lo1 : (r == 2 ? lo2 : lo3));
-        const int vh = r == 0 ? hi0 : (r == 1 ? hi1 : (r == 2 ? hi2 : hi3));
-        const int a = __builtin_amdgcn_readlane(vl, l), b = __builtin_amdgcn_readlane(vh, l);
-        return ((qt_u64)(unsigned)b << 32) | (unsigned)a;
-    }
-    // v_writelane with two scalar operands exceeds gfx9's one-SGPR constant-bus limit (it would need M0); a compare +
-    // select on the lane id is just as good here
-    __device__ __forceinline__ void set(int i, qt_u64 v)
-    {
-        const int r = i >> 6;
-        const bool me = (int)(threadIdx.x & 63) == (i & 63);
-        const int a = (int)(unsigned)v, b = (int)(unsigned)(v >> 32);
-        lo0 = (me && r == 0) ? a : lo0; hi0 = (me && r == 0) ? b : hi0;
-        lo1 = (me && r == 1) ? a : lo1; hi1 = (me && r == 1) ? b : hi1;
-        lo2 = (me && r == 2) ? a : lo2; hi2 = (me && r == 2) ? b : hi2;
-        lo3 = (me && r == 3) ? a : lo3; hi3 = (me && r == 3) ? b : hi3;
-    }
 };
 
 // the workgroup is a single wave: ordering only has to hold inside the wave
@@ -1162,22 +1132,8 @@ __device__ void qt_body(const QtArgs &a, const OrbxLevelGeom &g, int f, int leve
                 const int prevSize2 = S.size;
                 const int nPrev = S.nSized;
                 S.nSized = 0;
-                if (false && nPrev <= 64 * QT_SORT_REGS) {  // lane-register sort measured 4x slower than the LDS sort (readlane hazards)
-                    QtLaneArr arr;
-                    {
-                        const qt_u64 v0 = lane < nPrev ? S.sized[lane] : 0ull, v1 = 64 + lane < nPrev ? S.sized[64 + lane] : 0ull;
-                        const qt_u64 v2 = 128 + lane < nPrev ? S.sized[128 + lane] : 0ull, v3 = 192 + lane < nPrev ? S.sized[192 + lane] : 0ull;
-                        arr.lo0 = (int)(unsigned)v0; arr.hi0 = (int)(unsigned)(v0 >> 32);
-                        arr.lo1 = (int)(unsigned)v1; arr.hi1 = (int)(unsigned)(v1 >> 32);
-                        arr.lo2 = (int)(unsigned)v2; arr.hi2 = (int)(unsigned)(v2 >> 32);
-                        arr.lo3 = (int)(unsigned)v3; arr.hi3 = (int)(unsigned)(v3 >> 32);
-                    }
-                    if (a.stop != 4) orbx_sort::sort_acc<qt_u64>(arr, nPrev, QtSizedLess(), S.sortStack);
-                    if (lane < nPrev) S.prev[lane] = ((qt_u64)(unsigned)arr.hi0 << 32) | (unsigned)arr.lo0;
-                    if (64 + lane < nPrev) S.prev[64 + lane] = ((qt_u64)(unsigned)arr.hi1 << 32) | (unsigned)arr.lo1;
-                    if (128 + lane < nPrev) S.prev[128 + lane] = ((qt_u64)(unsigned)arr.hi2 << 32) | (unsigned)arr.lo2;
-                    if (192 + lane < nPrev) S.prev[192 + lane] = ((qt_u64)(unsigned)arr.hi3 << 32) | (unsigned)arr.lo3;
-                } else {
+                {
+                    // (a variant with the elements in lane registers + v_readlane measured 4x slower than this LDS sort)
                     for (int i = lane; i < nPrev; i += WAVE) S.prev[i] = S.sized[i];
                     qt_sync<LDSK>();
                     if (lane == 0 && a.stop != 4) orbx_sort::sort(S.prev, nPrev, QtSizedLess(), S.sortStack);
