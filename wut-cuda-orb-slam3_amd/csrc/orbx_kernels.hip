@@ -19,6 +19,7 @@
 #include "orbx_internal.h"
 #include "libstdcxx_sort.h"
 #include "orbx_pattern.inc"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -672,6 +673,8 @@ struct BlurArgs {
     int w, h;
     int taps[7];
     int nframes, tilesX, tilesY;
+    int srcAligned;  // k_blur3: source rows may be read with aligned 8-byte loads
+    uint32_t biasH, biasL, biasHi;  // k_blur3: constant-term operand bytes (bl3_bias_bytes)
 };
 
 __global__ __launch_bounds__(256) void k_blur(BlurArgs a)
@@ -815,6 +818,122 @@ __global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
     }
 }
 
+// ---- v3: the separable 7-tap blur on the matrix cores (exact integer arithmetic, v_mfma_i32_16x16x32_i8).
+// A 7-tap convolution of a 16-wide block is a banded 32 x 16 Toeplitz product, so one wave walks down a 16-column strip in
+// chunks of 16 rows:
+//   horizontal  H[16 rows][16 cols] = X[16 rows][32 cols] * Th          A = pixels - 128 (8 bytes of a row per lane, straight
+//                                                                       from global memory), B = taps; accumulator preset to
+//                                                                       128 * sum(taps), so H is the exact 16-bit row sum
+//   vertical    V^T[16 cols][16 rows] = H^T[16 cols][32 rows] * Tv      the result layout of the first product (4 consecutive
+//                                                                       rows of one column per lane) IS the A layout of the
+//                                                                       second (summation over rows) - no lane movement, no LDS;
+//                                                                       H is split into a low and a high byte plane (two
+//                                                                       products, V = 256 * Vh + Vl); K = this chunk + the next
+// and each lane ends up with 4 horizontally adjacent output pixels of one row: one dword store.  BORDER_REFLECT_101 is applied
+// when the A operand is loaded (interior strips take aligned 8-byte loads, the strips at the left / right image border gather
+// reflected bytes).  About 25 VALU + 3 MFMA instructions per 256 pixels, against ~150 VALU in the SWAR version.
+#define BL3_SEG 8  // 16-row output blocks per wave (plus one extra chunk of rows)
+typedef int bl3_v4i __attribute__((ext_vector_type(4)));
+
+// The constant terms (128 * sum(taps) from the signed-byte operands, + 32768 rounding) ride in K slots whose taps are zero
+// anyway - the last 8 window columns of the horizontal product, the last 4 "next chunk" rows of the vertical one, both held by
+// lanes 48..63 - as sum(a_i * b_i) with b = {127, 127, 127, 1}; so the accumulators start from the inline constant 0 and no
+// bias is added on the VALU.  Returns the a bytes for the constant X <= 4 * 127 * 127.
+static uint32_t bl3_bias_bytes(int X)
+{
+    const int q = X / 127, r = X % 127;
+    const int a0 = std::min(q, 127), a1 = std::min(std::max(q - 127, 0), 127), a2 = std::max(q - 254, 0);
+    return (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)r << 24);
+}
+#define BL3_BIAS_B 0x017F7F7Fu
+
+__device__ __forceinline__ int bl3_reflect(int p, int len)  // REFLECT_101 for -len < p < 2 * len - 1, clamped beyond (unused taps)
+{
+    int q = p < 0 ? -p : p;
+    q = q >= len ? 2 * (len - 1) - q : q;
+    return max(q, 0);
+}
+
+__global__ __launch_bounds__(256) void k_blur3(BlurArgs a)
+{
+    int f, unit;
+    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, unit)) return;
+    const int sgx = unit % a.tilesX, seg = unit / a.tilesX;
+    const int lane = threadIdx.x & 63;
+    const int x0 = (sgx * 4 + (int)(threadIdx.x >> 6)) * 16;  // wave-uniform; the kernel has no barrier
+    if (x0 >= a.w) return;
+    const int n = lane & 15, g = lane >> 4;
+    const int nBlk = (a.h + 15) >> 4;
+    const int b0 = seg * BL3_SEG, b1 = min(b0 + BL3_SEG, nBlk);
+    unsigned long T64 = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) T64 |= (unsigned long)(unsigned)a.taps[k] << (8 * k);
+    auto tapWin = [&](int k0) -> uint32_t {  // bytes tap[k0 .. k0 + 3], zero outside 0 .. 6
+        const int sh = 8 * k0;
+        const unsigned long v = sh >= 0 ? T64 >> min(sh, 63) : T64 << min(-sh, 63);
+        return (sh >= 64 || sh <= -32) ? 0u : (uint32_t)v;
+    };
+    // tap matrices.  K slot (g, jj) of the horizontal product is window column 8g + jj (image column x0 - 4 + 8g + jj), tap
+    // 8g + jj - n - 1 for output column n; of the vertical product it is row 4g + jj of the previous chunk (jj < 4), tap
+    // 4g + jj - n for output row n, or row 4g + jj - 4 of this one, tap 16 + 4g + jj - 4 - n.
+    const bool biasLane = g == 3;
+    const uint32_t bh0 = biasLane ? BL3_BIAS_B : tapWin(8 * g - n - 1), bh1 = biasLane ? 0u : tapWin(8 * g + 4 - n - 1);
+    const uint32_t bv0 = tapWin(4 * g - n), bv1 = biasLane ? BL3_BIAS_B : tapWin(16 + 4 * g - n);
+    const long Bh = (long)(((unsigned long)bh1 << 32) | bh0), Bv = (long)(((unsigned long)bv1 << 32) | bv0);
+    const bool fast = a.srcAligned && x0 >= 4 && x0 + 28 <= a.w;
+    const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
+    uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
+    auto loadA = [&](int c) -> uint2 {  // rows 16c - 3 + (lane & 15) of the REFLECT_101-extended image, pixels - 128
+        if (biasLane) return make_uint2(a.biasH, 0);
+        const uint8_t *row = srcF + (size_t)bl3_reflect(16 * c - 3 + n, a.h) * a.srcPitch;
+        uint2 v;
+        if (fast) v = *(const uint2 *)(row + x0 - 4 + 8 * g);
+        else {
+            uint32_t t[2] = {0, 0};
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t[jj >> 2] |= (uint32_t)row[bl3_reflect(x0 - 4 + 8 * g + jj, a.w)] << (8 * (jj & 3));
+            v = make_uint2(t[0], t[1]);
+        }
+        return make_uint2(v.x ^ 0x80808080u, v.y ^ 0x80808080u);
+    };
+    const bl3_v4i zero = {0, 0, 0, 0};
+    const int xo = x0 + 4 * g;
+    // all source rows of the segment are requested up front (18 VGPRs): one memory latency per wave, not one per chunk
+    uint2 aBuf[BL3_SEG + 1];
+#pragma unroll
+    for (int i = 0; i <= BL3_SEG; ++i) aBuf[i] = b0 + i <= b1 ? loadA(b0 + i) : make_uint2(0, 0);
+    uint32_t loPrev = 0, hiPrev = 0;
+#pragma unroll
+    for (int i = 0; i <= BL3_SEG; ++i) {
+        const int c = b0 + i;
+        if (c > b1) break;  // wave-uniform
+        const long A = (long)(((unsigned long)aBuf[i].y << 32) | aBuf[i].x);
+        const bl3_v4i H = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bh, zero, 0, 0, 0);  // exact row sums, 0 .. 255 * S <= 65535
+        const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)H[1], (uint32_t)H[0], 0x05010400u);
+        const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)H[3], (uint32_t)H[2], 0x05010400u);
+        const uint32_t lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;  // low bytes of rows 4g .. 4g + 3, - 128
+        const uint32_t hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u;  // high bytes, - 128
+        if (i > 0) {
+            const long Alo = (long)(((unsigned long)(biasLane ? a.biasL : lo) << 32) | loPrev);
+            const long Ahi = (long)(((unsigned long)(biasLane ? a.biasHi : hi) << 32) | hiPrev);
+            const bl3_v4i Dl = __builtin_amdgcn_mfma_i32_16x16x32_i8(Alo, Bv, zero, 0, 0, 0);
+            const bl3_v4i Dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(Ahi, Bv, zero, 0, 0, 0);  // includes the rounding term >> 8
+            const int y = 16 * (c - 1) + n;
+            if (y < a.h && xo < a.w) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);
+                uint8_t *d = dstF + (size_t)y * a.dstPitch + xo;
+                if (xo + 3 < a.w) *(uint32_t *)d = packed;
+                else
+                    for (int r = 0; r < 4 && xo + r < a.w; ++r) d[r] = (uint8_t)(packed >> (8 * r));
+            }
+        }
+        loPrev = lo; hiPrev = hi;
+    }
+}
+
 hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8_t *src, int srcPitch,
                           long long srcFrameStride, uint8_t *dst, int dstPitch, long long dstFrameStride,
                           const int taps[7])
@@ -828,7 +947,19 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
     const bool small = (taps[0] + taps[1] + taps[2]) * 2 + taps[3] <= 257;  // packed 16-bit horizontal sums cannot overflow
     const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride | (uintptr_t)dst | (uintptr_t)dstPitch |
                            (uintptr_t)dstFrameStride;
-    if (symmetric && small && (bits & 3) == 0) {
+    static const int variant = [] { const char *e = getenv("ORBX_BLUR_KERNEL"); return e ? atoi(e) : 3; }();  // 2: SWAR, 1: generic (A/B timing)
+    bool i8ok = true;
+    for (int k = 0; k < 7; ++k) i8ok = i8ok && taps[k] >= 0 && taps[k] <= 127;
+    const uintptr_t dbits = (uintptr_t)dst | (uintptr_t)dstPitch | (uintptr_t)dstFrameStride;
+    a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 3) == 0;
+    if (variant == 3 && small && i8ok && (dbits & 3) == 0 && w >= 32 && h >= 16) {
+        const int S = taps[0] + taps[1] + taps[2] + taps[3] + taps[4] + taps[5] + taps[6];
+        a.biasH = bl3_bias_bytes(128 * S);         // pixels - 128
+        a.biasL = bl3_bias_bytes(128 * S);         // low byte plane - 128
+        a.biasHi = bl3_bias_bytes(128 * S + 128);  // high byte plane - 128, + 32768 >> 8 for the final rounding
+        a.nframes = nframes; a.tilesX = (w + 63) / 64; a.tilesY = ((h + 15) / 16 + BL3_SEG - 1) / BL3_SEG;
+        hipLaunchKernelGGL(k_blur3, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
+    } else if (variant >= 2 && symmetric && small && (bits & 3) == 0) {
         a.nframes = nframes; a.tilesX = (w + BL2_GW * 4 - 1) / (BL2_GW * 4); a.tilesY = (h + BL2_TH - 1) / BL2_TH;
         hipLaunchKernelGGL(k_blur2, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
     } else {
