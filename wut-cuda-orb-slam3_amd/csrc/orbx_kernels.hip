@@ -208,16 +208,18 @@ __device__ __forceinline__ uint32_t fast_group_pretest(const uint32_t (&w0)[4], 
     return ((d & ~ltVT) | (b & ~ltCV)) & SW_H;
 }
 
+// exclusive prefix sum over the wave (all 64 lanes active): Kogge-Stone inside the rows of 16 lanes with DPP row shifts, then the
+// row totals with the two gfx9 row broadcasts - six full-rate VALU operations, no LDS crossbar round trips
 __device__ __forceinline__ int wave_excl_scan(int v, int &total)
 {
-    const int lane = threadIdx.x & 63;
     int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
-    total = __shfl(x, 63);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 
@@ -673,7 +675,7 @@ struct BlurArgs {
     int w, h;
     int taps[7];
     int nframes, tilesX, tilesY;
-    int srcAligned;  // k_blur3: source rows may be read with aligned 8-byte loads
+    int srcAligned;  // k_blur3: source rows may be staged with aligned 16-byte loads
     uint32_t biasH, biasL, biasHi;  // k_blur3: constant-term operand bytes (bl3_bias_bytes)
 };
 
@@ -854,7 +856,118 @@ __device__ __forceinline__ int bl3_reflect(int p, int len)  // REFLECT_101 for -
     return max(q, 0);
 }
 
-__global__ __launch_bounds__(256) void k_blur3(BlurArgs a)
+// NW waves per workgroup = NW adjacent 16-column strips of one row segment.  The source rows of the segment are staged in LDS
+// with coalesced 16-byte loads (each 128-byte line is fetched once per workgroup; per-wave 8-byte gathers straight from global
+// memory fetched every line ~5 times through a thrashing L1) and the A operands are read from there.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
+{
+    constexpr int TW = 16 * NW, NVEC = NW + 2, LP = 16 * (NW + 3), NT = 64 * NW, ROWS = 16 * (BL3_SEG + 1);
+    __shared__ __attribute__((aligned(16))) uint8_t tile[ROWS * LP];  // image columns [tx0, tx0 + TW + 32), REFLECT_101 rows
+    int f, unit;
+    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, unit)) return;
+    const int sgx = unit % a.tilesX, seg = unit / a.tilesX;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx0 = sgx * TW - 16;
+    const int x0 = sgx * TW + wv * 16;  // wave-uniform
+    const int n = lane & 15, g = lane >> 4;
+    const int nBlk = (a.h + 15) >> 4;
+    const int b0 = seg * BL3_SEG, b1 = min(b0 + BL3_SEG, nBlk);
+    const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
+    uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
+    const int nRows = 16 * (b1 - b0 + 1);
+    if (a.srcAligned) {
+        for (int it = tid; it < nRows * NVEC; it += NT) {
+            const int r = it / NVEC, v = it - r * NVEC;
+            const int col = tx0 + 16 * v;
+            if (col >= 0 && col + 16 <= a.srcPitch)
+                *(uint4 *)(tile + r * LP + 16 * v) =
+                    *(const uint4 *)(srcF + (size_t)bl3_reflect(16 * b0 - 3 + r, a.h) * a.srcPitch + col);
+        }
+    } else {
+        for (int it = tid; it < nRows * (TW + 32); it += NT) {
+            const int r = it / (TW + 32), cx = it - r * (TW + 32);
+            const int col = tx0 + cx;
+            if (col >= 0 && col < a.w) tile[r * LP + cx] = srcF[(size_t)bl3_reflect(16 * b0 - 3 + r, a.h) * a.srcPitch + col];
+        }
+    }
+    __syncthreads();
+    if (x0 >= a.w) return;
+
+    unsigned long T64 = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) T64 |= (unsigned long)(unsigned)a.taps[k] << (8 * k);
+    auto tapWin = [&](int k0) -> uint32_t {  // bytes tap[k0 .. k0 + 3], zero outside 0 .. 6
+        const int sh = 8 * k0;
+        const unsigned long v = sh >= 0 ? T64 >> min(sh, 63) : T64 << min(-sh, 63);
+        return (sh >= 64 || sh <= -32) ? 0u : (uint32_t)v;
+    };
+    // tap matrices.  K slot (g, jj) of the horizontal product is window column 8g + jj (image column x0 - 4 + 8g + jj), tap
+    // 8g + jj - n - 1 for output column n; of the vertical product it is row 4g + jj of the previous chunk (jj < 4), tap
+    // 4g + jj - n for output row n, or row 4g + jj - 4 of this one, tap 16 + 4g + jj - 4 - n.
+    const bool biasLane = g == 3;
+    const uint32_t bh0 = biasLane ? BL3_BIAS_B : tapWin(8 * g - n - 1), bh1 = biasLane ? 0u : tapWin(8 * g + 4 - n - 1);
+    const uint32_t bv0 = tapWin(4 * g - n), bv1 = biasLane ? BL3_BIAS_B : tapWin(16 + 4 * g - n);
+    const long Bh = (long)(((unsigned long)bh1 << 32) | bh0), Bv = (long)(((unsigned long)bv1 << 32) | bv0);
+    const bool fast = x0 >= 4 && x0 + 28 <= a.w;  // the whole window lies inside the image
+    // LDS byte offsets of this lane's 8 window columns (strips at the image border: REFLECT_101, clamped where the tap is 0)
+    int colOff[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+        colOff[jj] = fast ? 0 : min(max(bl3_reflect(x0 - 4 + 8 * g + jj, a.w) - tx0, 0), TW + 31);
+    const uint8_t *myRow = tile + n * LP + (x0 - 4 + 8 * g - tx0);
+    auto loadA = [&](int i) -> uint2 {  // rows 16 (b0 + i) - 3 + (lane & 15) of the extended image, pixels - 128
+        if (biasLane) return make_uint2(a.biasH, 0);
+        uint2 v;
+        if (fast) {
+            const uint32_t *q = (const uint32_t *)(myRow + 16 * i * LP);
+            v = make_uint2(q[0], q[1]);
+        } else {
+            const uint8_t *row = tile + (16 * i + n) * LP;
+            uint32_t t[2] = {0, 0};
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) t[jj >> 2] |= (uint32_t)row[colOff[jj]] << (8 * (jj & 3));
+            v = make_uint2(t[0], t[1]);
+        }
+        return make_uint2(v.x ^ 0x80808080u, v.y ^ 0x80808080u);
+    };
+    const bl3_v4i zero = {0, 0, 0, 0};
+    const int xo = x0 + 4 * g;
+    uint32_t loPrev = 0, hiPrev = 0;
+#pragma unroll
+    for (int i = 0; i <= BL3_SEG; ++i) {
+        const int c = b0 + i;
+        if (c > b1) break;  // wave-uniform
+        const uint2 av = loadA(i);
+        const long A = (long)(((unsigned long)av.y << 32) | av.x);
+        const bl3_v4i H = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bh, zero, 0, 0, 0);  // exact row sums, 0 .. 255 * S <= 65535
+        const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)H[1], (uint32_t)H[0], 0x05010400u);
+        const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)H[3], (uint32_t)H[2], 0x05010400u);
+        const uint32_t lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;  // low bytes of rows 4g .. 4g + 3, - 128
+        const uint32_t hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u;  // high bytes, - 128
+        if (i > 0) {
+            const long Alo = (long)(((unsigned long)(biasLane ? a.biasL : lo) << 32) | loPrev);
+            const long Ahi = (long)(((unsigned long)(biasLane ? a.biasHi : hi) << 32) | hiPrev);
+            const bl3_v4i Dl = __builtin_amdgcn_mfma_i32_16x16x32_i8(Alo, Bv, zero, 0, 0, 0);
+            const bl3_v4i Dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(Ahi, Bv, zero, 0, 0, 0);  // includes the rounding term >> 8
+            const int y = 16 * (c - 1) + n;
+            if (y < a.h && xo < a.w) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);
+                uint8_t *d = dstF + (size_t)y * a.dstPitch + xo;
+                if (xo + 3 < a.w) *(uint32_t *)d = packed;
+                else
+                    for (int r = 0; r < 4 && xo + r < a.w; ++r) d[r] = (uint8_t)(packed >> (8 * r));
+            }
+        }
+        loPrev = lo; hiPrev = hi;
+    }
+}
+
+// LDS-free variant: every wave gathers its 8-byte window pieces straight from global memory (aligned to 4 bytes)
+__global__ __launch_bounds__(256) void k_blur3d(BlurArgs a)
 {
     int f, unit;
     if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, unit)) return;
@@ -951,14 +1064,25 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
     bool i8ok = true;
     for (int k = 0; k < 7; ++k) i8ok = i8ok && taps[k] >= 0 && taps[k] <= 127;
     const uintptr_t dbits = (uintptr_t)dst | (uintptr_t)dstPitch | (uintptr_t)dstFrameStride;
-    a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 3) == 0;
+    a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 15) == 0;
     if (variant == 3 && small && i8ok && (dbits & 3) == 0 && w >= 32 && h >= 16) {
         const int S = taps[0] + taps[1] + taps[2] + taps[3] + taps[4] + taps[5] + taps[6];
         a.biasH = bl3_bias_bytes(128 * S);         // pixels - 128
         a.biasL = bl3_bias_bytes(128 * S);         // low byte plane - 128
         a.biasHi = bl3_bias_bytes(128 * S + 128);  // high byte plane - 128, + 32768 >> 8 for the final rounding
-        a.nframes = nframes; a.tilesX = (w + 63) / 64; a.tilesY = ((h + 15) / 16 + BL3_SEG - 1) / BL3_SEG;
-        hipLaunchKernelGGL(k_blur3, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
+        static const int nw = [] { const char *e = getenv("ORBX_BLUR_WAVES"); return e ? atoi(e) : 4; }();
+        a.nframes = nframes; a.tilesY = ((h + 15) / 16 + BL3_SEG - 1) / BL3_SEG;
+        if (nw == 0) {
+            a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 3) == 0;
+            a.tilesX = (w + 63) / 64;
+            hipLaunchKernelGGL(k_blur3d, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
+        } else if (nw == 8) {
+            a.tilesX = (w + 127) / 128;
+            hipLaunchKernelGGL(k_blur3<8>, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(512), 0, st, a);
+        } else {
+            a.tilesX = (w + 63) / 64;
+            hipLaunchKernelGGL(k_blur3<4>, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
+        }
     } else if (variant >= 2 && symmetric && small && (bits & 3) == 0) {
         a.nframes = nframes; a.tilesX = (w + BL2_GW * 4 - 1) / (BL2_GW * 4); a.tilesY = (h + BL2_TH - 1) / BL2_TH;
         hipLaunchKernelGGL(k_blur2, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
@@ -977,7 +1101,7 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
 // the FAST candidates and the per-node arg-max.  List order (push_front / erase) is kept exactly with a
 // doubly linked list in LDS; the std::sort tie order with the libstdc++ introsort emulation.
 // =====================================================================================================
-#define QT_LDS_KEYS 2048   // candidates of one (frame, level) held in LDS (two buffers); larger sets use global scratch
+#define QT_LDS_KEYS 0      // candidates of one (frame, level) held in an LDS buffer behind the node arrays; 0: always in global scratch
 
 typedef unsigned long long qt_u64;
 
@@ -991,8 +1115,14 @@ struct QtArgs {
     int nlevels, nframes;
     int pool;     // node pool size P
     int listCap;  // capacity of list-sized arrays (max quota + 8)
+    int ldsKeys;  // candidates of one instance held in LDS (0: always in global scratch)
+    int nodeBytes;  // LDS bytes of the node arrays (keys follow)
+    int variant;  // 3: level-synchronous (default), 1: serial list walk (ORBX_QT_KERNEL; also taken for > QT3_MAX_KEYS candidates)
     int stop;     // debug (ORBX_QT_STOP): 1 return after the gather, 2 after the roots, 3 skip the sorted phase, 4 skip the sort only
 };
+
+// the kernels read the argument block in place from the kernarg segment (no private copy when it is passed on by reference)
+typedef const __attribute__((address_space(4))) QtArgs QtArgsK;
 
 // (count, UL.x, node id) of an expandable node packed as count << 32 | ulx << 16 | id; compareNodes (:569-582)
 // orders by (count, UL.x) only = key >> 16
@@ -1139,7 +1269,7 @@ __device__ __forceinline__ int qt_flatten(QtCtx &S, int nOrder, short *dst)
 }
 
 template <bool LDSK, class KP>
-__device__ void qt_body(const QtArgs &a, const OrbxLevelGeom &g, int f, int level, uint8_t *qlds, KP A, KP B, int M,
+__device__ __noinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int f, int level, uint8_t *qlds, KP A, KP B, int M,
                         const int *tc, uint32_t *selOut, int *selCnt)
 {
     const int lane = threadIdx.x;
@@ -1309,19 +1439,447 @@ __device__ void qt_body(const QtArgs &a, const OrbxLevelGeom &g, int f, int leve
     if (lane == 0) *selCnt = nFinal;
 }
 
+// ---- v3: level-synchronous formulation.  The list is an ARRAY of nodes in list order and the keys are kept in list order
+// too (a node's keys = one contiguous run, in candidate order), so one pass of the reference's list walk - or one round of its
+// sorted phase - becomes a handful of wave-parallel sweeps instead of one serial DivideNode per node:
+//   1. key sweep:   every key finds its node (popcount over a bitmap of run starts) and its quadrant; per-node child counts
+//                   with ballots restricted to the node's lane range;
+//   2. node sweep:  nodes to divide, in processing order t (list order, or the std::sort order from the largest count down);
+//                   prefix sums over t give the list size before each divide (-> the reference's `break` at size >= N), the
+//                   creation index of every child and its slot in vSizeAndPointerToNode.  push_front makes the new list
+//                   reverse(children in creation order) ++ untouched nodes in their old order;
+//   3. key sweep:   stable scatter of every key to its node's new run (children by quadrant, untouched nodes verbatim).
+// Only the std::sort emulation (the tie order of libstdc++'s introsort is observable) still runs on one lane.
+// A single wave runs these sweeps as chains of LDS round trips, so they keep several independent reads in flight: lists of
+// up to 256 nodes are handled as 4 entries per lane (loads first, then the scans), up to QT3_KCH * 64 keys stay in registers for
+// a whole pass (the scatter is then in place, in one LDS buffer), and counters advance with fire-and-forget LDS atomics.
+#define QT3_MAX_KEYS 8192  // run-start bitmap in LDS (1 KB), 16-bit key offsets; larger candidate sets take the serial formulation
+#define QT3_KCH 32         // 64-key chunks held in registers
+
+struct Qt3 {
+    qt_u64 *V;                 // [L] expandable nodes (count << 32 | UL.x << 16 | list position): vSizeAndPointerToNode
+    uint32_t *gx[2], *gy[2];   // [L] node bounds by list position: UL.x | UR.x << 16, UL.y | BR.y << 16 (two generations)
+    uint32_t *cc;              // [L][2] four 16-bit slots: child counts of the pass, then list positions, then write cursors
+    uint32_t *aux;             // [L] creation index of the node's first child | index of its first entry in V << 16; ~0: untouched
+    uint16_t *cnt[2], *beg[2]; // [L], [L + 2] keys of the node, exclusive prefix
+    uint16_t *proc;            // [L] list positions of the nodes to divide, in processing order
+    int *sortStack;            // [216]
+    uint32_t *starts;          // [QT3_MAX_KEYS / 32 + 2] bitmap: key e is the first key of its node
+};
+#define QT3_NONE 0xFFFFu
+
+static size_t qt3NodeBytes(int L) { return (((size_t)L * 46 + 8 + 216 * 4 + (QT3_MAX_KEYS / 32 + 2) * 4) + 15) & ~(size_t)15; }
+
+// A / B: key buffers.  With M <= QT3_KCH * 64 they are the same (LDS) buffer, larger sets ping-pong between two global ones.
+__device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int f, uint8_t *qlds, uint32_t *A, uint32_t *B, int M,
+                         const int *tc, uint32_t *selOut, int *selCnt)
+{
+    const int lane = threadIdx.x;
+    const unsigned long long lt = lanemask_lt();
+    const int L = a.listCap;
+    const bool inRegs = M <= QT3_KCH * WAVE;
+    Qt3 S;
+    S.V = (qt_u64 *)qlds;
+    S.gx[0] = (uint32_t *)(S.V + L); S.gx[1] = S.gx[0] + L; S.gy[0] = S.gx[1] + L; S.gy[1] = S.gy[0] + L;
+    S.cc = S.gy[1] + L; S.aux = S.cc + 2 * L;
+    S.cnt[0] = (uint16_t *)(S.aux + L); S.cnt[1] = S.cnt[0] + L; S.beg[0] = S.cnt[1] + L; S.beg[1] = S.beg[0] + L + 2;
+    S.proc = S.beg[1] + L + 2;
+    S.sortStack = (int *)(S.proc + L);
+    S.starts = (uint32_t *)(S.sortStack + 216);
+
+    uint32_t kk[QT3_KCH];  // keys base + u * 64 + lane of the running batch of chunks
+    // ---- ordered gather of the FAST candidates (tile slots in cell-row-major order) --------------------
+    {
+        int *tileOff = (int *)qlds;  // nTiles + 1 prefix offsets; the node arrays are not in use yet
+        int base = 0;
+        for (int tb = 0; tb < g.nTiles; tb += WAVE) {
+            const int t = tb + lane;
+            const int myN = t < g.nTiles ? tc[t] : 0;
+            int total;
+            const int myOff = wave_excl_scan(myN, total);
+            if (t < g.nTiles) tileOff[t] = base + myOff;
+            base += total;
+        }
+        if (lane == 0) tileOff[g.nTiles] = base;
+        qt_sync<true>();
+        const uint32_t *slots = a.cand + (size_t)f * a.candFrameStride + g.candBase;
+        for (int e0 = 0; e0 < M; e0 += QT3_KCH * WAVE) {  // all slot loads of a batch are in flight together
+#pragma unroll
+            for (int u = 0; u < QT3_KCH; ++u) {
+                const int e = e0 + u * WAVE + lane;
+                if (e0 + u * WAVE < M) {
+                    int lo = 0, hi = g.nTiles;  // largest t with tileOff[t] <= e
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (tileOff[mid] <= e) lo = mid; else hi = mid;
+                    }
+                    kk[u] = e < M ? slots[(size_t)lo * g.slotCap + (e - tileOff[lo])] : 0u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QT3_KCH; ++u) {
+                const int e = e0 + u * WAVE + lane;
+                if (e < M) A[e] = kk[u];
+            }
+        }
+    }
+    qt_sync<false>();
+    if (a.stop == 1) { if (lane == 0) *selCnt = 0; return; }
+
+    // ---- roots (:589-626): push_back in order, keys stably grouped by root ---------------------------------------------
+    const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
+    const int N = g.quota;
+    const int nIni = (int)roundf(__fdiv_rn((float)W, (float)H));
+    const float hX = __fdiv_rn((float)W, (float)nIni);
+    int cur = 0, size = 0;
+    bool kkValid = inRegs;  // kk holds A[0 .. M)
+    {
+        uint32_t *R = inRegs ? a.scratchB + (size_t)f * a.candFrameStride + g.candBase : B;  // grouping target
+        int off = 0;
+        for (int r = 0; r < nIni; ++r) {
+            int cnt;
+            if (nIni == 1) cnt = M;
+            else {
+                cnt = 0;
+                for (int base = 0; base < M; base += WAVE) {
+                    const bool act = base + lane < M;
+                    const uint32_t key = act ? A[base + lane] : 0u;
+                    const bool mine = act && (int)__fdiv_rn((float)(key & 0xFFF), hX) == r;
+                    const unsigned long long m = __ballot(mine);
+                    if (mine) R[off + cnt + __popcll(m & lt)] = key;
+                    cnt += __popcll(m);
+                }
+            }
+            if (cnt > 0 && lane == 0) {
+                S.gx[0][size] = (uint32_t)(int)__fmul_rn(hX, (float)r) | ((uint32_t)(int)__fmul_rn(hX, (float)(r + 1)) << 16);
+                S.gy[0][size] = 0u | ((uint32_t)H << 16);
+                S.cnt[0][size] = (uint16_t)cnt;
+            }
+            if (cnt > 0) ++size;
+            off += cnt;
+        }
+        if (nIni > 1) {
+            qt_sync<false>();
+            if (inRegs) { for (int i = lane; i < M; i += WAVE) A[i] = R[i]; kkValid = false; }
+            else { uint32_t *t = A; A = B; B = t; }
+        }
+    }
+    qt_sync<false>();
+    if (a.stop == 2) { if (lane == 0) *selCnt = 0; return; }
+
+    int nV = 0;  // entries of V after a pass
+    // one pass / one sorted round.  nSorted < 0: divide every node with more than one key, in list order; otherwise divide
+    // V[nSorted - 1], V[nSorted - 2], ... while the list holds fewer than N nodes.
+    auto pass = [&](int nSorted) {
+        uint32_t *gx = S.gx[cur], *gy = S.gy[cur];
+        uint16_t *cn = S.cnt[cur], *bg = S.beg[cur];
+        uint32_t *gx2 = S.gx[cur ^ 1], *gy2 = S.gy[cur ^ 1];
+        uint16_t *cn2 = S.cnt[cur ^ 1], *bg2 = S.beg[cur ^ 1];
+        // (a) run starts: exclusive prefix of the counts, bitmap of first keys; child counters to zero
+        for (int i = lane; i < ((M + 63) >> 6) * 2 + 2; i += WAVE) S.starts[i] = 0;
+        {
+            int base = 0;
+            for (int pb0 = 0; pb0 < size; pb0 += 4 * WAVE) {
+                int c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int p = pb0 + u * WAVE + lane; c[u] = p < size ? (int)cn[p] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb0 + u * WAVE + lane;
+                    int total;
+                    const int o = base + wave_excl_scan(c[u], total);
+                    if (p < size) {
+                        bg[p] = (uint16_t)o;
+                        atomicOr(&S.starts[o >> 5], 1u << (o & 31));
+                        *(uint2 *)(S.cc + 2 * p) = make_uint2(0, 0);
+                        S.aux[p] = ~0u;
+                    }
+                    base += total;
+                }
+            }
+            if (lane == 0) bg[size] = (uint16_t)M;
+        }
+        qt_sync<true>();
+        // key -> (node, quadrant, lane range of the node inside its 64-key chunk)
+        struct KeyInfo { uint32_t key; int p, q, lo, e0; bool act, big; unsigned long long R; };
+        auto classify = [&](int base, int p, uint32_t key, uint32_t ngx, uint32_t ngy, int nb, int nc) -> KeyInfo {
+            KeyInfo k;
+            const int e = base + lane;
+            k.act = e < M; k.p = p; k.key = key;
+            const int ulx = ngx & 0xFFFF, urx = ngx >> 16, uly = ngy & 0xFFFF, bry = ngy >> 16;
+            const int mx = ulx + ((urx - ulx + 1) >> 1), my = uly + ((bry - uly + 1) >> 1);  // UL + ceil(extent / 2)
+            const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
+            k.q = x < mx ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+            k.big = k.act && nc > 1;
+            k.e0 = e - nb;
+            k.lo = max(nb - base, 0);
+            const int hi = min(nb + nc - base, 64);
+            k.R = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << k.lo) - 1ull);
+            return k;
+        };
+        // a sweep over all keys: batches of QT3_KCH chunks (keys -> registers), inside a batch 4 chunks per step (bitmap words,
+        // then owners, then node fields), then `body(KeyInfo)` chunk by chunk in key order
+        auto sweep = [&](bool reload, auto &&body) {
+            int before = 0;
+            for (int b0 = 0; b0 < M; b0 += QT3_KCH * WAVE) {
+                if (reload) {
+#pragma unroll
+                    for (int u = 0; u < QT3_KCH; ++u) {
+                        const int e = b0 + u * WAVE + lane;
+                        if (b0 + u * WAVE < M) kk[u] = e < M ? A[e] : 0u;
+                    }
+                }
+#pragma unroll
+                for (int u0 = 0; u0 < QT3_KCH; u0 += 4) {
+                    if (b0 + u0 * WAVE < M) {  // (no `break`: the loop must unroll completely, kk is indexed statically)
+                    unsigned long long w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int base = b0 + (u0 + u) * WAVE;
+                        const int wi = base >> 5;
+                        w[u] = base < M ? ((unsigned long long)S.starts[wi] | ((unsigned long long)S.starts[wi + 1] << 32)) : 0ull;
+                    }
+                    int pp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int base = b0 + (u0 + u) * WAVE;
+                        pp[u] = base + lane < M ? before + __popcll(w[u] & (lt | (1ull << lane))) - 1 : 0;
+                        before += __popcll(w[u]);
+                    }
+                    uint32_t ngx[4], ngy[4]; int nb[4], nc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { ngx[u] = gx[pp[u]]; ngy[u] = gy[pp[u]]; nb[u] = (int)bg[pp[u]]; nc[u] = (int)cn[pp[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int base = b0 + (u0 + u) * WAVE;
+                        if (base < M) body(classify(base, pp[u], kk[u0 + u], ngx[u], ngy[u], nb[u], nc[u]));
+                    }
+                    }
+                }
+            }
+        };
+        auto addSlots = [&](const KeyInfo &k, const unsigned long long (&m)[4]) {  // first lane of the node's run in the chunk
+            const uint32_t lo2 = (uint32_t)__popcll(m[0] & k.R) | ((uint32_t)__popcll(m[1] & k.R) << 16);
+            const uint32_t hi2 = (uint32_t)__popcll(m[2] & k.R) | ((uint32_t)__popcll(m[3] & k.R) << 16);
+            if (lo2) atomicAdd(&S.cc[2 * k.p], lo2);
+            if (hi2) atomicAdd(&S.cc[2 * k.p + 1], hi2);
+        };
+        // (b) child counts
+        sweep(!kkValid, [&](const KeyInfo &k) {
+            unsigned long long m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = __ballot(k.big && k.q == j);
+            if (k.big && lane == k.lo) addSlots(k, m);
+        });
+        // (c) nodes to divide, in processing order
+        int nProc = 0;
+        if (nSorted < 0) {
+            for (int pb = 0; pb < size; pb += WAVE) {
+                const int p = pb + lane;
+                const bool big = p < size && cn[p] > 1;
+                const unsigned long long m = __ballot(big);
+                if (big) S.proc[nProc + __popcll(m & lt)] = (uint16_t)p;
+                nProc += __popcll(m);
+            }
+        } else {
+            for (int t = lane; t < nSorted; t += WAVE) S.proc[t] = (uint16_t)(S.V[nSorted - 1 - t] & 0xFFFF);
+            nProc = nSorted;
+        }
+        qt_sync<true>();
+        // (d) prefix sums over the processing order: list size before each divide (a sorted round stops dividing once the
+        //     list holds N nodes), creation index of the first child, index of the first new V entry
+        int C = 0;
+        nV = 0;
+        {
+            int sz = size;
+            bool stop = false;
+            for (int tb = 0; tb < nProc && !stop; tb += WAVE) {
+                const int t = tb + lane;
+                const bool val = t < nProc;
+                const int p = val ? S.proc[t] : 0;
+                const uint2 c2 = *(const uint2 *)(S.cc + 2 * p);
+                const uint32_t c0 = c2.x & 0xFFFF, c1 = c2.x >> 16, c2_ = c2.y & 0xFFFF, c3 = c2.y >> 16;
+                const int ne = val ? (c0 > 0) + (c1 > 0) + (c2_ > 0) + (c3 > 0) : 0;
+                const int nx = val ? (c0 > 1) + (c1 > 1) + (c2_ > 1) + (c3 > 1) : 0;
+                int totNe, totNx, totG;
+                const int cb = wave_excl_scan(ne, totNe);
+                const int vb = wave_excl_scan(nx, totNx);
+                const int gEx = wave_excl_scan(val ? ne - 1 : 0, totG);
+                bool take = val;
+                if (nSorted >= 0) {
+                    // the reference divides node t and THEN breaks if size >= N: node t is divided iff the size before it is < N
+                    take = val && sz + gEx < N;
+                    const int nTake = __popcll(__ballot(take));  // a prefix of the chunk: sizes never decrease
+                    if (nTake < min(WAVE, nProc - tb)) stop = true;
+                    const int last = max(nTake - 1, 0);
+                    const int iNe = __shfl(cb + ne, last), iNx = __shfl(vb + nx, last), iG = __shfl(gEx + ne - 1, last);
+                    totNe = nTake > 0 ? iNe : 0; totNx = nTake > 0 ? iNx : 0; totG = nTake > 0 ? iG : 0;
+                }
+                if (take) S.aux[p] = (uint32_t)(C + cb) | ((uint32_t)(nV + vb) << 16);
+                C += totNe; nV += totNx; sz += totG;
+            }
+        }
+        qt_sync<true>();
+        // (e) new list: children (reverse creation order) then the untouched nodes; new V in creation order.  The slots of cc
+        //     now hold the list position of the child (untouched node: its own new position in slot 0), QT3_NONE where there is none.
+        int nKeep = 0;
+        for (int pb0 = 0; pb0 < size; pb0 += 4 * WAVE) {
+            uint32_t ax[4], ogx[4], ogy[4], ocn[4]; uint2 c2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = min(pb0 + u * WAVE + lane, size - 1);
+                ax[u] = S.aux[p]; ogx[u] = gx[p]; ogy[u] = gy[p]; ocn[u] = cn[p]; c2[u] = *(const uint2 *)(S.cc + 2 * p);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pb0 + u * WAVE + lane;
+                const bool val = p < size;
+                const bool keep = val && ax[u] == ~0u;
+                const unsigned long long mk = __ballot(keep);
+                if (keep) {
+                    const int np = C + nKeep + __popcll(mk & lt);
+                    gx2[np] = ogx[u]; gy2[np] = ogy[u]; cn2[np] = (uint16_t)ocn[u];
+                    *(uint2 *)(S.cc + 2 * p) = make_uint2((uint32_t)np | (QT3_NONE << 16), QT3_NONE | (QT3_NONE << 16));
+                } else if (val) {
+                    const int ulx = ogx[u] & 0xFFFF, urx = ogx[u] >> 16, uly = ogy[u] & 0xFFFF, bry = ogy[u] >> 16;
+                    const int mx = ulx + ((urx - ulx + 1) >> 1), my = uly + ((bry - uly + 1) >> 1);
+                    int ci = (int)(ax[u] & 0xFFFF), vi = (int)(ax[u] >> 16);
+                    const uint32_t cj[4] = {c2[u].x & 0xFFFF, c2[u].x >> 16, c2[u].y & 0xFFFF, c2[u].y >> 16};
+                    uint32_t slot[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {  // n1 (UL), n2 (UR), n3 (BL), n4 (BR) in push order
+                        slot[j] = QT3_NONE;
+                        if (cj[j] > 0) {
+                            const int np = C - 1 - ci;
+                            const int cul = (j & 1) ? mx : ulx, cur_ = (j & 1) ? urx : mx;
+                            const int cuy = (j & 2) ? my : uly, cby = (j & 2) ? bry : my;
+                            gx2[np] = (uint32_t)cul | ((uint32_t)cur_ << 16);
+                            gy2[np] = (uint32_t)cuy | ((uint32_t)cby << 16);
+                            cn2[np] = (uint16_t)cj[j];
+                            if (cj[j] > 1) S.V[vi++] = ((qt_u64)cj[j] << 32) | ((qt_u64)(unsigned)cul << 16) | (unsigned)np;
+                            slot[j] = (uint32_t)np;
+                            ++ci;
+                        }
+                    }
+                    *(uint2 *)(S.cc + 2 * p) = make_uint2(slot[0] | (slot[1] << 16), slot[2] | (slot[3] << 16));
+                }
+                nKeep += __popcll(mk);
+            }
+        }
+        const int size2 = C + nKeep;
+        qt_sync<true>();
+        // (f) prefix of the new counts; (g) list positions -> key offsets (write cursors)
+        {
+            int base = 0;
+            for (int pb0 = 0; pb0 < size2; pb0 += 4 * WAVE) {
+                int c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int p = pb0 + u * WAVE + lane; c[u] = p < size2 ? (int)cn2[p] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb0 + u * WAVE + lane;
+                    int total;
+                    const int o = base + wave_excl_scan(c[u], total);
+                    if (p < size2) bg2[p] = (uint16_t)o;
+                    base += total;
+                }
+            }
+        }
+        qt_sync<true>();
+        for (int pb0 = 0; pb0 < size; pb0 += 4 * WAVE) {
+            uint2 c2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c2[u] = *(const uint2 *)(S.cc + 2 * min(pb0 + u * WAVE + lane, size - 1));
+            uint32_t o[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t sj[4] = {c2[u].x & 0xFFFF, c2[u].x >> 16, c2[u].y & 0xFFFF, c2[u].y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[u][j] = sj[j] != QT3_NONE ? (uint32_t)bg2[sj[j]] : QT3_NONE;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pb0 + u * WAVE + lane;
+                if (p < size) *(uint2 *)(S.cc + 2 * p) = make_uint2(o[u][0] | (o[u][1] << 16), o[u][2] | (o[u][3] << 16));
+            }
+        }
+        qt_sync<true>();
+        // (h) stable scatter of the keys to their new runs (in place when all keys are in registers)
+        sweep(!inRegs, [&](const KeyInfo &k) {
+            const bool div = k.act && S.aux[k.p] != ~0u;
+            unsigned long long m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = __ballot(div && k.q == j);
+            const unsigned long long mq = k.q == 0 ? m[0] : (k.q == 1 ? m[1] : (k.q == 2 ? m[2] : m[3]));
+            const int sl = div ? k.q : 0;
+            const uint32_t cursor = k.act ? (S.cc[2 * k.p + (sl >> 1)] >> (16 * (sl & 1))) & 0xFFFFu : 0u;
+            const uint32_t dest = div ? cursor + (uint32_t)__popcll(mq & k.R & lt) : cursor + (uint32_t)k.e0;
+            if (div && lane == k.lo) addSlots(k, m);  // (LDS operations of a wave complete in order: every lane has read its cursor)
+            if (k.act) B[dest] = k.key;
+        });
+        if (!inRegs) { uint32_t *t = A; A = B; B = t; }
+        kkValid = false;
+        cur ^= 1;
+        size = size2;
+        qt_sync<false>();
+    };
+
+    // ---- subdivision (:630-752): list walks until the next one could overshoot N, then sorted rounds (:701-751) until done.
+    // (one call site: the pass is inlined and its state stays in registers)
+    bool finish = false, sorted = false;
+    while (!finish) {
+        const int prevSize = size;
+        int nSorted = -1;
+        if (sorted) {
+            nSorted = nV;
+            if (lane == 0 && a.stop != 4) orbx_sort::sort(S.V, nSorted, QtSizedLess(), S.sortStack);
+            qt_sync<true>();
+        }
+        pass(nSorted);
+        if (size >= N || size == prevSize) finish = true;
+        else if (!sorted && size + nV * 3 > N) {
+            if (a.stop == 3) break;
+            sorted = true;
+        }
+    }
+
+    // ---- retain the best (first strictly greatest response) key of every node, in list order (:755-771) --
+    {
+        const uint16_t *cn = S.cnt[cur];
+        int base = 0;
+        for (int pb = 0; pb < size; pb += WAVE) {
+            const int p = pb + lane;
+            const int n = p < size ? (int)cn[p] : 0;
+            int total;
+            const int b = base + wave_excl_scan(n, total);
+            if (p < size) {
+                uint32_t best = A[b];
+                for (int i = 1; i < n; ++i) {
+                    const uint32_t key = A[b + i];
+                    if ((key >> 24) > (best >> 24)) best = key;
+                }
+                selOut[p] = best;
+            }
+            base += total;
+        }
+    }
+    if (lane == 0) *selCnt = size;
+}
+
 static size_t qtNodeBytes(int P, int L)
 {
     // gx, gy, beg, cnt (16 B) + fl, front, freeL (6 B) per pool entry; sized, prev (16 B) + order, tmpC, tmpK (6 B) per list entry
     return (((size_t)P * 22 + (size_t)L * 22 + 216 * 4) + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
+__global__ __launch_bounds__(64) void k_quadtree(QtArgs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
+    QtArgsK &a = *(QtArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
     int f, level;
     if (!xcd_decode(a.nframes, a.nlevels, f, level)) return;
     const int lane = threadIdx.x;
-    const OrbxLevelGeom g = a.geoms[level];
+    const OrbxLevelGeom &g = a.geoms[level];
     uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
     int *selCnt = a.selCount + (size_t)f * a.nlevels + level;
     const int *tc = a.tileCount + (size_t)f * a.tilesPerFrame + g.tileBase;
@@ -1333,18 +1891,20 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs a)
         M += v;
     }
     if (M == 0) { if (lane == 0) *selCnt = 0; return; }
-    // node / list arrays first (8-byte aligned: the 64-bit `sized` array follows 4 * P ints), keys after them
-    uint8_t *keysBase = qlds + ((((size_t)a.pool * 22 + (size_t)a.listCap * 22 + 216 * 4) + 15) & ~(size_t)15);
-    // second key buffer: only used while a node still holds more than 64 keys (the first few divides), so it lives in
-    // global scratch and the LDS footprint of an instance stays at ~25 KB (6 instances per CU)
-    uint32_t *B = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
-    if (M <= QT_LDS_KEYS) {
-        uint32_t *A = (uint32_t *)keysBase;
-        qt_body<true>(a, g, f, level, qlds, A, B, M, tc, selOut, selCnt);
-    } else {
-        uint32_t *A = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
-        qt_body<false>(a, g, f, level, qlds, A, B, M, tc, selOut, selCnt);
+    uint32_t *gA = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
+    uint32_t *gB = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
+    if (a.variant == 3 && M <= QT3_MAX_KEYS) {
+        // all keys in registers for a pass + one LDS buffer behind the node arrays; larger sets ping-pong in global scratch
+        uint32_t *lK = (uint32_t *)(qlds + a.nodeBytes);
+        const bool inRegs = M <= QT3_KCH * WAVE;
+        uint32_t *kA = inRegs && M <= a.ldsKeys ? lK : gA;
+        qt3_body(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
+        return;
     }
+    // serial formulation: one key buffer in LDS when it fits; the second one is only used while a node still holds more than
+    // 64 keys (the first few divides), so it always lives in global scratch
+    if (M <= a.ldsKeys) qt_body<true>(a, g, f, level, qlds, (uint32_t *)(qlds + a.nodeBytes), gB, M, tc, selOut, selCnt);
+    else qt_body<false>(a, g, f, level, qlds, gA, gB, M, tc, selOut, selCnt);
 }
 
 hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const OrbxLevelGeom *geomsHost,
@@ -1352,7 +1912,6 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
                               const int *tileCount, int tilesPerFrame, uint32_t *scratchA, uint32_t *scratchB,
                               uint32_t *sel, int selFrameStride, int *selCount, int maxQuota)
 {
-    (void)geomsHost;
     QtArgs a;
     a.geoms = geomsDev;
     a.cand = cand; a.candFrameStride = candFrameStride;
@@ -1361,15 +1920,25 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     a.sel = sel; a.selFrameStride = selFrameStride; a.selCount = selCount;
     a.nlevels = nlevels; a.nframes = nframes;
     { static int stop = -1; if (stop < 0) { const char *e = getenv("ORBX_QT_STOP"); stop = e ? atoi(e) : 0; } a.stop = stop; }
-    a.listCap = (maxQuota + 16 + 3) & ~3;
-    a.pool = (2 * maxQuota + 64 + 3) & ~3;
+    int maxRoots = 1, maxTiles = 1;
+    for (int l = 0; l < nlevels; ++l) {
+        const OrbxLevelGeom &g = geomsHost[l];
+        const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
+        maxRoots = std::max(maxRoots, (int)roundf((float)W / (float)H));
+        maxTiles = std::max(maxTiles, g.nTiles);
+    }
+    a.listCap = (std::max(maxQuota + 16, 4 * maxRoots + 8) + 3) & ~3;
+    a.pool = (2 * maxQuota + 64 + 4 * maxRoots + 3) & ~3;
     {   // test hook: ORBX_QT_POOL_SLACK=k shrinks the pool to quota + k so that the tombstone compaction path runs
         static int slack = -2;
         if (slack == -2) { const char *e = getenv("ORBX_QT_POOL_SLACK"); slack = e ? atoi(e) : -1; }
         if (slack >= 8) a.pool = (maxQuota + slack + 3) & ~3;
     }
-    if (a.pool > 32767) return hipErrorInvalidValue;  // node ids are 15-bit
-    size_t lds = qtNodeBytes(a.pool, a.listCap) + (size_t)QT_LDS_KEYS * sizeof(uint32_t);
+    if (a.pool > 32767 || a.listCap > 32767) return hipErrorInvalidValue;  // node ids / list positions are 15-bit
+    { static int lk = -1; if (lk < 0) { const char *e = getenv("ORBX_QT_LDS_KEYS"); lk = e ? atoi(e) : QT_LDS_KEYS; } a.ldsKeys = lk; }  // measured: 0 (13 KB per instance, 12 per CU) beats 2048 (21 KB)
+    { static int v = -1; if (v < 0) { const char *e = getenv("ORBX_QT_KERNEL"); v = e ? atoi(e) : 3; } a.variant = v; }
+    a.nodeBytes = (int)std::max(std::max(qtNodeBytes(a.pool, a.listCap), qt3NodeBytes(a.listCap)), (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15);
+    size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attrSet = false;
     if (!attrSet && lds > 48 * 1024) {
