@@ -9,7 +9,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(sys.argv[1])):
     agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']]+=float(r['Counter_Value'])
 for k,v in agg.items():
-    if k.startswith('k_pyr') or k.startswith('k_blur'): print(k, {c: f"{x/3:.4g}" for c,x in v.items()})
+    if 'k_' in k: print(k, {c: f"{x/3:.4g}" for c,x in v.items()})
 PY
 }
 run a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"

@@ -549,6 +549,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     const int subSize = ((nframes + nsub - 1) / nsub + 7) / 8 * 8;
     nsub = (nframes + subSize - 1) / subSize;
 
+    static const bool qtPerLevel = [] { const char *e = getenv("ORBX_QT_PER_LEVEL"); return e ? atoi(e) != 0 : false; }();
     static const bool earlyBlur = [] { const char *e = getenv("ORBX_EARLY_BLUR"); return e ? atoi(e) != 0 : false; }();  // measured: 6.37 ms with early blur vs 6.02 ms with blur || quadtree
     hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * PROF_EVENTS] : nullptr;
     if (earlyBlur) {
@@ -579,6 +580,17 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
                                       ex->d_cand.p + (size_t)f0 * ex->candFrameStride, ex->candFrameStride,
                                       ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame, ex->prm.ini_th_fast,
                                       ex->prm.min_th_fast));
+            if (qtPerLevel) {
+                // the quadtree of this level only needs this level's candidates: it runs on the back stream next to the
+                // pyramid + FAST launches of the smaller levels (latency-bound single waves under a throughput-bound kernel)
+                HIP_TRY(hipEventRecord(ex->evLevel[l], sFront));
+                HIP_TRY(hipStreamWaitEvent(sBack, ex->evLevel[l], 0));
+                HIP_TRY(orbxLaunchQuadtree(sBack, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
+                                           ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
+                                           ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
+                                           ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
+                                           ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, l, 1));
+            }
             if (l + 1 < nl && earlyBlur) {
                 // level l + 1 now exists: its GaussianBlur may start on the blur stream while the front stream goes on
                 // with pyr_fast(l + 1) (the fused kernel is barrier-bound, the blur fills its idle issue slots)
@@ -607,11 +619,13 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
         // ---- back stream: quadtree -> pack -> (join blur) -> orientation + descriptors -----------------------------
         HIP_TRY(hipStreamWaitEvent(sBack, ex->evFront[sb], 0));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2], sBack));
-        HIP_TRY(orbxLaunchQuadtree(sBack, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
-                                   ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
-                                   ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
-                                   ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
-                                   ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota));
+        if (!qtPerLevel) {
+            HIP_TRY(orbxLaunchQuadtree(sBack, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
+                                       ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
+                                       ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
+                                       ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
+                                       ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, 0, nl));
+        }
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2 + 1], sBack));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 3) * 2], sBack));
         HIP_TRY(orbxLaunchPack(sBack, nf, tb, ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
 // and each lane ends up with 4 horizontally adjacent output pixels of one row: one dword store.  BORDER_REFLECT_101 is applied
 // when the A operand is loaded (interior strips take aligned 8-byte loads, the strips at the left / right image border gather
 // reflected bytes).  About 25 VALU + 3 MFMA instructions per 256 pixels, against ~150 VALU in the SWAR version.
-#define BL3_SEG 8  // 16-row output blocks per wave (plus one extra chunk of rows)
+#define BL3_SEG 4  // 16-row output blocks per wave (plus one extra chunk of rows); 4 measured best next to the quadtree (8: +2 %, 2: +4 %)
 typedef int bl3_v4i __attribute__((ext_vector_type(4)));
 
 // The constant terms (128 * sum(taps) from the signed-byte operands, + 32768 rounding) ride in K slots whose taps are zero
@@ -1113,6 +1113,7 @@ struct QtArgs {
     uint32_t *sel; int selFrameStride;
     int *selCount;
     int nlevels, nframes;
+    int levelBase, levelsRun;  // this launch covers levels [levelBase, levelBase + levelsRun)
     int pool;     // node pool size P
     int listCap;  // capacity of list-sized arrays (max quota + 8)
     int ldsKeys;  // candidates of one instance held in LDS (0: always in global scratch)
@@ -1877,7 +1878,8 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
     extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
     QtArgsK &a = *(QtArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
     int f, level;
-    if (!xcd_decode(a.nframes, a.nlevels, f, level)) return;
+    if (!xcd_decode(a.nframes, a.levelsRun, f, level)) return;
+    level += a.levelBase;
     const int lane = threadIdx.x;
     const OrbxLevelGeom &g = a.geoms[level];
     uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
@@ -1910,7 +1912,7 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
 hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const OrbxLevelGeom *geomsHost,
                               const OrbxLevelGeom *geomsDev, const uint32_t *cand, long long candFrameStride,
                               const int *tileCount, int tilesPerFrame, uint32_t *scratchA, uint32_t *scratchB,
-                              uint32_t *sel, int selFrameStride, int *selCount, int maxQuota)
+                              uint32_t *sel, int selFrameStride, int *selCount, int maxQuota, int levelBase, int levelsRun)
 {
     QtArgs a;
     a.geoms = geomsDev;
@@ -1919,6 +1921,7 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     a.scratchA = scratchA; a.scratchB = scratchB;
     a.sel = sel; a.selFrameStride = selFrameStride; a.selCount = selCount;
     a.nlevels = nlevels; a.nframes = nframes;
+    a.levelBase = levelBase; a.levelsRun = levelsRun;
     { static int stop = -1; if (stop < 0) { const char *e = getenv("ORBX_QT_STOP"); stop = e ? atoi(e) : 0; } a.stop = stop; }
     int maxRoots = 1, maxTiles = 1;
     for (int l = 0; l < nlevels; ++l) {
@@ -1950,7 +1953,7 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
         fprintf(stderr, "[orbx] k_quadtree: pool %d, list %d, LDS %zu B, %d blocks/CU\n", a.pool, a.listCap, lds, nb);
     }
-    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(nframes, nlevels)), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(nframes, levelsRun)), dim3(64), lds, st, a);
     return hipGetLastError();
 }
 
