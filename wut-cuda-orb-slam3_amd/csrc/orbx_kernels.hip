@@ -2,18 +2,20 @@
 //
 // Pipeline per batch of frames (all levels, all frames per launch; everything stays in HBM):
 //   k_pyr_fast   (x nlevels)  fused: level-l tile -> LDS; bilinear level l+1 (cv::resize fixed point);
-//                             FAST-9/16 score at minThFAST; cell-local 3x3 NMS; per-cell iniTh/minTh
-//                             fallback; ordered (cell-row-major, raster) compaction with wave ballots.
-//                             Replaces ComputePyramid (reference src/ORBextractor.cc:1309-1329) +
+//                             FAST-9/16 in the reference's two rounds (iniThFAST, then minThFAST in the empty
+//                             cells); score; cell-local 3x3 NMS; ordered (cell-row-major, raster)
+//                             compaction.  Replaces ComputePyramid (reference src/ORBextractor.cc:1309-1329) +
 //                             tileCalcKeypoints (:867-950) [and the fork's tileCalcKeypoints_kernel].
 //   k_quadtree                one wave per (frame, level): DistributeOctTree (:584-774) with exact list
-//                             order and libstdc++ std::sort tie order.
-//   k_blur       (x nlevels)  cv::GaussianBlur 7x7 sigma 2, fixed point (:1270-1273).
+//                             order and libstdc++ std::sort tie order, as level-synchronous wave-parallel sweeps.
+//   k_blur3      (x nlevels)  cv::GaussianBlur 7x7 sigma 2, fixed point (:1270-1273), as int8 MFMA products
+//                             (k_blur2: SWAR, k_blur: generic fallbacks).
 //   k_pack                    border/octave/size (:1004-1017), pt *= scale, mono/stereo split (:1283-1303).
-//   k_orient_desc             one wave per keypoint: IC_Angle moments + fastAtan2 (Angle.cl:24-60) and the
+//   k_orient_desc             one wave per 8 keypoints: IC_Angle moments + fastAtan2 (Angle.cl:24-60) and the
 //                             256-bit steered BRIEF (computeOrbDescriptor, :105-149), 64 bits per ballot.
 //
-// Integer / bitwise work throughout: no MFMA.  Floating point only where the reference has it, evaluated
+// Integer / bitwise work on the VALU; the separable blur - a banded Toeplitz product - runs on the matrix cores in exact int8 /
+// int32 arithmetic (k_blur3).  Floating point only where the reference has it, evaluated
 // with explicitly rounded, un-fused operations (__fmul_rn/__fadd_rn/__fdiv_rn; file is also built with
 // -ffp-contract=off) so results are bit-identical to the x86 CPU path.
 #include "orbx_internal.h"
