@@ -125,6 +125,10 @@ extern "C" int orbx_device_count(void)
     return n;
 }
 
+// blurred levels are stored as 16 x 8 tiles of 128 B (orbx_kernels.hip: orbx_blur_tiled_offset)
+static inline int blurTilesX(const OrbxLevelGeom &g) { return (g.w + 15) / 16; }
+static inline long long blurFrameBytes(const OrbxLevelGeom &g) { return (long long)blurTilesX(g) * ((g.h + 7) / 8) * 128; }
+
 static int computeGeometry(orbx_extractor *ex, int w, int h);
 static int ensureBuffers(orbx_extractor *ex);
 
@@ -433,7 +437,7 @@ static int ensureBuffers(orbx_extractor *ex)
     for (int l = 0; l < nl; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
         if (l > 0 && (rc = ex->d_raw[l].ensure(B * g.frameStride + 64)) != ORBX_OK) return rc;
-        if ((rc = ex->d_blur[l].ensure(B * g.frameStride + 64)) != ORBX_OK) return rc;
+        if ((rc = ex->d_blur[l].ensure(B * (size_t)blurFrameBytes(g) + 64)) != ORBX_OK) return rc;
     }
     ex->inPitch = ex->geom[0].pitch;
     ex->inFrameStride = (long long)ex->inPitch * ex->geom[0].h;  // rows of consecutive frames are contiguous: one bulk H2D copy per batch
@@ -610,8 +614,8 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
             const int srcPitch = l == 0 ? (int)stride : g.pitch;
             const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
             if (earlyBlur && l > 0) HIP_TRY(hipStreamWaitEvent(sBlur, ex->evLevel[l], 0));
-            HIP_TRY(orbxLaunchBlur(sBlur, nf, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p + (size_t)f0 * g.frameStride, g.pitch,
-                                   g.frameStride, ex->taps));
+            HIP_TRY(orbxLaunchBlur(sBlur, nf, g.w, g.h, src, srcPitch, srcFS, ex->d_blur[l].p + (size_t)f0 * blurFrameBytes(g), blurTilesX(g),
+                                   blurFrameBytes(g), ex->taps));
         }
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 2) * 2 + 1], sBlur));
         HIP_TRY(hipEventRecord(ex->evBlur[sb], sBlur));
@@ -640,7 +644,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
             lv.raw[l] = l == 0 ? src0 + (size_t)f0 * frame_stride : ex->d_raw[l].p + (size_t)f0 * g.frameStride;
             lv.rawPitch[l] = l == 0 ? (int)stride : g.pitch;
             lv.rawFrameStride[l] = l == 0 ? (long long)frame_stride : g.frameStride;
-            lv.blur[l] = ex->d_blur[l].p + (size_t)f0 * g.frameStride; lv.blurPitch[l] = g.pitch; lv.blurFrameStride[l] = g.frameStride;
+            lv.blur[l] = ex->d_blur[l].p + (size_t)f0 * blurFrameBytes(g); lv.blurPitch[l] = blurTilesX(g) * 128; lv.blurFrameStride[l] = blurFrameBytes(g);
             lv.w[l] = g.w; lv.h[l] = g.h;
         }
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 4) * 2], sBack));
@@ -763,11 +767,19 @@ extern "C" int orbx_get_pyramid_level(orbx_extractor *ex, int frame, int level, 
         return setError(ORBX_ERR_INVALID_ARG, "orbx_get_pyramid_level: bad argument");
     HIP_TRY(hipSetDevice(ex->prm.device));
     const OrbxLevelGeom &g = ex->geom[level];
-    const uint8_t *src; int pitch; long long fs;
-    if (blurred) { src = ex->d_blur[level].p; pitch = g.pitch; fs = g.frameStride; }
-    else if (level == 0) { src = ex->lastSrc; pitch = ex->lastSrcPitch; fs = ex->lastSrcFrameStride; }
-    else { src = ex->d_raw[level].p; pitch = g.pitch; fs = g.frameStride; }
     HIP_TRY(hipStreamSynchronize(ex->stream));
+    if (blurred) {  // tiled on the device: fetch the frame's tiles and lay them out row-major
+        const int tx = blurTilesX(g);
+        std::vector<uint8_t> tiles((size_t)blurFrameBytes(g));
+        HIP_TRY(hipMemcpy(tiles.data(), ex->d_blur[level].p + (size_t)frame * blurFrameBytes(g), tiles.size(), hipMemcpyDeviceToHost));
+        for (int y = 0; y < g.h; ++y)
+            for (int x = 0; x < g.w; ++x)
+                out[(size_t)y * g.w + x] = tiles[((size_t)(y >> 3) * tx + (x >> 4)) * 128 + (size_t)((y & 7) * 16 + (x & 15))];
+        return ORBX_OK;
+    }
+    const uint8_t *src; int pitch; long long fs;
+    if (level == 0) { src = ex->lastSrc; pitch = ex->lastSrcPitch; fs = ex->lastSrcFrameStride; }
+    else { src = ex->d_raw[level].p; pitch = g.pitch; fs = g.frameStride; }
     HIP_TRY(hipMemcpy2D(out, g.w, src + (size_t)frame * fs, pitch, g.w, g.h, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }

@@ -671,9 +671,17 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// The blurred levels are only ever read as 37 x 37 patches around keypoints (k_orient_desc), so they are stored TILED: 16 x 8 pixel
+// tiles of 128 contiguous bytes (one L2 line), tiles in raster order.  A patch then touches ~18 lines instead of ~51 row
+// segments of a row-major image - that kernel is bound by L1 line fills - and a wave of the blur writes whole lines.
+__host__ __device__ __forceinline__ size_t orbx_blur_tiled_offset(int x, int y, int tilesX)
+{
+    return ((size_t)(y >> 3) * tilesX + (x >> 4)) * 128 + (size_t)((y & 7) * 16 + (x & 15));
+}
+
 struct BlurArgs {
     const uint8_t *src; int srcPitch; long long srcFrameStride;
-    uint8_t *dst; int dstPitch; long long dstFrameStride;
+    uint8_t *dst; int dstPitch; long long dstFrameStride;  // dst is tiled: dstPitch = tiles per tile row
     int w, h;
     int taps[7];
     int nframes, tilesX, tilesY;
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(256) void k_blur(BlurArgs a)
 #pragma unroll
             for (int k = 0; k < 7; ++k) acc += (unsigned)a.taps[k] * hs[r + k][c];
             unsigned v = (acc + 32768u) >> 16;
-            dstF[(size_t)gy * a.dstPitch + gx] = (uint8_t)min(v, 255u);
+            dstF[orbx_blur_tiled_offset(gx, gy, a.dstPitch)] = (uint8_t)min(v, 255u);
         }
     }
 }
@@ -803,7 +811,6 @@ __global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
         t[j][0] = v.x & 0xFFFFu; t[j][2] = v.x >> 16; t[j][1] = v.y & 0xFFFFu; t[j][3] = v.y >> 16;
     }
     uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
-    const bool fullw = x + 3 < a.w;
 #pragma unroll
     for (int i = 0; i < BL2_RT; ++i) {
         const int gy = y0 + r0 + i;
@@ -814,10 +821,7 @@ __global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
                 const uint32_t acc = k0 * (t[i][c] + t[i + 6][c]) + k1 * (t[i + 1][c] + t[i + 5][c]) + k2 * (t[i + 2][c] + t[i + 4][c]) + k3 * t[i + 3][c];
                 packed |= min((acc + 32768u) >> 16, 255u) << (8 * c);
             }
-            uint8_t *d = dstF + (size_t)gy * a.dstPitch + x;
-            if (fullw) *(uint32_t *)d = packed;
-            else
-                for (int c = 0; c < 4 && x + c < a.w; ++c) d[c] = (uint8_t)(packed >> (8 * c));
+            *(uint32_t *)(dstF + orbx_blur_tiled_offset(x, gy, a.dstPitch)) = packed;  // (a tile row holds all 4 pixels)
         }
     }
 }
@@ -958,10 +962,7 @@ __global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);
-                uint8_t *d = dstF + (size_t)y * a.dstPitch + xo;
-                if (xo + 3 < a.w) *(uint32_t *)d = packed;
-                else
-                    for (int r = 0; r < 4 && xo + r < a.w; ++r) d[r] = (uint8_t)(packed >> (8 * r));
+                *(uint32_t *)(dstF + orbx_blur_tiled_offset(xo, y, a.dstPitch)) = packed;  // (a tile row holds all 4 pixels)
             }
         }
         loPrev = lo; hiPrev = hi;
@@ -1039,10 +1040,7 @@ __global__ __launch_bounds__(256) void k_blur3d(BlurArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);
-                uint8_t *d = dstF + (size_t)y * a.dstPitch + xo;
-                if (xo + 3 < a.w) *(uint32_t *)d = packed;
-                else
-                    for (int r = 0; r < 4 && xo + r < a.w; ++r) d[r] = (uint8_t)(packed >> (8 * r));
+                *(uint32_t *)(dstF + orbx_blur_tiled_offset(xo, y, a.dstPitch)) = packed;  // (a tile row holds all 4 pixels)
             }
         }
         loPrev = lo; hiPrev = hi;
@@ -1060,12 +1058,11 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
     for (int k = 0; k < 7; ++k) a.taps[k] = taps[k];
     const bool symmetric = taps[0] == taps[6] && taps[1] == taps[5] && taps[2] == taps[4];
     const bool small = (taps[0] + taps[1] + taps[2]) * 2 + taps[3] <= 257;  // packed 16-bit horizontal sums cannot overflow
-    const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride | (uintptr_t)dst | (uintptr_t)dstPitch |
-                           (uintptr_t)dstFrameStride;
+    const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride | (uintptr_t)dst | (uintptr_t)dstFrameStride;
     static const int variant = [] { const char *e = getenv("ORBX_BLUR_KERNEL"); return e ? atoi(e) : 3; }();  // 2: SWAR, 1: generic (A/B timing)
     bool i8ok = true;
     for (int k = 0; k < 7; ++k) i8ok = i8ok && taps[k] >= 0 && taps[k] <= 127;
-    const uintptr_t dbits = (uintptr_t)dst | (uintptr_t)dstPitch | (uintptr_t)dstFrameStride;
+    const uintptr_t dbits = (uintptr_t)dst | (uintptr_t)dstFrameStride;
     a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 15) == 0;
     if (variant == 3 && small && i8ok && (dbits & 3) == 0 && w >= 32 && h >= 16) {
         const int S = taps[0] + taps[1] + taps[2] + taps[3] + taps[4] + taps[5] + taps[6];
@@ -1978,6 +1975,17 @@ __global__ __launch_bounds__(256) void k_pack(OrbxTables tb, const uint32_t *sel
     }
     __syncthreads();
     const int n = min(lvOff[tb.nlevels], cap);
+    // The orientation / descriptor kernel takes its keypoints in WORK order, which is free to choose (results go to slot
+    // `pos`): raster order inside each level, so that consecutive waves read neighbouring patches (DRAM pages, L2 lines)
+    // instead of the quadtree's scattered list order.  Rank of a key among the keys of its level = its work slot.
+    extern __shared__ uint32_t skey[];
+    for (int gi = tid; gi < n; gi += 256) {
+        int l = 0;
+        while (gi >= lvOff[l + 1]) ++l;
+        const uint32_t key = sel[(size_t)f * selFrameStride + tb.selBase[l] + (gi - lvOff[l])];
+        skey[gi] = ((key & 0xFFF) + ORBX_BORDER) | ((((key >> 12) & 0xFFF) + ORBX_BORDER) << 12) | ((uint32_t)l << 24);
+    }
+    __syncthreads();
     int running = 0;
     const unsigned long long lt = lanemask_lt();
     for (int base = 0; base < n; base += 256) {
@@ -2010,8 +2018,12 @@ __global__ __launch_bounds__(256) void k_pack(OrbxTables tb, const uint32_t *sel
             kp.x = fx; kp.y = fy; kp.size = (float)tb.patchSize[l]; kp.angle = -1.f;
             kp.response = (float)(key >> 24); kp.octave = l; kp.class_id = -1;
             kps[(size_t)f * cap + pos] = kp;
-            workKey[(size_t)f * cap + gi] = (uint32_t)xl | ((uint32_t)yl << 12) | ((uint32_t)l << 24);
-            workPos[(size_t)f * cap + gi] = pos;
+            const uint32_t wk = (uint32_t)xl | ((uint32_t)yl << 12) | ((uint32_t)l << 24);
+            int slot = lvOff[l];
+            const int jEnd = min(lvOff[l + 1], n);
+            for (int j = lvOff[l]; j < jEnd; ++j) slot += skey[j] < wk;  // positions are unique inside a level
+            workKey[(size_t)f * cap + slot] = wk;
+            workPos[(size_t)f * cap + slot] = pos;
         }
         running += blockTot;
         __syncthreads();
@@ -2023,7 +2035,7 @@ hipError_t orbxLaunchPack(hipStream_t st, int nframes, OrbxTables tabs, const ui
                           const int *selCount, int lap0, int lap1, void *kps, int cap, uint32_t *workKey,
                           int *workPos, int *nOut, int *monoOut)
 {
-    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, st, tabs, sel, selFrameStride, selCount, lap0, lap1,
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), (size_t)cap * sizeof(uint32_t), st, tabs, sel, selFrameStride, selCount, lap0, lap1,
                        (OrbxKp *)kps, cap, workKey, workPos, nOut, monoOut);
     return hipGetLastError();
 }
@@ -2061,11 +2073,14 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 #define OD_KPW 8   // keypoints per wave: small single-wave workgroups keep fewer frames in flight per XCD (L2 reuse of the
                    // patches); measured 0.76 ms (8 x 1 wave) vs 0.83 ms (32 x 4 waves) per batch
 #endif
+#ifndef OD_KPB
+#define OD_KPB 8   // keypoints whose patch loads are in flight together in the moment pass
+#endif
 #ifndef OD_WPB
 #define OD_WPB 1   // waves per workgroup (the waves are independent)
 #endif
-#define OD_PROWS 37    // blurred patch rows staged per keypoint (sample reach is +-18)
-#define OD_PPITCH 64   // 4 x 16-byte chunks per row: covers [x - 18 - 15, x + 18] for any alignment
+#define OD_PROWS 48    // blurred patch rows staged per keypoint: up to 6 tile rows of 8 (sample reach is +-18)
+#define OD_PPITCH 64   // up to 4 tiles of 16 columns: covers [x - 18 - 15, x + 18] for any alignment
 
 // Waves of one workgroup use disjoint LDS slices here, so ordering only has to hold inside a wave: wait for this
 // wave's own LDS traffic and stop the compiler from moving LDS accesses across the point.
@@ -2104,6 +2119,10 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
     const int base = (chunk * OD_WPB + wave) * OD_KPW;
     if (base >= n) return;
     const int cnt = min(OD_KPW, n - base);
+#if defined(OD_STOP) && OD_STOP == 6
+    if (lane == 0) kps[(size_t)f * cap + base].angle = (float)n;
+    return;
+#endif
     uint32_t myKey = 0;
     int myPos = 0;
     if (lane < cnt) {
@@ -2131,54 +2150,75 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         myRp = lv.rawPitch[l];
         myBp = lv.blurPitch[l];
         myRaw = (unsigned long long)(lv.raw[l] + (size_t)f * lv.rawFrameStride[l] + (size_t)yl * myRp + xl);
-        const int cx0 = (xl - 18) & ~15;  // 16-byte aligned first column of the staged blurred patch
-        myBlur = (unsigned long long)(lv.blur[l] + (size_t)f * lv.blurFrameStride[l] + (size_t)(yl - 18) * myBp + cx0);
+        // first 16 x 8 tile of the staged blurred patch (tiled layout, orbx_blur_tiled_offset; myBp = bytes per tile row)
+        myBlur = (unsigned long long)(lv.blur[l] + (size_t)f * lv.blurFrameStride[l] + (size_t)((yl - 18) >> 3) * myBp + ((xl - 18) >> 4) * 128);
     }
-    const int u = (lane & 31) - 15;
-    const int au = u < 0 ? -u : u;
-    // this lane's 16 (row, column) patch samples: row v = 2 * it + (lane >> 5) - 15, column u; a sample outside the
-    // circular patch (|u| > umax[|v|], or the 32nd row / column) gets weight 0 — loads stay unconditional (every
-    // address is inside the image: keypoints keep a 19-px margin) and the loop is branch-free
-    int wu[16], wv[16], vrow[16];
+    // The 31 x 31 patch is read as dwords: lane = (row r = lane >> 3, dword j = lane & 7) covers row v = 8 it + r - 15 (it = 0..3)
+    // and the 4 columns u = 4j - 15 .. 4j - 12, loaded from the exact (byte-unaligned) address - four loads per lane and
+    // keypoint instead of 16 byte loads (the texture addresser takes a wave's 64 addresses at the same rate for either).
+    // Samples outside the circular patch (|u| > umax[|v|], or the 32nd row / column, which are still inside the image:
+    // keypoints keep a 19-px margin) get weight 0, so the loads are unconditional and the loop is branch-free.
+    //   m10 = sum u p = sum (u + 16) p - 16 sum p,   m01 = sum v p      with two v_dot4_u32_u8 per dword
+    const int pj = lane & 7, pr = lane >> 3;
+    uint32_t w1[4], w0[4];
+    int vv[4];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int v = it * 2 + (lane >> 5) - 15;
+    for (int it = 0; it < 4; ++it) {
+        const int v = 8 * it + pr - 15;
         const int av = v < 0 ? -v : v;
         const int um = (int)((tb.umaxPacked >> (4 * (av & 15))) & 15);
-        const bool in = v <= 15 && au <= um;
-        wu[it] = in ? u : 0;
-        wv[it] = in ? v : 0;
-        vrow[it] = v;
+        w1[it] = 0; w0[it] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int u = 4 * pj - 15 + b;
+            const bool in = v <= 15 && (u < 0 ? -u : u) <= um;
+            w1[it] |= in ? (uint32_t)(u + 16) << (8 * b) : 0u;
+            w0[it] |= in ? 1u << (8 * b) : 0u;
+        }
+        vv[it] = v;
     }
     typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    typedef const __attribute__((address_space(1))) u32_unaligned *gdw_t;
     int myM01 = 0, myM10 = 0;
-    // two keypoints per iteration: 32 independent byte loads in flight per lane before the first reduction
-    for (int k = 0; k < cnt; k += 2) {
-        const bool two = k + 1 < cnt;
-        const int k1 = two ? k + 1 : k;
-        const gptr_t c0 = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myRaw >> 32), k) << 32) |
-                                   (unsigned)__builtin_amdgcn_readlane((int)myRaw, k));
-        const gptr_t c1 = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myRaw >> 32), k1) << 32) |
-                                   (unsigned)__builtin_amdgcn_readlane((int)myRaw, k1));
-        const int rp0 = __builtin_amdgcn_readlane(myRp, k), rp1 = __builtin_amdgcn_readlane(myRp, k1);
-        int I0[16], I1[16];
+#if defined(OD_STOP) && OD_STOP == 5
+    if (lane < cnt) kps[(size_t)f * cap + myPos].angle = (float)(myRp + (int)myRaw + (int)w1[0] + (int)w0[3] + (int)px0[0]);
+    return;
+#endif
+    // OD_KPB keypoints per step: 4 * OD_KPB independent dword loads in flight per lane before the first reduction (the pass is
+    // bound by the latency of these loads)
+    for (int k0 = 0; k0 < cnt; k0 += OD_KPB) {
+        uint32_t P[OD_KPB][4];
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            I0[it] = c0[vrow[it] * rp0 + u];
-            I1[it] = c1[vrow[it] * rp1 + u];
-        }
-        int a10 = 0, a01 = 0, b10 = 0, b01 = 0;
+        for (int q = 0; q < OD_KPB; ++q) {
+            const int k = min(k0 + q, cnt - 1);
+            const gptr_t c = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myRaw >> 32), k) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)myRaw, k));
+            const int rp = __builtin_amdgcn_readlane(myRp, k);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            a10 += wu[it] * I0[it]; a01 += wv[it] * I0[it];
-            b10 += wu[it] * I1[it]; b01 += wv[it] * I1[it];
+            for (int it = 0; it < 4; ++it) P[q][it] = *(gdw_t)(c + vv[it] * rp + 4 * pj - 15);
         }
-        a10 = wave_sum_i32(a10); a01 = wave_sum_i32(a01);
-        b10 = wave_sum_i32(b10); b01 = wave_sum_i32(b01);
-        if (lane == k) { myM10 = a10; myM01 = a01; }
-        if (two && lane == k1) { myM10 = b10; myM01 = b01; }
+#pragma unroll
+        for (int q = 0; q < OD_KPB; ++q) {
+            uint32_t s1 = 0, s0 = 0;
+            int m01 = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                s1 = __builtin_amdgcn_udot4(P[q][it], w1[it], s1, false);
+                const uint32_t t = __builtin_amdgcn_udot4(P[q][it], w0[it], 0u, false);
+                s0 += t;
+                m01 += vv[it] * (int)t;
+            }
+            const int m10 = wave_sum_i32((int)s1 - 16 * (int)s0);
+            m01 = wave_sum_i32(m01);
+            if (k0 + q < cnt && lane == k0 + q) { myM10 = m10; myM01 = m01; }
+        }
     }
 
+#if defined(OD_STOP) && OD_STOP == 1
+    if (lane < cnt) kps[(size_t)f * cap + myPos].angle = (float)(myM10 + myM01);
+    return;
+#endif
     // ---- pass 2: orientation + rotation, one keypoint per lane ---------------------------------------------------
     float angle;
     if (tb.angleMode == 1) {
@@ -2193,25 +2233,37 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
     const float myA = (float)cos((double)ar), myB = (float)sin((double)ar);
     if (lane < cnt) kps[(size_t)f * cap + myPos].angle = angle;
 
+#if defined(OD_STOP) && OD_STOP == 2
+    return;
+#endif
     // ---- pass 3: descriptors --------------------------------------------------------------------------------
     // The 512 sample points of a keypoint lie within +-18 px of it.  Instead of 8 wave-wide 64-way divergent byte
-    // gathers from global memory (texture-address bound), the 37 x 37 blurred patch is staged into this wave's LDS
-    // slice with coalesced 16-byte-per-lane loads (37 rows x 4 chunks = 148 loads = 3 wave instructions) and the
-    // samples are gathered from LDS.
+    // gathers from global memory (texture-address bound), the tiles that cover the 37 x 37 blurred patch (at most 4 x 6
+    // tiles of 128 B, one 16-byte tile row per lane = 3 wave instructions) are staged row-major into this wave's LDS slice
+    // and the samples are gathered from LDS.
     __shared__ __attribute__((aligned(16))) uint8_t patchLds[OD_WPB][OD_PROWS * OD_PPITCH];
     uint8_t *patch = patchLds[wave];
     // staging loads of keypoint k + 1 are issued before the samples of keypoint k are consumed
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 nxt[3];
+    auto tilesOf = [&](int kk, int &ntx, int &nty) {
+        const uint32_t key = __builtin_amdgcn_readlane(myKey, kk);
+        const int xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
+        ntx = ((xl + 18) >> 4) - ((xl - 18) >> 4) + 1;
+        nty = ((yl + 18) >> 3) - ((yl - 18) >> 3) + 1;
+    };
     auto issue = [&](int kk) {
         typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
         const gptr_t src = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myBlur >> 32), kk) << 32) |
                                     (unsigned)__builtin_amdgcn_readlane((int)myBlur, kk));
         const int bp = __builtin_amdgcn_readlane(myBp, kk);
+        int ntx, nty;
+        tilesOf(kk, ntx, nty);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int idx = lane + 64 * i;
-            if (idx < OD_PROWS * 4) nxt[i] = *(const __attribute__((address_space(1))) u32x4 *)(src + (idx >> 2) * bp + (idx & 3) * 16);
+            const int idx = lane + 64 * i, r = idx >> 2, tc = idx & 3;  // patch row r = 8 * tile row + row in tile, tile column tc
+            if (tc < ntx && (r >> 3) < nty)
+                nxt[i] = *(const __attribute__((address_space(1))) u32x4 *)(src + (r >> 3) * bp + tc * 128 + (r & 7) * 16);
         }
     };
     issue(0);
@@ -2220,17 +2272,18 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         const int pos = __builtin_amdgcn_readlane(myPos, k);
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myA), k));
         const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myB), k));
-        const int xl = key & 0xFFF;
-        const int cx0 = (xl - 18) & ~15;
+        const int xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
+        int ntx, nty;
+        tilesOf(k, ntx, nty);
         __syncthreads_lds_wave();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int idx = lane + 64 * i;
-            if (idx < OD_PROWS * 4) *(u32x4 *)(patch + (idx >> 2) * OD_PPITCH + (idx & 3) * 16) = nxt[i];
+            const int idx = lane + 64 * i, r = idx >> 2, tc = idx & 3;
+            if (tc < ntx && (r >> 3) < nty) *(u32x4 *)(patch + r * OD_PPITCH + tc * 16) = nxt[i];
         }
         if (k + 1 < cnt) issue(k + 1);
         __syncthreads_lds_wave();
-        const uint8_t *bc = patch + 18 * OD_PPITCH + (xl - cx0);
+        const uint8_t *bc = patch + (yl - (((yl - 18) >> 3) << 3)) * OD_PPITCH + (xl - (((xl - 18) >> 4) << 4));
         int t0[4], t1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
