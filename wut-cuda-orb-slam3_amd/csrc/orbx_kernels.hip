@@ -1975,17 +1975,6 @@ __global__ __launch_bounds__(256) void k_pack(OrbxTables tb, const uint32_t *sel
     }
     __syncthreads();
     const int n = min(lvOff[tb.nlevels], cap);
-    // The orientation / descriptor kernel takes its keypoints in WORK order, which is free to choose (results go to slot
-    // `pos`): raster order inside each level, so that consecutive waves read neighbouring patches (DRAM pages, L2 lines)
-    // instead of the quadtree's scattered list order.  Rank of a key among the keys of its level = its work slot.
-    extern __shared__ uint32_t skey[];
-    for (int gi = tid; gi < n; gi += 256) {
-        int l = 0;
-        while (gi >= lvOff[l + 1]) ++l;
-        const uint32_t key = sel[(size_t)f * selFrameStride + tb.selBase[l] + (gi - lvOff[l])];
-        skey[gi] = ((key & 0xFFF) + ORBX_BORDER) | ((((key >> 12) & 0xFFF) + ORBX_BORDER) << 12) | ((uint32_t)l << 24);
-    }
-    __syncthreads();
     int running = 0;
     const unsigned long long lt = lanemask_lt();
     for (int base = 0; base < n; base += 256) {
@@ -2018,12 +2007,9 @@ __global__ __launch_bounds__(256) void k_pack(OrbxTables tb, const uint32_t *sel
             kp.x = fx; kp.y = fy; kp.size = (float)tb.patchSize[l]; kp.angle = -1.f;
             kp.response = (float)(key >> 24); kp.octave = l; kp.class_id = -1;
             kps[(size_t)f * cap + pos] = kp;
-            const uint32_t wk = (uint32_t)xl | ((uint32_t)yl << 12) | ((uint32_t)l << 24);
-            int slot = lvOff[l];
-            const int jEnd = min(lvOff[l + 1], n);
-            for (int j = lvOff[l]; j < jEnd; ++j) slot += skey[j] < wk;  // positions are unique inside a level
-            workKey[(size_t)f * cap + slot] = wk;
-            workPos[(size_t)f * cap + slot] = pos;
+            // work order of k_orient_desc = list order (a raster order inside each level was measured: no gain)
+            workKey[(size_t)f * cap + gi] = (uint32_t)xl | ((uint32_t)yl << 12) | ((uint32_t)l << 24);
+            workPos[(size_t)f * cap + gi] = pos;
         }
         running += blockTot;
         __syncthreads();
@@ -2035,7 +2021,7 @@ hipError_t orbxLaunchPack(hipStream_t st, int nframes, OrbxTables tabs, const ui
                           const int *selCount, int lap0, int lap1, void *kps, int cap, uint32_t *workKey,
                           int *workPos, int *nOut, int *monoOut)
 {
-    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), (size_t)cap * sizeof(uint32_t), st, tabs, sel, selFrameStride, selCount, lap0, lap1,
+    hipLaunchKernelGGL(k_pack, dim3(nframes), dim3(256), 0, st, tabs, sel, selFrameStride, selCount, lap0, lap1,
                        (OrbxKp *)kps, cap, workKey, workPos, nOut, monoOut);
     return hipGetLastError();
 }
@@ -2153,6 +2139,8 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         // first 16 x 8 tile of the staged blurred patch (tiled layout, orbx_blur_tiled_offset; myBp = bytes per tile row)
         myBlur = (unsigned long long)(lv.blur[l] + (size_t)f * lv.blurFrameStride[l] + (size_t)((yl - 18) >> 3) * myBp + ((xl - 18) >> 4) * 128);
     }
+    // (A tiled copy of the raw levels for this pass - 14 line fills per patch instead of 38 - was measured and dropped: the
+    // per-dword circle masks it needs cost more VALU than the fills it saves, 0.67 vs 0.60 ms, and the copy slows the blur.)
     // The 31 x 31 patch is read as dwords: lane = (row r = lane >> 3, dword j = lane & 7) covers row v = 8 it + r - 15 (it = 0..3)
     // and the 4 columns u = 4j - 15 .. 4j - 12, loaded from the exact (byte-unaligned) address - four loads per lane and
     // keypoint instead of 16 byte loads (the texture addresser takes a wave's 64 addresses at the same rate for either).
