@@ -2062,6 +2062,9 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 #ifndef OD_KPB
 #define OD_KPB 8   // keypoints whose patch loads are in flight together in the moment pass
 #endif
+#ifndef OD_PF
+#define OD_PF 3    // descriptor pass: keypoints whose patch loads are in flight ahead of the one being sampled
+#endif
 #ifndef OD_WPB
 #define OD_WPB 1   // waves per workgroup (the waves are independent)
 #endif
@@ -2094,21 +2097,27 @@ __device__ __forceinline__ int wave_sum_i32(int x)
 //           lane, DPP row reduction); lane k keeps the moments of keypoint k
 //   pass 2  per lane: fastAtan2 + (float)cos/sin((double)angle) for all keypoints of the wave at once
 //   pass 3  per keypoint, wave-cooperative: 256 steered-BRIEF tests, 64 per ballot
+#ifdef OD_TIMING
+// debug build (-DOD_TIMING): phase time stamps (s_memtime) of the first 8192 workgroups, read back with orbx_debug_od_timing
+// (tools/od_timing.py)
+__device__ unsigned long long g_odTiming[8192][8];
+extern "C" int orbx_debug_od_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_odTiming), sizeof(g_odTiming)); }
+#define OD_STAMP(i) do { if (blockIdx.x < 8192 && threadIdx.x == 0) g_odTiming[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define OD_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, OrbxLevelPtrs lv, const uint32_t *workKey,
                                                      const int *workPos, const int *nOut, OrbxKp *kps, uint8_t *desc,
                                                      int cap, int nframes, int chunks)
 {
     int f, chunk;
+    OD_STAMP(0);
     if (!xcd_decode(nframes, chunks, f, chunk)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = nOut[f];
     const int base = (chunk * OD_WPB + wave) * OD_KPW;
     if (base >= n) return;
     const int cnt = min(OD_KPW, n - base);
-#if defined(OD_STOP) && OD_STOP == 6
-    if (lane == 0) kps[(size_t)f * cap + base].angle = (float)n;
-    return;
-#endif
     uint32_t myKey = 0;
     int myPos = 0;
     if (lane < cnt) {
@@ -2169,10 +2178,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
     typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
     typedef const __attribute__((address_space(1))) u32_unaligned *gdw_t;
     int myM01 = 0, myM10 = 0;
-#if defined(OD_STOP) && OD_STOP == 5
-    if (lane < cnt) kps[(size_t)f * cap + myPos].angle = (float)(myRp + (int)myRaw + (int)w1[0] + (int)w0[3] + (int)px0[0]);
-    return;
-#endif
+    OD_STAMP(1);
     // OD_KPB keypoints per step: 4 * OD_KPB independent dword loads in flight per lane before the first reduction (the pass is
     // bound by the latency of these loads)
     for (int k0 = 0; k0 < cnt; k0 += OD_KPB) {
@@ -2203,10 +2209,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         }
     }
 
-#if defined(OD_STOP) && OD_STOP == 1
-    if (lane < cnt) kps[(size_t)f * cap + myPos].angle = (float)(myM10 + myM01);
-    return;
-#endif
+    OD_STAMP(2);
     // ---- pass 2: orientation + rotation, one keypoint per lane ---------------------------------------------------
     float angle;
     if (tb.angleMode == 1) {
@@ -2221,9 +2224,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
     const float myA = (float)cos((double)ar), myB = (float)sin((double)ar);
     if (lane < cnt) kps[(size_t)f * cap + myPos].angle = angle;
 
-#if defined(OD_STOP) && OD_STOP == 2
-    return;
-#endif
+    OD_STAMP(3);
     // ---- pass 3: descriptors --------------------------------------------------------------------------------
     // The 512 sample points of a keypoint lie within +-18 px of it.  Instead of 8 wave-wide 64-way divergent byte
     // gathers from global memory (texture-address bound), the tiles that cover the 37 x 37 blurred patch (at most 4 x 6
@@ -2231,16 +2232,18 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
     // and the samples are gathered from LDS.
     __shared__ __attribute__((aligned(16))) uint8_t patchLds[OD_WPB][OD_PROWS * OD_PPITCH];
     uint8_t *patch = patchLds[wave];
-    // staging loads of keypoint k + 1 are issued before the samples of keypoint k are consumed
+    // A wave spends most of this pass waiting for the staging loads (~5000 cycles under load against ~1000 cycles of work
+    // per keypoint, tools/od_timing.py): the loads of the next OD_PF keypoints are in flight (a ring of 3-register slots,
+    // indexed statically because the keypoint loop is fully unrolled) while the samples of keypoint k are consumed.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 nxt[3];
+    u32x4 nxt[OD_PF][3];
     auto tilesOf = [&](int kk, int &ntx, int &nty) {
         const uint32_t key = __builtin_amdgcn_readlane(myKey, kk);
         const int xl = key & 0xFFF, yl = (key >> 12) & 0xFFF;
         ntx = ((xl + 18) >> 4) - ((xl - 18) >> 4) + 1;
         nty = ((yl + 18) >> 3) - ((yl - 18) >> 3) + 1;
     };
-    auto issue = [&](int kk) {
+    auto issue = [&](int kk, u32x4 (&dst)[3]) {
         typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
         const gptr_t src = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myBlur >> 32), kk) << 32) |
                                     (unsigned)__builtin_amdgcn_readlane((int)myBlur, kk));
@@ -2251,11 +2254,15 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         for (int i = 0; i < 3; ++i) {
             const int idx = lane + 64 * i, r = idx >> 2, tc = idx & 3;  // patch row r = 8 * tile row + row in tile, tile column tc
             if (tc < ntx && (r >> 3) < nty)
-                nxt[i] = *(const __attribute__((address_space(1))) u32x4 *)(src + (r >> 3) * bp + tc * 128 + (r & 7) * 16);
+                dst[i] = *(const __attribute__((address_space(1))) u32x4 *)(src + (r >> 3) * bp + tc * 128 + (r & 7) * 16);
         }
     };
-    issue(0);
-    for (int k = 0; k < cnt; ++k) {
+#pragma unroll
+    for (int k = 0; k < OD_PF; ++k)
+        if (k < cnt) issue(k, nxt[k]);
+#pragma unroll
+    for (int k = 0; k < OD_KPW; ++k) {
+        if (k >= cnt) break;  // wave-uniform
         const uint32_t key = __builtin_amdgcn_readlane(myKey, k);
         const int pos = __builtin_amdgcn_readlane(myPos, k);
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myA), k));
@@ -2267,9 +2274,9 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int idx = lane + 64 * i, r = idx >> 2, tc = idx & 3;
-            if (tc < ntx && (r >> 3) < nty) *(u32x4 *)(patch + r * OD_PPITCH + tc * 16) = nxt[i];
+            if (tc < ntx && (r >> 3) < nty) *(u32x4 *)(patch + r * OD_PPITCH + tc * 16) = nxt[k % OD_PF][i];
         }
-        if (k + 1 < cnt) issue(k + 1);
+        if (k + OD_PF < cnt) issue(k + OD_PF, nxt[k % OD_PF]);
         __syncthreads_lds_wave();
         const uint8_t *bc = patch + (yl - (((yl - 18) >> 3) << 3)) * OD_PPITCH + (xl - (((xl - 18) >> 4) << 4));
         int t0[4], t1[4];
@@ -2290,6 +2297,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         }
         if (lane < 4) *(unsigned long long *)(desc + ((size_t)f * cap + pos) * 32 + lane * 8) = word;
     }
+    OD_STAMP(4);
 }
 
 hipError_t orbxLaunchOrientDesc(hipStream_t st, int nframes, OrbxTables tabs, OrbxLevelPtrs lv, const uint32_t *workKey,
