@@ -233,15 +233,28 @@ def test_two_handles_concurrently(pkg, orc):
     [e.close() for e in exs]
 
 
-def test_quadtree_pool_compaction_path(pkg):
-    """The quadtree recycles node ids by compacting its tombstoned list when the node pool runs low.  With the
-    default pool (2 * quota + 64) that path is rare; force a tiny pool in a subprocess and check full parity."""
+def _gpu_check_subprocess(extra_env, arg_sets):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ORBX_QT_POOL_SLACK="12")
-    for args in (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]):
+    env = dict(os.environ, **extra_env)
+    for args in arg_sets:
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py")] + args, env=env,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert out.returncode == 0 and "ALL STAGES BIT-IDENTICAL" in out.stdout, out.stdout[-2000:]
+
+
+def test_quadtree_pool_compaction_path(pkg):
+    """The serial quadtree formulation (k_quadtree_serial) recycles node ids by compacting its tombstoned list when the node
+    pool runs low.  With the default pool (2 * quota + 64) that path is rare; force the serial kernel with a tiny pool in a
+    subprocess (the switches are read once per process) and check full parity."""
+    _gpu_check_subprocess({"ORBX_QT_KERNEL": "1", "ORBX_QT_POOL_SLACK": "12"},
+                          (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
+
+
+def test_quadtree_deferred_instances(pkg):
+    """Candidate sets above the capacity of the level-synchronous kernel are marked and taken by the serial kernel in a
+    second launch.  At VGA no set reaches the real limit (8192 keys): lower it so that the large levels are deferred while
+    the small ones stay on the parallel kernel, and check full parity of the mixed result."""
+    _gpu_check_subprocess({"ORBX_QT_MAX_KEYS": "600"}, (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))

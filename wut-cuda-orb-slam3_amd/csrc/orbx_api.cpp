@@ -553,7 +553,9 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     const int subSize = ((nframes + nsub - 1) / nsub + 7) / 8 * 8;
     nsub = (nframes + subSize - 1) / subSize;
 
-    static const bool qtPerLevel = [] { const char *e = getenv("ORBX_QT_PER_LEVEL"); return e ? atoi(e) != 0 : false; }();
+    // 0: one quadtree launch for all levels; 1: one launch per level, next to k_pyr_fast of the following level; k >= 2: groups
+    // of k - 1 levels per launch after k_pyr_fast (LDS per instance sized by the group's largest quota)
+    static const int qtPerLevel = [] { const char *e = getenv("ORBX_QT_PER_LEVEL"); return e ? atoi(e) : 3; }();  // measured: 0 4.34 ms, 2 4.40, 3 4.17, 4 4.20, 5 4.29
     static const bool earlyBlur = [] { const char *e = getenv("ORBX_EARLY_BLUR"); return e ? atoi(e) != 0 : false; }();  // measured: 6.37 ms with early blur vs 6.02 ms with blur || quadtree
     hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * PROF_EVENTS] : nullptr;
     if (earlyBlur) {
@@ -584,7 +586,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
                                       ex->d_cand.p + (size_t)f0 * ex->candFrameStride, ex->candFrameStride,
                                       ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame, ex->prm.ini_th_fast,
                                       ex->prm.min_th_fast));
-            if (qtPerLevel) {
+            if (qtPerLevel == 1) {
                 // the quadtree of this level only needs this level's candidates: it runs on the back stream next to the
                 // pyramid + FAST launches of the smaller levels (latency-bound single waves under a throughput-bound kernel)
                 HIP_TRY(hipEventRecord(ex->evLevel[l], sFront));
@@ -623,12 +625,15 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
         // ---- back stream: quadtree -> pack -> (join blur) -> orientation + descriptors -----------------------------
         HIP_TRY(hipStreamWaitEvent(sBack, ex->evFront[sb], 0));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2], sBack));
-        if (!qtPerLevel) {
-            HIP_TRY(orbxLaunchQuadtree(sBack, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
-                                       ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
-                                       ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
-                                       ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
-                                       ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, 0, nl));
+        if (qtPerLevel != 1) {
+            // one launch per group of `qtPerLevel` levels (0: all levels in one launch): LDS per instance follows the quota
+            const int step = qtPerLevel >= 2 ? qtPerLevel - 1 : nl;
+            for (int l0 = 0; l0 < nl; l0 += step)
+                HIP_TRY(orbxLaunchQuadtree(sBack, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
+                                           ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
+                                           ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
+                                           ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
+                                           ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, l0, std::min(step, nl - l0)));
         }
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2 + 1], sBack));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 3) * 2], sBack));

@@ -1116,6 +1116,7 @@ struct QtArgs {
     int pool;     // node pool size P
     int listCap;  // capacity of list-sized arrays (max quota + 8)
     int ldsKeys;  // candidates of one instance held in LDS (0: always in global scratch)
+    int maxKeys;  // largest candidate set the level-synchronous kernel takes (<= QT3_MAX_KEYS; ORBX_QT_MAX_KEYS lowers it in tests)
     int nodeBytes;  // LDS bytes of the node arrays (keys follow)
     int variant;  // 3: level-synchronous (default), 1: serial list walk (ORBX_QT_KERNEL; also taken for > QT3_MAX_KEYS candidates)
     int stop;     // debug (ORBX_QT_STOP): 1 return after the gather, 2 after the roots, 3 skip the sorted phase, 4 skip the sort only
@@ -1269,7 +1270,7 @@ __device__ __forceinline__ int qt_flatten(QtCtx &S, int nOrder, short *dst)
 }
 
 template <bool LDSK, class KP>
-__device__ __noinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int f, int level, uint8_t *qlds, KP A, KP B, int M,
+__device__ __forceinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int f, int level, uint8_t *qlds, KP A, KP B, int M,
                         const int *tc, uint32_t *selOut, int *selCnt)
 {
     const int lane = threadIdx.x;
@@ -1872,38 +1873,64 @@ static size_t qtNodeBytes(int P, int L)
     return (((size_t)P * 22 + (size_t)L * 22 + 216 * 4) + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(64) void k_quadtree(QtArgs)
+#define QT_DEFERRED (-1)  // selCount marker: candidate set too large for the level-synchronous kernel, left to k_quadtree_serial
+
+// common prologue: (frame, level) of this instance, its output slots and candidate count
+__device__ __forceinline__ bool qt_instance(QtArgsK &a, int &f, int &level, int &M)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
-    QtArgsK &a = *(QtArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
-    int f, level;
-    if (!xcd_decode(a.nframes, a.levelsRun, f, level)) return;
+    if (!xcd_decode(a.nframes, a.levelsRun, f, level)) return false;
     level += a.levelBase;
     const int lane = threadIdx.x;
     const OrbxLevelGeom &g = a.geoms[level];
-    uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
-    int *selCnt = a.selCount + (size_t)f * a.nlevels + level;
     const int *tc = a.tileCount + (size_t)f * a.tilesPerFrame + g.tileBase;
-    int M = 0;
+    M = 0;
     for (int tb = 0; tb < g.nTiles; tb += WAVE) {
         int v = tb + lane < g.nTiles ? tc[tb + lane] : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         M += v;
     }
-    if (M == 0) { if (lane == 0) *selCnt = 0; return; }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_quadtree(QtArgs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
+    QtArgsK &a = *(QtArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    int f, level, M;
+    if (!qt_instance(a, f, level, M)) return;
+    const OrbxLevelGeom &g = a.geoms[level];
+    uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
+    int *selCnt = a.selCount + (size_t)f * a.nlevels + level;
+    const int *tc = a.tileCount + (size_t)f * a.tilesPerFrame + g.tileBase;
+    if (M == 0 || M > a.maxKeys) { if (threadIdx.x == 0) *selCnt = M == 0 ? 0 : QT_DEFERRED; return; }
     uint32_t *gA = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
     uint32_t *gB = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
-    if (a.variant == 3 && M <= QT3_MAX_KEYS) {
-        // all keys in registers for a pass + one LDS buffer behind the node arrays; larger sets ping-pong in global scratch
-        uint32_t *lK = (uint32_t *)(qlds + a.nodeBytes);
-        const bool inRegs = M <= QT3_KCH * WAVE;
-        uint32_t *kA = inRegs && M <= a.ldsKeys ? lK : gA;
-        qt3_body(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
-        return;
-    }
-    // serial formulation: one key buffer in LDS when it fits; the second one is only used while a node still holds more than
-    // 64 keys (the first few divides), so it always lives in global scratch
+    // all keys in registers for a pass + one LDS buffer behind the node arrays; larger sets ping-pong in global scratch
+    uint32_t *lK = (uint32_t *)(qlds + a.nodeBytes);
+    const bool inRegs = M <= QT3_KCH * WAVE;
+    uint32_t *kA = inRegs && M <= a.ldsKeys ? lK : gA;
+    qt3_body(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
+}
+
+// serial formulation (one DivideNode at a time): every instance (a.variant == 1, A/B runs) or only those the kernel above
+// deferred.  One key buffer in LDS when it fits; the second one is only used while a node still holds more than 64 keys (the
+// first few divides), so it always lives in global scratch.
+__global__ __launch_bounds__(64) void k_quadtree_serial(QtArgs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
+    QtArgsK &a = *(QtArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    int f, level, M;
+    if (!xcd_decode(a.nframes, a.levelsRun, f, level)) return;
+    if (a.variant == 3 && a.selCount[(size_t)f * a.nlevels + level + a.levelBase] != QT_DEFERRED) return;  // the common case
+    if (!qt_instance(a, f, level, M)) return;
+    const OrbxLevelGeom &g = a.geoms[level];
+    uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
+    int *selCnt = a.selCount + (size_t)f * a.nlevels + level;
+    const int *tc = a.tileCount + (size_t)f * a.tilesPerFrame + g.tileBase;
+    if (M == 0) { if (threadIdx.x == 0) *selCnt = 0; return; }
+    uint32_t *gA = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
+    uint32_t *gB = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
     if (M <= a.ldsKeys) qt_body<true>(a, g, f, level, qlds, (uint32_t *)(qlds + a.nodeBytes), gB, M, tc, selOut, selCnt);
     else qt_body<false>(a, g, f, level, qlds, gA, gB, M, tc, selOut, selCnt);
 }
@@ -1922,9 +1949,12 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     a.nlevels = nlevels; a.nframes = nframes;
     a.levelBase = levelBase; a.levelsRun = levelsRun;
     { static int stop = -1; if (stop < 0) { const char *e = getenv("ORBX_QT_STOP"); stop = e ? atoi(e) : 0; } a.stop = stop; }
+    // LDS is sized for the levels of THIS launch (list capacity = largest quota + slack)
     int maxRoots = 1, maxTiles = 1;
-    for (int l = 0; l < nlevels; ++l) {
+    maxQuota = 0;
+    for (int l = levelBase; l < levelBase + levelsRun; ++l) {
         const OrbxLevelGeom &g = geomsHost[l];
+        maxQuota = std::max(maxQuota, g.quota);
         const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
         maxRoots = std::max(maxRoots, (int)roundf((float)W / (float)H));
         maxTiles = std::max(maxTiles, g.nTiles);
@@ -1939,20 +1969,32 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     if (a.pool > 32767 || a.listCap > 32767) return hipErrorInvalidValue;  // node ids / list positions are 15-bit
     { static int lk = -1; if (lk < 0) { const char *e = getenv("ORBX_QT_LDS_KEYS"); lk = e ? atoi(e) : QT_LDS_KEYS; } a.ldsKeys = lk; }  // measured: 0 (13 KB per instance, 12 per CU) beats 2048 (21 KB)
     { static int v = -1; if (v < 0) { const char *e = getenv("ORBX_QT_KERNEL"); v = e ? atoi(e) : 3; } a.variant = v; }
-    a.nodeBytes = (int)std::max(std::max(qtNodeBytes(a.pool, a.listCap), qt3NodeBytes(a.listCap)), (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15);
-    size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    { static int mk = -1; if (mk < 0) { const char *e = getenv("ORBX_QT_MAX_KEYS"); mk = e ? std::min(std::max(atoi(e), 0), QT3_MAX_KEYS) : QT3_MAX_KEYS; } a.maxKeys = mk; }
     static bool attrSet = false;
-    if (!attrSet && lds > 48 * 1024) {
+    if (!attrSet) {
         (void)hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_quadtree_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
     }
-    if (getenv("ORBX_DEBUG")) {
-        int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
-        fprintf(stderr, "[orbx] k_quadtree: pool %d, list %d, LDS %zu B, %d blocks/CU\n", a.pool, a.listCap, lds, nb);
+    const size_t tileOffBytes = (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15;  // both kernels stage the tile prefix in LDS first
+    const dim3 grid(xcd_grid(nframes, levelsRun));
+    if (a.variant == 3) {
+        a.nodeBytes = (int)std::max(qt3NodeBytes(a.listCap), tileOffBytes);
+        const size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        if (getenv("ORBX_DEBUG")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
+            fprintf(stderr, "[orbx] k_quadtree levels %d..%d: list %d, LDS %zu B, %d instances/CU\n", levelBase, levelBase + levelsRun - 1, a.listCap, lds, nb);
+        }
+        hipLaunchKernelGGL(k_quadtree, grid, dim3(64), lds, st, a);
     }
-    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(nframes, levelsRun)), dim3(64), lds, st, a);
+    {   // candidate sets beyond QT3_MAX_KEYS (deferred above; large images), or everything in the A/B variant
+        a.nodeBytes = (int)std::max(qtNodeBytes(a.pool, a.listCap), tileOffBytes);
+        const size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_quadtree_serial, grid, dim3(64), lds, st, a);
+    }
     return hipGetLastError();
 }
 
