@@ -273,6 +273,15 @@ __device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *
     }
 }
 
+#ifdef PF_TIMING
+// debug build (-DPF_TIMING): s_memtime stamps of wave 0 at the phase boundaries of the first 8192 workgroups of the last launch
+// that also produced a pyramid level; read back with orbx_debug_pf_timing (tools/pf_timing.py runs a 2-level extractor)
+__device__ unsigned long long g_pfTiming[8192][16];
+extern "C" int orbx_debug_pf_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfTiming), sizeof(g_pfTiming)); }
+#define PF_STAMP(i) do { if (blockIdx.x < 8192 && threadIdx.x == 0 && a.dst) g_pfTiming[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PF_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
     KArgs &a = *(KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) OrbxLevelGeom &g = a.g;
     int f, tileId;
+    PF_STAMP(0);
     if (!xcd_decode(a.nframes, g.nTiles, f, tileId)) return;
     const int crow = tileId / g.nGroups, grp = tileId - crow * g.nGroups;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -322,13 +332,68 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
     __shared__ unsigned gqCountR[2], cqCountR[2];           // queue fill counters, one pair per round (no reset barrier)
 
     // ---- stage the tile: coalesced 16-byte loads of row-major image rows into LDS ------------------------
+    // The prologue has two chains of global loads - the tile, and (two levels deep) the resize tables of this tile.  Both are
+    // ISSUED first (tile vectors and table entries into registers), the LDS-only setup (zeroing, cell table) runs under
+    // their latency, and the registers go to LDS last; issued one after the other the chains cost ~2500 cycles each.
     const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
     const int nRowsL = ly1 - ly0;
+    const bool doResize = a.dst && (a.phases & 1);
+    int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
+    if (doResize) {
+        dy0 = a.tabs.rowBeg[crow]; dy1 = a.tabs.rowBeg[crow + 1];
+        dx0 = a.tabs.colBeg[grp]; dx1 = a.tabs.colBeg[grp + 1];
+    }
+    const int nV = (lx1 - ax0 + 15) >> 4;
+    const float invNV = __builtin_amdgcn_rcpf((float)nV);  // 1-ulp reciprocal: the quotients below sit >= 0.5/n from an integer
+    const int nVec = nRowsL * nV;
+    uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;  // (two named registers sets: an array here ends up in scratch)
+    int tvOff0 = -1, tvOff1 = -1;
     if (a.srcAlign == 16) {
-        const int nV = (lx1 - ax0 + 15) >> 4;
-        const float invNV = __builtin_amdgcn_rcpf((float)nV);  // 1-ulp reciprocal: the quotients below sit >= 0.5/n from an integer
-        const int n = nRowsL * nV;
-        for (int it = otid(); it < n; it += PF_NT) {
+        const int it0 = otid(), it1 = it0 + PF_NT;
+        if (it0 < nVec) {
+            const int r = (int)(((float)it0 + 0.5f) * invNV), c = it0 - r * nV;
+            tv0 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+            tvOff0 = r * tp + PF_XO + c * 16;
+        }
+        if (it1 < nVec) {
+            const int r = (int)(((float)it1 + 0.5f) * invNV), c = it1 - r * nV;
+            tv1 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+            tvOff1 = r * tp + PF_XO + c * 16;
+        }
+    }
+    int xo_ = 0, xw_ = 0, yo_ = 0, yw_ = 0;  // first table entries of this thread
+    if (doResize) {
+        const int i = otid();
+        if (i < dx1 - dx0) { xo_ = a.tabs.xofs[dx0 + i]; xw_ = a.tabs.xab[dx0 + i]; }
+        if (i < dy1 - dy0) { yo_ = a.tabs.yofs[dy0 + i]; yw_ = a.tabs.yab[dy0 + i]; }
+    }
+    // zero the score tile and the per-cell NMS bitmaps (16-byte stores)
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *zs = (uint4 *)score;
+        const int nz = ((g.hCell + 2) * tp) >> 4;
+#pragma nounroll
+        for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
+        const int nb = g.groupCells * cellWords;
+#pragma nounroll
+        for (int i = otid(); i < nb; i += PF_NT) bits[i] = 0;
+    }
+    if (tid < PF_MAX_GROUP_CELLS) cnt[tid] = 0;
+    if (tid < 2) { gqCountR[tid] = 0; cqCountR[tid] = 0; }
+    // per interior column: cell index | bit7 first column of its cell | bit6 last column
+    const float invWC = __builtin_amdgcn_rcpf((float)g.wCell);
+#pragma nounroll
+    for (int x = otid(); x < TWi; x += PF_NT) {
+        int cell = (int)(((float)x + 0.5f) * invWC), cx = x - cell * g.wCell;
+        int cw = min(g.wCell, TWi - cell * g.wCell);
+        colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
+    }
+    // the tile
+    if (a.srcAlign == 16) {
+        if (tvOff0 >= 0) *(uint4 *)(tile + tvOff0) = tv0;
+        if (tvOff1 >= 0) *(uint4 *)(tile + tvOff1) = tv1;
+#pragma nounroll
+        for (int it = otid() + 2 * PF_NT; it < nVec; it += PF_NT) {  // tiles of more than 1024 vectors
             const int r = (int)(((float)it + 0.5f) * invNV);
             const int c = it - r * nV;
             const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
@@ -353,47 +418,26 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             for (int c = otid() & 63; c < nB; c += 64) trow[c] = srow[c];
         }
     }
+    PF_STAMP(1);
     if ((a.phases >> 4) == 1) return;
-    // zero the score tile and the per-cell NMS bitmaps (16-byte stores)
-    {
-        uint4 z = make_uint4(0, 0, 0, 0);
-        uint4 *zs = (uint4 *)score;
-        const int nz = ((g.hCell + 2) * tp) >> 4;
-#pragma nounroll
-        for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
-        const int nb = g.groupCells * cellWords;
-#pragma nounroll
-        for (int i = otid(); i < nb; i += PF_NT) bits[i] = 0;
-    }
-    if (tid < PF_MAX_GROUP_CELLS) cnt[tid] = 0;
-    if (tid < 2) { gqCountR[tid] = 0; cqCountR[tid] = 0; }
-    // per interior column: cell index | bit7 first column of its cell | bit6 last column
-    const float invWC = __builtin_amdgcn_rcpf((float)g.wCell);
-#pragma nounroll
-    for (int x = otid(); x < TWi; x += PF_NT) {
-        int cell = (int)(((float)x + 0.5f) * invWC), cx = x - cell * g.wCell;
-        int cw = min(g.wCell, TWi - cell * g.wCell);
-        colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
-    }
     // resize coefficient tables of this tile's destination rows / columns -> LDS
-    int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
-    const bool doResize = a.dst && (a.phases & 1);
     if (doResize) {
-        dy0 = a.tabs.rowBeg[crow]; dy1 = a.tabs.rowBeg[crow + 1];
-        dx0 = a.tabs.colBeg[grp]; dx1 = a.tabs.colBeg[grp + 1];
-#pragma nounroll
-        for (int i = otid(); i < dx1 - dx0; i += PF_NT) {
-            // the right tap is always the next LDS column: where cv::resize clamps sx to w - 1 its weight is 0
-            xt[i] = make_int2(a.tabs.xofs[dx0 + i] + colOf0, a.tabs.xab[dx0 + i]);
-        }
-#pragma nounroll
-        for (int i = otid(); i < dy1 - dy0; i += PF_NT) {
-            const int sy = a.tabs.yofs[dy0 + i];
+        auto xEntry = [&](int sx, int w2) { return make_int2(sx + colOf0, w2); };  // the right tap is always the next LDS column: where
+                                                                                  // cv::resize clamps sx to w - 1 its weight is 0
+        auto yEntry = [&](int sy, int w2) {  // LDS byte offsets of the two source rows
             const int sy0 = min(max(sy, 0), g.h - 1) - ly0, sy1 = min(max(sy + 1, 0), g.h - 1) - ly0;
-            yt[i] = make_int2((sy0 * tp) | ((sy1 * tp) << 16), a.tabs.yab[dy0 + i]);  // LDS byte offsets of the two source rows
-        }
+            return make_int2((sy0 * tp) | ((sy1 * tp) << 16), w2);
+        };
+        const int i0 = otid();
+        if (i0 < dx1 - dx0) xt[i0] = xEntry(xo_, xw_);
+        if (i0 < dy1 - dy0) yt[i0] = yEntry(yo_, yw_);
+#pragma nounroll
+        for (int i = i0 + PF_NT; i < dx1 - dx0; i += PF_NT) xt[i] = xEntry(a.tabs.xofs[dx0 + i], a.tabs.xab[dx0 + i]);
+#pragma nounroll
+        for (int i = i0 + PF_NT; i < dy1 - dy0; i += PF_NT) yt[i] = yEntry(a.tabs.yofs[dy0 + i], a.tabs.yab[dy0 + i]);
     }
     __syncthreads();
+    PF_STAMP(2);
     if ((a.phases >> 4) == 2) return;
 
     // ---- next pyramid level: cv::resize INTER_LINEAR fixed point; 4 px per lane -------
@@ -440,6 +484,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
         }
     }
 
+    PF_STAMP(3);
     if ((a.phases >> 4) == 3) return;
     // ---- FAST-9/16 + cell-local NMS, in the reference's two rounds -----------------------------------------------
     // round 0: threshold iniThFAST everywhere; round 1: threshold minThFAST, only in cells that produced no keypoint
@@ -521,6 +566,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             }
         }
         __syncthreads();
+        PF_STAMP(4 + 4 * round);
         if ((a.phases >> 4) == 4) return;
 
         // (B) full ring test of the queued groups -> corner queue
@@ -554,6 +600,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             }
         }
         __syncthreads();
+        PF_STAMP(5 + 4 * round);
         if ((a.phases >> 4) == 5) return;
 
         // (C) dense corner score (merging it into (B) measured slower: 3.26 vs 3.0 ms — divergent scoring loops)
@@ -563,6 +610,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
         }
         __syncthreads();
+        PF_STAMP(6 + 4 * round);
         if ((a.phases >> 4) == 6) return;
 
         // (D) cell-local NMS -> bitmaps; (E) per-cell counts by LDS atomics
@@ -583,6 +631,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             }
         }
         __syncthreads();
+        PF_STAMP(7 + 4 * round);
         if ((a.phases >> 4) == 7) return;
     }
     if (!(a.phases & 8)) return;
@@ -621,6 +670,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             base += total;
         }
     }
+    PF_STAMP(12);
 }
 
 hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch,
