@@ -3,7 +3,7 @@
 # the differences between consecutive runs are the VALU / LDS / SALU instructions and the time each phase adds.
 # Usage on the GPU box: bash tools/pmc_phases.sh > gpurun_out/pmc_phases.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for k in 1 2 3 4 5 6 7 0; do
+for k in 1 2 3 4 5 6 7 0; do  # (stop points: see PyrFastArgs::phases)
 export ORBX_PF_PHASES=$((15 + 16 * k))
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmcph_$k -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcph_$k.log 2>&1
 f=$(find gpurun_out/pmcph_$k -name "*counter_collection.csv" | head -1)
