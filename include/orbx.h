@@ -206,6 +206,28 @@ int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, const uint8
                            const orbx_keypoint *kr, const uint8_t *dr, int nr, int n_rows, const float *scale_factors,
                            int nlevels, float min_d, float max_d, int32_t *best_idx, int32_t *best_dist);
 
+/* ---- the frame grid and the windowed initialization search -------------------------------------- */
+#define ORBX_FRAME_GRID_COLS 64 /* FRAME_GRID_COLS, reference include/Frame.h:45 */
+#define ORBX_FRAME_GRID_ROWS 48 /* FRAME_GRID_ROWS, reference include/Frame.h:44 */
+
+/* Frame::AssignFeaturesToGrid + Frame::PosInGrid — reference src/Frame.cc:387-418, 755-766 (monocular branch: mvKeysUn).
+ * Buckets the n keypoints into the 64 x 48 grid over [min_x, max_x) x [min_y, max_y) (Frame::mnMinX .. mnMaxY, src/Frame.cc:41,
+ * 808-839) and returns it as CSR: cell_start[64 * 48 + 1] with cell = ix * 48 + iy (mGrid[ix][iy]), items[] = the indices of
+ * every cell in push_back order.  Returns the number of keypoints placed (those inside the grid) or a negative status. */
+int orbx_assign_features_to_grid(orbx_matcher *m, const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y, float max_y,
+                                 int32_t *cell_start, int32_t *items);
+
+/* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12,
+ * int windowSize) — reference src/ORBmatcher1.cc:650-765 (decl include/ORBmatcher.h:72), with Frame::GetFeaturesInArea
+ * (src/Frame.cc:687-753), DescriptorDistance, TH_LOW = 50, the NN ratio test and the 30-bin rotation histogram +
+ * ORBmatcher::ComputeThreeMaxima (src/ORBmatcher3.cc:592-633) when check_orientation != 0 (mbCheckOrientation).
+ * k1/d1, k2/d2 = F1 / F2 .mvKeysUn and .mDescriptors; prev_matched = vbPrevMatched as n1 (x, y) pairs, updated in place like
+ * the reference does; matches12[n1] receives vnMatches12 (-1 = no match).  nnratio = mfNNratio (the reference's monocular
+ * initializer constructs ORBmatcher(0.9, true) and passes windowSize 100, src/Tracking3.cc:740-741).  Returns nmatches (>= 0) or a negative status. */
+int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, const uint8_t *d1, int n1, const orbx_keypoint *k2,
+                                   const uint8_t *d2, int n2, float min_x, float max_x, float min_y, float max_y, float *prev_matched,
+                                   int32_t *matches12, int window_size, float nnratio, int check_orientation);
+
 /* Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011: the row-band Hamming
  * stage above, then for every accepted left keypoint the 11x11 L1 sliding-window refinement (+-5 px) on
  * mvImagePyramid[octave] of the left / right extractor (the device-resident pyramids of frame `frame_left` /

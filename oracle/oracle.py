@@ -55,6 +55,11 @@ def lib() -> ctypes.CDLL:
                                          c_void_p, c_void_p]
         L.oracle_stereo_matches.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float,
                                             c_void_p, c_void_p]
+        L.oracle_assign_grid.argtypes = [c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p]
+        L.oracle_features_in_area.argtypes = [c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int,
+                                              c_void_p, c_int]
+        L.oracle_search_for_initialization.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
+                                                       c_float, c_void_p, c_void_p, c_int, c_float, c_int]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -219,3 +224,35 @@ def stereo_matches(left: Oracle, right: Oracle, kl, dl, kr, dr, mb: float, mbf: 
     n = lib().oracle_stereo_matches(left.h, right.h, kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data, dr.ctypes.data, len(kr),
                                     mb, mbf, ur.ctypes.data, dp.ctypes.data)
     return ur, dp, n
+
+
+def assign_grid(kps, bounds):
+    """Frame::AssignFeaturesToGrid (reference src/Frame.cc:387-418) -> (cell_start[64 * 48 + 1], items)."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    cs = np.zeros(64 * 48 + 1, np.int32)
+    items = np.zeros(max(len(kps), 1), np.int32)
+    n = lib().oracle_assign_grid(kps.ctypes.data, len(kps), *[float(b) for b in bounds], cs.ctypes.data, items.ctypes.data)
+    return cs, items[:n]
+
+
+def features_in_area(kps, bounds, x, y, r, min_level=-1, max_level=-1):
+    """Frame::GetFeaturesInArea (reference src/Frame.cc:687-753)."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    out = np.zeros(max(len(kps), 1), np.int32)
+    n = lib().oracle_features_in_area(kps.ctypes.data, len(kps), *[float(b) for b in bounds], float(x), float(y), float(r), int(min_level),
+                                      int(max_level), out.ctypes.data, len(out))
+    return out[:n]
+
+
+def search_for_initialization(k1, d1, k2, d2, prev_matched, bounds, window_size=10, nnratio=0.6, check_orientation=True):
+    """ORBmatcher::SearchForInitialization (reference src/ORBmatcher1.cc:650-765) -> (nmatches, vnMatches12, vbPrevMatched)."""
+    k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE)
+    k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+    prev = np.array(prev_matched, np.float32).reshape(-1, 2).copy()
+    m12 = np.full(len(k1), -1, np.int32)
+    n = lib().oracle_search_for_initialization(k1.ctypes.data, d1.ctypes.data, len(k1), k2.ctypes.data, d2.ctypes.data, len(k2),
+                                               *[float(b) for b in bounds], prev.ctypes.data, m12.ctypes.data, int(window_size),
+                                               float(nnratio), int(bool(check_orientation)))
+    return n, m12, prev

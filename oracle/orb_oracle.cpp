@@ -945,6 +945,175 @@ int oracle_stereo_matches(const oracle_handle *L, const oracle_handle *R, const 
     return (int)vDistIdx.size();
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// the frame grid and ORBmatcher::SearchForInitialization
+// ---------------------------------------------------------------------------------------------------------
+#define ORACLE_GRID_COLS 64  // FRAME_GRID_COLS, reference include/Frame.h:45
+#define ORACLE_GRID_ROWS 48  // FRAME_GRID_ROWS, :44
+
+struct FrameGrid {  // Frame::mGrid + the static image bounds (src/Frame.cc:41, 161-162)
+    std::vector<std::vector<size_t>> cell;  // [ix * ROWS + iy], indices in push_back order
+    float minX, minY, invW, invH;
+};
+
+// Frame::AssignFeaturesToGrid + Frame::PosInGrid (src/Frame.cc:387-418, 755-766), monocular branch (Nleft == -1)
+static FrameGrid assignFeaturesToGrid(const oracle_keypoint *k, int n, float minX, float maxX, float minY, float maxY)
+{
+    FrameGrid G;
+    G.cell.resize(ORACLE_GRID_COLS * ORACLE_GRID_ROWS);
+    G.minX = minX; G.minY = minY;
+    G.invW = static_cast<float>(ORACLE_GRID_COLS) / (maxX - minX);
+    G.invH = static_cast<float>(ORACLE_GRID_ROWS) / (maxY - minY);
+    for (int i = 0; i < n; ++i) {
+        const int posX = (int)std::round((k[i].x - minX) * G.invW);  // std::round(float): half away from zero
+        const int posY = (int)std::round((k[i].y - minY) * G.invH);
+        if (posX < 0 || posX >= ORACLE_GRID_COLS || posY < 0 || posY >= ORACLE_GRID_ROWS) continue;
+        G.cell[posX * ORACLE_GRID_ROWS + posY].push_back((size_t)i);
+    }
+    return G;
+}
+
+// Frame::GetFeaturesInArea (src/Frame.cc:687-753), bRight = false
+static std::vector<size_t> getFeaturesInArea(const FrameGrid &G, const oracle_keypoint *k, float x, float y, float r, int minLevel,
+                                             int maxLevel)
+{
+    std::vector<size_t> vIndices;
+    const float factorX = r, factorY = r;
+    const int nMinCellX = std::max(0, (int)std::floor((x - G.minX - factorX) * G.invW));
+    if (nMinCellX >= ORACLE_GRID_COLS) return vIndices;
+    const int nMaxCellX = std::min((int)ORACLE_GRID_COLS - 1, (int)std::ceil((x - G.minX + factorX) * G.invW));
+    if (nMaxCellX < 0) return vIndices;
+    const int nMinCellY = std::max(0, (int)std::floor((y - G.minY - factorY) * G.invH));
+    if (nMinCellY >= ORACLE_GRID_ROWS) return vIndices;
+    const int nMaxCellY = std::min((int)ORACLE_GRID_ROWS - 1, (int)std::ceil((y - G.minY + factorY) * G.invH));
+    if (nMaxCellY < 0) return vIndices;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<size_t> &vCell = G.cell[ix * ORACLE_GRID_ROWS + iy];
+            for (size_t j = 0; j < vCell.size(); j++) {
+                const oracle_keypoint &kpUn = k[vCell[j]];
+                if (bCheckLevels) {
+                    if (kpUn.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+                }
+                const float distx = kpUn.x - x, disty = kpUn.y - y;
+                if (std::fabs(distx) < factorX && std::fabs(disty) < factorY) vIndices.push_back(vCell[j]);
+            }
+        }
+    return vIndices;
+}
+
+// ORBmatcher::ComputeThreeMaxima (src/ORBmatcher3.cc:592-633) on the histogram sizes
+static void computeThreeMaxima(const int *histoSize, int L, int &ind1, int &ind2, int &ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histoSize[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+extern "C" {
+
+int oracle_assign_grid(const oracle_keypoint *k, int n, float minX, float maxX, float minY, float maxY, int32_t *cell_start,
+                       int32_t *items)
+{
+    const FrameGrid G = assignFeaturesToGrid(k, n, minX, maxX, minY, maxY);
+    int o = 0;
+    for (int c = 0; c < ORACLE_GRID_COLS * ORACLE_GRID_ROWS; ++c) {
+        cell_start[c] = o;
+        for (size_t v : G.cell[c]) items[o++] = (int32_t)v;
+    }
+    cell_start[ORACLE_GRID_COLS * ORACLE_GRID_ROWS] = o;
+    return o;
+}
+
+int oracle_features_in_area(const oracle_keypoint *k, int n, float minX, float maxX, float minY, float maxY, float x, float y, float r,
+                            int min_level, int max_level, int32_t *out, int cap)
+{
+    const FrameGrid G = assignFeaturesToGrid(k, n, minX, maxX, minY, maxY);
+    const std::vector<size_t> v = getFeaturesInArea(G, k, x, y, r, min_level, max_level);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = (int32_t)v[i];
+    return (int)v.size();
+}
+
+// ORBmatcher::SearchForInitialization (src/ORBmatcher1.cc:650-765).  F1 / F2 = undistorted keypoints + descriptors of the two
+// frames; (minX .. maxY) = Frame::mnMinX .. mnMaxY; prev_matched = vbPrevMatched [n1][2], updated in place; matches12 [n1].
+int oracle_search_for_initialization(const oracle_keypoint *k1, const uint8_t *d1, int n1, const oracle_keypoint *k2, const uint8_t *d2,
+                                     int n2, float minX, float maxX, float minY, float maxY, float *prev_matched, int32_t *matches12,
+                                     int window_size, float nnratio, int check_orientation)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;  // src/ORBmatcher1.cc:37-39
+    const FrameGrid G2 = assignFeaturesToGrid(k2, n2, minX, maxX, minY, maxY);
+    int nmatches = 0;
+    std::vector<int> vnMatches12(n1, -1);
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX);
+    std::vector<int> vnMatches21(n2, -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const oracle_keypoint kp1 = k1[i1];
+        const int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        const std::vector<size_t> vIndices2 =
+            getFeaturesInArea(G2, k2, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t *dd1 = d1 + (size_t)i1 * 32;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (size_t v = 0; v < vIndices2.size(); ++v) {
+            const size_t i2 = vIndices2[v];
+            const int dist = oracle_hamming256(dd1, d2 + i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[30];
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = (int)rotHist[i].size();
+        computeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                const int idx1 = rotHist[i][j];
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++) {
+        matches12[i1] = vnMatches12[i1];
+        if (vnMatches12[i1] >= 0) { prev_matched[2 * i1] = k2[vnMatches12[i1]].x; prev_matched[2 * i1 + 1] = k2[vnMatches12[i1]].y; }
+    }
+    return nmatches;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride)
 {
     orbx_synth_frame_impl(seed, w, h, out, stride);

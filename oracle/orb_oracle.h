@@ -93,6 +93,19 @@ int oracle_stereo_matches(const oracle_handle *left, const oracle_handle *right,
                           int nl, const oracle_keypoint *kr, const uint8_t *dr, int nr, float mb, float mbf, float *u_right,
                           float *depth);
 
+/* SURVEY §8(f) rank 2.  Frame::AssignFeaturesToGrid + PosInGrid (reference src/Frame.cc:387-418, 755-766): the 64 x 48 grid over
+ * [min_x, max_x) x [min_y, max_y) (Frame::mnMinX ..) as CSR: cell_start[64 * 48 + 1] (cell = ix * 48 + iy), items in push order. */
+int oracle_assign_grid(const oracle_keypoint *k, int n, float min_x, float max_x, float min_y, float max_y, int32_t *cell_start,
+                       int32_t *items);
+/* Frame::GetFeaturesInArea (src/Frame.cc:687-753) on that grid; returns the count, indices in the reference's order. */
+int oracle_features_in_area(const oracle_keypoint *k, int n, float min_x, float max_x, float min_y, float max_y, float x, float y, float r,
+                            int min_level, int max_level, int32_t *out, int cap);
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher1.cc:650-765) incl. ComputeThreeMaxima (src/ORBmatcher3.cc:592-633).
+ * prev_matched = vbPrevMatched [n1][2] (in / out), matches12 [n1] = vnMatches12; returns nmatches. */
+int oracle_search_for_initialization(const oracle_keypoint *k1, const uint8_t *d1, int n1, const oracle_keypoint *k2, const uint8_t *d2,
+                                     int n2, float min_x, float max_x, float min_y, float max_y, float *prev_matched, int32_t *matches12,
+                                     int window_size, float nnratio, int check_orientation);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

@@ -85,6 +85,55 @@ static int runExtractAndCompare(int w, int h, int nfeatures, std::vector<int> la
     return 0;
 }
 
+// Monocular initialization matching as src/Tracking3.cc:700-741 drives it: 5 x nFeatures extractor on two frames,
+// mvbPrevMatched = the first frame's keypoint positions, ORBmatcher(0.9, true).SearchForInitialization(.., 100).
+static int runSearchForInitialization()
+{
+    const int w = 640, h = 480;
+    std::vector<uint8_t> img1((size_t)w * h), img2((size_t)w * h);
+    orbx_synth_frame_impl(11, w, h, img1.data(), w);
+    for (int y = 0; y < h; ++y)  // the same scene 5 px to the right, 3 px down
+        for (int x = 0; x < w; ++x) img2[(size_t)y * w + x] = img1[(size_t)((y + h - 3) % h) * w + (x + w - 5) % w];
+    orbx::ORBextractor mpIniORBextractor(5000, 1.2f, 8, 20, 7, 0, w, h);
+    std::vector<int> lap = {0, 0};
+    std::vector<orbx::KeyPoint> keys1, keys2;
+    orbx::Descriptors desc1, desc2;
+    mpIniORBextractor(orbx::Image(img1.data(), w, h), orbx::Image(), keys1, desc1, lap);
+    mpIniORBextractor(orbx::Image(img2.data(), w, h), orbx::Image(), keys2, desc2, lap);
+    orbx::FrameView mInitialFrame, mCurrentFrame;
+    mInitialFrame.mvKeysUn = &keys1; mInitialFrame.mDescriptors = &desc1;
+    mCurrentFrame.mvKeysUn = &keys2; mCurrentFrame.mDescriptors = &desc2;
+    mInitialFrame.mnMinX = mCurrentFrame.mnMinX = 0.f; mInitialFrame.mnMaxX = mCurrentFrame.mnMaxX = (float)w;
+    mInitialFrame.mnMinY = mCurrentFrame.mnMinY = 0.f; mInitialFrame.mnMaxY = mCurrentFrame.mnMaxY = (float)h;
+    std::vector<orbx::Point2f> mvbPrevMatched(keys1.size());
+    for (size_t i = 0; i < keys1.size(); i++) mvbPrevMatched[i] = keys1[i].pt;
+    std::vector<float> refPrev(keys1.size() * 2);
+    for (size_t i = 0; i < keys1.size(); i++) { refPrev[2 * i] = keys1[i].pt.x; refPrev[2 * i + 1] = keys1[i].pt.y; }
+
+    orbx::ORBmatcher matcher(0.9f, true);
+    std::vector<int> mvIniMatches;
+    const int nmatches = matcher.SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100);
+
+    std::vector<int32_t> refMatches(keys1.size());
+    const int refN = oracle_search_for_initialization((const oracle_keypoint *)keys1.data(), desc1.data.data(), (int)keys1.size(),
+                                                      (const oracle_keypoint *)keys2.data(), desc2.data.data(), (int)keys2.size(), 0.f,
+                                                      (float)w, 0.f, (float)h, refPrev.data(), refMatches.data(), 100, 0.9f, 1);
+    ASSERT_EQ(nmatches, refN);
+    ASSERT_TRUE(nmatches >= 100);  // enough for the initializer (src/Tracking3.cc:744)
+    ASSERT_EQ(mvIniMatches.size(), refMatches.size());
+    for (size_t i = 0; i < refMatches.size(); ++i) ASSERT_EQ(mvIniMatches[i], refMatches[i]);
+    ASSERT_TRUE(memcmp(mvbPrevMatched.data(), refPrev.data(), refPrev.size() * sizeof(float)) == 0);
+
+    std::vector<int32_t> cellStart, items, rcs(64 * 48 + 1), ritems(keys2.size());
+    matcher.AssignFeaturesToGrid(mCurrentFrame, cellStart, items);
+    const int placed = oracle_assign_grid((const oracle_keypoint *)keys2.data(), (int)keys2.size(), 0.f, (float)w, 0.f, (float)h, rcs.data(),
+                                          ritems.data());
+    ritems.resize((size_t)placed);
+    ASSERT_TRUE(cellStart == rcs);
+    ASSERT_TRUE(items == ritems);
+    return 0;
+}
+
 int main()
 {
     // empty image -> -1 (reference src/ORBextractor.cc:1231-1232)
@@ -103,6 +152,7 @@ int main()
     if (runExtractAndCompare(640, 480, 1000, {0, 1000})) return 1;   // mono call of Frame.cc:313
     if (runExtractAndCompare(752, 480, 1200, {0, 0})) return 1;      // EuRoC geometry
     if (runExtractAndCompare(512, 512, 1500, {100, 300})) return 1;  // TUM-VI geometry with a lapping band
+    if (runSearchForInitialization()) return 1;
     printf("OK host mirror\n");
     return 0;
 }

@@ -146,3 +146,62 @@ def test_distribute_keeps_best_and_quota(orc):
     assert 217 <= len(sel) <= 220 and len(set(sel.tolist())) == len(sel)
     one = orc.distribute(cand[:1], W, H, 217)
     assert list(one) == [0]
+
+
+def test_frame_grid_and_area_query_against_brute_force(orc):
+    """Frame::AssignFeaturesToGrid / GetFeaturesInArea (SURVEY 8f rank 2) restated in the oracle vs a direct numpy evaluation of
+    the same formulas (src/Frame.cc:687-766)."""
+    o = orc.Oracle(2000, 1.2, 8, 20, 7)
+    _, k, d = o.extract(orc.synth_frame(0x4F524230 + 3, 640, 480), (0, 0))
+    bounds = (-4.5, 648.25, 2.0, 470.0)
+    inv_w = np.float32(64) / (np.float32(bounds[1]) - np.float32(bounds[0]))
+    inv_h = np.float32(48) / (np.float32(bounds[3]) - np.float32(bounds[2]))
+    fx = (k["x"] - np.float32(bounds[0])) * inv_w
+    fy = (k["y"] - np.float32(bounds[2])) * inv_h
+    px = (np.sign(fx) * np.floor(np.abs(fx) + np.float32(0.5))).astype(int)  # std::round: half away from zero
+    py = (np.sign(fy) * np.floor(np.abs(fy) + np.float32(0.5))).astype(int)
+    inside = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    cell = np.where(inside, px * 48 + py, -1)
+    cs, items = orc.assign_grid(k, bounds)
+    assert cs[-1] == inside.sum() == len(items)
+    for c in range(64 * 48):
+        assert list(items[cs[c]:cs[c + 1]]) == list(np.nonzero(cell == c)[0])
+    for (x, y, r, lo, hi) in [(320, 240, 100, 0, 0), (10, 470, 50, -1, -1), (600, 20, 25.5, 1, 3), (-300, 240, 100, 0, 0), (320, 240, 2000, 0, 7)]:
+        got = orc.features_in_area(k, bounds, x, y, r, lo, hi)
+        x32, y32, r32 = np.float32(x), np.float32(y), np.float32(r)
+        cx0 = max(0, int(np.floor((x32 - np.float32(bounds[0]) - r32) * inv_w)))
+        cx1 = min(63, int(np.ceil((x32 - np.float32(bounds[0]) + r32) * inv_w)))
+        cy0 = max(0, int(np.floor((y32 - np.float32(bounds[2]) - r32) * inv_h)))
+        cy1 = min(47, int(np.ceil((y32 - np.float32(bounds[2]) + r32) * inv_h)))
+        want = []
+        if cx0 < 64 and cx1 >= 0 and cy0 < 48 and cy1 >= 0:
+            check = lo > 0 or hi >= 0
+            for ix in range(cx0, cx1 + 1):
+                for iy in range(cy0, cy1 + 1):
+                    for i in np.nonzero(cell == ix * 48 + iy)[0]:
+                        if check and (k["octave"][i] < lo or (hi >= 0 and k["octave"][i] > hi)):
+                            continue
+                        if abs(k["x"][i] - x32) < r32 and abs(k["y"][i] - y32) < r32:
+                            want.append(i)
+        assert list(got) == want, (x, y, r, lo, hi)
+
+
+def test_search_for_initialization_properties(orc):
+    """ORBmatcher::SearchForInitialization restated in the oracle: a frame matched against itself pairs every level-0 keypoint
+    with itself; matches are one-to-one, only between level-0 keypoints, and vbPrevMatched follows the matches."""
+    o = orc.Oracle(3000, 1.2, 8, 20, 7)
+    _, k, d = o.extract(orc.synth_frame(0x4F524230 + 5, 640, 480), (0, 0))
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    prev = np.stack([k["x"], k["y"]], axis=1)
+    n, m12, pv = orc.search_for_initialization(k, d, k, d, prev, bounds, 100, 0.9, True)
+    lvl0 = k["octave"] == 0
+    assert n == lvl0.sum() and np.array_equal(m12[lvl0], np.nonzero(lvl0)[0]) and (m12[~lvl0] == -1).all()
+    assert np.array_equal(pv, prev)
+    # against a different frame: plausibility only (no reference vectors exist for this path: parity unpinned)
+    _, k2, d2 = o.extract(orc.synth_frame(0x4F524230 + 6, 640, 480), (0, 0))
+    n, m12, pv = orc.search_for_initialization(k, d, k2, d2, prev, bounds, 100, 0.9, True)
+    hit = np.nonzero(m12 >= 0)[0]
+    assert n == len(hit) and len(set(m12[hit].tolist())) == len(hit)
+    assert (k["octave"][hit] == 0).all() and (k2["octave"][m12[hit]] == 0).all()
+    assert np.array_equal(pv[hit], np.stack([k2["x"][m12[hit]], k2["y"][m12[hit]]], axis=1))
+    assert (np.abs(k2["x"][m12[hit]] - prev[hit, 0]) < 100).all() and (np.abs(k2["y"][m12[hit]] - prev[hit, 1]) < 100).all()

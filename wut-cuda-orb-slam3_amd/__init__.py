@@ -59,6 +59,7 @@ ABI_SYMBOLS = [
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
+    "orbx_assign_features_to_grid", "orbx_search_for_initialization",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -120,6 +121,9 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_level_sizes.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_compute_stereo_matches.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                                 c_float, c_float, c_void_p, c_void_p]
+    lib.orbx_assign_features_to_grid.argtypes = [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p]
+    lib.orbx_search_for_initialization.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
+                                                   c_float, c_void_p, c_void_p, c_int, c_float, c_int]
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -364,3 +368,38 @@ class ORBmatcher:
                                                      len(kl), kr.ctypes.data, dr.ctypes.data, len(kr), mb, mbf, ur.ctypes.data,
                                                      dp.ctypes.data), "orbx_compute_stereo_matches")
         return ur, dp
+
+    # ---- SURVEY §8(f) rank 2 ----------------------------------------------------------------------------------------
+    FRAME_GRID_COLS = 64
+    FRAME_GRID_ROWS = 48
+
+    def AssignFeaturesToGrid(self, kps, bounds):
+        """Frame::AssignFeaturesToGrid (reference src/Frame.cc:387-418) for the undistorted keypoints `kps` and the image bounds
+        (mnMinX, mnMaxX, mnMinY, mnMaxY).  Returns (cell_start[64 * 48 + 1], items): mGrid[ix][iy] = items[cell_start[c] :
+        cell_start[c + 1]] with c = ix * 48 + iy."""
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+        cs = np.zeros(self.FRAME_GRID_COLS * self.FRAME_GRID_ROWS + 1, np.int32)
+        items = np.zeros(max(len(kps), 1), np.int32)
+        n = self._lib.orbx_assign_features_to_grid(self._h, kps.ctypes.data, len(kps), *[float(b) for b in bounds], cs.ctypes.data,
+                                                   items.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_assign_features_to_grid")
+        return cs, items[:n]
+
+    def SearchForInitialization(self, k1, d1, k2, d2, vbPrevMatched, bounds, windowSize: int = 10, nnratio: float = 0.6,
+                                checkOrientation: bool = True):
+        """ORBmatcher::SearchForInitialization (reference src/ORBmatcher1.cc:650-765; ORBmatcher(nnratio, checkOri) as in
+        include/ORBmatcher.h:40).  Returns (nmatches, vnMatches12, vbPrevMatched updated)."""
+        k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        prev = np.array(vbPrevMatched, np.float32).reshape(-1, 2).copy()
+        assert len(prev) == len(k1)
+        m12 = np.full(len(k1), -1, np.int32)
+        n = self._lib.orbx_search_for_initialization(self._h, k1.ctypes.data, d1.ctypes.data, len(k1), k2.ctypes.data, d2.ctypes.data,
+                                                     len(k2), *[float(b) for b in bounds], prev.ctypes.data, m12.ctypes.data,
+                                                     int(windowSize), float(nnratio), int(bool(checkOrientation)))
+        if n < 0:
+            _check(n, "orbx_search_for_initialization")
+        return n, m12, prev

@@ -841,6 +841,9 @@ struct orbx_matcher {
     DevBuf<orbx_keypoint> d_kl, d_kr;
     DevBuf<float> d_scale, d_uRight, d_depth;
     DevBuf<int> d_sad;
+    DevBuf<int> d_grid, d_work;   // frame grid (cellStart + items + cellOf), SearchForInitialization state
+    DevBuf<float> d_prev;
+    DevBuf<signed char> d_bin;
 };
 
 extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orbx_matcher **out)
@@ -876,6 +879,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release();
     m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
+    m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release();
     delete m;
 }
 
@@ -953,6 +957,73 @@ extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, 
     HIP_TRY(hipMemcpyAsync(best_dist, m->d_dist.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return ORBX_OK;
+}
+
+#define ORBX_GRID_CELLS (64 * 48)
+
+static int checkGridBounds(float minX, float maxX, float minY, float maxY, const char *who)
+{
+    if (!(maxX > minX) || !(maxY > minY)) return setError(ORBX_ERR_INVALID_ARG, "%s: empty image bounds", who);
+    return ORBX_OK;
+}
+
+// Frame::AssignFeaturesToGrid — reference src/Frame.cc:387-418 (+ PosInGrid :755-766).
+extern "C" int orbx_assign_features_to_grid(orbx_matcher *m, const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y,
+                                            float max_y, int32_t *cell_start, int32_t *items)
+{
+    if (!m || n < 0 || (n > 0 && !kps) || !cell_start || (n > 0 && !items))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_assign_features_to_grid: bad argument");
+    if (n > m->maxT) return setError(ORBX_ERR_CAPACITY, "%d keypoints exceed the matcher capacity %d", n, m->maxT);
+    int rc = checkGridBounds(min_x, max_x, min_y, max_y, "orbx_assign_features_to_grid");
+    if (rc != ORBX_OK) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
+    int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
+    if (n > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
+    HIP_TRY(hipMemcpyAsync(cell_start, cs, (ORBX_GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const int total = cell_start[ORBX_GRID_CELLS];
+    if (total > 0) HIP_TRY(hipMemcpy(items, it, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+    return total;
+}
+
+// ORBmatcher::SearchForInitialization — reference src/ORBmatcher1.cc:650-765.
+extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, const uint8_t *d1, int n1, const orbx_keypoint *k2,
+                                              const uint8_t *d2, int n2, float min_x, float max_x, float min_y, float max_y,
+                                              float *prev_matched, int32_t *matches12, int window_size, float nnratio,
+                                              int check_orientation)
+{
+    if (!m || n1 < 0 || n2 < 0 || (n1 > 0 && (!k1 || !d1 || !prev_matched || !matches12)) || (n2 > 0 && (!k2 || !d2)) || window_size < 0)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_search_for_initialization: bad argument");
+    if (n1 > m->maxQ || n2 > m->maxT) return setError(ORBX_ERR_CAPACITY, "%d x %d keypoints exceed the matcher capacity %d x %d", n1, n2, m->maxQ, m->maxT);
+    int rc = checkGridBounds(min_x, max_x, min_y, max_y, "orbx_search_for_initialization");
+    if (rc != ORBX_OK) return rc;
+    if (n1 == 0) return 0;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, d1, n1, d2, n2)) != ORBX_OK) return rc;
+    if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
+    if ((rc = m->d_work.ensure((size_t)m->maxQ + 2 * (size_t)m->maxT + 4)) != ORBX_OK) return rc;
+    if ((rc = m->d_prev.ensure(2 * (size_t)m->maxQ)) != ORBX_OK) return rc;
+    if ((rc = m->d_bin.ensure((size_t)m->maxQ)) != ORBX_OK) return rc;
+    int level0of2 = 0;  // the LDS-resident kernel takes F2 subsets of limited size; ORBX_SEARCH_INIT_GENERIC forces the generic one
+    for (int i = 0; i < n2; ++i) level0of2 += k2[i].octave == 0;
+    static const bool forceGeneric = getenv("ORBX_SEARCH_INIT_GENERIC") != nullptr;
+    if (forceGeneric) level0of2 = -1;
+    int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
+    int *m12 = m->d_work.p, *m21 = m12 + m->maxQ, *md = m21 + m->maxT, *nm = md + m->maxT;
+    HIP_TRY(hipMemcpyAsync(m->d_kl.p, k1, (size_t)n1 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    if (n2 > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, k2, (size_t)n2 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->d_prev.p, prev_matched, 2 * (size_t)n1 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (!orbxSearchInitInLds(n1, n2, level0of2)) HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n2, min_x, max_x, min_y, max_y, cs, it, co));
+    HIP_TRY(orbxLaunchSearchInit(m->stream, m->d_kl.p, m->d_q.p, n1, m->d_kr.p, m->d_t.p, n2, cs, it, min_x, max_x, min_y, max_y,
+                                 m->d_prev.p, m12, m21, md, m->d_bin.p, nm, window_size, nnratio, check_orientation, level0of2));
+    int nmatches = 0;
+    HIP_TRY(hipMemcpyAsync(matches12, m12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(prev_matched, m->d_prev.p, 2 * (size_t)n1 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&nmatches, nm, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return nmatches;
 }
 
 // Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011.

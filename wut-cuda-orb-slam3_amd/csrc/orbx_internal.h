@@ -108,4 +108,12 @@ struct OrbxStereoLevels {
 hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void *kl, int nl, const void *kr, const int *bestIdx,
                                   const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist);
 
+hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
+                               int *items, int *cellOf);
+bool orbxSearchInitInLds(int n1, int n2, int level0of2);
+hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
+                                const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
+                                int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
+                                int checkOri, int level0of2);
+
 #endif

@@ -296,3 +296,473 @@ hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void
     hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(256), 0, st, nl, uRight, depth, sadDist);
     return hipGetLastError();
 }
+
+// =====================================================================================================
+// the frame grid (Frame::AssignFeaturesToGrid / GetFeaturesInArea, reference src/Frame.cc:387-418,
+// 687-766) and ORBmatcher::SearchForInitialization (src/ORBmatcher1.cc:650-765) with ComputeThreeMaxima
+// (src/ORBmatcher3.cc:592-633).
+// The search is sequential in the reference - keypoint i1 sees the distances recorded by the matches of all earlier i1
+// (vMatchedDistance) and steals their partners (vnMatches21) - so one wave walks i1 in order and spends its lanes on the
+// candidates of the current i1; a batch of frame pairs would run one wave each.
+// =====================================================================================================
+#define GRID_COLS 64  // FRAME_GRID_COLS (reference include/Frame.h:45)
+#define GRID_ROWS 48  // FRAME_GRID_ROWS (:44)
+#define GRID_CELLS (GRID_COLS * GRID_ROWS)
+
+struct GridBounds { float minX, minY, invW, invH; };
+
+__device__ __forceinline__ int mt_excl_scan(int v, int &total)  // all 64 lanes active
+{
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if ((int)(threadIdx.x & 63) >= o) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
+// One wave per frame: cell = ix * GRID_ROWS + iy of every keypoint (PosInGrid: std::round, half away from zero; -1 outside),
+// counts, exclusive prefix (cellStart[GRID_CELLS + 1]) and the items of every cell in push_back order (increasing index).
+__global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBounds b, int *cellStart, int *items, int *cellOf)
+{
+    __shared__ int cnt[GRID_CELLS];
+    const int lane = threadIdx.x;
+    for (int c = lane; c < GRID_CELLS; c += 64) cnt[c] = 0;
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(k[i].x, b.minX), b.invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(k[i].y, b.minY), b.invH));
+        const int c = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+        cellOf[i] = c;
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    int base = 0;
+    for (int cb = 0; cb < GRID_CELLS; cb += 64) {
+        int total;
+        const int v = cnt[cb + lane];
+        const int o = base + mt_excl_scan(v, total);
+        cellStart[cb + lane] = o;
+        cnt[cb + lane] = o;  // becomes the write cursor of the cell
+        base += total;
+    }
+    if (lane == 0) cellStart[GRID_CELLS] = base;
+    __syncthreads();
+    // stable placement: 64 keypoints per step in index order; lanes that share a cell are ranked by lane
+    for (int ib = 0; ib < n; ib += 64) {
+        const int i = ib + lane;
+        const int c = i < n ? cellOf[i] : -1;
+        unsigned long long todo = __ballot(c >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int cl = __shfl(c, leader);
+            const unsigned long long same = __ballot(c == cl);
+            if (c == cl) items[cnt[cl] + __popcll(same & ((1ull << lane) - 1ull))] = i;
+            __syncthreads();
+            if (lane == leader) cnt[cl] += __popcll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+    }
+}
+
+struct SearchInitArgs {
+    const MtKp *k1; const uint8_t *d1; int n1;
+    const MtKp *k2; const uint8_t *d2; int n2;
+    const int *cellStart, *items;  // grid of F2
+    GridBounds b;
+    float *prev;                   // vbPrevMatched [n1][2], in / out
+    int *m12, *m21, *mdist;        // vnMatches12 [n1], vnMatches21 [n2], vMatchedDistance [n2]
+    signed char *binOf;            // [n1] rotation-histogram bin of the match recorded for i1, -1: none
+    int *nmatches;
+    int window; float nnratio; int checkOri;
+};
+
+__global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
+    __shared__ int hist[32];
+    __shared__ int cand[512];  // candidate indices of the current i1, in GetFeaturesInArea order (larger sets are re-walked)
+    const int lane = threadIdx.x;
+    if (lane < 32) hist[lane] = 0;
+    for (int i = lane; i < a.n1; i += 64) { a.m12[i] = -1; a.binOf[i] = -1; }
+    for (int i = lane; i < a.n2; i += 64) { a.m21[i] = -1; a.mdist[i] = INT_MAX; }
+    __threadfence_block();
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    const float r = (float)a.window;
+    for (int i1 = 0; i1 < a.n1; ++i1) {
+        if (a.k1[i1].octave > 0) continue;  // wave-uniform
+        const int level1 = a.k1[i1].octave;
+        const float x = a.prev[2 * i1], y = a.prev[2 * i1 + 1];
+        // Frame::GetFeaturesInArea(x, y, r, level1, level1)
+        const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+        if (cx0 >= GRID_COLS) continue;
+        const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+        if (cx1 < 0) continue;
+        const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+        if (cy0 >= GRID_ROWS) continue;
+        const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+        if (cy1 < 0) continue;
+        const int ny = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny;
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
+        // lane-local best / second best in candidate order `ord`; the lanes are merged at the end
+        int bestD = INT_MAX, best2 = INT_MAX, bestI = -1, bestOrd = INT_MAX;
+        auto consider = [&](int i2, int ord) {
+            const MtKp kp = a.k2[i2];
+            if (kp.octave < level1 || kp.octave > level1) return;  // bCheckLevels with minLevel == maxLevel == level1
+            if (!(fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r)) return;
+            const uint32_t *t = (const uint32_t *)(a.d2 + (size_t)i2 * 32);
+            int dist = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+            if (a.mdist[i2] <= dist) return;
+            // the reference's sequential rule (`if dist < best ... else if dist < best2`) written so that it does not depend on
+            // the order in which a lane meets its candidates: best = smallest (dist, ord), best2 = second smallest distance
+            if (dist < bestD || (dist == bestD && ord < bestOrd)) { best2 = bestD; bestD = dist; bestI = i2; bestOrd = ord; }
+            else if (dist < best2) best2 = dist;
+        };
+        int ordBase = 0, nCand = 0;
+        for (int cb = 0; cb < nCells; cb += 64) {  // cells in (ix outer, iy inner) order
+            const int ci = cb + lane;
+            int s = 0, e = 0;
+            if (ci < nCells) {
+                const int ix = cx0 + ci / ny, iy = cy0 + ci % ny;
+                s = a.cellStart[ix * GRID_ROWS + iy]; e = a.cellStart[ix * GRID_ROWS + iy + 1];
+            }
+            int total;
+            const int off = ordBase + mt_excl_scan(e - s, total);
+            for (int j = s; j < e; ++j) {  // (cells hold a few keypoints; every item gets its position in the reference's order)
+                const int o = off + (j - s);
+                if (o < 512) cand[o] = a.items[j];
+                else consider(a.items[j], o);  // beyond the staging list: evaluated directly (same (dist, ord) rule)
+            }
+            ordBase += total;
+        }
+        nCand = min(ordBase, 512);
+        __threadfence_block();
+        __syncthreads();
+        for (int o = lane; o < nCand; o += 64) consider(cand[o], o);  // independent loads for 64 candidates at a time
+        __syncthreads();
+        // merge: best = min (dist, ord); best2 = second smallest of the multiset
+        unsigned key = bestI >= 0 ? ((unsigned)bestD << 20) | (unsigned)min(bestOrd, (1 << 20) - 1) : 0xFFFFFFFFu;
+        unsigned kmin = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+        if (kmin == 0xFFFFFFFFu) continue;  // no candidate survived
+        const unsigned long long win = __ballot(key == kmin);
+        const int wl = __ffsll((long long)win) - 1;
+        const int gBestD = __shfl(bestD, wl), gBestI = __shfl(bestI, wl);
+        int second = lane == wl ? best2 : bestD;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+        if (gBestD <= TH_LOW && (float)gBestD < __fmul_rn((float)second, a.nnratio)) {
+            if (lane == 0) {
+                const int old = a.m21[gBestI];
+                if (old >= 0) a.m12[old] = -1;
+                a.m12[i1] = gBestI; a.m21[gBestI] = i1; a.mdist[gBestI] = gBestD;
+                if (a.checkOri) {
+                    float rot = __fsub_rn(a.k1[i1].angle, a.k2[gBestI].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    a.binOf[i1] = (signed char)bin;
+                    hist[bin] += 1;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (a.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima (every lane, uniform)
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        for (int i = lane; i < a.n1; i += 64) {
+            const int b = a.binOf[i];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && a.m12[i] >= 0) a.m12[i] = -1;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    int cntM = 0;
+    for (int i = lane; i < a.n1; i += 64) {
+        const int m = a.m12[i];
+        if (m >= 0) { a.prev[2 * i] = a.k2[m].x; a.prev[2 * i + 1] = a.k2[m].y; ++cntM; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cntM += __shfl_xor(cntM, o);
+    // nmatches as the reference counts it (++ per accepted match, -- per stolen or rotation-filtered one) = entries still >= 0
+    if (lane == 0) *a.nmatches = cntM;
+}
+
+// The same search with everything the candidate loop touches in LDS.  Only octave-0 keypoints take part (F1: `level1 > 0` is
+// skipped; F2: GetFeaturesInArea(.., level1, level1)), so the kernel compacts both sides to their octave-0 subsets, rebuilds
+// the grid over the F2 subset (same PosInGrid cells, same push order) and keeps positions, angles, descriptors, vMatchedDistance
+// and vnMatches21 of that subset in LDS: a global round trip per dependent step made the generic kernel above take ~21 us per
+// keypoint of F1.  Used when F2 has at most SI_CAP2 octave-0 keypoints and both frames have fewer than 65536 keypoints.
+#define SI_CAP2 2048   // octave-0 keypoints of F2 held in LDS (48 B each)
+#define SI_CAND 1024   // staged candidates per F1 keypoint (more are evaluated straight from the cells)
+
+__global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
+    extern __shared__ __attribute__((aligned(16))) uint8_t si_lds[];
+    uint32_t *desc = (uint32_t *)si_lds;                    // [SI_CAP2][8]
+    float *kx = (float *)(desc + SI_CAP2 * 8);              // [SI_CAP2]
+    float *ky = kx + SI_CAP2;                               // [SI_CAP2]
+    float *kang = ky + SI_CAP2;                             // [SI_CAP2]
+    int *m21 = (int *)(kang + SI_CAP2);                     // [SI_CAP2] vnMatches21 of the subset (F1 index)
+    uint16_t *orig = (uint16_t *)(m21 + SI_CAP2);           // [SI_CAP2] index in F2
+    uint16_t *mdist = orig + SI_CAP2;                       // [SI_CAP2] vMatchedDistance (0xFFFF = INT_MAX)
+    uint16_t *items0 = mdist + SI_CAP2;                     // [SI_CAP2] subset indices by cell, push order
+    uint16_t *cellOf = items0 + SI_CAP2;                    // [SI_CAP2] (setup only)
+    uint16_t *cs0 = cellOf + SI_CAP2;                       // [GRID_CELLS + 2] cell starts of the subset grid
+    uint16_t *cand = cs0 + GRID_CELLS + 2;                  // [SI_CAND]
+    uint16_t *list1 = cand + SI_CAND;                       // [n1 rounded] octave-0 keypoints of F1 in index order
+    int *cnt = (int *)desc;                                 // [GRID_CELLS] setup only: aliases the descriptors (loaded last)
+    __shared__ int hist[32];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (lane < 32) hist[lane] = 0;
+    for (int i = lane; i < a.n1; i += 64) { a.m12[i] = -1; a.binOf[i] = -1; }
+    // ---- octave-0 subsets ------------------------------------------------------------------------------------
+    int n0 = 0, nL1 = 0;
+    for (int ib = 0; ib < a.n2; ib += 64) {
+        const int i = ib + lane;
+        const bool z = i < a.n2 && a.k2[i].octave == 0;
+        const unsigned long long m = __ballot(z);
+        if (z) orig[n0 + __popcll(m & lt)] = (uint16_t)i;
+        n0 += __popcll(m);
+    }
+    for (int ib = 0; ib < a.n1; ib += 64) {
+        const int i = ib + lane;
+        const bool z = i < a.n1 && !(a.k1[i].octave > 0);
+        const unsigned long long m = __ballot(z);
+        if (z) list1[nL1 + __popcll(m & lt)] = (uint16_t)i;
+        nL1 += __popcll(m);
+    }
+    for (int c = lane; c < GRID_CELLS; c += 64) cnt[c] = 0;
+    __syncthreads();
+    for (int c = lane; c < n0; c += 64) {  // Frame::PosInGrid of the subset
+        const MtKp kp = a.k2[orig[c]];
+        kx[c] = kp.x; ky[c] = kp.y; kang[c] = kp.angle; m21[c] = -1; mdist[c] = 0xFFFF;
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, a.b.minX), a.b.invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, a.b.minY), a.b.invH));
+        const int cl = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? 0xFFFF : px * GRID_ROWS + py;
+        cellOf[c] = (uint16_t)cl;
+        if (cl != 0xFFFF) atomicAdd(&cnt[cl], 1);
+    }
+    __syncthreads();
+    {
+        int base = 0;
+        for (int cb = 0; cb < GRID_CELLS; cb += 64) {
+            int total;
+            const int v = cnt[cb + lane];
+            const int o = base + mt_excl_scan(v, total);
+            cs0[cb + lane] = (uint16_t)o;
+            cnt[cb + lane] = o;
+            base += total;
+        }
+        if (lane == 0) cs0[GRID_CELLS] = (uint16_t)base;
+    }
+    __syncthreads();
+    for (int ib = 0; ib < n0; ib += 64) {  // stable placement, 64 keypoints per step in index order
+        const int c = ib + lane;
+        const int cl = c < n0 ? (int)cellOf[c] : 0xFFFF;
+        unsigned long long todo = __ballot(cl != 0xFFFF);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int cll = __shfl(cl, leader);
+            const unsigned long long same = __ballot(cl == cll);
+            if (cl == cll) items0[cnt[cll] + __popcll(same & lt)] = (uint16_t)c;
+            __syncthreads();
+            if (lane == leader) cnt[cll] += __popcll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n0 * 8; i += 64) desc[i] = ((const uint32_t *)(a.d2 + (size_t)orig[i >> 3] * 32))[i & 7];  // (over cnt[])
+    __syncthreads();
+
+    // ---- the sequential walk over the octave-0 keypoints of F1 ---------------------------------------------------
+    const float factor = 1.0f / HISTO_LENGTH;
+    const float r = (float)a.window;
+    // registers of the NEXT keypoint are requested while the current one is matched
+    float nx = 0.f, ny = 0.f, nang = 0.f;
+    uint32_t nq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto fetch = [&](int t) {
+        if (t < nL1) {
+            const int i1 = list1[t];
+            nx = a.prev[2 * i1]; ny = a.prev[2 * i1 + 1]; nang = a.k1[i1].angle;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) nq[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
+        }
+    };
+    fetch(0);
+    for (int t = 0; t < nL1; ++t) {
+        const int i1 = list1[t];
+        const float x = nx, y = ny, ang1 = nang;
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = nq[w];
+        fetch(t + 1);
+        // Frame::GetFeaturesInArea(x, y, r, 0, 0)
+        const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+        if (cx0 >= GRID_COLS) continue;
+        const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+        if (cx1 < 0) continue;
+        const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+        if (cy0 >= GRID_ROWS) continue;
+        const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+        if (cy1 < 0) continue;
+        const int ny_ = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny_;
+        int bestD = INT_MAX, best2 = INT_MAX, bestC = -1, bestOrd = INT_MAX;
+        auto consider = [&](int c2, int ord) {
+            if (!(fabsf(__fsub_rn(kx[c2], x)) < r && fabsf(__fsub_rn(ky[c2], y)) < r)) return;
+            const uint32_t *tt = desc + c2 * 8;
+            int dist = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ tt[w]);
+            if ((int)mdist[c2] <= dist) return;
+            if (dist < bestD || (dist == bestD && ord < bestOrd)) { best2 = bestD; bestD = dist; bestC = c2; bestOrd = ord; }
+            else if (dist < best2) best2 = dist;
+        };
+        int ordBase = 0;
+        for (int cb = 0; cb < nCells; cb += 64) {  // cells in (ix outer, iy inner) order
+            const int ci = cb + lane;
+            int sB = 0, eB = 0;
+            if (ci < nCells) {
+                const int cell = (cx0 + ci / ny_) * GRID_ROWS + cy0 + ci % ny_;
+                sB = cs0[cell]; eB = cs0[cell + 1];
+            }
+            int total;
+            const int off = ordBase + mt_excl_scan(eB - sB, total);
+            for (int j = sB; j < eB; ++j) {
+                const int o = off + (j - sB);
+                if (o < SI_CAND) cand[o] = items0[j];
+                else consider(items0[j], o);
+            }
+            ordBase += total;
+        }
+        const int nCand = min(ordBase, SI_CAND);
+        __syncthreads();
+        for (int o = lane; o < nCand; o += 64) consider(cand[o], o);
+        __syncthreads();
+        unsigned key = bestC >= 0 ? ((unsigned)bestD << 20) | (unsigned)min(bestOrd, (1 << 20) - 1) : 0xFFFFFFFFu;
+        unsigned kmin = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+        if (kmin == 0xFFFFFFFFu) continue;
+        const int wl = __ffsll((long long)__ballot(key == kmin)) - 1;
+        const int gBestD = __shfl(bestD, wl), gBestC = __shfl(bestC, wl);
+        int second = lane == wl ? best2 : bestD;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+        if (gBestD <= TH_LOW && (float)gBestD < __fmul_rn((float)second, a.nnratio)) {
+            if (lane == 0) {
+                const int old = m21[gBestC];
+                if (old >= 0) a.m12[old] = -1;
+                a.m12[i1] = orig[gBestC]; m21[gBestC] = i1; mdist[gBestC] = (uint16_t)gBestD;
+                if (a.checkOri) {
+                    float rot = __fsub_rn(ang1, kang[gBestC]);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    a.binOf[i1] = (signed char)bin;
+                    hist[bin] += 1;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (a.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima (every lane, uniform)
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        for (int i = lane; i < a.n1; i += 64) {
+            const int b = a.binOf[i];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && a.m12[i] >= 0) a.m12[i] = -1;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    int cntM = 0;
+    for (int i = lane; i < a.n1; i += 64) {
+        const int m = a.m12[i];
+        if (m >= 0) { a.prev[2 * i] = a.k2[m].x; a.prev[2 * i + 1] = a.k2[m].y; ++cntM; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cntM += __shfl_xor(cntM, o);
+    if (lane == 0) *a.nmatches = cntM;
+}
+
+// true when orbxLaunchSearchInit takes the LDS-resident kernel (which builds its own grid: no orbxLaunchGridBuild needed)
+bool orbxSearchInitInLds(int n1, int n2, int level0of2);
+
+static size_t searchInitLdsBytes(int n1)
+{
+    return (size_t)SI_CAP2 * (32 + 4 * 4 + 2 * 4) + (GRID_CELLS + 2) * 2 + SI_CAND * 2 + ((size_t)n1 + 64) * 2;
+}
+
+hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
+                               int *items, int *cellOf)
+{
+    GridBounds b;
+    b.minX = minX; b.minY = minY;
+    b.invW = (float)GRID_COLS / (maxX - minX); b.invH = (float)GRID_ROWS / (maxY - minY);
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(64), 0, st, (const MtKp *)k, n, b, cellStart, items, cellOf);
+    return hipGetLastError();
+}
+
+bool orbxSearchInitInLds(int n1, int n2, int level0of2)
+{
+    return level0of2 >= 0 && level0of2 <= SI_CAP2 && n1 < 65536 && n2 < 65536 && searchInitLdsBytes(n1) <= 160 * 1024 - 1024;
+}
+
+hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
+                                const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
+                                int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
+                                int checkOri, int level0of2)
+{
+    SearchInitArgs a;
+    a.k1 = (const MtKp *)k1; a.d1 = d1; a.n1 = n1; a.k2 = (const MtKp *)k2; a.d2 = d2; a.n2 = n2;
+    a.cellStart = cellStart; a.items = items;
+    a.b.minX = minX; a.b.minY = minY;
+    a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);
+    a.prev = prev; a.m12 = m12; a.m21 = m21; a.mdist = mdist; a.binOf = binOf; a.nmatches = nmatches;
+    a.window = window; a.nnratio = nnratio; a.checkOri = checkOri;
+    // level0of2 = number of octave-0 keypoints of F2 (counted by the caller on its host copy), < 0: unknown
+    const size_t lds = searchInitLdsBytes(n1);
+    if (orbxSearchInitInLds(n1, n2, level0of2)) {
+        static size_t attrBytes = 0;  // (the kernel also has 128 B of static LDS: the dynamic part may not be set to the full 160 KB)
+        if (lds > attrBytes) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_search_init_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attrBytes = lds;
+        }
+        hipLaunchKernelGGL(k_search_init_lds, dim3(1), dim3(64), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(k_search_init, dim3(1), dim3(64), 0, st, a);
+    }
+    return hipGetLastError();
+}

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -134,13 +135,68 @@ private:
     orbx_extractor *h_ = nullptr;
 };
 
+// The part of `ORB_SLAM3::Frame` the windowed searches read (reference include/Frame.h): undistorted keypoints, descriptors and
+// the static image bounds mnMinX .. mnMaxY (src/Frame.cc:41, 808-839) that define the 64 x 48 feature grid.
+struct FrameView {
+    const std::vector<KeyPoint> *mvKeysUn = nullptr;
+    const Descriptors *mDescriptors = nullptr;
+    float mnMinX = 0.f, mnMaxX = 0.f, mnMinY = 0.f, mnMaxY = 0.f;
+};
 class ORBmatcher {
 public:
     static const int TH_LOW = 50;      // reference src/ORBmatcher1.cc:38
     static const int TH_HIGH = 100;    // :37
     static const int HISTO_LENGTH = 30;  // :39
+    // ORBmatcher(float nnratio = 0.6, bool checkOri = true) — reference include/ORBmatcher.h:40.  (The reference's matcher is a
+    // stateless value object; this one additionally owns the device buffers of the searches, sized at construction.)
+    explicit ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int maxKeypoints = 8192, int device = 0)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri)
+    {
+        check(orbx_matcher_create(device, maxKeypoints, maxKeypoints, &m_), "ORBmatcher");
+    }
+    ~ORBmatcher() { orbx_matcher_destroy(m_); }
+    ORBmatcher(const ORBmatcher &) = delete;
+    ORBmatcher &operator=(const ORBmatcher &) = delete;
+
     // Computes the Hamming distance between two ORB descriptors (rows of 32 bytes)
     static int DescriptorDistance(const uint8_t *a, const uint8_t *b) { return orbx_hamming256(a, b); }
+
+    // Matching for the Map Initialization (only used in the monocular case) — reference include/ORBmatcher.h:72,
+    // src/ORBmatcher1.cc:650-765
+    int SearchForInitialization(const FrameView &F1, const FrameView &F2, std::vector<Point2f> &vbPrevMatched, std::vector<int> &vnMatches12,
+                                int windowSize = 10)
+    {
+        const int n1 = (int)F1.mvKeysUn->size(), n2 = (int)F2.mvKeysUn->size();
+        if ((int)vbPrevMatched.size() != n1) throw std::runtime_error("SearchForInitialization: vbPrevMatched.size() != F1.mvKeysUn.size()");
+        vnMatches12.assign((size_t)n1, -1);
+        static_assert(sizeof(Point2f) == 2 * sizeof(float), "Point2f layout");
+        const int n = orbx_search_for_initialization(m_, (const orbx_keypoint *)F1.mvKeysUn->data(), F1.mDescriptors->data.data(), n1,
+                                                     (const orbx_keypoint *)F2.mvKeysUn->data(),
+                                                     F2.mDescriptors->data.data(), n2, F2.mnMinX, F2.mnMaxX, F2.mnMinY, F2.mnMaxY,
+                                                     n1 ? &vbPrevMatched[0].x : nullptr, vnMatches12.data(), windowSize, mfNNratio,
+                                                     mbCheckOrientation ? 1 : 0);
+        if (n < 0) check(n, "SearchForInitialization");
+        return n;
+    }
+
+    // Frame::AssignFeaturesToGrid — reference src/Frame.cc:387-418: mGrid[ix][iy] = items[cellStart[ix * 48 + iy] .. cellStart[.. + 1])
+    void AssignFeaturesToGrid(const FrameView &F, std::vector<int32_t> &cellStart, std::vector<int32_t> &items)
+    {
+        const int n = (int)F.mvKeysUn->size();
+        cellStart.assign(ORBX_FRAME_GRID_COLS * ORBX_FRAME_GRID_ROWS + 1, 0);
+        items.assign((size_t)std::max(n, 1), 0);
+        const int placed = orbx_assign_features_to_grid(m_, (const orbx_keypoint *)F.mvKeysUn->data(), n, F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY, cellStart.data(),
+                                                        items.data());
+        if (placed < 0) check(placed, "AssignFeaturesToGrid");
+        items.resize((size_t)placed);
+    }
+
+    orbx_matcher *handle() { return m_; }
+
+private:
+    float mfNNratio;
+    bool mbCheckOrientation;
+    orbx_matcher *m_ = nullptr;
 };
 
 // cv::BFMatcher(cv::NORM_HAMMING) for k = 2 (the only use in the reference, src/Frame.cc:1174)
