@@ -40,6 +40,22 @@ def main():
             crcs.append([zlib.crc32(o.level(l).tobytes()), zlib.crc32(o.level(l, True).tobytes()),
                          zlib.crc32(o.candidates(l).tobytes()), len(o.candidates(l)), len(o.level_keypoints(l))])
         out[name + "/levels"] = np.array(crcs, np.int64)
+    # ORBmatcher::SearchForInitialization on a frame and a shifted, re-noised view of it (5 x nFeatures
+    # extractor, window 100, ORBmatcher(0.9, true): src/Tracking3.cc:740-741); a second call on the updated vbPrevMatched
+    img1 = orc.synth_frame(7, 640, 480)
+    rng = np.random.default_rng(1)
+    img2 = np.clip(np.roll(np.roll(img1, -6, axis=0), 9, axis=1).astype(np.int16) + rng.integers(-3, 4, img1.shape, dtype=np.int16), 0, 255)
+    img2 = img2.astype(np.uint8)
+    o = orc.Oracle(5000, 1.2, 8, 20, 7)
+    _, k1, d1 = o.extract(img1, (0, 0))
+    _, k2, d2 = o.extract(img2, (0, 0))
+    prev = np.stack([k1["x"], k1["y"]], axis=1)
+    n, m12, pv = orc.search_for_initialization(k1, d1, k2, d2, prev, (0, 640, 0, 480), 100, 0.9, True)
+    n2, m12b, _ = orc.search_for_initialization(k1, d1, k2, d2, pv, (0, 640, 0, 480), 100, 0.9, True)
+    out["search_init/input_crc"] = np.array([zlib.crc32(img1.tobytes()), zlib.crc32(img2.tobytes())], np.uint32)
+    out["search_init/nmatches"] = np.array([n, n2], np.int64)
+    out["search_init/matches12"] = np.stack([m12, m12b])
+    out["search_init/grid_crc"] = np.array([zlib.crc32(np.concatenate(orc.assign_grid(k2, (0, 640, 0, 480))).tobytes())], np.uint32)
     path = os.path.join(ROOT, "tests", "golden", "orb_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

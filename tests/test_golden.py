@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "orb_golden.npz"))
-CASES = sorted({k.split("/")[0] for k in GOLD.files})
+CASES = sorted({k.split("/")[0] for k in GOLD.files} - {"search_init"})
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -48,3 +48,41 @@ def test_hip_path_reproduces_golden(pkg, case):
         assert len(cand) == lv[l, 3] and zlib.crc32(cand.tobytes()) == lv[l, 2], f"candidates level {l}"
         assert len(ex.debug_selected(0, l)) == lv[l, 4]
     ex.close()
+
+
+def _search_init_inputs(mod, extract):
+    img1 = mod.synth_frame(7, 640, 480)
+    rng = np.random.default_rng(1)
+    img2 = np.clip(np.roll(np.roll(img1, -6, axis=0), 9, axis=1).astype(np.int16) + rng.integers(-3, 4, img1.shape, dtype=np.int16), 0, 255)
+    img2 = img2.astype(np.uint8)
+    assert [zlib.crc32(img1.tobytes()), zlib.crc32(img2.tobytes())] == GOLD["search_init/input_crc"].tolist()
+    k1, d1 = extract(img1)
+    k2, d2 = extract(img2)
+    return k1, d1, k2, d2, np.stack([k1["x"], k1["y"]], axis=1)
+
+
+def test_oracle_reproduces_search_for_initialization_golden(orc):
+    o = orc.Oracle(5000, 1.2, 8, 20, 7)
+    k1, d1, k2, d2, prev = _search_init_inputs(orc, lambda im: o.extract(im, (0, 0))[1:])
+    n, m12, pv = orc.search_for_initialization(k1, d1, k2, d2, prev, (0, 640, 0, 480), 100, 0.9, True)
+    n2, m12b, _ = orc.search_for_initialization(k1, d1, k2, d2, pv, (0, 640, 0, 480), 100, 0.9, True)
+    assert [n, n2] == GOLD["search_init/nmatches"].tolist()
+    assert np.array_equal(np.stack([m12, m12b]), GOLD["search_init/matches12"])
+    assert zlib.crc32(np.concatenate(orc.assign_grid(k2, (0, 640, 0, 480))).tobytes()) == int(GOLD["search_init/grid_crc"][0])
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_search_for_initialization_golden(pkg):
+    ex = pkg.ORBextractor(5000, 1.2, 8, 20, 7)
+
+    def extract(im):
+        _, k, d = ex(im, None, (0, 0))
+        return k.copy(), d.copy()
+    k1, d1, k2, d2, prev = _search_init_inputs(pkg, extract)
+    m = pkg.ORBmatcher(8192, 8192)
+    n, m12, pv = m.SearchForInitialization(k1, d1, k2, d2, prev, (0, 640, 0, 480), 100, 0.9, True)
+    n2, m12b, _ = m.SearchForInitialization(k1, d1, k2, d2, pv, (0, 640, 0, 480), 100, 0.9, True)
+    assert [n, n2] == GOLD["search_init/nmatches"].tolist()
+    assert np.array_equal(np.stack([m12, m12b]), GOLD["search_init/matches12"])
+    assert zlib.crc32(np.concatenate(m.AssignFeaturesToGrid(k2, (0, 640, 0, 480))).tobytes()) == int(GOLD["search_init/grid_crc"][0])
+    m.close(); ex.close()
