@@ -35,6 +35,7 @@ def lib() -> ctypes.CDLL:
         L.oracle_destroy.restype = None
         L.oracle_get_tables.argtypes = [c_void_p] + [c_void_p] * 6
         L.oracle_max_keypoints.argtypes = [c_void_p]
+        L.oracle_max_keypoints_for.argtypes = [c_void_p, c_int, c_int]
         L.oracle_extract.argtypes = [c_void_p, c_void_p, c_int, c_int, c_ssize_t, c_int, c_int, c_void_p, c_void_p, POINTER(c_int)]
         L.oracle_level_size.argtypes = [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]
         L.oracle_get_level.argtypes = [c_void_p, c_int, c_int, c_void_p]
@@ -96,7 +97,8 @@ class Oracle:
             return -1, np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        cap = max(self.capacity, 64) + 64
+        cap = max(self.L.oracle_max_keypoints_for(self.h, w, h), self.capacity, 64) + 64
+        self._last_cap = cap
         kps = np.zeros(cap, KEYPOINT_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = c_int()
@@ -121,7 +123,7 @@ class Oracle:
         return out[:n].copy()
 
     def level_keypoints(self, level):
-        out = np.zeros(self.capacity + 64, KEYPOINT_DTYPE)
+        out = np.zeros(max(self.capacity, getattr(self, "_last_cap", 0)) + 64, KEYPOINT_DTYPE)
         n = self.L.oracle_get_level_keypoints(self.h, level, out.ctypes.data, len(out))
         return out[:n].copy()
 
@@ -130,7 +132,7 @@ class Oracle:
         b, h, w = imgs.shape
         counts = np.zeros(b, np.int32)
         mono = np.zeros(b, np.int32)
-        cap = self.capacity
+        cap = max(self.capacity, self.L.oracle_max_keypoints_for(self.h, w, h))
         kps = np.zeros((b, cap), KEYPOINT_DTYPE) if want_outputs else None
         desc = np.zeros((b, cap, 32), np.uint8) if want_outputs else None
         self.L.oracle_extract_batch(self.h, imgs.ctypes.data, b, w, h, imgs.strides[1], int(lap[0]), int(lap[1]), threads,

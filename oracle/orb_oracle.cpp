@@ -670,6 +670,20 @@ int oracle_max_keypoints(const oracle_handle *h)
     for (int v : h->featuresPerLevel) s += v + 3;
     return s;
 }
+// DistributeOctTree returns up to max(N + 3, 4 * nIni) keypoints of a level: the first pass splits every one of the
+// nIni = round(W / H) root nodes (src/ORBextractor.cc:589) into up to 4 before the quota is looked at (:697), so very wide images
+// with small quotas exceed N + 3.
+int oracle_max_keypoints_for(const oracle_handle *h, int w, int hh)
+{
+    int s = 0;
+    for (size_t l = 0; l < h->featuresPerLevel.size(); ++l) {
+        const int lw = l == 0 ? w : cvRoundF((float)w * h->invScale[l]), lh = l == 0 ? hh : cvRoundF((float)hh * h->invScale[l]);
+        const int W = std::max(lw - 32, 1), H = std::max(lh - 32, 1);
+        const int nIni = (int)std::round((float)W / (float)H);
+        s += std::max(h->featuresPerLevel[l] + 3, 4 * nIni);
+    }
+    return s;
+}
 int oracle_extract(oracle_handle *h, const uint8_t *img, int w, int h_, ptrdiff_t stride, int lap0, int lap1,
                    oracle_keypoint *kps, uint8_t *desc, int *n_out)
 {

@@ -40,6 +40,9 @@ void oracle_destroy(oracle_handle *);
 int oracle_get_tables(const oracle_handle *, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
                       int32_t *features_per_level, int32_t *umax16);
 int oracle_max_keypoints(const oracle_handle *); /* sum(N_l + 3) */
+/* sum over levels of max(N_l + 3, 4 * nIni_l) for a w x h image: the bound that also holds for very wide images (nIni = round(W / H)
+ * root nodes are split into up to 4 before the quota is looked at); kps / desc of oracle_extract must hold this many entries. */
+int oracle_max_keypoints_for(const oracle_handle *, int w, int h);
 
 /* ORBextractor::operator() (reference src/ORBextractor.cc:1227-1307).  Returns monoIndex, or -1 on an
  * empty image.  kps/desc must hold oracle_max_keypoints() entries. */

@@ -123,11 +123,43 @@ def test_empty_and_error_paths(pkg):
         ex(np.zeros((100, 100), np.uint8))
     with pytest.raises(pkg.OrbxError, match="max_batch"):
         ex.extract_batch(np.zeros((3, 480, 640), np.uint8))
+    # portrait images with W / H < 0.5: DistributeOctTree would start from round(W / H) = 0 root nodes (the reference divides by
+    # zero and indexes an empty vector there) -> a clean error
+    with pytest.raises(pkg.OrbxError, match="aspect ratio"):
+        pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=236, max_height=483)(np.zeros((483, 236), np.uint8))
     img = pkg.synth_frame(1, 640, 480)
     # an extraction still works after the errors, and a smaller image re-derives the geometry
     assert len(ex(img, None, (0, 0))[1]) >= 1000
     assert len(ex(img[:300, :400], None, (0, 0))[1]) > 0
     ex.close()
+
+
+def test_wide_image_small_quota(pkg, orc):
+    """DistributeOctTree starts from nIni = round(W / H) root nodes and splits each of them into up to 4 before it looks at the
+    quota: a very wide image with few features returns up to 4 * nIni keypoints per level, far more than N + 3."""
+    img = pkg.synth_frame(77, 943, 137)
+    ex = pkg.ORBextractor(96, 1.25, 4, 8, 2, max_width=943, max_height=137)
+    ref = orc.Oracle(96, 1.25, 4, 8, 2)
+    mono, kps, desc = ex(img, None, (764, 1777))
+    rmono, rk, rd = ref.extract(img, (764, 1777))
+    assert mono == rmono
+    _assert_same(pkg, kps, desc, rk, rd, "943x137, 96 features")
+    assert len(kps) > 96 + 4 * 3  # more than sum(N_l + 3)
+    assert ex.capacity >= len(kps)
+    ex.close()
+
+
+def test_level_quota_beyond_lds(pkg, orc):
+    """A level quota whose list does not fit in LDS (~3500 nodes): the quadtree kernels keep their node arrays in global scratch."""
+    img = np.random.default_rng(3).integers(0, 256, (600, 800), dtype=np.uint8)
+    for nf, nlevels in ((5544, 1), (9000, 2)):
+        ex = pkg.ORBextractor(nf, 1.25, nlevels, 29, 3, max_width=800, max_height=600)
+        mono, kps, desc = ex(img, None, (85, 936))
+        rmono, rk, rd = orc.Oracle(nf, 1.25, nlevels, 29, 3).extract(img, (85, 936))
+        assert mono == rmono
+        _assert_same(pkg, kps, desc, rk, rd, f"nfeatures {nf} on {nlevels} level(s)")
+        assert len(kps) > 4000
+        ex.close()
 
 
 def test_strided_and_unaligned_input(pkg, orc):

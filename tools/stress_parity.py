@@ -1,0 +1,54 @@
+"""Randomised end-to-end parity sweep (development tool, not part of the test suite): random image sizes, feature counts, level
+counts, scale factors, thresholds and image content against the CPU oracle.  Usage: python tools/stress_parity.py [n] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g  # noqa: E402
+
+pkg = g.load_package()
+orc = g.load_oracle()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # skip the cases before this one (same random stream)
+bad = 0
+for case in range(n_cases):
+    w = int(rng.integers(120, 1400))
+    h = int(rng.integers(100, 1000))
+    nlev = int(rng.integers(1, 9))
+    scale = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
+    while min(w, h) / scale ** (nlev - 1) < 70:  # every level must hold one 35-px FAST cell + borders
+        nlev -= 1
+    if (w - 32) / (h - 32) < 0.55 :  # nIni = round(W / H) = 0: undefined behaviour in the reference, rejected by the library
+        h = int(w * 1.5)
+    nf = int(rng.integers(50, 6000))
+    ini = int(rng.integers(5, 40))
+    mn = int(rng.integers(0, ini + 1))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        img = pkg.synth_frame(int(rng.integers(0, 1 << 30)), w, h)
+    elif kind == 1:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == 2:
+        img = (128 + rng.integers(-9, 10, (h, w))).astype(np.uint8)
+    else:
+        img = np.kron(rng.integers(0, 256, (h // 16 + 1, w // 16 + 1), dtype=np.uint8), np.ones((16, 16), np.uint8))[:h, :w].copy()
+    lap = (int(rng.integers(-10, w)), int(rng.integers(0, 2 * w)))
+    if case < first:
+        continue
+    print(f"case {case}: {w}x{h} nf={nf} levels={nlev} scale={scale} th={ini}/{mn} kind={kind} lap={lap}", end=" ", flush=True)
+    try:
+        ex = pkg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w, max_height=h)
+        mono, kps, desc = ex(img, None, lap)
+        rmono, rk, rd = orc.Oracle(nf, scale, nlev, ini, mn).extract(img, lap)
+        ok = mono == rmono and len(kps) == len(rk) and np.array_equal(kps.view(np.uint8), rk.view(np.uint8)) and np.array_equal(desc, rd)
+        ex.close()
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("   exception:", e)
+    print(f"n={len(rk) if ok else '?'} {'ok' if ok else 'MISMATCH'}", flush=True)
+    bad += not ok
+print("ALL OK" if bad == 0 else f"{bad} MISMATCHES")
+sys.exit(1 if bad else 0)

@@ -89,6 +89,7 @@ struct orbx_extractor {
     // device memory
     DevBuf<uint8_t> d_in;                       // staging for host-pointer input (level 0)
     int inPitch = 0; long long inFrameStride = 0;
+    DevBuf<uint8_t> d_qtNodes;                   // quadtree node arrays when a level quota does not fit in LDS (ensureBuffers)
     std::vector<DevBuf<uint8_t>> d_raw, d_blur; // per level [max_batch][h][pitch]
     DevBuf<int> d_tabs;
     DevBuf<OrbxLevelGeom> d_geom;
@@ -185,12 +186,15 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
             ++v0;
         }
     }
-    // DistributeOctTree may overshoot a quota by up to 3 (:697); tiny quotas are floored at 16 slots so that
-    // the up-to-4-per-root first split always fits.
+    // DistributeOctTree may overshoot a quota by up to 3 (:697), and its first pass splits each of the nIni = round(W / H) root nodes
+    // (:589) into up to 4 before any quota is looked at: a level returns up to max(N + 3, 4 * nIni) keypoints.  nIni is largest for
+    // the widest, flattest image the handle accepts (width max_width, FAST region one 35-px cell high).
     ex->levelCap.resize(nl);
     ex->maxKeypoints = 0; ex->maxQuota = 0;
     for (int l = 0; l < nl; ++l) {
-        ex->levelCap[l] = std::max(ex->quota[l] + 3, 16);
+        const int wl = l == 0 ? p->max_width : cvRoundF((float)p->max_width * ex->invScale[l]);
+        const int nIniMax = (int)std::round((float)std::max(wl - 2 * ORBX_BORDER, 1) / 35.0f);
+        ex->levelCap[l] = std::max(std::max(ex->quota[l] + 3, 16), 4 * nIniMax);
         ex->maxKeypoints += ex->levelCap[l];
         ex->maxQuota = std::max(ex->maxQuota, ex->quota[l]);
     }
@@ -240,6 +244,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     ex->d_in.release();
     for (auto &b : ex->d_raw) b.release();
     for (auto &b : ex->d_blur) b.release();
+    ex->d_qtNodes.release();
     ex->d_tabs.release(); ex->d_geom.release(); ex->d_cand.release(); ex->d_scratchA.release(); ex->d_scratchB.release();
     ex->d_sel.release(); ex->d_workKey.release(); ex->d_tileCount.release(); ex->d_selCount.release();
     ex->d_workPos.release(); ex->d_n.release(); ex->d_mono.release(); ex->d_kps.release(); ex->d_desc.release();
@@ -299,13 +304,20 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         const int nCols = (int)(width / 35.f), nRows = (int)(height / 35.f);
         if (nCols < 1 || nRows < 1 || g.w < 2 * ORBX_FAST_MARGIN + 1 || g.h < 2 * ORBX_FAST_MARGIN + 1)
             return setError(ORBX_ERR_TOO_SMALL, "pyramid level %d (%dx%d) is smaller than one 35-px FAST cell", l, g.w, g.h);
+        // DistributeOctTree starts from nIni = round(W / H) root nodes (src/ORBextractor.cc:589): below 0.5 that is 0, hX = W / 0 and the
+        // reference indexes an empty vector (:611-614) - undefined behaviour there, an error here
+        if ((int)std::round(width / height) < 1)
+            return setError(ORBX_ERR_INVALID_ARG, "pyramid level %d (%dx%d): aspect ratio below 0.5 leaves DistributeOctTree without a root node "
+                                                  "(nIni = round(W / H) = 0, reference src/ORBextractor.cc:589)", l, g.w, g.h);
         g.wCell = (int)std::ceil(width / nCols);
         g.hCell = (int)std::ceil(height / nRows);
         const int iw = g.w - 2 * ORBX_FAST_MARGIN, ih = g.h - 2 * ORBX_FAST_MARGIN;  // corner-capable interior
         g.ncx = std::min(nCols, (iw + g.wCell - 1) / g.wCell);
         g.ncy = std::min(nRows, (ih + g.hCell - 1) / g.hCell);
         static const int tileW = [] { const char *e = getenv("ORBX_TILE_W"); return e ? atoi(e) : 288; }();  // target interior width of a tile
-        int gmax = std::max(1, tileW / g.wCell);
+        // cells are 35 .. 69 px high (height / nRows): keep the tile area - and with it the LDS footprint - about constant
+        const int tileWl = std::max(g.wCell, tileW * 35 / std::max(g.hCell, 35));
+        int gmax = std::max(1, tileWl / g.wCell);
         g.nGroups = (g.ncx + gmax - 1) / gmax;
         g.groupCells = (g.ncx + g.nGroups - 1) / g.nGroups;
         g.nGroups = (g.ncx + g.groupCells - 1) / g.groupCells;
@@ -438,6 +450,12 @@ static int ensureBuffers(orbx_extractor *ex)
         const OrbxLevelGeom &g = ex->geom[l];
         if (l > 0 && (rc = ex->d_raw[l].ensure(B * g.frameStride + 64)) != ORBX_OK) return rc;
         if ((rc = ex->d_blur[l].ensure(B * (size_t)blurFrameBytes(g) + 64)) != ORBX_OK) return rc;
+    }
+    {   // quadtree node arrays in global memory for level quotas beyond LDS (list capacity > ~3500 nodes): sized for the worst launch
+        size_t need = 0;
+        for (int l0 = 0; l0 < nl; ++l0)
+            for (int run = 1; l0 + run <= nl; ++run) need = std::max(need, orbxQuadtreeScratchBytes((int)B, ex->geom.data(), l0, run));
+        if (need && (rc = ex->d_qtNodes.ensure(need)) != ORBX_OK) return rc;
     }
     ex->inPitch = ex->geom[0].pitch;
     ex->inFrameStride = (long long)ex->inPitch * ex->geom[0].h;  // rows of consecutive frames are contiguous: one bulk H2D copy per batch
@@ -595,7 +613,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
                                            ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
                                            ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
                                            ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
-                                           ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, l, 1));
+                                           ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, l, 1, ex->d_qtNodes.p, ex->d_qtNodes.n));
             }
             if (l + 1 < nl && earlyBlur) {
                 // level l + 1 now exists: its GaussianBlur may start on the blur stream while the front stream goes on
@@ -633,7 +651,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
                                            ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
                                            ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
                                            ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
-                                           ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, l0, std::min(step, nl - l0)));
+                                           ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, l0, std::min(step, nl - l0), ex->d_qtNodes.p, ex->d_qtNodes.n));
         }
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2 + 1], sBack));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 3) * 2], sBack));

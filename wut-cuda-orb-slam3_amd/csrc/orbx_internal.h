@@ -84,7 +84,9 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
 hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const OrbxLevelGeom *geomsHost,
                               const OrbxLevelGeom *geomsDev, const uint32_t *cand, long long candFrameStride,
                               const int *tileCount, int tilesPerFrame, uint32_t *scratchA, uint32_t *scratchB,
-                              uint32_t *sel, int selFrameStride, int *selCount, int maxQuota, int levelBase, int levelsRun);
+                              uint32_t *sel, int selFrameStride, int *selCount, int maxQuota, int levelBase, int levelsRun,
+                              uint8_t *nodeScratch, size_t nodeScratchBytes);
+size_t orbxQuadtreeScratchBytes(int nframes, const OrbxLevelGeom *geomsHost, int levelBase, int levelsRun);
 hipError_t orbxLaunchPack(hipStream_t st, int nframes, OrbxTables tabs, const uint32_t *sel, int selFrameStride,
                           const int *selCount, int lap0, int lap1, void *kps, int cap, uint32_t *workKey,
                           int *workPos, int *nOut, int *monoOut);

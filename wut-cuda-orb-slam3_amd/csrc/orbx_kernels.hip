@@ -1167,7 +1167,8 @@ struct QtArgs {
     int listCap;  // capacity of list-sized arrays (max quota + 8)
     int ldsKeys;  // candidates of one instance held in LDS (0: always in global scratch)
     int maxKeys;  // largest candidate set the level-synchronous kernel takes (<= QT3_MAX_KEYS; ORBX_QT_MAX_KEYS lowers it in tests)
-    int nodeBytes;  // LDS bytes of the node arrays (keys follow)
+    int nodeBytes;  // bytes of the node arrays of one instance (in LDS the keys follow)
+    uint8_t *nodeScratch;  // != nullptr: node arrays in global memory, nodeBytes per instance of this launch (quotas beyond LDS)
     int variant;  // 3: level-synchronous (default), 1: serial list walk (ORBX_QT_KERNEL; also taken for > QT3_MAX_KEYS candidates)
     int stop;     // debug (ORBX_QT_STOP): 1 return after the gather, 2 after the roots, 3 skip the sorted phase, 4 skip the sort only
 };
@@ -1319,7 +1320,7 @@ __device__ __forceinline__ int qt_flatten(QtCtx &S, int nOrder, short *dst)
     return out;
 }
 
-template <bool LDSK, class KP>
+template <bool LDSK, bool NG, class KP>
 __device__ __forceinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int f, int level, uint8_t *qlds, KP A, KP B, int M,
                         const int *tc, uint32_t *selOut, int *selCnt)
 {
@@ -1349,7 +1350,7 @@ __device__ __forceinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int 
             base += total;
         }
         if (lane == 0) tileOff[g.nTiles] = base;
-        qt_sync<true>();
+        qt_sync<!NG>();
         const uint32_t *slots = a.cand + (size_t)f * a.candFrameStride + g.candBase;
         for (int e = lane; e < M; e += WAVE) {
             int lo = 0, hi = g.nTiles;  // largest t with tileOff[t] <= e
@@ -1522,6 +1523,7 @@ struct Qt3 {
 static size_t qt3NodeBytes(int L) { return (((size_t)L * 46 + 8 + 216 * 4 + (QT3_MAX_KEYS / 32 + 2) * 4) + 15) & ~(size_t)15; }
 
 // A / B: key buffers.  With M <= QT3_KCH * 64 they are the same (LDS) buffer, larger sets ping-pong between two global ones.
+template <bool NG>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS
 __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int f, uint8_t *qlds, uint32_t *A, uint32_t *B, int M,
                          const int *tc, uint32_t *selOut, int *selCnt)
 {
@@ -1552,7 +1554,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
             base += total;
         }
         if (lane == 0) tileOff[g.nTiles] = base;
-        qt_sync<true>();
+        qt_sync<!NG>();
         const uint32_t *slots = a.cand + (size_t)f * a.candFrameStride + g.candBase;
         for (int e0 = 0; e0 < M; e0 += QT3_KCH * WAVE) {  // all slot loads of a batch are in flight together
 #pragma unroll
@@ -1650,7 +1652,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
             }
             if (lane == 0) bg[size] = (uint16_t)M;
         }
-        qt_sync<true>();
+        qt_sync<!NG>();
         // key -> (node, quadrant, lane range of the node inside its 64-key chunk)
         struct KeyInfo { uint32_t key; int p, q, lo, e0; bool act, big; unsigned long long R; };
         auto classify = [&](int base, int p, uint32_t key, uint32_t ngx, uint32_t ngy, int nb, int nc) -> KeyInfo {
@@ -1736,7 +1738,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
             for (int t = lane; t < nSorted; t += WAVE) S.proc[t] = (uint16_t)(S.V[nSorted - 1 - t] & 0xFFFF);
             nProc = nSorted;
         }
-        qt_sync<true>();
+        qt_sync<!NG>();
         // (d) prefix sums over the processing order: list size before each divide (a sorted round stops dividing once the
         //     list holds N nodes), creation index of the first child, index of the first new V entry
         int C = 0;
@@ -1770,7 +1772,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
                 C += totNe; nV += totNx; sz += totG;
             }
         }
-        qt_sync<true>();
+        qt_sync<!NG>();
         // (e) new list: children (reverse creation order) then the untouched nodes; new V in creation order.  The slots of cc
         //     now hold the list position of the child (untouched node: its own new position in slot 0), QT3_NONE where there is none.
         int nKeep = 0;
@@ -1818,7 +1820,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
             }
         }
         const int size2 = C + nKeep;
-        qt_sync<true>();
+        qt_sync<!NG>();
         // (f) prefix of the new counts; (g) list positions -> key offsets (write cursors)
         {
             int base = 0;
@@ -1836,7 +1838,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
                 }
             }
         }
-        qt_sync<true>();
+        qt_sync<!NG>();
         for (int pb0 = 0; pb0 < size; pb0 += 4 * WAVE) {
             uint2 c2[4];
 #pragma unroll
@@ -1854,7 +1856,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
                 if (p < size) *(uint2 *)(S.cc + 2 * p) = make_uint2(o[u][0] | (o[u][1] << 16), o[u][2] | (o[u][3] << 16));
             }
         }
-        qt_sync<true>();
+        qt_sync<!NG>();
         // (h) stable scatter of the keys to their new runs (in place when all keys are in registers)
         sweep(!inRegs, [&](const KeyInfo &k) {
             const bool div = k.act && S.aux[k.p] != ~0u;
@@ -1884,7 +1886,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
         if (sorted) {
             nSorted = nV;
             if (lane == 0 && a.stop != 4) orbx_sort::sort(S.V, nSorted, QtSizedLess(), S.sortStack);
-            qt_sync<true>();
+            qt_sync<!NG>();
         }
         pass(nSorted);
         if (size >= N || size == prevSize) finish = true;
@@ -1956,11 +1958,16 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
     if (M == 0 || M > a.maxKeys) { if (threadIdx.x == 0) *selCnt = M == 0 ? 0 : QT_DEFERRED; return; }
     uint32_t *gA = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
     uint32_t *gB = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
+    const bool inRegs = M <= QT3_KCH * WAVE;
+    if (a.nodeScratch) {  // list capacity beyond LDS: node arrays (and keys) in global memory
+        uint8_t *nodes = a.nodeScratch + ((size_t)f * a.levelsRun + (level - a.levelBase)) * (size_t)a.nodeBytes;
+        qt3_body<true>(a, g, f, nodes, gA, inRegs ? gA : gB, M, tc, selOut, selCnt);
+        return;
+    }
     // all keys in registers for a pass + one LDS buffer behind the node arrays; larger sets ping-pong in global scratch
     uint32_t *lK = (uint32_t *)(qlds + a.nodeBytes);
-    const bool inRegs = M <= QT3_KCH * WAVE;
     uint32_t *kA = inRegs && M <= a.ldsKeys ? lK : gA;
-    qt3_body(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
+    qt3_body<false>(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
 }
 
 // serial formulation (one DivideNode at a time): every instance (a.variant == 1, A/B runs) or only those the kernel above
@@ -1981,14 +1988,38 @@ __global__ __launch_bounds__(64) void k_quadtree_serial(QtArgs)
     if (M == 0) { if (threadIdx.x == 0) *selCnt = 0; return; }
     uint32_t *gA = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
     uint32_t *gB = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
-    if (M <= a.ldsKeys) qt_body<true>(a, g, f, level, qlds, (uint32_t *)(qlds + a.nodeBytes), gB, M, tc, selOut, selCnt);
-    else qt_body<false>(a, g, f, level, qlds, gA, gB, M, tc, selOut, selCnt);
+    if (a.nodeScratch) {
+        uint8_t *nodes = a.nodeScratch + ((size_t)f * a.levelsRun + (level - a.levelBase)) * (size_t)a.nodeBytes;
+        qt_body<false, true>(a, g, f, level, nodes, gA, gB, M, tc, selOut, selCnt);
+    } else if (M <= a.ldsKeys) qt_body<true, false>(a, g, f, level, qlds, (uint32_t *)(qlds + a.nodeBytes), gB, M, tc, selOut, selCnt);
+    else qt_body<false, false>(a, g, f, level, qlds, gA, gB, M, tc, selOut, selCnt);
+}
+
+// Global scratch the quadtree launch of levels [levelBase, levelBase + levelsRun) needs for its node arrays: 0 while they fit in
+// LDS (list capacity up to ~3500 nodes), else the per-instance bytes of the larger of the two kernels x instances.
+size_t orbxQuadtreeScratchBytes(int nframes, const OrbxLevelGeom *geomsHost, int levelBase, int levelsRun)
+{
+    int maxRoots = 1, maxTiles = 1, maxQuota = 0;
+    for (int l = levelBase; l < levelBase + levelsRun; ++l) {
+        const OrbxLevelGeom &g = geomsHost[l];
+        maxQuota = std::max(maxQuota, g.quota);
+        const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
+        maxRoots = std::max(maxRoots, (int)roundf((float)W / (float)H));
+        maxTiles = std::max(maxTiles, g.nTiles);
+    }
+    const int listCap = (std::max(maxQuota + 16, 4 * maxRoots + 8) + 3) & ~3;
+    const int pool = (2 * maxQuota + 64 + 4 * maxRoots + 3) & ~3;
+    const size_t tileOffBytes = (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15;
+    const size_t nb = std::max(std::max(qt3NodeBytes(listCap), qtNodeBytes(pool, listCap)), tileOffBytes);
+    if (nb + (size_t)QT_LDS_KEYS * sizeof(uint32_t) <= 160 * 1024) return 0;
+    return nb * (size_t)nframes * (size_t)levelsRun;
 }
 
 hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const OrbxLevelGeom *geomsHost,
                               const OrbxLevelGeom *geomsDev, const uint32_t *cand, long long candFrameStride,
                               const int *tileCount, int tilesPerFrame, uint32_t *scratchA, uint32_t *scratchB,
-                              uint32_t *sel, int selFrameStride, int *selCount, int maxQuota, int levelBase, int levelsRun)
+                              uint32_t *sel, int selFrameStride, int *selCount, int maxQuota, int levelBase, int levelsRun,
+                              uint8_t *nodeScratch, size_t nodeScratchBytes)
 {
     QtArgs a;
     a.geoms = geomsDev;
@@ -2026,12 +2057,18 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
         (void)hipFuncSetAttribute((const void *)k_quadtree_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
     }
-    const size_t tileOffBytes = (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15;  // both kernels stage the tile prefix in LDS first
+    const size_t tileOffBytes = (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15;  // both kernels stage the tile prefix in the node area first
     const dim3 grid(xcd_grid(nframes, levelsRun));
+    const size_t ldsMax = 160 * 1024;
     if (a.variant == 3) {
         a.nodeBytes = (int)std::max(qt3NodeBytes(a.listCap), tileOffBytes);
-        const size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
-        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
+        a.nodeScratch = nullptr;
+        if (lds > ldsMax) {  // quota too large for LDS: node arrays in the caller's scratch
+            if (!nodeScratch || nodeScratchBytes < (size_t)a.nodeBytes * nframes * levelsRun) return hipErrorInvalidValue;
+            a.nodeScratch = nodeScratch;
+            lds = 0;
+        }
         if (getenv("ORBX_DEBUG")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
@@ -2041,8 +2078,13 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     }
     {   // candidate sets beyond QT3_MAX_KEYS (deferred above; large images), or everything in the A/B variant
         a.nodeBytes = (int)std::max(qtNodeBytes(a.pool, a.listCap), tileOffBytes);
-        const size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
-        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
+        a.nodeScratch = nullptr;
+        if (lds > ldsMax) {
+            if (!nodeScratch || nodeScratchBytes < (size_t)a.nodeBytes * nframes * levelsRun) return hipErrorInvalidValue;
+            a.nodeScratch = nodeScratch;
+            lds = 0;
+        }
         hipLaunchKernelGGL(k_quadtree_serial, grid, dim3(64), lds, st, a);
     }
     return hipGetLastError();
