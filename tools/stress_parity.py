@@ -15,8 +15,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # skip the cases before this one (same random stream)
 bad = 0
 for case in range(n_cases):
-    w = int(rng.integers(120, 1400))
-    h = int(rng.integers(100, 1000))
+    w = int(rng.integers(120, 2000))
+    h = int(rng.integers(100, 1300))
     nlev = int(rng.integers(1, 9))
     scale = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
     while min(w, h) / scale ** (nlev - 1) < 70:  # every level must hold one 35-px FAST cell + borders
@@ -39,13 +39,32 @@ for case in range(n_cases):
     if case < first:
         continue
     print(f"case {case}: {w}x{h} nf={nf} levels={nlev} scale={scale} th={ini}/{mn} kind={kind} lap={lap}", end=" ", flush=True)
+    bv, am = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    nb = int(rng.integers(1, 4))
+    pad_w, pad_h = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+    # which of the extra dimensions to exercise.  "am" (angle_mode 1 = libm atan2f like the fork's OpenCL kernel) is off by default:
+    # the device and the host atan2f are different implementations and differ in the last bits - only fastAtan2 is bit-pinned
+    dims = os.environ.get("STRESS_DIMS", "bv,nb,pad").split(",")
+    bv = bv if "bv" in dims else 0
+    am = am if "am" in dims else 0
+    nb = nb if "nb" in dims else 1
+    pad_w, pad_h = (pad_w, pad_h) if "pad" in dims else (0, 0)
     try:
-        ex = pkg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w, max_height=h)
-        mono, kps, desc = ex(img, None, lap)
-        rmono, rk, rd = orc.Oracle(nf, scale, nlev, ini, mn).extract(img, lap)
-        ok = mono == rmono and len(kps) == len(rk) and np.array_equal(kps.view(np.uint8), rk.view(np.uint8)) and np.array_equal(desc, rd)
+        ex = pkg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w + pad_w, max_height=h + pad_h,
+                              max_batch=nb, blur_variant=bv, angle_mode=am)
+        imgs = np.stack([img] + [np.roll(img, 17 * (i + 1), axis=1) for i in range(nb - 1)])
+        n, mono, kps, desc = ex.extract_batch(imgs, lap)
+        ok = True
+        ref = orc.Oracle(nf, scale, nlev, ini, mn, blur_variant=bv, angle_mode=am)
+        for i in range(nb):
+            rmono, rk, rd = ref.extract(imgs[i], lap)
+            ok = ok and mono[i] == rmono and n[i] == len(rk) and np.array_equal(kps[i][: n[i]].view(np.uint8), rk.view(np.uint8)) \
+                and np.array_equal(desc[i][: n[i]], rd)
         ex.close()
     except Exception as e:  # noqa: BLE001
+        if "aspect ratio below 0.5" in str(e):  # a small level became too narrow: undefined behaviour in the reference, rejected here
+            print("skipped (portrait level)", flush=True)
+            continue
         ok = False
         print("   exception:", e)
     print(f"n={len(rk) if ok else '?'} {'ok' if ok else 'MISMATCH'}", flush=True)
