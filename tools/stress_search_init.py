@@ -1,0 +1,49 @@
+"""Randomised parity sweep of SearchForInitialization / AssignFeaturesToGrid against the oracle (development tool).
+Usage: python tools/stress_search_init.py [n] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g  # noqa: E402
+
+pkg = g.load_package()
+orc = g.load_oracle()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+m = pkg.ORBmatcher(8192, 8192)
+bad = 0
+for case in range(n_cases):
+    w, h = int(rng.integers(200, 1300)), int(rng.integers(200, 900))
+    if (w - 32) / (h - 32) < 0.6:
+        h = w
+    nf = int(rng.integers(200, 7000))
+    nlev = int(rng.integers(1, 7))
+    while min(w, h) / 1.2 ** (nlev - 1) < 80:
+        nlev -= 1
+    ex = pkg.ORBextractor(nf, 1.2, nlev, 20, 7, max_width=w, max_height=h)
+    img1 = pkg.synth_frame(int(rng.integers(0, 1 << 30)), w, h)
+    dx, dy = int(rng.integers(-30, 31)), int(rng.integers(-30, 31))
+    img2 = np.clip(np.roll(np.roll(img1, dy, 0), dx, 1).astype(np.int16) + rng.integers(-4, 5, img1.shape), 0, 255).astype(np.uint8)
+    _, k1, d1 = ex(img1, None, (0, 0)); k1, d1 = k1.copy(), d1.copy()
+    _, k2, d2 = ex(img2, None, (0, 0)); k2, d2 = k2.copy(), d2.copy()
+    ex.close()
+    if rng.random() < 0.3:  # duplicated descriptors: ties
+        d2[rng.integers(0, len(d2), len(d2) // 3)] = d2[rng.integers(0, len(d2), len(d2) // 3)]
+    bounds = (float(rng.uniform(-20, 5)), float(w + rng.uniform(-5, 20)), float(rng.uniform(-20, 5)), float(h + rng.uniform(-5, 20)))
+    window = int(rng.choice([5, 10, 30, 100, 250]))
+    ratio = float(rng.choice([0.6, 0.75, 0.9, 1.0]))
+    check = bool(rng.integers(0, 2))
+    prev = np.stack([k1["x"], k1["y"]], 1) + rng.uniform(-8, 8, (len(k1), 2)).astype(np.float32)
+    n, m12, pv = m.SearchForInitialization(k1, d1, k2, d2, prev, bounds, window, ratio, check)
+    rn, rm12, rpv = orc.search_for_initialization(k1, d1, k2, d2, prev, bounds, window, ratio, check)
+    cs, it = m.AssignFeaturesToGrid(k2, bounds)
+    rcs, rit = orc.assign_grid(k2, bounds)
+    ok = n == rn and np.array_equal(m12, rm12) and np.array_equal(pv.view(np.uint32), rpv.view(np.uint32)) and np.array_equal(cs, rcs) \
+        and np.array_equal(it, rit)
+    print(f"case {case}: {w}x{h} nf={nf} levels={nlev} n1={len(k1)} n2={len(k2)} window={window} ratio={ratio} check={check} matches={rn} "
+          f"{'ok' if ok else 'MISMATCH'}", flush=True)
+    bad += not ok
+print("ALL OK" if bad == 0 else f"{bad} MISMATCHES")
+sys.exit(1 if bad else 0)
