@@ -1019,84 +1019,6 @@ __global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
     }
 }
 
-// LDS-free variant: every wave gathers its 8-byte window pieces straight from global memory (aligned to 4 bytes)
-__global__ __launch_bounds__(256) void k_blur3d(BlurArgs a)
-{
-    int f, unit;
-    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, unit)) return;
-    const int sgx = unit % a.tilesX, seg = unit / a.tilesX;
-    const int lane = threadIdx.x & 63;
-    const int x0 = (sgx * 4 + (int)(threadIdx.x >> 6)) * 16;  // wave-uniform; the kernel has no barrier
-    if (x0 >= a.w) return;
-    const int n = lane & 15, g = lane >> 4;
-    const int nBlk = (a.h + 15) >> 4;
-    const int b0 = seg * BL3_SEG, b1 = min(b0 + BL3_SEG, nBlk);
-    unsigned long T64 = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) T64 |= (unsigned long)(unsigned)a.taps[k] << (8 * k);
-    auto tapWin = [&](int k0) -> uint32_t {  // bytes tap[k0 .. k0 + 3], zero outside 0 .. 6
-        const int sh = 8 * k0;
-        const unsigned long v = sh >= 0 ? T64 >> min(sh, 63) : T64 << min(-sh, 63);
-        return (sh >= 64 || sh <= -32) ? 0u : (uint32_t)v;
-    };
-    // tap matrices.  K slot (g, jj) of the horizontal product is window column 8g + jj (image column x0 - 4 + 8g + jj), tap
-    // 8g + jj - n - 1 for output column n; of the vertical product it is row 4g + jj of the previous chunk (jj < 4), tap
-    // 4g + jj - n for output row n, or row 4g + jj - 4 of this one, tap 16 + 4g + jj - 4 - n.
-    const bool biasLane = g == 3;
-    const uint32_t bh0 = biasLane ? BL3_BIAS_B : tapWin(8 * g - n - 1), bh1 = biasLane ? 0u : tapWin(8 * g + 4 - n - 1);
-    const uint32_t bv0 = tapWin(4 * g - n), bv1 = biasLane ? BL3_BIAS_B : tapWin(16 + 4 * g - n);
-    const long Bh = (long)(((unsigned long)bh1 << 32) | bh0), Bv = (long)(((unsigned long)bv1 << 32) | bv0);
-    const bool fast = a.srcAligned && x0 >= 4 && x0 + 28 <= a.w;
-    const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
-    uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
-    auto loadA = [&](int c) -> uint2 {  // rows 16c - 3 + (lane & 15) of the REFLECT_101-extended image, pixels - 128
-        if (biasLane) return make_uint2(a.biasH, 0);
-        const uint8_t *row = srcF + (size_t)bl3_reflect(16 * c - 3 + n, a.h) * a.srcPitch;
-        uint2 v;
-        if (fast) v = *(const uint2 *)(row + x0 - 4 + 8 * g);
-        else {
-            uint32_t t[2] = {0, 0};
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) t[jj >> 2] |= (uint32_t)row[bl3_reflect(x0 - 4 + 8 * g + jj, a.w)] << (8 * (jj & 3));
-            v = make_uint2(t[0], t[1]);
-        }
-        return make_uint2(v.x ^ 0x80808080u, v.y ^ 0x80808080u);
-    };
-    const bl3_v4i zero = {0, 0, 0, 0};
-    const int xo = x0 + 4 * g;
-    // all source rows of the segment are requested up front (18 VGPRs): one memory latency per wave, not one per chunk
-    uint2 aBuf[BL3_SEG + 1];
-#pragma unroll
-    for (int i = 0; i <= BL3_SEG; ++i) aBuf[i] = b0 + i <= b1 ? loadA(b0 + i) : make_uint2(0, 0);
-    uint32_t loPrev = 0, hiPrev = 0;
-#pragma unroll
-    for (int i = 0; i <= BL3_SEG; ++i) {
-        const int c = b0 + i;
-        if (c > b1) break;  // wave-uniform
-        const long A = (long)(((unsigned long)aBuf[i].y << 32) | aBuf[i].x);
-        const bl3_v4i H = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bh, zero, 0, 0, 0);  // exact row sums, 0 .. 255 * S <= 65535
-        const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)H[1], (uint32_t)H[0], 0x05010400u);
-        const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)H[3], (uint32_t)H[2], 0x05010400u);
-        const uint32_t lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;  // low bytes of rows 4g .. 4g + 3, - 128
-        const uint32_t hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u;  // high bytes, - 128
-        if (i > 0) {
-            const long Alo = (long)(((unsigned long)(biasLane ? a.biasL : lo) << 32) | loPrev);
-            const long Ahi = (long)(((unsigned long)(biasLane ? a.biasHi : hi) << 32) | hiPrev);
-            const bl3_v4i Dl = __builtin_amdgcn_mfma_i32_16x16x32_i8(Alo, Bv, zero, 0, 0, 0);
-            const bl3_v4i Dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(Ahi, Bv, zero, 0, 0, 0);  // includes the rounding term >> 8
-            const int y = 16 * (c - 1) + n;
-            if (y < a.h && xo < a.w) {
-                uint32_t packed = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);
-                *(uint32_t *)(dstF + orbx_blur_tiled_offset(xo, y, a.dstPitch)) = packed;  // (a tile row holds all 4 pixels)
-            }
-        }
-        loPrev = lo; hiPrev = hi;
-    }
-}
-
 hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8_t *src, int srcPitch,
                           long long srcFrameStride, uint8_t *dst, int dstPitch, long long dstFrameStride,
                           const int taps[7])
@@ -1121,11 +1043,7 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
         a.biasHi = bl3_bias_bytes(128 * S + 128);  // high byte plane - 128, + 32768 >> 8 for the final rounding
         static const int nw = [] { const char *e = getenv("ORBX_BLUR_WAVES"); return e ? atoi(e) : 4; }();
         a.nframes = nframes; a.tilesY = ((h + 15) / 16 + BL3_SEG - 1) / BL3_SEG;
-        if (nw == 0) {
-            a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 3) == 0;
-            a.tilesX = (w + 63) / 64;
-            hipLaunchKernelGGL(k_blur3d, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
-        } else if (nw == 8) {
+        if (nw == 8) {
             a.tilesX = (w + 127) / 128;
             hipLaunchKernelGGL(k_blur3<8>, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(512), 0, st, a);
         } else {
