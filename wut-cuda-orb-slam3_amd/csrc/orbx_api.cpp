@@ -315,8 +315,9 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         g.ncx = std::min(nCols, (iw + g.wCell - 1) / g.wCell);
         g.ncy = std::min(nRows, (ih + g.hCell - 1) / g.hCell);
         static const int tileW = [] { const char *e = getenv("ORBX_TILE_W"); return e ? atoi(e) : 288; }();  // target interior width of a tile
-        // cells are 35 .. 69 px high (height / nRows): keep the tile area - and with it the LDS footprint - about constant
-        const int tileWl = std::max(g.wCell, tileW * 35 / std::max(g.hCell, 35));
+        // cells are 35 .. 69 px high (height / nRows): beyond the usual 35 .. 40 rows keep the tile area - and with it the LDS
+        // footprint - about constant
+        const int tileWl = std::max(g.wCell, tileW * 40 / std::max(g.hCell, 40));
         int gmax = std::max(1, tileWl / g.wCell);
         g.nGroups = (g.ncx + gmax - 1) / gmax;
         g.groupCells = (g.ncx + g.nGroups - 1) / g.nGroups;
