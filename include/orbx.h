@@ -228,6 +228,34 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, con
                                    const uint8_t *d2, int n2, float min_x, float max_x, float min_y, float max_y, float *prev_matched,
                                    int32_t *matches12, int window_size, float nnratio, int check_orientation);
 
+/* One projected map point of the last frame, as ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, ..)
+ * has it after `x3Dc = Tcw * x3Dw; invzc = 1.0 / x3Dc(2); uv = mpCamera->project(x3Dc)` (reference src/ORBmatcher3.cc:283-296). */
+typedef struct {
+    float u, v, invz; /* uv(0), uv(1), invzc */
+    float angle;      /* kpLF.angle: LastFrame.mvKeysUn[i].angle (:345) */
+    int32_t octave;   /* nLastOctave: LastFrame.mvKeys[i].octave (:303) */
+    int32_t flags;    /* bit 0: LastFrame.mvpMapPoints[i] != NULL && !LastFrame.mvbOutlier[i] (:277-280);
+                         bit 1: that map point has Observations() > 0 (decides whether it blocks later points, :325-327) */
+} orbx_projection;
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) — reference
+ * src/ORBmatcher3.cc:256-467 (decl include/ORBmatcher.h:54), the CurrentFrame.Nleft == -1 branch (monocular / rectified stereo),
+ * called every frame by Tracking::TrackWithMotionModel (src/Tracking4.cc:210,218).  The pose / camera arithmetic of the loop head
+ * (Sophus `Tcw * x3Dw`, GeometricCamera::project) stays with the caller, who passes the projections; the library does the bounds
+ * tests (invzc < 0, uv outside mnMinX .. mnMaxY), the window search radius = th * scale_factors[octave] with
+ * Frame::GetFeaturesInArea (forward: levels >= octave, backward: <= octave, else octave - 1 .. octave + 1), the mvuRight
+ * consistency test, DescriptorDistance against proj_desc[i] (MapPoint::GetDescriptor), TH_HIGH = 100, and the rotation histogram.
+ *   kc / dc / nc        CurrentFrame.mvKeysUn / mDescriptors / N;  u_right = CurrentFrame.mvuRight or NULL (monocular)
+ *   cur_state[nc]       CurrentFrame.mvpMapPoints before the call: -1 NULL, 0 a point with Observations() == 0, 1 with > 0
+ *   forward / backward  bForward / bBackward (:271-272): tlc(2) > mb && !bMono, -tlc(2) > mb && !bMono
+ *   assign[nc]          what the call did to CurrentFrame.mvpMapPoints[i2]: -1 untouched, j >= 0 now LastFrame.mvpMapPoints[j],
+ *                       -2 set to NULL by the rotation-consistency check (:447-463)
+ * Returns nmatches (>= 0) or a negative status.  At most 512 window candidates per projected point. */
+int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, const float *u_right, const int8_t *cur_state,
+                              int nc, float min_x, float max_x, float min_y, float max_y, const float *scale_factors, int nlevels,
+                              float mbf, const orbx_projection *proj, const uint8_t *proj_desc, int np, float th, int forward,
+                              int backward, int check_orientation, int32_t *assign);
+
 /* Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011: the row-band Hamming
  * stage above, then for every accepted left keypoint the 11x11 L1 sliding-window refinement (+-5 px) on
  * mvImagePyramid[octave] of the left / right extractor (the device-resident pyramids of frame `frame_left` /

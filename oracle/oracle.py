@@ -61,6 +61,8 @@ def lib() -> ctypes.CDLL:
                                               c_void_p, c_int]
         L.oracle_search_for_initialization.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
                                                        c_float, c_void_p, c_void_p, c_int, c_float, c_int]
+        L.oracle_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p,
+                                                  c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -258,3 +260,24 @@ def search_for_initialization(k1, d1, k2, d2, prev_matched, bounds, window_size=
                                                *[float(b) for b in bounds], prev.ctypes.data, m12.ctypes.data, int(window_size),
                                                float(nnratio), int(bool(check_orientation)))
     return n, m12, prev
+
+
+PROJECTION_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("invz", "<f4"), ("angle", "<f4"), ("octave", "<i4"), ("flags", "<i4")])
+
+
+def search_by_projection(kc, dc, cur_state, bounds, scale_factors, proj, proj_desc, th, u_right=None, mbf=0.0, forward=False,
+                         backward=False, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference src/ORBmatcher3.cc:256-467, Nleft == -1)
+    -> (nmatches, assign)."""
+    kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+    dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+    st = np.ascontiguousarray(cur_state, np.int8)
+    pr = np.ascontiguousarray(proj, PROJECTION_DTYPE)
+    pd = np.ascontiguousarray(proj_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    assign = np.full(len(kc), -1, np.int32)
+    n = lib().oracle_search_by_projection(kc.ctypes.data, dc.ctypes.data, None if ur is None else ur.ctypes.data, st.ctypes.data, len(kc),
+                                          *[float(b) for b in bounds], sf.ctypes.data, len(sf), float(mbf), pr.ctypes.data, pd.ctypes.data,
+                                          len(pr), float(th), int(forward), int(backward), int(bool(check_orientation)), assign.ctypes.data)
+    return n, assign

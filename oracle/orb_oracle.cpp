@@ -1124,6 +1124,79 @@ int oracle_search_for_initialization(const oracle_keypoint *k1, const uint8_t *d
     return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) — reference
+// src/ORBmatcher3.cc:256-467, branch CurrentFrame.Nleft == -1 (monocular / rectified stereo).  The pose and camera arithmetic
+// that precedes the search in the reference loop (x3Dc = Tcw * x3Dw with Sophus, mpCamera->project) stays with the caller: a
+// projection carries (u, v, invzc), the octave and angle of the last frame's keypoint, MapPoint::GetDescriptor() and two flags
+// (bit 0: the keypoint has a map point and is not an outlier; bit 1: that map point has Observations() > 0).
+// cur_state[nc] = CurrentFrame.mvpMapPoints before the call: -1 none, 0 a map point with no observations, 1 with observations.
+// assign[nc] receives what the call did to CurrentFrame.mvpMapPoints[i2]: -1 untouched, j >= 0 = the map point of last-frame
+// keypoint j, -2 set to NULL by the rotation check.  Returns nmatches.
+int oracle_search_by_projection(const oracle_keypoint *kc, const uint8_t *dc, const float *u_right, const int8_t *cur_state, int nc,
+                                float minX, float maxX, float minY, float maxY, const float *scale_factors, int nlevels, float mbf,
+                                const oracle_projection *proj, const uint8_t *dproj, int np, float th, int forward, int backward,
+                                int check_orientation, int32_t *assign)
+{
+    (void)nlevels;
+    const int TH_HIGH = 100, HISTO_LENGTH = 30;  // src/ORBmatcher1.cc:37-39
+    const FrameGrid G = assignFeaturesToGrid(kc, nc, minX, maxX, minY, maxY);
+    std::vector<int> mp(nc), obs(nc);  // mvpMapPoints: -1 none, -2 NULLed, -3 the pre-existing one, j the last-frame index; its Observations() > 0
+    for (int i = 0; i < nc; ++i) { mp[i] = cur_state[i] < 0 ? -1 : -3; obs[i] = cur_state[i] > 0; assign[i] = -1; }
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < np; i++) {
+        const oracle_projection &P = proj[i];
+        if (!(P.flags & 1)) continue;  // pMP && !mvbOutlier[i]
+        const float invzc = P.invz;
+        if (invzc < 0) continue;
+        if (P.u < minX || P.u > maxX) continue;
+        if (P.v < minY || P.v > maxY) continue;
+        const int nLastOctave = P.octave;
+        const float radius = th * scale_factors[nLastOctave];
+        std::vector<size_t> vIndices2;
+        if (forward) vIndices2 = getFeaturesInArea(G, kc, P.u, P.v, radius, nLastOctave, -1);
+        else if (backward) vIndices2 = getFeaturesInArea(G, kc, P.u, P.v, radius, 0, nLastOctave);
+        else vIndices2 = getFeaturesInArea(G, kc, P.u, P.v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t *dMP = dproj + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t v = 0; v < vIndices2.size(); ++v) {
+            const size_t i2 = vIndices2[v];
+            if (mp[i2] != -1 && mp[i2] != -2)
+                if (obs[i2]) continue;
+            if (u_right && u_right[i2] > 0) {
+                const float ur = P.u - mbf * invzc;
+                const float er = std::fabs(ur - u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = oracle_hamming256(dMP, dc + i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            mp[bestIdx2] = i; obs[bestIdx2] = (P.flags >> 1) & 1;
+            nmatches++;
+            if (check_orientation) {
+                float rot = P.angle - kc[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[30];
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = (int)rotHist[i].size();
+        computeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { mp[rotHist[i][j]] = -2; nmatches--; }
+    }
+    for (int i = 0; i < nc; ++i) assign[i] = mp[i] == -3 ? -1 : mp[i];
+    return nmatches;
+}
+
 }  // extern "C"
 
 extern "C" {

@@ -109,6 +109,21 @@ int oracle_search_for_initialization(const oracle_keypoint *k1, const uint8_t *d
                                      int n2, float min_x, float max_x, float min_y, float max_y, float *prev_matched, int32_t *matches12,
                                      int window_size, float nnratio, int check_orientation);
 
+/* One projected map point of the last frame, as ORBmatcher::SearchByProjection(Frame&, const Frame&, ..) consumes it after
+ * `x3Dc = Tcw * x3Dw; uv = mpCamera->project(x3Dc)` (reference src/ORBmatcher3.cc:283-296): same layout as orbx_projection. */
+typedef struct {
+    float u, v, invz;  /* projection and 1 / depth in the current camera */
+    float angle;       /* angle of the last frame's keypoint (kpLF.angle) */
+    int32_t octave;    /* nLastOctave */
+    int32_t flags;     /* bit 0: map point present and not an outlier; bit 1: its Observations() > 0 */
+} oracle_projection;
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (src/ORBmatcher3.cc:256-467), the
+ * CurrentFrame.Nleft == -1 branch; see orb_oracle.cpp for the argument contract.  Returns nmatches. */
+int oracle_search_by_projection(const oracle_keypoint *kc, const uint8_t *dc, const float *u_right, const int8_t *cur_state, int nc,
+                                float min_x, float max_x, float min_y, float max_y, const float *scale_factors, int nlevels, float mbf,
+                                const oracle_projection *proj, const uint8_t *dproj, int np, float th, int forward, int backward,
+                                int check_orientation, int32_t *assign);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

@@ -205,3 +205,39 @@ def test_search_for_initialization_properties(orc):
     assert (k["octave"][hit] == 0).all() and (k2["octave"][m12[hit]] == 0).all()
     assert np.array_equal(pv[hit], np.stack([k2["x"][m12[hit]], k2["y"][m12[hit]]], axis=1))
     assert (np.abs(k2["x"][m12[hit]] - prev[hit, 0]) < 100).all() and (np.abs(k2["y"][m12[hit]] - prev[hit, 1]) < 100).all()
+
+
+def test_search_by_projection_properties(orc):
+    """ORBmatcher::SearchByProjection(Frame, Frame) restated in the oracle (reference src/ORBmatcher3.cc:256-467): projecting a
+    frame's own keypoints with their own descriptors matches every valid point to itself; a second copy of each projection is
+    blocked exactly when the first taker has observations; pre-occupied keypoints with observations are never taken."""
+    o = orc.Oracle(800, 1.2, 8, 20, 7)
+    _, k, d = o.extract(orc.synth_frame(0x4F524230 + 9, 640, 480), (0, 0))
+    sf = o.tables()["scale"]
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    n = len(k)
+    pr = np.zeros(n, orc.PROJECTION_DTYPE)
+    pr["u"], pr["v"], pr["invz"], pr["angle"], pr["octave"], pr["flags"] = k["x"], k["y"], 0.5, k["angle"], k["octave"], 3
+    free = np.full(n, -1, np.int8)
+    nm, assign = orc.search_by_projection(k, d, free, bounds, sf, pr, d, 2.0, check_orientation=False)
+    assert nm == n and np.array_equal(assign, np.arange(n))
+    # invalid / behind the camera / outside the image are skipped
+    pr2 = pr.copy()
+    pr2["flags"][0::4] = 0
+    pr2["invz"][1::4] = -0.1
+    pr2["u"][2::4] = 700.0
+    nm, assign = orc.search_by_projection(k, d, free, bounds, sf, pr2, d, 2.0, check_orientation=False)
+    assert nm == len(range(3, n, 4)) and (assign[3::4] == np.arange(n)[3::4]).all() and (np.delete(assign, np.s_[3::4]) == -1).all()
+    # every projection twice: the copy is blocked iff the first taker has observations (bit 1); without, it overwrites (and counts)
+    pr3 = np.concatenate([pr, pr])
+    pr3["flags"][:n] = np.where(np.arange(n) % 2 == 0, 3, 1)
+    nm, assign = orc.search_by_projection(k, d, free, bounds, sf, pr3, np.concatenate([d, d]), 0.5, check_orientation=False)
+    even = np.arange(n) % 2 == 0
+    lone = np.array([np.sum((np.abs(k["x"] - k["x"][i]) < 0.5 * sf[k["octave"][i]]) & (np.abs(k["y"] - k["y"][i]) < 0.5 * sf[k["octave"][i]])) == 1
+                     for i in range(n)])  # keypoints whose window holds no other keypoint
+    assert (assign[lone & even] == np.arange(n)[lone & even]).all()          # blocked copy: the first taker stays
+    assert (assign[lone & ~even] == (np.arange(n) + n)[lone & ~even]).all()  # unobserved first taker: the copy overwrites
+    # keypoints that already hold an observed map point are never taken
+    busy = np.full(n, 1, np.int8)
+    nm, assign = orc.search_by_projection(k, d, busy, bounds, sf, pr, d, 15.0)
+    assert nm == 0 and (assign == -1).all()

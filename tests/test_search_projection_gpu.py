@@ -1,0 +1,90 @@
+"""GPU parity of ORBmatcher::SearchByProjection(Frame, Frame) against the CPU oracle: bit-exact nmatches and
+the resulting CurrentFrame.mvpMapPoints assignment.  Inputs mimic Tracking::TrackWithMotionModel (src/Tracking4.cc:190-218): the
+last frame's keypoints carry map points, their projections into the current frame are the keypoint positions moved by the image
+motion plus a prediction error; th = 15 (monocular) or 7 (stereo)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BOUNDS = (0.0, 640.0, 0.0, 480.0)
+
+
+def _frames(pkg, seed, dx, dy):
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
+    img1 = pkg.synth_frame(seed, 640, 480)
+    rng = np.random.default_rng(seed)
+    img2 = np.clip(np.roll(np.roll(img1, dy, axis=0), dx, axis=1).astype(np.int16) + rng.integers(-3, 4, img1.shape, dtype=np.int16), 0, 255)
+    _, k1, d1 = ex(img1, None, (0, 0)); k1, d1 = k1.copy(), d1.copy()
+    _, k2, d2 = ex(img2.astype(np.uint8), None, (0, 0)); k2, d2 = k2.copy(), d2.copy()
+    sf = ex.GetScaleFactors().copy()
+    ex.close()
+    return k1, d1, k2, d2, sf, rng
+
+
+def _projections(pkg, k1, rng, dx, dy, p_mp=0.7, p_obs=0.8, noise=3.0):
+    pr = np.zeros(len(k1), pkg.PROJECTION_DTYPE)
+    pr["u"] = k1["x"] + dx + rng.normal(0, noise, len(k1)).astype(np.float32)
+    pr["v"] = k1["y"] + dy + rng.normal(0, noise, len(k1)).astype(np.float32)
+    pr["invz"] = (1.0 / rng.uniform(0.5, 20.0, len(k1))).astype(np.float32)
+    pr["invz"][rng.random(len(k1)) < 0.02] *= -1  # behind the camera
+    pr["angle"] = k1["angle"]
+    pr["octave"] = k1["octave"]
+    has = rng.random(len(k1)) < p_mp
+    obs = rng.random(len(k1)) < p_obs
+    pr["flags"] = has.astype(np.int32) | (obs.astype(np.int32) << 1)
+    return pr
+
+
+@pytest.mark.parametrize("th,forward,backward,check,stereo", [(15, False, False, True, False), (7, False, False, True, True),
+                                                             (7, True, False, True, True), (7, False, True, False, True),
+                                                             (30, False, False, True, False), (2, False, False, True, False)])
+def test_search_by_projection(pkg, orc, th, forward, backward, check, stereo):
+    dx, dy = 6, -4
+    k1, d1, k2, d2, sf, rng = _frames(pkg, 17, dx, dy)
+    pr = _projections(pkg, k1, rng, dx, dy)
+    state = rng.choice(np.int8([-1, -1, -1, 0, 1]), len(k2))  # some current keypoints already hold map points
+    ur = None
+    mbf = 0.0
+    if stereo:
+        ur = np.where(rng.random(len(k2)) < 0.6, k2["x"] - rng.uniform(0.5, 40, len(k2)), -1).astype(np.float32)
+        mbf = 40.0
+    m = pkg.ORBmatcher(8192, 8192)
+    n, assign = m.SearchByProjection(k2, d2, state, BOUNDS, sf, pr, d1, th, u_right=ur, mbf=mbf, forward=forward, backward=backward,
+                                     checkOrientation=check)
+    rn, rassign = orc.search_by_projection(k2, d2, state, BOUNDS, sf, pr, d1, th, ur, mbf, forward, backward, check)
+    assert n == rn and np.array_equal(assign, rassign)
+    if th >= 7 and not stereo:
+        assert n > 50
+    m.close()
+
+
+def test_search_by_projection_conflicts_and_edges(pkg, orc):
+    """Many projections compete for few keypoints (every projection lands on one of 40 spots): long chains of "an earlier point with
+    observations took it"; points without observations do not block and are overwritten by later takers."""
+    k1, d1, k2, d2, sf, rng = _frames(pkg, 23, 0, 0)
+    pr = _projections(pkg, k1, rng, 0, 0, p_mp=1.0, p_obs=0.5, noise=0.5)
+    spots = rng.integers(0, len(k2), 40)
+    pick = spots[rng.integers(0, 40, len(k1))]
+    pr["u"], pr["v"] = k2["x"][pick], k2["y"][pick]
+    pr["octave"] = k2["octave"][pick]
+    d1b = d2[pick].copy()
+    d1b[:, :2] ^= rng.integers(0, 256, (len(k1), 2), dtype=np.uint8)  # near-identical descriptors: distance ties and near ties
+    state = np.full(len(k2), -1, np.int8)
+    m = pkg.ORBmatcher(8192, 8192)
+    for th in (15, 40):
+        n, assign = m.SearchByProjection(k2, d2, state, BOUNDS, sf, pr, d1b, th)
+        rn, rassign = orc.search_by_projection(k2, d2, state, BOUNDS, sf, pr, d1b, th)
+        assert n == rn and np.array_equal(assign, rassign)
+    # no projections / no valid flags / empty current frame
+    n, assign = m.SearchByProjection(k2, d2, state, BOUNDS, sf, pr[:0], d1b[:0], 15)
+    assert n == 0 and (assign == -1).all()
+    pr2 = pr.copy(); pr2["flags"] = 0
+    n, assign = m.SearchByProjection(k2, d2, state, BOUNDS, sf, pr2, d1b, 15)
+    assert n == 0 and (assign == -1).all()
+    n, assign = m.SearchByProjection(k2[:0], d2[:0], state[:0], BOUNDS, sf, pr, d1b, 15)
+    assert n == 0 and len(assign) == 0
+    with pytest.raises(pkg.OrbxError, match="octave"):
+        pr3 = pr.copy(); pr3["octave"][0] = 9
+        m.SearchByProjection(k2, d2, state, BOUNDS, sf, pr3, d1b, 15)
+    m.close()

@@ -24,6 +24,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbx.so")
 
+PROJECTION_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("invz", "<f4"), ("angle", "<f4"), ("octave", "<i4"), ("flags", "<i4")])  # orbx_projection
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
 )
@@ -59,7 +60,7 @@ ABI_SYMBOLS = [
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
-    "orbx_assign_features_to_grid", "orbx_search_for_initialization",
+    "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -124,6 +125,8 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_assign_features_to_grid.argtypes = [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p]
     lib.orbx_search_for_initialization.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
                                                    c_float, c_void_p, c_void_p, c_int, c_float, c_int]
+    lib.orbx_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
+                                              c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -403,3 +406,25 @@ class ORBmatcher:
         if n < 0:
             _check(n, "orbx_search_for_initialization")
         return n, m12, prev
+
+    def SearchByProjection(self, kc, dc, cur_state, bounds, scale_factors, proj, proj_desc, th: float, *, u_right=None, mbf: float = 0.0,
+                           forward: bool = False, backward: bool = False, checkOrientation: bool = True):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (reference src/ORBmatcher3.cc:256-467, Nleft == -1) on
+        projections computed by the caller (PROJECTION_DTYPE).  Returns (nmatches, assign[nc]) with assign = -1 untouched, j >= 0 the
+        map point of last-frame keypoint j, -2 set to NULL by the rotation check."""
+        kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+        dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+        st = np.ascontiguousarray(cur_state, np.int8)
+        pr = np.ascontiguousarray(proj, PROJECTION_DTYPE)
+        pd = np.ascontiguousarray(proj_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        assert len(st) == len(kc) and len(pd) == len(pr) and (ur is None or len(ur) == len(kc))
+        assign = np.full(len(kc), -1, np.int32)
+        n = self._lib.orbx_search_by_projection(self._h, kc.ctypes.data, dc.ctypes.data, None if ur is None else ur.ctypes.data, st.ctypes.data,
+                                                len(kc), *[float(b) for b in bounds], sf.ctypes.data, len(sf), float(mbf), pr.ctypes.data,
+                                                pd.ctypes.data, len(pr), float(th), int(forward), int(backward), int(checkOrientation),
+                                                assign.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_projection")
+        return n, assign

@@ -863,6 +863,8 @@ struct orbx_matcher {
     DevBuf<int> d_grid, d_work;   // frame grid (cellStart + items + cellOf), SearchForInitialization state
     DevBuf<float> d_prev;
     DevBuf<signed char> d_bin;
+    DevBuf<uint32_t> d_sbpCand;   // SearchByProjection: candidate lists [maxQ][ORBX_SBP_CAP]
+    DevBuf<orbx_projection> d_proj;
 };
 
 extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orbx_matcher **out)
@@ -898,7 +900,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release();
     m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
-    m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release();
+    m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release(); m->d_sbpCand.release(); m->d_proj.release();
     delete m;
 }
 
@@ -1043,6 +1045,55 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     HIP_TRY(hipMemcpyAsync(&nmatches, nm, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) — reference src/ORBmatcher3.cc:256-467 (Nleft == -1).
+extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, const float *u_right,
+                                         const int8_t *cur_state, int nc, float min_x, float max_x, float min_y, float max_y,
+                                         const float *scale_factors, int nlevels, float mbf, const orbx_projection *proj,
+                                         const uint8_t *proj_desc, int np, float th, int forward, int backward, int check_orientation,
+                                         int32_t *assign)
+{
+    if (!m || nc < 0 || np < 0 || (nc > 0 && (!kc || !dc || !cur_state || !assign)) || (np > 0 && (!proj || !proj_desc)) || !scale_factors ||
+        nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(th >= 0.f))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_projection: bad argument");
+    if (np > m->maxQ || nc > m->maxT) return setError(ORBX_ERR_CAPACITY, "%d x %d exceeds the matcher capacity %d x %d", np, nc, m->maxQ, m->maxT);
+    if (nc >= 65536) return setError(ORBX_ERR_CAPACITY, "orbx_search_by_projection: at most 65535 keypoints in the current frame");
+    int rc = checkGridBounds(min_x, max_x, min_y, max_y, "orbx_search_by_projection");
+    if (rc != ORBX_OK) return rc;
+    for (int i = 0; i < np; ++i)
+        if ((proj[i].flags & 1) && (proj[i].octave < 0 || proj[i].octave >= nlevels))
+            return setError(ORBX_ERR_INVALID_ARG, "projection %d has octave %d outside [0,%d)", i, proj[i].octave, nlevels);
+    if (nc == 0) return 0;
+    static_assert(sizeof(orbx_projection) == 24, "orbx_projection layout");
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, proj_desc, np, dc, nc)) != ORBX_OK) return rc;
+    if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
+    // work: count[maxQ], choice[maxQ], owner[2 * maxT], assign[maxT], result[2], curState (maxT bytes, int-aligned)
+    const size_t workInts = 2 * (size_t)m->maxQ + 3 * (size_t)m->maxT + 2 + ((size_t)m->maxT + 3) / 4 + 4;
+    if ((rc = m->d_work.ensure(workInts)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_CAP)) != ORBX_OK) return rc;
+    if ((rc = m->d_proj.ensure((size_t)m->maxQ)) != ORBX_OK) return rc;
+    if ((rc = m->d_prev.ensure(2 * (size_t)std::max(m->maxQ, m->maxT))) != ORBX_OK) return rc;
+    int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
+    int *count = m->d_work.p, *choice = count + m->maxQ, *owner = choice + m->maxQ, *dAssign = owner + 2 * m->maxT, *result = dAssign + m->maxT;
+    signed char *dState = (signed char *)(result + 2);
+    float *dURight = u_right ? m->d_prev.p : nullptr;
+    HIP_TRY(hipMemcpyAsync(m->d_kr.p, kc, (size_t)nc * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(dState, cur_state, (size_t)nc, hipMemcpyHostToDevice, m->stream));
+    if (u_right) HIP_TRY(hipMemcpyAsync(dURight, u_right, (size_t)nc * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (np > 0) HIP_TRY(hipMemcpyAsync(m->d_proj.p, proj, (size_t)np * sizeof(orbx_projection), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, nc, min_x, max_x, min_y, max_y, cs, it, co));
+    HIP_TRY(orbxLaunchSearchByProjection(m->stream, m->d_kr.p, m->d_t.p, dURight, dState, nc, cs, it, min_x, max_x, min_y, max_y,
+                                         m->d_scale.p, mbf, m->d_proj.p, m->d_q.p, np, th, forward != 0, backward != 0,
+                                         check_orientation != 0, m->d_sbpCand.p, count, choice, owner, dAssign, result));
+    int res[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(assign, dAssign, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(res, result, sizeof res, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (res[1]) return setError(ORBX_ERR_CAPACITY, "orbx_search_by_projection: a search window holds more than %d candidates", ORBX_SBP_CAP);
+    return res[0];
 }
 
 // Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011.

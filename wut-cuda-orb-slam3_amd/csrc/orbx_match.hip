@@ -766,3 +766,210 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     }
     return hipGetLastError();
 }
+
+// =====================================================================================================
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) — reference src/ORBmatcher3.cc:256-467,
+// CurrentFrame.Nleft == -1.  The reference walks the last frame's map points in order; point i may not take a current keypoint
+// that an EARLIER accepted point with Observations() > 0 took (or that held such a map point before the call).  That is the only
+// coupling between points, so the search runs in two parallel steps:
+//   k_sbp_candidates  one wave per projected point: Frame::GetFeaturesInArea in the reference's order, the static filters
+//                     (levels, mvuRight) and the Hamming distances -> an ordered (index, distance) list per point;
+//   k_sbp_resolve     one workgroup iterates to the fixed point of "every point takes the first minimum of its list among the
+//                     keypoints no earlier owner blocks; owner(i2) = the earliest accepted taker with observations".  The
+//                     choice of point i depends only on points j < i, so after k rounds the first k points are final; the
+//                     chains are short in practice (a conflict needs two points that want the same keypoint).
+// =====================================================================================================
+#define SBP_CAP 512  // candidates kept per projected point (more -> the call reports a capacity error)
+
+struct SbpProj { float u, v, invz, angle; int octave, flags; };
+
+struct SbpArgs {
+    const MtKp *kc; const uint8_t *dc; const float *uRight; const signed char *curState; int nc;
+    const int *cellStart, *items;
+    GridBounds b; float minX, maxX, minY, maxY;
+    const float *scale; float mbf;
+    const SbpProj *proj; const uint8_t *dproj; int np;
+    float th; int forward, backward, checkOri;
+    uint32_t *cand;  // [np][SBP_CAP] index | dist << 16
+    int *count;      // [np] list length, -1: point not searched
+    int *choice;     // [np] work
+    int *owner;      // [2][nc] work
+    int *assign;     // [nc] out
+    int *result;     // [2] out: nmatches, overflow flag
+};
+
+__global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= a.np) return;
+    const SbpProj P = a.proj[i];
+    int *cnt = a.count + i;
+    bool search = (P.flags & 1) && !(P.invz < 0) && !(P.u < a.minX || P.u > a.maxX) && !(P.v < a.minY || P.v > a.maxY);
+    if (!search) { if (lane == 0) *cnt = -1; return; }
+    const int lastOct = P.octave;
+    const float r = __fmul_rn(a.th, a.scale[lastOct]);
+    int minLevel, maxLevel;
+    if (a.forward) { minLevel = lastOct; maxLevel = -1; }
+    else if (a.backward) { minLevel = 0; maxLevel = lastOct; }
+    else { minLevel = lastOct - 1; maxLevel = lastOct + 1; }
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    const float x = P.u, y = P.v;
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+    const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+    const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+    if (cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0) { if (lane == 0) *cnt = 0; return; }
+    uint32_t q[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.dproj + (size_t)i * 32))[w];
+    const float ur = __fsub_rn(x, __fmul_rn(a.mbf, P.invz));
+    const int ny = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny;
+    uint32_t *out = a.cand + (size_t)i * SBP_CAP;
+    __shared__ int stage[1024];  // keypoints of up to 64 cells in the reference's order, then filtered with ballots
+    int nOut = 0;
+    bool overflow = false;
+    for (int cb = 0; cb < nCells; cb += 64) {  // cells in (ix outer, iy inner) order
+        const int ci = cb + lane;
+        int s = 0, e = 0;
+        if (ci < nCells) {
+            const int cell = (cx0 + ci / ny) * GRID_ROWS + cy0 + ci % ny;
+            s = a.cellStart[cell]; e = a.cellStart[cell + 1];
+        }
+        int total;
+        const int off = mt_excl_scan(e - s, total);
+        if (total > 1024) { overflow = true; break; }  // wave-uniform
+        for (int j = s; j < e; ++j) stage[off + (j - s)] = a.items[j];
+        __syncthreads();
+        for (int ob = 0; ob < total; ob += 64) {
+            const int o = ob + lane;
+            bool keep = false;
+            int i2 = 0, dist = 0;
+            if (o < total) {
+                i2 = stage[o];
+                const MtKp kp = a.kc[i2];
+                keep = true;
+                if (checkLevels) {
+                    if (kp.octave < minLevel) keep = false;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) keep = false;
+                }
+                if (keep) keep = fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;
+                if (keep && a.uRight) {
+                    const float urc = a.uRight[i2];
+                    if (urc > 0 && fabsf(__fsub_rn(ur, urc)) > r) keep = false;
+                }
+                if (keep) {
+                    const uint32_t *t = (const uint32_t *)(a.dc + (size_t)i2 * 32);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            const int pos = nOut + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep) {
+                if (pos < SBP_CAP) out[pos] = (uint32_t)i2 | ((uint32_t)dist << 16);
+                else overflow = true;
+            }
+            nOut += __popcll(m);
+        }
+        __syncthreads();
+    }
+    if (__ballot(overflow) || nOut > SBP_CAP) { if (lane == 0) { *cnt = 0; atomicExch(&a.result[1], 1); } return; }
+    if (lane == 0) *cnt = nOut;
+}
+
+__global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
+{
+    const int TH_HIGH = 100, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
+    const int tid = threadIdx.x;
+    __shared__ int changed, hist[32], nAcc;
+    int *own = a.owner, *ownNew = a.owner + a.nc;
+    for (int i = tid; i < a.nc; i += 1024) { own[i] = INT_MAX; a.assign[i] = -1; }
+    if (tid < 32) hist[tid] = 0;
+    if (tid == 0) nAcc = 0;
+    __syncthreads();
+    for (int round = 0; round <= a.np + 1; ++round) {
+        for (int i = tid; i < a.nc; i += 1024) ownNew[i] = INT_MAX;
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (int i = tid; i < a.np; i += 1024) {
+            const int n = a.count[i];
+            int best = 256, bestI = -1;
+            const uint32_t *lst = a.cand + (size_t)i * SBP_CAP;
+            for (int c = 0; c < n; ++c) {
+                const uint32_t e = lst[c];
+                const int i2 = e & 0xFFFF, dist = e >> 16;
+                if (a.curState[i2] > 0 || own[i2] < i) continue;  // mvpMapPoints[i2]->Observations() > 0: before the call / taken earlier
+                if (dist < best) { best = dist; bestI = i2; }
+            }
+            const int ch = best <= TH_HIGH ? bestI : -1;
+            a.choice[i] = ch;
+            if (ch >= 0 && (a.proj[i].flags & 2)) atomicMin(&ownNew[ch], i);
+        }
+        __syncthreads();
+        for (int i = tid; i < a.nc; i += 1024)
+            if (ownNew[i] != own[i]) changed = 1;
+        __syncthreads();
+        const int ch = changed;
+        int *t = own; own = ownNew; ownNew = t;
+        __syncthreads();
+        if (!ch) break;
+    }
+    // CurrentFrame.mvpMapPoints[i2] = the map point of the LAST accepted taker (later ones overwrite); nmatches counts every taker
+    for (int i = tid; i < a.np; i += 1024) {
+        const int ch = a.count[i] >= 0 ? a.choice[i] : -1;
+        if (ch >= 0) {
+            atomicMax(&a.assign[ch], i);
+            atomicAdd(&nAcc, 1);
+            if (a.checkOri) {
+                float rot = __fsub_rn(a.proj[i].angle, a.kc[ch].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                atomicAdd(&hist[bin], 1);
+                a.choice[i] = ch | (bin << 16);
+            }
+        } else a.choice[i] = -1;
+    }
+    __syncthreads();
+    if (a.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        __syncthreads();
+        for (int i = tid; i < a.np; i += 1024) {
+            const int c = a.choice[i];
+            if (c < 0) continue;
+            const int bin = c >> 16, ch = c & 0xFFFF;
+            if (bin != ind1 && bin != ind2 && bin != ind3) { a.assign[ch] = -2; atomicSub(&nAcc, 1); }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) a.result[0] = nAcc;
+}
+
+hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const uint8_t *dc, const float *uRight, const signed char *curState,
+                                        int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
+                                        const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
+                                        int backward, int checkOri, uint32_t *cand, int *count, int *choice, int *owner, int *assign,
+                                        int *result)
+{
+    SbpArgs a;
+    a.kc = (const MtKp *)kc; a.dc = dc; a.uRight = uRight; a.curState = curState; a.nc = nc;
+    a.cellStart = cellStart; a.items = items;
+    a.b.minX = minX; a.b.minY = minY; a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);
+    a.minX = minX; a.maxX = maxX; a.minY = minY; a.maxY = maxY;
+    a.scale = scale; a.mbf = mbf; a.proj = (const SbpProj *)proj; a.dproj = dproj; a.np = np;
+    a.th = th; a.forward = forward; a.backward = backward; a.checkOri = checkOri;
+    a.cand = cand; a.count = count; a.choice = choice; a.owner = owner; a.assign = assign; a.result = result;
+    hipError_t e = hipMemsetAsync(result, 0, 2 * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    if (np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(np), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_sbp_resolve, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}

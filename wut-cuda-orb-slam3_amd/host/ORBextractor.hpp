@@ -179,6 +179,29 @@ public:
         return n;
     }
 
+    // Project MapPoints tracked in last frame into the current frame and search matches (Used to track from previous frame) —
+    // reference include/ORBmatcher.h:54, src/ORBmatcher3.cc:256-467 (CurrentFrame.Nleft == -1).  The caller projects
+    // (x3Dc = Tcw * x3Dw, uv = mpCamera->project(x3Dc)) and passes the result per last-frame keypoint; mvpMapPointsState holds
+    // -1 / 0 / 1 = CurrentFrame.mvpMapPoints[i] NULL / without / with observations; vnAssigned receives -1 untouched, j the map
+    // point of last-frame keypoint j, -2 NULLed by the rotation check.
+    int SearchByProjection(const FrameView &CurrentFrame, const std::vector<float> &mvuRight, const std::vector<int8_t> &mvpMapPointsState,
+                           const std::vector<float> &mvScaleFactors, float mbf, const std::vector<orbx_projection> &vProjections,
+                           const Descriptors &vMapPointDescriptors, std::vector<int> &vnAssigned, const float th, const bool bForward,
+                           const bool bBackward)
+    {
+        const int nc = (int)CurrentFrame.mvKeysUn->size(), np = (int)vProjections.size();
+        if ((int)mvpMapPointsState.size() != nc || (!mvuRight.empty() && (int)mvuRight.size() != nc) || vMapPointDescriptors.rows != np)
+            throw std::runtime_error("SearchByProjection: inconsistent array sizes");
+        vnAssigned.assign((size_t)nc, -1);
+        const int n = orbx_search_by_projection(m_, (const orbx_keypoint *)CurrentFrame.mvKeysUn->data(), CurrentFrame.mDescriptors->data.data(),
+                                                mvuRight.empty() ? nullptr : mvuRight.data(), mvpMapPointsState.data(), nc, CurrentFrame.mnMinX,
+                                                CurrentFrame.mnMaxX, CurrentFrame.mnMinY, CurrentFrame.mnMaxY, mvScaleFactors.data(),
+                                                (int)mvScaleFactors.size(), mbf, vProjections.data(), vMapPointDescriptors.data.data(), np, th,
+                                                bForward, bBackward, mbCheckOrientation ? 1 : 0, vnAssigned.data());
+        if (n < 0) check(n, "SearchByProjection");
+        return n;
+    }
+
     // Frame::AssignFeaturesToGrid — reference src/Frame.cc:387-418: mGrid[ix][iy] = items[cellStart[ix * 48 + iy] .. cellStart[.. + 1])
     void AssignFeaturesToGrid(const FrameView &F, std::vector<int32_t> &cellStart, std::vector<int32_t> &items)
     {
