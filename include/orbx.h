@@ -256,6 +256,19 @@ int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const ui
                               float mbf, const orbx_projection *proj, const uint8_t *proj_desc, int np, float th, int forward,
                               int backward, int check_orientation, int32_t *assign);
 
+/* int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th, const bool bFarPoints,
+ * const float thFarPoints) — reference src/ORBmatcher1.cc:45-215 (decl include/ORBmatcher.h:48), the F.Nleft == -1 branch, called
+ * every frame by Tracking::SearchLocalPoints (src/Tracking4.cc:737).  One orbx_projection per map point with the fields
+ * Frame::isInFrustum (src/Frame.cc:527-616) left on it: u, v = mTrackProjX, mTrackProjY; invz = mTrackProjXR; angle = mTrackViewCos;
+ * octave = mnTrackScaleLevel; flags bit 0 = mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth > thFarPoints), bit 1 =
+ * Observations() > 0.  Window radius = RadiusByViewingCos(viewCos) [* th if th != 1] * scale_factors[level], levels level - 1 ..
+ * level, best and second best with the ratio test only when both lie in the same level (nnratio = mfNNratio), TH_HIGH = 100.
+ * cur_state / assign as in orbx_search_by_projection.  Returns nmatches (>= 0) or a negative status. */
+int orbx_search_by_projection_points(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, const float *u_right,
+                                     const int8_t *cur_state, int nc, float min_x, float max_x, float min_y, float max_y,
+                                     const float *scale_factors, int nlevels, const orbx_projection *map_points,
+                                     const uint8_t *map_point_desc, int np, float th, float nnratio, int32_t *assign);
+
 /* Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011: the row-band Hamming
  * stage above, then for every accepted left keypoint the 11x11 L1 sliding-window refinement (+-5 px) on
  * mvImagePyramid[octave] of the left / right extractor (the device-resident pyramids of frame `frame_left` /

@@ -63,6 +63,8 @@ def lib() -> ctypes.CDLL:
                                                        c_float, c_void_p, c_void_p, c_int, c_float, c_int]
         L.oracle_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p,
                                                   c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
+        L.oracle_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
+                                                         c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -280,4 +282,21 @@ def search_by_projection(kc, dc, cur_state, bounds, scale_factors, proj, proj_de
     n = lib().oracle_search_by_projection(kc.ctypes.data, dc.ctypes.data, None if ur is None else ur.ctypes.data, st.ctypes.data, len(kc),
                                           *[float(b) for b in bounds], sf.ctypes.data, len(sf), float(mbf), pr.ctypes.data, pd.ctypes.data,
                                           len(pr), float(th), int(forward), int(backward), int(bool(check_orientation)), assign.ctypes.data)
+    return n, assign
+
+
+def search_by_projection_points(kc, dc, cur_state, bounds, scale_factors, mps, mp_desc, th=1.0, nnratio=0.6, u_right=None):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ..) (reference src/ORBmatcher1.cc:45-215, Nleft == -1) -> (nmatches, assign).
+    mps: PROJECTION_DTYPE with u, v = mTrackProjX / Y, invz = mTrackProjXR, angle = mTrackViewCos, octave = mnTrackScaleLevel."""
+    kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+    dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+    st = np.ascontiguousarray(cur_state, np.int8)
+    pr = np.ascontiguousarray(mps, PROJECTION_DTYPE)
+    pd = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    assign = np.full(len(kc), -1, np.int32)
+    n = lib().oracle_search_by_projection_points(kc.ctypes.data, dc.ctypes.data, None if ur is None else ur.ctypes.data, st.ctypes.data,
+                                                 len(kc), *[float(b) for b in bounds], sf.ctypes.data, len(sf), pr.ctypes.data,
+                                                 pd.ctypes.data, len(pr), float(th), float(nnratio), assign.ctypes.data)
     return n, assign

@@ -1197,6 +1197,57 @@ int oracle_search_by_projection(const oracle_keypoint *kc, const uint8_t *dc, co
     return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th, bFarPoints, thFarPoints) —
+// reference src/ORBmatcher1.cc:45-215, branch F.Nleft == -1, map points with mbTrackInView (set by Frame::isInFrustum together
+// with mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos; the caller also applies the isBad() and far-point tests and clears
+// flag bit 0 for those).  A record = {u: mTrackProjX, v: mTrackProjY, invz: mTrackProjXR, angle: mTrackViewCos,
+// octave: mnTrackScaleLevel, flags}.  cur_state / assign as in oracle_search_by_projection.  Returns nmatches.
+int oracle_search_by_projection_points(const oracle_keypoint *kc, const uint8_t *dc, const float *u_right, const int8_t *cur_state, int nc,
+                                       float minX, float maxX, float minY, float maxY, const float *scale_factors, int nlevels,
+                                       const oracle_projection *mps, const uint8_t *dmp, int np, float th, float nnratio, int32_t *assign)
+{
+    (void)nlevels;
+    const int TH_HIGH = 100;
+    const FrameGrid G = assignFeaturesToGrid(kc, nc, minX, maxX, minY, maxY);
+    std::vector<int> mp(nc), obs(nc);
+    for (int i = 0; i < nc; ++i) { mp[i] = cur_state[i] < 0 ? -1 : -3; obs[i] = cur_state[i] > 0; }
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < np; iMP++) {
+        const oracle_projection &P = mps[iMP];
+        if (!(P.flags & 1)) continue;  // !mbTrackInView, far point or isBad()
+        const int nPredictedLevel = P.octave;
+        float r = P.angle > 0.998 ? 2.5 : 4.0;  // RadiusByViewingCos(mTrackViewCos), :217-223
+        if (bFactor) r *= th;
+        const std::vector<size_t> vIndices =
+            getFeaturesInArea(G, kc, P.u, P.v, r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t *MPdescriptor = dmp + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t v = 0; v < vIndices.size(); ++v) {
+            const size_t idx = vIndices[v];
+            if (mp[idx] != -1)
+                if (obs[idx]) continue;
+            if (u_right && u_right[idx] > 0) {
+                const float er = std::fabs(P.invz - u_right[idx]);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = oracle_hamming256(MPdescriptor, dc + idx * 32);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kc[idx].octave; bestIdx = (int)idx; }
+            else if (dist < bestDist2) { bestLevel2 = kc[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                mp[bestIdx] = iMP; obs[bestIdx] = (P.flags >> 1) & 1;
+                nmatches++;
+            }
+        }
+    }
+    for (int i = 0; i < nc; ++i) assign[i] = mp[i] == -3 ? -1 : mp[i];
+    return nmatches;
+}
+
 }  // extern "C"
 
 extern "C" {

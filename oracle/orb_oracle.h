@@ -124,6 +124,13 @@ int oracle_search_by_projection(const oracle_keypoint *kc, const uint8_t *dc, co
                                 const oracle_projection *proj, const uint8_t *dproj, int np, float th, int forward, int backward,
                                 int check_orientation, int32_t *assign);
 
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th, ..) (src/ORBmatcher1.cc:45-215), F.Nleft == -1, points
+ * with mbTrackInView: a record holds u = mTrackProjX, v = mTrackProjY, invz = mTrackProjXR, angle = mTrackViewCos,
+ * octave = mnTrackScaleLevel, flags as above.  Returns nmatches. */
+int oracle_search_by_projection_points(const oracle_keypoint *kc, const uint8_t *dc, const float *u_right, const int8_t *cur_state, int nc,
+                                       float min_x, float max_x, float min_y, float max_y, const float *scale_factors, int nlevels,
+                                       const oracle_projection *mps, const uint8_t *dmp, int np, float th, float nnratio, int32_t *assign);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

@@ -134,6 +134,63 @@ static int runSearchForInitialization()
     return 0;
 }
 
+// Tracking against the last frame and against the local map: both SearchByProjection overloads of include/ORBmatcher.h:48,54 on
+// two views of one scene (src/Tracking4.cc:190-218 TrackWithMotionModel, :737 SearchLocalPoints).
+static int runSearchByProjection()
+{
+    const int w = 640, h = 480;
+    std::vector<uint8_t> img1((size_t)w * h), img2((size_t)w * h);
+    orbx_synth_frame_impl(19, w, h, img1.data(), w);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) img2[(size_t)y * w + x] = img1[(size_t)((y + h - 2) % h) * w + (x + w - 4) % w];
+    orbx::ORBextractor ex(1200, 1.2f, 8, 20, 7, 0, w, h);
+    std::vector<int> lap = {0, 0};
+    std::vector<orbx::KeyPoint> keysLast, keysCur;
+    orbx::Descriptors descLast, descCur;
+    ex(orbx::Image(img1.data(), w, h), orbx::Image(), keysLast, descLast, lap);
+    ex(orbx::Image(img2.data(), w, h), orbx::Image(), keysCur, descCur, lap);
+    orbx::FrameView CurrentFrame;
+    CurrentFrame.mvKeysUn = &keysCur; CurrentFrame.mDescriptors = &descCur;
+    CurrentFrame.mnMinX = 0.f; CurrentFrame.mnMaxX = (float)w; CurrentFrame.mnMinY = 0.f; CurrentFrame.mnMaxY = (float)h;
+    const std::vector<float> mvScaleFactors = ex.GetScaleFactors();
+    const int nc = (int)keysCur.size(), np = (int)keysLast.size();
+    std::vector<orbx_projection> proj((size_t)np);
+    for (int i = 0; i < np; ++i) {
+        proj[i].u = keysLast[i].pt.x + 4.f + (float)(i % 5 - 2) * 0.5f;
+        proj[i].v = keysLast[i].pt.y + 2.f + (float)(i % 3 - 1) * 0.5f;
+        proj[i].invz = 0.25f;
+        proj[i].angle = keysLast[i].angle;
+        proj[i].octave = keysLast[i].octave;
+        proj[i].flags = (i % 7 ? 1 : 0) | (i % 4 ? 2 : 0);
+    }
+    std::vector<int8_t> state((size_t)nc);
+    for (int i = 0; i < nc; ++i) state[i] = i % 9 == 0 ? 1 : (i % 5 == 0 ? 0 : -1);
+    std::vector<float> noRight;
+    std::vector<int> assigned;
+    std::vector<int32_t> ref((size_t)nc);
+
+    orbx::ORBmatcher matcher(0.9f, true);
+    const int n1 = matcher.SearchByProjection(CurrentFrame, noRight, state, mvScaleFactors, 0.f, proj, descLast, assigned, 15, false, false);
+    const int r1 = oracle_search_by_projection((const oracle_keypoint *)keysCur.data(), descCur.data.data(), nullptr, state.data(), nc, 0.f, (float)w,
+                                               0.f, (float)h, mvScaleFactors.data(), (int)mvScaleFactors.size(), 0.f,
+                                               (const oracle_projection *)proj.data(), descLast.data.data(), np, 15, 0, 0, 1, ref.data());
+    ASSERT_EQ(n1, r1);
+    ASSERT_TRUE(n1 > 50);
+    for (int i = 0; i < nc; ++i) ASSERT_EQ(assigned[i], ref[i]);
+
+    // local map: the same points as Frame::isInFrustum would leave them (mTrackViewCos, mnTrackScaleLevel, mTrackProjXR)
+    for (int i = 0; i < np; ++i) { proj[i].angle = i % 2 ? 0.9995f : 0.97f; proj[i].invz = proj[i].u - 10.f; }
+    orbx::ORBmatcher local(0.8f);
+    const int n2 = local.SearchByProjection(CurrentFrame, noRight, state, mvScaleFactors, proj, descLast, assigned, 3);
+    const int r2 = oracle_search_by_projection_points((const oracle_keypoint *)keysCur.data(), descCur.data.data(), nullptr, state.data(), nc, 0.f,
+                                                      (float)w, 0.f, (float)h, mvScaleFactors.data(), (int)mvScaleFactors.size(),
+                                                      (const oracle_projection *)proj.data(), descLast.data.data(), np, 3, 0.8f, ref.data());
+    ASSERT_EQ(n2, r2);
+    ASSERT_TRUE(n2 > 50);
+    for (int i = 0; i < nc; ++i) ASSERT_EQ(assigned[i], ref[i]);
+    return 0;
+}
+
 int main()
 {
     // empty image -> -1 (reference src/ORBextractor.cc:1231-1232)
@@ -153,6 +210,7 @@ int main()
     if (runExtractAndCompare(752, 480, 1200, {0, 0})) return 1;      // EuRoC geometry
     if (runExtractAndCompare(512, 512, 1500, {100, 300})) return 1;  // TUM-VI geometry with a lapping band
     if (runSearchForInitialization()) return 1;
+    if (runSearchByProjection()) return 1;                           // SURVEY 8(f) rank 2, tracking searches
     printf("OK host mirror\n");
     return 0;
 }

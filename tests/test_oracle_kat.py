@@ -241,3 +241,53 @@ def test_search_by_projection_properties(orc):
     busy = np.full(n, 1, np.int8)
     nm, assign = orc.search_by_projection(k, d, busy, bounds, sf, pr, d, 15.0)
     assert nm == 0 and (assign == -1).all()
+
+
+def test_search_by_projection_map_points_properties(orc):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) restated in the oracle (reference src/ORBmatcher1.cc:45-215): a frame's own
+    keypoints as map points at their own level match themselves; the window follows RadiusByViewingCos (2.5 above cos 0.998, else 4,
+    times th unless th == 1, times the level's scale) and only levels level-1 .. level are searched; a twin in the same level within
+    the ratio is rejected, a twin in another level is not."""
+    o = orc.Oracle(800, 1.2, 8, 20, 7)
+    _, k, d = o.extract(orc.synth_frame(0x4F524230 + 11, 640, 480), (0, 0))
+    sf = o.tables()["scale"]
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    n = len(k)
+    pr = np.zeros(n, orc.PROJECTION_DTYPE)
+    pr["u"], pr["v"], pr["invz"], pr["angle"], pr["octave"], pr["flags"] = k["x"], k["y"], -1.0, 0.9999, k["octave"], 3
+    free = np.full(n, -1, np.int8)
+    nm, assign = orc.search_by_projection_points(k, d, free, bounds, sf, pr, d, 1.0, 0.8)
+    took = assign >= 0
+    assert nm == took.sum() and (assign[took] == np.arange(n)[took]).all() and nm > 0.9 * n  # losers: a same-level twin in the window
+    # predicted level two above the keypoint's: outside [level-1, level], nothing found for isolated points
+    one = np.zeros(1, orc.PROJECTION_DTYPE)
+    i0 = int(np.flatnonzero(k["octave"] == 0)[0])
+    one["u"], one["v"], one["angle"], one["flags"] = k["x"][i0], k["y"][i0], 0.5, 3
+    kk, dd = k[i0:i0 + 1], d[i0:i0 + 1]
+    for lvl, expect in ((0, 1), (1, 1), (2, 0)):
+        one["octave"] = lvl
+        nm, assign = orc.search_by_projection_points(kk, dd, free[:1], bounds, sf, one, dd, 1.0, 0.8)
+        assert nm == expect
+    # radius: offset 3 px at level 0 is inside 4 (cos 0.5) but outside 2.5 (cos 0.999); th = 2 doubles both; the compare is in
+    # double, so float(0.998) = 0.99800003 counts as above 0.998 and the float just below it does not
+    one["octave"] = 0
+    one["u"] = k["x"][i0] + 3.0
+    for cosv, th, expect in ((0.5, 1.0, 1), (0.999, 1.0, 0), (0.999, 2.0, 1), (np.float32(0.998), 1.0, 0),
+                             (np.nextafter(np.float32(0.998), np.float32(0)), 1.0, 1)):
+        one["angle"] = cosv
+        nm, _ = orc.search_by_projection_points(kk, dd, free[:1], bounds, sf, one, dd, th, 0.8)
+        assert nm == expect, (cosv, th)
+    # a same-level twin at nearly the same distance (10 vs 11 bits): 10 > 0.8 * 11, rejected by the ratio test; the same twin in the
+    # next level is not compared, accepted
+    two_k = np.concatenate([kk, kk]); two_d = np.concatenate([dd, dd])
+    two_d[1, 31] ^= 0x01
+    mpd = dd.copy(); mpd[0, 0] ^= 0xFF; mpd[0, 1] ^= 0x03  # 10 bits from keypoint 0, 11 from keypoint 1
+    assert orc.hamming256(mpd[0], two_d[0]) == 10 and orc.hamming256(mpd[0], two_d[1]) == 11
+    one["u"] = k["x"][i0]; one["angle"] = 0.5; one["octave"] = 1
+    nm, _ = orc.search_by_projection_points(two_k, two_d, free[:2], bounds, sf, one, mpd, 1.0, 0.8)
+    assert nm == 0
+    nm, assign = orc.search_by_projection_points(two_k, two_d, free[:2], bounds, sf, one, mpd, 1.0, 0.95)
+    assert nm == 1 and assign[0] == 0
+    two_k["octave"][1] = 1
+    nm, assign = orc.search_by_projection_points(two_k, two_d, free[:2], bounds, sf, one, mpd, 1.0, 0.8)
+    assert nm == 1 and assign[0] == 0 and assign[1] == -1

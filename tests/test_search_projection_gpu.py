@@ -88,3 +88,63 @@ def test_search_by_projection_conflicts_and_edges(pkg, orc):
         pr3 = pr.copy(); pr3["octave"][0] = 9
         m.SearchByProjection(k2, d2, state, BOUNDS, sf, pr3, d1b, 15)
     m.close()
+
+
+def _map_points(pkg, k1, rng, dx, dy, noise=1.5):
+    """Frame::isInFrustum outputs for the local map points: projections near the keypoints of another view, predicted level near the
+    keypoint's octave, viewing cosines on both sides of RadiusByViewingCos' 0.998 (and exactly float(0.998))."""
+    pr = np.zeros(len(k1), pkg.PROJECTION_DTYPE)
+    pr["u"] = k1["x"] + dx + rng.normal(0, noise, len(k1)).astype(np.float32)
+    pr["v"] = k1["y"] + dy + rng.normal(0, noise, len(k1)).astype(np.float32)
+    pr["angle"] = rng.choice(np.float32([0.5, 0.9, 0.99, 0.998, 0.9981, 0.9999, 1.0]), len(k1))
+    pr["octave"] = np.clip(k1["octave"] + rng.integers(-1, 2, len(k1)), 0, 7)
+    pr["invz"] = pr["u"] - rng.uniform(0.5, 40, len(k1)).astype(np.float32)  # mTrackProjXR
+    inview = rng.random(len(k1)) < 0.85
+    obs = rng.random(len(k1)) < 0.8
+    pr["flags"] = inview.astype(np.int32) | (obs.astype(np.int32) << 1)
+    return pr
+
+
+@pytest.mark.parametrize("th,nnratio,stereo", [(1.0, 0.8, False), (3.0, 0.8, False), (5.0, 0.8, True), (15.0, 0.6, False), (1.0, 0.9, True)])
+def test_search_by_projection_map_points(pkg, orc, th, nnratio, stereo):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) as Tracking::SearchLocalPoints calls it (matcher(0.8), th 1 / 3 / 5 / 15)."""
+    dx, dy = 3, 2
+    k1, d1, k2, d2, sf, rng = _frames(pkg, 31, dx, dy)
+    pr = _map_points(pkg, k1, rng, dx, dy)
+    state = rng.choice(np.int8([-1, -1, -1, 0, 1]), len(k2))
+    ur = np.where(rng.random(len(k2)) < 0.6, k2["x"] - rng.uniform(0.5, 40, len(k2)), -1).astype(np.float32) if stereo else None
+    m = pkg.ORBmatcher(8192, 8192)
+    n, assign = m.SearchByProjectionPoints(k2, d2, state, BOUNDS, sf, pr, d1, th, nnratio, u_right=ur)
+    rn, rassign = orc.search_by_projection_points(k2, d2, state, BOUNDS, sf, pr, d1, th, nnratio, ur)
+    assert n == rn and np.array_equal(assign, rassign)
+    if not stereo:
+        assert n > 50
+    m.close()
+
+
+def test_search_by_projection_map_points_ratio_and_conflicts(pkg, orc):
+    """Dense competition: several map points per keypoint with near-identical descriptors, so the same-level ratio test and the
+    "already has a point with observations" rule both fire; plus empty inputs."""
+    k1, d1, k2, d2, sf, rng = _frames(pkg, 37, 0, 0)
+    n1 = len(k1)
+    pr = _map_points(pkg, k1, rng, 0, 0, noise=0.3)
+    spots = rng.integers(0, len(k2), 60)
+    pick = spots[rng.integers(0, 60, n1)]
+    pr["u"], pr["v"] = k2["x"][pick], k2["y"][pick]
+    pr["octave"] = np.clip(k2["octave"][pick] + rng.integers(0, 2, n1), 0, 7)
+    dmp = d2[pick].copy()
+    dmp[:, :3] ^= rng.integers(0, 256, (n1, 3), dtype=np.uint8)
+    state = np.full(len(k2), -1, np.int8)
+    m = pkg.ORBmatcher(8192, 8192)
+    tot = 0
+    for th, ratio in ((1.0, 0.8), (4.0, 0.8), (4.0, 0.5), (15.0, 1.0)):
+        n, assign = m.SearchByProjectionPoints(k2, d2, state, BOUNDS, sf, pr, dmp, th, ratio)
+        rn, rassign = orc.search_by_projection_points(k2, d2, state, BOUNDS, sf, pr, dmp, th, ratio)
+        assert n == rn and np.array_equal(assign, rassign)
+        tot += n
+    assert tot > 0
+    n, assign = m.SearchByProjectionPoints(k2, d2, state, BOUNDS, sf, pr[:0], dmp[:0], 1.0, 0.8)
+    assert n == 0 and (assign == -1).all()
+    n, assign = m.SearchByProjectionPoints(k2[:0], d2[:0], state[:0], BOUNDS, sf, pr, dmp, 1.0, 0.8)
+    assert n == 0 and len(assign) == 0
+    m.close()

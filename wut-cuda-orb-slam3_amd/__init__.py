@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
+    "orbx_search_by_projection_points",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -127,6 +128,8 @@ def load_library() -> ctypes.CDLL:
                                                    c_float, c_void_p, c_void_p, c_int, c_float, c_int]
     lib.orbx_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
                                               c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
+    lib.orbx_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
+                                                     c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -427,4 +430,25 @@ class ORBmatcher:
                                                 assign.ctypes.data)
         if n < 0:
             _check(n, "orbx_search_by_projection")
+        return n, assign
+
+    def SearchByProjectionPoints(self, kc, dc, cur_state, bounds, scale_factors, map_points, mp_desc, th: float = 1.0, nnratio: float = 0.6,
+                                 *, u_right=None):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ..) (reference src/ORBmatcher1.cc:45-215, Nleft == -1).  map_points:
+        PROJECTION_DTYPE with u, v = mTrackProjX / Y, invz = mTrackProjXR, angle = mTrackViewCos, octave = mnTrackScaleLevel.
+        Returns (nmatches, assign[nc])."""
+        kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+        dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+        st = np.ascontiguousarray(cur_state, np.int8)
+        pr = np.ascontiguousarray(map_points, PROJECTION_DTYPE)
+        pd = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        assert len(st) == len(kc) and len(pd) == len(pr) and (ur is None or len(ur) == len(kc))
+        assign = np.full(len(kc), -1, np.int32)
+        n = self._lib.orbx_search_by_projection_points(self._h, kc.ctypes.data, dc.ctypes.data, None if ur is None else ur.ctypes.data,
+                                                       st.ctypes.data, len(kc), *[float(b) for b in bounds], sf.ctypes.data, len(sf),
+                                                       pr.ctypes.data, pd.ctypes.data, len(pr), float(th), float(nnratio), assign.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_projection_points")
         return n, assign

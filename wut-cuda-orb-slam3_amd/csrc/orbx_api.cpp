@@ -1048,11 +1048,11 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
 }
 
 // ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) — reference src/ORBmatcher3.cc:256-467 (Nleft == -1).
-extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, const float *u_right,
-                                         const int8_t *cur_state, int nc, float min_x, float max_x, float min_y, float max_y,
-                                         const float *scale_factors, int nlevels, float mbf, const orbx_projection *proj,
-                                         const uint8_t *proj_desc, int np, float th, int forward, int backward, int check_orientation,
-                                         int32_t *assign)
+static int searchByProjectionImpl(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, const float *u_right,
+                                  const int8_t *cur_state, int nc, float min_x, float max_x, float min_y, float max_y,
+                                  const float *scale_factors, int nlevels, float mbf, const orbx_projection *proj,
+                                  const uint8_t *proj_desc, int np, float th, int forward, int backward, int check_orientation,
+                                  int mode, float nnratio, int32_t *assign)
 {
     if (!m || nc < 0 || np < 0 || (nc > 0 && (!kc || !dc || !cur_state || !assign)) || (np > 0 && (!proj || !proj_desc)) || !scale_factors ||
         nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(th >= 0.f))
@@ -1087,13 +1087,33 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *k
     HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, nc, min_x, max_x, min_y, max_y, cs, it, co));
     HIP_TRY(orbxLaunchSearchByProjection(m->stream, m->d_kr.p, m->d_t.p, dURight, dState, nc, cs, it, min_x, max_x, min_y, max_y,
                                          m->d_scale.p, mbf, m->d_proj.p, m->d_q.p, np, th, forward != 0, backward != 0,
-                                         check_orientation != 0, m->d_sbpCand.p, count, choice, owner, dAssign, result));
+                                         check_orientation != 0, mode, nnratio, m->d_sbpCand.p, count, choice, owner, dAssign, result));
     int res[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(assign, dAssign, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(res, result, sizeof res, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (res[1]) return setError(ORBX_ERR_CAPACITY, "orbx_search_by_projection: a search window holds more than %d candidates", ORBX_SBP_CAP);
     return res[0];
+}
+
+extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, const float *u_right,
+                                         const int8_t *cur_state, int nc, float min_x, float max_x, float min_y, float max_y,
+                                         const float *scale_factors, int nlevels, float mbf, const orbx_projection *proj,
+                                         const uint8_t *proj_desc, int np, float th, int forward, int backward, int check_orientation,
+                                         int32_t *assign)
+{
+    return searchByProjectionImpl(m, kc, dc, u_right, cur_state, nc, min_x, max_x, min_y, max_y, scale_factors, nlevels, mbf, proj, proj_desc,
+                                  np, th, forward, backward, check_orientation, 0, 0.f, assign);
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ..) — reference src/ORBmatcher1.cc:45-215 (Nleft == -1).
+extern "C" int orbx_search_by_projection_points(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, const float *u_right,
+                                                const int8_t *cur_state, int nc, float min_x, float max_x, float min_y, float max_y,
+                                                const float *scale_factors, int nlevels, const orbx_projection *map_points,
+                                                const uint8_t *map_point_desc, int np, float th, float nnratio, int32_t *assign)
+{
+    return searchByProjectionImpl(m, kc, dc, u_right, cur_state, nc, min_x, max_x, min_y, max_y, scale_factors, nlevels, 0.f, map_points,
+                                  map_point_desc, np, th, 0, 0, 0, 1, nnratio, assign);
 }
 
 // Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011.

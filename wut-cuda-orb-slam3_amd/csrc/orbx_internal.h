@@ -121,8 +121,8 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
 hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const uint8_t *dc, const float *uRight, const signed char *curState,
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
                                         const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
-                                        int backward, int checkOri, uint32_t *cand, int *count, int *choice, int *owner, int *assign,
-                                        int *result);
+                                        int backward, int checkOri, int mode, float nnratio, uint32_t *cand, int *count, int *choice,
+                                        int *owner, int *assign, int *result);
 #define ORBX_SBP_CAP 512  // == SBP_CAP in orbx_match.hip
 
 #endif

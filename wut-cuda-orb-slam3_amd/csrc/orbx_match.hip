@@ -790,7 +790,10 @@ struct SbpArgs {
     const float *scale; float mbf;
     const SbpProj *proj; const uint8_t *dproj; int np;
     float th; int forward, backward, checkOri;
-    uint32_t *cand;  // [np][SBP_CAP] index | dist << 16
+    int mode;        // 0: SearchByProjection(Frame, Frame); 1: SearchByProjection(Frame, vector<MapPoint*>) - then SbpProj holds
+                     //    u, v = mTrackProjX / Y, invz = mTrackProjXR, angle = mTrackViewCos, octave = mnTrackScaleLevel
+    float nnratio;
+    uint32_t *cand;  // [np][SBP_CAP] index | dist << 16 | octave << 25
     int *count;      // [np] list length, -1: point not searched
     int *choice;     // [np] work
     int *owner;      // [2][nc] work
@@ -804,14 +807,23 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     if (i >= a.np) return;
     const SbpProj P = a.proj[i];
     int *cnt = a.count + i;
-    bool search = (P.flags & 1) && !(P.invz < 0) && !(P.u < a.minX || P.u > a.maxX) && !(P.v < a.minY || P.v > a.maxY);
+    bool search = (P.flags & 1) != 0;
+    if (a.mode == 0) search = search && !(P.invz < 0) && !(P.u < a.minX || P.u > a.maxX) && !(P.v < a.minY || P.v > a.maxY);
     if (!search) { if (lane == 0) *cnt = -1; return; }
     const int lastOct = P.octave;
-    const float r = __fmul_rn(a.th, a.scale[lastOct]);
+    float r;
     int minLevel, maxLevel;
-    if (a.forward) { minLevel = lastOct; maxLevel = -1; }
-    else if (a.backward) { minLevel = 0; maxLevel = lastOct; }
-    else { minLevel = lastOct - 1; maxLevel = lastOct + 1; }
+    if (a.mode == 0) {
+        r = __fmul_rn(a.th, a.scale[lastOct]);
+        if (a.forward) { minLevel = lastOct; maxLevel = -1; }
+        else if (a.backward) { minLevel = 0; maxLevel = lastOct; }
+        else { minLevel = lastOct - 1; maxLevel = lastOct + 1; }
+    } else {
+        float rv = (double)P.angle > 0.998 ? 2.5f : 4.0f;  // ORBmatcher::RadiusByViewingCos (src/ORBmatcher1.cc:217-223), a double compare
+        if (a.th != 1.0f) rv = __fmul_rn(rv, a.th);
+        r = __fmul_rn(rv, a.scale[lastOct]);
+        minLevel = lastOct - 1; maxLevel = lastOct;
+    }
     const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
     const float x = P.u, y = P.v;
     const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
@@ -822,7 +834,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     uint32_t q[8];
 #pragma unroll
     for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.dproj + (size_t)i * 32))[w];
-    const float ur = __fsub_rn(x, __fmul_rn(a.mbf, P.invz));
+    const float ur = a.mode == 0 ? __fsub_rn(x, __fmul_rn(a.mbf, P.invz)) : P.invz;  // mode 1: mTrackProjXR
     const int ny = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny;
     uint32_t *out = a.cand + (size_t)i * SBP_CAP;
     __shared__ int stage[1024];  // keypoints of up to 64 cells in the reference's order, then filtered with ballots
@@ -843,10 +855,11 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
         for (int ob = 0; ob < total; ob += 64) {
             const int o = ob + lane;
             bool keep = false;
-            int i2 = 0, dist = 0;
+            int i2 = 0, dist = 0, oct = 0;
             if (o < total) {
                 i2 = stage[o];
                 const MtKp kp = a.kc[i2];
+                oct = kp.octave & 15;
                 keep = true;
                 if (checkLevels) {
                     if (kp.octave < minLevel) keep = false;
@@ -866,7 +879,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
             const unsigned long long m = __ballot(keep);
             const int pos = nOut + __popcll(m & ((1ull << lane) - 1ull));
             if (keep) {
-                if (pos < SBP_CAP) out[pos] = (uint32_t)i2 | ((uint32_t)dist << 16);
+                if (pos < SBP_CAP) out[pos] = (uint32_t)i2 | ((uint32_t)dist << 16) | ((uint32_t)oct << 25);
                 else overflow = true;
             }
             nOut += __popcll(m);
@@ -893,15 +906,18 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
         __syncthreads();
         for (int i = tid; i < a.np; i += 1024) {
             const int n = a.count[i];
-            int best = 256, bestI = -1;
+            int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1;
             const uint32_t *lst = a.cand + (size_t)i * SBP_CAP;
             for (int c = 0; c < n; ++c) {
                 const uint32_t e = lst[c];
-                const int i2 = e & 0xFFFF, dist = e >> 16;
+                const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
                 if (a.curState[i2] > 0 || own[i2] < i) continue;  // mvpMapPoints[i2]->Observations() > 0: before the call / taken earlier
-                if (dist < best) { best = dist; bestI = i2; }
+                if (dist < best) { best2 = best; bestL2 = bestL; best = dist; bestL = lv; bestI = i2; }
+                else if (dist < best2) { best2 = dist; bestL2 = lv; }
             }
-            const int ch = best <= TH_HIGH ? bestI : -1;
+            int ch = best <= TH_HIGH ? bestI : -1;
+            // map-point variant: ratio to the second match, only if best and second are in the same scale level (:122-129)
+            if (a.mode == 1 && ch >= 0 && bestL == bestL2 && (float)best > __fmul_rn(a.nnratio, (float)best2)) ch = -1;
             a.choice[i] = ch;
             if (ch >= 0 && (a.proj[i].flags & 2)) atomicMin(&ownNew[ch], i);
         }
@@ -956,10 +972,11 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
 hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const uint8_t *dc, const float *uRight, const signed char *curState,
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
                                         const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
-                                        int backward, int checkOri, uint32_t *cand, int *count, int *choice, int *owner, int *assign,
-                                        int *result)
+                                        int backward, int checkOri, int mode, float nnratio, uint32_t *cand, int *count, int *choice,
+                                        int *owner, int *assign, int *result)
 {
     SbpArgs a;
+    a.mode = mode; a.nnratio = nnratio;
     a.kc = (const MtKp *)kc; a.dc = dc; a.uRight = uRight; a.curState = curState; a.nc = nc;
     a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY; a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);

@@ -202,6 +202,26 @@ public:
         return n;
     }
 
+    // Search matches between Frame keypoints and projected MapPoints. Returns number of matches (Used to track the local map) —
+    // reference include/ORBmatcher.h:48, src/ORBmatcher1.cc:45-215 (F.Nleft == -1).  One record per map point with what
+    // Frame::isInFrustum left on it: u, v = mTrackProjX / Y, invz = mTrackProjXR, angle = mTrackViewCos, octave = mnTrackScaleLevel,
+    // flags bit 0 = mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth > thFarPoints), bit 1 = Observations() > 0.
+    int SearchByProjection(const FrameView &F, const std::vector<float> &mvuRight, const std::vector<int8_t> &mvpMapPointsState,
+                           const std::vector<float> &mvScaleFactors, const std::vector<orbx_projection> &vpMapPoints,
+                           const Descriptors &vMapPointDescriptors, std::vector<int> &vnAssigned, const float th = 3)
+    {
+        const int nc = (int)F.mvKeysUn->size(), np = (int)vpMapPoints.size();
+        if ((int)mvpMapPointsState.size() != nc || (!mvuRight.empty() && (int)mvuRight.size() != nc) || vMapPointDescriptors.rows != np)
+            throw std::runtime_error("SearchByProjection: inconsistent array sizes");
+        vnAssigned.assign((size_t)nc, -1);
+        const int n = orbx_search_by_projection_points(m_, (const orbx_keypoint *)F.mvKeysUn->data(), F.mDescriptors->data.data(),
+                                                       mvuRight.empty() ? nullptr : mvuRight.data(), mvpMapPointsState.data(), nc, F.mnMinX, F.mnMaxX,
+                                                       F.mnMinY, F.mnMaxY, mvScaleFactors.data(), (int)mvScaleFactors.size(), vpMapPoints.data(),
+                                                       vMapPointDescriptors.data.data(), np, th, mfNNratio, vnAssigned.data());
+        if (n < 0) check(n, "SearchByProjection");
+        return n;
+    }
+
     // Frame::AssignFeaturesToGrid — reference src/Frame.cc:387-418: mGrid[ix][iy] = items[cellStart[ix * 48 + iy] .. cellStart[.. + 1])
     void AssignFeaturesToGrid(const FrameView &F, std::vector<int32_t> &cellStart, std::vector<int32_t> &items)
     {
