@@ -79,6 +79,20 @@ __device__ __forceinline__ int max3i(int a, int b, int c)
     return r;
 }
 
+// Number of set bits of a wave mask below this lane.
+__device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// `total` (wave-uniform) slots of an LDS queue for the active lanes of this wave: the first active lane does the one atomic.
+__device__ __forceinline__ unsigned wave_queue_alloc(unsigned *counter, unsigned total)
+{
+    unsigned base = 0;
+    if (mbcnt64(__ballot(1)) == 0) base = atomicAdd(counter, total);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
 // FAST corner score (cornerScore<16>: largest threshold for which the pixel is still a corner = max over the
 // 16 arcs of 9 of the minimum one-sided difference, minus 1).  `c` points at the centre pixel inside an LDS tile
 // with row pitch `tp`.  Only called for pixels that passed the ring test (sparse), so byte reads are fine here.
@@ -523,9 +537,12 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             const uint32_t f0 = fast_group_pretest<0>(w0, w3, w6, T4, C4);
             const uint32_t f1 = fast_group_pretest<1>(w0, w3, w6, T4, C4);
             const unsigned m = (((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4)) & valid;
-            const unsigned g0 = (m & 0x0F) != 0, g1 = (m & 0xF0) != 0;
-            if (g0 | g1) {
-                unsigned pos = atomicAdd(&gqCountR[round], g0 + g1);
+            const bool g0 = (m & 0x0F) != 0, g1 = (m & 0xF0) != 0;
+            // queue slots: one LDS atomic per wave and ballot prefix counts (a per-lane atomicAdd on one address is expanded by
+            // the compiler into a readlane loop over the active lanes: ~9 scalar instructions per passing strip)
+            const unsigned long long bg0 = __ballot(g0), bg1 = __ballot(g1);
+            if (bg0 | bg1) {
+                unsigned pos = wave_queue_alloc(&gqCountR[round], (unsigned)(__popcll(bg0) + __popcll(bg1))) + mbcnt64(bg0) + mbcnt64(bg1);
                 const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
                 if (g0) gq[pos++] = (uint16_t)e;
                 if (g1) gq[pos] = (uint16_t)(e | 1u);
@@ -588,8 +605,11 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
                 const unsigned keep = (((eMask >> cl) & 1u) ? lo : 0u) | (((eMask >> ch) & 1u) ? all & ~lo : 0u);
                 m &= keep << plo;
             }
-            if (m) {
-                unsigned pos = atomicAdd(&cqCountR[round], (unsigned)__popc(m));
+            const unsigned nc = __popc(m);  // 0..4
+            const unsigned long long n1 = __ballot((nc & 1u) != 0), n2 = __ballot((nc & 2u) != 0), n4 = __ballot((nc & 4u) != 0);
+            if (n1 | n2 | n4) {
+                unsigned pos = wave_queue_alloc(&cqCountR[round], (unsigned)(__popcll(n1) + 2 * __popcll(n2) + 4 * __popcll(n4))) +
+                               mbcnt64(n1) + 2u * mbcnt64(n2) + 4u * mbcnt64(n4);
                 while (m) {
                     const int k = __ffs(m) - 1;
                     m &= m - 1;
