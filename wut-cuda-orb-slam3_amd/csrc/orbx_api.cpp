@@ -574,7 +574,11 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
 
     // 0: one quadtree launch for all levels; 1: one launch per level, next to k_pyr_fast of the following level; k >= 2: groups
     // of k - 1 levels per launch after k_pyr_fast (LDS per instance sized by the group's largest quota)
-    static const int qtPerLevel = [] { const char *e = getenv("ORBX_QT_PER_LEVEL"); return e ? atoi(e) : 3; }();  // measured: 0 4.34 ms, 2 4.40, 3 4.17, 4 4.20, 5 4.29
+    // Default: pairs of levels for large batches (1024 frames: 0 4.34 ms, 2 4.40, 3 4.17, 4 4.20, 5 4.29); one launch for small ones,
+    // where the launches of a stream run one after the other and each costs an instance's latency (1 frame: 0.37 ms per call with
+    // one launch, 0.67 ms with pairs; 512 frames: 2.05 vs 2.10 ms; tools/experiments/qt_mode_sweep.sh)
+    static const int qtPerLevelEnv = [] { const char *e = getenv("ORBX_QT_PER_LEVEL"); return e ? atoi(e) : -1; }();
+    const int qtPerLevel = qtPerLevelEnv >= 0 ? qtPerLevelEnv : (nframes >= 640 ? 3 : 0);
     static const bool earlyBlur = [] { const char *e = getenv("ORBX_EARLY_BLUR"); return e ? atoi(e) != 0 : false; }();  // measured: 6.37 ms with early blur vs 6.02 ms with blur || quadtree
     hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * PROF_EVENTS] : nullptr;
     if (earlyBlur) {
