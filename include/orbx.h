@@ -256,6 +256,18 @@ int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const ui
                               float mbf, const orbx_projection *proj, const uint8_t *proj_desc, int np, float th, int forward,
                               int backward, int check_orientation, int32_t *assign);
 
+/* void Frame::UndistortKeyPoints() — reference src/Frame.cc:777-811 (decl include/Frame.h): mvKeysUn from mvKeys.
+ * k4 = fx, fy, cx, cy of static_cast<Pinhole*>(mpCamera)->toK(); dist = mDistCoef (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]], up to
+ * 12 floats); knew4 = fx, fy, cx, cy of mK.  dist[0] == 0 (or ndist == 0) copies, as the reference does; otherwise
+ * cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK): double arithmetic, five iterations.  out may alias kps. */
+int orbx_undistort_keypoints(orbx_matcher *m, const orbx_keypoint *kps, int n, const float *k4, const float *dist, int ndist,
+                             const float *knew4, orbx_keypoint *out);
+
+/* void Frame::ComputeImageBounds(const cv::Mat &imLeft) — reference src/Frame.cc:813-845: bounds = mnMinX, mnMaxX, mnMinY, mnMaxY
+ * (the undistorted image corners; 0, cols, 0, rows without distortion) — the bounds the grid / search entry points take. */
+int orbx_compute_image_bounds(orbx_matcher *m, int cols, int rows, const float *k4, const float *dist, int ndist, const float *knew4,
+                              float *bounds);
+
 /* int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th, const bool bFarPoints,
  * const float thFarPoints) — reference src/ORBmatcher1.cc:45-215 (decl include/ORBmatcher.h:48), the F.Nleft == -1 branch, called
  * every frame by Tracking::SearchLocalPoints (src/Tracking4.cc:737).  One orbx_projection per map point with the fields

@@ -65,6 +65,8 @@ def lib() -> ctypes.CDLL:
                                                   c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
         L.oracle_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
                                                          c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
+        L.oracle_undistort_keypoints.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+        L.oracle_compute_image_bounds.argtypes = [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -300,3 +302,27 @@ def search_by_projection_points(kc, dc, cur_state, bounds, scale_factors, mps, m
                                                  len(kc), *[float(b) for b in bounds], sf.ctypes.data, len(sf), pr.ctypes.data,
                                                  pd.ctypes.data, len(pr), float(th), float(nnratio), assign.ctypes.data)
     return n, assign
+
+
+def _camera(k4, dist, knew4):
+    k4 = np.ascontiguousarray(k4, np.float32); d = np.ascontiguousarray(dist, np.float32).ravel()
+    kn = k4 if knew4 is None else np.ascontiguousarray(knew4, np.float32)
+    assert k4.shape == (4,) and kn.shape == (4,) and len(d) <= 12
+    return k4, d, kn
+
+
+def undistort_keypoints(kps, k4, dist, knew4=None):
+    """Frame::UndistortKeyPoints (reference src/Frame.cc:777-811) -> mvKeysUn.  k4 = (fx, fy, cx, cy), dist = mDistCoef."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    k4, d, kn = _camera(k4, dist, knew4)
+    out = np.empty_like(kps)
+    lib().oracle_undistort_keypoints(kps.ctypes.data, len(kps), k4.ctypes.data, d.ctypes.data, len(d), kn.ctypes.data, out.ctypes.data)
+    return out
+
+
+def compute_image_bounds(cols, rows, k4, dist, knew4=None):
+    """Frame::ComputeImageBounds (reference src/Frame.cc:813-845) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    k4, d, kn = _camera(k4, dist, knew4)
+    b = np.zeros(4, np.float32)
+    lib().oracle_compute_image_bounds(int(cols), int(rows), k4.ctypes.data, d.ctypes.data, len(d), kn.ctypes.data, b.ctypes.data)
+    return tuple(float(v) for v in b)

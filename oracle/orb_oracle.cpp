@@ -1248,6 +1248,64 @@ int oracle_search_by_projection_points(const oracle_keypoint *kc, const uint8_t 
     return nmatches;
 }
 
+// cv::undistortPoints(src, dst, cameraMatrix, distCoeffs, R = noArray(), P) as Frame::UndistortKeyPoints / ComputeImageBounds call it
+// (reference src/Frame.cc:777-811, :813-845; OpenCV is an external dependency of the reference, not vendored: 4.x, calib3d
+// cvUndistortPointsInternal restated here from its published source — parity unpinned): everything in double, five fixed-point
+// iterations of the inverse Brown-Conrady model (TermCriteria(MAX_ITER, 5, 0.01)), coefficients k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4]]],
+// then the new camera matrix P (fx fy cx cy; zero skew).  k / kNew: fx, fy, cx, cy.
+static void undistortPoint(double u, double v, const double K[4], const double k[12], const double KN[4], float &ox, float &oy)
+{
+    const double fx = K[0], fy = K[1], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[3];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    // RR = P * I: rows (fx' 0 cx'), (0 fy' cy'), (0 0 1)
+    const double xx = KN[0] * x + 0. * y + KN[2], yy = 0. * x + KN[1] * y + KN[3], ww = 1. / (0. * x + 0. * y + 1.);
+    ox = (float)(xx * ww);
+    oy = (float)(yy * ww);
+}
+
+static void loadCamera(const float *k4, const float *dist, int ndist, const float *knew4, double K[4], double k[12], double KN[4])
+{
+    for (int i = 0; i < 4; ++i) { K[i] = k4[i]; KN[i] = knew4[i]; }
+    for (int i = 0; i < 12; ++i) k[i] = i < ndist ? (double)dist[i] : 0.;
+}
+
+// Frame::UndistortKeyPoints — reference src/Frame.cc:777-811: copy when distCoef[0] == 0, else undistort the positions and keep
+// the other fields.  Returns 0.
+int oracle_undistort_keypoints(const oracle_keypoint *kps, int n, const float *k4, const float *dist, int ndist, const float *knew4,
+                               oracle_keypoint *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = kps[i];
+    if (ndist <= 0 || dist[0] == 0.0) return 0;
+    double K[4], k[12], KN[4];
+    loadCamera(k4, dist, ndist, knew4, K, k, KN);
+    for (int i = 0; i < n; ++i) undistortPoint(kps[i].x, kps[i].y, K, k, KN, out[i].x, out[i].y);
+    return 0;
+}
+
+// Frame::ComputeImageBounds — reference src/Frame.cc:813-845: bounds[4] = mnMinX, mnMaxX, mnMinY, mnMaxY.
+int oracle_compute_image_bounds(int cols, int rows, const float *k4, const float *dist, int ndist, const float *knew4, float *bounds)
+{
+    if (ndist <= 0 || dist[0] == 0.0) { bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows; return 0; }
+    double K[4], k[12], KN[4];
+    loadCamera(k4, dist, ndist, knew4, K, k, KN);
+    const float cx[4] = {0.0f, (float)cols, 0.0f, (float)cols}, cy[4] = {0.0f, 0.0f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; ++i) undistortPoint(cx[i], cy[i], K, k, KN, ux[i], uy[i]);
+    bounds[0] = std::min(ux[0], ux[2]); bounds[1] = std::max(ux[1], ux[3]);
+    bounds[2] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
+    return 0;
+}
+
 }  // extern "C"
 
 extern "C" {

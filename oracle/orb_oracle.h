@@ -131,6 +131,12 @@ int oracle_search_by_projection_points(const oracle_keypoint *kc, const uint8_t 
                                        float min_x, float max_x, float min_y, float max_y, const float *scale_factors, int nlevels,
                                        const oracle_projection *mps, const uint8_t *dmp, int np, float th, float nnratio, int32_t *assign);
 
+/* Frame::UndistortKeyPoints / Frame::ComputeImageBounds (src/Frame.cc:777-845) over cv::undistortPoints (OpenCV 4.x, restated;
+ * parity unpinned).  k4 / knew4 = fx, fy, cx, cy of toK() / mK; dist = mDistCoef (4, 5, 8 or 12 floats). */
+int oracle_undistort_keypoints(const oracle_keypoint *kps, int n, const float *k4, const float *dist, int ndist, const float *knew4,
+                               oracle_keypoint *out);
+int oracle_compute_image_bounds(int cols, int rows, const float *k4, const float *dist, int ndist, const float *knew4, float *bounds);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

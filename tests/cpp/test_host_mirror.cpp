@@ -178,6 +178,23 @@ static int runSearchByProjection()
     ASSERT_TRUE(n1 > 50);
     for (int i = 0; i < nc; ++i) ASSERT_EQ(assigned[i], ref[i]);
 
+    // Frame::UndistortKeyPoints / ComputeImageBounds with EuRoC's camera (src/Frame.cc:777-845)
+    {
+        const float K[4] = {458.654f, 457.296f, 367.215f, 248.375f};
+        const std::vector<float> mDistCoef = {-0.28340811f, 0.07395907f, 0.00019359f, 1.76187114e-05f};
+        std::vector<orbx::KeyPoint> mvKeysUn;
+        matcher.UndistortKeyPoints(keysCur, K, mDistCoef, K, mvKeysUn);
+        std::vector<oracle_keypoint> refUn(keysCur.size());
+        oracle_undistort_keypoints((const oracle_keypoint *)keysCur.data(), nc, K, mDistCoef.data(), 4, K, refUn.data());
+        ASSERT_TRUE(memcmp(mvKeysUn.data(), refUn.data(), refUn.size() * sizeof(oracle_keypoint)) == 0);
+        orbx::FrameView B;
+        matcher.ComputeImageBounds(w, h, K, mDistCoef, K, B);
+        float rb[4];
+        oracle_compute_image_bounds(w, h, K, mDistCoef.data(), 4, K, rb);
+        ASSERT_TRUE(B.mnMinX == rb[0] && B.mnMaxX == rb[1] && B.mnMinY == rb[2] && B.mnMaxY == rb[3]);
+        ASSERT_TRUE(B.mnMinX < 0.f && B.mnMaxX > (float)w);
+    }
+
     // local map: the same points as Frame::isInFrustum would leave them (mTrackViewCos, mnTrackScaleLevel, mTrackProjXR)
     for (int i = 0; i < np; ++i) { proj[i].angle = i % 2 ? 0.9995f : 0.97f; proj[i].invz = proj[i].u - 10.f; }
     orbx::ORBmatcher local(0.8f);

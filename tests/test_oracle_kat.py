@@ -291,3 +291,34 @@ def test_search_by_projection_map_points_properties(orc):
     two_k["octave"][1] = 1
     nm, assign = orc.search_by_projection_points(two_k, two_d, free[:2], bounds, sf, one, mpd, 1.0, 0.8)
     assert nm == 1 and assign[0] == 0 and assign[1] == -1
+
+
+def test_undistort_keypoints_inverts_the_distortion_model(orc):
+    """Frame::UndistortKeyPoints restated in the oracle (reference src/Frame.cc:777-811 over cv::undistortPoints): pushing the
+    undistorted points forward through the Brown-Conrady model (k1 k2 p1 p2 k3) must land on the input pixels (five iterations
+    converge to under 0.01 px away from the corners for EuRoC's distortion); without distortion the call copies; the image bounds are the
+    undistorted corners."""
+    k4 = (458.654, 457.296, 367.215, 248.375)
+    dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+    rng = np.random.default_rng(0)
+    kps = np.zeros(2000, orc.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, 752, len(kps)); kps["y"] = rng.uniform(0, 480, len(kps)); kps["octave"] = 3
+    un = orc.undistort_keypoints(kps, k4, dist)
+    fx, fy, cx, cy = k4
+    k1, k2, p1, p2, k3 = dist
+    x = (un["x"].astype(np.float64) - cx) / fx; y = (un["y"].astype(np.float64) - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    err = np.hypot(xd * fx + cx - kps["x"], yd * fy + cy - kps["y"])
+    # five fixed iterations: converged in the middle of the image, a few tenths of a pixel short in the far corners (as OpenCV is)
+    assert err[r2 < 0.5 ** 2].max() < 0.01 and np.median(err) < 0.01 and err.max() < 0.5
+    assert (un["octave"] == 3).all()
+    assert orc.undistort_keypoints(kps, k4, (0.0, 0.5, 0, 0)).tobytes() == kps.tobytes()
+    b = orc.compute_image_bounds(752, 480, k4, dist)
+    c = orc.undistort_keypoints(np.array([(0, 0, 0, 0, 0, 0, 0), (752, 0, 0, 0, 0, 0, 0), (0, 480, 0, 0, 0, 0, 0), (752, 480, 0, 0, 0, 0, 0)],
+                                         orc.KEYPOINT_DTYPE), k4, dist)
+    assert b == (min(c["x"][0], c["x"][2]), max(c["x"][1], c["x"][3]), min(c["y"][0], c["y"][1]), max(c["y"][2], c["y"][3]))
+    assert b[0] < 0 and b[1] > 752 and b[2] < 0 and b[3] > 480  # barrel distortion: the undistorted image is larger
+    assert orc.compute_image_bounds(752, 480, k4, (0.0,) * 4) == (0.0, 752.0, 0.0, 480.0)

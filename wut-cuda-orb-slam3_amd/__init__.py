@@ -62,6 +62,8 @@ ABI_SYMBOLS = [
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points",
+    "orbx_undistort_keypoints",
+    "orbx_compute_image_bounds",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -130,6 +132,8 @@ def load_library() -> ctypes.CDLL:
                                               c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
     lib.orbx_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
                                                      c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
+    lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -378,6 +382,33 @@ class ORBmatcher:
     # ---- SURVEY §8(f) rank 2 ----------------------------------------------------------------------------------------
     FRAME_GRID_COLS = 64
     FRAME_GRID_ROWS = 48
+
+    @staticmethod
+    def _camera(k4, dist, knew4):
+        k4 = np.ascontiguousarray(k4, np.float32)
+        d = np.ascontiguousarray(dist, np.float32).ravel()
+        kn = k4 if knew4 is None else np.ascontiguousarray(knew4, np.float32)
+        if k4.shape != (4,) or kn.shape != (4,) or len(d) > 12:
+            raise ValueError("camera: k4 / knew4 = (fx, fy, cx, cy), at most 12 distortion coefficients")
+        return k4, d, kn
+
+    def UndistortKeyPoints(self, kps, k4, dist, knew4=None):
+        """Frame::UndistortKeyPoints (reference src/Frame.cc:777-811) -> mvKeysUn.  k4 = toK() as (fx, fy, cx, cy), dist = mDistCoef,
+        knew4 = mK (default: k4)."""
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+        k4, d, kn = self._camera(k4, dist, knew4)
+        out = np.empty_like(kps)
+        _check(self._lib.orbx_undistort_keypoints(self._h, kps.ctypes.data, len(kps), k4.ctypes.data, d.ctypes.data if len(d) else None, len(d),
+                                                  kn.ctypes.data, out.ctypes.data), "orbx_undistort_keypoints")
+        return out
+
+    def ComputeImageBounds(self, cols: int, rows: int, k4, dist, knew4=None):
+        """Frame::ComputeImageBounds (reference src/Frame.cc:813-845) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+        k4, d, kn = self._camera(k4, dist, knew4)
+        b = np.zeros(4, np.float32)
+        _check(self._lib.orbx_compute_image_bounds(self._h, int(cols), int(rows), k4.ctypes.data, d.ctypes.data if len(d) else None, len(d),
+                                                   kn.ctypes.data, b.ctypes.data), "orbx_compute_image_bounds")
+        return tuple(float(v) for v in b)
 
     def AssignFeaturesToGrid(self, kps, bounds):
         """Frame::AssignFeaturesToGrid (reference src/Frame.cc:387-418) for the undistorted keypoints `kps` and the image bounds

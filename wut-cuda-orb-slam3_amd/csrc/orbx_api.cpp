@@ -992,6 +992,51 @@ static int checkGridBounds(float minX, float maxX, float minY, float maxY, const
     return ORBX_OK;
 }
 
+// Frame::UndistortKeyPoints — reference src/Frame.cc:777-811.
+static int checkCamera(const float *k4, const float *dist, int ndist, const float *knew4, const char *fn)
+{
+    if (!k4 || !knew4 || ndist < 0 || ndist > 12 || (ndist > 0 && !dist)) return setError(ORBX_ERR_INVALID_ARG, "%s: bad camera arguments", fn);
+    if (!(k4[0] != 0.f) || !(k4[1] != 0.f)) return setError(ORBX_ERR_INVALID_ARG, "%s: zero focal length", fn);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_keypoint *kps, int n, const float *k4, const float *dist, int ndist,
+                                        const float *knew4, orbx_keypoint *out)
+{
+    if (!m || n < 0 || (n > 0 && (!kps || !out))) return setError(ORBX_ERR_INVALID_ARG, "orbx_undistort_keypoints: bad argument");
+    int rc = checkCamera(k4, dist, ndist, knew4, "orbx_undistort_keypoints");
+    if (rc != ORBX_OK) return rc;
+    if (n == 0) return ORBX_OK;
+    if (ndist == 0 || dist[0] == 0.0) {  // mvKeysUn = mvKeys (:779-783)
+        if (out != kps) memcpy(out, kps, (size_t)n * sizeof(orbx_keypoint));
+        return ORBX_OK;
+    }
+    if (n > m->maxT) return setError(ORBX_ERR_CAPACITY, "%d keypoints exceed the matcher capacity %d", n, m->maxT);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(m->d_kr.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(orbxLaunchUndistort(m->stream, m->d_kr.p, m->d_kl.p, n, k4, dist, ndist, knew4));
+    HIP_TRY(hipMemcpyAsync(out, m->d_kl.p, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+// Frame::ComputeImageBounds — reference src/Frame.cc:813-845: the four image corners through the same kernel.
+extern "C" int orbx_compute_image_bounds(orbx_matcher *m, int cols, int rows, const float *k4, const float *dist, int ndist,
+                                         const float *knew4, float *bounds)
+{
+    if (!m || !bounds || cols <= 0 || rows <= 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_image_bounds: bad argument");
+    int rc = checkCamera(k4, dist, ndist, knew4, "orbx_compute_image_bounds");
+    if (rc != ORBX_OK) return rc;
+    if (ndist == 0 || dist[0] == 0.0) { bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows; return ORBX_OK; }
+    orbx_keypoint c[4], u[4];
+    memset(c, 0, sizeof c);
+    c[1].x = (float)cols; c[2].y = (float)rows; c[3].x = (float)cols; c[3].y = (float)rows;
+    if ((rc = orbx_undistort_keypoints(m, c, 4, k4, dist, ndist, knew4, u)) != ORBX_OK) return rc;
+    bounds[0] = std::min(u[0].x, u[2].x); bounds[1] = std::max(u[1].x, u[3].x);
+    bounds[2] = std::min(u[0].y, u[1].y); bounds[3] = std::max(u[2].y, u[3].y);
+    return ORBX_OK;
+}
+
 // Frame::AssignFeaturesToGrid — reference src/Frame.cc:387-418 (+ PosInGrid :755-766).
 extern "C" int orbx_assign_features_to_grid(orbx_matcher *m, const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y,
                                             float max_y, int32_t *cell_start, int32_t *items)

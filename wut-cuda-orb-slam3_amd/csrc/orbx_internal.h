@@ -110,6 +110,7 @@ struct OrbxStereoLevels {
 hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void *kl, int nl, const void *kr, const int *bestIdx,
                                   const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist);
 
+hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4);
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
                                int *items, int *cellOf);
 bool orbxSearchInitInLds(int n1, int n2, int level0of2);

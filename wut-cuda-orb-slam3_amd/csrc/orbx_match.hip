@@ -990,3 +990,52 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
     hipLaunchKernelGGL(k_sbp_resolve, dim3(1), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
+
+
+// ---- Frame::UndistortKeyPoints / ComputeImageBounds (reference src/Frame.cc:777-845) ----------------------------------------------
+// cv::undistortPoints with R = noArray() and P = mK: per point, in double (f64 is IEEE here and the library is built with
+// -ffp-contract=off, so the five fixed-point iterations round exactly like the host's): normalise with the old camera matrix,
+// invert the Brown-Conrady distortion, apply the new matrix.  One thread per point; the other keypoint fields are copied.
+struct UndistortArgs {
+    const MtKp *in;
+    MtKp *out;
+    int n;
+    double K[4], KN[4], k[12];  // fx fy cx cy (old / new), k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+};
+
+__global__ __launch_bounds__(256) void k_undistort(UndistortArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    MtKp kp = a.in[i];
+    const double u = (double)kp.x, v = (double)kp.y;
+    const double ifx = __ddiv_rn(1., a.K[0]), ify = __ddiv_rn(1., a.K[1]), cx = a.K[2], cy = a.K[3];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    const double *k = a.k;
+#pragma nounroll
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = __ddiv_rn(1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2, 1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = a.KN[0] * x + 0. * y + a.KN[2], yy = 0. * x + a.KN[1] * y + a.KN[3], ww = __ddiv_rn(1., 0. * x + 0. * y + 1.);
+    kp.x = (float)(xx * ww);
+    kp.y = (float)(yy * ww);
+    a.out[i] = kp;
+}
+
+hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4)
+{
+    if (n <= 0) return hipSuccess;
+    UndistortArgs a;
+    a.in = (const MtKp *)in; a.out = (MtKp *)out; a.n = n;
+    for (int i = 0; i < 4; ++i) { a.K[i] = (double)k4[i]; a.KN[i] = (double)knew4[i]; }
+    for (int i = 0; i < 12; ++i) a.k[i] = i < ndist ? (double)dist[i] : 0.;
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

@@ -222,6 +222,24 @@ public:
         return n;
     }
 
+    // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811: mvKeysUn from mvKeys.  K = toK() and mK as {fx, fy, cx, cy},
+    // mDistCoef as the reference's 4 / 5 / 8 / 12 floats (copies when mDistCoef[0] == 0).
+    void UndistortKeyPoints(const std::vector<KeyPoint> &mvKeys, const float (&K)[4], const std::vector<float> &mDistCoef, const float (&mK)[4],
+                            std::vector<KeyPoint> &mvKeysUn)
+    {
+        mvKeysUn.resize(mvKeys.size());
+        check(orbx_undistort_keypoints(m_, (const orbx_keypoint *)mvKeys.data(), (int)mvKeys.size(), K, mDistCoef.data(), (int)mDistCoef.size(), mK,
+                                       (orbx_keypoint *)mvKeysUn.data()), "UndistortKeyPoints");
+    }
+
+    // Frame::ComputeImageBounds — reference src/Frame.cc:813-845: fills F.mnMinX / mnMaxX / mnMinY / mnMaxY.
+    void ComputeImageBounds(int cols, int rows, const float (&K)[4], const std::vector<float> &mDistCoef, const float (&mK)[4], FrameView &F)
+    {
+        float b[4];
+        check(orbx_compute_image_bounds(m_, cols, rows, K, mDistCoef.data(), (int)mDistCoef.size(), mK, b), "ComputeImageBounds");
+        F.mnMinX = b[0]; F.mnMaxX = b[1]; F.mnMinY = b[2]; F.mnMaxY = b[3];
+    }
+
     // Frame::AssignFeaturesToGrid — reference src/Frame.cc:387-418: mGrid[ix][iy] = items[cellStart[ix * 48 + iy] .. cellStart[.. + 1])
     void AssignFeaturesToGrid(const FrameView &F, std::vector<int32_t> &cellStart, std::vector<int32_t> &items)
     {
