@@ -300,6 +300,34 @@ void orbx_synth_frame(uint64_t frame_index, int w, int h, uint8_t *out, ptrdiff_
 /* Per-level geometry for a w x h image: sizes out[level] (reference src/ORBextractor.cc:1313). */
 int orbx_level_sizes(const orbx_extractor *ex, int w, int h, int32_t *lw, int32_t *lh);
 
+/* ---- DBoW2 vocabulary ---------------------------------------------------------------------------------------
+ * ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (reference include/ORBVocabulary.h, vendored
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h): the k-ary tree lives in HBM (child descriptors contiguous per node) and
+ * Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:768-775) become one call. */
+typedef struct orbx_vocabulary orbx_vocabulary;
+
+/* The tree as TemplatedVocabulary::loadFromTextFile builds it (TemplatedVocabulary.h:1338-1423): node 0 = root, parent[i] < i, one
+ * 32-byte descriptor and one weight per node, leaves numbered as words in node order; scoring / weighting = the enums of
+ * BowVector.h:39-56 (L1_NORM 0, L2_NORM 1, CHI_SQUARE 2, KL 3, BHATTACHARYYA 4, DOT_PRODUCT 5; TF_IDF 0, TF 1, IDF 2, BINARY 3). */
+int orbx_vocabulary_create(int device, int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                           const uint8_t *desc, const double *weight, orbx_vocabulary **out);
+/* bool loadFromTextFile(const std::string &filename) — the ORBvoc.txt format ("k L scoring weighting", then "parent is_leaf d0..d31
+ * weight" per node). */
+int orbx_vocabulary_load_text(int device, const char *path, orbx_vocabulary **out);
+void orbx_vocabulary_destroy(orbx_vocabulary *v);
+int orbx_vocabulary_size(const orbx_vocabulary *v); /* unsigned int size() const: number of words */
+
+/* void transform(const std::vector<TDescriptor> &features, BowVector &v, FeatureVector &fv, int levelsup) const —
+ * TemplatedVocabulary.h:1127-1196 with the descent of :1218-1261 (first child with the strictly smallest FORB::distance).
+ * desc: n x 32 bytes (n <= 16384).  BowVector = (bow_word[i], bow_value[i]), i < *n_bow, ascending word id, weighted and
+ * normalised as the vocabulary's weighting / scoring prescribe (doubles, bit-identical to the std::map arithmetic).
+ * FeatureVector = node fv_node[j], j < *n_fv (ascending), holding features fv_feature[fv_start[j] .. fv_start[j + 1]) in
+ * increasing order.  feat_word / feat_node (optional): the word and the node `levelsup` levels up of every feature, -1 for a
+ * stopped word (weight <= 0).  Capacities: n entries each, fv_start n + 1.  Returns *n_bow or a negative status. */
+int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc, int n, int levelsup, int32_t *feat_word, int32_t *feat_node,
+                              int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start, int32_t *fv_feature,
+                              int32_t *n_fv);
+
 #ifdef __cplusplus
 }
 #endif

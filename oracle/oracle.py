@@ -67,6 +67,12 @@ def lib() -> ctypes.CDLL:
                                                          c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
         L.oracle_undistort_keypoints.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.oracle_compute_image_bounds.argtypes = [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+        L.oracle_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.oracle_vocabulary_create.restype = c_void_p
+        L.oracle_vocabulary_destroy.argtypes = [c_void_p]
+        L.oracle_vocabulary_destroy.restype = None
+        L.oracle_vocabulary_words.argtypes = [c_void_p]
+        L.oracle_vocabulary_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -326,3 +332,43 @@ def compute_image_bounds(cols, rows, k4, dist, knew4=None):
     b = np.zeros(4, np.float32)
     lib().oracle_compute_image_bounds(int(cols), int(rows), k4.ctypes.data, d.ctypes.data, len(d), kn.ctypes.data, b.ctypes.data)
     return tuple(float(v) for v in b)
+
+
+class Vocabulary:
+    """DBoW2 TemplatedVocabulary<FORB> as Frame::ComputeBoW uses it (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1261).
+    parent / is_leaf / desc / weight: one entry per node in loadFromTextFile's order, node 0 = root."""
+
+    def __init__(self, k, L, scoring, weighting, parent, is_leaf, desc, weight):
+        self.parent = np.ascontiguousarray(parent, np.int32)
+        self.is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.weight = np.ascontiguousarray(weight, np.float64)
+        n = len(self.parent)
+        assert len(self.is_leaf) == n and len(self.desc) == n and len(self.weight) == n
+        self._h = lib().oracle_vocabulary_create(int(k), int(L), int(scoring), int(weighting), n, self.parent.ctypes.data,
+                                                 self.is_leaf.ctypes.data, self.desc.ctypes.data, self.weight.ctypes.data)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().oracle_vocabulary_destroy(self._h)
+        except Exception:  # interpreter shutdown
+            pass
+        self._h = None
+
+    def size(self):
+        return lib().oracle_vocabulary_words(self._h)
+
+    def transform(self, desc, levelsup=4):
+        """-> dict(feat_word, feat_node, bow_word, bow_value, fv_node, fv_start, fv_feature): BowVector in ascending word order,
+        FeatureVector as CSR over ascending node ids."""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        fw = np.zeros(n, np.int32); fn = np.zeros(n, np.int32)
+        bw = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1), np.float64); nb = np.zeros(1, np.int32)
+        vn = np.zeros(max(n, 1), np.int32); vs = np.zeros(n + 1, np.int32); vf = np.zeros(max(n, 1), np.int32); nv = np.zeros(1, np.int32)
+        lib().oracle_vocabulary_transform(self._h, d.ctypes.data, n, int(levelsup), fw.ctypes.data, fn.ctypes.data, bw.ctypes.data,
+                                          bv.ctypes.data, nb.ctypes.data, vn.ctypes.data, vs.ctypes.data, vf.ctypes.data, nv.ctypes.data)
+        nb, nv = int(nb[0]), int(nv[0])
+        return dict(feat_word=fw, feat_node=fn, bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=vn[:nv].copy(),
+                    fv_start=vs[:nv + 1].copy(), fv_feature=vf[:int(vs[nv])].copy())

@@ -24,6 +24,7 @@
 #include <list>
 #include <thread>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "../include/orbx_synth.h"
@@ -1304,6 +1305,116 @@ int oracle_compute_image_bounds(int cols, int rows, const float *k4, const float
     bounds[0] = std::min(ux[0], ux[2]); bounds[1] = std::max(ux[1], ux[3]);
     bounds[2] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
     return 0;
+}
+
+// ---- DBoW2 (vendored in the reference: Thirdparty/DBoW2/DBoW2) — SURVEY 8f rank 4 ---------------------------------------------------
+// TemplatedVocabulary<FORB::TDescriptor, FORB> as Frame::ComputeBoW uses it (reference src/Frame.cc:768-775 ->
+// TemplatedVocabulary.h:1127-1196 transform(features, BowVector, FeatureVector, levelsup) -> :1218-1261 transform(feature, ..) with
+// FORB::distance, FORB.cpp:79-98).  The tree is given as the loader builds it (loadFromTextFile :1338-1423): node 0 is the root,
+// node i > 0 has parent[i] < i, children in node-id order, word ids in order of the leaves.
+struct OracleVocabulary {
+    int k, L, scoring, weighting;
+    std::vector<std::vector<int> > children;
+    std::vector<int> parent, wordId;
+    std::vector<uint8_t> desc;
+    std::vector<double> weight;
+    int nWords;
+};
+
+void *oracle_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                               const uint8_t *desc, const double *weight)
+{
+    OracleVocabulary *v = new OracleVocabulary;
+    v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting;
+    v->children.resize(n_nodes); v->parent.assign(parent, parent + n_nodes); v->wordId.assign(n_nodes, 0);
+    v->desc.assign(desc, desc + (size_t)n_nodes * 32); v->weight.assign(weight, weight + n_nodes);
+    v->nWords = 0;
+    for (int nid = 1; nid < n_nodes; ++nid) {
+        v->children[parent[nid]].push_back(nid);
+        if (is_leaf[nid] > 0) v->wordId[nid] = v->nWords++;
+    }
+    return v;
+}
+void oracle_vocabulary_destroy(void *h) { delete (OracleVocabulary *)h; }
+int oracle_vocabulary_words(void *h) { return ((OracleVocabulary *)h)->nWords; }
+
+// transform(feature, word_id, weight, nid, levelsup) — TemplatedVocabulary.h:1218-1261.  (A leaf above the level asked for
+// leaves *nid untouched in the reference, whose caller passes an uninitialised variable; here it then holds the leaf's id.)
+static void vocTransformOne(const OracleVocabulary &V, const uint8_t *feature, int &word_id, double &weight, int &nid, int levelsup)
+{
+    const int nid_level = V.L - levelsup;
+    bool nidSet = false;
+    if (nid_level <= 0) { nid = 0; nidSet = true; }
+    int final_id = 0, current_level = 0;
+    do {
+        ++current_level;
+        const std::vector<int> &nodes = V.children[final_id];
+        final_id = nodes[0];
+        double best_d = oracle_hamming256(feature, &V.desc[(size_t)final_id * 32]);
+        for (size_t c = 1; c < nodes.size(); ++c) {
+            const int id = nodes[c];
+            const double d = oracle_hamming256(feature, &V.desc[(size_t)id * 32]);
+            if (d < best_d) { best_d = d; final_id = id; }
+        }
+        if (current_level == nid_level) { nid = final_id; nidSet = true; }
+    } while (!V.children[final_id].empty());
+    if (!nidSet) nid = final_id;
+    word_id = V.wordId[final_id];
+    weight = V.weight[final_id];
+}
+
+// transform(features, v, fv, levelsup) — TemplatedVocabulary.h:1127-1196 with BowVector::addWeight / addIfNotExist / normalize
+// (BowVector.cpp:34-84) and FeatureVector::addFeature (FeatureVector.cpp:31-45) on std::map, exactly as there.  Outputs: the
+// BowVector as (word, value) in ascending word order, the FeatureVector as CSR over ascending node ids, plus the per-feature
+// word / node (−1 where the word is stopped, weight <= 0).  Returns the number of words in the BowVector.
+int oracle_vocabulary_transform(void *h, const uint8_t *desc, int n, int levelsup, int32_t *feat_word, int32_t *feat_node,
+                                int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
+                                int32_t *fv_feature, int32_t *n_fv)
+{
+    const OracleVocabulary &V = *(OracleVocabulary *)h;
+    std::map<unsigned, double> v;
+    std::map<unsigned, std::vector<unsigned> > fv;
+    *n_bow = 0; *n_fv = 0; fv_start[0] = 0;
+    if (V.children.empty() || V.children[0].empty()) return 0;  // empty()
+    const bool must = V.scoring != 5;                 // DotProductScoring does not normalise (ScoringObject.h:74-89)
+    const bool l2 = V.scoring == 1;                   // L2Scoring: L2, all others L1
+    for (int i = 0; i < n; ++i) {
+        int id, nid; double w;
+        vocTransformOne(V, desc + (size_t)i * 32, id, w, nid, levelsup);
+        feat_word[i] = w > 0 ? id : -1; feat_node[i] = w > 0 ? nid : -1;
+        if (!(w > 0)) continue;  // stopped
+        if (V.weighting == 0 || V.weighting == 1) {   // TF_IDF, TF: addWeight
+            std::map<unsigned, double>::iterator vit = v.lower_bound((unsigned)id);
+            if (vit != v.end() && !(v.key_comp()((unsigned)id, vit->first))) vit->second += w;
+            else v.insert(vit, std::make_pair((unsigned)id, w));
+        } else {                                      // IDF, BINARY: addIfNotExist
+            std::map<unsigned, double>::iterator vit = v.lower_bound((unsigned)id);
+            if (vit == v.end() || v.key_comp()((unsigned)id, vit->first)) v.insert(vit, std::make_pair((unsigned)id, w));
+        }
+        std::map<unsigned, std::vector<unsigned> >::iterator fit = fv.lower_bound((unsigned)nid);
+        if (fit != fv.end() && fit->first == (unsigned)nid) fit->second.push_back((unsigned)i);
+        else { fit = fv.insert(fit, std::make_pair((unsigned)nid, std::vector<unsigned>())); fit->second.push_back((unsigned)i); }
+    }
+    if ((V.weighting == 0 || V.weighting == 1) && !v.empty() && !must) {
+        const double nd = v.size();
+        for (std::map<unsigned, double>::iterator vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
+    }
+    if (must) {
+        double norm = 0.0;
+        if (!l2) { for (std::map<unsigned, double>::iterator it = v.begin(); it != v.end(); ++it) norm += fabs(it->second); }
+        else { for (std::map<unsigned, double>::iterator it = v.begin(); it != v.end(); ++it) norm += it->second * it->second; norm = sqrt(norm); }
+        if (norm > 0.0) for (std::map<unsigned, double>::iterator it = v.begin(); it != v.end(); ++it) it->second /= norm;
+    }
+    int nb = 0;
+    for (std::map<unsigned, double>::iterator it = v.begin(); it != v.end(); ++it, ++nb) { bow_word[nb] = (int32_t)it->first; bow_value[nb] = it->second; }
+    int nf = 0, pos = 0;
+    for (std::map<unsigned, std::vector<unsigned> >::iterator it = fv.begin(); it != fv.end(); ++it, ++nf) {
+        fv_node[nf] = (int32_t)it->first; fv_start[nf] = pos;
+        for (size_t j = 0; j < it->second.size(); ++j) fv_feature[pos++] = (int32_t)it->second[j];
+    }
+    fv_start[nf] = pos;
+    *n_bow = nb; *n_fv = nf;
+    return nb;
 }
 
 }  // extern "C"

@@ -137,6 +137,17 @@ int oracle_undistort_keypoints(const oracle_keypoint *kps, int n, const float *k
                                oracle_keypoint *out);
 int oracle_compute_image_bounds(int cols, int rows, const float *k4, const float *dist, int ndist, const float *knew4, float *bounds);
 
+/* DBoW2 vocabulary tree as Frame::ComputeBoW uses it (src/Frame.cc:768-775 -> Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1261).
+ * Nodes as loadFromTextFile builds them: node 0 = root, parent[i] < i, word ids in leaf order; scoring / weighting = the enums of
+ * BowVector.h:39-56 (L1_NORM 0 .. DOT_PRODUCT 5; TF_IDF 0, TF 1, IDF 2, BINARY 3). */
+void *oracle_vocabulary_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                               const uint8_t *desc, const double *weight);
+void oracle_vocabulary_destroy(void *h);
+int oracle_vocabulary_words(void *h);
+int oracle_vocabulary_transform(void *h, const uint8_t *desc, int n, int levelsup, int32_t *feat_word, int32_t *feat_node,
+                                int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
+                                int32_t *fv_feature, int32_t *n_fv);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

@@ -208,6 +208,70 @@ static int runSearchByProjection()
     return 0;
 }
 
+// Frame::ComputeBoW (src/Frame.cc:768-775): mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) on a synthetic
+// 6-ary, 4-level vocabulary (the reference's ORBvoc.txt is not in its tree) with the extractor's own descriptors.
+static int runComputeBoW()
+{
+    const int k = 6, L = 4, w = 640, h = 480;
+    std::vector<int32_t> parent(1, 0);
+    std::vector<uint8_t> isLeaf(1, 0), desc(32, 0);
+    std::vector<double> weight(1, 0.0);
+    uint64_t rs = 88172645463325252ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+    // breadth first: level by level, every node of a level gets k children (ids ascend with the parent's)
+    size_t levelBegin = 0, levelEnd = 1;
+    for (int depth = 1; depth <= L; ++depth) {
+        for (size_t p = levelBegin; p < levelEnd; ++p)
+            for (int c = 0; c < k; ++c) {
+                parent.push_back((int32_t)p);
+                isLeaf.push_back(depth == L);
+                for (int b = 0; b < 32; ++b) desc.push_back((uint8_t)(rnd() >> 32));
+                weight.push_back(depth == L ? (rnd() % 16 == 0 ? 0.0 : 0.25 + (double)(rnd() % 1000) / 128.0) : 0.0);
+            }
+        levelBegin = levelEnd;
+        levelEnd = parent.size();
+    }
+    orbx::ORBVocabulary mpORBvocabulary;
+    mpORBvocabulary.create(k, L, 0 /*TF_IDF*/, 0 /*L1_NORM*/, parent, isLeaf, desc, weight);
+    ASSERT_EQ(mpORBvocabulary.size(), (unsigned)(k * k * k * k));
+
+    std::vector<uint8_t> img((size_t)w * h);
+    orbx_synth_frame_impl(23, w, h, img.data(), w);
+    orbx::ORBextractor ex(1500, 1.2f, 8, 20, 7, 0, w, h);
+    std::vector<int> lap = {0, 0};
+    std::vector<orbx::KeyPoint> keys;
+    orbx::Descriptors mDescriptors;
+    ex(orbx::Image(img.data(), w, h), orbx::Image(), keys, mDescriptors, lap);
+    orbx::BowVector mBowVec;
+    orbx::FeatureVector mFeatVec;
+    mpORBvocabulary.transform(mDescriptors, mBowVec, mFeatVec, 2);  // two levels above the words, as 4 is for L = 6
+
+    void *ref = oracle_vocabulary_create(k, L, 0, 0, (int)parent.size(), parent.data(), isLeaf.data(), desc.data(), weight.data());
+    const int n = mDescriptors.rows;
+    std::vector<int32_t> fw(n), fnode(n), bw(n), vn(n), vs(n + 1), vf(n);
+    std::vector<double> bv(n);
+    int32_t nb = 0, nv = 0;
+    oracle_vocabulary_transform(ref, mDescriptors.data.data(), n, 2, fw.data(), fnode.data(), bw.data(), bv.data(), &nb, vn.data(), vs.data(),
+                                vf.data(), &nv);
+    oracle_vocabulary_destroy(ref);
+    ASSERT_EQ((int)mBowVec.size(), nb);
+    ASSERT_TRUE(nb > 100);
+    int i = 0;
+    for (orbx::BowVector::const_iterator it = mBowVec.begin(); it != mBowVec.end(); ++it, ++i) {
+        ASSERT_EQ(it->first, (unsigned)bw[i]);
+        ASSERT_TRUE(memcmp(&it->second, &bv[i], sizeof(double)) == 0);
+    }
+    ASSERT_EQ((int)mFeatVec.size(), nv);
+    ASSERT_TRUE(nv > 1 && nv <= k * k);
+    int j = 0;
+    for (orbx::FeatureVector::const_iterator it = mFeatVec.begin(); it != mFeatVec.end(); ++it, ++j) {
+        ASSERT_EQ(it->first, (unsigned)vn[j]);
+        ASSERT_EQ((int)it->second.size(), vs[j + 1] - vs[j]);
+        for (size_t q = 0; q < it->second.size(); ++q) ASSERT_EQ(it->second[q], (unsigned)vf[vs[j] + q]);
+    }
+    return 0;
+}
+
 int main()
 {
     // empty image -> -1 (reference src/ORBextractor.cc:1231-1232)
@@ -228,6 +292,7 @@ int main()
     if (runExtractAndCompare(512, 512, 1500, {100, 300})) return 1;  // TUM-VI geometry with a lapping band
     if (runSearchForInitialization()) return 1;
     if (runSearchByProjection()) return 1;                           // SURVEY 8(f) rank 2, tracking searches
+    if (runComputeBoW()) return 1;
     printf("OK host mirror\n");
     return 0;
 }

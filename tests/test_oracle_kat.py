@@ -322,3 +322,44 @@ def test_undistort_keypoints_inverts_the_distortion_model(orc):
     assert b == (min(c["x"][0], c["x"][2]), max(c["x"][1], c["x"][3]), min(c["y"][0], c["y"][1]), max(c["y"][2], c["y"][3]))
     assert b[0] < 0 and b[1] > 752 and b[2] < 0 and b[3] > 480  # barrel distortion: the undistorted image is larger
     assert orc.compute_image_bounds(752, 480, k4, (0.0,) * 4) == (0.0, 752.0, 0.0, 480.0)
+
+
+def test_vocabulary_transform_against_a_plain_python_tree_walk(orc):
+    """DBoW2 transform restated in the oracle (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1261) against a literal
+    Python walk with dicts: first child with the strictly smallest Hamming distance at every level, tf-idf accumulation in feature
+    order, L1 normalisation in ascending word order, node `levelsup` levels above the word."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from voc_synth import features_near_words, make_vocabulary
+    k, L, levelsup = 4, 3, 1
+    parent, leaf, desc, weight = make_vocabulary(k, L, seed=2, p_stop=0.1)
+    V = orc.Vocabulary(k, L, 0, 0, parent, leaf, desc, weight)
+    children = {}
+    for i in range(1, len(parent)):
+        children.setdefault(int(parent[i]), []).append(i)
+    word_of = {}
+    for i in range(1, len(parent)):
+        if leaf[i]:
+            word_of[i] = len(word_of)
+    f = features_near_words(desc, leaf, 300, 3)
+    bow, fv = {}, {}
+    for i, q in enumerate(f):
+        node, level, nid = 0, 0, None
+        while node in children:
+            level += 1
+            ds = [orc.hamming256(q, desc[c]) for c in children[node]]
+            node = children[node][int(np.argmin(ds))]  # argmin: the first minimum
+            if level == L - levelsup:
+                nid = node
+        if weight[node] > 0:
+            bow[word_of[node]] = bow[word_of[node]] + weight[node] if word_of[node] in bow else weight[node]
+            fv.setdefault(nid, []).append(i)
+    norm = 0.0
+    for wid in sorted(bow):
+        norm += abs(bow[wid])
+    out = V.transform(f, levelsup)
+    assert out["bow_word"].tolist() == sorted(bow) and out["bow_value"].tolist() == [bow[wid] / norm for wid in sorted(bow)]
+    assert out["fv_node"].tolist() == sorted(fv)
+    for j, nid in enumerate(sorted(fv)):
+        assert out["fv_feature"][out["fv_start"][j]:out["fv_start"][j + 1]].tolist() == fv[nid]
+    assert abs(out["bow_value"].sum() - 1.0) < 1e-12 and V.size() == len(word_of)

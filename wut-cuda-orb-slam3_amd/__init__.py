@@ -64,6 +64,11 @@ ABI_SYMBOLS = [
     "orbx_search_by_projection_points",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
+    "orbx_vocabulary_create",
+    "orbx_vocabulary_load_text",
+    "orbx_vocabulary_destroy",
+    "orbx_vocabulary_size",
+    "orbx_vocabulary_transform",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -134,6 +139,12 @@ def load_library() -> ctypes.CDLL:
                                                      c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
+    lib.orbx_vocabulary_load_text.argtypes = [c_int, ctypes.c_char_p, ctypes.POINTER(c_void_p)]
+    lib.orbx_vocabulary_destroy.argtypes = [c_void_p]
+    lib.orbx_vocabulary_destroy.restype = None
+    lib.orbx_vocabulary_size.argtypes = [c_void_p]
+    lib.orbx_vocabulary_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -483,3 +494,69 @@ class ORBmatcher:
         if n < 0:
             _check(n, "orbx_search_by_projection_points")
         return n, assign
+
+
+class ORBVocabulary:
+    """Mirror of ORB_SLAM3::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (reference include/ORBVocabulary.h,
+    Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) for the part Frame::ComputeBoW uses: the tree resident in HBM, transform() on the
+    GPU.  Build it from node arrays (parent / is_leaf / desc / weight in loadFromTextFile's node order) or from an ORBvoc.txt."""
+
+    def __init__(self, k=10, L=5, weighting=0, scoring=0, *, parent=None, is_leaf=None, desc=None, weight=None, device: int = 0):
+        self._lib = load_library()
+        self._h = c_void_p()
+        self._device = device
+        if parent is not None:
+            parent = np.ascontiguousarray(parent, np.int32)
+            is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+            weight = np.ascontiguousarray(weight, np.float64)
+            if not (len(parent) == len(is_leaf) == len(desc) == len(weight)):
+                raise ValueError("ORBVocabulary: one parent / is_leaf / descriptor / weight per node")
+            _check(self._lib.orbx_vocabulary_create(device, int(k), int(L), int(scoring), int(weighting), len(parent), parent.ctypes.data,
+                                                    is_leaf.ctypes.data, desc.ctypes.data, weight.ctypes.data, ctypes.byref(self._h)),
+                   "orbx_vocabulary_create")
+
+    def loadFromTextFile(self, filename: str) -> bool:
+        """bool loadFromTextFile(const std::string &filename) — TemplatedVocabulary.h:1338-1423 (ORBvoc.txt)."""
+        self.close()
+        rc = self._lib.orbx_vocabulary_load_text(self._device, str(filename).encode(), ctypes.byref(self._h))
+        if rc != 0:
+            self._h = c_void_p()
+            return False
+        return True
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.orbx_vocabulary_destroy(self._h)
+        self._h = c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def empty(self) -> bool:
+        return not self._h or self.size() == 0
+
+    def size(self) -> int:
+        return self._lib.orbx_vocabulary_size(self._h) if self._h else 0
+
+    def transform(self, features, levelsup: int = 4):
+        """transform(features, BowVector &v, FeatureVector &fv, levelsup) — TemplatedVocabulary.h:1127-1196.  Returns a dict:
+        bow_word / bow_value (the BowVector, ascending word ids), fv_node / fv_start / fv_feature (the FeatureVector as CSR over
+        ascending node ids), feat_word / feat_node (per feature, -1 = stopped word)."""
+        if not self._h:
+            raise OrbxError("ORBVocabulary: no vocabulary loaded")
+        d = np.ascontiguousarray(features, np.uint8).reshape(-1, 32)
+        n = len(d)
+        fw = np.zeros(n, np.int32); fn = np.zeros(n, np.int32)
+        bw = np.zeros(max(n, 1), np.int32); bv = np.zeros(max(n, 1), np.float64); nb = np.zeros(1, np.int32)
+        vn = np.zeros(max(n, 1), np.int32); vs = np.zeros(n + 1, np.int32); vf = np.zeros(max(n, 1), np.int32); nv = np.zeros(1, np.int32)
+        rc = self._lib.orbx_vocabulary_transform(self._h, d.ctypes.data, n, int(levelsup), fw.ctypes.data, fn.ctypes.data, bw.ctypes.data,
+                                                 bv.ctypes.data, nb.ctypes.data, vn.ctypes.data, vs.ctypes.data, vf.ctypes.data, nv.ctypes.data)
+        if rc < 0:
+            _check(rc, "orbx_vocabulary_transform")
+        nb, nv = int(nb[0]), int(nv[0])
+        return dict(feat_word=fw, feat_node=fn, bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=vn[:nv].copy(),
+                    fv_start=vs[:nv + 1].copy(), fv_feature=vf[:int(vs[nv])].copy())

@@ -1218,3 +1218,153 @@ extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left
     HIP_TRY(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }
+
+// =====================================================================================================
+// DBoW2 vocabulary: ORBVocabulary = TemplatedVocabulary<FORB::TDescriptor, FORB> resident in HBM.
+// =====================================================================================================
+#define ORBX_BOW_MAX_FEATURES 16384  // (word, feature) keys of one transform are sorted in one workgroup's LDS (128 KB)
+
+struct orbx_vocabulary {
+    int device = 0, k = 0, L = 0, scoring = 0, weighting = 0, nNodes = 0, nWords = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<int> d_childStart, d_childNode, d_wordOfNode;
+    DevBuf<uint8_t> d_childDesc, d_feat;
+    DevBuf<double> d_weight, d_featWeight, d_bowValue;
+    DevBuf<int> d_work;  // featWord, featNode, bowWord, fvNode, fvStart, fvFeature, counts
+};
+
+extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
+    v->d_childStart.release(); v->d_childNode.release(); v->d_wordOfNode.release(); v->d_childDesc.release(); v->d_feat.release();
+    v->d_weight.release(); v->d_featWeight.release(); v->d_bowValue.release(); v->d_work.release();
+    delete v;
+}
+
+// Nodes as TemplatedVocabulary::loadFromTextFile builds them (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423): node 0 is
+// the root, node i > 0 hangs under parent[i] < i, children keep node-id order, leaves get word ids in node order.
+extern "C" int orbx_vocabulary_create(int device, int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
+                                      const uint8_t *is_leaf, const uint8_t *desc, const double *weight, orbx_vocabulary **out)
+{
+    if (!out) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_create: null output");
+    *out = nullptr;
+    if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3)  // the loader's own check (:1359)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_create: k / L / scoring / weighting out of range");
+    if (n_nodes < 1 || !parent || !is_leaf || !desc || !weight) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_create: bad argument");
+    for (int i = 1; i < n_nodes; ++i)
+        if (parent[i] < 0 || parent[i] >= i) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_create: node %d has parent %d (must be an earlier node)", i, parent[i]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return setError(ORBX_ERR_NO_DEVICE, "orbx_vocabulary_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_create: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    // child lists (counting sort by parent keeps node-id order) and the descriptors in child-list order
+    std::vector<int> childStart((size_t)n_nodes + 1, 0), childNode((size_t)std::max(n_nodes - 1, 1)), wordOfNode((size_t)n_nodes, 0);
+    for (int i = 1; i < n_nodes; ++i) childStart[(size_t)parent[i] + 1]++;
+    for (int i = 0; i < n_nodes; ++i) childStart[(size_t)i + 1] += childStart[i];
+    std::vector<int> fill(childStart.begin(), childStart.end() - 1);
+    std::vector<uint8_t> childDesc((size_t)std::max(n_nodes - 1, 1) * 32);
+    int nWords = 0;
+    for (int i = 1; i < n_nodes; ++i) {
+        const int p = fill[parent[i]]++;
+        childNode[p] = i;
+        memcpy(&childDesc[(size_t)p * 32], desc + (size_t)i * 32, 32);
+        if (is_leaf[i] > 0) wordOfNode[i] = nWords++;
+    }
+    orbx_vocabulary *v = new (std::nothrow) orbx_vocabulary();
+    if (!v) return setError(ORBX_ERR_OUT_OF_MEMORY, "orbx_vocabulary_create: host allocation failed");
+    v->device = device; v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->nNodes = n_nodes; v->nWords = nWords;
+    hipError_t e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete v; return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    const size_t F = ORBX_BOW_MAX_FEATURES;
+    int rc;
+    if ((rc = v->d_childStart.ensure(childStart.size())) != ORBX_OK || (rc = v->d_childNode.ensure(childNode.size())) != ORBX_OK ||
+        (rc = v->d_wordOfNode.ensure(wordOfNode.size())) != ORBX_OK || (rc = v->d_childDesc.ensure(childDesc.size())) != ORBX_OK ||
+        (rc = v->d_weight.ensure((size_t)n_nodes)) != ORBX_OK || (rc = v->d_feat.ensure(F * 32)) != ORBX_OK ||
+        (rc = v->d_featWeight.ensure(F)) != ORBX_OK || (rc = v->d_bowValue.ensure(F)) != ORBX_OK || (rc = v->d_work.ensure(6 * F + 8)) != ORBX_OK) {
+        orbx_vocabulary_destroy(v);
+        return rc;
+    }
+    e = hipMemcpy(v->d_childStart.p, childStart.data(), childStart.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_childNode.p, childNode.data(), childNode.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_wordOfNode.p, wordOfNode.data(), wordOfNode.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_childDesc.p, childDesc.data(), childDesc.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_weight.p, weight, (size_t)n_nodes * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { orbx_vocabulary_destroy(v); return setError(ORBX_ERR_HIP, "orbx_vocabulary_create: upload: %s", hipGetErrorString(e)); }
+    *out = v;
+    return ORBX_OK;
+}
+
+// bool TemplatedVocabulary::loadFromTextFile(const std::string &filename) — Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423
+// (ORBvoc.txt; called by System::System, src/System.cc).  First line "k L scoring weighting", then one node per line:
+// "parent is_leaf d0 .. d31 weight".  (An empty last line, which the reference's eof loop turns into a root child with an
+// unspecified descriptor, is skipped.)
+extern "C" int orbx_vocabulary_load_text(int device, const char *path, orbx_vocabulary **out)
+{
+    if (!out) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_load_text: null output");
+    *out = nullptr;
+    if (!path) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_load_text: null path");
+    FILE *f = fopen(path, "r");
+    if (!f) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_load_text: cannot open %s", path);
+    int k = 0, L = 0, n1 = 0, n2 = 0;
+    if (fscanf(f, "%d %d %d %d", &k, &L, &n1, &n2) != 4 || k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) {
+        fclose(f);
+        return setError(ORBX_ERR_INVALID_ARG, "Vocabulary loading failure: This is not a correct text file!");
+    }
+    std::vector<int32_t> parent(1, 0);
+    std::vector<uint8_t> leaf(1, 0), desc(32, 0);
+    std::vector<double> weight(1, 0.0);
+    for (;;) {
+        int pid, isLeaf;
+        if (fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;
+        uint8_t d[32];
+        bool ok = true;
+        for (int i = 0; i < 32 && ok; ++i) { int b; ok = fscanf(f, "%d", &b) == 1; d[i] = (uint8_t)b; }
+        double w = 0;
+        ok = ok && fscanf(f, "%lf", &w) == 1;
+        if (!ok || pid < 0 || pid >= (int)parent.size()) { fclose(f); return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_load_text: malformed node %zu", parent.size()); }
+        parent.push_back(pid); leaf.push_back(isLeaf > 0); desc.insert(desc.end(), d, d + 32); weight.push_back(w);
+    }
+    fclose(f);
+    return orbx_vocabulary_create(device, k, L, n1, n2, (int)parent.size(), parent.data(), leaf.data(), desc.data(), weight.data(), out);
+}
+
+extern "C" int orbx_vocabulary_size(const orbx_vocabulary *v) { return v ? v->nWords : 0; }  // size(): number of words
+
+// void TemplatedVocabulary::transform(const std::vector<TDescriptor> &features, BowVector &v, FeatureVector &fv, int levelsup)
+// — TemplatedVocabulary.h:1127-1196, as Frame::ComputeBoW / KeyFrame::ComputeBoW call it with levelsup = 4.
+extern "C" int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc, int n, int levelsup, int32_t *feat_word, int32_t *feat_node,
+                                         int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
+                                         int32_t *fv_feature, int32_t *n_fv)
+{
+    if (!v || n < 0 || (n > 0 && !desc) || !n_bow || !n_fv || !fv_start || (n > 0 && (!bow_word || !bow_value || !fv_node || !fv_feature)))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform: bad argument");
+    if (n > ORBX_BOW_MAX_FEATURES) return setError(ORBX_ERR_CAPACITY, "%d features exceed the transform capacity %d", n, ORBX_BOW_MAX_FEATURES);
+    *n_bow = 0; *n_fv = 0; fv_start[0] = 0;
+    if (n == 0 || v->nNodes <= 1) return 0;  // empty()
+    HIP_TRY(hipSetDevice(v->device));
+    const size_t F = ORBX_BOW_MAX_FEATURES;
+    int *featWord = v->d_work.p, *featNode = featWord + F, *bowWord = featNode + F, *fvNode = bowWord + F, *fvStart = fvNode + F,
+        *fvFeature = fvStart + F + 1, *counts = fvFeature + F;
+    HIP_TRY(hipMemcpyAsync(v->d_feat.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    HIP_TRY(orbxLaunchBowTransform(v->stream, v->d_childStart.p, v->d_childNode.p, v->d_childDesc.p, v->d_wordOfNode.p, v->d_weight.p, v->L,
+                                   v->scoring, v->weighting, v->d_feat.p, n, levelsup, featWord, featNode, v->d_featWeight.p, bowWord,
+                                   v->d_bowValue.p, fvNode, fvStart, fvFeature, counts));
+    int cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(cnt, counts, sizeof cnt, hipMemcpyDeviceToHost, v->stream));
+    if (feat_word) HIP_TRY(hipMemcpyAsync(feat_word, featWord, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    if (feat_node) HIP_TRY(hipMemcpyAsync(feat_node, featNode, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (cnt[0] > 0) {
+        HIP_TRY(hipMemcpyAsync(bow_word, bowWord, (size_t)cnt[0] * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+        HIP_TRY(hipMemcpyAsync(bow_value, v->d_bowValue.p, (size_t)cnt[0] * sizeof(double), hipMemcpyDeviceToHost, v->stream));
+    }
+    if (cnt[1] > 0) HIP_TRY(hipMemcpyAsync(fv_node, fvNode, (size_t)cnt[1] * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(fv_start, fvStart, ((size_t)cnt[1] + 1) * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    if (fv_start[cnt[1]] > 0) HIP_TRY(hipMemcpy(fv_feature, fvFeature, (size_t)fv_start[cnt[1]] * sizeof(int), hipMemcpyDeviceToHost));
+    *n_bow = cnt[0]; *n_fv = cnt[1];
+    return cnt[0];
+}

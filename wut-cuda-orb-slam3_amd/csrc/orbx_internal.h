@@ -110,6 +110,10 @@ struct OrbxStereoLevels {
 hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void *kl, int nl, const void *kr, const int *bestIdx,
                                   const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist);
 
+hipError_t orbxLaunchBowTransform(hipStream_t st, const int *childStart, const int *childNode, const void *childDesc, const int *wordOfNode,
+                                  const double *weightOfNode, int L, int scoring, int weighting, const void *feat, int n, int levelsup,
+                                  int *featWord, int *featNode, double *featWeight, int *bowWord, double *bowValue, int *fvNode, int *fvStart,
+                                  int *fvFeature, int *counts);
 hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4);
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
                                int *items, int *cellOf);

@@ -20,6 +20,7 @@
 #include <stdexcept>
 #include <string>
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "../../include/orbx.h"
@@ -282,6 +283,64 @@ public:
 
 private:
     orbx_matcher *m_ = nullptr;
+};
+
+// DBoW2::BowVector / DBoW2::FeatureVector — reference Thirdparty/DBoW2/DBoW2/BowVector.h, FeatureVector.h
+typedef std::map<unsigned int, double> BowVector;
+typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
+
+// ORB_SLAM3::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (reference include/ORBVocabulary.h) for the
+// calls of System::System (loadFromTextFile) and Frame::ComputeBoW / KeyFrame::ComputeBoW (transform, src/Frame.cc:768-775).
+class ORBVocabulary {
+public:
+    explicit ORBVocabulary(int device = 0) : device_(device) {}
+    ~ORBVocabulary() { orbx_vocabulary_destroy(v_); }
+    ORBVocabulary(const ORBVocabulary &) = delete;
+    ORBVocabulary &operator=(const ORBVocabulary &) = delete;
+
+    // Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1423
+    bool loadFromTextFile(const std::string &filename)
+    {
+        orbx_vocabulary_destroy(v_);
+        v_ = nullptr;
+        return orbx_vocabulary_load_text(device_, filename.c_str(), &v_) == ORBX_OK;
+    }
+    // the same tree from arrays (node 0 = root, parent[i] < i)
+    void create(int k, int L, int weighting, int scoring, const std::vector<int32_t> &parent, const std::vector<uint8_t> &isLeaf,
+                const std::vector<uint8_t> &descriptors, const std::vector<double> &weights)
+    {
+        orbx_vocabulary_destroy(v_);
+        v_ = nullptr;
+        if (isLeaf.size() != parent.size() || weights.size() != parent.size() || descriptors.size() != parent.size() * 32)
+            throw std::runtime_error("ORBVocabulary::create: one is_leaf / descriptor / weight per node");
+        check(orbx_vocabulary_create(device_, k, L, scoring, weighting, (int)parent.size(), parent.data(), isLeaf.data(), descriptors.data(),
+                                     weights.data(), &v_), "ORBVocabulary::create");
+    }
+    bool empty() const { return size() == 0; }
+    unsigned int size() const { return (unsigned int)orbx_vocabulary_size(v_); }
+
+    // void transform(const std::vector<TDescriptor> &features, BowVector &v, FeatureVector &fv, int levelsup) const
+    // — TemplatedVocabulary.h:1127-1196.  features = the rows of mDescriptors (Converter::toDescriptorVector).
+    void transform(const Descriptors &features, BowVector &v, FeatureVector &fv, int levelsup) const
+    {
+        v.clear();
+        fv.clear();
+        if (!v_ || features.rows == 0) return;
+        const int n = features.rows;
+        std::vector<int32_t> bw((size_t)n), fn((size_t)n), fs((size_t)n + 1), ff((size_t)n);
+        std::vector<double> bv((size_t)n);
+        int32_t nb = 0, nf = 0;
+        const int rc = orbx_vocabulary_transform(v_, features.data.data(), n, levelsup, nullptr, nullptr, bw.data(), bv.data(), &nb, fn.data(),
+                                                 fs.data(), ff.data(), &nf);
+        if (rc < 0) check(rc, "ORBVocabulary::transform");
+        for (int i = 0; i < nb; ++i) v.insert(v.end(), BowVector::value_type((unsigned)bw[i], bv[i]));
+        for (int j = 0; j < nf; ++j)
+            fv.insert(fv.end(), FeatureVector::value_type((unsigned)fn[j], std::vector<unsigned int>(ff.begin() + fs[j], ff.begin() + fs[j + 1])));
+    }
+
+private:
+    int device_;
+    orbx_vocabulary *v_ = nullptr;
 };
 
 }  // namespace orbx
