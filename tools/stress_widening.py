@@ -1,0 +1,80 @@
+"""Randomised parity sweep of the widened entry points against the CPU oracle: both tracking
+SearchByProjection variants, UndistortKeyPoints and the vocabulary transform, with random sizes / parameters per case.
+Usage on the GPU box: python tools/stress_widening.py [cases] [seed]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401
+pkg = importlib.import_module("wut-cuda-orb-slam3_amd")
+from oracle import oracle as orc
+from voc_synth import features_near_words, make_vocabulary
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+
+
+def frames(seed, w, h, nfeat):
+    ex = pkg.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    img1 = pkg.synth_frame(seed, w, h)
+    dx, dy = int(rng.integers(-8, 9)), int(rng.integers(-8, 9))
+    img2 = np.clip(np.roll(np.roll(img1, dy, 0), dx, 1).astype(np.int16) + rng.integers(-4, 5, img1.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+    _, k1, d1 = ex(img1, None, (0, 0)); k1, d1 = k1.copy(), d1.copy()
+    _, k2, d2 = ex(img2, None, (0, 0)); k2, d2 = k2.copy(), d2.copy()
+    sf = ex.GetScaleFactors().copy(); ex.close()
+    return k1, d1, k2, d2, sf, dx, dy
+
+
+m = pkg.ORBmatcher(8192, 8192)
+for c in range(cases):
+    w, h = [(640, 480), (752, 480), (512, 512), (1241, 376)][int(rng.integers(0, 4))]
+    k1, d1, k2, d2, sf, dx, dy = frames(int(rng.integers(0, 1 << 20)), w, h, int(rng.integers(300, 2500)))
+    bounds = (0.0, float(w), 0.0, float(h))
+    n1 = len(k1)
+    pr = np.zeros(n1, pkg.PROJECTION_DTYPE)
+    noise = float(rng.uniform(0.2, 6.0))
+    pr["u"] = k1["x"] + dx + rng.normal(0, noise, n1); pr["v"] = k1["y"] + dy + rng.normal(0, noise, n1)
+    pr["octave"] = np.clip(k1["octave"] + rng.integers(-1, 2, n1), 0, 7)
+    pr["flags"] = (rng.random(n1) < rng.uniform(0.3, 1.0)).astype(np.int32) | ((rng.random(n1) < rng.uniform(0.0, 1.0)).astype(np.int32) << 1)
+    state = rng.choice(np.int8([-1, -1, 0, 1]), len(k2))
+    ur = np.where(rng.random(len(k2)) < 0.5, k2["x"] - rng.uniform(0.5, 40, len(k2)), -1).astype(np.float32) if rng.random() < 0.5 else None
+    # SearchByProjection(Frame, Frame)
+    pr["invz"] = 1.0 / rng.uniform(0.5, 20.0, n1); pr["angle"] = k1["angle"]
+    th = float(rng.choice([2, 7, 15, 30])); fwd, bwd = bool(rng.random() < 0.2), False
+    mbf = float(rng.uniform(10, 60)) if ur is not None else 0.0
+    chk = bool(rng.random() < 0.7)
+    a = m.SearchByProjection(k2, d2, state, bounds, sf, pr, d1, th, u_right=ur, mbf=mbf, forward=fwd, backward=bwd, checkOrientation=chk)
+    ra = orc.search_by_projection(k2, d2, state, bounds, sf, pr, d1, th, ur, mbf, fwd, bwd, chk)
+    ok0 = a[0] == ra[0] and np.array_equal(a[1], ra[1])
+    # SearchByProjection(Frame, MapPoints)
+    pm = pr.copy(); pm["angle"] = rng.choice(np.float32([0.3, 0.99, 0.998, 0.9985, 1.0]), n1); pm["invz"] = pm["u"] - rng.uniform(0.5, 40, n1)
+    thm, ratio = float(rng.choice([1, 3, 5, 15])), float(rng.choice([0.6, 0.8, 0.9, 1.0]))
+    g = m.SearchByProjectionPoints(k2, d2, state, bounds, sf, pm, d1, thm, ratio, u_right=ur)
+    r = orc.search_by_projection_points(k2, d2, state, bounds, sf, pm, d1, thm, ratio, ur)
+    ok1 = g[0] == r[0] and np.array_equal(g[1], r[1])
+    # UndistortKeyPoints
+    k4 = (float(rng.uniform(300, 900)), float(rng.uniform(300, 900)), w / 2 + float(rng.uniform(-30, 30)), h / 2 + float(rng.uniform(-30, 30)))
+    nd = int(rng.choice([4, 5, 8, 12]))
+    scale = np.float32([1, 0.3, 0.01, 0.01, 0.1, 0.05, 0.05, 0.05, 0.005, 0.005, 0.005, 0.005])[:nd]
+    dist = (rng.uniform(-0.4, 0.4, nd) * scale).astype(np.float32)
+    ok2 = m.UndistortKeyPoints(k2, k4, dist).tobytes() == orc.undistort_keypoints(k2, k4, dist).tobytes() and \
+        m.ComputeImageBounds(w, h, k4, dist) == orc.compute_image_bounds(w, h, k4, dist)
+    # vocabulary
+    kk, LL = int(rng.integers(2, 13)), int(rng.integers(1, 5))
+    sc, wt = int(rng.integers(0, 6)), int(rng.integers(0, 4))
+    par, leaf, vd, vw = make_vocabulary(kk, LL, seed=int(rng.integers(0, 1 << 20)), ragged=bool(rng.random() < 0.5), p_stop=float(rng.uniform(0, 0.3)), min_leaf_depth=LL)
+    voc = pkg.ORBVocabulary(kk, LL, wt, sc, parent=par, is_leaf=leaf, desc=vd, weight=vw)
+    ref = orc.Vocabulary(kk, LL, sc, wt, par, leaf, vd, vw)
+    f = np.concatenate([features_near_words(vd, leaf, int(rng.integers(1, 3000)), int(rng.integers(0, 1000))), d2[: int(rng.integers(0, len(d2)))]])
+    lu = int(rng.integers(0, LL + 2))
+    o, e = voc.transform(f, lu), ref.transform(f, lu)
+    ok3 = all(o[key].tobytes() == e[key].tobytes() for key in e)
+    voc.close()
+    if not (ok0 and ok1 and ok2 and ok3):
+        bad += 1
+        print("case %d MISMATCH: frame search %s, map-point search %s, undistort %s, vocabulary %s (k=%d L=%d scoring=%d weighting=%d n=%d levelsup=%d)" % (c, ok0, ok1, ok2, ok3, kk, LL, sc, wt, len(f), lu), flush=True)
+    elif c % 10 == 0:
+        print("case %d ok (%d x %d, %d / %d keypoints, %d matches; vocabulary k=%d L=%d, %d features -> %d words)" % (c, w, h, n1, len(k2), g[0], kk, LL, len(f), len(o["bow_word"])), flush=True)
+print("cases: %d, mismatches: %d" % (cases, bad))
+sys.exit(1 if bad else 0)
