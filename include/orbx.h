@@ -256,6 +256,19 @@ int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const ui
                               float mbf, const orbx_projection *proj, const uint8_t *proj_desc, int np, float th, int forward,
                               int backward, int check_orientation, int32_t *assign);
 
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference
+ * src/ORBmatcher1.cc:225-427 (decl include/ORBmatcher.h:62), F.Nleft == -1 / pKF->mpCamera2 == NULL; Tracking::TrackReferenceKeyFrame
+ * and Relocalization.  Both FeatureVectors (pKF->mFeatVec, F.mFeatVec) as orbx_vocabulary_transform returns them: ascending node
+ * ids, fv_start offsets, feature indices.  kf_keys = pKF->mvKeysUn, kf_desc = pKF->mDescriptors, kf_valid[i] = the keyframe's
+ * map point i exists and !isBad(); f_keys = F.mvKeys, f_desc = F.mDescriptors.  Inside every shared node each keyframe feature
+ * (in order) takes the closest frame feature that has no map point yet (TH_LOW = 50, ratio nnratio = mfNNratio to the second
+ * closest), then the rotation-histogram check.  matches[f] = keyframe feature index whose map point F.mvpMapPoints[f] becomes,
+ * -1 = NULL.  Returns nmatches (>= 0) or a negative status. */
+int orbx_search_by_bow(orbx_matcher *m, const int32_t *kf_fv_node, const int32_t *kf_fv_start, const int32_t *kf_fv_feature, int kf_nfv,
+                       const orbx_keypoint *kf_keys, const uint8_t *kf_desc, const uint8_t *kf_valid, int kf_n, const int32_t *f_fv_node,
+                       const int32_t *f_fv_start, const int32_t *f_fv_feature, int f_nfv, const orbx_keypoint *f_keys, const uint8_t *f_desc,
+                       int f_n, float nnratio, int check_orientation, int32_t *matches);
+
 /* void Frame::UndistortKeyPoints() — reference src/Frame.cc:777-811 (decl include/Frame.h): mvKeysUn from mvKeys.
  * k4 = fx, fy, cx, cy of static_cast<Pinhole*>(mpCamera)->toK(); dist = mDistCoef (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]], up to
  * 12 floats); knew4 = fx, fy, cx, cy of mK.  dist[0] == 0 (or ndist == 0) copies, as the reference does; otherwise

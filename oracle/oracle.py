@@ -73,6 +73,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_vocabulary_destroy.restype = None
         L.oracle_vocabulary_words.argtypes = [c_void_p]
         L.oracle_vocabulary_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
+        L.oracle_search_by_bow.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -372,3 +374,18 @@ class Vocabulary:
         nb, nv = int(nb[0]), int(nv[0])
         return dict(feat_word=fw, feat_node=fn, bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=vn[:nv].copy(),
                     fv_start=vs[:nv + 1].copy(), fv_feature=vf[:int(vs[nv])].copy())
+
+
+def search_by_bow(kf_fv, kf_keys, kf_desc, kf_valid, f_fv, f_keys, f_desc, nnratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (reference src/ORBmatcher1.cc:225-427, Nleft == -1) -> (nmatches, matches).
+    kf_fv / f_fv: dicts with fv_node, fv_start, fv_feature (Vocabulary.transform); kf_valid[i] = map point i exists and is not bad."""
+    kk = np.ascontiguousarray(kf_keys, KEYPOINT_DTYPE); fk = np.ascontiguousarray(f_keys, KEYPOINT_DTYPE)
+    kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32); fd = np.ascontiguousarray(f_desc, np.uint8).reshape(-1, 32)
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    a = [np.ascontiguousarray(kf_fv[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+    b = [np.ascontiguousarray(f_fv[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+    matches = np.full(len(fk), -1, np.int32)
+    n = lib().oracle_search_by_bow(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]), kk.ctypes.data, kd.ctypes.data, kv.ctypes.data,
+                                   b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data, len(b[0]), fk.ctypes.data, fd.ctypes.data, len(fk),
+                                   float(nnratio), int(bool(check_orientation)), matches.ctypes.data)
+    return n, matches

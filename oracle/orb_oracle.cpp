@@ -1417,6 +1417,69 @@ int oracle_vocabulary_transform(void *h, const uint8_t *desc, int n, int levelsu
     return nb;
 }
 
+// int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) — reference src/ORBmatcher1.cc:225-427,
+// branch F.Nleft == -1 (pKF->mpCamera2 == NULL).  Both FeatureVectors as CSR over ascending node ids (what transform() returns);
+// kf_valid[i] = vpMapPointsKF[i] && !isBad(); kf_keys = pKF->mvKeysUn, f_keys = F.mvKeys (angles for the rotation histogram).
+// matches[f] = index of the keyframe feature whose map point the frame feature f received, -1 = NULL.  Returns nmatches.
+int oracle_search_by_bow(const int32_t *kf_node, const int32_t *kf_start, const int32_t *kf_feat, int kf_nfv, const oracle_keypoint *kf_keys,
+                         const uint8_t *kf_desc, const uint8_t *kf_valid, const int32_t *f_node, const int32_t *f_start, const int32_t *f_feat,
+                         int f_nfv, const oracle_keypoint *f_keys, const uint8_t *f_desc, int f_n, float nnratio, int check_orientation,
+                         int32_t *matches)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int i = 0; i < f_n; ++i) matches[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int KFit = 0, Fit = 0;
+    while (KFit != kf_nfv && Fit != f_nfv) {
+        if (kf_node[KFit] == f_node[Fit]) {
+            for (int iKF = kf_start[KFit]; iKF < kf_start[KFit + 1]; iKF++) {
+                const int realIdxKF = kf_feat[iKF];
+                if (!kf_valid[realIdxKF]) continue;  // !pMP || pMP->isBad()
+                const uint8_t *dKF = kf_desc + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int iF = f_start[Fit]; iF < f_start[Fit + 1]; iF++) {
+                    const int realIdxF = f_feat[iF];
+                    if (matches[realIdxF] >= 0) continue;  // vpMapPointMatches[realIdxF]
+                    const int dist = oracle_hamming256(dKF, f_desc + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matches[bestIdxF] = realIdxKF;
+                        if (check_orientation) {
+                            float rot = kf_keys[realIdxKF].angle - f_keys[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            KFit++; Fit++;
+        } else if (kf_node[KFit] < f_node[Fit]) {
+            KFit = (int)(std::lower_bound(kf_node, kf_node + kf_nfv, f_node[Fit]) - kf_node);
+        } else {
+            Fit = (int)(std::lower_bound(f_node, f_node + f_nfv, kf_node[KFit]) - f_node);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        computeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { matches[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 }  // extern "C"
 
 extern "C" {

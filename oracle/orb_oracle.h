@@ -148,6 +148,12 @@ int oracle_vocabulary_transform(void *h, const uint8_t *desc, int n, int levelsu
                                 int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
                                 int32_t *fv_feature, int32_t *n_fv);
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher1.cc:225-427), F.Nleft == -1; FeatureVectors as CSR. */
+int oracle_search_by_bow(const int32_t *kf_node, const int32_t *kf_start, const int32_t *kf_feat, int kf_nfv, const oracle_keypoint *kf_keys,
+                         const uint8_t *kf_desc, const uint8_t *kf_valid, const int32_t *f_node, const int32_t *f_start, const int32_t *f_feat,
+                         int f_nfv, const oracle_keypoint *f_keys, const uint8_t *f_desc, int f_n, float nnratio, int check_orientation,
+                         int32_t *matches);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

@@ -246,6 +246,44 @@ static int runComputeBoW()
     orbx::FeatureVector mFeatVec;
     mpORBvocabulary.transform(mDescriptors, mBowVec, mFeatVec, 2);  // two levels above the words, as 4 is for L = 6
 
+    // TrackReferenceKeyFrame: the same scene 3 px to the right as the "keyframe", ORBmatcher(0.7, true).SearchByBoW (src/ORBmatcher1.cc:225-427)
+    {
+        std::vector<uint8_t> img2((size_t)w * h);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) img2[(size_t)y * w + x] = img[(size_t)y * w + (x + w - 3) % w];
+        std::vector<orbx::KeyPoint> keysKF;
+        orbx::Descriptors descKF;
+        ex(orbx::Image(img2.data(), w, h), orbx::Image(), keysKF, descKF, lap);
+        orbx::BowVector bowKF;
+        orbx::FeatureVector featKF;
+        mpORBvocabulary.transform(descKF, bowKF, featKF, 3);
+        orbx::FeatureVector featF;
+        orbx::BowVector bowF;
+        mpORBvocabulary.transform(mDescriptors, bowF, featF, 3);
+        std::vector<uint8_t> valid(keysKF.size());
+        for (size_t i = 0; i < valid.size(); ++i) valid[i] = i % 5 != 0;
+        orbx::FrameView KF, F;
+        KF.mvKeysUn = &keysKF; KF.mDescriptors = &descKF; F.mvKeysUn = &keys; F.mDescriptors = &mDescriptors;
+        orbx::ORBmatcher matcher(0.7f, true);
+        std::vector<int> vnMatches;
+        const int nm = matcher.SearchByBoW(featKF, KF, valid, featF, F, vnMatches);
+        // the same through the oracle, FeatureVectors flattened from the oracle's own transform
+        void *rv = oracle_vocabulary_create(k, L, 0, 0, (int)parent.size(), parent.data(), isLeaf.data(), desc.data(), weight.data());
+        const int nk = descKF.rows, nf = mDescriptors.rows, nn = std::max(nk, nf);
+        std::vector<int32_t> a0(nn), a1(nn), bwx(nn), kn(nn), ks(nn + 1), kfe(nn), fnn(nn), fss(nn + 1), ffe(nn), refM(nf);
+        std::vector<double> bvx(nn);
+        int32_t nbx = 0, nkv = 0, nfv = 0;
+        oracle_vocabulary_transform(rv, descKF.data.data(), nk, 3, a0.data(), a1.data(), bwx.data(), bvx.data(), &nbx, kn.data(), ks.data(), kfe.data(), &nkv);
+        oracle_vocabulary_transform(rv, mDescriptors.data.data(), nf, 3, a0.data(), a1.data(), bwx.data(), bvx.data(), &nbx, fnn.data(), fss.data(), ffe.data(), &nfv);
+        oracle_vocabulary_destroy(rv);
+        const int rm = oracle_search_by_bow(kn.data(), ks.data(), kfe.data(), nkv, (const oracle_keypoint *)keysKF.data(), descKF.data.data(), valid.data(),
+                                            fnn.data(), fss.data(), ffe.data(), nfv, (const oracle_keypoint *)keys.data(), mDescriptors.data.data(), nf,
+                                            0.7f, 1, refM.data());
+        ASSERT_EQ(nm, rm);
+        ASSERT_TRUE(nm > 30);
+        for (int i = 0; i < nf; ++i) ASSERT_EQ(vnMatches[i], refM[i]);
+    }
+
     void *ref = oracle_vocabulary_create(k, L, 0, 0, (int)parent.size(), parent.data(), isLeaf.data(), desc.data(), weight.data());
     const int n = mDescriptors.rows;
     std::vector<int32_t> fw(n), fnode(n), bw(n), vn(n), vs(n + 1), vf(n);

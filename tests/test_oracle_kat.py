@@ -363,3 +363,32 @@ def test_vocabulary_transform_against_a_plain_python_tree_walk(orc):
     for j, nid in enumerate(sorted(fv)):
         assert out["fv_feature"][out["fv_start"][j]:out["fv_start"][j + 1]].tolist() == fv[nid]
     assert abs(out["bow_value"].sum() - 1.0) < 1e-12 and V.size() == len(word_of)
+
+
+def test_search_by_bow_properties(orc):
+    """ORBmatcher::SearchByBoW restated in the oracle (reference src/ORBmatcher1.cc:225-427): a frame against itself matches
+    every feature of a non-stopped word to itself; features only meet inside a shared node; a frame feature is given away once;
+    keyframe features without a (good) map point never match."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from voc_synth import make_vocabulary
+    o = orc.Oracle(600, 1.2, 8, 20, 7)
+    _, k, d = o.extract(orc.synth_frame(0x4F524230 + 21, 640, 480), (0, 0))
+    parent, leaf, desc, weight = make_vocabulary(5, 3, seed=4, p_stop=0.1)
+    V = orc.Vocabulary(5, 3, 0, 0, parent, leaf, desc, weight)
+    fv = V.transform(d, 2)
+    n = len(k)
+    in_fv = np.zeros(n, bool); in_fv[fv["fv_feature"]] = True
+    nm, matches = orc.search_by_bow(fv, k, d, np.ones(n, np.uint8), fv, k, d, 0.7, True)
+    assert nm == in_fv.sum() and (matches[in_fv] == np.arange(n)[in_fv]).all() and (matches[~in_fv] == -1).all()
+    # only the even keyframe features carry map points
+    valid = (np.arange(n) % 2 == 0).astype(np.uint8)
+    nm, matches = orc.search_by_bow(fv, k, d, valid, fv, k, d, 0.7, False)
+    got = matches >= 0
+    assert (valid[matches[got]] == 1).all() and len(set(matches[got].tolist())) == got.sum() == nm
+    node_of = np.full(n, -1); node_of[fv["fv_feature"]] = np.repeat(fv["fv_node"], np.diff(fv["fv_start"]))
+    assert (node_of[matches[got]] == node_of[np.flatnonzero(got)]).all()
+    # a second, disjoint node set on the frame side: nothing in common, nothing matched
+    other = dict(fv_node=fv["fv_node"] + 100000, fv_start=fv["fv_start"], fv_feature=fv["fv_feature"])
+    nm, matches = orc.search_by_bow(fv, k, d, np.ones(n, np.uint8), other, k, d, 0.7, True)
+    assert nm == 0 and (matches == -1).all()

@@ -86,3 +86,88 @@ def test_orbvoc_scale_and_text_file(pkg, orc, tmp_path):
         pkg.ORBVocabulary(5, 3, 0, 0, parent=parent, is_leaf=leaf, desc=desc, weight=weight).transform(np.zeros((20000, 32), np.uint8))
     with pytest.raises(pkg.OrbxError, match="earlier node"):
         pkg.ORBVocabulary(5, 3, 0, 0, parent=[0, 2, 1], is_leaf=[0, 1, 1], desc=np.zeros((3, 32), np.uint8), weight=[0, 1, 1])
+
+
+def _two_views(pkg, seed, nfeat=1500):
+    ex = pkg.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    img1 = pkg.synth_frame(seed, 640, 480)
+    rng = np.random.default_rng(seed)
+    img2 = np.clip(np.roll(np.roll(img1, 3, axis=0), -5, axis=1).astype(np.int16) + rng.integers(-3, 4, img1.shape, dtype=np.int16), 0, 255)
+    _, k1, d1 = ex(img1, None, (0, 0)); k1, d1 = k1.copy(), d1.copy()
+    _, k2, d2 = ex(img2.astype(np.uint8), None, (0, 0)); k2, d2 = k2.copy(), d2.copy()
+    ex.close()
+    return k1, d1, k2, d2, rng
+
+
+def _vocabulary_from_descriptors(d, k, L, seed):
+    """A vocabulary whose words sit near real descriptors: the tree of make_vocabulary re-rooted on image descriptors (leaf
+    descriptors = extractor descriptors with a little noise), so that two views of a scene fall into the same nodes."""
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc, weight = make_vocabulary(k, L, seed=seed, p_stop=0.02)
+    # top-down: every node's descriptor = one sample descriptor, children perturb their parent's
+    pick = d[rng.integers(0, len(d), len(parent))]
+    depth = np.zeros(len(parent), np.int32)
+    for i in range(1, len(parent)):
+        depth[i] = depth[parent[i]] + 1
+    for i in range(1, len(parent)):
+        if depth[i] == 1:
+            desc[i] = pick[i]
+        else:
+            flips = rng.integers(0, 256, 6 * (L - depth[i] + 1))
+            desc[i] = desc[parent[i]]
+            for b in flips:
+                desc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return parent, leaf, desc, weight
+
+
+@pytest.mark.parametrize("k,L,levelsup,ratio,check", [(10, 4, 2, 0.7, True), (10, 4, 3, 0.9, True), (6, 3, 3, 0.7, False), (10, 3, 1, 0.75, True)])
+def test_search_by_bow(pkg, orc, k, L, levelsup, ratio, check):
+    """Tracking::TrackReferenceKeyFrame: ComputeBoW on both sides, then ORBmatcher(0.7, true).SearchByBoW(pKF, F, matches)
+    (reference src/ORBmatcher1.cc:225-427): bit-exact nmatches and assignment against the oracle, FeatureVectors from the GPU
+    transform."""
+    k1, d1, k2, d2, rng = _two_views(pkg, 41)
+    parent, leaf, desc, weight = _vocabulary_from_descriptors(d1, k, L, 13)
+    voc = pkg.ORBVocabulary(k, L, 0, 0, parent=parent, is_leaf=leaf, desc=desc, weight=weight)
+    fv1, fv2 = voc.transform(d1, levelsup), voc.transform(d2, levelsup)
+    valid = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    m = pkg.ORBmatcher(8192, 8192)
+    n, matches = m.SearchByBoW(fv1, k1, d1, valid, fv2, k2, d2, ratio, check)
+    rn, rmatches = orc.search_by_bow(fv1, k1, d1, valid, fv2, k2, d2, ratio, check)
+    assert n == rn and np.array_equal(matches, rmatches)
+    assert n == int((matches >= 0).sum())
+    if levelsup >= L:  # one node (the root) holds everything: the most contended case, > 64 frame features per node
+        assert len(fv1["fv_node"]) == 1 and n > 100
+    # no valid map points / empty sides
+    n0, m0 = m.SearchByBoW(fv1, k1, d1, np.zeros(len(k1), np.uint8), fv2, k2, d2, ratio, check)
+    assert n0 == 0 and (m0 == -1).all()
+    empty = dict(fv_node=np.zeros(0, np.int32), fv_start=np.zeros(1, np.int32), fv_feature=np.zeros(0, np.int32))
+    n0, m0 = m.SearchByBoW(empty, k1, d1, valid, fv2, k2, d2, ratio, check)
+    assert n0 == 0 and (m0 == -1).all()
+    if len(fv2["fv_node"]) > 1:
+        bad = dict(fv2); bad["fv_node"] = fv2["fv_node"][::-1].copy()
+        with pytest.raises(pkg.OrbxError, match="ascending"):
+            m.SearchByBoW(fv1, k1, d1, valid, bad, k2, d2, ratio, check)
+    voc.close(); m.close()
+
+
+def test_search_by_bow_contention(pkg, orc):
+    """Many keyframe features per node chase few frame features with near-identical descriptors: every accepted match removes a
+    candidate for the following keyframe features of the node, ties in distance go to the first frame feature."""
+    k1, d1, k2, d2, rng = _two_views(pkg, 43, 1200)
+    n2 = len(k2)
+    src = rng.integers(0, 60, n2)
+    d2b = d2[src].copy()
+    d2b[:, 0] ^= rng.integers(0, 4, n2, dtype=np.uint8)          # groups of near twins in the frame
+    d1b = d2[rng.integers(0, 60, len(k1))].copy()
+    d1b[:, 1] ^= rng.integers(0, 8, len(k1), dtype=np.uint8)
+    parent, leaf, desc, weight = _vocabulary_from_descriptors(d2[:60], 5, 2, 3)
+    voc = pkg.ORBVocabulary(5, 2, 0, 0, parent=parent, is_leaf=leaf, desc=desc, weight=weight)
+    fv1, fv2 = voc.transform(d1b, 1), voc.transform(d2b, 1)
+    valid = np.ones(len(k1), np.uint8)
+    m = pkg.ORBmatcher(8192, 8192)
+    for ratio in (0.7, 1.0, 2.0):
+        n, matches = m.SearchByBoW(fv1, k1, d1b, valid, fv2, k2, d2b, ratio, True)
+        rn, rmatches = orc.search_by_bow(fv1, k1, d1b, valid, fv2, k2, d2b, ratio, True)
+        assert n == rn and np.array_equal(matches, rmatches)
+    assert n > 20
+    voc.close(); m.close()

@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points",
+    "orbx_search_by_bow",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
     "orbx_vocabulary_create",
@@ -137,6 +138,8 @@ def load_library() -> ctypes.CDLL:
                                               c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
     lib.orbx_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
                                                      c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
+    lib.orbx_search_by_bow.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
@@ -393,6 +396,24 @@ class ORBmatcher:
     # ---- SURVEY §8(f) rank 2 ----------------------------------------------------------------------------------------
     FRAME_GRID_COLS = 64
     FRAME_GRID_ROWS = 48
+
+    def SearchByBoW(self, kf_fv, kf_keys, kf_desc, kf_valid, f_fv, f_keys, f_desc, nnratio: float = 0.7, checkOrientation: bool = True):
+        """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (reference src/ORBmatcher1.cc:225-427, Nleft == -1).  kf_fv / f_fv: the
+        FeatureVectors as ORBVocabulary.transform returns them (fv_node, fv_start, fv_feature); kf_valid[i] = map point i of the
+        keyframe exists and is not bad.  Returns (nmatches, matches[f_n]) with matches[f] = keyframe feature index or -1."""
+        kk = np.ascontiguousarray(kf_keys, KEYPOINT_DTYPE); fk = np.ascontiguousarray(f_keys, KEYPOINT_DTYPE)
+        kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32); fd = np.ascontiguousarray(f_desc, np.uint8).reshape(-1, 32)
+        kv = np.ascontiguousarray(kf_valid, np.uint8)
+        assert len(kd) == len(kk) == len(kv) and len(fd) == len(fk)
+        a = [np.ascontiguousarray(kf_fv[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+        b = [np.ascontiguousarray(f_fv[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+        matches = np.full(len(fk), -1, np.int32)
+        n = self._lib.orbx_search_by_bow(self._h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]), kk.ctypes.data, kd.ctypes.data,
+                                         kv.ctypes.data, len(kk), b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data, len(b[0]), fk.ctypes.data,
+                                         fd.ctypes.data, len(fk), float(nnratio), int(bool(checkOrientation)), matches.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_bow")
+        return n, matches
 
     @staticmethod
     def _camera(k4, dist, knew4):

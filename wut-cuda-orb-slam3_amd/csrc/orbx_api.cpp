@@ -992,6 +992,64 @@ static int checkGridBounds(float minX, float maxX, float minY, float maxY, const
     return ORBX_OK;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) — reference src/ORBmatcher1.cc:225-427 (F.Nleft == -1).
+static int checkFeatureVector(const int32_t *node, const int32_t *start, const int32_t *feat, int nfv, int n, const char *which)
+{
+    if (nfv < 0 || (nfv > 0 && (!node || !start || !feat))) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: bad %s FeatureVector", which);
+    if (nfv == 0) return ORBX_OK;
+    if (start[0] != 0 || start[nfv] > n) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector offsets outside [0, %d]", which, n);
+    for (int j = 0; j < nfv; ++j) {
+        if (start[j + 1] < start[j]) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector offsets not ascending", which);
+        if (j > 0 && node[j] <= node[j - 1]) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector node ids not ascending", which);
+    }
+    for (int i = 0; i < start[nfv]; ++i)
+        if (feat[i] < 0 || feat[i] >= n) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector holds feature %d of %d", which, feat[i], n);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_bow(orbx_matcher *m, const int32_t *kf_fv_node, const int32_t *kf_fv_start, const int32_t *kf_fv_feature,
+                                  int kf_nfv, const orbx_keypoint *kf_keys, const uint8_t *kf_desc, const uint8_t *kf_valid, int kf_n,
+                                  const int32_t *f_fv_node, const int32_t *f_fv_start, const int32_t *f_fv_feature, int f_nfv,
+                                  const orbx_keypoint *f_keys, const uint8_t *f_desc, int f_n, float nnratio, int check_orientation,
+                                  int32_t *matches)
+{
+    if (!m || kf_n < 0 || f_n < 0 || (kf_n > 0 && (!kf_keys || !kf_desc || !kf_valid)) || (f_n > 0 && (!f_keys || !f_desc || !matches)))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: bad argument");
+    if (kf_n > m->maxQ || f_n > m->maxT || f_n > 65535)
+        return setError(ORBX_ERR_CAPACITY, "%d x %d features exceed the matcher capacity %d x %d", kf_n, f_n, m->maxQ, std::min(m->maxT, 65535));
+    int rc;
+    if ((rc = checkFeatureVector(kf_fv_node, kf_fv_start, kf_fv_feature, kf_nfv, kf_n, "keyframe")) != ORBX_OK) return rc;
+    if ((rc = checkFeatureVector(f_fv_node, f_fv_start, f_fv_feature, f_nfv, f_n, "frame")) != ORBX_OK) return rc;
+    for (int i = 0; i < f_n; ++i) matches[i] = -1;
+    if (kf_nfv == 0 || f_nfv == 0 || kf_n == 0 || f_n == 0) return 0;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, kf_desc, kf_n, f_desc, f_n)) != ORBX_OK) return rc;
+    const size_t Q = (size_t)m->maxQ, T = (size_t)m->maxT;
+    if ((rc = m->d_work.ensure(3 * Q + 5 * T + 2 + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_bin.ensure(Q)) != ORBX_OK) return rc;
+    int *kfNode = m->d_work.p, *kfStart = kfNode + Q, *kfFeat = kfStart + Q + 1, *fNode = kfFeat + Q, *fStart = fNode + T, *fFeat = fStart + T + 1,
+        *dMatches = fFeat + T, *binOf = dMatches + T, *result = binOf + T;
+    int maxNodeF = 1;
+    for (int j = 0; j < f_nfv; ++j) maxNodeF = std::max(maxNodeF, f_fv_start[j + 1] - f_fv_start[j]);
+    hipStream_t st = m->stream;
+    HIP_TRY(hipMemcpyAsync(kfNode, kf_fv_node, (size_t)kf_nfv * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(kfStart, kf_fv_start, ((size_t)kf_nfv + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    if (kf_fv_start[kf_nfv] > 0) HIP_TRY(hipMemcpyAsync(kfFeat, kf_fv_feature, (size_t)kf_fv_start[kf_nfv] * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(fNode, f_fv_node, (size_t)f_nfv * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(fStart, f_fv_start, ((size_t)f_nfv + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    if (f_fv_start[f_nfv] > 0) HIP_TRY(hipMemcpyAsync(fFeat, f_fv_feature, (size_t)f_fv_start[f_nfv] * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kf_keys, (size_t)kf_n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_kr.p, f_keys, (size_t)f_n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_bin.p, kf_valid, (size_t)kf_n, hipMemcpyHostToDevice, st));
+    HIP_TRY(orbxLaunchSearchByBoW(st, kfNode, kfStart, kfFeat, kf_nfv, m->d_kl.p, m->d_q.p, m->d_bin.p, fNode, fStart, fFeat, f_nfv, m->d_kr.p,
+                                  m->d_t.p, f_n, maxNodeF, nnratio, check_orientation != 0, dMatches, binOf, result));
+    int nmatches = 0;
+    HIP_TRY(hipMemcpyAsync(matches, dMatches, (size_t)f_n * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&nmatches, result, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return nmatches;
+}
+
 // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811.
 static int checkCamera(const float *k4, const float *dist, int ndist, const float *knew4, const char *fn)
 {

@@ -1039,3 +1039,143 @@ hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n,
     hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
+
+
+// ---- ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) ---------------------------------------
+// reference src/ORBmatcher1.cc:225-427, F.Nleft == -1: features are only compared inside the vocabulary node they share (the
+// FeatureVectors of DBoW2's transform()).  A frame feature that received a map point is skipped by every later keyframe feature
+// - but only features of the same node compete, so the nodes are independent: one wave per shared node walks the keyframe
+// features of the node in order, its lanes take the frame features of the node (the first 64 keep their descriptor in
+// registers), best / second best by two wave reductions of (distance << 16 | position) keys.  Then one workgroup applies the
+// rotation-histogram check over all matches.
+struct SbowArgs {
+    const int *kfNode, *kfStart, *kfFeat; int kfNfv;
+    const MtKp *kfKeys; const uint8_t *kfDesc; const signed char *kfValid;
+    const int *fNode, *fStart, *fFeat; int fNfv;
+    const MtKp *fKeys; const uint8_t *fDesc; int nF;
+    float nnratio; int checkOri;
+    int *matches;  // [nF] out (-1 preset)
+    int *binOf;    // [nF] work
+    int *result;   // [0] nmatches, [1 .. 30] rotation histogram
+};
+
+__device__ __forceinline__ unsigned sbow_wave_min(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_sbow_match(SbowArgs a)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
+    extern __shared__ uint8_t taken[];        // per frame feature of this node: already holds a map point
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int node = a.kfNode[j];
+    int lo = 0, hi = a.fNfv;  // the merge of the two maps only ever pairs equal node ids
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fNode[mid] < node) lo = mid + 1; else hi = mid; }
+    if (lo >= a.fNfv || a.fNode[lo] != node) return;
+    const int fs = a.fStart[lo], nFn = a.fStart[lo + 1] - fs;
+    for (int i = lane; i < nFn; i += 64) taken[i] = 0;
+    uint32_t d0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int realF0 = -1;
+    if (lane < nFn) {
+        realF0 = a.fFeat[fs + lane];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) d0[w] = ((const uint32_t *)(a.fDesc + (size_t)realF0 * 32))[w];
+    }
+    __syncthreads();
+    const unsigned NONE = (256u << 16) | 0xFFFFu;
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int iKF = a.kfStart[j]; iKF < a.kfStart[j + 1]; ++iKF) {
+        const int realIdxKF = a.kfFeat[iKF];
+        if (!a.kfValid[realIdxKF]) continue;  // !pMP || pMP->isBad()
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.kfDesc + (size_t)realIdxKF * 32))[w];
+        unsigned k1 = NONE, k2 = NONE;  // this lane's smallest and second smallest key
+        if (lane < nFn && !taken[lane]) {
+            int dist = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ d0[w]);
+            k1 = ((unsigned)dist << 16) | (unsigned)lane;
+        }
+        for (int c0 = 64; c0 < nFn; c0 += 64) {
+            const int iF = c0 + lane;
+            if (iF < nFn && !taken[iF]) {
+                const uint32_t *t = (const uint32_t *)(a.fDesc + (size_t)a.fFeat[fs + iF] * 32);
+                int dist = 0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+                const unsigned key = ((unsigned)dist << 16) | (unsigned)iF;
+                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+            }
+        }
+        const unsigned best = sbow_wave_min(k1);
+        const unsigned second = sbow_wave_min(k1 == best ? k2 : k1);  // (keys are unique: the position is part of them)
+        const int bestDist1 = (int)(best >> 16), bestDist2 = (int)(second >> 16);
+        if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(a.nnratio, (float)bestDist2)) {
+            const int pos = (int)(best & 0xFFFFu);
+            if (lane == 0) {
+                const int bestIdxF = a.fFeat[fs + pos];
+                taken[pos] = 1;
+                a.matches[bestIdxF] = realIdxKF;
+                if (a.checkOri) {
+                    float rot = __fsub_rn(a.kfKeys[realIdxKF].angle, a.fKeys[bestIdxF].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    a.binOf[bestIdxF] = bin;
+                    atomicAdd(&a.result[1 + bin], 1);
+                }
+                atomicAdd(&a.result[0], 1);
+            }
+            __syncthreads();  // (one wave) the next keyframe feature must see taken[pos]
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sbow_finish(SbowArgs a)
+{
+    const int HISTO_LENGTH = 30;
+    if (!a.checkOri) return;
+    __shared__ int removed;
+    if (threadIdx.x == 0) removed = 0;
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima (every thread, uniform)
+        const int s = a.result[1 + i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.nF; i += 256) {
+        if (a.matches[i] < 0) continue;
+        const int bin = a.binOf[i];
+        if (bin != ind1 && bin != ind2 && bin != ind3) { a.matches[i] = -1; atomicAdd(&removed, 1); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.result[0] -= removed;
+}
+
+hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *kfStart, const int *kfFeat, int kfNfv, const void *kfKeys,
+                                 const uint8_t *kfDesc, const signed char *kfValid, const int *fNode, const int *fStart, const int *fFeat,
+                                 int fNfv, const void *fKeys, const uint8_t *fDesc, int nF, int maxNodeF, float nnratio, int checkOri,
+                                 int *matches, int *binOf, int *result)
+{
+    SbowArgs a;
+    a.kfNode = kfNode; a.kfStart = kfStart; a.kfFeat = kfFeat; a.kfNfv = kfNfv; a.kfKeys = (const MtKp *)kfKeys; a.kfDesc = kfDesc;
+    a.kfValid = kfValid; a.fNode = fNode; a.fStart = fStart; a.fFeat = fFeat; a.fNfv = fNfv; a.fKeys = (const MtKp *)fKeys; a.fDesc = fDesc;
+    a.nF = nF; a.nnratio = nnratio; a.checkOri = checkOri; a.matches = matches; a.binOf = binOf; a.result = result;
+    hipError_t e = hipMemsetAsync(result, 0, 32 * sizeof(int), st);
+    if (e == hipSuccess && nF > 0) e = hipMemsetAsync(matches, 0xFF, (size_t)nF * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    if (kfNfv > 0 && fNfv > 0) {
+        const size_t lds = ((size_t)std::max(maxNodeF, 1) + 63) & ~(size_t)63;
+        hipLaunchKernelGGL(k_sbow_match, dim3(kfNfv), dim3(64), lds, st, a);
+        hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}

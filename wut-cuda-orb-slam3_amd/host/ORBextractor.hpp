@@ -136,6 +136,10 @@ private:
     orbx_extractor *h_ = nullptr;
 };
 
+// DBoW2::BowVector / DBoW2::FeatureVector — reference Thirdparty/DBoW2/DBoW2/BowVector.h, FeatureVector.h
+typedef std::map<unsigned int, double> BowVector;
+typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
+
 // The part of `ORB_SLAM3::Frame` the windowed searches read (reference include/Frame.h): undistorted keypoints, descriptors and
 // the static image bounds mnMinX .. mnMaxY (src/Frame.cc:41, 808-839) that define the 64 x 48 feature grid.
 struct FrameView {
@@ -223,6 +227,34 @@ public:
         return n;
     }
 
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference include/ORBmatcher.h:62,
+    // src/ORBmatcher1.cc:225-427 (F.Nleft == -1).  KF: mvKeysUn + mDescriptors of the keyframe, vbValidKF[i] = its map point i exists
+    // and !isBad(); F: mvKeys + mDescriptors of the frame (FrameView::mvKeysUn carries them).  vnMatches[f] = keyframe feature
+    // whose map point F.mvpMapPoints[f] becomes, -1 = NULL.
+    int SearchByBoW(const FeatureVector &vFeatVecKF, const FrameView &KF, const std::vector<uint8_t> &vbValidKF, const FeatureVector &vFeatVecF,
+                    const FrameView &F, std::vector<int> &vnMatches)
+    {
+        const int nk = (int)KF.mvKeysUn->size(), nf = (int)F.mvKeysUn->size();
+        if ((int)vbValidKF.size() != nk) throw std::runtime_error("SearchByBoW: inconsistent array sizes");
+        std::vector<int32_t> node[2], start[2], feat[2];
+        const FeatureVector *fv[2] = {&vFeatVecKF, &vFeatVecF};
+        for (int s = 0; s < 2; ++s) {
+            start[s].push_back(0);
+            for (FeatureVector::const_iterator it = fv[s]->begin(); it != fv[s]->end(); ++it) {
+                node[s].push_back((int32_t)it->first);
+                feat[s].insert(feat[s].end(), it->second.begin(), it->second.end());
+                start[s].push_back((int32_t)feat[s].size());
+            }
+        }
+        vnMatches.assign((size_t)nf, -1);
+        const int n = orbx_search_by_bow(m_, node[0].data(), start[0].data(), feat[0].data(), (int)node[0].size(), (const orbx_keypoint *)KF.mvKeysUn->data(),
+                                         KF.mDescriptors->data.data(), vbValidKF.data(), nk, node[1].data(), start[1].data(), feat[1].data(),
+                                         (int)node[1].size(), (const orbx_keypoint *)F.mvKeysUn->data(), F.mDescriptors->data.data(), nf, mfNNratio,
+                                         mbCheckOrientation ? 1 : 0, vnMatches.data());
+        if (n < 0) check(n, "SearchByBoW");
+        return n;
+    }
+
     // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811: mvKeysUn from mvKeys.  K = toK() and mK as {fx, fy, cx, cy},
     // mDistCoef as the reference's 4 / 5 / 8 / 12 floats (copies when mDistCoef[0] == 0).
     void UndistortKeyPoints(const std::vector<KeyPoint> &mvKeys, const float (&K)[4], const std::vector<float> &mDistCoef, const float (&mK)[4],
@@ -284,10 +316,6 @@ public:
 private:
     orbx_matcher *m_ = nullptr;
 };
-
-// DBoW2::BowVector / DBoW2::FeatureVector — reference Thirdparty/DBoW2/DBoW2/BowVector.h, FeatureVector.h
-typedef std::map<unsigned int, double> BowVector;
-typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
 
 // ORB_SLAM3::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (reference include/ORBVocabulary.h) for the
 // calls of System::System (loadFromTextFile) and Frame::ComputeBoW / KeyFrame::ComputeBoW (transform, src/Frame.cc:768-775).
