@@ -131,13 +131,20 @@ def main() -> None:
     n, mono, _, _ = ex.download_outputs(B)
     total_kps = int(n.sum())
 
-    pcie_fps = None
+    pcie_fps = pcie_pinned_fps = None
     if args.pcie and rank == 0:
         ex.extract_batch(host, (0, 1000))
         t1 = time.perf_counter()
         for _ in range(3):
             ex.extract_batch(host, (0, 1000))
         pcie_fps = 3 * B / (time.perf_counter() - t1)
+        # the same call with the frames in page-locked host memory (what a capture pipeline that owns its buffers would pass)
+        pinned = torch.from_numpy(host).pin_memory().numpy()
+        ex.extract_batch(pinned, (0, 1000))
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ex.extract_batch(pinned, (0, 1000))
+        pcie_pinned_fps = 3 * B / (time.perf_counter() - t1)
 
     if rank == 0:
         frames_total = world * B * args.steps
@@ -180,6 +187,7 @@ def main() -> None:
         }
         if pcie_fps is not None:
             out["pcie_inclusive_frames_per_s"] = round(pcie_fps, 1)
+            out["pcie_inclusive_pinned_input_frames_per_s"] = round(pcie_pinned_fps, 1)
         if not args.no_cpu_baseline:
             orc = graft.load_oracle()
             threads = min(os.cpu_count() or 1, 16)
