@@ -28,6 +28,9 @@ def test_transform_matches_oracle(pkg, orc, k, L, scoring, weighting, levelsup):
         _same(out, exp)
         if n > 100:
             assert len(out["bow_word"]) < n and len(out["fv_node"]) <= len(out["bow_word"]) + 1  # repeated words, shared ancestors
+    if (k, L) == (10, 4):  # the largest sort: 16384 keys = 128 KB of LDS
+        f = features_near_words(desc, leaf, 16384, 11)
+        _same(voc.transform(f, levelsup), ref.transform(f, levelsup))
     out = voc.transform(np.zeros((0, 32), np.uint8), levelsup)
     assert len(out["bow_word"]) == 0 and len(out["fv_node"]) == 0 and out["fv_start"].tolist() == [0]
     voc.close()
