@@ -211,6 +211,29 @@ def test_batch_parity_and_composition_independence(pkg, orc):
     ex.close()
 
 
+def test_host_batch_in_sub_batches(pkg, orc):
+    """Host-pointer batches of >= 256 frames are staged and processed in sub-batches (copy of the next one under the kernels of
+    this one): 300 frames (sub-batches of 152 + 148), all 300 against the oracle's counts, every 7th frame byte for byte, and
+    the same frames again through the device-resident call (no sub-batches)."""
+    B = 300
+    imgs = np.stack([pkg.synth_frame(5000 + i, 640, 480) for i in range(B)])
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    n, mono, kps, desc = ex.extract_batch(imgs, (100, 500))
+    sel = np.arange(0, B, 7)
+    rc, rmono, rk, rd = orc.Oracle(1000, 1.2, 8, 20, 7).extract_batch(imgs[sel], (100, 500), threads=8, want_outputs=True)
+    assert np.array_equal(n[sel], rc) and np.array_equal(mono[sel], rmono)
+    for j, f in enumerate(sel):
+        assert kps[f][: n[f]].tobytes() == rk[j][: rc[j]].tobytes() and desc[f][: n[f]].tobytes() == rd[j][: rc[j]].tobytes(), f"frame {f}"
+    import torch
+    d = torch.from_numpy(imgs).cuda()
+    ex.extract_batch_device(d.data_ptr(), B, 640, 480, 640, 640 * 480, (100, 500))
+    n2, mono2, kps2, desc2 = ex.download_outputs(B)
+    assert np.array_equal(n, n2) and np.array_equal(mono, mono2)
+    for f in range(B):
+        assert kps[f][: n[f]].tobytes() == kps2[f][: n[f]].tobytes() and desc[f][: n[f]].tobytes() == desc2[f][: n[f]].tobytes(), f"frame {f}"
+    ex.close()
+
+
 def test_full_size_batch_properties(pkg, orc):
     """BASELINE configs[1] at full size (1024 frames, device-resident): size-independent properties."""
     import torch

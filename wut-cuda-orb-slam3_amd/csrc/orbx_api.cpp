@@ -77,6 +77,8 @@ struct orbx_extractor {
     hipStream_t stream3 = nullptr;          // back stream: quadtree -> pack -> orientation + descriptors
     hipEvent_t evJoin = nullptr;
     hipEvent_t evFront[8] = {}, evBlur[8] = {};  // per sub-batch hand-offs between the streams
+    hipStream_t streamCopy = nullptr;       // host-pointer API: H2D of sub-batch i + 1 under the kernels of sub-batch i
+    hipEvent_t evCopy[8] = {};
     hipEvent_t evLevel[ORBX_MAX_LEVELS] = {};    // level l of the pyramid is complete (recorded after pyr_fast(l-1))
 
     // geometry of the current image size
@@ -215,7 +217,9 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     for (int i = 0; i < 8 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&ex->evFront[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBlur[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evCopy[i], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->streamCopy, hipStreamNonBlocking);
     for (int i = 0; i < ORBX_MAX_LEVELS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ex->evLevel[i], hipEventDisableTiming);
     if (e != hipSuccess) { orbx_destroy(ex); return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ex->d_raw.resize(nl); ex->d_blur.resize(nl);
@@ -230,6 +234,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
 {
     if (!ex) return;
     (void)hipSetDevice(ex->prm.device);
+    if (ex->streamCopy) { (void)hipStreamSynchronize(ex->streamCopy); (void)hipStreamDestroy(ex->streamCopy); }
     if (ex->stream3) { (void)hipStreamSynchronize(ex->stream3); (void)hipStreamDestroy(ex->stream3); }
     if (ex->stream2) { (void)hipStreamSynchronize(ex->stream2); (void)hipStreamDestroy(ex->stream2); }
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
@@ -237,6 +242,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     for (int i = 0; i < 8; ++i) {
         if (ex->evFront[i]) (void)hipEventDestroy(ex->evFront[i]);
         if (ex->evBlur[i]) (void)hipEventDestroy(ex->evBlur[i]);
+        if (ex->evCopy[i]) (void)hipEventDestroy(ex->evCopy[i]);
     }
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i)
         if (ex->evLevel[i]) (void)hipEventDestroy(ex->evLevel[i]);
@@ -548,8 +554,19 @@ static OrbxTables makeTables(const orbx_extractor *ex)
 // stream) of sub-batch s.  No buffer is shared between sub-batches (everything is indexed by frame), so no double
 // buffering is needed.  The front stream finally waits for the back stream: orbx_sync() and the next batch order
 // themselves after all work of this batch.
+struct HostFrames { const uint8_t *imgs; ptrdiff_t stride, frameStride; };  // host-pointer API: frames still to be staged into d_imgs
+
+static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0,
+                    int lap1, const HostFrames *host);
+
 extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride,
                                          ptrdiff_t frame_stride, int lap0, int lap1)
+{
+    return runBatch(ex, d_imgs, nframes, w, h, stride, frame_stride, lap0, lap1, nullptr);
+}
+
+static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0,
+                    int lap1, const HostFrames *host)
 {
     if (!ex || !d_imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: null argument");
     if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: bad shape");
@@ -569,6 +586,9 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     // sub-batch size: a multiple of 8 frames (one frame per XCD in flight), at least 64 frames
     static const int maxSub = [] { const char *e = getenv("ORBX_SUBBATCHES"); int v = e ? atoi(e) : 1; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
     int nsub = std::min(maxSub, std::max(1, nframes / 64));
+    // frames arriving from the host: sub-batches of >= 128 frames, so that the copy of the next one runs under this one's kernels
+    static const int hostSub = [] { const char *e = getenv("ORBX_HOST_SUBBATCHES"); int v = e ? atoi(e) : 4; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
+    if (host) nsub = std::max(nsub, std::min(hostSub, std::max(1, nframes / 128)));
     const int subSize = ((nframes + nsub - 1) / nsub + 7) / 8 * 8;
     nsub = (nframes + subSize - 1) / subSize;
 
@@ -578,7 +598,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     // where the launches of a stream run one after the other and each costs an instance's latency (1 frame: 0.37 ms per call with
     // one launch, 0.67 ms with pairs; 512 frames: 2.05 vs 2.10 ms; tools/experiments/qt_mode_sweep.sh)
     static const int qtPerLevelEnv = [] { const char *e = getenv("ORBX_QT_PER_LEVEL"); return e ? atoi(e) : -1; }();
-    const int qtPerLevel = qtPerLevelEnv >= 0 ? qtPerLevelEnv : (nframes >= 640 ? 3 : 0);
+    const int qtPerLevel = qtPerLevelEnv >= 0 ? qtPerLevelEnv : (subSize >= 640 ? 3 : 0);
     static const bool earlyBlur = [] { const char *e = getenv("ORBX_EARLY_BLUR"); return e ? atoi(e) != 0 : false; }();  // measured: 6.37 ms with early blur vs 6.02 ms with blur || quadtree
     hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * PROF_EVENTS] : nullptr;
     if (earlyBlur) {
@@ -588,6 +608,25 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs,
     }
     for (int sb = 0; sb < nsub; ++sb) {
         const int f0 = sb * subSize, nf = std::min(subSize, nframes - f0);
+        if (host) {
+            // stage this sub-batch's frames: one 2-D copy when the frames are row-contiguous on both sides, else one per frame
+            uint8_t *dst = (uint8_t *)const_cast<void *>(d_imgs) + (size_t)f0 * frame_stride;
+            const uint8_t *srcH = host->imgs + (size_t)f0 * host->frameStride;
+            if (sb == 0) {  // the staging buffer is free once everything ordered before this call on the front stream is done
+                HIP_TRY(hipEventRecord(ex->evCopy[0], sFront));
+                HIP_TRY(hipStreamWaitEvent(ex->streamCopy, ex->evCopy[0], 0));
+            }
+            if (host->frameStride == host->stride * h && frame_stride == stride * h) {
+                HIP_TRY(hipMemcpy2DAsync(dst, stride, srcH, host->stride, w, (size_t)h * nf, hipMemcpyHostToDevice, ex->streamCopy));
+            } else {
+                for (int f = 0; f < nf; ++f)
+                    HIP_TRY(hipMemcpy2DAsync(dst + (size_t)f * frame_stride, stride, srcH + (size_t)f * host->frameStride, host->stride, w, h,
+                                             hipMemcpyHostToDevice, ex->streamCopy));
+            }
+            HIP_TRY(hipEventRecord(ex->evCopy[sb], ex->streamCopy));
+            HIP_TRY(hipStreamWaitEvent(sFront, ex->evCopy[sb], 0));
+            HIP_TRY(hipStreamWaitEvent(sBlur, ex->evCopy[sb], 0));
+        }
         // ---- front: fused pyramid + FAST, one launch per level -----------------------------------------------
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 0) * 2], sFront));
         for (int l = 0; l < nl; ++l) {
@@ -751,16 +790,9 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
     int rc = computeGeometry(ex, w, h);
     if (rc != ORBX_OK) return rc;
     if ((rc = ensureBuffers(ex)) != ORBX_OK) return rc;
-    // H2D staging: one 2-D copy for the whole batch when the frames are row-contiguous (rows of all frames form one
-    // [nframes * h] x w matrix with a constant row pitch on both sides), else one 2-D copy per frame
-    if (frame_stride == (ptrdiff_t)stride * h && ex->inFrameStride == (long long)ex->inPitch * h) {
-        HIP_TRY(hipMemcpy2DAsync(ex->d_in.p, ex->inPitch, imgs, stride, w, (size_t)h * nframes, hipMemcpyHostToDevice, ex->stream));
-    } else {
-        for (int f = 0; f < nframes; ++f)
-            HIP_TRY(hipMemcpy2DAsync(ex->d_in.p + (size_t)f * ex->inFrameStride, ex->inPitch, imgs + (size_t)f * frame_stride, stride, w, h,
-                                     hipMemcpyHostToDevice, ex->stream));
-    }
-    rc = orbx_extract_batch_device(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1);
+    // H2D staging happens inside the launch sequence, sub-batch by sub-batch on the copy stream
+    const HostFrames host = {imgs, stride, frame_stride};
+    rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &host);
     if (rc != ORBX_OK) return rc;
     return orbx_download_outputs(ex, nframes, kps, desc, capacity, n_out, mono_out);
 }
