@@ -987,10 +987,11 @@ __global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
     const long Bh = (long)(((unsigned long)bh1 << 32) | bh0), Bv = (long)(((unsigned long)bv1 << 32) | bv0);
     const bool fast = x0 >= 4 && x0 + 28 <= a.w;  // the whole window lies inside the image
     // LDS byte offsets of this lane's 8 window columns (strips at the image border: REFLECT_101, clamped where the tap is 0)
-    int colOff[8];
+    int colOff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!fast) {  // wave-uniform: only the strips at the left / right image border pay for the reflections
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj)
-        colOff[jj] = fast ? 0 : min(max(bl3_reflect(x0 - 4 + 8 * g + jj, a.w) - tx0, 0), TW + 31);
+        for (int jj = 0; jj < 8; ++jj) colOff[jj] = min(max(bl3_reflect(x0 - 4 + 8 * g + jj, a.w) - tx0, 0), TW + 31);
+    }
     const uint8_t *myRow = tile + n * LP + (x0 - 4 + 8 * g - tx0);
     auto loadA = [&](int i) -> uint2 {  // rows 16 (b0 + i) - 3 + (lane & 15) of the extended image, pixels - 128
         if (biasLane) return make_uint2(a.biasH, 0);
