@@ -724,7 +724,8 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
                 g.nTiles, g.nGroups, g.ncy, g.groupCells, g.ldsBytes, PF_NT, nb);
     }
     dim3 grid(xcd_grid(nframes, g.nTiles));
-    hipLaunchKernelGGL(k_pyr_fast, grid, dim3(PF_NT), g.ldsBytes, st, a);
+    static const int ldsPad = [] { const char *e = getenv("ORBX_PF_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments
+    hipLaunchKernelGGL(k_pyr_fast, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
     return hipGetLastError();
 }
 
