@@ -269,6 +269,17 @@ int orbx_search_by_bow(orbx_matcher *m, const int32_t *kf_fv_node, const int32_t
                        const int32_t *f_fv_start, const int32_t *f_fv_feature, int f_nfv, const orbx_keypoint *f_keys, const uint8_t *f_desc,
                        int f_n, float nnratio, int check_orientation, int32_t *matches);
 
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint*> &vpMatches12) — reference
+ * src/ORBmatcher2.cc:37-177 (decl include/ORBmatcher.h:63; loop closing / merging), NLeft == -1 on both sides.  As
+ * orbx_search_by_bow, with valid2 masking the second keyframe's features (its map point exists and !isBad()), the strict distance
+ * test of that overload (bestDist1 < TH_LOW) and the result indexed by the first keyframe's feature: matches12[idx1] = idx2 whose
+ * map point vpMatches12[idx1] becomes, -1 = NULL.  Returns nmatches (>= 0) or a negative status. */
+int orbx_search_by_bow_keyframes(orbx_matcher *m, const int32_t *fv1_node, const int32_t *fv1_start, const int32_t *fv1_feature, int nfv1,
+                                 const orbx_keypoint *keys1, const uint8_t *desc1, const uint8_t *valid1, int n1, const int32_t *fv2_node,
+                                 const int32_t *fv2_start, const int32_t *fv2_feature, int nfv2, const orbx_keypoint *keys2,
+                                 const uint8_t *desc2, const uint8_t *valid2, int n2, float nnratio, int check_orientation,
+                                 int32_t *matches12);
+
 /* void Frame::UndistortKeyPoints() — reference src/Frame.cc:777-811 (decl include/Frame.h): mvKeysUn from mvKeys.
  * k4 = fx, fy, cx, cy of static_cast<Pinhole*>(mpCamera)->toK(); dist = mDistCoef (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]], up to
  * 12 floats); knew4 = fx, fy, cx, cy of mK.  dist[0] == 0 (or ndist == 0) copies, as the reference does; otherwise

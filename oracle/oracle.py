@@ -75,6 +75,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_vocabulary_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
         L.oracle_search_by_bow.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
+        L.oracle_search_by_bow_keyframes.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                     c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -388,4 +390,19 @@ def search_by_bow(kf_fv, kf_keys, kf_desc, kf_valid, f_fv, f_keys, f_desc, nnrat
     n = lib().oracle_search_by_bow(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]), kk.ctypes.data, kd.ctypes.data, kv.ctypes.data,
                                    b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data, len(b[0]), fk.ctypes.data, fd.ctypes.data, len(fk),
                                    float(nnratio), int(bool(check_orientation)), matches.ctypes.data)
+    return n, matches
+
+
+def search_by_bow_keyframes(fv1, keys1, desc1, valid1, fv2, keys2, desc2, valid2, nnratio=0.8, check_orientation=True):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher2.cc:37-177) -> (nmatches, matches12[n1])."""
+    k1 = np.ascontiguousarray(keys1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(keys2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    v1 = np.ascontiguousarray(valid1, np.uint8); v2 = np.ascontiguousarray(valid2, np.uint8)
+    a = [np.ascontiguousarray(fv1[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+    b = [np.ascontiguousarray(fv2[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+    matches = np.full(len(k1), -1, np.int32)
+    n = lib().oracle_search_by_bow_keyframes(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]), k1.ctypes.data, d1.ctypes.data,
+                                             v1.ctypes.data, len(k1), b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data, len(b[0]),
+                                             k2.ctypes.data, d2.ctypes.data, v2.ctypes.data, len(k2), float(nnratio),
+                                             int(bool(check_orientation)), matches.ctypes.data)
     return n, matches

@@ -1480,6 +1480,71 @@ int oracle_search_by_bow(const int32_t *kf_node, const int32_t *kf_start, const 
     return nmatches;
 }
 
+// int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) — reference src/ORBmatcher2.cc:37-177
+// (NLeft == -1 on both sides).  valid1 / valid2[i] = the keyframe's map point i exists and !isBad(); matches12[idx1] = idx2 whose
+// map point vpMatches12[idx1] becomes, -1 = NULL.  Differences from the frame variant: the second side is masked by valid2 and
+// vbMatched2, the distance test is strict (bestDist1 < TH_LOW), the result and the rotation bins are indexed by idx1.
+int oracle_search_by_bow_keyframes(const int32_t *node1, const int32_t *start1, const int32_t *feat1, int nfv1, const oracle_keypoint *keys1,
+                                   const uint8_t *desc1, const uint8_t *valid1, int n1, const int32_t *node2, const int32_t *start2,
+                                   const int32_t *feat2, int nfv2, const oracle_keypoint *keys2, const uint8_t *desc2, const uint8_t *valid2,
+                                   int n2, float nnratio, int check_orientation, int32_t *matches12)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    std::vector<bool> vbMatched2((size_t)n2, false);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    int f1it = 0, f2it = 0;
+    while (f1it != nfv1 && f2it != nfv2) {
+        if (node1[f1it] == node2[f2it]) {
+            for (int i1 = start1[f1it]; i1 < start1[f1it + 1]; i1++) {
+                const int idx1 = feat1[i1];
+                if (!valid1[idx1]) continue;
+                const uint8_t *d1 = desc1 + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = start2[f2it]; i2 < start2[f2it + 1]; i2++) {
+                    const int idx2 = feat2[i2];
+                    if (vbMatched2[idx2] || !valid2[idx2]) continue;
+                    const int dist = oracle_hamming256(d1, desc2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (check_orientation) {
+                            float rot = keys1[idx1].angle - keys2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++; f2it++;
+        } else if (node1[f1it] < node2[f2it]) {
+            f1it = (int)(std::lower_bound(node1, node1 + nfv1, node2[f2it]) - node1);
+        } else {
+            f2it = (int)(std::lower_bound(node2, node2 + nfv2, node1[f1it]) - node2);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        computeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 }  // extern "C"
 
 extern "C" {

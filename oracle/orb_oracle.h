@@ -154,6 +154,12 @@ int oracle_search_by_bow(const int32_t *kf_node, const int32_t *kf_start, const 
                          int f_nfv, const oracle_keypoint *f_keys, const uint8_t *f_desc, int f_n, float nnratio, int check_orientation,
                          int32_t *matches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (src/ORBmatcher2.cc:37-177), NLeft == -1. */
+int oracle_search_by_bow_keyframes(const int32_t *node1, const int32_t *start1, const int32_t *feat1, int nfv1, const oracle_keypoint *keys1,
+                                   const uint8_t *desc1, const uint8_t *valid1, int n1, const int32_t *node2, const int32_t *start2,
+                                   const int32_t *feat2, int nfv2, const oracle_keypoint *keys2, const uint8_t *desc2, const uint8_t *valid2,
+                                   int n2, float nnratio, int check_orientation, int32_t *matches12);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

@@ -174,3 +174,24 @@ def test_search_by_bow_contention(pkg, orc):
         assert n == rn and np.array_equal(matches, rmatches)
     assert n > 20
     voc.close(); m.close()
+
+
+@pytest.mark.parametrize("levelsup,ratio,check", [(2, 0.8, True), (4, 0.75, True), (1, 0.9, False)])
+def test_search_by_bow_keyframes(pkg, orc, levelsup, ratio, check):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher2.cc:37-177): the keyframe - keyframe overload
+    (second side masked by its own map points, strict distance test, result indexed by the first keyframe's features)."""
+    k1, d1, k2, d2, rng = _two_views(pkg, 47)
+    parent, leaf, desc, weight = _vocabulary_from_descriptors(d1, 10, 4, 17)
+    voc = pkg.ORBVocabulary(10, 4, 0, 0, parent=parent, is_leaf=leaf, desc=desc, weight=weight)
+    fv1, fv2 = voc.transform(d1, levelsup), voc.transform(d2, levelsup)
+    v1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    v2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    m = pkg.ORBmatcher(8192, 8192)
+    n, m12 = m.SearchByBoWKeyFrames(fv1, k1, d1, v1, fv2, k2, d2, v2, ratio, check)
+    rn, rm12 = orc.search_by_bow_keyframes(fv1, k1, d1, v1, fv2, k2, d2, v2, ratio, check)
+    assert n == rn and np.array_equal(m12, rm12)
+    got = m12 >= 0
+    assert n == got.sum() > 50 and (v1[got] == 1).all() and (v2[m12[got]] == 1).all() and len(set(m12[got].tolist())) == n
+    n0, m0 = m.SearchByBoWKeyFrames(fv1, k1, d1, v1, fv2, k2, d2, np.zeros(len(k2), np.uint8), ratio, check)
+    assert n0 == 0 and (m0 == -1).all()
+    voc.close(); m.close()

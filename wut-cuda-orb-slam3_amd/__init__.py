@@ -63,6 +63,7 @@ ABI_SYMBOLS = [
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points",
     "orbx_search_by_bow",
+    "orbx_search_by_bow_keyframes",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
     "orbx_vocabulary_create",
@@ -140,6 +141,8 @@ def load_library() -> ctypes.CDLL:
                                                      c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
     lib.orbx_search_by_bow.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                        c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
+    lib.orbx_search_by_bow_keyframes.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
@@ -413,6 +416,24 @@ class ORBmatcher:
                                          fd.ctypes.data, len(fk), float(nnratio), int(bool(checkOrientation)), matches.ctypes.data)
         if n < 0:
             _check(n, "orbx_search_by_bow")
+        return n, matches
+
+    def SearchByBoWKeyFrames(self, fv1, keys1, desc1, valid1, fv2, keys2, desc2, valid2, nnratio: float = 0.8, checkOrientation: bool = True):
+        """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (reference src/ORBmatcher2.cc:37-177).  Returns (nmatches, matches12[n1]) with
+        matches12[idx1] = feature of the second keyframe whose map point vpMatches12[idx1] becomes, or -1."""
+        k1 = np.ascontiguousarray(keys1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(keys2, KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        v1 = np.ascontiguousarray(valid1, np.uint8); v2 = np.ascontiguousarray(valid2, np.uint8)
+        assert len(d1) == len(k1) == len(v1) and len(d2) == len(k2) == len(v2)
+        a = [np.ascontiguousarray(fv1[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+        b = [np.ascontiguousarray(fv2[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+        matches = np.full(len(k1), -1, np.int32)
+        n = self._lib.orbx_search_by_bow_keyframes(self._h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]), k1.ctypes.data,
+                                                   d1.ctypes.data, v1.ctypes.data, len(k1), b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data,
+                                                   len(b[0]), k2.ctypes.data, d2.ctypes.data, v2.ctypes.data, len(k2), float(nnratio),
+                                                   int(bool(checkOrientation)), matches.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_bow_keyframes")
         return n, matches
 
     @staticmethod

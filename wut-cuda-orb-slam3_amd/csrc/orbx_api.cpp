@@ -1039,28 +1039,32 @@ static int checkFeatureVector(const int32_t *node, const int32_t *start, const i
     return ORBX_OK;
 }
 
-extern "C" int orbx_search_by_bow(orbx_matcher *m, const int32_t *kf_fv_node, const int32_t *kf_fv_start, const int32_t *kf_fv_feature,
-                                  int kf_nfv, const orbx_keypoint *kf_keys, const uint8_t *kf_desc, const uint8_t *kf_valid, int kf_n,
-                                  const int32_t *f_fv_node, const int32_t *f_fv_start, const int32_t *f_fv_feature, int f_nfv,
-                                  const orbx_keypoint *f_keys, const uint8_t *f_desc, int f_n, float nnratio, int check_orientation,
-                                  int32_t *matches)
+// mode 0: matches[f_n] indexed by frame feature; mode 1 (keyframe - keyframe, src/ORBmatcher2.cc:37-177): f_valid masks the second
+// side, matches[kf_n] indexed by the first keyframe's feature
+static int searchByBowImpl(orbx_matcher *m, const int32_t *kf_fv_node, const int32_t *kf_fv_start, const int32_t *kf_fv_feature,
+                           int kf_nfv, const orbx_keypoint *kf_keys, const uint8_t *kf_desc, const uint8_t *kf_valid, int kf_n,
+                           const int32_t *f_fv_node, const int32_t *f_fv_start, const int32_t *f_fv_feature, int f_nfv,
+                           const orbx_keypoint *f_keys, const uint8_t *f_desc, const uint8_t *f_valid, int f_n, float nnratio,
+                           int check_orientation, int mode, int32_t *matches)
 {
-    if (!m || kf_n < 0 || f_n < 0 || (kf_n > 0 && (!kf_keys || !kf_desc || !kf_valid)) || (f_n > 0 && (!f_keys || !f_desc || !matches)))
+    const int nOut = mode == 0 ? f_n : kf_n;
+    if (!m || kf_n < 0 || f_n < 0 || (kf_n > 0 && (!kf_keys || !kf_desc || !kf_valid)) || (f_n > 0 && (!f_keys || !f_desc)) ||
+        (nOut > 0 && !matches) || (mode == 1 && f_n > 0 && !f_valid))
         return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: bad argument");
     if (kf_n > m->maxQ || f_n > m->maxT || f_n > 65535)
         return setError(ORBX_ERR_CAPACITY, "%d x %d features exceed the matcher capacity %d x %d", kf_n, f_n, m->maxQ, std::min(m->maxT, 65535));
     int rc;
     if ((rc = checkFeatureVector(kf_fv_node, kf_fv_start, kf_fv_feature, kf_nfv, kf_n, "keyframe")) != ORBX_OK) return rc;
     if ((rc = checkFeatureVector(f_fv_node, f_fv_start, f_fv_feature, f_nfv, f_n, "frame")) != ORBX_OK) return rc;
-    for (int i = 0; i < f_n; ++i) matches[i] = -1;
+    for (int i = 0; i < nOut; ++i) matches[i] = -1;
     if (kf_nfv == 0 || f_nfv == 0 || kf_n == 0 || f_n == 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
     if ((rc = uploadQT(m, kf_desc, kf_n, f_desc, f_n)) != ORBX_OK) return rc;
-    const size_t Q = (size_t)m->maxQ, T = (size_t)m->maxT;
-    if ((rc = m->d_work.ensure(3 * Q + 5 * T + 2 + 64)) != ORBX_OK) return rc;
-    if ((rc = m->d_bin.ensure(Q)) != ORBX_OK) return rc;
+    const size_t Q = (size_t)m->maxQ, T = (size_t)m->maxT, X = std::max(Q, T);
+    if ((rc = m->d_work.ensure(3 * Q + 3 * T + 2 * X + 2 + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_bin.ensure(Q + T)) != ORBX_OK) return rc;
     int *kfNode = m->d_work.p, *kfStart = kfNode + Q, *kfFeat = kfStart + Q + 1, *fNode = kfFeat + Q, *fStart = fNode + T, *fFeat = fStart + T + 1,
-        *dMatches = fFeat + T, *binOf = dMatches + T, *result = binOf + T;
+        *dMatches = fFeat + T, *binOf = dMatches + X, *result = binOf + X;
     int maxNodeF = 1;
     for (int j = 0; j < f_nfv; ++j) maxNodeF = std::max(maxNodeF, f_fv_start[j + 1] - f_fv_start[j]);
     hipStream_t st = m->stream;
@@ -1073,13 +1077,35 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const int32_t *kf_fv_node, co
     HIP_TRY(hipMemcpyAsync(m->d_kl.p, kf_keys, (size_t)kf_n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->d_kr.p, f_keys, (size_t)f_n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->d_bin.p, kf_valid, (size_t)kf_n, hipMemcpyHostToDevice, st));
+    if (mode == 1) HIP_TRY(hipMemcpyAsync(m->d_bin.p + Q, f_valid, (size_t)f_n, hipMemcpyHostToDevice, st));
     HIP_TRY(orbxLaunchSearchByBoW(st, kfNode, kfStart, kfFeat, kf_nfv, m->d_kl.p, m->d_q.p, m->d_bin.p, fNode, fStart, fFeat, f_nfv, m->d_kr.p,
-                                  m->d_t.p, f_n, maxNodeF, nnratio, check_orientation != 0, dMatches, binOf, result));
+                                  m->d_t.p, f_n, maxNodeF, nnratio, check_orientation != 0, mode, m->d_bin.p + Q, nOut, dMatches, binOf, result));
     int nmatches = 0;
-    HIP_TRY(hipMemcpyAsync(matches, dMatches, (size_t)f_n * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(matches, dMatches, (size_t)nOut * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&nmatches, result, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return nmatches;
+}
+
+extern "C" int orbx_search_by_bow(orbx_matcher *m, const int32_t *kf_fv_node, const int32_t *kf_fv_start, const int32_t *kf_fv_feature,
+                                  int kf_nfv, const orbx_keypoint *kf_keys, const uint8_t *kf_desc, const uint8_t *kf_valid, int kf_n,
+                                  const int32_t *f_fv_node, const int32_t *f_fv_start, const int32_t *f_fv_feature, int f_nfv,
+                                  const orbx_keypoint *f_keys, const uint8_t *f_desc, int f_n, float nnratio, int check_orientation,
+                                  int32_t *matches)
+{
+    return searchByBowImpl(m, kf_fv_node, kf_fv_start, kf_fv_feature, kf_nfv, kf_keys, kf_desc, kf_valid, kf_n, f_fv_node, f_fv_start,
+                           f_fv_feature, f_nfv, f_keys, f_desc, nullptr, f_n, nnratio, check_orientation, 0, matches);
+}
+
+// int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) — reference src/ORBmatcher2.cc:37-177.
+extern "C" int orbx_search_by_bow_keyframes(orbx_matcher *m, const int32_t *fv1_node, const int32_t *fv1_start, const int32_t *fv1_feature,
+                                            int nfv1, const orbx_keypoint *keys1, const uint8_t *desc1, const uint8_t *valid1, int n1,
+                                            const int32_t *fv2_node, const int32_t *fv2_start, const int32_t *fv2_feature, int nfv2,
+                                            const orbx_keypoint *keys2, const uint8_t *desc2, const uint8_t *valid2, int n2, float nnratio,
+                                            int check_orientation, int32_t *matches12)
+{
+    return searchByBowImpl(m, fv1_node, fv1_start, fv1_feature, nfv1, keys1, desc1, valid1, n1, fv2_node, fv2_start, fv2_feature, nfv2, keys2,
+                           desc2, valid2, n2, nnratio, check_orientation, 1, matches12);
 }
 
 // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811.

@@ -117,7 +117,7 @@ hipError_t orbxLaunchBowTransform(hipStream_t st, const int *childStart, const i
 hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *kfStart, const int *kfFeat, int kfNfv, const void *kfKeys,
                                  const uint8_t *kfDesc, const signed char *kfValid, const int *fNode, const int *fStart, const int *fFeat,
                                  int fNfv, const void *fKeys, const uint8_t *fDesc, int nF, int maxNodeF, float nnratio, int checkOri,
-                                 int *matches, int *binOf, int *result);
+                                 int mode, const signed char *fValid, int nOut, int *matches, int *binOf, int *result);
 hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4);
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
                                int *items, int *cellOf);

@@ -1054,8 +1054,11 @@ struct SbowArgs {
     const int *fNode, *fStart, *fFeat; int fNfv;
     const MtKp *fKeys; const uint8_t *fDesc; int nF;
     float nnratio; int checkOri;
-    int *matches;  // [nF] out (-1 preset)
-    int *binOf;    // [nF] work
+    int mode;                    // 0: SearchByBoW(KeyFrame, Frame); 1: SearchByBoW(KeyFrame, KeyFrame) - src/ORBmatcher2.cc:37-177
+    const signed char *fValid;   // mode 1: the second keyframe's map point exists and !isBad()
+    int nOut;                    // entries of matches / binOf: nF (mode 0, indexed by frame feature), kf_n (mode 1, by idx1)
+    int *matches;  // [nOut] out (-1 preset)
+    int *binOf;    // [nOut] work
     int *result;   // [0] nmatches, [1 .. 30] rotation histogram
 };
 
@@ -1076,7 +1079,7 @@ __global__ __launch_bounds__(64) void k_sbow_match(SbowArgs a)
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fNode[mid] < node) lo = mid + 1; else hi = mid; }
     if (lo >= a.fNfv || a.fNode[lo] != node) return;
     const int fs = a.fStart[lo], nFn = a.fStart[lo + 1] - fs;
-    for (int i = lane; i < nFn; i += 64) taken[i] = 0;
+    for (int i = lane; i < nFn; i += 64) taken[i] = a.mode == 1 && !a.fValid[a.fFeat[fs + i]] ? 1 : 0;  // (mode 1: !pMP2 || isBad())
     uint32_t d0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int realF0 = -1;
     if (lane < nFn) {
@@ -1114,18 +1117,20 @@ __global__ __launch_bounds__(64) void k_sbow_match(SbowArgs a)
         const unsigned best = sbow_wave_min(k1);
         const unsigned second = sbow_wave_min(k1 == best ? k2 : k1);  // (keys are unique: the position is part of them)
         const int bestDist1 = (int)(best >> 16), bestDist2 = (int)(second >> 16);
-        if (bestDist1 <= TH_LOW && (float)bestDist1 < __fmul_rn(a.nnratio, (float)bestDist2)) {
+        const bool near = a.mode == 0 ? bestDist1 <= TH_LOW : bestDist1 < TH_LOW;  // (:352 `<=`, ORBmatcher2.cc:127 `<`)
+        if (near && (float)bestDist1 < __fmul_rn(a.nnratio, (float)bestDist2)) {
             const int pos = (int)(best & 0xFFFFu);
             if (lane == 0) {
                 const int bestIdxF = a.fFeat[fs + pos];
                 taken[pos] = 1;
-                a.matches[bestIdxF] = realIdxKF;
+                const int slot = a.mode == 0 ? bestIdxF : realIdxKF;  // vpMapPointMatches[bestIdxF] / vpMatches12[idx1]
+                a.matches[slot] = a.mode == 0 ? realIdxKF : bestIdxF;
                 if (a.checkOri) {
                     float rot = __fsub_rn(a.kfKeys[realIdxKF].angle, a.fKeys[bestIdxF].angle);
                     if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                     int bin = (int)roundf(__fmul_rn(rot, factor));
                     if (bin == HISTO_LENGTH) bin = 0;
-                    a.binOf[bestIdxF] = bin;
+                    a.binOf[slot] = bin;
                     atomicAdd(&a.result[1 + bin], 1);
                 }
                 atomicAdd(&a.result[0], 1);
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_sbow_finish(SbowArgs a)
     if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
     else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
     __syncthreads();
-    for (int i = threadIdx.x; i < a.nF; i += 256) {
+    for (int i = threadIdx.x; i < a.nOut; i += 256) {
         if (a.matches[i] < 0) continue;
         const int bin = a.binOf[i];
         if (bin != ind1 && bin != ind2 && bin != ind3) { a.matches[i] = -1; atomicAdd(&removed, 1); }
@@ -1163,14 +1168,15 @@ __global__ __launch_bounds__(256) void k_sbow_finish(SbowArgs a)
 hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *kfStart, const int *kfFeat, int kfNfv, const void *kfKeys,
                                  const uint8_t *kfDesc, const signed char *kfValid, const int *fNode, const int *fStart, const int *fFeat,
                                  int fNfv, const void *fKeys, const uint8_t *fDesc, int nF, int maxNodeF, float nnratio, int checkOri,
-                                 int *matches, int *binOf, int *result)
+                                 int mode, const signed char *fValid, int nOut, int *matches, int *binOf, int *result)
 {
     SbowArgs a;
+    a.mode = mode; a.fValid = fValid; a.nOut = nOut;
     a.kfNode = kfNode; a.kfStart = kfStart; a.kfFeat = kfFeat; a.kfNfv = kfNfv; a.kfKeys = (const MtKp *)kfKeys; a.kfDesc = kfDesc;
     a.kfValid = kfValid; a.fNode = fNode; a.fStart = fStart; a.fFeat = fFeat; a.fNfv = fNfv; a.fKeys = (const MtKp *)fKeys; a.fDesc = fDesc;
     a.nF = nF; a.nnratio = nnratio; a.checkOri = checkOri; a.matches = matches; a.binOf = binOf; a.result = result;
     hipError_t e = hipMemsetAsync(result, 0, 32 * sizeof(int), st);
-    if (e == hipSuccess && nF > 0) e = hipMemsetAsync(matches, 0xFF, (size_t)nF * sizeof(int), st);
+    if (e == hipSuccess && nOut > 0) e = hipMemsetAsync(matches, 0xFF, (size_t)nOut * sizeof(int), st);
     if (e != hipSuccess) return e;
     if (kfNfv > 0 && fNfv > 0) {
         const size_t lds = ((size_t)std::max(maxNodeF, 1) + 63) & ~(size_t)63;

@@ -255,6 +255,33 @@ public:
         return n;
     }
 
+    // int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint*> &vpMatches12) — reference include/ORBmatcher.h:63,
+    // src/ORBmatcher2.cc:37-177 (NLeft == -1).  vnMatches12[idx1] = feature of pKF2 whose map point vpMatches12[idx1] becomes, -1 = NULL.
+    int SearchByBoW(const FeatureVector &vFeatVec1, const FrameView &KF1, const std::vector<uint8_t> &vbValid1, const FeatureVector &vFeatVec2,
+                    const FrameView &KF2, const std::vector<uint8_t> &vbValid2, std::vector<int> &vnMatches12)
+    {
+        const int n1 = (int)KF1.mvKeysUn->size(), n2 = (int)KF2.mvKeysUn->size();
+        if ((int)vbValid1.size() != n1 || (int)vbValid2.size() != n2) throw std::runtime_error("SearchByBoW: inconsistent array sizes");
+        std::vector<int32_t> node[2], start[2], feat[2];
+        const FeatureVector *fv[2] = {&vFeatVec1, &vFeatVec2};
+        for (int s = 0; s < 2; ++s) {
+            start[s].push_back(0);
+            for (FeatureVector::const_iterator it = fv[s]->begin(); it != fv[s]->end(); ++it) {
+                node[s].push_back((int32_t)it->first);
+                feat[s].insert(feat[s].end(), it->second.begin(), it->second.end());
+                start[s].push_back((int32_t)feat[s].size());
+            }
+        }
+        vnMatches12.assign((size_t)n1, -1);
+        const int n = orbx_search_by_bow_keyframes(m_, node[0].data(), start[0].data(), feat[0].data(), (int)node[0].size(),
+                                                   (const orbx_keypoint *)KF1.mvKeysUn->data(), KF1.mDescriptors->data.data(), vbValid1.data(), n1,
+                                                   node[1].data(), start[1].data(), feat[1].data(), (int)node[1].size(),
+                                                   (const orbx_keypoint *)KF2.mvKeysUn->data(), KF2.mDescriptors->data.data(), vbValid2.data(), n2,
+                                                   mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data());
+        if (n < 0) check(n, "SearchByBoW");
+        return n;
+    }
+
     // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811: mvKeysUn from mvKeys.  K = toK() and mK as {fx, fy, cx, cy},
     // mDistCoef as the reference's 4 / 5 / 8 / 12 floats (copies when mDistCoef[0] == 0).
     void UndistortKeyPoints(const std::vector<KeyPoint> &mvKeys, const float (&K)[4], const std::vector<float> &mDistCoef, const float (&mK)[4],
