@@ -352,6 +352,13 @@ int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc, int n, in
                               int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start, int32_t *fv_feature,
                               int32_t *n_fv);
 
+/* Frame::ComputeBoW on the extractor's own outputs: the descriptors of frame `frame` of the extractor's last batch are read where
+ * they lie in HBM (no host round trip; the extractor's pending work is awaited).  Capacities: orbx_max_keypoints(ex) entries
+ * (fv_start one more).  Outputs and return value as orbx_vocabulary_transform. */
+int orbx_vocabulary_transform_frame(orbx_vocabulary *v, orbx_extractor *ex, int frame, int levelsup, int32_t *feat_word, int32_t *feat_node,
+                                    int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
+                                    int32_t *fv_feature, int32_t *n_fv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,3 +195,23 @@ def test_search_by_bow_keyframes(pkg, orc, levelsup, ratio, check):
     n0, m0 = m.SearchByBoWKeyFrames(fv1, k1, d1, v1, fv2, k2, d2, np.zeros(len(k2), np.uint8), ratio, check)
     assert n0 == 0 and (m0 == -1).all()
     voc.close(); m.close()
+
+
+def test_transform_frame_from_extractor_outputs(pkg):
+    """orbx_vocabulary_transform_frame reads the descriptors where the extractor left them in HBM: same BowVector / FeatureVector as
+    the host-descriptor call, for every frame of a small batch."""
+    B = 3
+    imgs = np.stack([pkg.synth_frame(300 + i, 640, 480) for i in range(B)])
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    n, mono, kps, desc = ex.extract_batch(imgs, (0, 0))
+    parent, leaf, vdesc, weight = _vocabulary_from_descriptors(desc[0][: n[0]], 10, 3, 5)
+    voc = pkg.ORBVocabulary(10, 3, 0, 0, parent=parent, is_leaf=leaf, desc=vdesc, weight=weight)
+    for f in range(B):
+        a = voc.transform_frame(ex, f, 2)
+        b = voc.transform(desc[f][: n[f]], 2)
+        for key in a:
+            assert a[key].tobytes() == b[key].tobytes(), (f, key)
+        assert len(a["bow_word"]) > 50
+    with pytest.raises(pkg.OrbxError, match="frame"):
+        voc.transform_frame(ex, B, 2)
+    voc.close(); ex.close()

@@ -71,6 +71,7 @@ ABI_SYMBOLS = [
     "orbx_vocabulary_destroy",
     "orbx_vocabulary_size",
     "orbx_vocabulary_transform",
+    "orbx_vocabulary_transform_frame",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -151,6 +152,7 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_vocabulary_destroy.restype = None
     lib.orbx_vocabulary_size.argtypes = [c_void_p]
     lib.orbx_vocabulary_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
+    lib.orbx_vocabulary_transform_frame.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -602,3 +604,20 @@ class ORBVocabulary:
         nb, nv = int(nb[0]), int(nv[0])
         return dict(feat_word=fw, feat_node=fn, bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=vn[:nv].copy(),
                     fv_start=vs[:nv + 1].copy(), fv_feature=vf[:int(vs[nv])].copy())
+
+    def transform_frame(self, extractor: "ORBextractor", frame: int = 0, levelsup: int = 4):
+        """Frame::ComputeBoW on the extractor's device-resident descriptors of `frame` of its last batch (no host round trip)."""
+        if not self._h:
+            raise OrbxError("ORBVocabulary: no vocabulary loaded")
+        n = extractor.capacity
+        fw = np.zeros(n, np.int32); fn = np.zeros(n, np.int32)
+        bw = np.zeros(n, np.int32); bv = np.zeros(n, np.float64); nb = np.zeros(1, np.int32)
+        vn = np.zeros(n, np.int32); vs = np.zeros(n + 1, np.int32); vf = np.zeros(n, np.int32); nv = np.zeros(1, np.int32)
+        rc = self._lib.orbx_vocabulary_transform_frame(self._h, extractor._h, int(frame), int(levelsup), fw.ctypes.data, fn.ctypes.data,
+                                                       bw.ctypes.data, bv.ctypes.data, nb.ctypes.data, vn.ctypes.data, vs.ctypes.data,
+                                                       vf.ctypes.data, nv.ctypes.data)
+        if rc < 0:
+            _check(rc, "orbx_vocabulary_transform_frame")
+        nb, nv = int(nb[0]), int(nv[0])
+        nf = int(vs[nv])
+        return dict(bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=vn[:nv].copy(), fv_start=vs[:nv + 1].copy(), fv_feature=vf[:nf].copy())

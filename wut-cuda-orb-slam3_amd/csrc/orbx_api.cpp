@@ -1451,9 +1451,10 @@ extern "C" int orbx_vocabulary_size(const orbx_vocabulary *v) { return v ? v->nW
 
 // void TemplatedVocabulary::transform(const std::vector<TDescriptor> &features, BowVector &v, FeatureVector &fv, int levelsup)
 // — TemplatedVocabulary.h:1127-1196, as Frame::ComputeBoW / KeyFrame::ComputeBoW call it with levelsup = 4.
-extern "C" int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc, int n, int levelsup, int32_t *feat_word, int32_t *feat_node,
-                                         int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
-                                         int32_t *fv_feature, int32_t *n_fv)
+// desc: host descriptors, or (deviceDesc) descriptors already in HBM on the vocabulary's device
+static int vocabularyTransformImpl(orbx_vocabulary *v, const uint8_t *desc, bool deviceDesc, int n, int levelsup, int32_t *feat_word,
+                                   int32_t *feat_node, int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
+                                   int32_t *fv_feature, int32_t *n_fv)
 {
     if (!v || n < 0 || (n > 0 && !desc) || !n_bow || !n_fv || !fv_start || (n > 0 && (!bow_word || !bow_value || !fv_node || !fv_feature)))
         return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform: bad argument");
@@ -1464,10 +1465,10 @@ extern "C" int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc
     const size_t F = ORBX_BOW_MAX_FEATURES;
     int *featWord = v->d_work.p, *featNode = featWord + F, *bowWord = featNode + F, *fvNode = bowWord + F, *fvStart = fvNode + F,
         *fvFeature = fvStart + F + 1, *counts = fvFeature + F;
-    HIP_TRY(hipMemcpyAsync(v->d_feat.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    if (!deviceDesc) HIP_TRY(hipMemcpyAsync(v->d_feat.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
     HIP_TRY(orbxLaunchBowTransform(v->stream, v->d_childStart.p, v->d_childNode.p, v->d_childDesc.p, v->d_wordOfNode.p, v->d_weight.p, v->L,
-                                   v->scoring, v->weighting, v->d_feat.p, n, levelsup, featWord, featNode, v->d_featWeight.p, bowWord,
-                                   v->d_bowValue.p, fvNode, fvStart, fvFeature, counts));
+                                   v->scoring, v->weighting, deviceDesc ? (const void *)desc : (const void *)v->d_feat.p, n, levelsup, featWord,
+                                   featNode, v->d_featWeight.p, bowWord, v->d_bowValue.p, fvNode, fvStart, fvFeature, counts));
     int cnt[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(cnt, counts, sizeof cnt, hipMemcpyDeviceToHost, v->stream));
     if (feat_word) HIP_TRY(hipMemcpyAsync(feat_word, featWord, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, v->stream));
@@ -1483,4 +1484,28 @@ extern "C" int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc
     if (fv_start[cnt[1]] > 0) HIP_TRY(hipMemcpy(fv_feature, fvFeature, (size_t)fv_start[cnt[1]] * sizeof(int), hipMemcpyDeviceToHost));
     *n_bow = cnt[0]; *n_fv = cnt[1];
     return cnt[0];
+}
+
+extern "C" int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc, int n, int levelsup, int32_t *feat_word, int32_t *feat_node,
+                                         int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
+                                         int32_t *fv_feature, int32_t *n_fv)
+{
+    return vocabularyTransformImpl(v, desc, false, n, levelsup, feat_word, feat_node, bow_word, bow_value, n_bow, fv_node, fv_start, fv_feature, n_fv);
+}
+
+// Frame::ComputeBoW straight from the extractor's results in HBM: the descriptors of frame `frame` of the last batch never visit
+// the host (the extractor's work is awaited first; both handles must live on the same device).
+extern "C" int orbx_vocabulary_transform_frame(orbx_vocabulary *v, orbx_extractor *ex, int frame, int levelsup, int32_t *feat_word,
+                                               int32_t *feat_node, int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node,
+                                               int32_t *fv_start, int32_t *fv_feature, int32_t *n_fv)
+{
+    if (!v || !ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_frame: null handle");
+    if (ex->prm.device != v->device) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_frame: extractor and vocabulary on different devices");
+    if (frame < 0 || frame >= ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_frame: frame %d of %d", frame, ex->lastFrames);
+    HIP_TRY(hipSetDevice(v->device));
+    int32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, ex->d_n.p + frame, sizeof n, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));  // everything of the batch is ordered before this on the front stream
+    const uint8_t *d = ex->d_desc.p + (size_t)frame * ex->maxKeypoints * 32;
+    return vocabularyTransformImpl(v, d, true, n, levelsup, feat_word, feat_node, bow_word, bow_value, n_bow, fv_node, fv_start, fv_feature, n_fv);
 }
