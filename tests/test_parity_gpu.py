@@ -313,3 +313,11 @@ def test_quadtree_deferred_instances(pkg):
     second launch.  At VGA no set reaches the real limit (8192 keys): lower it so that the large levels are deferred while
     the small ones stay on the parallel kernel, and check full parity of the mixed result."""
     _gpu_check_subprocess({"ORBX_QT_MAX_KEYS": "600"}, (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
+
+
+@pytest.mark.parametrize("env", [{"ORBX_BLUR_KERNEL": "2"}, {"ORBX_BLUR_KERNEL": "1"}, {"ORBX_BLUR_WAVES": "8"}])
+def test_blur_fallback_kernels(pkg, env):
+    """The GaussianBlur normally runs on the matrix cores (k_blur3, 4 waves per workgroup); taps that do not fit int8 or
+    unaligned buffers take the byte-SWAR kernel (k_blur2) or the generic one (k_blur), and k_blur3 has an 8-wave shape.  Force
+    each in a subprocess (the switch is read once per process) and check every stage against the oracle."""
+    _gpu_check_subprocess(env, (["640", "480", "1000", "2"], ["333", "257", "600", "1"]))
