@@ -321,3 +321,12 @@ def test_blur_fallback_kernels(pkg, env):
     unaligned buffers take the byte-SWAR kernel (k_blur2) or the generic one (k_blur), and k_blur3 has an 8-wave shape.  Force
     each in a subprocess (the switch is read once per process) and check every stage against the oracle."""
     _gpu_check_subprocess(env, (["640", "480", "1000", "2"], ["333", "257", "600", "1"]))
+
+
+@pytest.mark.parametrize("env,args", [({"ORBX_QT_PER_LEVEL": "1"}, ["640", "480", "1000", "3"]), ({"ORBX_QT_PER_LEVEL": "3"}, ["640", "480", "1000", "3"]),
+                                      ({"ORBX_QT_PER_LEVEL": "4"}, ["752", "480", "1200", "2"]), ({"ORBX_EARLY_BLUR": "1"}, ["640", "480", "1000", "3"]),
+                                      ({"ORBX_SUBBATCHES": "3"}, ["640", "480", "1000", "200"])])
+def test_launch_schedules(pkg, env, args):
+    """The launch sequence has measured alternatives behind environment switches (quadtree per level / per group of levels, blur
+    of a level as soon as it exists, device batches cut into sub-batches): every one of them must give the same bytes."""
+    _gpu_check_subprocess(env, (args,))
