@@ -9,10 +9,11 @@
 // reproduces the exact permutation instead of "a" sorted order.  No recursion: an explicit stack of
 // sub-ranges (the sub-ranges are disjoint, so processing order does not change the result).
 //
-// The algorithm is written against an accessor (get(i) / set(i, v)) so that the device can keep the elements
-// in lane registers (v_readlane / v_writelane with scalar indices: the whole sort then runs at scalar-ALU
-// latency instead of one dependent LDS round trip per element access) while the host tests and the LDS
-// fallback use a plain pointer accessor.  The sequence of comparisons and moves is identical for every accessor.
+// The algorithm is written against an accessor (get(i) / set(i, v)); the host tests and the kernels use the plain
+// pointer accessor (LDS on the device).  An accessor that keeps the elements in lane registers (v_readlane /
+// v_writelane with scalar indices) was measured and is no faster: a lone wave pays about as much for the ~30 scalar
+// instructions of one element step as for one LDS round trip.  The sequence of comparisons and moves is identical
+// for every accessor.
 #ifndef ORBX_LIBSTDCXX_SORT_H
 #define ORBX_LIBSTDCXX_SORT_H
 
