@@ -359,6 +359,13 @@ int orbx_vocabulary_transform_frame(orbx_vocabulary *v, orbx_extractor *ex, int 
                                     int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
                                     int32_t *fv_feature, int32_t *n_fv);
 
+/* The same for the first `nframes` frames of the extractor's last batch in two launches (throughput use: a batch of frames goes from
+ * pixels to BowVectors without leaving HBM in between).  cap = orbx_max_keypoints(ex); frame f: BowVector (bow_word, bow_value)
+ * [f * cap .. + n_bow[f]), FeatureVector nodes fv_node[f * cap .. + n_fv[f]), offsets fv_start[f * (cap + 1) ..], features
+ * fv_feature[f * cap + offset]. */
+int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extractor *ex, int nframes, int levelsup, int32_t *bow_word, double *bow_value,
+                                    int32_t *n_bow, int32_t *fv_node, int32_t *fv_start, int32_t *fv_feature, int32_t *n_fv);
+
 #ifdef __cplusplus
 }
 #endif

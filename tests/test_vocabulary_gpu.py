@@ -215,3 +215,23 @@ def test_transform_frame_from_extractor_outputs(pkg):
     with pytest.raises(pkg.OrbxError, match="frame"):
         voc.transform_frame(ex, B, 2)
     voc.close(); ex.close()
+
+
+def test_transform_batch_from_extractor_outputs(pkg):
+    """A whole batch from pixels to BowVectors without leaving HBM in between: orbx_vocabulary_transform_batch == the per-frame
+    calls, for every frame (ragged keypoint counts; an all-black frame with zero keypoints in the middle)."""
+    B = 6
+    imgs = np.stack([pkg.synth_frame(400 + i, 640, 480) for i in range(B)])
+    imgs[3] = 0
+    ex = pkg.ORBextractor(800, 1.2, 8, 20, 7, max_batch=B)
+    n, mono, kps, desc = ex.extract_batch(imgs, (0, 0))
+    assert n[3] == 0 and n[0] > 700
+    parent, leaf, vdesc, weight = _vocabulary_from_descriptors(desc[0][: n[0]], 10, 3, 6)
+    voc = pkg.ORBVocabulary(10, 3, 0, 0, parent=parent, is_leaf=leaf, desc=vdesc, weight=weight)
+    out = voc.transform_batch(ex, B, 2)
+    for f in range(B):
+        ref = voc.transform(desc[f][: n[f]], 2)
+        for key in out[f]:
+            assert out[f][key].tobytes() == ref[key].tobytes(), (f, key)
+    assert len(out[3]["bow_word"]) == 0 and len(out[0]["bow_word"]) > 50
+    voc.close(); ex.close()

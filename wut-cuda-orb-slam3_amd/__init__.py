@@ -72,6 +72,7 @@ ABI_SYMBOLS = [
     "orbx_vocabulary_size",
     "orbx_vocabulary_transform",
     "orbx_vocabulary_transform_frame",
+    "orbx_vocabulary_transform_batch",
 ]
 STAGE_NAMES = ["pyramid+FAST", "quadtree", "blur", "pack", "orient+desc"]
 
@@ -153,6 +154,7 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_vocabulary_size.argtypes = [c_void_p]
     lib.orbx_vocabulary_transform.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
     lib.orbx_vocabulary_transform_frame.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 9
+    lib.orbx_vocabulary_transform_batch.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7
     lib.orbx_set_profiling.argtypes = [c_void_p, c_int]
     lib.orbx_get_stage_times.argtypes = [c_void_p, c_void_p]
     _lib = lib
@@ -621,3 +623,18 @@ class ORBVocabulary:
         nb, nv = int(nb[0]), int(nv[0])
         nf = int(vs[nv])
         return dict(bow_word=bw[:nb].copy(), bow_value=bv[:nb].copy(), fv_node=vn[:nv].copy(), fv_start=vs[:nv + 1].copy(), fv_feature=vf[:nf].copy())
+
+    def transform_batch(self, extractor: "ORBextractor", nframes: int, levelsup: int = 4):
+        """Frame::ComputeBoW for the first `nframes` frames of the extractor's last batch, two launches, descriptors read in HBM.
+        Returns a list of per-frame dicts like transform_frame."""
+        if not self._h:
+            raise OrbxError("ORBVocabulary: no vocabulary loaded")
+        cap = extractor.capacity
+        bw = np.zeros((nframes, cap), np.int32); bv = np.zeros((nframes, cap), np.float64); nb = np.zeros(nframes, np.int32)
+        vn = np.zeros((nframes, cap), np.int32); vs = np.zeros((nframes, cap + 1), np.int32); vf = np.zeros((nframes, cap), np.int32)
+        nv = np.zeros(nframes, np.int32)
+        _check(self._lib.orbx_vocabulary_transform_batch(self._h, extractor._h, int(nframes), int(levelsup), bw.ctypes.data, bv.ctypes.data,
+                                                         nb.ctypes.data, vn.ctypes.data, vs.ctypes.data, vf.ctypes.data, nv.ctypes.data),
+               "orbx_vocabulary_transform_batch")
+        return [dict(bow_word=bw[f, :nb[f]].copy(), bow_value=bv[f, :nb[f]].copy(), fv_node=vn[f, :nv[f]].copy(),
+                     fv_start=vs[f, :nv[f] + 1].copy(), fv_feature=vf[f, :vs[f, nv[f]]].copy()) for f in range(nframes)]

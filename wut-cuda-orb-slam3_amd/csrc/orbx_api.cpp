@@ -1347,6 +1347,8 @@ struct orbx_vocabulary {
     DevBuf<uint8_t> d_childDesc, d_feat;
     DevBuf<double> d_weight, d_featWeight, d_bowValue;
     DevBuf<int> d_work;  // featWord, featNode, bowWord, fvNode, fvStart, fvFeature, counts
+    DevBuf<int> d_batchInt;       // the same per frame of a batch (orbx_vocabulary_transform_batch)
+    DevBuf<double> d_batchDbl;
 };
 
 extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
@@ -1356,6 +1358,7 @@ extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
     if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
     v->d_childStart.release(); v->d_childNode.release(); v->d_wordOfNode.release(); v->d_childDesc.release(); v->d_feat.release();
     v->d_weight.release(); v->d_featWeight.release(); v->d_bowValue.release(); v->d_work.release();
+    v->d_batchInt.release(); v->d_batchDbl.release();
     delete v;
 }
 
@@ -1508,4 +1511,44 @@ extern "C" int orbx_vocabulary_transform_frame(orbx_vocabulary *v, orbx_extracto
     HIP_TRY(hipStreamSynchronize(ex->stream));  // everything of the batch is ordered before this on the front stream
     const uint8_t *d = ex->d_desc.p + (size_t)frame * ex->maxKeypoints * 32;
     return vocabularyTransformImpl(v, d, true, n, levelsup, feat_word, feat_node, bow_word, bow_value, n_bow, fv_node, fv_start, fv_feature, n_fv);
+}
+
+// Frame::ComputeBoW for every frame of the extractor's last batch, descriptors read in HBM: two launches for the whole batch.
+// Per-frame outputs at stride cap = orbx_max_keypoints(ex) (fv_start: cap + 1).
+extern "C" int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extractor *ex, int nframes, int levelsup, int32_t *bow_word,
+                                               double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start, int32_t *fv_feature,
+                                               int32_t *n_fv)
+{
+    if (!v || !ex || !bow_word || !bow_value || !n_bow || !fv_node || !fv_start || !fv_feature || !n_fv)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_batch: null argument");
+    if (ex->prm.device != v->device) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_batch: extractor and vocabulary on different devices");
+    if (nframes <= 0 || nframes > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_batch: %d frames of %d", nframes, ex->lastFrames);
+    const int cap = ex->maxKeypoints;
+    if (cap > ORBX_BOW_MAX_FEATURES) return setError(ORBX_ERR_CAPACITY, "%d keypoints per frame exceed the transform capacity %d", cap, ORBX_BOW_MAX_FEATURES);
+    HIP_TRY(hipSetDevice(v->device));
+    const size_t F = (size_t)nframes * cap;
+    int rc;
+    if ((rc = v->d_batchInt.ensure(6 * F + 3 * (size_t)nframes + 16)) != ORBX_OK || (rc = v->d_batchDbl.ensure(2 * F)) != ORBX_OK) return rc;
+    int *featWord = v->d_batchInt.p, *featNode = featWord + F, *bowWord = featNode + F, *fvNode = bowWord + F, *fvFeature = fvNode + F,
+        *fvStart = fvFeature + F, *counts = fvStart + F + nframes;
+    double *featWeight = v->d_batchDbl.p, *bowValue = featWeight + F;
+    HIP_TRY(hipStreamSynchronize(ex->stream));  // the batch's results are complete
+    if (v->nNodes <= 1) {  // empty()
+        for (int f = 0; f < nframes; ++f) { n_bow[f] = 0; n_fv[f] = 0; fv_start[(size_t)f * (cap + 1)] = 0; }
+        return ORBX_OK;
+    }
+    HIP_TRY(hipMemsetAsync(counts, 0, 2 * (size_t)nframes * sizeof(int), v->stream));
+    HIP_TRY(orbxLaunchBowTransformBatch(v->stream, v->d_childStart.p, v->d_childNode.p, v->d_childDesc.p, v->d_wordOfNode.p, v->d_weight.p, v->L,
+                                        v->scoring, v->weighting, ex->d_desc.p, ex->d_n.p, nframes, cap, levelsup, featWord, featNode, featWeight,
+                                        bowWord, bowValue, fvNode, fvStart, fvFeature, counts));
+    std::vector<int> cnt(2 * (size_t)nframes);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), counts, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(bow_word, bowWord, F * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(bow_value, bowValue, F * sizeof(double), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(fv_node, fvNode, F * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(fv_feature, fvFeature, F * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipMemcpyAsync(fv_start, fvStart, (F + nframes) * sizeof(int), hipMemcpyDeviceToHost, v->stream));
+    HIP_TRY(hipStreamSynchronize(v->stream));
+    for (int f = 0; f < nframes; ++f) { n_bow[f] = cnt[2 * (size_t)f]; n_fv[f] = cnt[2 * (size_t)f + 1]; }
+    return ORBX_OK;
 }

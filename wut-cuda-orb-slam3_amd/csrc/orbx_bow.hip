@@ -27,9 +27,15 @@ __device__ __forceinline__ int bow_popc256(const uint4 &a0, const uint4 &a1, con
            __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
+// Batched form (nPerFrame != nullptr): blockIdx.y = frame, its features at feat + frame * cap * 2 and its outputs at frame * cap.
 __global__ __launch_bounds__(256) void k_bow_descend(BowVocDev V, const uint4 *feat, int n, int levelsup, int *featWord, int *featNode,
-                                                     double *featWeight)
+                                                     double *featWeight, const int *nPerFrame, int cap)
 {
+    if (nPerFrame) {
+        const size_t o = (size_t)blockIdx.y * cap;
+        n = nPerFrame[blockIdx.y];
+        feat += 2 * o; featWord += o; featNode += o; featWeight += o;
+    }
     const int f = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (f >= n) return;  // whole 16-lane groups leave together: the shuffles below stay inside a group
     const uint4 q0 = feat[2 * f], q1 = feat[2 * f + 1];
@@ -85,10 +91,18 @@ struct BowAsmArgs {
     int *bowWord; double *bowValue;          // [n]
     int *fvNode, *fvStart, *fvFeature;       // [n], [n + 1], [n]
     int *counts;                             // [2] words in the BowVector, nodes in the FeatureVector
+    const int *nPerFrame; int cap;           // batched form: blockIdx.x = frame, n = nPerFrame[frame], arrays at frame * cap
 };
 
 __global__ __launch_bounds__(BOW_NT) void k_bow_assemble(BowAsmArgs a)
 {
+    if (a.nPerFrame) {
+        const size_t o = (size_t)blockIdx.x * a.cap;
+        a.n = a.nPerFrame[blockIdx.x];
+        a.featWord += o; a.featNode += o; a.featWeight += o; a.bowWord += o; a.bowValue += o; a.fvNode += o; a.fvFeature += o;
+        a.fvStart += o + blockIdx.x;  // (cap + 1 offsets per frame)
+        a.counts += 2 * blockIdx.x;
+    }
     extern __shared__ __attribute__((aligned(16))) bow_u64 keys[];  // [np2]
     __shared__ int headBase, nHeads, nValid;
     __shared__ double normS;
@@ -187,13 +201,15 @@ hipError_t orbxLaunchBowTransform(hipStream_t st, const int *childStart, const i
     BowVocDev V;
     V.childStart = childStart; V.childNode = childNode; V.childDesc = (const uint4 *)childDesc; V.wordOfNode = wordOfNode;
     V.weightOfNode = weightOfNode; V.L = L; V.scoring = scoring; V.weighting = weighting;
-    if (n > 0) hipLaunchKernelGGL(k_bow_descend, dim3((n + 15) / 16), dim3(256), 0, st, V, (const uint4 *)feat, n, levelsup, featWord, featNode, featWeight);
+    if (n > 0) hipLaunchKernelGGL(k_bow_descend, dim3((n + 15) / 16), dim3(256), 0, st, V, (const uint4 *)feat, n, levelsup, featWord, featNode, featWeight,
+                                  (const int *)nullptr, 0);
     BowAsmArgs a;
     a.featWord = featWord; a.featNode = featNode; a.featWeight = featWeight; a.n = n;
     int np2 = 2;
     while (np2 < n) np2 <<= 1;
     a.np2 = np2; a.scoring = scoring; a.weighting = weighting;
     a.bowWord = bowWord; a.bowValue = bowValue; a.fvNode = fvNode; a.fvStart = fvStart; a.fvFeature = fvFeature; a.counts = counts;
+    a.nPerFrame = nullptr; a.cap = 0;
     const size_t lds = (size_t)np2 * sizeof(bow_u64);
     static size_t attrBytes = 0;
     if (lds > 48 * 1024 && lds > attrBytes) {
@@ -202,5 +218,34 @@ hipError_t orbxLaunchBowTransform(hipStream_t st, const int *childStart, const i
         attrBytes = lds;
     }
     hipLaunchKernelGGL(k_bow_assemble, dim3(1), dim3(BOW_NT), lds, st, a);
+    return hipGetLastError();
+}
+
+// Every frame of a batch in two launches: features of frame f at feat + f * cap * 32 bytes (the extractor's descriptor buffer),
+// nPerFrame[f] of them; all per-feature and per-frame outputs at f * cap (fvStart at f * (cap + 1), counts at 2 f).
+hipError_t orbxLaunchBowTransformBatch(hipStream_t st, const int *childStart, const int *childNode, const void *childDesc, const int *wordOfNode,
+                                       const double *weightOfNode, int L, int scoring, int weighting, const void *feat, const int *nPerFrame,
+                                       int nframes, int cap, int levelsup, int *featWord, int *featNode, double *featWeight, int *bowWord,
+                                       double *bowValue, int *fvNode, int *fvStart, int *fvFeature, int *counts)
+{
+    if (nframes <= 0) return hipSuccess;
+    BowVocDev V;
+    V.childStart = childStart; V.childNode = childNode; V.childDesc = (const uint4 *)childDesc; V.wordOfNode = wordOfNode;
+    V.weightOfNode = weightOfNode; V.L = L; V.scoring = scoring; V.weighting = weighting;
+    hipLaunchKernelGGL(k_bow_descend, dim3((cap + 15) / 16, nframes), dim3(256), 0, st, V, (const uint4 *)feat, 0, levelsup, featWord, featNode,
+                       featWeight, nPerFrame, cap);
+    BowAsmArgs a;
+    a.featWord = featWord; a.featNode = featNode; a.featWeight = featWeight; a.n = 0;
+    int np2 = 2;
+    while (np2 < cap) np2 <<= 1;
+    a.np2 = np2; a.scoring = scoring; a.weighting = weighting;
+    a.bowWord = bowWord; a.bowValue = bowValue; a.fvNode = fvNode; a.fvStart = fvStart; a.fvFeature = fvFeature; a.counts = counts;
+    a.nPerFrame = nPerFrame; a.cap = cap;
+    const size_t lds = (size_t)np2 * sizeof(bow_u64);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_bow_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_bow_assemble, dim3(nframes), dim3(BOW_NT), lds, st, a);
     return hipGetLastError();
 }

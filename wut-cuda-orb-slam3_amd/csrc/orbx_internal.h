@@ -118,6 +118,10 @@ hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *k
                                  const uint8_t *kfDesc, const signed char *kfValid, const int *fNode, const int *fStart, const int *fFeat,
                                  int fNfv, const void *fKeys, const uint8_t *fDesc, int nF, int maxNodeF, float nnratio, int checkOri,
                                  int mode, const signed char *fValid, int nOut, int *matches, int *binOf, int *result);
+hipError_t orbxLaunchBowTransformBatch(hipStream_t st, const int *childStart, const int *childNode, const void *childDesc, const int *wordOfNode,
+                                       const double *weightOfNode, int L, int scoring, int weighting, const void *feat, const int *nPerFrame,
+                                       int nframes, int cap, int levelsup, int *featWord, int *featNode, double *featWeight, int *bowWord,
+                                       double *bowValue, int *fvNode, int *fvStart, int *fvFeature, int *counts);
 hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4);
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
                                int *items, int *cellOf);
