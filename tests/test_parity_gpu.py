@@ -295,7 +295,7 @@ def _gpu_check_subprocess(extra_env, arg_sets):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **extra_env)
     for args in arg_sets:
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_check.py")] + args, env=env,
+        out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "gpu_check.py")] + args, env=env,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert out.returncode == 0 and "ALL STAGES BIT-IDENTICAL" in out.stdout, out.stdout[-2000:]
 

@@ -1,12 +1,12 @@
 """Stage-by-stage GPU-vs-oracle comparison for development (prints the first divergence per stage).
-Usage: python tools/gpu_check.py [w h nfeatures nframes]"""
+Usage: python tests/tools/gpu_check.py [w h nfeatures nframes]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()

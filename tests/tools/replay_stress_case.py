@@ -3,7 +3,7 @@ sys.path.insert(0,'.')
 import __graft_entry__ as g
 pkg=g.load_package(); orc=g.load_oracle()
 rng=np.random.default_rng(7)
-# replay the random stream of tools/stress_parity.py up to case 11
+# replay the random stream of tests/tools/stress_parity.py up to case 11
 for case in range(12):
     w=int(rng.integers(120,1400)); h=int(rng.integers(100,1000)); nlev=int(rng.integers(1,9)); scale=float(rng.choice([1.1,1.2,1.25,1.5,2.0]))
     while min(w,h)/scale**(nlev-1)<70: nlev-=1

@@ -1,11 +1,11 @@
 """Randomised end-to-end parity sweep (development tool, not part of the test suite): random image sizes, feature counts, level
-counts, scale factors, thresholds and image content against the CPU oracle.  Usage: python tools/stress_parity.py [n] [seed]"""
+counts, scale factors, thresholds and image content against the CPU oracle.  Usage: python tests/tools/stress_parity.py [n] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()

@@ -1,11 +1,11 @@
 """Randomised parity sweep of SearchForInitialization / AssignFeaturesToGrid against the oracle (development tool).
-Usage: python tools/stress_search_init.py [n] [seed]"""
+Usage: python tests/tools/stress_search_init.py [n] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()

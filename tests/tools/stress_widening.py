@@ -1,9 +1,9 @@
 """Randomised parity sweep of the widened entry points against the CPU oracle: both tracking
 SearchByProjection variants, UndistortKeyPoints and the vocabulary transform, with random sizes / parameters per case.
-Usage on the GPU box: python tools/stress_widening.py [cases] [seed]"""
+Usage on the GPU box: python tests/tools/stress_widening.py [cases] [seed]"""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401
 pkg = importlib.import_module("wut-cuda-orb-slam3_amd")

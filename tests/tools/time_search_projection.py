@@ -1,7 +1,7 @@
 """Times orbx_search_by_projection (H2D + grid + candidate lists + fixed-point resolve + D2H) against the single-threaded oracle."""
 import sys, time, importlib, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import __graft_entry__ as g
 pkg = g.load_package(); orc = g.load_oracle()
 ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7)
