@@ -196,6 +196,27 @@ int orbx_match_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t,
  * matcher's stream; orbx_matcher_sync() waits. */
 int orbx_match_knn2_device(orbx_matcher *m, const void *d_q, int nq, const void *d_t, int nt, void *d_idx,
                            void *d_dist);
+/* The same for `npairs` independent (query, train) sets in ONE launch, everything device-resident and asynchronous - the
+ * form in which Frame::ComputeStereoFishEyeMatches (reference src/Frame.cc:1156-1196) runs over a batch of stereo pairs:
+ *   matcher->knnMatch(mDescriptors.rowRange(monoLeft, rows), mDescriptorsRight.rowRange(monoRight, rows), matches, 2)  (:1174)
+ * Pair p reads its query rows at d_q + p * q_pair_stride + 32 * (q_begin .. nq_p - 1) with nq_p = d_nq[p] (device array; NULL:
+ * max_nq rows for every pair) and q_begin = d_q_begin[p] (device array; NULL: 0), likewise the train rows - so the descriptors,
+ * counts and monoIndex values of two extractors' orbx_device_outputs() plug in directly (pair stride = capacity * 32).
+ * idx / dist are [npairs][max_nq][2]; row i of pair p belongs to query row q_begin + i and train indices are relative to
+ * t_begin, as cv::DMatch::queryIdx / trainIdx are relative to the rowRange.  Rows i >= nq_p - q_begin are not written. */
+int orbx_match_knn2_batch_device(orbx_matcher *m, int npairs, const void *d_q, int64_t q_pair_stride, const int32_t *d_nq,
+                                 const int32_t *d_q_begin, int max_nq, const void *d_t, int64_t t_pair_stride,
+                                 const int32_t *d_nt, const int32_t *d_t_begin, int max_nt, void *d_idx, void *d_dist);
+/* The batch form bound to two extractors: pair p = frame p of `query`'s and `train`'s last batch (orbx_extract_batch[_device]);
+ * descriptors, counts and - with lapping_only != 0 - the monoIndex row offsets are read from the extractors' device outputs.
+ * The call orders the matcher's stream behind both extractors' work and the extractors' next batch behind the matcher, so it can
+ * be issued right after orbx_extract_batch_device without a host synchronisation.  d_idx / d_dist: device buffers
+ * [npairs][orbx_max_keypoints(query)][2] (int32). */
+int orbx_match_knn2_frames(orbx_matcher *m, orbx_extractor *query, orbx_extractor *train, int npairs, int lapping_only,
+                           void *d_idx, void *d_dist);
+/* Copies `bytes` from a device buffer to the host on the matcher's stream and waits for it (results of the asynchronous,
+ * device-resident entry points). */
+int orbx_matcher_download(orbx_matcher *m, const void *d_src, void *h_dst, size_t bytes);
 int orbx_matcher_sync(orbx_matcher *m);
 
 /* Hamming stage of Frame::ComputeStereoMatches — reference src/Frame.cc:841-925: for each left keypoint
@@ -314,6 +335,15 @@ int orbx_search_by_projection_points(orbx_matcher *m, const orbx_keypoint *kc, c
 int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left, int frame_left, orbx_extractor *right, int frame_right,
                                 const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr, const uint8_t *dr, int nr,
                                 float mb, float mbf, float *u_right, float *depth);
+
+/* The same for `npairs` stereo pairs at once, entirely device-resident: pair p = frame p of the left / right extractor's last
+ * batch; keypoints, descriptors, counts and pyramids are read where the extractors left them, the three kernels run once over
+ * all pairs (blockIdx.y = pair) and nothing crosses PCIe - this is how the stereo Frame constructor (reference src/Frame.cc:143)
+ * runs over a batch.  d_u_right / d_depth: device buffers [npairs][orbx_max_keypoints(left)] (float); entries beyond a frame's
+ * keypoint count are not written.  Asynchronous on the matcher's stream, ordered against the extractors like
+ * orbx_match_knn2_frames. */
+int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int npairs, float mb, float mbf,
+                                       void *d_u_right, void *d_depth);
 
 /* ---- utilities ---------------------------------------------------------------------------------- */
 

@@ -116,3 +116,73 @@ def test_compute_stereo_matches_full(pkg, orc, shift, mb, mbf):
     ur0, dp0 = m.ComputeStereoMatches(exL, exR, kl, dl, kr[:0], dr[:0], mb, mbf)
     assert np.all(ur0 == -1) and np.all(dp0 == -1)
     exL.close(); exR.close(); m.close()
+
+
+def test_knn2_split_merge_with_ties_across_split_boundaries(pkg, orc, monkeypatch):
+    """The train rows are scanned in splits and merged by (distance, train index): duplicates of the best rows placed on both
+    sides of every split boundary must still resolve to the lower index first, for any split count."""
+    rng = np.random.default_rng(99)
+    nq, nt = 300, 1000
+    q, t = _desc(rng, nq), _desc(rng, nt)
+    for b in range(0, nt, 37):          # near-copies of queries sprinkled over the train set ...
+        t[b] = q[b % nq]
+    for b in (62, 63, 64, 65, 124, 125, 126, 250, 499, 500, 501, 998, 999):
+        t[b] = q[5]                     # ... and exact ties straddling the boundaries of 2 / 4 / 8 / 16-way splits
+    t[0] = q[7]; t[999] = q[7]          # best two are the first and the last row
+    ridx, rdist = orc.knn2(q, t)
+    m = pkg.ORBmatcher(1024, 1024)
+    for split in ("1", "2", "3", "7", "16", "1000"):
+        monkeypatch.setenv("ORBX_KNN_SPLIT", split)
+        idx, dist = m.knnMatch(q, t)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), split
+    monkeypatch.delenv("ORBX_KNN_SPLIT")
+    idx, dist = m.knnMatch(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    m.close()
+
+
+def _stereo_batch(pkg, P, w=752, h=480, nf=1200, lap=(0, 0)):
+    left = np.stack([pkg.synth_frame(300 + i, w, h) for i in range(P)])
+    right = np.stack([np.roll(left[i], -(6 + 3 * i), axis=1) for i in range(P)])
+    exl = pkg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=P)
+    exr = pkg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=P)
+    outl = exl.extract_batch(left, lap)
+    outr = exr.extract_batch(right, lap)
+    return exl, exr, outl, outr
+
+
+@pytest.mark.parametrize("lapping", [False, True])
+def test_knn2_frames_batch_equals_single_pairs(pkg, orc, lapping):
+    """orbx_match_knn2_frames: P stereo pairs in one launch on the extractors' device-resident descriptors ==
+    knnMatch(desc.rowRange(mono, n), descR.rowRange(monoR, nR)) per pair (reference src/Frame.cc:1174)."""
+    P = 5
+    exl, exr, (nl, ml, kl, dl), (nr, mr, kr, dr) = _stereo_batch(pkg, P, lap=(200, 600) if lapping else (0, 0))
+    m = pkg.ORBmatcher(4096, 4096)
+    idx, dist = m.knnMatchFrames(exl, exr, P, lapping_only=lapping)
+    for p in range(P):
+        qb, tb = (int(ml[p]), int(mr[p])) if lapping else (0, 0)
+        if lapping:
+            assert 0 < qb < nl[p] and 0 < tb < nr[p]
+        q, t = dl[p, qb:nl[p]], dr[p, tb:nr[p]]
+        ridx, rdist = orc.knn2(q, t)
+        assert np.array_equal(idx[p, : len(q)], ridx) and np.array_equal(dist[p, : len(q)], rdist), p
+        sidx, sdist = m.knnMatch(q, t)  # the single-pair entry point gives the same bytes
+        assert np.array_equal(sidx, ridx) and np.array_equal(sdist, rdist)
+    m.close(); exl.close(); exr.close()
+
+
+def test_compute_stereo_matches_frames_batch(pkg, orc):
+    """orbx_compute_stereo_matches_frames: the batch form is bit-equal to P single calls and to the oracle restatement of
+    Frame::ComputeStereoMatches (reference src/Frame.cc:841-1011)."""
+    P = 4
+    exl, exr, (nl, ml, kl, dl), (nr, mr, kr, dr) = _stereo_batch(pkg, P)
+    m = pkg.ORBmatcher(4096, 4096)
+    mb, mbf = 0.11, 47.9
+    ur, dp = m.ComputeStereoMatchesFrames(exl, exr, P, mb, mbf)
+    matched = 0
+    for p in range(P):
+        sur, sdp = m.ComputeStereoMatches(exl, exr, kl[p, : nl[p]], dl[p, : nl[p]], kr[p, : nr[p]], dr[p, : nr[p]], mb, mbf, frame_left=p, frame_right=p)
+        assert ur[p, : nl[p]].tobytes() == sur.tobytes() and dp[p, : nl[p]].tobytes() == sdp.tobytes(), p
+        matched += int((sur >= 0).sum())
+    assert matched > 100 * P
+    m.close(); exl.close(); exr.close()

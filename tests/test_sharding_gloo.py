@@ -1,6 +1,7 @@
 """N>1 path on CPU: frame sharding + ordered result gather with torch.distributed (gloo, world_size 2 and 3).
-The per-frame extractor is the CPU oracle here (no GPU in this container); on the GPU node the same code runs
-with backend nccl (RCCL) and the HIP extractor."""
+The per-frame extractor is the CPU oracle here (no GPU in this container); on the GPU node the same functions
+(sharding.extract_sharded / gather_frame_records, also used by bench.py --gather) run with backend nccl (RCCL) on zero-copy
+views of the HIP extractor's HBM output buffers."""
 import os
 import socket
 import sys
@@ -31,17 +32,26 @@ def _worker(rank, world, port, n_frames, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch
     ref = orc.Oracle(300, 1.2, 8, 20, 7)
     cap = ref.capacity
 
-    def extract(imgs):
-        n, mono, kps, desc = ref.extract_batch(imgs, (0, 1000), threads=2, want_outputs=True)
-        return n, mono, kps, desc
+    def extract(imgs):  # records as torch tensors, like device_output_tensors() of the HIP extractor (here on the CPU)
+        if len(imgs) == 0:
+            n = mono = np.zeros(0, np.int32)
+            kps = np.zeros((0, cap), orc.KEYPOINT_DTYPE)
+            desc = np.zeros((0, cap, 32), np.uint8)
+        else:
+            n, mono, kps, desc = ref.extract_batch(imgs, (0, 1000), threads=2, want_outputs=True)
+        return {"kps": torch.from_numpy(np.ascontiguousarray(kps).view(np.uint8).reshape(len(n), cap * 28)),
+                "desc": torch.from_numpy(np.ascontiguousarray(desc).reshape(len(n), cap * 32)),
+                "n": torch.from_numpy(np.ascontiguousarray(n, np.int32)), "mono": torch.from_numpy(np.ascontiguousarray(mono, np.int32))}
 
     def frames_of(idx):
-        return np.stack([orc.synth_frame(int(i), 320, 240) for i in idx])
+        return np.stack([orc.synth_frame(int(i), 320, 240) for i in idx]) if len(idx) else np.zeros((0, 240, 320), np.uint8)
 
-    n, mono, kps, desc = sharding.extract_sharded(extract, frames_of, n_frames, cap, orc.KEYPOINT_DTYPE)
+    rec = sharding.extract_sharded(extract, frames_of, n_frames)
+    n, mono, kps, desc = sharding.records_to_numpy(rec, cap, orc.KEYPOINT_DTYPE)
     if rank == 0:
         q.put((n, mono, kps.tobytes(), desc.tobytes()))
     dist.barrier()
@@ -83,14 +93,10 @@ def test_shard_helpers(pkg):
     assert sh.slots_per_rank(10, 4) == 3 and sh.slots_per_rank(8, 8) == 1
     cover = np.sort(np.concatenate([sh.frames_of_rank(37, 8, r) for r in range(8)]))
     assert np.array_equal(cover, np.arange(37))
-    cap = 5
-    n = np.array([3, 0], np.int32)
-    mono = np.array([1, 0], np.int32)
-    kps = np.zeros((2, cap), pkg.KEYPOINT_DTYPE)
-    kps["x"][0, :3] = [1.5, 2.5, 3.5]
-    desc = np.arange(2 * cap * 32, dtype=np.uint8).reshape(2, cap, 32)
-    rec = sh.pack_records(n, mono, kps, desc, cap, 3)
-    assert rec.shape == (3, sh.record_bytes(cap))
-    n2, m2, k2, d2 = sh.unpack_records(rec, cap, pkg.KEYPOINT_DTYPE)
-    assert list(n2) == [3, 0, -1] and list(m2) == [1, 0, 0]
-    assert np.array_equal(k2[:2], kps) and np.array_equal(d2[:2], desc)
+    assert sh.record_bytes(1003) == 8 + 1003 * 60
+    # single-process gather: padding + transpose back to frame order
+    import torch
+    local = {"kps": torch.arange(3 * 4, dtype=torch.uint8).reshape(3, 4), "desc": torch.zeros((3, 8), dtype=torch.uint8),
+             "n": torch.tensor([5, 6, 7], dtype=torch.int32), "mono": torch.tensor([1, 2, 3], dtype=torch.int32)}
+    out = sh.gather_frame_records(local, 3)
+    assert out["n"].tolist() == [5, 6, 7] and torch.equal(out["kps"], local["kps"])

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_ssize_t, c_uint64, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_ssize_t, c_uint64, c_void_p
 
 import numpy as np
 
@@ -58,7 +58,8 @@ ABI_SYMBOLS = [
     "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
-    "orbx_match_knn2_device", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
+    "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
+    "orbx_matcher_download", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points",
@@ -127,6 +128,11 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_hamming_matrix.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]
     lib.orbx_match_knn2.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_match_knn2_device.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_match_knn2_batch_device.argtypes = [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p,
+                                                 c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_match_knn2_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_compute_stereo_matches_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]
+    lib.orbx_matcher_download.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
     lib.orbx_match_stereo_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                            c_int, c_float, c_float, c_void_p, c_void_p]
     lib.orbx_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
@@ -190,6 +196,7 @@ class ORBextractor:
         h = c_void_p()
         _check(self._lib.orbx_create(byref(p), byref(h)), "orbx_create")
         self._h = h
+        self.device = device
         self.nlevels = nlevels
         self.max_batch = max_batch
         self.capacity = int(self._lib.orbx_max_keypoints(self._h))
@@ -372,6 +379,43 @@ class ORBmatcher:
         dist = np.full((len(q), 2), np.iinfo(np.int32).max, np.int32)
         _check(self._lib.orbx_match_knn2(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data, dist.ctypes.data), "orbx_match_knn2")
         return idx, dist
+
+    # ---- device-resident, batched forms: pair p = frame p of the two extractors' last batches -----------------------
+    def _dev_empty(self, shape, dtype, device: int):
+        import torch  # device memory only
+        return torch.empty(shape, dtype=dtype, device=f"cuda:{device}")
+
+    def _download(self, tensor) -> np.ndarray:
+        out = np.empty(tuple(tensor.shape), {4: np.int32}.get(tensor.element_size(), np.int32) if not tensor.is_floating_point() else np.float32)
+        _check(self._lib.orbx_matcher_download(self._h, c_void_p(tensor.data_ptr()), out.ctypes.data, out.nbytes), "orbx_matcher_download")
+        return out
+
+    def knnMatchFrames(self, query: "ORBextractor", train: "ORBextractor", npairs: int, lapping_only: bool = False, download: bool = True):
+        """knnMatch(k=2) of `npairs` frame pairs in one launch on the extractors' device-resident descriptors
+        (Frame::ComputeStereoFishEyeMatches' matcher call, reference src/Frame.cc:1174; lapping_only = the rowRange(monoIndex, rows)
+        form).  Returns (idx, dist) as [npairs, query.capacity, 2] - numpy arrays, or torch device tensors with download=False."""
+        import torch
+        dev = query.device
+        idx = self._dev_empty((npairs, query.capacity, 2), torch.int32, dev)
+        dist = self._dev_empty((npairs, query.capacity, 2), torch.int32, dev)
+        _check(self._lib.orbx_match_knn2_frames(self._h, query._h, train._h, npairs, int(lapping_only), c_void_p(idx.data_ptr()),
+                                                c_void_p(dist.data_ptr())), "orbx_match_knn2_frames")
+        if not download:
+            return idx, dist
+        return self._download(idx), self._download(dist)
+
+    def ComputeStereoMatchesFrames(self, left: "ORBextractor", right: "ORBextractor", npairs: int, mb: float, mbf: float, download: bool = True):
+        """Frame::ComputeStereoMatches (reference src/Frame.cc:841-1011) for `npairs` stereo pairs in three launches, reading the
+        extractors' keypoints, descriptors and pyramids where they lie in HBM -> (mvuRight, mvDepth) as [npairs, left.capacity]."""
+        import torch
+        dev = left.device
+        ur = self._dev_empty((npairs, left.capacity), torch.float32, dev)
+        dp = self._dev_empty((npairs, left.capacity), torch.float32, dev)
+        _check(self._lib.orbx_compute_stereo_matches_frames(self._h, left._h, right._h, npairs, mb, mbf, c_void_p(ur.data_ptr()),
+                                                            c_void_p(dp.data_ptr())), "orbx_compute_stereo_matches_frames")
+        if not download:
+            return ur, dp
+        return self._download(ur), self._download(dp)
 
     def stereo_rows(self, kl, dl, kr, dr, n_rows: int, scale_factors, min_d: float, max_d: float):
         kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)

@@ -893,6 +893,9 @@ struct orbx_matcher {
     hipStream_t stream = nullptr;
     DevBuf<uint8_t> d_q, d_t;
     DevBuf<int> d_idx, d_dist, d_mat;
+    DevBuf<uint32_t> d_part;      // kNN-2: per-split partial results
+    DevBuf<int> d_bIdx, d_bDist, d_bSad;  // batched stereo matching: per-pair row-band results
+    hipEvent_t evWait = nullptr;  // ordering against the extractors' streams
     DevBuf<orbx_keypoint> d_kl, d_kr;
     DevBuf<float> d_scale, d_uRight, d_depth;
     DevBuf<int> d_sad;
@@ -934,7 +937,8 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release();
+    m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release(); m->d_part.release(); m->d_bIdx.release(); m->d_bDist.release(); m->d_bSad.release();
+    if (m->evWait) (void)hipEventDestroy(m->evWait);
     m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
     m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release(); m->d_sbpCand.release(); m->d_proj.release();
     delete m;
@@ -970,12 +974,42 @@ extern "C" int orbx_hamming_matrix(orbx_matcher *m, const uint8_t *q, int nq, co
     return ORBX_OK;
 }
 
+// kNN-2 of `npairs` independent (query, train) sets in one launch: split count, scratch for the per-split partial results
+static int knn2Launch(orbx_matcher *m, int npairs, const uint8_t *q, long long qStride, const int *nqDev, const int *qBeginDev, int nq,
+                      const uint8_t *t, long long tStride, const int *ntDev, const int *tBeginDev, int nt, int *idx, int *dist)
+{
+    if (nt >= (1 << 23)) return setError(ORBX_ERR_CAPACITY, "kNN-2: at most 2^23 - 1 train rows per pair (got %d)", nt);
+    const char *fe = getenv("ORBX_KNN_SPLIT");  // tests of the split merge force a split count
+    const int force = fe ? atoi(fe) : 0;
+    const int nSplit = orbxKnn2Splits(npairs, nq, nt, force);
+    if (nSplit > 1) {
+        int rc = m->d_part.ensure((size_t)npairs * nSplit * nq * 2);
+        if (rc != ORBX_OK) return rc;
+    }
+    HIP_TRY(orbxLaunchKnn2Batch(m->stream, npairs, q, qStride, nqDev, qBeginDev, nq, t, tStride, ntDev, tBeginDev, nt, nSplit, m->d_part.p, idx, dist));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_match_knn2_device(orbx_matcher *m, const void *d_q, int nq, const void *d_t, int nt, void *d_idx, void *d_dist)
 {
-    if (!m || nq < 0 || nt < 0 || !d_idx || !d_dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_device: bad argument");
+    if (!m || nq < 0 || nt < 0 || !d_idx || !d_dist || (nq > 0 && !d_q) || (nt > 0 && !d_t))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_device: bad argument");
+    if (nq == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(orbxLaunchKnn2(m->stream, (const uint8_t *)d_q, nq, (const uint8_t *)d_t, nt, (int *)d_idx, (int *)d_dist));
-    return ORBX_OK;
+    return knn2Launch(m, 1, (const uint8_t *)d_q, 0, nullptr, nullptr, nq, (const uint8_t *)d_t, 0, nullptr, nullptr, nt, (int *)d_idx, (int *)d_dist);
+}
+
+extern "C" int orbx_match_knn2_batch_device(orbx_matcher *m, int npairs, const void *d_q, int64_t q_pair_stride, const int32_t *d_nq,
+                                            const int32_t *d_q_begin, int max_nq, const void *d_t, int64_t t_pair_stride,
+                                            const int32_t *d_nt, const int32_t *d_t_begin, int max_nt, void *d_idx, void *d_dist)
+{
+    if (!m || npairs < 0 || max_nq < 0 || max_nt < 0 || !d_idx || !d_dist || (max_nq > 0 && !d_q) || (max_nt > 0 && !d_t) || q_pair_stride < 0 ||
+        t_pair_stride < 0)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_batch_device: bad argument");
+    if (npairs == 0 || max_nq == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    return knn2Launch(m, npairs, (const uint8_t *)d_q, q_pair_stride, d_nq, d_q_begin, max_nq, (const uint8_t *)d_t, t_pair_stride, d_nt, d_t_begin,
+                      max_nt, (int *)d_idx, (int *)d_dist);
 }
 
 extern "C" int orbx_match_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
@@ -985,7 +1019,7 @@ extern "C" int orbx_match_knn2(orbx_matcher *m, const uint8_t *q, int nq, const 
     HIP_TRY(hipSetDevice(m->device));
     int rc = uploadQT(m, q, nq, t, nt);
     if (rc != ORBX_OK) return rc;
-    HIP_TRY(orbxLaunchKnn2(m->stream, m->d_q.p, nq, m->d_t.p, nt, m->d_idx.p, m->d_dist.p));
+    if ((rc = knn2Launch(m, 1, m->d_q.p, 0, nullptr, nullptr, nq, m->d_t.p, 0, nullptr, nullptr, nt, m->d_idx.p, m->d_dist.p)) != ORBX_OK) return rc;
     HIP_TRY(hipMemcpyAsync(idx, m->d_idx.p, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(dist, m->d_dist.p, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1009,7 +1043,7 @@ extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, 
     if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, n_rows, m->d_scale.p, min_d, max_d,
-                                 m->d_idx.p, m->d_dist.p));
+                                 m->d_idx.p, m->d_dist.p, nullptr));
     HIP_TRY(hipMemcpyAsync(best_idx, m->d_idx.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(best_dist, m->d_dist.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1314,7 +1348,7 @@ extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left
     const float minZ = mb, minD = 0.f, maxD = mbf / minZ;
     const int nRows = left->geom[0].h;  // mvImagePyramid[0].rows (:848)
     HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, nRows, m->d_scale.p, minD, maxD,
-                                 m->d_idx.p, m->d_dist.p));
+                                 m->d_idx.p, m->d_dist.p, nullptr));
     OrbxStereoLevels lv;
     memset(&lv, 0, sizeof lv);
     for (int l = 0; l < nlev; ++l) {
@@ -1328,9 +1362,105 @@ extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left
         lv.invScale[l] = left->invScale[l];
     }
     HIP_TRY(orbxLaunchStereoRefine(m->stream, &lv, m->d_kl.p, nl, m->d_kr.p, m->d_idx.p, m->d_dist.p, mbf, minD, maxD, m->d_uRight.p,
-                                   m->d_depth.p, m->d_sad.p));
+                                   m->d_depth.p, m->d_sad.p, nullptr));
     HIP_TRY(hipMemcpyAsync(u_right, m->d_uRight.p, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(depth, m->d_depth.p, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-resident, batched forms: pair p = frame p of the two extractors' last batches.  Nothing crosses PCIe; the
+// matcher's stream is ordered behind the extractors' work by events, and the extractors' next batch behind the matcher.
+// ---------------------------------------------------------------------------------------------------------
+static int orderAfterExtractors(orbx_matcher *m, orbx_extractor *a, orbx_extractor *b)
+{
+    if (!m->evWait) HIP_TRY(hipEventCreateWithFlags(&m->evWait, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->evWait, a->stream));
+    HIP_TRY(hipStreamWaitEvent(m->stream, m->evWait, 0));
+    if (b != a) {
+        HIP_TRY(hipEventRecord(m->evWait, b->stream));
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->evWait, 0));
+    }
+    return ORBX_OK;
+}
+static int orderExtractorsAfter(orbx_matcher *m, orbx_extractor *a, orbx_extractor *b)
+{
+    HIP_TRY(hipEventRecord(m->evWait, m->stream));
+    HIP_TRY(hipStreamWaitEvent(a->stream, m->evWait, 0));
+    if (b != a) HIP_TRY(hipStreamWaitEvent(b->stream, m->evWait, 0));
+    return ORBX_OK;
+}
+static int checkFramePairs(const char *fn, orbx_matcher *m, orbx_extractor *a, orbx_extractor *b, int npairs)
+{
+    if (!m || !a || !b) return setError(ORBX_ERR_INVALID_ARG, "%s: null handle", fn);
+    if (a->prm.device != m->device || b->prm.device != m->device)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: matcher and extractors must live on the same device", fn);
+    if (npairs < 0 || npairs > a->lastFrames || npairs > b->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: %d pairs, but the extractors' last batches hold %d / %d frames", fn, npairs, a->lastFrames, b->lastFrames);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_match_knn2_frames(orbx_matcher *m, orbx_extractor *query, orbx_extractor *train, int npairs, int lapping_only,
+                                      void *d_idx, void *d_dist)
+{
+    int rc = checkFramePairs("orbx_match_knn2_frames", m, query, train, npairs);
+    if (rc != ORBX_OK) return rc;
+    if (!d_idx || !d_dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_frames: null output");
+    if (npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = orderAfterExtractors(m, query, train)) != ORBX_OK) return rc;
+    const int capQ = query->maxKeypoints, capT = train->maxKeypoints;
+    rc = knn2Launch(m, npairs, query->d_desc.p, (long long)capQ * 32, query->d_n.p, lapping_only ? query->d_mono.p : nullptr, capQ,
+                    train->d_desc.p, (long long)capT * 32, train->d_n.p, lapping_only ? train->d_mono.p : nullptr, capT, (int *)d_idx, (int *)d_dist);
+    if (rc != ORBX_OK) return rc;
+    return orderExtractorsAfter(m, query, train);
+}
+
+extern "C" int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int npairs, float mb, float mbf,
+                                                  void *d_u_right, void *d_depth)
+{
+    int rc = checkFramePairs("orbx_compute_stereo_matches_frames", m, left, right, npairs);
+    if (rc != ORBX_OK) return rc;
+    if (!d_u_right || !d_depth) return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches_frames: null output");
+    if (left->prm.nlevels != right->prm.nlevels || left->curW != right->curW || left->curH != right->curH)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches_frames: left / right extractors differ in geometry");
+    if (npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const int nlev = left->prm.nlevels, capL = left->maxKeypoints, capR = right->maxKeypoints;
+    const size_t nOut = (size_t)npairs * capL;
+    if ((rc = m->d_bIdx.ensure(nOut)) != ORBX_OK || (rc = m->d_bDist.ensure(nOut)) != ORBX_OK || (rc = m->d_bSad.ensure(nOut)) != ORBX_OK) return rc;
+    if ((rc = orderAfterExtractors(m, left, right)) != ORBX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p, left->scale.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const float minZ = mb, minD = 0.f, maxD = mbf / minZ;
+    OrbxStereoBatch sb;
+    sb.npairs = npairs; sb.kpStrideL = capL; sb.kpStrideR = capR; sb.outStride = capL; sb.nlDev = left->d_n.p; sb.nrDev = right->d_n.p;
+    HIP_TRY(orbxLaunchStereoRows(m->stream, left->d_kps.p, left->d_desc.p, capL, right->d_kps.p, right->d_desc.p, capR, left->geom[0].h, m->d_scale.p,
+                                 minD, maxD, m->d_bIdx.p, m->d_bDist.p, &sb));
+    OrbxStereoLevels lv;
+    memset(&lv, 0, sizeof lv);
+    for (int l = 0; l < nlev; ++l) {
+        const OrbxLevelGeom &g = left->geom[l];
+        lv.left[l] = l == 0 ? left->lastSrc : left->d_raw[l].p;
+        lv.right[l] = l == 0 ? right->lastSrc : right->d_raw[l].p;
+        lv.pitchL[l] = l == 0 ? left->lastSrcPitch : g.pitch;
+        lv.pitchR[l] = l == 0 ? right->lastSrcPitch : g.pitch;
+        lv.frameStrideL[l] = l == 0 ? left->lastSrcFrameStride : g.frameStride;
+        lv.frameStrideR[l] = l == 0 ? right->lastSrcFrameStride : g.frameStride;
+        lv.colsR[l] = g.w;
+        lv.scale[l] = left->scale[l];
+        lv.invScale[l] = left->invScale[l];
+    }
+    HIP_TRY(orbxLaunchStereoRefine(m->stream, &lv, left->d_kps.p, capL, right->d_kps.p, m->d_bIdx.p, m->d_bDist.p, mbf, minD, maxD, (float *)d_u_right,
+                                   (float *)d_depth, m->d_bSad.p, &sb));
+    return orderExtractorsAfter(m, left, right);
+}
+
+extern "C" int orbx_matcher_download(orbx_matcher *m, const void *d_src, void *h_dst, size_t bytes)
+{
+    if (!m || (bytes > 0 && (!d_src || !h_dst))) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_download: bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    if (bytes > 0) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }

@@ -95,10 +95,20 @@ hipError_t orbxLaunchOrientDesc(hipStream_t st, int nframes, OrbxTables tabs, Or
 
 // matcher (orbx_match.hip)
 hipError_t orbxLaunchHammingMatrix(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int *dist);
-hipError_t orbxLaunchKnn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist);
+int orbxKnn2Splits(int npairs, int nq, int nt, int forceSplit);
+hipError_t orbxLaunchKnn2Batch(hipStream_t st, int npairs, const uint8_t *q, long long qPairStride, const int *nqDev, const int *qBeginDev,
+                               int nq, const uint8_t *t, long long tPairStride, const int *ntDev, const int *tBeginDev, int nt,
+                               int nSplit, uint32_t *part, int *idx, int *dist);
+// a batch of stereo pairs in one launch (NULL: one pair, host-side counts)
+struct OrbxStereoBatch {
+    int npairs;
+    long long kpStrideL, kpStrideR;  // keypoint / descriptor records between consecutive pairs
+    long long outStride;             // result records between consecutive pairs
+    const int *nlDev, *nrDev;        // per-pair keypoint counts on the device
+};
 hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *dl, int nl, const void *kr,
                                 const uint8_t *dr, int nr, int nRows, const float *scaleDev, float minD, float maxD,
-                                int *bestIdx, int *bestDist);
+                                int *bestIdx, int *bestDist, const OrbxStereoBatch *batch);
 
 // stereo refinement (orbx_match.hip); `levels` points to a host StereoLevelsHost with the layout below
 struct OrbxStereoLevels {
@@ -106,9 +116,11 @@ struct OrbxStereoLevels {
     int pitchL[ORBX_MAX_LEVELS], pitchR[ORBX_MAX_LEVELS];
     int colsR[ORBX_MAX_LEVELS];
     float scale[ORBX_MAX_LEVELS], invScale[ORBX_MAX_LEVELS];
+    long long frameStrideL[ORBX_MAX_LEVELS], frameStrideR[ORBX_MAX_LEVELS];
 };
 hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void *kl, int nl, const void *kr, const int *bestIdx,
-                                  const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist);
+                                  const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist,
+                                  const OrbxStereoBatch *batch);
 
 hipError_t orbxLaunchBowTransform(hipStream_t st, const int *childStart, const int *childNode, const void *childDesc, const int *wordOfNode,
                                   const double *weightOfNode, int L, int scoring, int weighting, const void *feat, int n, int levelsup,

@@ -4,12 +4,13 @@
 //   k_knn2            cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) (reference src/Frame.cc:45,1174)
 //   k_stereo_rows     Hamming stage of Frame::ComputeStereoMatches (reference src/Frame.cc:841-925)
 //
-// Integer xor + v_bcnt_u32_b32 popcount; train descriptors are staged through LDS in tiles so each one is
-// read from HBM once per workgroup; a query lives in 8 VGPRs.  Tie rule of knnMatch (strict `<` insertion,
-// lower train index first) is kept by scanning train rows in index order inside a lane and merging the
-// per-split results with (distance, index) lexicographic order.
+// Integer xor + v_bcnt_u32_b32 popcount; a query lives in 8 VGPRs.  k_knn2_scan splits the train rows over the grid
+// and reads them through the scalar cache; the tie rule of knnMatch (strict `<` insertion, lower train index first) is
+// the lexicographic (distance, index) order, kept by packed keys inside a split and by k_knn2_merge across splits.
+// k_hamming_matrix / k_stereo_rows stage train descriptors through LDS tiles.
 #include "orbx_internal.h"
 #include <limits.h>
+#include <algorithm>
 
 #define MT_TILE 256  // train descriptors per LDS tile (8 KB)
 
@@ -47,44 +48,128 @@ hipError_t orbxLaunchHammingMatrix(hipStream_t st, const uint8_t *q, int nq, con
     return hipGetLastError();
 }
 
-// One lane per query; lanes of a 64-thread workgroup share the LDS train tile.  64-thread groups (instead of
-// 256) so that 4000 queries still spread over 63 CUs.
-__global__ __launch_bounds__(64) void k_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist)
+// ---- kNN-2 (cv::BFMatcher::knnMatch, k = 2) ------------------------------------------------------------------------
+// Work decomposition: a wave = 64 queries (one per lane, the descriptor in 8 VGPRs) x one SPLIT of the train rows; the
+// grid is (query waves) x (splits) x (pairs), so a single 4000 x 4000 pair already fills the chip (63 x 32 waves) and a
+// batch of stereo pairs is one launch.  A train row is wave-uniform: it is read with scalar loads (s_load_dwordx8 from
+// the scalar cache - no LDS staging, no barriers) and xor-ed into the lanes' queries; v_bcnt_u32_b32 accumulates.
+// Order: batchDistance inserts with a strict `<`, so the result is the two smallest (distance, train index) pairs in
+// lexicographic order.  Distance and index are packed into one key (distance << 23 | index; distance <= 256), the scan
+// keeps the two smallest keys with min / med3, and the per-split pairs are merged by the same rule in k_knn2_merge -
+// exact for any split boundaries, ties included.
+#define KN_IDX_BITS 23                    // train rows per pair < 2^23
+#define KN_NONE 0xFFFFFFFFu
+struct Knn2Args {
+    const uint8_t *q, *t;                 // descriptors of pair 0
+    long long qPairStride, tPairStride;   // bytes between consecutive pairs
+    const int *nqDev, *ntDev;             // per-pair row counts on the device (NULL: nq / nt for every pair)
+    const int *qBeginDev, *tBeginDev;     // per-pair first row (Frame::monoLeft / monoRight, src/Frame.cc:1174), NULL: 0
+    int nq, nt;                           // host-side counts = capacities of the grid
+    int nSplit, splitRows;
+    uint32_t *part;                       // [pair][split][nq][2] partial keys (nSplit > 1)
+    int *idx, *dist;                      // [pair][nq][2]
+};
+
+__device__ __forceinline__ void kn_insert(uint32_t &k0, uint32_t &k1, uint32_t key)
 {
-    __shared__ uint32_t tt[MT_TILE * 8];
-    const int qi = blockIdx.x * 64 + threadIdx.x;
+    uint32_t m;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k0), "v"(key), "v"(k1));  // second smallest of {k0 <= k1, key}
+    k0 = min(k0, key);
+    k1 = m;
+}
+
+__device__ __forceinline__ void kn_store(int *idx, int *dist, size_t o, uint32_t k0, uint32_t k1)
+{
+    idx[o] = k0 == KN_NONE ? -1 : (int)(k0 & ((1u << KN_IDX_BITS) - 1));
+    dist[o] = k0 == KN_NONE ? INT_MAX : (int)(k0 >> KN_IDX_BITS);
+    idx[o + 1] = k1 == KN_NONE ? -1 : (int)(k1 & ((1u << KN_IDX_BITS) - 1));
+    dist[o + 1] = k1 == KN_NONE ? INT_MAX : (int)(k1 >> KN_IDX_BITS);
+}
+
+__global__ __launch_bounds__(64) void k_knn2_scan(Knn2Args a)
+{
+    const int pair = blockIdx.z, split = blockIdx.y;
+    const int qb = a.qBeginDev ? a.qBeginDev[pair] : 0, tb = a.tBeginDev ? a.tBeginDev[pair] : 0;
+    const int nq = min(a.nqDev ? a.nqDev[pair] - qb : a.nq, a.nq);  // rows [qb, nqDev[pair]) are the queries
+    const int nt = min(a.ntDev ? a.ntDev[pair] - tb : a.nt, a.nt);
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= nq) return;  // wave-uniform
+    const int qi = q0 + (int)threadIdx.x;
     uint32_t qq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (qi < nq) {
-        const uint4 *qs = (const uint4 *)(q + (size_t)qi * 32);
-        uint4 v0 = qs[0], v1 = qs[1];
+        const uint4 *qs = (const uint4 *)(a.q + (size_t)pair * a.qPairStride + (size_t)(qb + qi) * 32);
+        const uint4 v0 = qs[0], v1 = qs[1];
         qq[0] = v0.x; qq[1] = v0.y; qq[2] = v0.z; qq[3] = v0.w; qq[4] = v1.x; qq[5] = v1.y; qq[6] = v1.z; qq[7] = v1.w;
     }
-    int d0 = INT_MAX, d1 = INT_MAX, i0 = -1, i1 = -1;
-    for (int t0 = 0; t0 < nt; t0 += MT_TILE) {
-        const int ntile = min(MT_TILE, nt - t0);
-        __syncthreads();
-        const uint4 *tsrc = (const uint4 *)(t + (size_t)t0 * 32);
-        for (int i = threadIdx.x; i < ntile * 2; i += 64) ((uint4 *)tt)[i] = tsrc[i];
-        __syncthreads();
-        for (int j = 0; j < ntile; ++j) {
-            const int d = ham256(qq, tt + j * 8);
-            // batchDistance insertion: d < dist[K-1]; shift while dist[k] > d (strict) -> earlier index wins ties
-            if (d < d1) {
-                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = t0 + j; }
-                else { d1 = d; i1 = t0 + j; }
-            }
-        }
+    const int j0 = split * a.splitRows, j1 = min(j0 + a.splitRows, nt);
+    // wave-uniform train rows through the scalar cache
+    typedef const __attribute__((address_space(4))) uint32_t CU32;
+    CU32 *tr = (CU32 *)(a.t + (size_t)pair * a.tPairStride + (size_t)tb * 32);
+    uint32_t k0 = KN_NONE, k1 = KN_NONE;
+    auto one = [&](CU32 *row, int j) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) d += __popc(qq[w] ^ row[w]);
+        kn_insert(k0, k1, (d << KN_IDX_BITS) | (uint32_t)j);
+    };
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {  // four rows' scalar loads in flight
+        CU32 *row = tr + (size_t)j * 8;
+        one(row, j); one(row + 8, j + 1); one(row + 16, j + 2); one(row + 24, j + 3);
     }
-    if (qi < nq) {
-        idx[qi * 2] = i0; idx[qi * 2 + 1] = i1;
-        dist[qi * 2] = d0; dist[qi * 2 + 1] = d1;
+    for (; j < j1; ++j) one(tr + (size_t)j * 8, j);
+    if (qi >= nq) return;
+    if (a.nSplit == 1) kn_store(a.idx, a.dist, ((size_t)pair * a.nq + qi) * 2, k0, k1);
+    else {
+        uint32_t *p = a.part + (((size_t)pair * a.nSplit + split) * a.nq + qi) * 2;
+        p[0] = k0; p[1] = k1;
     }
 }
 
-hipError_t orbxLaunchKnn2(hipStream_t st, const uint8_t *q, int nq, const uint8_t *t, int nt, int *idx, int *dist)
+__global__ __launch_bounds__(256) void k_knn2_merge(Knn2Args a)
 {
-    if (nq <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64), dim3(64), 0, st, q, nq, t, nt, idx, dist);
+    const int pair = blockIdx.y;
+    const int qb = a.qBeginDev ? a.qBeginDev[pair] : 0;
+    const int nq = min(a.nqDev ? a.nqDev[pair] - qb : a.nq, a.nq);
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t k0 = KN_NONE, k1 = KN_NONE;
+    for (int s = 0; s < a.nSplit; ++s) {
+        const uint32_t *p = a.part + (((size_t)pair * a.nSplit + s) * a.nq + qi) * 2;
+        const uint32_t c0 = p[0], c1 = p[1];
+        kn_insert(k0, k1, c0);
+        kn_insert(k0, k1, c1);
+    }
+    kn_store(a.idx, a.dist, ((size_t)pair * a.nq + qi) * 2, k0, k1);
+}
+
+// Number of train splits for `npairs` pairs of nq x nt rows: enough waves to fill 1024 SIMDs a few times over, splits of at
+// least 64 rows.  `forceSplit` > 0 overrides it (tests of the merge).
+int orbxKnn2Splits(int npairs, int nq, int nt, int forceSplit)
+{
+    if (nt <= 0) return 1;
+    if (forceSplit > 0) return std::min(forceSplit, nt);
+    const long long qWaves = (long long)npairs * ((nq + 63) / 64);
+    long long s = (4096 + qWaves - 1) / std::max(qWaves, 1ll);
+    s = std::min<long long>(s, (nt + 63) / 64);
+    return (int)std::max<long long>(s, 1);
+}
+
+hipError_t orbxLaunchKnn2Batch(hipStream_t st, int npairs, const uint8_t *q, long long qPairStride, const int *nqDev, const int *qBeginDev,
+                               int nq, const uint8_t *t, long long tPairStride, const int *ntDev, const int *tBeginDev, int nt,
+                               int nSplit, uint32_t *part, int *idx, int *dist)
+{
+    if (npairs <= 0 || nq <= 0) return hipSuccess;
+    if (nt >= (1 << KN_IDX_BITS)) return hipErrorInvalidValue;
+    Knn2Args a;
+    a.q = q; a.t = t; a.qPairStride = qPairStride; a.tPairStride = tPairStride;
+    a.nqDev = nqDev; a.ntDev = ntDev; a.qBeginDev = qBeginDev; a.tBeginDev = tBeginDev;
+    a.nq = nq; a.nt = nt;
+    a.nSplit = std::max(nSplit, 1);
+    a.splitRows = nt > 0 ? (nt + a.nSplit - 1) / a.nSplit : 1;
+    a.part = part; a.idx = idx; a.dist = dist;
+    hipLaunchKernelGGL(k_knn2_scan, dim3((nq + 63) / 64, a.nSplit, npairs), dim3(64), 0, st, a);
+    if (a.nSplit > 1) hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256, npairs), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -93,10 +178,27 @@ struct MtKp { float x, y, size, angle, response; int octave, class_id; };
 // Row-band stereo candidates: right keypoint iR is a candidate of left keypoint iL iff
 // floor(yR - r) <= (int)yL <= ceil(yR + r), r = 2 * scale[octR]  (row buckets, :858-868), |octave diff| <= 1 and
 // uR in [uL - maxD, uL - minD]; candidates are visited in increasing iR (bucket push order) with a strict `<`.
+// blockIdx.y = stereo pair: keypoints / descriptors / results of pair p start p * pairStride records further, and the counts come
+// from the device arrays nlDev / nrDev when those are given (the extractors' per-frame keypoint counts) - a batch of pairs is one
+// launch and nothing returns to the host in between.
+struct StereoBatch {
+    long long kpStrideL, kpStrideR;  // keypoint / descriptor records between consecutive pairs (left, right extractor)
+    long long outStride;             // result records between consecutive pairs
+    const int *nlDev, *nrDev;
+};
+
 __global__ __launch_bounds__(64) void k_stereo_rows(const MtKp *kl, const uint8_t *dl, int nl, const MtKp *kr,
                                                     const uint8_t *dr, int nr, int nRows, const float *scale,
-                                                    float minD, float maxD, int *bestIdx, int *bestDist)
+                                                    float minD, float maxD, int *bestIdx, int *bestDist, StereoBatch sb)
 {
+    {
+        const size_t p = blockIdx.y;
+        kl += p * sb.kpStrideL; dl += p * sb.kpStrideL * 32; kr += p * sb.kpStrideR; dr += p * sb.kpStrideR * 32;
+        bestIdx += p * sb.outStride; bestDist += p * sb.outStride;
+        if (sb.nlDev) nl = min(nl, sb.nlDev[p]);
+        if (sb.nrDev) nr = min(nr, sb.nrDev[p]);
+        if ((int)(blockIdx.x * 64) >= nl) return;
+    }
     __shared__ uint32_t tt[MT_TILE * 8];
     __shared__ int tMinR[MT_TILE], tMaxR[MT_TILE], tOct[MT_TILE];
     __shared__ float tU[MT_TILE];
@@ -147,13 +249,21 @@ __global__ __launch_bounds__(64) void k_stereo_rows(const MtKp *kl, const uint8_
     if (li < nl) { bestIdx[li] = bi; bestDist[li] = best; }
 }
 
+static StereoBatch stereoBatch(const OrbxStereoBatch *b)
+{
+    StereoBatch sb;
+    sb.kpStrideL = b ? b->kpStrideL : 0; sb.kpStrideR = b ? b->kpStrideR : 0; sb.outStride = b ? b->outStride : 0;
+    sb.nlDev = b ? b->nlDev : nullptr; sb.nrDev = b ? b->nrDev : nullptr;
+    return sb;
+}
+
 hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *dl, int nl, const void *kr,
                                 const uint8_t *dr, int nr, int nRows, const float *scaleDev, float minD, float maxD,
-                                int *bestIdx, int *bestDist)
+                                int *bestIdx, int *bestDist, const OrbxStereoBatch *batch)
 {
     if (nl <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_stereo_rows, dim3((nl + 63) / 64), dim3(64), 0, st, (const MtKp *)kl, dl, nl, (const MtKp *)kr,
-                       dr, nr, nRows, scaleDev, minD, maxD, bestIdx, bestDist);
+    hipLaunchKernelGGL(k_stereo_rows, dim3((nl + 63) / 64, batch ? batch->npairs : 1), dim3(64), 0, st, (const MtKp *)kl, dl, nl, (const MtKp *)kr,
+                       dr, nr, nRows, scaleDev, minD, maxD, bestIdx, bestDist, stereoBatch(batch));
     return hipGetLastError();
 }
 
@@ -168,6 +278,7 @@ struct StereoLevels {
     int pitchL[ORBX_MAX_LEVELS], pitchR[ORBX_MAX_LEVELS];
     int colsR[ORBX_MAX_LEVELS];
     float scale[ORBX_MAX_LEVELS], invScale[ORBX_MAX_LEVELS];
+    long long frameStrideL[ORBX_MAX_LEVELS], frameStrideR[ORBX_MAX_LEVELS];  // bytes between the level images of consecutive pairs
 };
 
 __device__ __forceinline__ int mt_wave_sum(int x)
@@ -182,8 +293,13 @@ __device__ __forceinline__ int mt_wave_sum(int x)
 
 __global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp *kl, int nl, const MtKp *kr, const int *bestIdx,
                                                     const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth,
-                                                    int *sadDist)
+                                                    int *sadDist, StereoBatch sb)
 {
+    const size_t pair = blockIdx.y;
+    kl += pair * sb.kpStrideL; kr += pair * sb.kpStrideR;
+    bestIdx += pair * sb.outStride; bestDist += pair * sb.outStride;
+    uRight += pair * sb.outStride; depth += pair * sb.outStride; sadDist += pair * sb.outStride;
+    if (sb.nlDev) nl = min(nl, sb.nlDev[pair]);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nl) return;
@@ -205,8 +321,8 @@ __global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp 
         if (!(iniu < 0 || endu >= (float)lv.colsR[oct])) {
             const int y0 = (int)__fsub_rn(scaledvL, (float)w), xL0 = (int)__fsub_rn(scaleduL, (float)w);
             const int xRb = (int)scaleduR0 - w;  // first column of the unshifted right patch
-            const uint8_t *pl = lv.left[oct] + (size_t)y0 * lv.pitchL[oct] + xL0;
-            const uint8_t *pr = lv.right[oct] + (size_t)y0 * lv.pitchR[oct] + xRb;
+            const uint8_t *pl = lv.left[oct] + pair * lv.frameStrideL[oct] + (size_t)y0 * lv.pitchL[oct] + xL0;
+            const uint8_t *pr = lv.right[oct] + pair * lv.frameStrideR[oct] + (size_t)y0 * lv.pitchR[oct] + xRb;
             // lane handles patch pixels p0 = lane and p1 = lane + 64 (121 pixels)
             const int p0 = lane, p1 = lane + 64;
             const int y0p = p0 / 11, x0p = p0 - y0p * 11, y1p = p1 / 11, x1p = p1 - y1p * 11;
@@ -256,8 +372,13 @@ __global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp 
 
 // median-based outlier rejection (:996-1010): median = SAD at rank size/2 of the accepted matches (a k-th order
 // statistic, no sort needed), thDist = 1.5f * 1.4f * median; every match with SAD >= thDist is dropped.
-__global__ __launch_bounds__(256) void k_stereo_outliers(int nl, float *uRight, float *depth, const int *sadDist)
+__global__ __launch_bounds__(256) void k_stereo_outliers(int nl, float *uRight, float *depth, const int *sadDist, StereoBatch sb)
 {
+    {
+        const size_t pair = blockIdx.x;
+        uRight += pair * sb.outStride; depth += pair * sb.outStride; sadDist += pair * sb.outStride;
+        if (sb.nlDev) nl = min(nl, sb.nlDev[pair]);
+    }
     __shared__ int red[4];
     __shared__ int total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,13 +408,16 @@ __global__ __launch_bounds__(256) void k_stereo_outliers(int nl, float *uRight, 
 }
 
 hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void *kl, int nl, const void *kr, const int *bestIdx,
-                                  const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist)
+                                  const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth, int *sadDist,
+                                  const OrbxStereoBatch *batch)
 {
     if (nl <= 0) return hipSuccess;
+    static_assert(sizeof(StereoLevels) == sizeof(OrbxStereoLevels), "host / device level tables differ");
     const StereoLevels &lv = *(const StereoLevels *)levels;
-    hipLaunchKernelGGL(k_stereo_sad, dim3((nl + 3) / 4), dim3(256), 0, st, lv, (const MtKp *)kl, nl, (const MtKp *)kr, bestIdx, bestDist,
-                       mbf, minD, maxD, uRight, depth, sadDist);
-    hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(256), 0, st, nl, uRight, depth, sadDist);
+    const int npairs = batch ? batch->npairs : 1;
+    hipLaunchKernelGGL(k_stereo_sad, dim3((nl + 3) / 4, npairs), dim3(256), 0, st, lv, (const MtKp *)kl, nl, (const MtKp *)kr, bestIdx, bestDist,
+                       mbf, minD, maxD, uRight, depth, sadDist, stereoBatch(batch));
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(npairs), dim3(256), 0, st, nl, uRight, depth, sadDist, stereoBatch(batch));
     return hipGetLastError();
 }
 
