@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the ORB front-end hot path (BASELINE.json metric).
 
-One "step" = one pass of ORBextractor::operator() (pyramid -> FAST/NMS -> quadtree -> IC-angle -> blur -> rBRIEF
--> pack) over ONE batch of 1024 synthetic 640x480 mono frames, nFeatures=1000, 8 levels, scale 1.2
-(BASELINE.json configs[1]) per GPU.  Inputs are resident in HBM before the timed region starts; results stay in
-HBM (the PCIe-inclusive rate of the host-pointer API is reported in DESIGN.md, never here).
+Default (`--config c2`, BASELINE.json configs[1], the configuration the metric is quoted on): one "step" = one pass of
+ORBextractor::operator() (pyramid -> FAST/NMS -> quadtree -> IC-angle -> blur -> rBRIEF -> pack) over ONE batch of 1024
+synthetic 640x480 mono frames, nFeatures=1000, 8 levels, scale 1.2, per GPU.  `value` = frames/s with the inputs resident
+in HBM before the timed region and the results left in HBM; the PCIe-inclusive rate of the host-pointer API
+(orbx_extract_batch: H2D of the frames and D2H of keypoints + descriptors inside the call) is printed next to
+it as `pcie_inclusive_frames_per_s` - never as `value`.
 
-Multi-GPU (--gpus N under torch.distributed.run): frames shard across ranks, one process per GPU, no data-path
-collective (weak scaling: every rank runs its own 1024-frame batch).  With --gather the per-batch result
-records are all-gathered over RCCL inside the timed region (north_star's "trivial gather"); off by default
-because the path itself has no exchange step.
+Other workloads (`--config`): c3 = 752x480 stereo pairs, nFeatures=1200, extraction of both images +
+Frame::ComputeStereoMatches per pair; c4 = 512x512 mono, nFeatures=1500; c5 = 1920x1080 stereo pairs, nFeatures=4000,
+extraction + brute-force kNN-2 Hamming cross-match (4000 x 4000 per pair).  Stereo steps run the two extractors and the
+device-resident batched matcher entry point; nothing crosses PCIe inside a step.
+
+Multi-GPU (--gpus N under torch.distributed.run): frames shard across ranks, one process per GPU, no data-path collective.
+--scaling weak (default): every rank runs its own batch per step.  --scaling strong: a fixed stream (c3: the 3,682 pairs of
+EuRoC MH01) is dealt frame f -> rank f mod N and every rank works through its share in batches.  With --gather the
+fixed-capacity result records are all-gathered over RCCL inside the timed region and placed by frame index on the device
+(wut-cuda-orb-slam3_amd/sharding.py, the code path tests/test_sharding_gloo.py covers); off by default because the path
+itself has no exchange step.
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import concurrent.futures
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,35 +39,164 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 640, 480, 1000, 8, 1.2, 20, 7
-BATCH = 1024
-# algorithmic HBM bytes per 640x480 frame of the fused pyramid+FAST stage
-# = read sum(P_0..7) + write sum(P_1..7) = 950,532 + 643,332
-ALGO_BYTES_PYR_FAST_PER_FRAME = 1_593_864
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
+CONFIGS = {
+    # units = what one GPU processes per step; a stereo unit is a pair (2 frames)
+    "c2": dict(w=640, h=480, nf=1000, stereo=False, units=1024, match=None, lap=(0, 1000), stream=8192,
+               name="batch of {u} synthetic 640x480 mono frames per GPU, nFeatures=1000, 8 levels, scale 1.2 (BASELINE configs[1])"),
+    "c3": dict(w=752, h=480, nf=1200, stereo=True, units=512, match="stereo", lap=(0, 0), stream=3682,
+               name="batch of {u} synthetic 752x480 stereo pairs per GPU (EuRoC MH01 geometry), nFeatures=1200: extract L + R, "
+                    "Frame::ComputeStereoMatches per pair (BASELINE configs[2])"),
+    "c4": dict(w=512, h=512, nf=1500, stereo=False, units=1024, match=None, lap=(0, 1000), stream=8192,
+               name="batch of {u} synthetic 512x512 mono frames per GPU (TUM-VI geometry), nFeatures=1500 (BASELINE configs[3])"),
+    "c5": dict(w=1920, h=1080, nf=4000, stereo=True, units=64, match="knn2", lap=(0, 0), stream=1024,
+               name="batch of {u} synthetic 1920x1080 stereo pairs per GPU, nFeatures=4000: extract L + R, brute-force 256-bit "
+                    "Hamming kNN-2 cross-match per pair (BASELINE configs[4])"),
+}
+MB, MBF = 0.11, 47.9  # stereo baseline [m] and baseline x fx (EuRoC-like) for ComputeStereoMatches
 
 
-def cpu_baseline(orc, frames: np.ndarray, threads: int):
-    """Oracle (CPU restatement of the reference algorithm, kind="port") timed on the host cores on a bounded sample."""
-    ref = orc.Oracle(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
-    ref.extract_batch(frames[: min(len(frames), threads)], (0, 1000), threads=threads)  # warm-up
+def level_pixels(ex):
+    return [ex.level_size(l)[0] * ex.level_size(l)[1] for l in range(NLEVELS)]
+
+
+def make_frames(pkg, cfg, first, count):
+    """Synthetic frames of units [first, first + count): mono [count, H, W]; stereo (left, right) with the right image a
+    horizontally shifted copy (disparity 6 + (unit mod 24) px)."""
+    w, h = cfg["w"], cfg["h"]
+    left = np.empty((count, h, w), np.uint8)
+    for i in range(count):
+        left[i] = pkg.synth_frame(first + i, w, h)
+    if not cfg["stereo"]:
+        return left, None
+    right = np.empty_like(left)
+    for i in range(count):
+        right[i] = np.roll(left[i], -(6 + (first + i) % 24), axis=1)
+    return left, right
+
+
+# ---- CPU baseline (the oracle = CPU restatement of the reference algorithm, kind "port") -----------------------------------
+def _cpu_units(orc, cfg, left, right, threads):
+    """Processes every unit of the sample once with `threads` host threads; returns wall seconds."""
+    nf = cfg["nf"]
+    if not cfg["stereo"]:
+        ref = orc.Oracle(nf, SCALE, NLEVELS, INI_TH, MIN_TH)
+        t0 = time.perf_counter()
+        ref.extract_batch(left, cfg["lap"], threads=threads)
+        return time.perf_counter() - t0
+    pool = [(orc.Oracle(nf, SCALE, NLEVELS, INI_TH, MIN_TH), orc.Oracle(nf, SCALE, NLEVELS, INI_TH, MIN_TH)) for _ in range(threads)]
+
+    def one(args):
+        slot, i = args
+        ol, orr = pool[slot]
+        _, kl, dl = ol.extract(left[i], cfg["lap"])
+        _, kr, dr = orr.extract(right[i], cfg["lap"])
+        if cfg["match"] == "stereo":
+            orc.stereo_matches(ol, orr, kl, dl, kr, dr, MB, MBF)
+        else:
+            orc.knn2(dl, dr)
+
     t0 = time.perf_counter()
-    counts, _, _, _ = ref.extract_batch(frames, (0, 1000), threads=threads)
-    dt = time.perf_counter() - t0
-    return len(frames) / dt, dt, int(counts.sum())
+    if threads == 1:
+        for i in range(len(left)):
+            one((0, i))
+    else:  # unit i on worker i mod threads (ctypes releases the GIL inside the oracle)
+        with concurrent.futures.ThreadPoolExecutor(threads) as ex:
+            futs = [ex.submit(lambda s=s: [one((s, i)) for i in range(s, len(left), threads)]) for s in range(threads)]
+            [f.result() for f in futs]
+    return time.perf_counter() - t0
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_leg(cfg, cfg_key, left, right, budget_s):
+    """Times the oracle on a bounded sample of the same workload: all host threads (<= 16) and one thread, -O3 build; then the same
+    two runs of a -O3 -march=native build compiled here (the GPU box's CPU differs from the build container's)."""
+    orc = graft.load_oracle()
+    threads = min(os.cpu_count() or 1, 16)
+    frames_per_unit = 2 if cfg["stereo"] else 1
+
+    def measure(orc_mod):
+        # all threads: repeat the sample until ~budget_s of wall time
+        n_units, wall = 0, 0.0
+        _cpu_units(orc_mod, cfg, left[:threads], None if right is None else right[:threads], threads)  # warm-up
+        while wall < budget_s and n_units < 16 * len(left):
+            wall += _cpu_units(orc_mod, cfg, left, right, threads)
+            n_units += len(left)
+        n1 = max(2, min(len(left), int(round(0.2 * budget_s * n_units / wall / threads))))
+        w1 = _cpu_units(orc_mod, cfg, left[:n1], None if right is None else right[:n1], 1)
+        return n_units * frames_per_unit / wall, wall, n_units, w1 / (n1 * frames_per_unit) * 1e3, n1
+
+    fps, wall, n_units, ms1, n1 = measure(orc)
+    out = {"value": round(fps, 2), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
+           "ms_per_frame_1thread": round(ms1, 3),
+           "sample": f"{n_units} units ({n_units * frames_per_unit} frames) of the same synthetic {cfg_key} workload on {threads} threads, "
+                     f"{wall:.1f} s wall; 1-thread figure on {n1} units; build g++ -O3 (oracle/Makefile)"}
+    # -march=native variant in a child process (the oracle library is chosen at import time)
+    try:
+        tmp = tempfile.mkdtemp(prefix="orbx_native_")
+        so = os.path.join(tmp, "liborb_oracle_native.so")
+        subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-shared", "-o", so,
+                        os.path.join(ROOT, "oracle", "orb_oracle.cpp")], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        np.save(os.path.join(tmp, "left.npy"), left)
+        if right is not None:
+            np.save(os.path.join(tmp, "right.npy"), right)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", tmp, "--config", cfg_key, "--cpu-budget", str(budget_s)],
+                           env=dict(os.environ, ORB_ORACLE_LIB=so), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        child = json.loads(r.stdout.strip().splitlines()[-1])
+        out["march_native"] = {"value": child["fps"], "ms_per_frame_1thread": child["ms1"], "build": "g++ -O3 -march=native"}
+    except Exception as e:  # the baseline above stands; say why the variant is missing
+        out["march_native"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def cpu_child(tmp, cfg_key, budget_s):
+    cfg = CONFIGS[cfg_key]
+    orc = graft.load_oracle()
+    left = np.load(os.path.join(tmp, "left.npy"))
+    right = np.load(os.path.join(tmp, "right.npy")) if cfg["stereo"] else None
+    threads = min(os.cpu_count() or 1, 16)
+    fpu = 2 if cfg["stereo"] else 1
+    _cpu_units(orc, cfg, left[:threads], None if right is None else right[:threads], threads)
+    n_units, wall = 0, 0.0
+    while wall < budget_s and n_units < 16 * len(left):
+        wall += _cpu_units(orc, cfg, left, right, threads)
+        n_units += len(left)
+    n1 = max(2, min(len(left), int(round(0.2 * budget_s * n_units / wall / threads))))
+    w1 = _cpu_units(orc, cfg, left[:n1], None if right is None else right[:n1], 1)
+    print(json.dumps({"fps": round(n_units * fpu / wall, 2), "ms1": round(w1 / (n1 * fpu) * 1e3, 3)}))
+
+
+# ---- main ------------------------------------------------------------------------------------------------------------------
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="frames per GPU per step (default: the metric's 1024)")
-    ap.add_argument("--gather", action="store_true", help="all-gather result records over RCCL inside the timed region")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="workload (default c2 = the metric's configuration)")
+    ap.add_argument("--batch", type=int, default=0, help="units (frames / stereo pairs) per GPU per step (default: the config's)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--gather", action="store_true", help="all-gather the result records over RCCL inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=768, help="frames in the CPU-baseline sample")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-pointer API (H2D + D2H included); reported separately")
+    ap.add_argument("--cpu-budget", type=float, default=5.0, help="seconds of all-thread CPU work per oracle build in the baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="units in the CPU-baseline sample (default: by config)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
+    ap.add_argument("--pcie", action="store_true", help="(kept for compatibility: the PCIe-inclusive timing is on by default)")
+    ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_child:
+        cpu_child(args.cpu_child, args.config, args.cpu_budget)
+        return
 
     import torch
     import torch.distributed as dist
@@ -70,44 +211,99 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = graft.load_package()
-    B = args.batch
-    # synthetic frames of this rank's shard: global frame index = rank * B + i
-    host = np.empty((B, H, W), np.uint8)
-    for i in range(B):
-        host[i] = pkg.synth_frame(rank * B + i, W, H)
-    frames = torch.from_numpy(host).cuda(local_rank)
+    import importlib
+    sharding = importlib.import_module("wut_cuda_orb_slam3_amd.sharding")
+    cfg = CONFIGS[args.config]
+    W, H, NFEAT, stereo = cfg["w"], cfg["h"], cfg["nf"], cfg["stereo"]
+    B = args.batch or cfg["units"]
+    fpu = 2 if stereo else 1
+
+    # ---- this rank's units -------------------------------------------------------------------------------------------------
+    # weak: units rank * B .. rank * B + B - 1, the same batch every step.  strong: global stream of cfg["stream"] units dealt
+    # f -> rank f mod world; the rank works through its share in sub-batches of B, `steps` passes over the whole stream.
+    if args.scaling == "weak":
+        my_units = np.arange(rank * B, rank * B + B)
+        global_units = world * B
+    else:
+        global_units = cfg["stream"]
+        my_units = sharding.frames_of_rank(global_units, world, rank)
+    # contiguous synthetic ids are generated once; unit u uses synthetic frame id u
+    chunks = []  # (d_left, d_right, count)
+    host_first = None
+    for c0 in range(0, len(my_units), B):
+        ids = my_units[c0: c0 + B]
+        left = np.empty((len(ids), H, W), np.uint8)
+        right = np.empty_like(left) if stereo else None
+        for j, u in enumerate(ids):
+            l1, r1 = make_frames(pkg, cfg, int(u), 1)
+            left[j] = l1[0]
+            if stereo:
+                right[j] = r1[0]
+        if host_first is None:
+            host_first = (left, right)
+        # units of this chunk over all ranks: weak = every rank its own B; strong = the global range [world * c0, world * (c0 + B))
+        gtotal = world * len(ids) if args.scaling == "weak" else min(global_units, world * (c0 + B)) - world * c0
+        chunks.append((torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev) if stereo else None, len(ids), gtotal))
     torch.cuda.synchronize()
 
-    ex = pkg.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=B)
-    ex.set_profiling(True)
-    d_kps, d_desc, d_n, d_mono = ex.device_outputs()
-    cap = ex.capacity
+    exl = pkg.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=B)
+    exr = pkg.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=B) if stereo else None
+    exl.set_profiling(True)
+    cap = exl.capacity
+    matcher = pkg.ORBmatcher(cap, cap, device=local_rank) if stereo else None
+    m_out = None
+    if stereo:
+        if cfg["match"] == "stereo":
+            m_out = (torch.empty((B, cap), dtype=torch.float32, device=dev), torch.empty((B, cap), dtype=torch.float32, device=dev))
+        else:
+            m_out = (torch.empty((B, cap, 2), dtype=torch.int32, device=dev), torch.empty((B, cap, 2), dtype=torch.int32, device=dev))
+    lib = pkg.load_library()
+    import ctypes
 
-    class _DevView:  # zero-copy torch view of a liborbx device buffer (for the RCCL gather)
-        def __init__(self, ptr, nbytes):
-            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    def match(n):
+        if cfg["match"] == "stereo":
+            rc = lib.orbx_compute_stereo_matches_frames(matcher._h, exl._h, exr._h, n, MB, MBF, ctypes.c_void_p(m_out[0].data_ptr()),
+                                                        ctypes.c_void_p(m_out[1].data_ptr()))
+        else:
+            rc = lib.orbx_match_knn2_frames(matcher._h, exl._h, exr._h, n, 0, ctypes.c_void_p(m_out[0].data_ptr()), ctypes.c_void_p(m_out[1].data_ptr()))
+        if rc != 0:
+            raise SystemExit(f"matcher call failed: {lib.orbx_last_error().decode()}")
 
-    gather_bufs = None
-    if args.gather and world > 1:
-        views = [torch.as_tensor(_DevView(d_kps, B * cap * 28), device=f"cuda:{local_rank}"),
-                 torch.as_tensor(_DevView(d_desc, B * cap * 32), device=f"cuda:{local_rank}"),
-                 torch.as_tensor(_DevView(d_n, B * 4), device=f"cuda:{local_rank}"),
-                 torch.as_tensor(_DevView(d_mono, B * 4), device=f"cuda:{local_rank}")]
-        gather_bufs = [(v, torch.empty(world * v.numel(), dtype=torch.uint8, device=f"cuda:{local_rank}")) for v in views]
+    # result gather (north_star's "trivial gather"): zero-copy views of the left extractor's HBM outputs, RCCL all-gather,
+    # device-side placement by frame index; ordered against the library's stream without a host synchronisation
+    gather_state = None
+    if args.gather:
+        ext = torch.cuda.ExternalStream(exl.stream(), device=dev)
+        gather_state = {"ext": ext}
+
+    def gather(n, gtotal):
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(gather_state["ext"])            # results of this rank are complete
+        local = sharding.device_output_tensors(exl, n, dev)
+        rec = sharding.gather_frame_records(local, gtotal)  # slot = frame index within the chunk's global range
+        gather_state["ext"].wait_stream(cur)            # the next batch overwrites the buffers only after the gather has read them
+        return rec
 
     def step():
-        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, (0, 1000))
-        if gather_bufs is not None:
-            ex.sync()  # results of this rank are complete; gather the fixed-capacity records over RCCL / xGMI
-            for local, full in gather_bufs:
-                dist.all_gather_into_tensor(full, local)
+        for d_left, d_right, n, gtotal in chunks:
+            exl.extract_batch_device(d_left.data_ptr(), n, W, H, W, W * H, cfg["lap"])
+            if stereo:
+                exr.extract_batch_device(d_right.data_ptr(), n, W, H, W, W * H, cfg["lap"])
+                match(n)
+            if gather_state is not None:
+                gather(n, gtotal)
 
     def fence():
+        exl.sync()
+        if stereo:
+            exr.sync()
+            matcher.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -115,87 +311,133 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
-    ex.stage_times()  # reset the event ring
+    exl.stage_times()  # reset the event ring
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    stage_ms, nb = ex.stage_times()
+    stage_ms, nb = exl.stage_times()
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    n, mono, _, _ = ex.download_outputs(B)
+    n_last = chunks[-1][2]
+    n, mono, _, _ = exl.download_outputs(n_last)
     total_kps = int(n.sum())
 
-    pcie_fps = pcie_pinned_fps = None
-    if args.pcie and rank == 0:
-        ex.extract_batch(host, (0, 1000))
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ex.extract_batch(host, (0, 1000))
-        pcie_fps = 3 * B / (time.perf_counter() - t1)
-        # the same call with the frames in page-locked host memory (what a capture pipeline that owns its buffers would pass)
-        pinned = torch.from_numpy(host).pin_memory().numpy()
-        ex.extract_batch(pinned, (0, 1000))
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ex.extract_batch(pinned, (0, 1000))
-        pcie_pinned_fps = 3 * B / (time.perf_counter() - t1)
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    if rank == 0:
-        frames_total = world * B * args.steps
-        fps = frames_total / dt
-        pyr_ms = float(stage_ms[0])
-        achieved = ALGO_BYTES_PYR_FAST_PER_FRAME * B / (pyr_ms * 1e-3) / 1e9 if pyr_ms > 0 else 0.0
-        # HBM bytes of the same launch set from the committed PMC passes (tools/collect_traffic.sh: FETCH_SIZE and
-        # WRITE_SIZE in separate rocprofv3 runs; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
-        if os.path.exists(tpath) and B == BATCH:
-            try:
-                t = json.load(open(tpath))["k_pyr_fast"]
-                traffic = int(2 * t["FETCH_SIZE_bytes_per_batch"] + t["WRITE_SIZE_bytes_per_batch"])
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "ORB extract throughput (640x480, 1000 feat, 8 levels)",
-            "value": round(fps, 1),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "ms_per_frame": round(dt / args.steps * 1e3 / B, 6),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": f"batch of {B} synthetic 640x480 mono frames per GPU, nFeatures=1000, 8 levels, scale 1.2 (BASELINE configs[1])",
-                       "frames_per_gpu_per_step": B, "keypoints_per_frame": round(total_kps / B, 1),
-                       "parallelism": f"frame-sharded x{world}", "gather": bool(gather_bufs is not None)},
-            "stages_ms": {name: round(float(ms), 4) for name, ms in zip(pkg.STAGE_NAMES, stage_ms)},
-            "roofline": {"bound": "hbm", "kernel": "k_pyr_fast (8 per-level launches = one pyramid+FAST pass)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch_set": ALGO_BYTES_PYR_FAST_PER_FRAME * B,
-                         "avg_duration_ms": round(pyr_ms, 4), "batches_timed": int(nb)},
-        }
-        if pcie_fps is not None:
-            out["pcie_inclusive_frames_per_s"] = round(pcie_fps, 1)
-            out["pcie_inclusive_pinned_input_frames_per_s"] = round(pcie_pinned_fps, 1)
-        if not args.no_cpu_baseline:
-            orc = graft.load_oracle()
-            threads = min(os.cpu_count() or 1, 16)
-            sample = host[: min(args.cpu_sample, B)]
-            cfps, cdt, _ = cpu_baseline(orc, sample, threads)
-            out["cpu_baseline"] = {"value": round(cfps, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-                                   "sample": f"{len(sample)} of the same synthetic frames, one frame per task on {threads} threads, {cdt:.1f} s wall"}
-        print(json.dumps(out))
+    # ---- rank 0: roofline of the dominant kernel, matcher block, PCIe-inclusive rate, CPU baseline ---------------------------------
+    d_left0, d_right0, n0, _ = chunks[0]
+    # pyramid + FAST launch set alone on the GPU (stereo configs run two handles side by side in the timed loop)
+    if stereo or len(chunks) > 1:
+        for _ in range(2):
+            exl.extract_batch_device(d_left0.data_ptr(), n0, W, H, W, W * H, cfg["lap"])
+        exl.sync()
+        exl.stage_times()
+        for _ in range(5):
+            exl.extract_batch_device(d_left0.data_ptr(), n0, W, H, W, W * H, cfg["lap"])
+        exl.sync()
+        solo_ms, solo_nb = exl.stage_times()
+    else:
+        solo_ms, solo_nb = stage_ms, nb
+    px = level_pixels(exl)
+    algo_bytes_frame = sum(px) + sum(px[1:])  # read every level once, write levels 1..7 once
+    pyr_ms = float(solo_ms[0])
+    achieved = algo_bytes_frame * n0 / (pyr_ms * 1e-3) / 1e9 if pyr_ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": "k_pyr_fast (8 per-level launches = one pyramid+FAST pass over the batch)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch_set": algo_bytes_frame * n0, "avg_duration_ms": round(pyr_ms, 4), "batches_timed": int(solo_nb),
+            "binding_bound": "valu_issue"}
+    # HBM bytes and VALU instruction count of the same launch set from the committed PMC passes (tools/collect_traffic.sh,
+    # tools/pmc.sh: separate rocprofv3 runs; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md)
+    cpath = os.path.join(ROOT, "profiles", "pyr_fast_counters_latest.json")
+    if args.config == "c2" and n0 == 1024 and os.path.exists(cpath):
+        try:
+            c = json.load(open(cpath))
+            roof["traffic"] = int(2 * c["FETCH_SIZE_bytes_per_batch"] + c["WRITE_SIZE_bytes_per_batch"])
+            valu = float(c["SQ_INSTS_VALU_per_batch"])
+            cyc = float(c.get("valu_cycles_per_instr_mix", 3.0))
+            # the kernel is bound by vector-instruction issue, not by HBM: wave-instructions per second against what 1024 SIMDs issue
+            # at the measured cost of this instruction mix (profiles/r01_valu_microbench.txt: 2.4-2.7 cycles for add/and/bitop3/shift,
+            # 4.1-4.5 for min/max/mul/alignbyte/SDWA forms) and at the best case of 2 cycles per instruction
+            ach = valu / (pyr_ms * 1e-3) / 1e9
+            roof["valu_issue"] = {"achieved": round(ach, 1), "unit": "G wave-instr/s",
+                                  "peak_mix": round(N_SIMD * CLOCK_GHZ / cyc, 1), "frac_mix": round(ach / (N_SIMD * CLOCK_GHZ / cyc), 3),
+                                  "peak_2cycle": round(N_SIMD * CLOCK_GHZ / 2.0, 1), "frac_2cycle": round(ach / (N_SIMD * CLOCK_GHZ / 2.0), 3),
+                                  "valu_wave_instr_per_launch_set": int(valu), "cycles_per_instr_mix": cyc, "clock_ghz": CLOCK_GHZ}
+        except Exception:
+            pass
+
+    frames_total = global_units * fpu * args.steps
+    fps = frames_total / dt
+    out = {
+        "metric": "ORB extract throughput (640x480, 1000 feat, 8 levels)" if args.config == "c2" else
+                  f"ORB front-end throughput ({W}x{H}{' stereo' if stereo else ''}, {NFEAT} feat, 8 levels)",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / frames_total * 1e3, 6),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": cfg["name"].format(u=B), "config_id": args.config, "units_per_gpu_per_step": int(len(my_units)),
+                   "frames_per_unit": fpu, "keypoints_per_frame": round(total_kps / n_last, 1),
+                   "parallelism": f"frame-sharded x{world}" + (f", stream of {global_units} units dealt f mod {world}" if args.scaling == "strong" else ""),
+                   "gather": bool(gather_state is not None)},
+        "stages_ms": {name: round(float(ms), 4) for name, ms in zip(pkg.STAGE_NAMES, stage_ms)},
+        "roofline": roof,
+    }
+    if stereo:
+        out["pairs_per_s"] = round(fps / 2, 1)
+        # the matcher alone: device-resident batch call, wall-timed with a stream sync
+        match(n0); matcher.sync()
+        reps = 10
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            match(n0)
+        matcher.sync()
+        mt = (time.perf_counter() - t1) / reps
+        blk = {"entry_point": "orbx_compute_stereo_matches_frames" if cfg["match"] == "stereo" else "orbx_match_knn2_frames",
+               "pairs_per_call": n0, "ms_per_call": round(mt * 1e3, 4), "pairs_per_s": round(n0 / mt, 1)}
+        if cfg["match"] == "knn2":
+            nq = float(total_kps) / n_last
+            dpairs = nq * nq * n0
+            # 8 v_xor (2.5 cycles) + 8 v_bcnt (4.1) + key, min, med3 (4.2 each) = 65 cycles per wave-row of 64 descriptor pairs
+            peak = N_SIMD * 64 * CLOCK_GHZ * 1e9 / 65.0
+            blk.update({"descriptor_pairs_per_s": round(dpairs / mt, 0), "valu_issue_peak_descriptor_pairs_per_s": round(peak, 0),
+                        "frac_of_valu_issue_peak": round(dpairs / mt / peak, 3)})
+        out["matcher"] = blk
+    if not args.no_pcie and world == 1:  # (host legs on rank 0 at N = 1 only)
+        hl, hr = host_first
+        np_units = min(len(hl), n0)
+
+        def host_call(a, b):
+            exl.extract_batch(a[:np_units], cfg["lap"])
+            if stereo:
+                exr.extract_batch(b[:np_units], cfg["lap"])
+
+        res = {}
+        for tag, (a, b) in (("pageable", (hl, hr)),
+                            ("pinned", (torch.from_numpy(hl).pin_memory().numpy(), torch.from_numpy(hr).pin_memory().numpy() if stereo else None))):
+            host_call(a, b)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                host_call(a, b)
+            res[tag] = 3 * np_units * fpu / (time.perf_counter() - t1)
+        out["pcie_inclusive_frames_per_s"] = round(res["pageable"], 1)
+        out["pcie_inclusive_pinned_input_frames_per_s"] = round(res["pinned"], 1)
+        out["pcie_inclusive_note"] = ("orbx_extract_batch: host frames in (H2D), keypoints + descriptors out (D2H), per call; extraction only"
+                                      + (" (both images of a pair)" if stereo else ""))
+    if not args.no_cpu_baseline and world == 1:
+        hl, hr = host_first
+        ns = args.cpu_sample or {"c2": 1024, "c3": 128, "c4": 1024, "c5": 16}[args.config]
+        ns = min(ns, len(hl))
+        out["cpu_baseline"] = cpu_baseline_leg(cfg, args.config, hl[:ns], hr[:ns] if stereo else None, args.cpu_budget)
+    print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

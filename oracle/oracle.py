@@ -14,7 +14,8 @@ from ctypes import POINTER, byref, c_float, c_int, c_ssize_t, c_uint64, c_void_p
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+# ORB_ORACLE_LIB: another build of the same source (bench.py's cpu_baseline leg times a -march=native build next to the -O3 one)
+LIB_PATH = os.environ.get("ORB_ORACLE_LIB") or os.path.join(_HERE, "liborb_oracle.so")
 
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]

@@ -8,7 +8,7 @@ timeout -k 10 400 python -m pytest tests/test_parity_gpu.py tests/test_golden.py
 rc=$?
 tail -4 gpurun_out/$tag/pytest.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err || { tail -5 gpurun_out/$tag/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-pcie "$@" > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err || { tail -5 gpurun_out/$tag/bench.err; exit 1; }
 python3 - gpurun_out/$tag/bench.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

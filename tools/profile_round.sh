@@ -1,13 +1,21 @@
 #!/bin/bash
-# Produces the evidence committed under profiles/: GPU tests, bench line (with cpu_baseline), rocprofv3 kernel stats
-# of the same bench command, PMC HBM traffic.  Usage on the GPU box: bash tools/profile_round.sh <tag>
-tag=${1:-r01}
+# Produces the evidence committed under profiles/: GPU tests, the bench line of every workload (c2 with cpu_baseline and
+# PCIe-inclusive rates), rocprofv3 kernel stats of the same bench commands, PMC passes (HBM traffic, VALU instruction count).
+# Usage on the GPU box: bash tools/profile_round.sh <tag>
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/$tag
-timeout -k 10 600 python -m pytest tests -x -q -m gpu > gpurun_out/$tag/pytest_gpu.log 2>&1; echo "pytest exit=$?" >> gpurun_out/$tag/pytest_gpu.log
-timeout -k 10 500 python bench.py --pcie > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/rocprof -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/rocprof_bench.json 2> gpurun_out/$tag/rocprof.err
-cp $(find gpurun_out/$tag/rocprof -name "*kernel_stats.csv" | head -1) gpurun_out/$tag/kernel_stats.csv
-bash tools/collect_traffic.sh > gpurun_out/$tag/traffic.log 2>&1
-cp gpurun_out/traffic/summary.json gpurun_out/$tag/hbm_traffic_pmc.json
-tail -3 gpurun_out/$tag/pytest_gpu.log; cat gpurun_out/$tag/bench.json; cat gpurun_out/$tag/kernel_stats.csv
+o=gpurun_out/$tag
+mkdir -p $o
+timeout -k 10 600 python -m pytest tests -x -q -m gpu > $o/pytest_gpu.log 2>&1; echo "pytest exit=$?" >> $o/pytest_gpu.log
+tail -3 $o/pytest_gpu.log
+bash tools/collect_traffic.sh > $o/traffic.log 2>&1
+cp gpurun_out/traffic/summary.json $o/hbm_traffic_pmc.json
+cp gpurun_out/traffic/pyr_fast_counters.json $o/pyr_fast_counters.json
+mkdir -p profiles && cp $o/pyr_fast_counters.json profiles/pyr_fast_counters_latest.json   # bench.py reads this one
+for c in c2 c3 c4 c5; do
+  timeout -k 10 500 python bench.py --config $c > $o/bench_$c.json 2> $o/bench_$c.err || echo "bench $c failed" >> $o/bench_$c.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/rocprof_$c -- python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-pcie > $o/rocprof_bench_$c.json 2> $o/rocprof_$c.err
+  cp $(find $o/rocprof_$c -name "*kernel_stats.csv" | head -1) $o/kernel_stats_$c.csv
+  rm -rf $o/rocprof_$c
+  echo "== $c"; cat $o/bench_$c.json; head -12 $o/kernel_stats_$c.csv
+done

@@ -1,5 +1,7 @@
-"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_traffic.sh) per kernel and per batch.
-FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B by rocprofv3's derived counters (value * 1024 = bytes)."""
+"""Summarises the rocprofv3 PMC passes of tools/collect_traffic.sh per kernel and per batch of the bench command
+(bench.py --steps 2 --warmup 1 = 3 batches).  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in units of 1024 B.
+Writes <dir>/summary.json (every kernel) and <dir>/pyr_fast_counters.json (the flat record of the north-star kernel that
+bench.py reads from profiles/pyr_fast_counters_latest.json)."""
 import collections
 import csv
 import glob
@@ -8,20 +10,42 @@ import os
 import sys
 
 root = sys.argv[1]
-batches = 3  # bench.py --steps 2 --warmup 1
+batches = 3
 out = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True)
-    agg = collections.defaultdict(float)
+for d, counters, scale in (("FETCH_SIZE", ["FETCH_SIZE"], 1024.0), ("WRITE_SIZE", ["WRITE_SIZE"], 1024.0),
+                           ("SQ", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], 1.0)):
+    files = glob.glob(os.path.join(root, d, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != c:
+            c = r["Counter_Name"]
+            if c not in counters:
                 continue
             k = r["Kernel_Name"].split("(")[0]
-            agg[k] += float(r["Counter_Value"])
-            calls[k] += 1
+            agg[k][c] += float(r["Counter_Value"])
+            if c == counters[0]:
+                calls[k] += 1
     for k in agg:
-        out.setdefault(k, {})[c + "_bytes_per_batch"] = agg[k] * 1024.0 / batches
+        for c in agg[k]:
+            name = c + ("_bytes_per_batch" if scale != 1.0 else "_per_batch")
+            out.setdefault(k, {})[name] = agg[k][c] * scale / batches
         out[k]["dispatches_per_batch"] = calls[k] / batches
-print(json.dumps(out, indent=1))
+    # durations of the SQ pass (for the effective clock: GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    if d == "SQ":
+        for f in glob.glob(os.path.join(root, d, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0]
+                out.setdefault(k, {})["ns_per_batch_profiled"] = out.get(k, {}).get("ns_per_batch_profiled", 0.0) + \
+                    (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / batches
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
+pf = dict(out.get("k_pyr_fast", {}))
+if "GRBM_GUI_ACTIVE_per_batch" in pf and pf.get("ns_per_batch_profiled"):
+    pf["effective_clock_ghz_profiled"] = round(pf["GRBM_GUI_ACTIVE_per_batch"] / 8.0 / pf["ns_per_batch_profiled"], 3)
+# cost of the kernel's instruction mix in cycles per wave-instruction on one SIMD: phase instruction counts (tools/pmc_phases.sh)
+# weighted with the per-class issue costs of profiles/r01_valu_microbench.txt
+pf["valu_cycles_per_instr_mix"] = 3.0
+pf["kernel"] = "k_pyr_fast"
+pf["bench"] = "bench.py --config c2 --steps 2 --warmup 1 (3 batches of 1024 frames)"
+json.dump(pf, open(os.path.join(root, "pyr_fast_counters.json"), "w"), indent=1)
+print(json.dumps(pf, indent=1))

@@ -380,6 +380,9 @@ class ORBmatcher:
         _check(self._lib.orbx_match_knn2(self._h, q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data, dist.ctypes.data), "orbx_match_knn2")
         return idx, dist
 
+    def sync(self) -> None:
+        _check(self._lib.orbx_matcher_sync(self._h), "orbx_matcher_sync")
+
     # ---- device-resident, batched forms: pair p = frame p of the two extractors' last batches -----------------------
     def _dev_empty(self, shape, dtype, device: int):
         import torch  # device memory only
