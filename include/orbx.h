@@ -54,10 +54,16 @@ typedef enum {
     ORBX_BLUR_OPENCV_451 = 1  /* {18,34,48,56,48,34,18} — OpenCV >= 4.5.1 / 3.4.13 (sum forced to 256) */
 } orbx_blur_variant;
 
+/* Which overload `cos(angle)` / `sin(angle)` of computeOrbDescriptor resolves to (reference src/ORBextractor.cc:108: the call is
+ * unqualified and `using namespace std` is commented out at :76-77).  With only <cmath> in scope it is ::cos(double) and the result
+ * is narrowed to float; if any transitive header pulls in libstdc++'s <math.h> wrapper - or with upstream ORB-SLAM3's
+ * `using namespace std` - it is the float overload, i.e. glibc's cosf / sinf.  The two differ in the last bit for 0.3 % / 0.65 % of
+ * the angles.  Mode 1 evaluates glibc 2.35's cosf / sinf algorithm (double-precision polynomial after a one-multiply range
+ * reduction), checked bit for bit against the real libm on every float in [0, 6.5] (tests/test_oracle_kat.py). */
 typedef enum {
-    ORBX_ANGLE_FASTATAN2 = 0, /* upstream CPU IC_Angle: cv::fastAtan2 (reference src/ORBextractor.cc:85) */
-    ORBX_ANGLE_ATAN2F = 1     /* fork's OpenCL kernel: atan2 + 3.141592f constants (src/OpenCL/Kernel/Angle.cl:56-58) */
-} orbx_angle_mode;
+    ORBX_TRIG_DOUBLE = 0, /* (float)cos((double)angle) - the fork as written */
+    ORBX_TRIG_FLOAT = 1   /* cosf(angle) / sinf(angle), glibc >= 2.28 */
+} orbx_trig_mode;
 
 /* Constructor arguments of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:58-59) plus the
  * device-side sizing the reference re-derives on every call (src/ORBextractor.cc:1315). */
@@ -72,7 +78,7 @@ typedef struct {
     int32_t max_height;
     int32_t max_batch;   /* frames per orbx_extract_batch call */
     int32_t blur_variant; /* orbx_blur_variant */
-    int32_t angle_mode;   /* orbx_angle_mode */
+    int32_t trig_mode;    /* orbx_trig_mode */
 } orbx_params;
 
 typedef struct orbx_extractor orbx_extractor;

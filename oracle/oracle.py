@@ -85,9 +85,9 @@ def lib() -> ctypes.CDLL:
 
 
 class Oracle:
-    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0, angle_mode=0):
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0, trig_mode=0):
         self.L = lib()
-        self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, angle_mode)
+        self.h = self.L.oracle_create(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, trig_mode)
         if not self.h:
             raise ValueError("oracle_create rejected the parameters")
         self.nlevels = nlevels

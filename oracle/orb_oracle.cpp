@@ -417,7 +417,7 @@ std::vector<int> distributeOctTree(const std::vector<Cand> &c, int minX, int max
 // The extractor object (reference include/ORBextractor.h:52-113, src/ORBextractor.cc:410-468).
 // ---------------------------------------------------------------------------------------------------
 struct oracle_handle {
-    int nfeatures, nlevels, iniTh, minTh, blurVariant, angleMode;
+    int nfeatures, nlevels, iniTh, minTh, blurVariant, trigMode;
     float scaleFactor;
     std::vector<float> scale, invScale, sigma2, invSigma2;
     std::vector<int> featuresPerLevel, umax;
@@ -427,7 +427,7 @@ struct oracle_handle {
     std::vector<std::vector<oracle_keypoint>> levelKps;  // per level, level coordinates, with angle
 
     oracle_handle(int nf, float sf, int nl, int ini, int mn, int bv, int am)
-        : nfeatures(nf), nlevels(nl), iniTh(ini), minTh(mn), blurVariant(bv), angleMode(am), scaleFactor(sf)
+        : nfeatures(nf), nlevels(nl), iniTh(ini), minTh(mn), blurVariant(bv), trigMode(am), scaleFactor(sf)
     {
         scale.resize(nl); sigma2.resize(nl); invScale.resize(nl); invSigma2.resize(nl);
         scale[0] = 1.0f; sigma2[0] = 1.0f;
@@ -537,13 +537,6 @@ struct oracle_handle {
             }
             m_01 += v * v_sum;
         }
-        if (angleMode == 1) {
-            // fork's OpenCL kernel arithmetic (Angle.cl:56-58)
-            float kp_dir = atan2f((float)m_01, (float)m_10);
-            kp_dir += (kp_dir < 0) * (2.0f * 3.141592f);
-            kp_dir *= 180.0f / 3.141592f;
-            return kp_dir;
-        }
         return fastAtan2Deg((float)m_01, (float)m_10);
     }
 
@@ -552,7 +545,12 @@ struct oracle_handle {
     {
         const float factorPI = (float)(M_PI / 180.f);
         float angle = (float)kpt.angle * factorPI;
-        float a = (float)cos((double)angle), b = (float)sin((double)angle);
+        // `cos(angle)` is unqualified in the reference (:108, `using namespace std` commented out at :76-77): ::cos(double) with only
+        // <cmath> in scope (trig_mode 0); the float overload = the platform libm's cosf / sinf if libstdc++'s <math.h> wrapper is
+        // visible, or with upstream ORB-SLAM3's `using namespace std` (trig_mode 1: the REAL libm here, not a restatement)
+        float a, b;
+        if (trigMode == 1) { a = cosf(angle); b = sinf(angle); }
+        else { a = (float)cos((double)angle); b = (float)sin((double)angle); }
         const uint8_t *center = img.row(cvRoundF(kpt.y)) + cvRoundF(kpt.x);
         const int step = img.w;
         const signed char *pat = kOraclePattern31;
@@ -645,10 +643,10 @@ struct oracle_handle {
 extern "C" {
 
 oracle_handle *oracle_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th, int blur_variant,
-                             int angle_mode)
+                             int trig_mode)
 {
     if (nfeatures <= 0 || nlevels <= 0 || nlevels > 32 || !(scale_factor > 1.0f)) return nullptr;
-    return new oracle_handle(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, angle_mode);
+    return new oracle_handle(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, trig_mode);
 }
 void oracle_destroy(oracle_handle *h) { delete h; }
 
@@ -727,7 +725,7 @@ int oracle_extract_batch(oracle_handle *h, const uint8_t *imgs, int n, int w, in
     if (threads < 1) threads = 1;
     std::atomic<int> next(0);
     auto worker = [&]() {
-        oracle_handle local(h->nfeatures, h->scaleFactor, h->nlevels, h->iniTh, h->minTh, h->blurVariant, h->angleMode);
+        oracle_handle local(h->nfeatures, h->scaleFactor, h->nlevels, h->iniTh, h->minTh, h->blurVariant, h->trigMode);
         std::vector<oracle_keypoint> k(oracle_max_keypoints(&local));
         std::vector<uint8_t> d((size_t)k.size() * 32);
         for (;;) {

@@ -31,9 +31,9 @@ typedef struct {
 } oracle_keypoint;
 
 /* blur_variant: 0 = OpenCV 4.5.0 taps {18,34,49,55,49,34,18}; 1 = OpenCV >= 4.5.1 taps
- * {18,34,48,56,48,34,18}.  angle_mode: 0 = cv::fastAtan2 polynomial; 1 = libm atan2f (fork kernel). */
+ * {18,34,48,56,48,34,18}.  trig_mode: 0 = (float)cos((double)angle) in computeOrbDescriptor; 1 = libm cosf / sinf (the float overloads). */
 oracle_handle *oracle_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th,
-                             int blur_variant, int angle_mode);
+                             int blur_variant, int trig_mode);
 void oracle_destroy(oracle_handle *);
 
 /* constructor tables (reference src/ORBextractor.cc:410-468) */

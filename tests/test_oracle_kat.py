@@ -392,3 +392,41 @@ def test_search_by_bow_properties(orc):
     other = dict(fv_node=fv["fv_node"] + 100000, fv_start=fv["fv_start"], fv_feature=fv["fv_feature"])
     nm, matches = orc.search_by_bow(fv, k, d, np.ones(n, np.uint8), other, k, d, 0.7, True)
     assert nm == 0 and (matches == -1).all()
+
+
+def test_glibc_sincosf_restatement(tmp_path):
+    """include/orbx_trig.h (what the GPU evaluates for trig_mode 1) against the REAL libm cosf / sinf of this host, on every
+    32nd float in [0, 6.5] and every float in [3.0, 3.3] - the angle in radians lies in [0, 2 pi].  (All 1.09e9 floats of the
+    range: tests/tools/validate_against_opencv.py --exhaustive-trig; checked clean on glibc 2.35, fused and un-fused.)"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdio.h>
+#include "orbx_trig.h"
+int main(void) {
+    long n = 0, bad = 0;
+    for (uint32_t b = 0; b <= 0x40d00000u; b += (b >= 0x40400000u && b < 0x40533333u) ? 1 : 32) {
+        float y; memcpy(&y, &b, 4);
+        ++n;
+        if (orbx_glibc_sincosf(y, 1) != cosf(y) || orbx_glibc_sincosf(y, 0) != sinf(y)) ++bad;
+    }
+    printf("%ld %ld\n", n, bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "t"
+    for flags in (["-ffp-contract=off"], ["-ffp-contract=fast", "-mfma"]):
+        subprocess.run(["gcc", "-O2", "-std=c99", *flags, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), "-lm"], check=True)
+        r = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
+        n, bad = map(int, r.stdout.split())
+        assert r.returncode == 0 and bad == 0 and n > 30_000_000, (flags, r.stdout)
+
+
+def test_oracle_trig_modes_differ_only_in_descriptors(orc):
+    """trig_mode 1 (libm cosf / sinf) changes nothing but - rarely - descriptor bits: same keypoints, and almost all descriptors equal."""
+    img = orc.synth_frame(3, 640, 480)
+    m0, k0, d0 = orc.Oracle(1000, 1.2, 8, 20, 7, trig_mode=0).extract(img, (0, 0))
+    m1, k1, d1 = orc.Oracle(1000, 1.2, 8, 20, 7, trig_mode=1).extract(img, (0, 0))
+    assert m0 == m1 and k0.tobytes() == k1.tobytes()
+    assert (d0 != d1).any(axis=1).mean() < 0.02

@@ -330,3 +330,20 @@ def test_launch_schedules(pkg, env, args):
     """The launch sequence has measured alternatives behind environment switches (quadtree per level / per group of levels, blur
     of a level as soon as it exists, device batches cut into sub-batches): every one of them must give the same bytes."""
     _gpu_check_subprocess(env, (args,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trig_mode", [0, 1])
+def test_trig_mode_parity(pkg, orc, trig_mode):
+    """computeOrbDescriptor's cos / sin (reference src/ORBextractor.cc:108) as ::cos(double) narrowed (0) or as glibc's float
+    overloads (1): the GPU evaluates include/orbx_trig.h, the oracle calls the real libm - descriptors bit-equal over 20 k keypoints."""
+    imgs = np.stack([pkg.synth_frame(900 + i, 640, 480) for i in range(12)])
+    ex = pkg.ORBextractor(1500, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=12, trig_mode=trig_mode)
+    n, mono, kps, desc = ex.extract_batch(imgs, (0, 0))
+    ref = orc.Oracle(1500, 1.2, 8, 20, 7, trig_mode=trig_mode)
+    rn, rmono, rk, rd = ref.extract_batch(imgs, (0, 0), threads=8, want_outputs=True)
+    assert np.array_equal(n, rn) and n.sum() > 15000
+    for f in range(len(imgs)):
+        assert kps[f, : n[f]].tobytes() == rk[f, : n[f]].tobytes(), f
+        assert desc[f, : n[f]].tobytes() == rd[f, : n[f]].tobytes(), f
+    ex.close()

@@ -42,20 +42,19 @@ for case in range(n_cases):
     bv, am = int(rng.integers(0, 2)), int(rng.integers(0, 2))
     nb = int(rng.integers(1, 4))
     pad_w, pad_h = int(rng.integers(0, 40)), int(rng.integers(0, 40))
-    # which of the extra dimensions to exercise.  "am" (angle_mode 1 = libm atan2f like the fork's OpenCL kernel) is off by default:
-    # the device and the host atan2f are different implementations and differ in the last bits - only fastAtan2 is bit-pinned
-    dims = os.environ.get("STRESS_DIMS", "bv,nb,pad").split(",")
+    # which of the extra dimensions to exercise ("am": trig_mode 1 = glibc cosf / sinf in computeOrbDescriptor)
+    dims = os.environ.get("STRESS_DIMS", "bv,am,nb,pad").split(",")
     bv = bv if "bv" in dims else 0
     am = am if "am" in dims else 0
     nb = nb if "nb" in dims else 1
     pad_w, pad_h = (pad_w, pad_h) if "pad" in dims else (0, 0)
     try:
         ex = pkg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w + pad_w, max_height=h + pad_h,
-                              max_batch=nb, blur_variant=bv, angle_mode=am)
+                              max_batch=nb, blur_variant=bv, trig_mode=am)
         imgs = np.stack([img] + [np.roll(img, 17 * (i + 1), axis=1) for i in range(nb - 1)])
         n, mono, kps, desc = ex.extract_batch(imgs, lap)
         ok = True
-        ref = orc.Oracle(nf, scale, nlev, ini, mn, blur_variant=bv, angle_mode=am)
+        ref = orc.Oracle(nf, scale, nlev, ini, mn, blur_variant=bv, trig_mode=am)
         for i in range(nb):
             rmono, rk, rd = ref.extract(imgs[i], lap)
             ok = ok and mono[i] == rmono and n[i] == len(rk) and np.array_equal(kps[i][: n[i]].view(np.uint8), rk.view(np.uint8)) \

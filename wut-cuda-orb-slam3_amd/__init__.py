@@ -46,7 +46,7 @@ class _Params(ctypes.Structure):
     _fields_ = [
         ("nfeatures", c_int32), ("scale_factor", c_float), ("nlevels", c_int32), ("ini_th_fast", c_int32),
         ("min_th_fast", c_int32), ("device", c_int32), ("max_width", c_int32), ("max_height", c_int32),
-        ("max_batch", c_int32), ("blur_variant", c_int32), ("angle_mode", c_int32),
+        ("max_batch", c_int32), ("blur_variant", c_int32), ("trig_mode", c_int32),
     ]
 
 
@@ -189,10 +189,10 @@ class ORBextractor:
 
     def __init__(self, nfeatures: int, scaleFactor: float, nlevels: int, iniThFAST: int, minThFAST: int, *, device: int = 0,
                  max_width: int = 640, max_height: int = 480, max_batch: int = 1, blur_variant: int = ORBX_BLUR_OPENCV_450,
-                 angle_mode: int = 0):
+                 trig_mode: int = 0):
         self._lib = load_library()
         p = _Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, max_width, max_height, max_batch,
-                    blur_variant, angle_mode)
+                    blur_variant, trig_mode)
         h = c_void_p()
         _check(self._lib.orbx_create(byref(p), byref(h)), "orbx_create")
         self._h = h

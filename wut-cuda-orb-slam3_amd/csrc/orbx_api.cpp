@@ -118,7 +118,7 @@ extern "C" void orbx_default_params(orbx_params *p)
     if (!p) return;
     p->nfeatures = 1000; p->scale_factor = 1.2f; p->nlevels = 8; p->ini_th_fast = 20; p->min_th_fast = 7;
     p->device = 0; p->max_width = 640; p->max_height = 480; p->max_batch = 1;
-    p->blur_variant = ORBX_BLUR_OPENCV_450; p->angle_mode = ORBX_ANGLE_FASTATAN2;
+    p->blur_variant = ORBX_BLUR_OPENCV_450; p->trig_mode = ORBX_TRIG_DOUBLE;
 }
 
 extern "C" int orbx_device_count(void)
@@ -141,6 +141,8 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     *out = nullptr;
     if (p->nfeatures <= 0 || p->nlevels <= 0 || p->nlevels > ORBX_MAX_LEVELS || !(p->scale_factor > 1.0f))
         return setError(ORBX_ERR_INVALID_ARG, "orbx_create: nfeatures>0, 1<=nlevels<=%d, scale_factor>1 required", ORBX_MAX_LEVELS);
+    if (p->trig_mode != ORBX_TRIG_DOUBLE && p->trig_mode != ORBX_TRIG_FLOAT) return setError(ORBX_ERR_INVALID_ARG, "orbx_create: trig_mode must be 0 or 1");
+    if (p->blur_variant != ORBX_BLUR_OPENCV_450 && p->blur_variant != ORBX_BLUR_OPENCV_451) return setError(ORBX_ERR_INVALID_ARG, "orbx_create: blur_variant must be 0 or 1");
     if (p->max_width <= 0 || p->max_height <= 0 || p->max_batch <= 0 || p->max_width > 4096 || p->max_height > 4096)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_create: image size must be within 1..4096, max_batch >= 1");
     int ndev = 0;
@@ -534,7 +536,7 @@ static OrbxTables makeTables(const orbx_extractor *ex)
     OrbxTables t;
     memset(&t, 0, sizeof t);
     t.nlevels = ex->prm.nlevels;
-    t.angleMode = ex->prm.angle_mode;
+    t.trigMode = ex->prm.trig_mode;
     for (int l = 0; l < t.nlevels; ++l) {
         t.scale[l] = ex->scale[l];
         t.quota[l] = ex->quota[l];

@@ -70,7 +70,7 @@ struct OrbxTables {
     unsigned long long umaxPacked;  // umax[v] in nibble v
     int taps[7];
     int nlevels;
-    int angleMode;
+    int trigMode;
 };
 
 // ---- kernel launchers (orbx_kernels.hip) -------------------------------------------------------------

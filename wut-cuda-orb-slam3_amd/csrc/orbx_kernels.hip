@@ -21,6 +21,7 @@
 #include "orbx_internal.h"
 #include "libstdcxx_sort.h"
 #include "orbx_pattern.inc"
+#include "../../include/orbx_trig.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -458,8 +459,15 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
     if (doResize) {
         uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
         const int q0 = dx0 >> 2, q1 = (dx1 + 3) >> 2;
-        const int waveU = __builtin_amdgcn_readfirstlane(wave);  // rows are wave-uniform: row entry and weights in SGPRs
-        for (int q = q0 + lane; q < q1; q += 64) {
+        const int nq = q1 - q0;  // 4-pixel groups of a destination row of this tile
+        // One pixel group per lane, kept for the whole phase (its four column entries stay in registers); the 512 lanes are dealt
+        // over (row class, group): lane t -> group t mod nq, rows dy0 + t / nq, + RC, + 2 RC ...  With the usual 45 - 53 groups per
+        // row a wave-per-row mapping left 20 - 30 % of the lanes idle; here 512 / nq row classes use all but 512 mod nq lanes.
+        // (Rows wider than 2048 pixels fall back to several groups per lane.)
+        const int RC = max(1, __builtin_amdgcn_readfirstlane((int)(512.5f * __builtin_amdgcn_rcpf((float)nq))));
+        const int t = otid();
+        const int rc = nq >= PF_NT ? 0 : (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)nq));
+        for (int q = q0 + (t - rc * nq); q < q1 && rc < RC; q += PF_NT) {
             int ca[4], wa[4], wb[4];
             bool ok[4];
 #pragma unroll
@@ -472,12 +480,12 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
                 wb[j] = e.y >> 16;
             }
             const bool full = ok[0] && ok[3];
-            for (int dy = dy0 + waveU; dy < dy1; dy += PF_NW) {
+#pragma nounroll
+            for (int dy = dy0 + rc; dy < dy1; dy += RC) {
                 const int2 ye = yt[dy - dy0];
-                const int yo = __builtin_amdgcn_readfirstlane(ye.x), yw = __builtin_amdgcn_readfirstlane(ye.y);
-                const int b0 = yw & 0xFFFF, b1 = (unsigned)yw >> 16;  // weights are in [0, 2048]
-                const uint8_t *r0 = tile + (yo & 0xFFFF);
-                const uint8_t *r1 = tile + ((unsigned)yo >> 16);
+                const int b0 = ye.y & 0xFFFF, b1 = (unsigned)ye.y >> 16;  // weights are in [0, 2048]
+                const uint8_t *r0 = tile + (ye.x & 0xFFFF);
+                const uint8_t *r1 = tile + ((unsigned)ye.x >> 16);
                 uint32_t packed = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -2285,17 +2293,12 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
 
     OD_STAMP(2);
     // ---- pass 2: orientation + rotation, one keypoint per lane ---------------------------------------------------
-    float angle;
-    if (tb.angleMode == 1) {
-        angle = atan2f((float)myM01, (float)myM10);
-        angle = __fadd_rn(angle, (angle < 0) ? __fmul_rn(2.0f, 3.141592f) : 0.f);
-        angle = __fmul_rn(angle, __fdiv_rn(180.0f, 3.141592f));
-    } else {
-        angle = fast_atan2_deg((float)myM01, (float)myM10);
-    }
+    const float angle = fast_atan2_deg((float)myM01, (float)myM10);
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float ar = __fmul_rn(angle, factorPI);
-    const float myA = (float)cos((double)ar), myB = (float)sin((double)ar);
+    float myA, myB;
+    if (tb.trigMode == 1) { myA = orbx_glibc_sincosf(ar, 1); myB = orbx_glibc_sincosf(ar, 0); }   // cosf / sinf (float overloads)
+    else { myA = (float)cos((double)ar); myB = (float)sin((double)ar); }                // ::cos(double), narrowed
     if (lane < cnt) kps[(size_t)f * cap + myPos].angle = angle;
 
     OD_STAMP(3);
