@@ -127,6 +127,11 @@ def test_empty_and_error_paths(pkg):
     # zero and indexes an empty vector there) -> a clean error
     with pytest.raises(pkg.OrbxError, match="aspect ratio"):
         pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=236, max_height=483)(np.zeros((483, 236), np.uint8))
+    # an image larger than the handle was created for is refused (the per-level capacities were fixed from max_width / max_height)
+    with pytest.raises(pkg.OrbxError, match="max_width x max_height"):
+        ex(np.zeros((480, 700), np.uint8))
+    with pytest.raises(pkg.OrbxError, match="trig_mode"):
+        pkg.ORBextractor(1000, 1.2, 8, 20, 7, trig_mode=2)
     img = pkg.synth_frame(1, 640, 480)
     # an extraction still works after the errors, and a smaller image re-derives the geometry
     assert len(ex(img, None, (0, 0))[1]) >= 1000
@@ -312,7 +317,15 @@ def test_quadtree_deferred_instances(pkg):
     """Candidate sets above the capacity of the level-synchronous kernel are marked and taken by the serial kernel in a
     second launch.  At VGA no set reaches the real limit (8192 keys): lower it so that the large levels are deferred while
     the small ones stay on the parallel kernel, and check full parity of the mixed result."""
-    _gpu_check_subprocess({"ORBX_QT_MAX_KEYS": "600"}, (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
+    _gpu_check_subprocess({"ORBX_QT_MAX_KEYS": "600", "ORBX_QT_MAX_KEYS2": "0"}, (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
+
+
+def test_quadtree_second_pass_instances(pkg):
+    """Sets between 8192 and 49152 keys (the large levels of 1080p frames) run in a second launch of the level-synchronous kernel
+    with a larger run-start bitmap, only what lies beyond goes to the serial kernel.  Lowered limits make all three contribute to
+    one result at VGA; the 1080p case runs the real limits."""
+    _gpu_check_subprocess({"ORBX_QT_MAX_KEYS": "500", "ORBX_QT_MAX_KEYS2": "1500"}, (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
+    _gpu_check_subprocess({}, (["1920", "1080", "4000", "2"],))
 
 
 @pytest.mark.parametrize("env", [{"ORBX_BLUR_KERNEL": "2"}, {"ORBX_BLUR_KERNEL": "1"}, {"ORBX_BLUR_WAVES": "8"}])
@@ -346,4 +359,34 @@ def test_trig_mode_parity(pkg, orc, trig_mode):
     for f in range(len(imgs)):
         assert kps[f, : n[f]].tobytes() == rk[f, : n[f]].tobytes(), f
         assert desc[f, : n[f]].tobytes() == rd[f, : n[f]].tobytes(), f
+    ex.close()
+
+
+@pytest.mark.parametrize("env", [{"ORBX_GRAPH": "0"}, {"ORBX_GRAPH": "2"}, {"ORBX_GRAPH": "1"}])
+def test_small_batch_schedules(pkg, env):
+    """Batches of up to 16 frames run a schedule of their own (quadtree of level l right behind k_pyr_fast(l) on its own branch),
+    captured once as a hipGraph and replayed per call (ORBX_GRAPH=1, default); 2 = that schedule without capture, 0 = the batch
+    schedule.  Every stage of all three must be bit-identical to the oracle."""
+    _gpu_check_subprocess(env, (["640", "480", "1000", "1"], ["752", "480", "1200", "3"], ["333", "257", "600", "2"]))
+
+
+@pytest.mark.gpu
+def test_graph_replay_and_recapture(pkg, orc):
+    """One handle, many calls (how Frame::ExtractORB drives operator()): the captured graph is replayed while the call signature
+    stays the same and re-captured when the image size, the lapping area or the batch size changes; results always equal the oracle."""
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=4)
+    ref = orc.Oracle(1000, 1.2, 8, 20, 7)
+    plan = [(640, 480, (0, 0)), (640, 480, (0, 0)), (640, 480, (0, 0)), (752, 480, (0, 0)), (752, 480, (100, 400)), (752, 480, (100, 400)),
+            (640, 480, (0, 0)), (400, 300, (0, 1000))]
+    for i, (w, h, lap) in enumerate(plan):
+        img = pkg.synth_frame(40 + i, w, h)
+        mono, kps, desc = ex(img, None, lap)
+        rmono, rk, rd = ref.extract(img, lap)
+        assert mono == rmono and kps.tobytes() == rk.tobytes() and desc.tobytes() == rd.tobytes(), (i, w, h, lap)
+    imgs = np.stack([pkg.synth_frame(70 + i, 640, 480) for i in range(3)])
+    for _ in range(2):
+        n, mono, kps, desc = ex.extract_batch(imgs, (0, 0))
+        for f in range(3):
+            rmono, rk, rd = ref.extract(imgs[f], (0, 0))
+            assert n[f] == len(rk) and kps[f, : n[f]].tobytes() == rk.tobytes() and desc[f, : n[f]].tobytes() == rd.tobytes()
     ex.close()

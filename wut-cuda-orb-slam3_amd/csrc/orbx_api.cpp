@@ -65,6 +65,8 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+#define ORBX_GRAPH_MAX_FRAMES 16  // "small batch": schedule, tile width and download path for a front end that feeds single frames
+
 struct orbx_extractor {
     orbx_params prm;
     // constructor tables (reference src/ORBextractor.cc:418-467)
@@ -105,6 +107,15 @@ struct orbx_extractor {
     std::vector<hipEvent_t> events;  // [PROF_RING][sub-batch][stage][begin, end]
     std::vector<int> profSubs;       // sub-batches recorded in each ring slot
     int profCount = 0;
+
+    // small batches (a SLAM front end calls operator() one frame at a time): the launch sequence as a captured hipGraph
+    struct GraphKey { const void *src; int nframes, w, h; long long stride, frameStride; int lap0, lap1, generation; };
+    hipGraphExec_t graphExec = nullptr;
+    GraphKey graphKey = {};
+    int generation = 0;                      // bumped whenever the geometry or a device buffer changes
+    hipStream_t qtStream[ORBX_MAX_LEVELS] = {};  // one branch per level for the quadtree instances of a small batch
+    hipEvent_t evQt[ORBX_MAX_LEVELS] = {};
+    uint8_t *h_out = nullptr; size_t h_outBytes = 0;  // pinned staging for the single-frame download
 
     // level-0 source of the last batch (for orbx_get_pyramid_level)
     const uint8_t *lastSrc = nullptr; int lastSrcPitch = 0; long long lastSrcFrameStride = 0; int lastFrames = 0;
@@ -225,6 +236,7 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     for (int i = 0; i < ORBX_MAX_LEVELS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ex->evLevel[i], hipEventDisableTiming);
     if (e != hipSuccess) { orbx_destroy(ex); return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ex->d_raw.resize(nl); ex->d_blur.resize(nl);
+    if ((e = orbxInitDevice()) != hipSuccess) { orbx_destroy(ex); return setError(ORBX_ERR_HIP, "device initialisation: %s", hipGetErrorString(e)); }
     int rc = computeGeometry(ex, p->max_width, p->max_height);
     if (rc == ORBX_OK) rc = ensureBuffers(ex);
     if (rc != ORBX_OK) { orbx_destroy(ex); return rc; }
@@ -249,6 +261,12 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i)
         if (ex->evLevel[i]) (void)hipEventDestroy(ex->evLevel[i]);
     for (auto &e : ex->events) (void)hipEventDestroy(e);
+    if (ex->graphExec) (void)hipGraphExecDestroy(ex->graphExec);
+    for (int i = 0; i < ORBX_MAX_LEVELS; ++i) {
+        if (ex->qtStream[i]) { (void)hipStreamSynchronize(ex->qtStream[i]); (void)hipStreamDestroy(ex->qtStream[i]); }
+        if (ex->evQt[i]) (void)hipEventDestroy(ex->evQt[i]);
+    }
+    if (ex->h_out) (void)hipHostFree(ex->h_out);
     ex->d_in.release();
     for (auto &b : ex->d_raw) b.release();
     for (auto &b : ex->d_blur) b.release();
@@ -296,6 +314,7 @@ extern "C" int orbx_level_sizes(const orbx_extractor *ex, int w, int h, int32_t 
 static int computeGeometry(orbx_extractor *ex, int w, int h)
 {
     if (w == ex->curW && h == ex->curH && !ex->geom.empty()) return ORBX_OK;
+    ++ex->generation;  // captured launch sequences of the old geometry are stale
     const int nl = ex->prm.nlevels;
     std::vector<OrbxLevelGeom> geom(nl);
     long long candOff = 0;
@@ -322,7 +341,10 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         const int iw = g.w - 2 * ORBX_FAST_MARGIN, ih = g.h - 2 * ORBX_FAST_MARGIN;  // corner-capable interior
         g.ncx = std::min(nCols, (iw + g.wCell - 1) / g.wCell);
         g.ncy = std::min(nRows, (ih + g.hCell - 1) / g.hCell);
-        static const int tileW = [] { const char *e = getenv("ORBX_TILE_W"); return e ? atoi(e) : 288; }();  // target interior width of a tile
+        // target interior width of a tile: wide tiles for throughput (fewer halo re-reads, less fixed cost per pixel); handles for small
+        // batches take narrow ones - a single frame is latency-bound, its launches should be many short workgroups
+        static const int tileWEnv = [] { const char *e = getenv("ORBX_TILE_W"); return e ? atoi(e) : 0; }();
+        const int tileW = tileWEnv > 0 ? tileWEnv : (ex->prm.max_batch <= ORBX_GRAPH_MAX_FRAMES ? 108 : 288);
         // cells are 35 .. 69 px high (height / nRows): beyond the usual 35 .. 40 rows keep the tile area - and with it the LDS
         // footprint - about constant
         const int tileWl = std::max(g.wCell, tileW * 40 / std::max(g.hCell, 40));
@@ -558,6 +580,137 @@ static OrbxTables makeTables(const orbx_extractor *ex)
 // themselves after all work of this batch.
 struct HostFrames { const uint8_t *imgs; ptrdiff_t stride, frameStride; };  // host-pointer API: frames still to be staged into d_imgs
 
+// ---- small batches ---------------------------------------------------------------------------------------------------
+// A SLAM front end calls operator() one frame at a time (Frame::ExtractORB, reference src/Frame.cc:430-455).  For a single frame the
+// critical path is the chain of dependent k_pyr_fast launches, then the longest quadtree instance (level 0, one wave), then pack +
+// orientation.  Small batches therefore use a schedule of their own: the quadtree of the first levels starts on the back stream as
+// soon as their candidates exist, each group on a branch of its own (ORBX_SMALL_QT_BRANCHES), and the handle's tiles are
+// narrower (computeGeometry) so that a level's launch is many short workgroups instead of a few long ones.
+// The sequence is captured once per (image size, source buffer, lapping area) as a hipGraph and replayed with one hipGraphLaunch per
+// call: launched directly, the ~30 launches and ~15 event operations of a call keep the host behind the GPU (the k_pyr_fast chain
+// stalls waiting for its next launch).  Measured (MI355X, ROCm 7.2, 640x480, device-resident call + sync): batch schedule 0.34 ms,
+// this schedule launched directly 0.33 (1 - 2 branches) / 0.41 (4 branches), replayed as a graph 0.29 / 0.275 / 0.30 ms with
+// 1 / 2 / 4 quadtree branches - more branches than two cost more in cross-queue dependencies than they overlap.
+// ORBX_GRAPH=0: batch schedule; 2: this schedule without capture (A/B runs, tools/experiments/single_frame_sweep.sh).
+
+static int smallBatchPrepare(orbx_extractor *ex)
+{
+    // the quadtree branches run concurrently: not when a quota is so large that the node arrays live in the one global scratch area
+    if (orbxQuadtreeScratchBytes(ex->prm.max_batch, ex->geom.data(), 0, ex->prm.nlevels) != 0) return 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!ex->qtStream[k] && hipStreamCreateWithFlags(&ex->qtStream[k], hipStreamNonBlocking) != hipSuccess) return 0;
+        if (!ex->evQt[k] && hipEventCreateWithFlags(&ex->evQt[k], hipEventDisableTiming) != hipSuccess) return 0;
+    }
+    return 1;
+}
+
+static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1)
+{
+    const int nl = ex->prm.nlevels;
+    hipStream_t sFront = ex->stream, sBlur = ex->stream2, sBack = ex->stream3;
+    const OrbxTables tb = makeTables(ex);
+    const int cap = ex->maxKeypoints;
+    hipError_t e;
+#define SB_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+    static const bool noBlur = getenv("ORBX_NO_BLUR") != nullptr;
+    // quadtree launches: the instance of level 0 is the longest single wave of the whole call (~150 us at VGA), level 1 the next.
+    // Default (2 branches): levels 0-1 start behind k_pyr_fast(1) on a branch of their own, the rest behind the last level on a
+    // second one (4 branches: {0}, {1}, {2, 3}, {4..}).  The branches launch the level-synchronous kernel only; the serial kernel
+    // for deferred instances (none on camera images) runs once, over all levels, after the join.
+    static const int branchEnv = [] { const char *q = getenv("ORBX_SMALL_QT_BRANCHES"); return q ? atoi(q) : 2; }();
+    int gEnd[4];  // last level of each group
+    int ng = 0;
+    if (branchEnv >= 4 && nl >= 5) { gEnd[0] = 0; gEnd[1] = 1; gEnd[2] = 3; gEnd[3] = nl - 1; ng = 4; }
+    else if (branchEnv >= 2 && nl >= 3) { gEnd[0] = 1; gEnd[1] = nl - 1; ng = 2; }
+    else { gEnd[0] = nl - 1; ng = 1; }
+    auto quadtree = [&](hipStream_t st, int l0, int run, int which) {
+        return orbxLaunchQuadtree(st, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p, ex->candFrameStride, ex->d_tileCount.p, ex->tilesPerFrame,
+                                  ex->d_scratchA.p, ex->d_scratchB.p, ex->d_sel.p, ex->selFrameStride, ex->d_selCount.p, ex->maxQuota, l0, run,
+                                  ex->d_qtNodes.p, ex->d_qtNodes.n, which);
+    };
+    int gi = 0, gBegin = 0;
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
+        const int srcPitch = l == 0 ? (int)stride : g.pitch;
+        const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
+        uint8_t *dst = nullptr; int dw = 0, dh = 0, dPitch = 0; long long dFS = 0;
+        OrbxResizeTabs tabs;
+        memset(&tabs, 0, sizeof tabs);
+        if (l + 1 < nl) {
+            const OrbxLevelGeom &d = ex->geom[l + 1];
+            dst = ex->d_raw[l + 1].p; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;
+            const int *o = &ex->tabOffsets[(size_t)l * 6];
+            tabs.xofs = ex->d_tabs.p + o[0]; tabs.xab = ex->d_tabs.p + o[1]; tabs.yofs = ex->d_tabs.p + o[2];
+            tabs.yab = ex->d_tabs.p + o[3]; tabs.rowBeg = ex->d_tabs.p + o[4]; tabs.colBeg = ex->d_tabs.p + o[5];
+        }
+        SB_TRY(orbxLaunchPyrFast(sFront, nf, g, src, srcPitch, srcFS, dst, dw, dh, dPitch, dFS, tabs, ex->d_cand.p, ex->candFrameStride,
+                                 ex->d_tileCount.p, ex->tilesPerFrame, ex->prm.ini_th_fast, ex->prm.min_th_fast));
+        if (gi < ng && l == gEnd[gi]) {
+            SB_TRY(hipEventRecord(ex->evLevel[l], sFront));
+            SB_TRY(hipStreamWaitEvent(ex->qtStream[gi], ex->evLevel[l], 0));
+            SB_TRY(quadtree(ex->qtStream[gi], gBegin, l - gBegin + 1, ORBX_QT_LEVEL_SYNC));
+            SB_TRY(hipEventRecord(ex->evQt[gi], ex->qtStream[gi]));
+            gBegin = l + 1;
+            ++gi;
+        }
+    }
+    SB_TRY(hipEventRecord(ex->evFront[0], sFront));
+    // blur stream: every level, once the pyramid exists (short kernels; they run beside the quadtree)
+    SB_TRY(hipStreamWaitEvent(sBlur, ex->evFront[0], 0));
+    for (int l = 0; l < nl && !noBlur; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        SB_TRY(orbxLaunchBlur(sBlur, nf, g.w, g.h, l == 0 ? src0 : ex->d_raw[l].p, l == 0 ? (int)stride : g.pitch,
+                              l == 0 ? (long long)frame_stride : g.frameStride, ex->d_blur[l].p, blurTilesX(g), blurFrameBytes(g), ex->taps));
+    }
+    SB_TRY(hipEventRecord(ex->evBlur[0], sBlur));
+    for (int k = 0; k < ng; ++k) SB_TRY(hipStreamWaitEvent(sBack, ex->evQt[k], 0));
+    SB_TRY(quadtree(sBack, 0, nl, ORBX_QT_SERIAL));
+    SB_TRY(orbxLaunchPack(sBack, nf, tb, ex->d_sel.p, ex->selFrameStride, ex->d_selCount.p, lap0, lap1, ex->d_kps.p, cap, ex->d_workKey.p,
+                          ex->d_workPos.p, ex->d_n.p, ex->d_mono.p));
+    SB_TRY(hipStreamWaitEvent(sBack, ex->evBlur[0], 0));
+    OrbxLevelPtrs lv;
+    memset(&lv, 0, sizeof lv);
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        lv.raw[l] = l == 0 ? src0 : ex->d_raw[l].p;
+        lv.rawPitch[l] = l == 0 ? (int)stride : g.pitch;
+        lv.rawFrameStride[l] = l == 0 ? (long long)frame_stride : g.frameStride;
+        lv.blur[l] = ex->d_blur[l].p; lv.blurPitch[l] = blurTilesX(g) * 128; lv.blurFrameStride[l] = blurFrameBytes(g);
+        lv.w[l] = g.w; lv.h[l] = g.h;
+    }
+    SB_TRY(orbxLaunchOrientDesc(sBack, nf, tb, lv, ex->d_workKey.p, ex->d_workPos.p, ex->d_n.p, ex->d_kps.p, ex->d_desc.p, cap));
+    SB_TRY(hipEventRecord(ex->evJoin, sBack));
+    SB_TRY(hipStreamWaitEvent(sFront, ex->evJoin, 0));
+#undef SB_TRY
+    return hipSuccess;
+}
+
+static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1,
+                         bool useGraph)
+{
+    if (!useGraph) { HIP_TRY(issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1)); return ORBX_OK; }
+    const orbx_extractor::GraphKey key = {src0, nf, w, h, (long long)stride, (long long)frame_stride, lap0, lap1, ex->generation};
+    if (!ex->graphExec || memcmp(&key, &ex->graphKey, sizeof key) != 0) {
+        if (ex->graphExec) { (void)hipGraphExecDestroy(ex->graphExec); ex->graphExec = nullptr; }
+        HIP_TRY(hipStreamBeginCapture(ex->stream, hipStreamCaptureModeRelaxed));
+        const hipError_t ie = issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(ex->stream, &graph);  // (always leave capture mode)
+        if (ie != hipSuccess || ce != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return setError(ORBX_ERR_HIP, "capturing the launch sequence failed: %s", hipGetErrorString(ie != hipSuccess ? ie : ce));
+        }
+        const hipError_t ge = hipGraphInstantiate(&ex->graphExec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ge != hipSuccess) { ex->graphExec = nullptr; return setError(ORBX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge)); }
+        memset(&ex->graphKey, 0, sizeof ex->graphKey);
+        ex->graphKey = key;
+    }
+    HIP_TRY(hipGraphLaunch(ex->graphExec, ex->stream));
+    return ORBX_OK;
+}
+
 static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0,
                     int lap1, const HostFrames *host);
 
@@ -573,7 +726,10 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
     if (!ex || !d_imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: null argument");
     if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
-    if (w > 4096 || h > 4096) return setError(ORBX_ERR_CAPACITY, "image %dx%d exceeds 4096", w, h);
+    // max_width / max_height are the largest image the handle will see: the per-level capacities of the selection and output buffers
+    // were fixed from them at orbx_create
+    if (w > ex->prm.max_width || h > ex->prm.max_height)
+        return setError(ORBX_ERR_CAPACITY, "image %dx%d exceeds the handle's max_width x max_height = %dx%d", w, h, ex->prm.max_width, ex->prm.max_height);
     HIP_TRY(hipSetDevice(ex->prm.device));
     int rc = computeGeometry(ex, w, h);
     if (rc != ORBX_OK) return rc;
@@ -584,6 +740,25 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
     hipStream_t sFront = ex->stream, sBlur = ex->stream2, sBack = ex->stream3;
     const OrbxTables tb = makeTables(ex);
     const int cap = ex->maxKeypoints;
+
+    // (an explicit batch-schedule switch - the A/B experiments of DESIGN 6 - keeps the batch schedule for small batches too)
+    static const int graphMode = [] {
+        if (getenv("ORBX_QT_PER_LEVEL") || getenv("ORBX_EARLY_BLUR") || getenv("ORBX_SUBBATCHES")) return 0;
+        const char *e = getenv("ORBX_GRAPH");
+        return e ? (atoi(e) == 2 ? 2 : (atoi(e) != 0)) : 1;  // 1 (default): captured graph; 2: the same schedule launched directly; 0: batch schedule
+    }();
+    if (graphMode && !ex->profiling && nframes <= ORBX_GRAPH_MAX_FRAMES && smallBatchPrepare(ex)) {
+        if (host) {  // stage the frames on the front stream, right in front of the graph
+            if (host->frameStride == host->stride * h && frame_stride == stride * h) {
+                HIP_TRY(hipMemcpy2DAsync(const_cast<void *>(d_imgs), stride, host->imgs, host->stride, w, (size_t)h * nframes, hipMemcpyHostToDevice, sFront));
+            } else {
+                for (int f = 0; f < nframes; ++f)
+                    HIP_TRY(hipMemcpy2DAsync((uint8_t *)const_cast<void *>(d_imgs) + (size_t)f * frame_stride, stride, host->imgs + (size_t)f * host->frameStride,
+                                             host->stride, w, h, hipMemcpyHostToDevice, sFront));
+            }
+        }
+        return runSmallBatch(ex, src0, nframes, w, h, stride, frame_stride, lap0, lap1, graphMode == 1);
+    }
 
     // sub-batch size: a multiple of 8 frames (one frame per XCD in flight), at least 64 frames
     static const int maxSub = [] { const char *e = getenv("ORBX_SUBBATCHES"); int v = e ? atoi(e) : 1; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
@@ -781,6 +956,37 @@ extern "C" int orbx_download_outputs(orbx_extractor *ex, int nframes, orbx_keypo
     return ORBX_OK;
 }
 
+// Small batches: everything (counts, keypoints, descriptors at full capacity) in four asynchronous copies into page-locked staging
+// and ONE synchronisation, instead of counts first and exact-size copies afterwards (two round trips).
+static int downloadSmall(orbx_extractor *ex, int nframes, orbx_keypoint *kps, uint8_t *desc, int capacity, int32_t *n_out, int32_t *mono_out)
+{
+    const int cap = ex->maxKeypoints;
+    const size_t bN = (size_t)nframes * sizeof(int32_t), bK = (size_t)nframes * cap * sizeof(orbx_keypoint), bD = (size_t)nframes * cap * 32;
+    const size_t need = 2 * bN + bK + bD + 64;
+    if (ex->h_outBytes < need) {
+        if (ex->h_out) { (void)hipHostFree(ex->h_out); ex->h_out = nullptr; ex->h_outBytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&ex->h_out, need, hipHostMallocDefault));
+        ex->h_outBytes = need;
+    }
+    int32_t *hn = (int32_t *)ex->h_out, *hm = hn + nframes;
+    orbx_keypoint *hk = (orbx_keypoint *)(ex->h_out + ((2 * bN + 15) & ~(size_t)15));
+    uint8_t *hd = (uint8_t *)(hk + (size_t)nframes * cap);
+    HIP_TRY(hipMemcpyAsync(hn, ex->d_n.p, bN, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(hm, ex->d_mono.p, bN, hipMemcpyDeviceToHost, ex->stream));
+    if (kps) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps.p, bK, hipMemcpyDeviceToHost, ex->stream));
+    if (desc) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc.p, bD, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    for (int f = 0; f < nframes; ++f)
+        if (hn[f] > capacity) return setError(ORBX_ERR_CAPACITY, "frame %d has %d keypoints, output capacity is %d", f, hn[f], capacity);
+    for (int f = 0; f < nframes; ++f) {
+        if (kps && hn[f] > 0) memcpy(kps + (size_t)f * capacity, hk + (size_t)f * cap, (size_t)hn[f] * sizeof(orbx_keypoint));
+        if (desc && hn[f] > 0) memcpy(desc + (size_t)f * capacity * 32, hd + (size_t)f * cap * 32, (size_t)hn[f] * 32);
+        if (n_out) n_out[f] = hn[f];
+        if (mono_out) mono_out[f] = hm[f];
+    }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
                                   ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
                                   int32_t *n_out, int32_t *mono_out)
@@ -788,6 +994,8 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
     if (!ex || !imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: null argument");
     if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
+    if (w > ex->prm.max_width || h > ex->prm.max_height)
+        return setError(ORBX_ERR_CAPACITY, "image %dx%d exceeds the handle's max_width x max_height = %dx%d", w, h, ex->prm.max_width, ex->prm.max_height);
     HIP_TRY(hipSetDevice(ex->prm.device));
     int rc = computeGeometry(ex, w, h);
     if (rc != ORBX_OK) return rc;
@@ -796,6 +1004,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
     const HostFrames host = {imgs, stride, frame_stride};
     rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &host);
     if (rc != ORBX_OK) return rc;
+    if (nframes <= ORBX_GRAPH_MAX_FRAMES) return downloadSmall(ex, nframes, kps, desc, capacity, n_out, mono_out);
     return orbx_download_outputs(ex, nframes, kps, desc, capacity, n_out, mono_out);
 }
 
@@ -1067,7 +1276,9 @@ static int checkFeatureVector(const int32_t *node, const int32_t *start, const i
     if (nfv == 0) return ORBX_OK;
     if (start[0] != 0 || start[nfv] > n) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector offsets outside [0, %d]", which, n);
     for (int j = 0; j < nfv; ++j) {
-        if (start[j + 1] < start[j]) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector offsets not ascending", which);
+        // a FeatureVector node holds at least one feature (std::map entries are created by push_back): strictly ascending offsets,
+        // which also bounds nfv by n - the device buffers of the node table are sized by the feature capacity
+        if (start[j + 1] <= start[j]) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector offsets not strictly ascending", which);
         if (j > 0 && node[j] <= node[j - 1]) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_bow: %s FeatureVector node ids not ascending", which);
     }
     for (int i = 0; i < start[nfv]; ++i)

@@ -211,11 +211,14 @@ hipError_t orbxLaunchBowTransform(hipStream_t st, const int *childStart, const i
     a.bowWord = bowWord; a.bowValue = bowValue; a.fvNode = fvNode; a.fvStart = fvStart; a.fvFeature = fvFeature; a.counts = counts;
     a.nPerFrame = nullptr; a.cap = 0;
     const size_t lds = (size_t)np2 * sizeof(bow_u64);
-    static size_t attrBytes = 0;
-    if (lds > 48 * 1024 && lds > attrBytes) {
+    static size_t attrBytes[64] = {};  // the attribute is per device: largest size set so far, by device ordinal
+    int devId = 0;
+    (void)hipGetDevice(&devId);
+    size_t &ab = attrBytes[devId & 63];
+    if (lds > 48 * 1024 && lds > ab) {
         const hipError_t e = hipFuncSetAttribute((const void *)k_bow_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attrBytes = lds;
+        ab = lds;
     }
     hipLaunchKernelGGL(k_bow_assemble, dim3(1), dim3(BOW_NT), lds, st, a);
     return hipGetLastError();

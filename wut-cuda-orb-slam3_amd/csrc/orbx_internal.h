@@ -74,6 +74,7 @@ struct OrbxTables {
 };
 
 // ---- kernel launchers (orbx_kernels.hip) -------------------------------------------------------------
+hipError_t orbxInitDevice();
 hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch,
                              long long srcFrameStride, uint8_t *dst, int dw, int dh, int dstPitch,
                              long long dstFrameStride, OrbxResizeTabs tabs, uint32_t *cand, long long candFrameStride,
@@ -85,7 +86,9 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
                               const OrbxLevelGeom *geomsDev, const uint32_t *cand, long long candFrameStride,
                               const int *tileCount, int tilesPerFrame, uint32_t *scratchA, uint32_t *scratchB,
                               uint32_t *sel, int selFrameStride, int *selCount, int maxQuota, int levelBase, int levelsRun,
-                              uint8_t *nodeScratch, size_t nodeScratchBytes);
+                              uint8_t *nodeScratch, size_t nodeScratchBytes, int which = 3);
+#define ORBX_QT_LEVEL_SYNC 1  // `which`: the level-synchronous kernel (first and, for large levels, second launch)
+#define ORBX_QT_SERIAL 2      //          the serial kernel for what the level-synchronous one deferred
 size_t orbxQuadtreeScratchBytes(int nframes, const OrbxLevelGeom *geomsHost, int levelBase, int levelsRun);
 hipError_t orbxLaunchPack(hipStream_t st, int nframes, OrbxTables tabs, const uint32_t *sel, int selFrameStride,
                           const int *selCount, int lap0, int lap1, void *kps, int cap, uint32_t *workKey,

@@ -1114,7 +1114,8 @@ struct QtArgs {
     int pool;     // node pool size P
     int listCap;  // capacity of list-sized arrays (max quota + 8)
     int ldsKeys;  // candidates of one instance held in LDS (0: always in global scratch)
-    int maxKeys;  // largest candidate set the level-synchronous kernel takes (<= QT3_MAX_KEYS; ORBX_QT_MAX_KEYS lowers it in tests)
+    int maxKeys;  // largest candidate set this launch of the level-synchronous kernel takes (ORBX_QT_MAX_KEYS / _KEYS2 lower it in tests)
+    int pass2;    // 1: second launch of the level-synchronous kernel - only the instances the first one deferred, larger run-start bitmap
     int nodeBytes;  // bytes of the node arrays of one instance (in LDS the keys follow)
     uint8_t *nodeScratch;  // != nullptr: node arrays in global memory, nodeBytes per instance of this launch (quotas beyond LDS)
     int variant;  // 3: level-synchronous (default), 1: serial list walk (ORBX_QT_KERNEL; also taken for > QT3_MAX_KEYS candidates)
@@ -1453,7 +1454,9 @@ __device__ __forceinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int 
 // A single wave runs these sweeps as chains of LDS round trips, so they keep several independent reads in flight: lists of
 // up to 256 nodes are handled as 4 entries per lane (loads first, then the scans), up to QT3_KCH * 64 keys stay in registers for
 // a whole pass (the scatter is then in place, in one LDS buffer), and counters advance with fire-and-forget LDS atomics.
-#define QT3_MAX_KEYS 8192  // run-start bitmap in LDS (1 KB), 16-bit key offsets; larger candidate sets take the serial formulation
+#define QT3_MAX_KEYS 8192   // first launch: run-start bitmap of 1 KB in LDS.  Larger candidate sets (levels of 1080p images) are deferred
+#define QT3_MAX_KEYS2 49152 // to a second launch of the same kernel with a 6 KB bitmap (key offsets are 16-bit, 0xFFFF is a sentinel);
+                            // beyond that - and for everything when ORBX_QT_KERNEL=1 - the serial formulation takes over
 #define QT3_KCH 32         // 64-key chunks held in registers
 
 struct Qt3 {
@@ -1464,11 +1467,11 @@ struct Qt3 {
     uint16_t *cnt[2], *beg[2]; // [L], [L + 2] keys of the node, exclusive prefix
     uint16_t *proc;            // [L] list positions of the nodes to divide, in processing order
     int *sortStack;            // [216]
-    uint32_t *starts;          // [QT3_MAX_KEYS / 32 + 2] bitmap: key e is the first key of its node
+    uint32_t *starts;          // [maxKeys / 32 + 2] bitmap: key e is the first key of its node
 };
 #define QT3_NONE 0xFFFFu
 
-static size_t qt3NodeBytes(int L) { return (((size_t)L * 46 + 8 + 216 * 4 + (QT3_MAX_KEYS / 32 + 2) * 4) + 15) & ~(size_t)15; }
+static size_t qt3NodeBytes(int L, int maxKeys = QT3_MAX_KEYS2) { return (((size_t)L * 46 + 8 + 216 * 4 + (size_t)(maxKeys / 32 + 2) * 4) + 15) & ~(size_t)15; }
 
 // A / B: key buffers.  With M <= QT3_KCH * 64 they are the same (LDS) buffer, larger sets ping-pong between two global ones.
 template <bool NG>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS
@@ -1898,6 +1901,10 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
     extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
     QtArgsK &a = *(QtArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
     int f, level, M;
+    if (a.pass2) {  // only what the first launch deferred (the common case: nothing)
+        if (!xcd_decode(a.nframes, a.levelsRun, f, level)) return;
+        if (a.selCount[(size_t)f * a.nlevels + level + a.levelBase] != QT_DEFERRED) return;
+    }
     if (!qt_instance(a, f, level, M)) return;
     const OrbxLevelGeom &g = a.geoms[level];
     uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
@@ -1967,7 +1974,7 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
                               const OrbxLevelGeom *geomsDev, const uint32_t *cand, long long candFrameStride,
                               const int *tileCount, int tilesPerFrame, uint32_t *scratchA, uint32_t *scratchB,
                               uint32_t *sel, int selFrameStride, int *selCount, int maxQuota, int levelBase, int levelsRun,
-                              uint8_t *nodeScratch, size_t nodeScratchBytes)
+                              uint8_t *nodeScratch, size_t nodeScratchBytes, int which)
 {
     QtArgs a;
     a.geoms = geomsDev;
@@ -1998,8 +2005,14 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     if (a.pool > 32767 || a.listCap > 32767) return hipErrorInvalidValue;  // node ids / list positions are 15-bit
     { static int lk = -1; if (lk < 0) { const char *e = getenv("ORBX_QT_LDS_KEYS"); lk = e ? atoi(e) : QT_LDS_KEYS; } a.ldsKeys = lk; }  // measured: 0 (13 KB per instance, 12 per CU) beats 2048 (21 KB)
     { static int v = -1; if (v < 0) { const char *e = getenv("ORBX_QT_KERNEL"); v = e ? atoi(e) : 3; } a.variant = v; }
-    { static int mk = -1; if (mk < 0) { const char *e = getenv("ORBX_QT_MAX_KEYS"); mk = e ? std::min(std::max(atoi(e), 0), QT3_MAX_KEYS) : QT3_MAX_KEYS; } a.maxKeys = mk; }
-    static bool attrSet = false;
+    static int mk = -1, mk2 = -1;
+    if (mk < 0) { const char *e = getenv("ORBX_QT_MAX_KEYS"); mk = e ? std::min(std::max(atoi(e), 0), QT3_MAX_KEYS) : QT3_MAX_KEYS; }
+    if (mk2 < 0) { const char *e = getenv("ORBX_QT_MAX_KEYS2"); mk2 = e ? std::min(std::max(atoi(e), 0), QT3_MAX_KEYS2) : QT3_MAX_KEYS2; }
+    a.maxKeys = mk; a.pass2 = 0;
+    static bool attrSetDev[64] = {};  // the attribute is per device
+    int devId = 0;
+    (void)hipGetDevice(&devId);
+    bool &attrSet = attrSetDev[devId & 63];
     if (!attrSet) {
         (void)hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_quadtree_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2008,23 +2021,33 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     const size_t tileOffBytes = (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15;  // both kernels stage the tile prefix in the node area first
     const dim3 grid(xcd_grid(nframes, levelsRun));
     const size_t ldsMax = 160 * 1024;
-    if (a.variant == 3) {
-        a.nodeBytes = (int)std::max(qt3NodeBytes(a.listCap), tileOffBytes);
-        size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
-        a.nodeScratch = nullptr;
-        if (lds > ldsMax) {  // quota too large for LDS: node arrays in the caller's scratch
-            if (!nodeScratch || nodeScratchBytes < (size_t)a.nodeBytes * nframes * levelsRun) return hipErrorInvalidValue;
-            a.nodeScratch = nodeScratch;
-            lds = 0;
+    if (a.variant == 3 && (which & ORBX_QT_LEVEL_SYNC)) {
+        // a level of the size of a VGA image never holds more than a few thousand candidates on camera images; the second launch
+        // (6 KB bitmap) is only issued where a level is large enough for > 8192 (2.5 % of the FAST region) - or in the tests
+        long long maxArea = 0;
+        for (int l = levelBase; l < levelBase + levelsRun; ++l) maxArea = std::max(maxArea, (long long)(geomsHost[l].w - 32) * (geomsHost[l].h - 32));
+        const int passes = (mk2 > mk && (maxArea / 40 > mk || mk != QT3_MAX_KEYS)) ? 2 : 1;
+        for (int pass = 0; pass < passes; ++pass) {
+            a.pass2 = pass;
+            a.maxKeys = pass ? mk2 : mk;
+            a.nodeBytes = (int)std::max(qt3NodeBytes(a.listCap, pass ? QT3_MAX_KEYS2 : QT3_MAX_KEYS), tileOffBytes);
+            size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
+            a.nodeScratch = nullptr;
+            if (lds > ldsMax) {  // quota too large for LDS: node arrays in the caller's scratch
+                if (!nodeScratch || nodeScratchBytes < (size_t)a.nodeBytes * nframes * levelsRun) return hipErrorInvalidValue;
+                a.nodeScratch = nodeScratch;
+                lds = 0;
+            }
+            if (getenv("ORBX_DEBUG")) {
+                int nb = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
+                fprintf(stderr, "[orbx] k_quadtree levels %d..%d pass %d: list %d, LDS %zu B, %d instances/CU\n", levelBase, levelBase + levelsRun - 1, pass, a.listCap, lds, nb);
+            }
+            hipLaunchKernelGGL(k_quadtree, grid, dim3(64), lds, st, a);
         }
-        if (getenv("ORBX_DEBUG")) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
-            fprintf(stderr, "[orbx] k_quadtree levels %d..%d: list %d, LDS %zu B, %d instances/CU\n", levelBase, levelBase + levelsRun - 1, a.listCap, lds, nb);
-        }
-        hipLaunchKernelGGL(k_quadtree, grid, dim3(64), lds, st, a);
+        a.pass2 = 0;
     }
-    {   // candidate sets beyond QT3_MAX_KEYS (deferred above; large images), or everything in the A/B variant
+    if ((which & ORBX_QT_SERIAL) || a.variant != 3) {   // candidate sets beyond QT3_MAX_KEYS2 (deferred above), or everything in the A/B variant
         a.nodeBytes = (int)std::max(qtNodeBytes(a.pool, a.listCap), tileOffBytes);
         size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
         a.nodeScratch = nullptr;
@@ -2377,16 +2400,28 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
     OD_STAMP(4);
 }
 
+// One-time, per-device state that needs synchronous calls (the rBRIEF pattern in constant memory, the dynamic-LDS limits): done at
+// orbx_create, never on the extraction path - a stream capture must not meet them.
+hipError_t orbxInitDevice()
+{
+    static bool done[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || done[dev]) return hipSuccess;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kOrbxPattern31, 1024);
+    if (e != hipSuccess) return e;
+    (void)hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_quadtree_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done[dev] = true;
+    return hipSuccess;
+}
+
 hipError_t orbxLaunchOrientDesc(hipStream_t st, int nframes, OrbxTables tabs, OrbxLevelPtrs lv, const uint32_t *workKey,
                                 const int *workPos, const int *nOut, void *kps, uint8_t *desc, int cap)
 {
-    static bool patternLoaded[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !patternLoaded[dev]) {
-        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kOrbxPattern31, 1024);
+    {
+        const hipError_t e = orbxInitDevice();
         if (e != hipSuccess) return e;
-        patternLoaded[dev] = true;
     }
     const int chunks = (cap + OD_WPB * OD_KPW - 1) / (OD_WPB * OD_KPW);
     hipLaunchKernelGGL(k_orient_desc, dim3(xcd_grid(nframes, chunks)), dim3(64 * OD_WPB), 0, st, tabs, lv, workKey, workPos, nOut, (OrbxKp *)kps, desc, cap,

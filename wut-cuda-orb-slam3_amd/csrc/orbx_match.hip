@@ -878,11 +878,14 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     // level0of2 = number of octave-0 keypoints of F2 (counted by the caller on its host copy), < 0: unknown
     const size_t lds = searchInitLdsBytes(n1);
     if (orbxSearchInitInLds(n1, n2, level0of2)) {
-        static size_t attrBytes = 0;  // (the kernel also has 128 B of static LDS: the dynamic part may not be set to the full 160 KB)
-        if (lds > attrBytes) {
+        static size_t attrBytes[64] = {};  // per device (the kernel also has 128 B of static LDS: the dynamic part may not be set to the full 160 KB)
+        int devId = 0;
+        (void)hipGetDevice(&devId);
+        size_t &ab = attrBytes[devId & 63];
+        if (lds > ab) {
             const hipError_t e = hipFuncSetAttribute((const void *)k_search_init_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            attrBytes = lds;
+            ab = lds;
         }
         hipLaunchKernelGGL(k_search_init_lds, dim3(1), dim3(64), lds, st, a);
     } else {
