@@ -351,6 +351,30 @@ int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left, int frame
 int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int npairs, float mb, float mbf,
                                        void *d_u_right, void *d_depth);
 
+/* void Frame::ComputeStereoFishEyeMatches() — reference src/Frame.cc:1156-1196 (fisheye stereo Frame constructor, :1078-1153), with
+ * KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:306-375).  The brute-force knnMatch runs on the lapping-area
+ * rows [mono_left, nl) x [mono_right, nr) (kNN-2 above), Lowe's ratio 0.7 selects the good matches, and each is triangulated between
+ * the two Kannala-Brandt cameras: parallax limit 0.9998, linear triangulation (null vector of the 4 x 4 system), positive depth in
+ * both cameras, reprojection error below 5.991 * sigma2[octave] in both images.
+ *   cam1 / cam2   mvParameters of mpCamera / mpCamera2: fx fy cx cy k0 k1 k2 k3;  precision = KannalaBrandt8::precision (1e-6)
+ *   R12 / t12     Frame::mRlr (row-major 3 x 3) / mtlr: x_left = R12 x_right + t12
+ *   level_sigma2  mvLevelSigma2 (orbx_get_scale_sigma_squares)
+ * Outputs: left_to_right[nl] = mvLeftToRightMatch, right_to_left[nr] = mvRightToLeftMatch, depth[nl] = mvDepth (-1: none),
+ * p3d[nl][3] = mvStereo3Dpoints (written where depth > 0).  Returns nMatches (>= 0) or a negative status.
+ * Floating point: the reference evaluates this with Eigen and libm; the restatement (operation order, double-narrowed transcendental
+ * calls, fixed Jacobi sweeps for the null vector) is documented in oracle/orb_oracle.cpp and its parity with Eigen is unpinned. */
+int orbx_compute_stereo_fisheye_matches(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int nl, int mono_left,
+                                        const orbx_keypoint *kr, const uint8_t *dr, int nr, int mono_right, const float *cam1,
+                                        const float *cam2, float precision, const float *R12, const float *t12,
+                                        const float *level_sigma2, int nlevels, int32_t *left_to_right, int32_t *right_to_left,
+                                        float *depth, float *p3d);
+/* The same for `npairs` stereo pairs in three launches on the two extractors' device-resident outputs (keypoints, descriptors, counts
+ * and monoIndex values of frame p of each handle's last batch).  Device outputs: d_left_to_right / d_depth [npairs][cap_left],
+ * d_right_to_left [npairs][cap_right], d_p3d [npairs][cap_left][3], d_nmatches [npairs]; cap = orbx_max_keypoints.  Asynchronous. */
+int orbx_compute_stereo_fisheye_matches_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int npairs, const float *cam1,
+                                               const float *cam2, float precision, const float *R12, const float *t12,
+                                               void *d_left_to_right, void *d_right_to_left, void *d_depth, void *d_p3d, void *d_nmatches);
+
 /* ---- utilities ---------------------------------------------------------------------------------- */
 
 /* Number of HIP devices (reference: Eden_resources::get_gpus_count, src/HipEdenResources/Ngpus_Ncpus.cpp). */

@@ -57,6 +57,11 @@ def lib() -> ctypes.CDLL:
                                          c_void_p, c_void_p]
         L.oracle_stereo_matches.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float,
                                             c_void_p, c_void_p]
+        L.oracle_kb8_triangulate_matches.argtypes = [c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_float,
+                                                     c_float, c_void_p]
+        L.oracle_kb8_triangulate_matches.restype = c_float
+        L.oracle_fisheye_stereo_matches.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
+                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         L.oracle_assign_grid.argtypes = [c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p]
         L.oracle_features_in_area.argtypes = [c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int,
                                               c_void_p, c_int]
@@ -337,6 +342,32 @@ def compute_image_bounds(cols, rows, k4, dist, knew4=None):
     b = np.zeros(4, np.float32)
     lib().oracle_compute_image_bounds(int(cols), int(rows), k4.ctypes.data, d.ctypes.data, len(d), kn.ctypes.data, b.ctypes.data)
     return tuple(float(v) for v in b)
+
+
+def kb8_triangulate_matches(cam1, cam2, pt1, pt2, R12, t12, sigma_level, unc, precision=1e-6):
+    """KannalaBrandt8::TriangulateMatches (reference src/CameraModels/KannalaBrandt8.cpp:306-375) -> (depth or negative code, p3D[3])."""
+    c1 = np.ascontiguousarray(cam1, np.float32); c2 = np.ascontiguousarray(cam2, np.float32)
+    R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32)
+    p = np.zeros(3, np.float32)
+    d = lib().oracle_kb8_triangulate_matches(c1.ctypes.data, c2.ctypes.data, precision, float(pt1[0]), float(pt1[1]), float(pt2[0]), float(pt2[1]),
+                                             R.ctypes.data, t.ctypes.data, float(sigma_level), float(unc), p.ctypes.data)
+    return float(d), p
+
+
+def fisheye_stereo_matches(kl, dl, mono_left, kr, dr, mono_right, cam1, cam2, R12, t12, level_sigma2, precision=1e-6):
+    """Frame::ComputeStereoFishEyeMatches (reference src/Frame.cc:1156-1196) ->
+    (nMatches, mvLeftToRightMatch[nl], mvRightToLeftMatch[nr], mvDepth[nl], mvStereo3Dpoints[nl, 3])."""
+    kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE); kr = np.ascontiguousarray(kr, KEYPOINT_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32); dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+    c1 = np.ascontiguousarray(cam1, np.float32); c2 = np.ascontiguousarray(cam2, np.float32)
+    R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32)
+    ls = np.ascontiguousarray(level_sigma2, np.float32)
+    l2r = np.full(len(kl), -1, np.int32); r2l = np.full(len(kr), -1, np.int32)
+    depth = np.full(len(kl), -1, np.float32); p3d = np.zeros((len(kl), 3), np.float32)
+    n = lib().oracle_fisheye_stereo_matches(kl.ctypes.data, dl.ctypes.data, len(kl), int(mono_left), kr.ctypes.data, dr.ctypes.data, len(kr),
+                                            int(mono_right), c1.ctypes.data, c2.ctypes.data, precision, R.ctypes.data, t.ctypes.data,
+                                            ls.ctypes.data, l2r.ctypes.data, r2l.ctypes.data, depth.ctypes.data, p3d.ctypes.data)
+    return int(n), l2r, r2l, depth, p3d
 
 
 class Vocabulary:

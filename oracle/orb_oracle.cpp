@@ -1545,6 +1545,168 @@ int oracle_search_by_bow_keyframes(const int32_t *node1, const int32_t *start1, 
 
 }  // extern "C"
 
+// =====================================================================================================================================
+// KannalaBrandt8::TriangulateMatches + Frame::ComputeStereoFishEyeMatches — reference src/CameraModels/KannalaBrandt8.cpp:306-375 (with
+// unproject :116-143, project :67-93, Triangulate :393-406) and src/Frame.cc:1156-1196 (second half).
+// PARITY UNPINNED for the floating-point part: the reference evaluates this with Eigen (float, expression templates, JacobiSVD) and the
+// platform libm (tanf / atan2f / cos / sin), neither of which exists in this image, and the reference holds no vectors for it.  What is
+// restated here, operation by operation, and what the GPU kernel reproduces bit for bit:
+//   * every +, -, *, / of the reference in float, in source order, un-fused; 3-term dot products and matrix-vector rows summed left to right;
+//   * sqrtf correctly rounded; transcendental calls as the double libm function narrowed to float ((float)tan((double)x), atan2, cos, sin);
+//     `cos(psi)` / `sin(psi)` in project() are unqualified there too: taken as ::cos(double), the product kept in double and narrowed
+//     once when it is stored into the Eigen::Vector2f (:81-82);
+//   * Eigen::JacobiSVD<Matrix4f>(A, ComputeFullV).matrixV().col(3) (:402-404) = the right singular vector of the smallest singular value.
+//     Restated as a one-sided (Hestenes) Jacobi iteration on the columns of A in DOUBLE: cyclic pairs (0,1) (0,2) (0,3) (1,2) (1,3) (2,3),
+//     exactly 12 sweeps, rotation skipped when |a_p . a_q| <= 1e-300; the column with the smallest norm (first one on ties) gives the
+//     vector, narrowed to float.  Its sign cancels in x3D = x3Dh.head(3) / x3Dh(3).
+// =====================================================================================================================================
+static void kb8Unproject(const float *P, float precision, float px, float py, float r[3])
+{
+    const float pwx = (px - P[2]) / P[0], pwy = (py - P[3]) / P[1];
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf((float)(-M_PI / 2.f), theta_d), (float)(M_PI / 2.f));
+    if ((double)theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0_theta2 = P[4] * theta2, k1_theta4 = P[5] * theta4;
+            const float k2_theta6 = P[6] * theta6, k3_theta8 = P[7] * theta8;
+            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < precision) break;
+        }
+        scale = (float)tan((double)theta) / theta_d;
+    }
+    r[0] = pwx * scale; r[1] = pwy * scale; r[2] = 1.f;
+}
+
+static void kb8Project(const float *P, const float v[3], float uv[2])
+{
+    const float x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
+    const float theta = (float)atan2((double)sqrtf(x2_plus_y2), (double)v[2]);
+    const float psi = (float)atan2((double)v[1], (double)v[0]);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + P[4] * theta3 + P[5] * theta5 + P[6] * theta7 + P[7] * theta9;
+    uv[0] = (float)((double)(P[0] * r) * cos((double)psi) + (double)P[2]);
+    uv[1] = (float)((double)(P[1] * r) * sin((double)psi) + (double)P[3]);
+}
+
+static inline float dot3f(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// right singular vector of the smallest singular value of the 4 x 4 matrix A (row-major), see the header comment
+static void smallestRightSingularVector4(const float A[16], float v[4])
+{
+    double U[4][4], V[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { U[i][j] = (double)A[i * 4 + j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 12; ++sweep)
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 4; ++i) { alpha += U[i][p] * U[i][p]; beta += U[i][q] * U[i][q]; gamma += U[i][p] * U[i][q]; }
+                if (fabs(gamma) <= 1e-300) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < 4; ++i) {
+                    const double up = U[i][p], uq = U[i][q];
+                    U[i][p] = c * up - s * uq; U[i][q] = s * up + c * uq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+                }
+            }
+    int best = 0;
+    double bestN = 0;
+    for (int j = 0; j < 4; ++j) {
+        double n = 0;
+        for (int i = 0; i < 4; ++i) n += U[i][j] * U[i][j];
+        if (j == 0 || n < bestN) { bestN = n; best = j; }
+    }
+    for (int i = 0; i < 4; ++i) v[i] = (float)V[i][best];
+}
+
+extern "C" float oracle_kb8_triangulate_matches(const float *cam1, const float *cam2, float precision, float x1, float y1, float x2, float y2,
+                                     const float *R12, const float *t12, float sigmaLevel, float unc, float *p3D)
+{
+    float r1[3], r2[3];
+    kb8Unproject(cam1, precision, x1, y1, r1);
+    kb8Unproject(cam2, precision, x2, y2, r2);
+    float r21[3];
+    for (int i = 0; i < 3; ++i) r21[i] = dot3f(R12 + 3 * i, r2);
+    const float cosParallaxRays = dot3f(r1, r21) / (sqrtf(dot3f(r1, r1)) * sqrtf(dot3f(r21, r21)));
+    if ((double)cosParallaxRays > 0.9998) return -1;
+    float R21[9], Tcw2[12];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R21[i * 3 + j] = R12[j * 3 + i];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) Tcw2[i * 4 + j] = R21[i * 3 + j];
+        const float nr[3] = {-R21[i * 3], -R21[i * 3 + 1], -R21[i * 3 + 2]};
+        Tcw2[i * 4 + 3] = dot3f(nr, t12);
+    }
+    static const float Tcw1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    float A[16];
+    for (int j = 0; j < 4; ++j) {
+        A[0 * 4 + j] = r1[0] * Tcw1[2 * 4 + j] - Tcw1[0 * 4 + j];
+        A[1 * 4 + j] = r1[1] * Tcw1[2 * 4 + j] - Tcw1[1 * 4 + j];
+        A[2 * 4 + j] = r2[0] * Tcw2[2 * 4 + j] - Tcw2[0 * 4 + j];
+        A[3 * 4 + j] = r2[1] * Tcw2[2 * 4 + j] - Tcw2[1 * 4 + j];
+    }
+    float x3Dh[4];
+    smallestRightSingularVector4(A, x3Dh);
+    const float x3D[3] = {x3Dh[0] / x3Dh[3], x3Dh[1] / x3Dh[3], x3Dh[2] / x3Dh[3]};
+    const float z1 = x3D[2];
+    if (!(z1 > 0)) return -2;   // `if (z1 <= 0)`: a NaN depth falls through there and fails `depth > 0.0001f` at the call site all the same
+    const float z2 = dot3f(R21 + 6, x3D) + Tcw2[2 * 4 + 3];
+    if (!(z2 > 0)) return -3;
+    float uv1[2];
+    kb8Project(cam1, x3D, uv1);
+    const float errX1 = uv1[0] - x1, errY1 = uv1[1] - y1;
+    if ((double)(errX1 * errX1 + errY1 * errY1) > 5.991 * (double)sigmaLevel) return -4;
+    float x3D2[3];
+    for (int i = 0; i < 3; ++i) x3D2[i] = dot3f(R21 + 3 * i, x3D) + Tcw2[i * 4 + 3];
+    float uv2[2];
+    kb8Project(cam2, x3D2, uv2);
+    const float errX2 = uv2[0] - x2, errY2 = uv2[1] - y2;
+    if ((double)(errX2 * errX2 + errY2 * errY2) > 5.991 * (double)unc) return -5;
+    p3D[0] = x3D[0]; p3D[1] = x3D[1]; p3D[2] = x3D[2];
+    return z1;
+}
+
+// Frame::ComputeStereoFishEyeMatches — reference src/Frame.cc:1156-1196.  kl / dl / nl / mono_left: mvKeys, mDescriptors, Nleft, monoLeft
+// (likewise right); level_sigma2 = mvLevelSigma2.  Outputs sized nl / nr: mvLeftToRightMatch, mvRightToLeftMatch, mvDepth, mvStereo3Dpoints
+// (3 floats per left keypoint; untouched entries are left as they were).  Returns nMatches.
+extern "C" int oracle_fisheye_stereo_matches(const oracle_keypoint *kl, const uint8_t *dl, int nl, int mono_left, const oracle_keypoint *kr,
+                                  const uint8_t *dr, int nr, int mono_right, const float *cam1, const float *cam2, float precision,
+                                  const float *R12, const float *t12, const float *level_sigma2, int32_t *left_to_right,
+                                  int32_t *right_to_left, float *depth, float *p3d)
+{
+    for (int i = 0; i < nl; ++i) { left_to_right[i] = -1; depth[i] = -1.0f; }
+    for (int i = 0; i < nr; ++i) right_to_left[i] = -1;
+    const int nq = nl - mono_left, nt = nr - mono_right;
+    if (nq <= 0) return 0;
+    std::vector<int32_t> idx((size_t)nq * 2), dist((size_t)nq * 2);
+    oracle_knn2(dl + (size_t)mono_left * 32, nq, dr + (size_t)mono_right * 32, std::max(nt, 0), idx.data(), dist.data());
+    int nMatches = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (idx[2 * i + 1] < 0) continue;                                                  // (*it).size() >= 2
+        if (!((double)(float)dist[2 * i] < (double)(float)dist[2 * i + 1] * 0.7)) continue;  // Lowe's ratio, DMatch::distance is float
+        const int iL = i + mono_left, iR = idx[2 * i] + mono_right;  // queryIdx / trainIdx are relative to the rowRange
+        const float sigma1 = level_sigma2[kl[iL].octave], sigma2 = level_sigma2[kr[iR].octave];
+        float p[3];
+        const float d = oracle_kb8_triangulate_matches(cam1, cam2, precision, kl[iL].x, kl[iL].y, kr[iR].x, kr[iR].y, R12, t12, sigma1, sigma2, p);
+        if (d > 0.0001f) {
+            left_to_right[iL] = iR;
+            right_to_left[iR] = iL;
+            p3d[3 * iL] = p[0]; p3d[3 * iL + 1] = p[1]; p3d[3 * iL + 2] = p[2];
+            depth[iL] = d;
+            nMatches++;
+        }
+    }
+    return nMatches;
+}
+
 extern "C" {
 
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride)

@@ -137,6 +137,16 @@ int oracle_undistort_keypoints(const oracle_keypoint *kps, int n, const float *k
                                oracle_keypoint *out);
 int oracle_compute_image_bounds(int cols, int rows, const float *k4, const float *dist, int ndist, const float *knew4, float *bounds);
 
+/* KannalaBrandt8::TriangulateMatches (reference src/CameraModels/KannalaBrandt8.cpp:306-375) and Frame::ComputeStereoFishEyeMatches
+ * (src/Frame.cc:1156-1196).  cam1 / cam2 = mvParameters (fx fy cx cy k0 k1 k2 k3), precision = KannalaBrandt8::precision (1e-6),
+ * R12 (row-major 3 x 3) / t12 = Frame::mRlr / mtlr.  Floating point PARITY UNPINNED (Eigen + libm): see the comment in orb_oracle.cpp. */
+float oracle_kb8_triangulate_matches(const float *cam1, const float *cam2, float precision, float x1, float y1, float x2, float y2,
+                                     const float *R12, const float *t12, float sigmaLevel, float unc, float *p3D);
+int oracle_fisheye_stereo_matches(const oracle_keypoint *kl, const uint8_t *dl, int nl, int mono_left, const oracle_keypoint *kr,
+                                  const uint8_t *dr, int nr, int mono_right, const float *cam1, const float *cam2, float precision,
+                                  const float *R12, const float *t12, const float *level_sigma2, int32_t *left_to_right,
+                                  int32_t *right_to_left, float *depth, float *p3d);
+
 /* DBoW2 vocabulary tree as Frame::ComputeBoW uses it (src/Frame.cc:768-775 -> Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1261).
  * Nodes as loadFromTextFile builds them: node 0 = root, parent[i] < i, word ids in leaf order; scoring / weighting = the enums of
  * BowVector.h:39-56 (L1_NORM 0 .. DOT_PRODUCT 5; TF_IDF 0, TF 1, IDF 2, BINARY 3). */

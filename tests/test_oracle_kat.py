@@ -430,3 +430,52 @@ def test_oracle_trig_modes_differ_only_in_descriptors(orc):
     m1, k1, d1 = orc.Oracle(1000, 1.2, 8, 20, 7, trig_mode=1).extract(img, (0, 0))
     assert m0 == m1 and k0.tobytes() == k1.tobytes()
     assert (d0 != d1).any(axis=1).mean() < 0.02
+
+
+def test_kb8_triangulation_recovers_synthetic_points(orc):
+    """oracle_kb8_triangulate_matches against an independent double-precision numpy model of the KannalaBrandt8 rig: exact projections
+    of known 3-D points triangulate back to them (depth = z in the left camera), noisy / swapped observations are rejected with the
+    reference's codes (src/CameraModels/KannalaBrandt8.cpp:316-371)."""
+    import fisheye_synth as fs
+    X1, uv1, uv2, R12, t12 = fs.scene(300, seed=4)
+    ok = 0
+    for i in range(len(X1)):
+        d, p = orc.kb8_triangulate_matches(fs.CAM1, fs.CAM2, uv1[i], uv2[i], R12, t12, 1.0, 1.0)
+        if d > 0:
+            ok += 1
+            assert abs(d - X1[i, 2]) < 2e-3 * X1[i, 2] + 1e-3, (i, d, X1[i])
+            assert np.allclose(p, X1[i], rtol=3e-3, atol=2e-3)
+        else:
+            assert d == -1 and np.linalg.norm(X1[i]) > 3.5        # only far points fail, on the parallax limit (cos > 0.9998 at 10 cm baseline)
+    assert ok > 200
+    # same ray in both cameras -> no parallax
+    far = np.array([[0.3, 0.2, 900.0]])
+    uvf1 = fs.project(fs.CAM1, far); uvf2 = fs.project(fs.CAM2, (far - t12) @ R12.astype(np.float64))
+    assert orc.kb8_triangulate_matches(fs.CAM1, fs.CAM2, uvf1[0], uvf2[0], R12, t12, 1.0, 1.0)[0] == -1
+    # a wrong partner: large reprojection error or a point behind a camera
+    codes = {orc.kb8_triangulate_matches(fs.CAM1, fs.CAM2, uv1[i], uv2[(i + 7) % len(uv2)], R12, t12, 1.0, 1.0)[0] for i in range(60)}
+    assert codes & {-2.0, -3.0, -4.0, -5.0}
+
+
+def test_kb8_smallest_singular_vector_matches_numpy(orc):
+    """The fixed one-sided Jacobi restatement of JacobiSVD(A).matrixV().col(3) agrees with numpy's SVD on the triangulated point."""
+    import fisheye_synth as fs
+    X1, uv1, uv2, R12, t12 = fs.scene(40, seed=9)
+    for i in range(len(X1)):
+        d, p = orc.kb8_triangulate_matches(fs.CAM1, fs.CAM2, uv1[i], uv2[i], R12, t12, 1e6, 1e6)
+        if d <= 0:
+            continue
+        # rebuild A in double from the same observations
+        def unproject(cam, uv):
+            c = cam.astype(np.float64)
+            pw = np.array([(uv[0] - c[2]) / c[0], (uv[1] - c[3]) / c[1]])
+            td = np.hypot(*pw); th = td
+            for _ in range(30):
+                th -= (th * (1 + c[4] * th**2 + c[5] * th**4 + c[6] * th**6 + c[7] * th**8) - td) / (1 + 3 * c[4] * th**2 + 5 * c[5] * th**4 + 7 * c[6] * th**6 + 9 * c[7] * th**8)
+            return pw * np.tan(th) / td
+        r1, r2 = unproject(fs.CAM1, uv1[i]), unproject(fs.CAM2, uv2[i])
+        R21 = R12.astype(np.float64).T
+        T1 = np.hstack([np.eye(3), np.zeros((3, 1))]); T2 = np.hstack([R21, (-R21 @ t12.astype(np.float64))[:, None]])
+        A = np.stack([r1[0] * T1[2] - T1[0], r1[1] * T1[2] - T1[1], r2[0] * T2[2] - T2[0], r2[1] * T2[2] - T2[1]])
+        v = np.linalg.svd(A)[2][3]
+        assert np.allclose(p, v[:3] / v[3], rtol=2e-3, atol=1e-3), i

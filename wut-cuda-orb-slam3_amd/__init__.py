@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
-    "orbx_matcher_download", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
+    "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points",
@@ -133,6 +133,10 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_match_knn2_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_compute_stereo_matches_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]
     lib.orbx_matcher_download.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.orbx_compute_stereo_fisheye_matches.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                                        c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.orbx_compute_stereo_fisheye_matches_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.orbx_match_stereo_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                            c_int, c_float, c_float, c_void_p, c_void_p]
     lib.orbx_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
@@ -419,6 +423,39 @@ class ORBmatcher:
         if not download:
             return ur, dp
         return self._download(ur), self._download(dp)
+
+    def ComputeStereoFishEyeMatches(self, kl, dl, mono_left, kr, dr, mono_right, cam1, cam2, R12, t12, level_sigma2, precision: float = 1e-6):
+        """Frame::ComputeStereoFishEyeMatches (reference src/Frame.cc:1156-1196) ->
+        (nMatches, mvLeftToRightMatch[nl], mvRightToLeftMatch[nr], mvDepth[nl], mvStereo3Dpoints[nl, 3])."""
+        kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE); kr = np.ascontiguousarray(kr, KEYPOINT_DTYPE)
+        dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32); dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+        c1 = np.ascontiguousarray(cam1, np.float32); c2 = np.ascontiguousarray(cam2, np.float32)
+        R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32)
+        ls = np.ascontiguousarray(level_sigma2, np.float32)
+        l2r = np.full(len(kl), -1, np.int32); r2l = np.full(len(kr), -1, np.int32)
+        depth = np.full(len(kl), -1, np.float32); p3d = np.zeros((len(kl), 3), np.float32)
+        n = self._lib.orbx_compute_stereo_fisheye_matches(self._h, kl.ctypes.data, dl.ctypes.data, len(kl), int(mono_left), kr.ctypes.data, dr.ctypes.data,
+                                                          len(kr), int(mono_right), c1.ctypes.data, c2.ctypes.data, precision, R.ctypes.data, t.ctypes.data,
+                                                          ls.ctypes.data, len(ls), l2r.ctypes.data, r2l.ctypes.data, depth.ctypes.data, p3d.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_compute_stereo_fisheye_matches")
+        return int(n), l2r, r2l, depth, p3d
+
+    def ComputeStereoFishEyeMatchesFrames(self, left: "ORBextractor", right: "ORBextractor", npairs: int, cam1, cam2, R12, t12, precision: float = 1e-6):
+        """The batch form on the extractors' device-resident outputs -> (nMatches[P], left_to_right[P, capL], right_to_left[P, capR],
+        depth[P, capL], p3d[P, capL, 3]) as numpy arrays."""
+        import torch
+        dev = left.device
+        c1 = np.ascontiguousarray(cam1, np.float32); c2 = np.ascontiguousarray(cam2, np.float32)
+        R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32)
+        l2r = self._dev_empty((npairs, left.capacity), torch.int32, dev); r2l = self._dev_empty((npairs, right.capacity), torch.int32, dev)
+        depth = self._dev_empty((npairs, left.capacity), torch.float32, dev); p3d = self._dev_empty((npairs, left.capacity, 3), torch.float32, dev)
+        nm = self._dev_empty((npairs,), torch.int32, dev)
+        _check(self._lib.orbx_compute_stereo_fisheye_matches_frames(self._h, left._h, right._h, npairs, c1.ctypes.data, c2.ctypes.data, precision,
+                                                                    R.ctypes.data, t.ctypes.data, c_void_p(l2r.data_ptr()), c_void_p(r2l.data_ptr()),
+                                                                    c_void_p(depth.data_ptr()), c_void_p(p3d.data_ptr()), c_void_p(nm.data_ptr())),
+               "orbx_compute_stereo_fisheye_matches_frames")
+        return self._download(nm), self._download(l2r), self._download(r2l), self._download(depth), self._download(p3d)
 
     def stereo_rows(self, kl, dl, kr, dr, n_rows: int, scale_factors, min_d: float, max_d: float):
         kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)

@@ -1669,6 +1669,100 @@ extern "C" int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extracto
     return orderExtractorsAfter(m, left, right);
 }
 
+// Frame::ComputeStereoFishEyeMatches — reference src/Frame.cc:1156-1196: knnMatch on the lapping-area rows, Lowe's ratio, TriangulateMatches
+static int fillFisheyeArgs(OrbxFisheyeArgs &a, const float *cam1, const float *cam2, float precision, const float *R12, const float *t12,
+                           const float *level_sigma2, int nlevels, const char *fn)
+{
+    if (!cam1 || !cam2 || !R12 || !t12 || !level_sigma2 || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(precision > 0))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad camera / level arguments", fn);
+    memset(&a, 0, sizeof a);
+    for (int i = 0; i < 8; ++i) { a.cam1[i] = cam1[i]; a.cam2[i] = cam2[i]; }
+    for (int i = 0; i < 9; ++i) a.R12[i] = R12[i];
+    for (int i = 0; i < 3; ++i) a.t12[i] = t12[i];
+    for (int i = 0; i < nlevels; ++i) a.sigma2[i] = level_sigma2[i];
+    a.precision = precision;
+    if (cam1[0] == 0.f || cam1[1] == 0.f || cam2[0] == 0.f || cam2[1] == 0.f) return setError(ORBX_ERR_INVALID_ARG, "%s: zero focal length", fn);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_compute_stereo_fisheye_matches(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int nl, int mono_left,
+                                                   const orbx_keypoint *kr, const uint8_t *dr, int nr, int mono_right, const float *cam1,
+                                                   const float *cam2, float precision, const float *R12, const float *t12,
+                                                   const float *level_sigma2, int nlevels, int32_t *left_to_right, int32_t *right_to_left,
+                                                   float *depth, float *p3d)
+{
+    const char *fn = "orbx_compute_stereo_fisheye_matches";
+    if (!m || nl < 0 || nr < 0 || mono_left < 0 || mono_right < 0 || mono_left > nl || mono_right > nr || (nl > 0 && (!kl || !dl || !left_to_right || !depth || !p3d)) ||
+        (nr > 0 && (!kr || !dr || !right_to_left)))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    OrbxFisheyeArgs a;
+    int rc = fillFisheyeArgs(a, cam1, cam2, precision, R12, t12, level_sigma2, nlevels, fn);
+    if (rc != ORBX_OK) return rc;
+    for (int i = 0; i < nl; ++i)
+        if (kl[i].octave < 0 || kl[i].octave >= nlevels) return setError(ORBX_ERR_INVALID_ARG, "%s: left keypoint %d has octave %d", fn, i, kl[i].octave);
+    for (int i = 0; i < nr; ++i)
+        if (kr[i].octave < 0 || kr[i].octave >= nlevels) return setError(ORBX_ERR_INVALID_ARG, "%s: right keypoint %d has octave %d", fn, i, kr[i].octave);
+    for (int i = 0; i < nl; ++i) { left_to_right[i] = -1; depth[i] = -1.0f; }
+    for (int i = 0; i < nr; ++i) right_to_left[i] = -1;
+    if (nl - mono_left <= 0) return 0;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, dl, nl, dr, nr)) != ORBX_OK) return rc;
+    if ((rc = m->d_uRight.ensure(m->maxQ)) != ORBX_OK || (rc = m->d_depth.ensure((size_t)m->maxQ * 3)) != ORBX_OK || (rc = m->d_sad.ensure(m->maxQ)) != ORBX_OK ||
+        (rc = m->d_bIdx.ensure((size_t)std::max(m->maxT, 16) + 16)) != ORBX_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    const int nq = nl - mono_left, nt = nr - mono_right;
+    if ((rc = knn2Launch(m, 1, m->d_q.p + (size_t)mono_left * 32, 0, nullptr, nullptr, nq, m->d_t.p + (size_t)mono_right * 32, 0, nullptr, nullptr, nt,
+                         m->d_idx.p, m->d_dist.p)) != ORBX_OK)
+        return rc;
+    a.kl = m->d_kl.p; a.kr = m->d_kr.p; a.nl = nl; a.nr = nr; a.monoL = mono_left; a.monoR = mono_right;
+    a.idx = m->d_idx.p; a.dist = m->d_dist.p; a.knnStride = nq;
+    a.leftToRight = m->d_sad.p; a.rightToLeft = m->d_bIdx.p; a.depth = m->d_uRight.p; a.p3d = m->d_depth.p;
+    a.outStrideL = nl; a.outStrideR = nr;
+    a.nMatches = m->d_bIdx.p + std::max(m->maxT, 16);
+    HIP_TRY(orbxLaunchFisheyeTriangulate(m->stream, &a, 1));
+    int nMatches = 0;
+    HIP_TRY(hipMemcpyAsync(left_to_right, a.leftToRight, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (nr > 0) HIP_TRY(hipMemcpyAsync(right_to_left, a.rightToLeft, (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(depth, a.depth, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(p3d, a.p3d, (size_t)nl * 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&nMatches, a.nMatches, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return nMatches;
+}
+
+extern "C" int orbx_compute_stereo_fisheye_matches_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int npairs, const float *cam1,
+                                                          const float *cam2, float precision, const float *R12, const float *t12,
+                                                          void *d_left_to_right, void *d_right_to_left, void *d_depth, void *d_p3d, void *d_nmatches)
+{
+    const char *fn = "orbx_compute_stereo_fisheye_matches_frames";
+    int rc = checkFramePairs(fn, m, left, right, npairs);
+    if (rc != ORBX_OK) return rc;
+    if (!d_left_to_right || !d_right_to_left || !d_depth || !d_p3d || !d_nmatches) return setError(ORBX_ERR_INVALID_ARG, "%s: null output", fn);
+    if (left->prm.nlevels != right->prm.nlevels) return setError(ORBX_ERR_INVALID_ARG, "%s: left / right extractors differ in levels", fn);
+    OrbxFisheyeArgs a;
+    if ((rc = fillFisheyeArgs(a, cam1, cam2, precision, R12, t12, left->sigma2.data(), left->prm.nlevels, fn)) != ORBX_OK) return rc;
+    if (npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const int capL = left->maxKeypoints, capR = right->maxKeypoints;
+    if ((rc = m->d_bIdx.ensure((size_t)npairs * capL * 2)) != ORBX_OK || (rc = m->d_bDist.ensure((size_t)npairs * capL * 2)) != ORBX_OK) return rc;
+    if ((rc = orderAfterExtractors(m, left, right)) != ORBX_OK) return rc;
+    // knnMatch(mDescriptors.rowRange(monoLeft, rows), mDescriptorsRight.rowRange(monoRight, rows), matches, 2) for every pair
+    if ((rc = knn2Launch(m, npairs, left->d_desc.p, (long long)capL * 32, left->d_n.p, left->d_mono.p, capL, right->d_desc.p, (long long)capR * 32,
+                         right->d_n.p, right->d_mono.p, capR, m->d_bIdx.p, m->d_bDist.p)) != ORBX_OK)
+        return rc;
+    a.kl = left->d_kps.p; a.kr = right->d_kps.p; a.kpStrideL = capL; a.kpStrideR = capR;
+    a.nlDev = left->d_n.p; a.nrDev = right->d_n.p; a.monoLDev = left->d_mono.p; a.monoRDev = right->d_mono.p;
+    a.nl = capL; a.nr = capR;
+    a.idx = m->d_bIdx.p; a.dist = m->d_bDist.p; a.knnStride = capL;
+    a.leftToRight = (int *)d_left_to_right; a.rightToLeft = (int *)d_right_to_left; a.depth = (float *)d_depth; a.p3d = (float *)d_p3d;
+    a.outStrideL = capL; a.outStrideR = capR;
+    a.nMatches = (int *)d_nmatches;
+    HIP_TRY(orbxLaunchFisheyeTriangulate(m->stream, &a, npairs));
+    return orderExtractorsAfter(m, left, right);
+}
+
 extern "C" int orbx_matcher_download(orbx_matcher *m, const void *d_src, void *h_dst, size_t bytes)
 {
     if (!m || (bytes > 0 && (!d_src || !h_dst))) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_download: bad argument");

@@ -137,6 +137,23 @@ hipError_t orbxLaunchBowTransformBatch(hipStream_t st, const int *childStart, co
                                        const double *weightOfNode, int L, int scoring, int weighting, const void *feat, const int *nPerFrame,
                                        int nframes, int cap, int levelsup, int *featWord, int *featNode, double *featWeight, int *bowWord,
                                        double *bowValue, int *fvNode, int *fvStart, int *fvFeature, int *counts);
+// Frame::ComputeStereoFishEyeMatches after knnMatch (orbx_match.hip); layout == FisheyeArgs there
+struct OrbxFisheyeArgs {
+    const void *kl, *kr;
+    long long kpStrideL, kpStrideR;
+    const int *nlDev, *nrDev, *monoLDev, *monoRDev;
+    int nl, nr, monoL, monoR;
+    const int *idx, *dist;
+    long long knnStride;
+    float cam1[8], cam2[8], precision;
+    float R12[9], t12[3];
+    float sigma2[ORBX_MAX_LEVELS];
+    int *leftToRight, *rightToLeft;
+    float *depth, *p3d;
+    long long outStrideL, outStrideR;
+    int *nMatches;
+};
+hipError_t orbxLaunchFisheyeTriangulate(hipStream_t st, const OrbxFisheyeArgs *args, int npairs);
 hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4);
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
                                int *items, int *cellOf);

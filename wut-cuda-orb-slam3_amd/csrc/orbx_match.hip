@@ -1167,6 +1167,207 @@ hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n,
     return hipGetLastError();
 }
 
+// =====================================================================================================================================
+// Frame::ComputeStereoFishEyeMatches (reference src/Frame.cc:1156-1196) after the brute-force knnMatch: Lowe's ratio, then
+// KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:306-375; unproject :116-143, project :67-93, Triangulate
+// :393-406) for every good match - SURVEY 8(f) rank 3.  One thread per query keypoint (= left keypoint of the lapping area), pair =
+// blockIdx.y.  Arithmetic: every float operation of the reference in source order and un-fused (this file is built with
+// -ffp-contract=off), 3-term products summed left to right, transcendental calls as the double function narrowed to float, and the
+// JacobiSVD null vector as a fixed one-sided Jacobi iteration in double (cyclic pairs, 12 sweeps) - the same restatement as
+// oracle/orb_oracle.cpp (floating-point parity with Eigen / libm is unpinned, see there).
+// mvRightToLeftMatch: the reference walks the queries in order and later matches overwrite earlier ones -> atomicMax of the left index.
+// =====================================================================================================================================
+struct FisheyeArgs {
+    const MtKp *kl, *kr;               // keypoints of pair 0 (all of them; the queries start at monoLeft / monoRight)
+    long long kpStrideL, kpStrideR;    // records between consecutive pairs
+    const int *nlDev, *nrDev, *monoLDev, *monoRDev;  // per-pair counts and lapping offsets on the device, or NULL: nl, nr, monoL, monoR
+    int nl, nr, monoL, monoR;
+    const int *idx, *dist;             // kNN-2 results [pair][knnStride][2], relative to the lapping ranges
+    long long knnStride;
+    float cam1[8], cam2[8], precision;
+    float R12[9], t12[3];
+    float sigma2[ORBX_MAX_LEVELS];
+    int *leftToRight, *rightToLeft;    // [pair][outStrideL], [pair][outStrideR]
+    float *depth, *p3d;                // [pair][outStrideL], [pair][outStrideL][3]
+    long long outStrideL, outStrideR;
+    int *nMatches;                     // [pair]
+};
+
+// correctly rounded float square root: __fsqrt_rn is 1 ulp off on gfx950 (measured: 0x1.a88fb8p+0 -> 0x1.49adf4p+0 instead of
+// 0x1.49adf6p+0); the double root narrowed once is exact (53 >= 2 * 24 + 2 bits)
+__device__ __forceinline__ float fe_sqrtf(float x) { return (float)__dsqrt_rn((double)x); }
+__device__ __forceinline__ float fe_dot3(const float *a, const float *b) { return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2])); }
+
+__device__ void fe_unproject(const float *P, float precision, float px, float py, float r[3])
+{
+    const float pwx = __fdiv_rn(__fsub_rn(px, P[2]), P[0]), pwy = __fdiv_rn(__fsub_rn(py, P[3]), P[1]);
+    float scale = 1.f;
+    float theta_d = fe_sqrtf(__fadd_rn(__fmul_rn(pwx, pwx), __fmul_rn(pwy, pwy)));
+    theta_d = fminf(fmaxf((float)(-3.14159265358979323846 / 2.f), theta_d), (float)(3.14159265358979323846 / 2.f));
+    if ((double)theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = __fmul_rn(theta, theta), theta4 = __fmul_rn(theta2, theta2), theta6 = __fmul_rn(theta4, theta2), theta8 = __fmul_rn(theta4, theta4);
+            const float k0 = __fmul_rn(P[4], theta2), k1 = __fmul_rn(P[5], theta4), k2 = __fmul_rn(P[6], theta6), k3 = __fmul_rn(P[7], theta8);
+            const float num = __fsub_rn(__fmul_rn(theta, __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(1.f, k0), k1), k2), k3)), theta_d);
+            const float den = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(1.f, __fmul_rn(3.f, k0)), __fmul_rn(5.f, k1)), __fmul_rn(7.f, k2)), __fmul_rn(9.f, k3));
+            const float theta_fix = __fdiv_rn(num, den);
+            theta = __fsub_rn(theta, theta_fix);
+            if (fabsf(theta_fix) < precision) break;
+        }
+        scale = __fdiv_rn((float)tan((double)theta), theta_d);
+    }
+    r[0] = __fmul_rn(pwx, scale); r[1] = __fmul_rn(pwy, scale); r[2] = 1.f;
+}
+
+__device__ void fe_project(const float *P, const float v[3], float uv[2])
+{
+    const float x2y2 = __fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1]));
+    const float theta = (float)atan2((double)fe_sqrtf(x2y2), (double)v[2]);
+    const float psi = (float)atan2((double)v[1], (double)v[0]);
+    const float t2 = __fmul_rn(theta, theta), t3 = __fmul_rn(theta, t2), t5 = __fmul_rn(t3, t2), t7 = __fmul_rn(t5, t2), t9 = __fmul_rn(t7, t2);
+    const float r = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(theta, __fmul_rn(P[4], t3)), __fmul_rn(P[5], t5)), __fmul_rn(P[6], t7)), __fmul_rn(P[7], t9));
+    uv[0] = (float)__dadd_rn(__dmul_rn((double)__fmul_rn(P[0], r), cos((double)psi)), (double)P[2]);
+    uv[1] = (float)__dadd_rn(__dmul_rn((double)__fmul_rn(P[1], r), sin((double)psi)), (double)P[3]);
+}
+
+__device__ void fe_null_vector4(const float A[16], float v[4])
+{
+    double U[4][4], V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { U[i][j] = (double)A[i * 4 + j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    alpha = __dadd_rn(alpha, __dmul_rn(U[i][p], U[i][p]));
+                    beta = __dadd_rn(beta, __dmul_rn(U[i][q], U[i][q]));
+                    gamma = __dadd_rn(gamma, __dmul_rn(U[i][p], U[i][q]));
+                }
+                if (fabs(gamma) <= 1e-300) continue;
+                const double zeta = __ddiv_rn(__dsub_rn(beta, alpha), __dmul_rn(2.0, gamma));
+                const double t = __ddiv_rn(zeta >= 0 ? 1.0 : -1.0, __dadd_rn(fabs(zeta), __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(zeta, zeta)))));
+                const double c = __ddiv_rn(1.0, __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(t, t)))), s = __dmul_rn(c, t);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double up = U[i][p], uq = U[i][q];
+                    U[i][p] = __dsub_rn(__dmul_rn(c, up), __dmul_rn(s, uq)); U[i][q] = __dadd_rn(__dmul_rn(s, up), __dmul_rn(c, uq));
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = __dsub_rn(__dmul_rn(c, vp), __dmul_rn(s, vq)); V[i][q] = __dadd_rn(__dmul_rn(s, vp), __dmul_rn(c, vq));
+                }
+            }
+    }
+    int best = 0;
+    double bestN = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n = __dadd_rn(n, __dmul_rn(U[i][j], U[i][j]));
+        if (j == 0 || n < bestN) { bestN = n; best = j; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)(best == 0 ? V[i][0] : best == 1 ? V[i][1] : best == 2 ? V[i][2] : V[i][3]);
+}
+
+__device__ float fe_triangulate(const FisheyeArgs &a, float x1, float y1, float x2, float y2, float sigmaLevel, float unc, float p3D[3])
+{
+    float r1[3], r2[3];
+    fe_unproject(a.cam1, a.precision, x1, y1, r1);
+    fe_unproject(a.cam2, a.precision, x2, y2, r2);
+    float r21[3];
+    for (int i = 0; i < 3; ++i) r21[i] = fe_dot3(a.R12 + 3 * i, r2);
+    const float cosPar = __fdiv_rn(fe_dot3(r1, r21), __fmul_rn(fe_sqrtf(fe_dot3(r1, r1)), fe_sqrtf(fe_dot3(r21, r21))));
+    if ((double)cosPar > 0.9998) return -1;
+    float R21[9], T2[12];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R21[i * 3 + j] = a.R12[j * 3 + i];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T2[i * 4 + j] = R21[i * 3 + j];
+        const float nr[3] = {-R21[i * 3], -R21[i * 3 + 1], -R21[i * 3 + 2]};
+        T2[i * 4 + 3] = fe_dot3(nr, a.t12);
+    }
+    const float T1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    float A[16];
+    for (int j = 0; j < 4; ++j) {
+        A[0 * 4 + j] = __fsub_rn(__fmul_rn(r1[0], T1[2 * 4 + j]), T1[0 * 4 + j]);
+        A[1 * 4 + j] = __fsub_rn(__fmul_rn(r1[1], T1[2 * 4 + j]), T1[1 * 4 + j]);
+        A[2 * 4 + j] = __fsub_rn(__fmul_rn(r2[0], T2[2 * 4 + j]), T2[0 * 4 + j]);
+        A[3 * 4 + j] = __fsub_rn(__fmul_rn(r2[1], T2[2 * 4 + j]), T2[1 * 4 + j]);
+    }
+    float xh[4];
+    fe_null_vector4(A, xh);
+    const float x3D[3] = {__fdiv_rn(xh[0], xh[3]), __fdiv_rn(xh[1], xh[3]), __fdiv_rn(xh[2], xh[3])};
+    const float z1 = x3D[2];
+    if (!(z1 > 0)) return -2;
+    const float z2 = __fadd_rn(fe_dot3(R21 + 6, x3D), T2[2 * 4 + 3]);
+    if (!(z2 > 0)) return -3;
+    float uv1[2];
+    fe_project(a.cam1, x3D, uv1);
+    const float ex1 = __fsub_rn(uv1[0], x1), ey1 = __fsub_rn(uv1[1], y1);
+    if ((double)__fadd_rn(__fmul_rn(ex1, ex1), __fmul_rn(ey1, ey1)) > __dmul_rn(5.991, (double)sigmaLevel)) return -4;
+    float x3D2[3];
+    for (int i = 0; i < 3; ++i) x3D2[i] = __fadd_rn(fe_dot3(R21 + 3 * i, x3D), T2[i * 4 + 3]);
+    float uv2[2];
+    fe_project(a.cam2, x3D2, uv2);
+    const float ex2 = __fsub_rn(uv2[0], x2), ey2 = __fsub_rn(uv2[1], y2);
+    if ((double)__fadd_rn(__fmul_rn(ex2, ex2), __fmul_rn(ey2, ey2)) > __dmul_rn(5.991, (double)unc)) return -5;
+    p3D[0] = x3D[0]; p3D[1] = x3D[1]; p3D[2] = x3D[2];
+    return z1;
+}
+
+__global__ __launch_bounds__(256) void k_fisheye_init(FisheyeArgs a)
+{
+    const size_t p = blockIdx.y;
+    const int nl = a.nlDev ? min(a.nlDev[p], a.nl) : a.nl, nr = a.nrDev ? min(a.nrDev[p], a.nr) : a.nr;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nl) { a.leftToRight[p * a.outStrideL + i] = -1; a.depth[p * a.outStrideL + i] = -1.0f; }
+    if (i < nr) a.rightToLeft[p * a.outStrideR + i] = -1;
+    if (i == 0) a.nMatches[p] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_fisheye_triangulate(FisheyeArgs a)
+{
+    const size_t p = blockIdx.y;
+    const int nl = a.nlDev ? min(a.nlDev[p], a.nl) : a.nl;
+    const int monoL = a.monoLDev ? a.monoLDev[p] : a.monoL, monoR = a.monoRDev ? a.monoRDev[p] : a.monoR;
+    const int i = blockIdx.x * 64 + threadIdx.x;   // query = left keypoint monoL + i
+    if (i >= nl - monoL) return;
+    const int *idx = a.idx + (p * a.knnStride + i) * 2, *dist = a.dist + (p * a.knnStride + i) * 2;
+    if (idx[1] < 0) return;                                                     // fewer than two train rows
+    if (!((double)(float)dist[0] < __dmul_rn((double)(float)dist[1], 0.7))) return;  // Lowe's ratio (:1181)
+    const int iL = i + monoL, iR = idx[0] + monoR;
+    const MtKp k1 = a.kl[p * a.kpStrideL + iL], k2 = a.kr[p * a.kpStrideR + iR];
+    float p3[3];
+    const float d = fe_triangulate(a, k1.x, k1.y, k2.x, k2.y, a.sigma2[k1.octave], a.sigma2[k2.octave], p3);
+    if (d > 0.0001f) {
+        a.leftToRight[p * a.outStrideL + iL] = iR;
+        atomicMax(&a.rightToLeft[p * a.outStrideR + iR], iL);
+        float *o = a.p3d + (p * a.outStrideL + iL) * 3;
+        o[0] = p3[0]; o[1] = p3[1]; o[2] = p3[2];
+        a.depth[p * a.outStrideL + iL] = d;
+        atomicAdd(&a.nMatches[p], 1);
+    }
+}
+
+hipError_t orbxLaunchFisheyeTriangulate(hipStream_t st, const OrbxFisheyeArgs *h, int npairs)
+{
+    if (npairs <= 0) return hipSuccess;
+    static_assert(sizeof(FisheyeArgs) == sizeof(OrbxFisheyeArgs), "host / device argument blocks differ");
+    const FisheyeArgs &a = *(const FisheyeArgs *)h;
+    const int nmax = std::max(a.nl, a.nr);
+    if (nmax <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fisheye_init, dim3((nmax + 255) / 256, npairs), dim3(256), 0, st, a);
+    if (a.nl > 0) hipLaunchKernelGGL(k_fisheye_triangulate, dim3((a.nl + 63) / 64, npairs), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
 
 // ---- ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) ---------------------------------------
 // reference src/ORBmatcher1.cc:225-427, F.Nleft == -1: features are only compared inside the vocabulary node they share (the

@@ -312,6 +312,27 @@ public:
         items.resize((size_t)placed);
     }
 
+    // Frame::ComputeStereoFishEyeMatches — reference src/Frame.cc:1156-1196 with KannalaBrandt8::TriangulateMatches
+    // (src/CameraModels/KannalaBrandt8.cpp:306-375).  camera1 / camera2 = mvParameters of mpCamera / mpCamera2 (8 floats),
+    // Rlr / tlr = mRlr (row-major) / mtlr.  Fills mvLeftToRightMatch, mvRightToLeftMatch, mvDepth, mvStereo3Dpoints; returns nMatches.
+    int ComputeStereoFishEyeMatches(const std::vector<KeyPoint> &mvKeys, const Descriptors &mDescriptors, int monoLeft,
+                                    const std::vector<KeyPoint> &mvKeysRight, const Descriptors &mDescriptorsRight, int monoRight,
+                                    const float (&camera1)[8], const float (&camera2)[8], const float (&Rlr)[9], const float (&tlr)[3],
+                                    const std::vector<float> &mvLevelSigma2, std::vector<int> &mvLeftToRightMatch, std::vector<int> &mvRightToLeftMatch,
+                                    std::vector<float> &mvDepth, std::vector<float> &mvStereo3Dpoints, float precision = 1e-6f)
+    {
+        const int nl = (int)mvKeys.size(), nr = (int)mvKeysRight.size();
+        mvLeftToRightMatch.assign((size_t)std::max(nl, 1), -1); mvRightToLeftMatch.assign((size_t)std::max(nr, 1), -1);
+        mvDepth.assign((size_t)std::max(nl, 1), -1.0f); mvStereo3Dpoints.assign((size_t)std::max(nl, 1) * 3, 0.f);
+        const int n = orbx_compute_stereo_fisheye_matches(m_, (const orbx_keypoint *)mvKeys.data(), mDescriptors.data.data(), nl, monoLeft,
+                                                          (const orbx_keypoint *)mvKeysRight.data(), mDescriptorsRight.data.data(), nr, monoRight, camera1,
+                                                          camera2, precision, Rlr, tlr, mvLevelSigma2.data(), (int)mvLevelSigma2.size(),
+                                                          mvLeftToRightMatch.data(), mvRightToLeftMatch.data(), mvDepth.data(), mvStereo3Dpoints.data());
+        if (n < 0) check(n, "ComputeStereoFishEyeMatches");
+        mvLeftToRightMatch.resize((size_t)nl); mvRightToLeftMatch.resize((size_t)nr); mvDepth.resize((size_t)nl); mvStereo3Dpoints.resize((size_t)nl * 3);
+        return n;
+    }
+
     orbx_matcher *handle() { return m_; }
 
 private:
