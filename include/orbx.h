@@ -283,6 +283,21 @@ int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const ui
                               float mbf, const orbx_projection *proj, const uint8_t *proj_desc, int np, float th, int forward,
                               int backward, int check_orientation, int32_t *assign);
 
+/* The tracker's every-frame matcher over a BATCH of frames, device-resident end to end (nothing crosses PCIe between the extractor and
+ * the match result): frame p = frame p of `ex`'s last batch; its keypoints go through Frame::UndistortKeyPoints (src/Frame.cc:777-811;
+ * k4 / dist / knew4 as in orbx_undistort_keypoints, knew4 NULL = k4), Frame::AssignFeaturesToGrid (:387-418) over [min_x, max_x) x
+ * [min_y, max_y) (orbx_compute_image_bounds, once per camera) and ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+ * (src/ORBmatcher3.cc:256-467) against the projections d_proj[p][0 .. d_np[p]) / d_proj_desc[p][..][32] of "its" last frame - device
+ * arrays with `max_np` records per frame.  d_u_right [nframes][cap] = mvuRight or NULL (monocular); d_cur_state [nframes][cap] =
+ * mvpMapPoints state before the call (-1 / 0 / 1) or NULL (all empty).  Outputs, device: d_kps_un [nframes][cap] = mvKeysUn (may be
+ * NULL), d_assign [nframes][cap] as `assign` above, d_nmatches [nframes] (-1: a search window held more than 512 candidates).
+ * cap = orbx_max_keypoints(ex).  Six launches for the whole batch, asynchronous on the matcher's stream. */
+int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
+                                     const float *knew4, float min_x, float max_x, float min_y, float max_y, float mbf,
+                                     const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_proj,
+                                     const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward, int backward,
+                                     int check_orientation, void *d_kps_un, void *d_assign, void *d_nmatches);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference
  * src/ORBmatcher1.cc:225-427 (decl include/ORBmatcher.h:62), F.Nleft == -1 / pKF->mpCamera2 == NULL; Tracking::TrackReferenceKeyFrame
  * and Relocalization.  Both FeatureVectors (pKF->mFeatVec, F.mFeatVec) as orbx_vocabulary_transform returns them: ascending node

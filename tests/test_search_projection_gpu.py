@@ -148,3 +148,42 @@ def test_search_by_projection_map_points_ratio_and_conflicts(pkg, orc):
     n, assign = m.SearchByProjectionPoints(k2[:0], d2[:0], state[:0], BOUNDS, sf, pr, dmp, 1.0, 0.8)
     assert n == 0 and len(assign) == 0
     m.close()
+
+
+@pytest.mark.parametrize("distorted,stereo", [(True, False), (False, True)])
+def test_search_by_projection_frames_batch(pkg, orc, distorted, stereo):
+    """orbx_search_by_projection_frames: extractor outputs -> UndistortKeyPoints -> grid -> SearchByProjection(Frame, Frame) for a batch of
+    frames without leaving HBM == the oracle's undistort_keypoints + search_by_projection per frame (bit-exact keypoints and assignment)."""
+    P, w, h = 5, 640, 480
+    rng = np.random.default_rng(23)
+    shifts = [(6, -4), (3, 5), (-7, 2), (0, 0), (10, 9)]
+    last = np.stack([pkg.synth_frame(600 + i, w, h) for i in range(P)])
+    cur = np.stack([np.clip(np.roll(np.roll(last[i], shifts[i][1], axis=0), shifts[i][0], axis=1).astype(np.int16)
+                            + rng.integers(-3, 4, last[i].shape, dtype=np.int16), 0, 255).astype(np.uint8) for i in range(P)])
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=P)
+    nl, _, kl, dl = ex.extract_batch(last, (0, 0))
+    kl, dl = kl.copy(), dl.copy()
+    nc, _, kc, dc = ex.extract_batch(cur, (0, 0))          # the extractor's device buffers now hold the CURRENT frames
+    sf = ex.GetScaleFactors().copy()
+    k4 = (458.654, 457.296, 367.215, 248.375)
+    dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05) if distorted else ()
+    m = pkg.ORBmatcher(4096, 4096)
+    bounds = m.ComputeImageBounds(w, h, k4, dist) if hasattr(m, "ComputeImageBounds") else orc.compute_image_bounds(w, h, k4, dist)
+    th, mbf = (7.0, 40.0) if stereo else (15.0, 0.0)
+    proj, pdesc, ur_all = [], [], np.full((P, ex.capacity), -1, np.float32)
+    for p in range(P):
+        k1 = orc.undistort_keypoints(kl[p, : nl[p]], k4, dist)
+        pr = _projections(pkg, k1, rng, shifts[p][0], shifts[p][1])
+        proj.append(pr); pdesc.append(dl[p, : nl[p]])
+        if stereo:
+            ur_all[p, : nc[p]] = np.where(rng.random(nc[p]) < 0.6, kc[p, : nc[p]]["x"] - rng.uniform(0.5, 40, nc[p]), -1)
+    nm, assign, kun = m.SearchByProjectionFrames(ex, P, k4, dist, bounds, mbf, proj, pdesc, th, u_right=ur_all if stereo else None)
+    for p in range(P):
+        rk = orc.undistort_keypoints(kc[p, : nc[p]], k4, dist)
+        assert kun[p, : nc[p]].tobytes() == rk.tobytes(), p
+        state = np.full(nc[p], -1, np.int8)
+        rn, rassign = orc.search_by_projection(rk, dc[p, : nc[p]], state, bounds, sf, proj[p], pdesc[p], th, ur_all[p, : nc[p]] if stereo else None,
+                                               mbf, False, False, True)
+        assert nm[p] == rn and np.array_equal(assign[p, : nc[p]], rassign), p
+        assert rn > 50
+    m.close(); ex.close()

@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
-    "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
+    "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_search_by_projection_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points",
@@ -133,6 +133,9 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_match_knn2_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_compute_stereo_matches_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]
     lib.orbx_matcher_download.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.orbx_search_by_projection_frames.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float,
+                                                     c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int,
+                                                     c_void_p, c_void_p, c_void_p]
     lib.orbx_compute_stereo_fisheye_matches.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                                         c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.orbx_compute_stereo_fisheye_matches_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
@@ -456,6 +459,38 @@ class ORBmatcher:
                                                                     c_void_p(depth.data_ptr()), c_void_p(p3d.data_ptr()), c_void_p(nm.data_ptr())),
                "orbx_compute_stereo_fisheye_matches_frames")
         return self._download(nm), self._download(l2r), self._download(r2l), self._download(depth), self._download(p3d)
+
+    def SearchByProjectionFrames(self, ex: "ORBextractor", nframes: int, k4, dist, bounds, mbf: float, proj, proj_desc, th: float,
+                                 forward: bool = False, backward: bool = False, checkOrientation: bool = True, u_right=None, cur_state=None,
+                                 download: bool = True):
+        """Batched, device-resident tracking matcher: UndistortKeyPoints -> AssignFeaturesToGrid -> SearchByProjection(Frame, Frame) for the
+        first `nframes` frames of the extractor's last batch.  proj[p] / proj_desc[p]: the projections of frame p (lists of arrays of
+        PROJECTION_DTYPE / [n, 32] uint8).  Returns (nmatches[P], assign[P, cap], kps_un[P, cap])."""
+        import torch
+        dev = ex.device
+        cap = ex.capacity
+        max_np = max(1, max(len(p) for p in proj))
+        hp = np.zeros((nframes, max_np), PROJECTION_DTYPE); hd = np.zeros((nframes, max_np, 32), np.uint8); hn = np.zeros(nframes, np.int32)
+        for p in range(nframes):
+            hn[p] = len(proj[p]); hp[p, : hn[p]] = proj[p]; hd[p, : hn[p]] = np.asarray(proj_desc[p], np.uint8).reshape(-1, 32)
+        d_p = torch.from_numpy(hp.view(np.uint8)).to(f"cuda:{dev}"); d_d = torch.from_numpy(hd).to(f"cuda:{dev}"); d_n = torch.from_numpy(hn).to(f"cuda:{dev}")
+        d_ur = torch.from_numpy(np.ascontiguousarray(u_right, np.float32)).to(f"cuda:{dev}") if u_right is not None else None
+        d_cs = torch.from_numpy(np.ascontiguousarray(cur_state, np.int8)).to(f"cuda:{dev}") if cur_state is not None else None
+        kun = self._dev_empty((nframes, cap * 28), torch.uint8, dev)
+        assign = self._dev_empty((nframes, cap), torch.int32, dev); nm = self._dev_empty((nframes,), torch.int32, dev)
+        k4 = np.ascontiguousarray(k4, np.float32); dist = np.ascontiguousarray(dist, np.float32).ravel()
+        torch.cuda.synchronize()
+        _check(self._lib.orbx_search_by_projection_frames(self._h, ex._h, nframes, k4.ctypes.data, dist.ctypes.data if len(dist) else None, len(dist), None,
+                                                          bounds[0], bounds[1], bounds[2], bounds[3], mbf, c_void_p(d_ur.data_ptr()) if d_ur is not None else None,
+                                                          c_void_p(d_cs.data_ptr()) if d_cs is not None else None, c_void_p(d_p.data_ptr()),
+                                                          c_void_p(d_d.data_ptr()), c_void_p(d_n.data_ptr()), max_np, th, int(forward), int(backward),
+                                                          int(checkOrientation), c_void_p(kun.data_ptr()), c_void_p(assign.data_ptr()),
+                                                          c_void_p(nm.data_ptr())), "orbx_search_by_projection_frames")
+        if not download:
+            return nm, assign, kun
+        hk = np.empty((nframes, cap), KEYPOINT_DTYPE)
+        _check(self._lib.orbx_matcher_download(self._h, c_void_p(kun.data_ptr()), hk.ctypes.data, hk.nbytes), "orbx_matcher_download")
+        return self._download(nm), self._download(assign), hk
 
     def stereo_rows(self, kl, dl, kr, dr, n_rows: int, scale_factors, min_d: float, max_d: float):
         kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)

@@ -1106,6 +1106,7 @@ struct orbx_matcher {
     DevBuf<int> d_idx, d_dist, d_mat;
     DevBuf<uint32_t> d_part;      // kNN-2: per-split partial results
     DevBuf<int> d_bIdx, d_bDist, d_bSad;  // batched stereo matching: per-pair row-band results
+    DevBuf<orbx_keypoint> d_bKps;         // batched tracking: undistorted keypoints
     hipEvent_t evWait = nullptr;  // ordering against the extractors' streams
     DevBuf<orbx_keypoint> d_kl, d_kr;
     DevBuf<float> d_scale, d_uRight, d_depth;
@@ -1148,7 +1149,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release(); m->d_part.release(); m->d_bIdx.release(); m->d_bDist.release(); m->d_bSad.release();
+    m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release(); m->d_part.release(); m->d_bIdx.release(); m->d_bDist.release(); m->d_bSad.release(); m->d_bKps.release();
     if (m->evWait) (void)hipEventDestroy(m->evWait);
     m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
     m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release(); m->d_sbpCand.release(); m->d_proj.release();
@@ -1667,6 +1668,58 @@ extern "C" int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extracto
     HIP_TRY(orbxLaunchStereoRefine(m->stream, &lv, left->d_kps.p, capL, right->d_kps.p, m->d_bIdx.p, m->d_bDist.p, mbf, minD, maxD, (float *)d_u_right,
                                    (float *)d_depth, m->d_bSad.p, &sb));
     return orderExtractorsAfter(m, left, right);
+}
+
+// Tracking::TrackWithMotionModel's matcher over a batch of frames, device-resident end to end: the extractor's keypoints ->
+// Frame::UndistortKeyPoints -> Frame::AssignFeaturesToGrid -> ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+// (reference src/Frame.cc:777-811, 387-418; src/ORBmatcher3.cc:256-467, Nleft == -1).  Frame p of the batch = frame p of the
+// extractor's last batch; the projected map points of "its" last frame come as device arrays.  Six launches for the whole batch.
+extern "C" int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
+                                                const float *knew4, float min_x, float max_x, float min_y, float max_y, float mbf,
+                                                const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_proj,
+                                                const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward, int backward,
+                                                int check_orientation, void *d_kps_un, void *d_assign, void *d_nmatches)
+{
+    const char *fn = "orbx_search_by_projection_frames";
+    if (!m || !ex) return setError(ORBX_ERR_INVALID_ARG, "%s: null handle", fn);
+    if (ex->prm.device != m->device) return setError(ORBX_ERR_INVALID_ARG, "%s: matcher and extractor must live on the same device", fn);
+    if (nframes < 0 || nframes > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "%s: %d frames, the extractor's last batch holds %d", fn, nframes, ex->lastFrames);
+    if (max_np < 0 || (max_np > 0 && (!d_proj || !d_proj_desc)) || !d_np || !d_assign || !d_nmatches || !(th >= 0.f))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    int rc = checkCamera(k4, dist, ndist, knew4 ? knew4 : k4, fn);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = checkGridBounds(min_x, max_x, min_y, max_y, fn)) != ORBX_OK) return rc;
+    const int cap = ex->maxKeypoints, nlev = ex->prm.nlevels;
+    if (cap >= 65536) return setError(ORBX_ERR_CAPACITY, "%s: at most 65535 keypoints per frame", fn);
+    if (nframes == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t F = (size_t)nframes;
+    // scratch: undistorted keypoints (unless the caller wants them), grid CSR + cellOf, candidate lists, resolve state
+    if (!d_kps_un) {
+        if ((rc = m->d_bKps.ensure(F * cap)) != ORBX_OK) return rc;
+        d_kps_un = m->d_bKps.p;
+    }
+    if ((rc = m->d_grid.ensure(F * ((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)cap))) != ORBX_OK) return rc;
+    const size_t workInts = F * (2 * (size_t)std::max(max_np, 1) + 2 * (size_t)cap + 2);
+    if ((rc = m->d_work.ensure(workInts)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure(F * (size_t)std::max(max_np, 1) * ORBX_SBP_CAP)) != ORBX_OK) return rc;
+    int *cs = m->d_grid.p, *it = cs + F * (ORBX_GRID_CELLS + 1), *co = it + F * cap;
+    int *count = m->d_work.p, *choice = count + F * std::max(max_np, 1), *owner = choice + F * std::max(max_np, 1), *result = owner + F * 2 * cap;
+    if ((rc = orderAfterExtractors(m, ex, ex)) != ORBX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p, ex->scale.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (ndist == 0 || dist[0] == 0.0)  // mvKeysUn = mvKeys (src/Frame.cc:779-783)
+        HIP_TRY(hipMemcpyAsync(d_kps_un, ex->d_kps.p, F * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToDevice, m->stream));
+    else
+        HIP_TRY(orbxLaunchUndistort(m->stream, ex->d_kps.p, d_kps_un, cap, k4, dist, ndist, knew4 ? knew4 : k4, nframes, cap, cap, ex->d_n.p));
+    HIP_TRY(orbxLaunchGridBuild(m->stream, d_kps_un, cap, min_x, max_x, min_y, max_y, cs, it, co, nframes, cap, ex->d_n.p));
+    OrbxSbpBatch b;
+    b.nframes = nframes; b.kcStride = cap; b.projStride = max_np; b.ncDev = ex->d_n.p; b.npDev = d_np;
+    HIP_TRY(orbxLaunchSearchByProjection(m->stream, d_kps_un, ex->d_desc.p, d_u_right, d_cur_state, cap, cs, it, min_x, max_x, min_y, max_y,
+                                         m->d_scale.p, mbf, d_proj, d_proj_desc, max_np, th, forward != 0, backward != 0, check_orientation != 0, 0, 0.f,
+                                         m->d_sbpCand.p, count, choice, owner, (int *)d_assign, result, &b));
+    // nmatches[p] = result[2 p]; a window with more than SBP_CAP candidates is reported as -1 for that frame
+    HIP_TRY(orbxLaunchGatherResults(m->stream, result, nframes, (int *)d_nmatches));
+    return orderExtractorsAfter(m, ex, ex);
 }
 
 // Frame::ComputeStereoFishEyeMatches — reference src/Frame.cc:1156-1196: knnMatch on the lapping-area rows, Lowe's ratio, TriangulateMatches

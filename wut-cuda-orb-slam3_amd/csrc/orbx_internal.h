@@ -154,9 +154,10 @@ struct OrbxFisheyeArgs {
     int *nMatches;
 };
 hipError_t orbxLaunchFisheyeTriangulate(hipStream_t st, const OrbxFisheyeArgs *args, int npairs);
-hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4);
+hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4,
+                               int nframes = 1, long long inStride = 0, long long outStride = 0, const int *nDev = nullptr);
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
-                               int *items, int *cellOf);
+                               int *items, int *cellOf, int nframes = 1, long long kpStride = 0, const int *nDev = nullptr);
 bool orbxSearchInitInLds(int n1, int n2, int level0of2);
 hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
                                 const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
@@ -167,7 +168,10 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
                                         const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
                                         int backward, int checkOri, int mode, float nnratio, uint32_t *cand, int *count, int *choice,
-                                        int *owner, int *assign, int *result);
+                                        int *owner, int *assign, int *result, const struct OrbxSbpBatch *batch = nullptr);
+hipError_t orbxLaunchGatherResults(hipStream_t st, const int *result, int n, int *out);
+// a batch of frames through the SearchByProjection kernels: per-frame strides (records) and device-side counts
+struct OrbxSbpBatch { int nframes; long long kcStride, projStride; const int *ncDev, *npDev; };
 #define ORBX_SBP_CAP 512  // == SBP_CAP in orbx_match.hip
 
 #endif

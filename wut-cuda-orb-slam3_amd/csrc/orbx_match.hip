@@ -449,8 +449,15 @@ __device__ __forceinline__ int mt_excl_scan(int v, int &total)  // all 64 lanes 
 
 // One wave per frame: cell = ix * GRID_ROWS + iy of every keypoint (PosInGrid: std::round, half away from zero; -1 outside),
 // counts, exclusive prefix (cellStart[GRID_CELLS + 1]) and the items of every cell in push_back order (increasing index).
-__global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBounds b, int *cellStart, int *items, int *cellOf)
+// blockIdx.x = frame of a batch: keypoints / items / cellOf advance by kpStride records, cellStart by GRID_CELLS + 1, n = nDev[frame]
+__global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBounds b, int *cellStart, int *items, int *cellOf, long long kpStride,
+                                                   const int *nDev)
 {
+    {
+        const size_t p = blockIdx.x;
+        k += p * kpStride; items += p * kpStride; cellOf += p * kpStride; cellStart += p * (GRID_CELLS + 1);
+        if (nDev) n = min(n, nDev[p]);
+    }
     __shared__ int cnt[GRID_CELLS];
     const int lane = threadIdx.x;
     for (int c = lane; c < GRID_CELLS; c += 64) cnt[c] = 0;
@@ -849,12 +856,13 @@ static size_t searchInitLdsBytes(int n1)
 }
 
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
-                               int *items, int *cellOf)
+                               int *items, int *cellOf, int nframes, long long kpStride, const int *nDev)
 {
     GridBounds b;
     b.minX = minX; b.minY = minY;
     b.invW = (float)GRID_COLS / (maxX - minX); b.invH = (float)GRID_ROWS / (maxY - minY);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(64), 0, st, (const MtKp *)k, n, b, cellStart, items, cellOf);
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_grid_build, dim3(nframes), dim3(64), 0, st, (const MtKp *)k, n, b, cellStart, items, cellOf, kpStride, nDev);
     return hipGetLastError();
 }
 
@@ -926,10 +934,28 @@ struct SbpArgs {
     int *owner;      // [2][nc] work
     int *assign;     // [nc] out
     int *result;     // [2] out: nmatches, overflow flag
+    // batch of frames (blockIdx.y of k_sbp_candidates / blockIdx.x of k_sbp_resolve): per-frame strides in records, counts on the device
+    long long kcStride, projStride;
+    const int *ncDev, *npDev;
 };
+
+// frame p of a batch: every per-frame array advances by its stride, the counts come from the device arrays
+__device__ __forceinline__ void sbp_select_frame(SbpArgs &a, size_t p)
+{
+    if (a.ncDev) a.nc = min(a.nc, a.ncDev[p]);
+    if (a.npDev) a.np = min(a.np, a.npDev[p]);
+    a.kc += p * a.kcStride; a.dc += p * a.kcStride * 32;
+    if (a.uRight) a.uRight += p * a.kcStride;
+    if (a.curState) a.curState += p * a.kcStride;
+    a.cellStart += p * (GRID_CELLS + 1); a.items += p * a.kcStride;
+    a.proj += p * a.projStride; a.dproj += p * a.projStride * 32;
+    a.cand += p * a.projStride * SBP_CAP; a.count += p * a.projStride; a.choice += p * a.projStride;
+    a.owner += p * 2 * a.kcStride; a.assign += p * a.kcStride; a.result += p * 2;
+}
 
 __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
 {
+    sbp_select_frame(a, blockIdx.y);
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= a.np) return;
     const SbpProj P = a.proj[i];
@@ -1020,6 +1046,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
 __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
 {
     const int TH_HIGH = 100, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
+    sbp_select_frame(a, blockIdx.x);
     const int tid = threadIdx.x;
     __shared__ int changed, hist[32], nAcc;
     int *own = a.owner, *ownNew = a.owner + a.nc;
@@ -1038,7 +1065,7 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
             for (int c = 0; c < n; ++c) {
                 const uint32_t e = lst[c];
                 const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
-                if (a.curState[i2] > 0 || own[i2] < i) continue;  // mvpMapPoints[i2]->Observations() > 0: before the call / taken earlier
+                if ((a.curState && a.curState[i2] > 0) || own[i2] < i) continue;  // mvpMapPoints[i2]->Observations() > 0: before the call / taken earlier
                 if (dist < best) { best2 = best; bestL2 = bestL; best = dist; bestL = lv; bestI = i2; }
                 else if (dist < best2) { best2 = dist; bestL2 = lv; }
             }
@@ -1100,9 +1127,13 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
                                         const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
                                         int backward, int checkOri, int mode, float nnratio, uint32_t *cand, int *count, int *choice,
-                                        int *owner, int *assign, int *result)
+                                        int *owner, int *assign, int *result, const OrbxSbpBatch *batch)
 {
     SbpArgs a;
+    const int nframes = batch ? batch->nframes : 1;
+    a.kcStride = batch ? batch->kcStride : 0; a.projStride = batch ? batch->projStride : 0;
+    a.ncDev = batch ? batch->ncDev : nullptr; a.npDev = batch ? batch->npDev : nullptr;
+    if (nframes <= 0) return hipSuccess;
     a.mode = mode; a.nnratio = nnratio;
     a.kc = (const MtKp *)kc; a.dc = dc; a.uRight = uRight; a.curState = curState; a.nc = nc;
     a.cellStart = cellStart; a.items = items;
@@ -1111,13 +1142,25 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
     a.scale = scale; a.mbf = mbf; a.proj = (const SbpProj *)proj; a.dproj = dproj; a.np = np;
     a.th = th; a.forward = forward; a.backward = backward; a.checkOri = checkOri;
     a.cand = cand; a.count = count; a.choice = choice; a.owner = owner; a.assign = assign; a.result = result;
-    hipError_t e = hipMemsetAsync(result, 0, 2 * sizeof(int), st);
+    hipError_t e = hipMemsetAsync(result, 0, (size_t)nframes * 2 * sizeof(int), st);
     if (e != hipSuccess) return e;
-    if (np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(np), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_sbp_resolve, dim3(1), dim3(1024), 0, st, a);
+    if (np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(np, nframes), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_sbp_resolve, dim3(nframes), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 
+
+// nmatches of a batch: result[2 p] (count) / result[2 p + 1] (candidate-list overflow) -> out[p] = count or -1
+__global__ void k_sbp_gather(const int *result, int n, int *out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = result[2 * p + 1] ? -1 : result[2 * p];
+}
+hipError_t orbxLaunchGatherResults(hipStream_t st, const int *result, int n, int *out)
+{
+    if (n > 0) hipLaunchKernelGGL(k_sbp_gather, dim3((n + 255) / 256), dim3(256), 0, st, result, n, out);
+    return hipGetLastError();
+}
 
 // ---- Frame::UndistortKeyPoints / ComputeImageBounds (reference src/Frame.cc:777-845) ----------------------------------------------
 // cv::undistortPoints with R = noArray() and P = mK: per point, in double (f64 is IEEE here and the library is built with
@@ -1127,12 +1170,19 @@ struct UndistortArgs {
     const MtKp *in;
     MtKp *out;
     int n;
+    long long inStride, outStride;  // records between the frames of a batch (blockIdx.y)
+    const int *nDev;                // per-frame counts on the device, or NULL
     double K[4], KN[4], k[12];  // fx fy cx cy (old / new), k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
 };
 
 __global__ __launch_bounds__(256) void k_undistort(UndistortArgs a)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    {
+        const size_t p = blockIdx.y;
+        a.in += p * a.inStride; a.out += p * a.outStride;
+        if (a.nDev) a.n = min(a.n, a.nDev[p]);
+    }
     if (i >= a.n) return;
     MtKp kp = a.in[i];
     const double u = (double)kp.x, v = (double)kp.y;
@@ -1156,14 +1206,16 @@ __global__ __launch_bounds__(256) void k_undistort(UndistortArgs a)
     a.out[i] = kp;
 }
 
-hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4)
+hipError_t orbxLaunchUndistort(hipStream_t st, const void *in, void *out, int n, const float *k4, const float *dist, int ndist, const float *knew4,
+                               int nframes, long long inStride, long long outStride, const int *nDev)
 {
-    if (n <= 0) return hipSuccess;
+    if (n <= 0 || nframes <= 0) return hipSuccess;
     UndistortArgs a;
     a.in = (const MtKp *)in; a.out = (MtKp *)out; a.n = n;
+    a.inStride = inStride; a.outStride = outStride; a.nDev = nDev;
     for (int i = 0; i < 4; ++i) { a.K[i] = (double)k4[i]; a.KN[i] = (double)knew4[i]; }
     for (int i = 0; i < 12; ++i) a.k[i] = i < ndist ? (double)dist[i] : 0.;
-    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256, nframes), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
