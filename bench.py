@@ -393,7 +393,9 @@ def main() -> None:
     }
     if stereo:
         out["pairs_per_s"] = round(fps / 2, 1)
-        # the matcher alone: device-resident batch call, wall-timed with a stream sync
+        # the matcher alone: device-resident batch call, wall-timed with a stream sync (on the first chunk's extraction results)
+        exl.extract_batch_device(d_left0.data_ptr(), n0, W, H, W, W * H, cfg["lap"])
+        exr.extract_batch_device(d_right0.data_ptr(), n0, W, H, W, W * H, cfg["lap"])
         match(n0); matcher.sync()
         reps = 10
         t1 = time.perf_counter()

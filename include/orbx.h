@@ -105,8 +105,9 @@ int orbx_get_inverse_scale_sigma_squares(const orbx_extractor *ex, float *out);
 /* mnFeaturesPerLevel (src/ORBextractor.cc:436-447) and umax[16] (:455-467) */
 int orbx_get_features_per_level(const orbx_extractor *ex, int32_t *out);
 int orbx_get_umax(const orbx_extractor *ex, int32_t *out16);
-/* Output capacity a caller must provide per frame: sum over levels of (quota + 3) — DistributeOctTree can
- * overshoot its quota by up to 3 (src/ORBextractor.cc:697). */
+/* Output capacity a caller must provide per frame: the sum over levels of max(quota + 3, 16, 4 * nIni) - DistributeOctTree can
+ * overshoot its quota by up to 3 (src/ORBextractor.cc:697), and its first pass splits each of the nIni = round(W / H) root nodes
+ * (:589) into four before any quota is looked at (very wide images with small quotas). */
 int orbx_max_keypoints(const orbx_extractor *ex);
 
 /* ORBextractor::operator()(image, mask (ignored), keypoints, descriptors, vLappingArea) —
