@@ -89,6 +89,7 @@ struct orbx_extractor {
     long long candFrameStride = 0;
     int tilesPerFrame = 0, selFrameStride = 0;
     std::vector<int> tabOffsets;  // per level transition: offsets into d_tabs for xofs,xab,yofs,yab,rowBeg,colBeg
+    std::vector<int> tileOffsets; // per level: offset (ints) of the OrbxPfTile records of k_pyr_fast in d_tabs
 
     // device memory
     DevBuf<uint8_t> d_in;                       // staging for host-pointer input (level 0)
@@ -447,12 +448,54 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         g.rsMaxDy = (int)roundUp(g.rsMaxDy + 1, 2);
         // strips cover [8s + 4, 8s + 12): at most (interior width + 7) / 8 + 1 strips per row, 2 groups each
         g.gqCap = (int)roundUp((size_t)2 * ((g.groupCells * g.wCell + 7) / 8 + 1) * g.hCell, 8);
-        size_t lds = (size_t)g.tileRows * g.tilePitch + (size_t)(g.hCell + 2) * g.tilePitch +
-                     (size_t)g.groupCells * g.hCell * g.wpc * 4 + 8 + (size_t)(g.rsMaxDx + g.rsMaxDy) * 8 +
-                     (size_t)g.gqCap * 2 + 1024 * 2 + (size_t)g.gqCap + roundUp(g.groupCells * g.wCell, 16);
-        g.ldsBytes = (int)roundUp(lds, 16);
+        // LDS sub-buffers: pixel tile | score tile | NMS bitmaps (zeroed together with the score tile: 16-byte multiple) | resize
+        // tables | group queue | corner queue (1024 entries) | group masks | per-column cell info
+        g.oScore = g.tileRows * g.tilePitch;
+        g.oBits = g.oScore + (g.hCell + 2) * g.tilePitch;
+        g.oXt = g.oBits + (int)roundUp((size_t)g.groupCells * g.hCell * g.wpc * 4, 16);
+        g.oYt = g.oXt + g.rsMaxDx * 8;
+        g.oGq = g.oYt + g.rsMaxDy * 8;
+        g.oCq = g.oGq + g.gqCap * 2;
+        g.oGqm = g.oCq + 1024 * 2;
+        g.oColInfo = g.oGqm + g.gqCap;
+        g.ldsBytes = (int)roundUp((size_t)g.oColInfo + roundUp(g.groupCells * g.wCell, 16), 16);
         if (g.ldsBytes > 64 * 1024)
             return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
+    }
+    // tile records of k_pyr_fast (OrbxPfTile): everything that depends only on (cell-row, cell group) of a level
+    std::vector<int> tileOffs(nl, 0);
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = geom[l];
+        while (tabs.size() % 32) tabs.push_back(0);  // 128-byte records, 128-byte aligned inside the table buffer
+        tileOffs[l] = (int)tabs.size();
+        const int *rowBeg = l + 1 < nl ? &tabs[offs[(size_t)l * 6 + 4]] : nullptr, *colBeg = l + 1 < nl ? &tabs[offs[(size_t)l * 6 + 5]] : nullptr;
+        std::vector<OrbxPfTile> recs((size_t)g.nTiles);
+        for (int crow = 0; crow < g.ncy; ++crow)
+            for (int grp = 0; grp < g.nGroups; ++grp) {
+                OrbxPfTile &t = recs[(size_t)crow * g.nGroups + grp];
+                memset(&t, 0, sizeof t);
+                const int ty0 = ORBX_FAST_MARGIN + crow * g.hCell, ty1 = std::min(ty0 + g.hCell, g.h - ORBX_FAST_MARGIN);
+                const int c0 = grp * g.groupCells, c1 = std::min(c0 + g.groupCells, g.ncx);
+                const int tx0 = ORBX_FAST_MARGIN + c0 * g.wCell, tx1 = std::min(ORBX_FAST_MARGIN + c1 * g.wCell, g.w - ORBX_FAST_MARGIN);
+                // rows / columns staged in LDS: interior + 3-px ring halo; edge tiles extend to the image border so that the tile also
+                // owns the source pixels of the next pyramid level there
+                const int ly0 = crow == 0 ? 0 : ty0 - 3, ly1 = crow == g.ncy - 1 ? g.h : ty1 + 3;
+                const int lx0 = grp == 0 ? 0 : tx0 - 3, lx1 = grp == g.nGroups - 1 ? g.w : tx1 + 3;
+                t.ty0 = ty0; t.THi = ty1 - ty0; t.ly0 = ly0; t.nRowsL = ly1 - ly0; t.rowOff = ty0 - ly0;
+                t.ax0 = lx0 & ~15; t.lx1 = lx1; t.nV = (lx1 - t.ax0 + 15) >> 4; t.nVec = t.nRowsL * t.nV;
+                t.colOf0 = 16 - t.ax0;  // PF_XO: LDS column 16 holds image column ax0
+                t.cInt0 = tx0 + t.colOf0; t.cInt1 = tx1 + t.colOf0;
+                t.nCells = c1 - c0; t.TWi = tx1 - tx0;
+                t.s0 = (t.cInt0 - 4) >> 3; t.NS = ((t.cInt1 - 1 - 4) >> 3) - t.s0 + 1;
+                t.RC = 1;
+                if (rowBeg) {
+                    t.dy0 = rowBeg[crow]; t.dy1 = rowBeg[crow + 1]; t.dx0 = colBeg[grp]; t.dx1 = colBeg[grp + 1];
+                    t.q0 = t.dx0 >> 2; t.nq = ((t.dx1 + 3) >> 2) - t.q0;
+                    t.RC = t.nq > 0 ? std::max(1, 512 / t.nq) : 1;  // resize row classes: 512 lanes over (row class, 4-pixel group)
+                }
+            }
+        const int *ri = (const int *)recs.data();
+        tabs.insert(tabs.end(), ri, ri + recs.size() * (sizeof(OrbxPfTile) / sizeof(int)));
     }
     if (tabs.empty()) tabs.push_back(0);
     (void)hipSetDevice(ex->prm.device);
@@ -465,6 +508,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
     HIP_TRY(hipMemcpy(ex->d_geom.p, geom.data(), nl * sizeof(OrbxLevelGeom), hipMemcpyHostToDevice));
     ex->geom.swap(geom);
     ex->tabOffsets.swap(offs);
+    ex->tileOffsets.swap(tileOffs);
     ex->candFrameStride = candOff;
     ex->tilesPerFrame = tileOff;
     ex->selFrameStride = selOff;
@@ -637,6 +681,7 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
         uint8_t *dst = nullptr; int dw = 0, dh = 0, dPitch = 0; long long dFS = 0;
         OrbxResizeTabs tabs;
         memset(&tabs, 0, sizeof tabs);
+        tabs.pfTiles = (const OrbxPfTile *)(ex->d_tabs.p + ex->tileOffsets[l]);
         if (l + 1 < nl) {
             const OrbxLevelGeom &d = ex->geom[l + 1];
             dst = ex->d_raw[l + 1].p; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;
@@ -814,6 +859,7 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
             uint8_t *dst = nullptr; int dw = 0, dh = 0, dPitch = 0; long long dFS = 0;
             OrbxResizeTabs tabs;
             memset(&tabs, 0, sizeof tabs);
+            tabs.pfTiles = (const OrbxPfTile *)(ex->d_tabs.p + ex->tileOffsets[l]);
             if (l + 1 < nl) {
                 const OrbxLevelGeom &d = ex->geom[l + 1];
                 dst = ex->d_raw[l + 1].p + (size_t)f0 * d.frameStride; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;

@@ -38,7 +38,31 @@ struct OrbxLevelGeom {
     int rsMaxDx, rsMaxDy;  // max destination columns / rows of the next level produced by one tile
     int gqCap;             // capacity of the pre-test group queue (2 groups per strip, all strips of the tile)
     int ldsBytes;
+    // byte offsets of the LDS sub-buffers (the pixel tile starts at 0): score tile, NMS bitmaps (directly behind the score tile: one
+    // zeroing loop), resize x / y tables, group queue, corner queue, group masks, per-column cell info
+    int oScore, oBits, oXt, oYt, oGq, oCq, oGqm, oColInfo;
 };
+
+// One tile of the fused pyramid+FAST kernel (cell-row x group of cells), built by the host per level and image size: everything
+// that depends only on the tile, so that the kernel reads it with scalar loads where it needs it instead of deriving ~40 values in
+// its prologue and keeping them live (128 B per tile).
+struct OrbxPfTile {
+    int ty0, THi;          // first interior (corner-capable) row, interior rows
+    int ly0, nRowsL;       // first staged row, staged rows (interior + 3-px halo; edge tiles reach the image border)
+    int rowOff;            // ty0 - ly0
+    int dy0, dy1;          // destination rows of the next level owned by this tile's cell-row
+    int nVec;              // 16-byte vectors of the staged tile (nRowsL * nV)
+    int cInt0, cInt1;      // LDS columns of the interior [tx0, tx1) + colOf0
+    int colOf0;            // LDS column of image column x is x + colOf0
+    int ax0, lx1;          // staged image columns [ax0, lx1), ax0 16-aligned
+    int nV;                // 16-byte vectors per staged row
+    int nCells, TWi;       // cells of the group, interior width
+    int s0, NS;            // first 8-pixel strip, number of strips (strip s covers LDS columns [8 s + 4, 8 s + 12))
+    int dx0, dx1;          // destination columns of the next level owned by this group
+    int q0, nq, RC;        // resize: first 4-pixel group of a destination row, groups, row classes (512 / nq)
+    int pad[9];
+};
+static_assert(sizeof(OrbxPfTile) == 128, "OrbxPfTile is read with aligned scalar loads");
 
 // Bilinear-resize coefficient tables for producing level l+1 from level l (OpenCV fixed point,
 // SURVEY App. A.1).  Device arrays; one set per level transition.
@@ -49,6 +73,7 @@ struct OrbxResizeTabs {
     const int *yab;    // [dh] b0 | b1 << 16
     const int *rowBeg; // [ncy + 1] first dst row owned by each cell-row of the source level
     const int *colBeg; // [nGroups + 1] first dst column owned by each column group
+    const OrbxPfTile *pfTiles;  // [nTiles] tile records of the SOURCE level (also set for the last level, which has no resize tables)
 };
 
 struct OrbxLevelPtrs {

@@ -249,6 +249,7 @@ struct PyrFastArgs {
     int *tileCount; int tilesPerFrame;
     int iniTh, minTh;
     int nframes;
+    const OrbxPfTile *tiles;  // [g.nTiles] host-built tile records of this level
     int phases;  // debug/ablation mask (ORBX_PF_PHASES): 1 resize, 2 ring test+score, 4 NMS, 8 count+emit;
                  // bits 4..7 = stop point for instruction-count profiles (tools/pmc_phases.sh): return after 1 tile load,
                  // 2 LDS setup, 3 resize, 4 pre-test, 5 ring test, 6 score, 7 NMS (round 0)
@@ -293,409 +294,417 @@ __device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *
 // that also produced a pyramid level; read back with orbx_debug_pf_timing (tools/pf_timing.py runs a 2-level extractor)
 __device__ unsigned long long g_pfTiming[8192][16];
 extern "C" int orbx_debug_pf_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pfTiming), sizeof(g_pfTiming)); }
-#define PF_STAMP(i) do { if (blockIdx.x < 8192 && threadIdx.x == 0 && a.dst) g_pfTiming[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PF_STAMP(i) do { if (blockIdx.x < 8192 && threadIdx.x == 0 && K().dst) g_pfTiming[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PF_STAMP(i) do { } while (0)
 #endif
+// DBG: the ablation mask / stop points of PyrFastArgs::phases (ORBX_PF_PHASES) are compiled in.  They are seven more wave-uniform
+// conditions that stay live through the FAST rounds (14 SGPRs, all spilled), so the production instance is built without them.
+template <bool DBG>
 __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    // The argument block is read in place from the kernarg segment (constant address space), field by field where it is
-    // used: as a by-value parameter all ~60 dwords are loaded in the prologue and then live (spilled to VGPR lanes at the
-    // 80-SGPR budget that 8 waves/SIMD allows) for the whole kernel.
+    // Scalars are kept PER PHASE.  The kernel has four phases (stage, resize, FAST rounds, emission) and ~60 wave-uniform values
+    // (tile geometry, LDS sub-buffer offsets, loop bounds); with all of them computed in the prologue and live to the end the
+    // 80-SGPR budget that 8 waves / SIMD leaves spilled ~50 of them to VGPR lanes - v_writelane / v_readlane are VALU
+    // instructions, ~8 % of this VALU-bound kernel.  So: the geometry of a tile is a host-built record (OrbxPfTile, one per tile of
+    // the level) and the argument block stays in the kernarg segment; every phase reads what it needs from both through pointers
+    // the compiler cannot look through (`K()`, `T()`), with scalar loads, into registers that die with the phase.
     typedef const __attribute__((address_space(4))) PyrFastArgs KArgs;
-    KArgs &a = *(KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    const __attribute__((address_space(4))) OrbxLevelGeom &g = a.g;
+    typedef const __attribute__((address_space(4))) OrbxPfTile TileK;
+    auto K = [&]() -> KArgs & { KArgs *p = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return *p; };
     int f, tileId;
     PF_STAMP(0);
-    if (!xcd_decode(a.nframes, g.nTiles, f, tileId)) return;
-    const int crow = tileId / g.nGroups, grp = tileId - crow * g.nGroups;
+    {
+        KArgs &a = K();
+        if (!xcd_decode(a.nframes, a.g.nTiles, f, tileId)) return;
+    }
+    auto T = [&]() -> TileK & { TileK *p = (TileK *)(unsigned long long)K().tiles + tileId; asm volatile("" : "+s"(p)); return *p; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // opaque copy of the thread index: stops the compiler from hoisting every phase's per-lane address arithmetic into the
     // kernel prologue, where it was being spilled to scratch at the 64-VGPR budget needed for 4 workgroups per CU
     auto otid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
-
-    // interior (corner-capable) pixel ranges of this tile
-    const int ty0 = ORBX_FAST_MARGIN + crow * g.hCell;
-    const int ty1 = min(ty0 + g.hCell, g.h - ORBX_FAST_MARGIN);
-    const int c0 = grp * g.groupCells, c1 = min(c0 + g.groupCells, g.ncx);
-    const int nCells = c1 - c0;
-    const int tx0 = ORBX_FAST_MARGIN + c0 * g.wCell;
-    const int tx1 = min(ORBX_FAST_MARGIN + c1 * g.wCell, g.w - ORBX_FAST_MARGIN);
-    const int THi = ty1 - ty0, TWi = tx1 - tx0;
-    // rows / columns staged in LDS: interior + 3-px ring halo; edge tiles extend to the image border so the
-    // tile also owns the source pixels of the next pyramid level there
-    const int ly0 = crow == 0 ? 0 : ty0 - 3, ly1 = crow == g.ncy - 1 ? g.h : ty1 + 3;
-    const int lx0 = grp == 0 ? 0 : tx0 - 3, lx1 = grp == g.nGroups - 1 ? g.w : tx1 + 3;
-    const int ax0 = lx0 & ~15;
-    const int tp = g.tilePitch;
-    const int colOf0 = PF_XO - ax0;             // LDS column of image column x is x + colOf0
-    const int cInt0 = tx0 + colOf0, cInt1 = tx1 + colOf0;
-
-    uint8_t *tile = lds;                                              // tileRows x tp
-    uint8_t *score = tile + (size_t)g.tileRows * tp;                  // (hCell + 2) x tp, same column indexing
-    uint32_t *bits = (uint32_t *)(score + (size_t)(g.hCell + 2) * tp); // [cell][row][wpc] NMS survivors
-    const int wpc = g.wpc;
-    const int cellWords = g.hCell * wpc;
-    int2 *xt = (int2 *)(bits + (((size_t)g.groupCells * cellWords + 1) & ~(size_t)1));  // resize x table of this tile's dst columns
-    int2 *yt = xt + g.rsMaxDx;                                        // resize y table of this tile's dst rows
-    uint16_t *gq = (uint16_t *)(yt + g.rsMaxDy);                      // groups that passed the pre-test: row << 9 | 2 * strip + grp
-    uint16_t *cq = gq + g.gqCap;                                      // ring-test survivors: row << 9 | interior column
-    uint8_t *gqm = (uint8_t *)(cq + PF_QCAP);                         // corner mask of each queued group (overflow path)
-    uint8_t *colInfo = gqm + g.gqCap;                                 // per interior column
     __shared__ int cnt[PF_MAX_GROUP_CELLS];                 // keypoints per cell (LDS atomics in the NMS phase)
     __shared__ unsigned gqCountR[2], cqCountR[2];           // queue fill counters, one pair per round (no reset barrier)
+    // LDS sub-buffers (byte offsets computed by the host, OrbxLevelGeom::o*): tile [tileRows][tp] | score [hCell + 2][tp], same column
+    // indexing | bits [cell][row][wpc] NMS survivors | xt / yt resize tables of this tile | gq groups that passed the pre-test
+    // (row << 9 | 2 * strip + grp) | cq ring-test survivors (row << 9 | interior column) | gqm | colInfo per interior column
+    uint8_t *const tile = lds;
 
-    // ---- stage the tile: coalesced 16-byte loads of row-major image rows into LDS ------------------------
-    // The prologue has two chains of global loads - the tile, and (two levels deep) the resize tables of this tile.  Both are
-    // ISSUED first (tile vectors and table entries into registers), the LDS-only setup (zeroing, cell table) runs under
-    // their latency, and the registers go to LDS last; issued one after the other the chains cost ~2500 cycles each.
-    const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
-    const int nRowsL = ly1 - ly0;
-    const bool doResize = a.dst && (a.phases & 1);
-    int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;
-    if (doResize) {
-        dy0 = a.tabs.rowBeg[crow]; dy1 = a.tabs.rowBeg[crow + 1];
-        dx0 = a.tabs.colBeg[grp]; dx1 = a.tabs.colBeg[grp + 1];
-    }
-    const int nV = (lx1 - ax0 + 15) >> 4;
-    const float invNV = __builtin_amdgcn_rcpf((float)nV);  // 1-ulp reciprocal: the quotients below sit >= 0.5/n from an integer
-    const int nVec = nRowsL * nV;
-    uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;  // (two named registers sets: an array here ends up in scratch)
-    int tvOff0 = -1, tvOff1 = -1;
-    if (a.srcAlign == 16) {
-        const int it0 = otid(), it1 = it0 + PF_NT;
-        if (it0 < nVec) {
-            const int r = (int)(((float)it0 + 0.5f) * invNV), c = it0 - r * nV;
-            tv0 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
-            tvOff0 = r * tp + PF_XO + c * 16;
-        }
-        if (it1 < nVec) {
-            const int r = (int)(((float)it1 + 0.5f) * invNV), c = it1 - r * nV;
-            tv1 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
-            tvOff1 = r * tp + PF_XO + c * 16;
-        }
-    }
-    int xo_ = 0, xw_ = 0, yo_ = 0, yw_ = 0;  // first table entries of this thread
-    if (doResize) {
-        const int i = otid();
-        if (i < dx1 - dx0) { xo_ = a.tabs.xofs[dx0 + i]; xw_ = a.tabs.xab[dx0 + i]; }
-        if (i < dy1 - dy0) { yo_ = a.tabs.yofs[dy0 + i]; yw_ = a.tabs.yab[dy0 + i]; }
-    }
-    // zero the score tile and the per-cell NMS bitmaps (16-byte stores)
+    // ---- phase 0: stage the tile: coalesced 16-byte loads of row-major image rows into LDS ------------------------
+    // Two chains of global loads - the tile, and (two levels deep) the resize tables of this tile.  Both are ISSUED first (tile
+    // vectors and table entries into registers), the LDS-only setup (zeroing, cell table) runs under their latency, and the
+    // registers go to LDS last; issued one after the other the chains cost ~2500 cycles each.
     {
-        uint4 z = make_uint4(0, 0, 0, 0);
-        uint4 *zs = (uint4 *)score;
-        const int nz = ((g.hCell + 2) * tp) >> 4;
-#pragma nounroll
-        for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
-        const int nb = g.groupCells * cellWords;
-#pragma nounroll
-        for (int i = otid(); i < nb; i += PF_NT) bits[i] = 0;
-    }
-    if (tid < PF_MAX_GROUP_CELLS) cnt[tid] = 0;
-    if (tid < 2) { gqCountR[tid] = 0; cqCountR[tid] = 0; }
-    // per interior column: cell index | bit7 first column of its cell | bit6 last column
-    const float invWC = __builtin_amdgcn_rcpf((float)g.wCell);
-#pragma nounroll
-    for (int x = otid(); x < TWi; x += PF_NT) {
-        int cell = (int)(((float)x + 0.5f) * invWC), cx = x - cell * g.wCell;
-        int cw = min(g.wCell, TWi - cell * g.wCell);
-        colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
-    }
-    // the tile
-    if (a.srcAlign == 16) {
-        if (tvOff0 >= 0) *(uint4 *)(tile + tvOff0) = tv0;
-        if (tvOff1 >= 0) *(uint4 *)(tile + tvOff1) = tv1;
-#pragma nounroll
-        for (int it = otid() + 2 * PF_NT; it < nVec; it += PF_NT) {  // tiles of more than 1024 vectors
-            const int r = (int)(((float)it + 0.5f) * invNV);
-            const int c = it - r * nV;
-            const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
-            *(uint4 *)(tile + r * tp + PF_XO + c * 16) = v;
+        KArgs &a = K();
+        TileK &t = T();
+        const int tp = a.g.tilePitch;
+        const int ly0 = t.ly0, nRowsL = t.nRowsL, ax0 = t.ax0, nV = t.nV, nVec = t.nVec;
+        const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
+        const bool doResize = a.dst && (!DBG || (a.phases & 1));
+        const int ndx = doResize ? t.dx1 - t.dx0 : 0, ndy = doResize ? t.dy1 - t.dy0 : 0, dx0 = t.dx0, dy0 = t.dy0;
+        const float invNV = __builtin_amdgcn_rcpf((float)nV);  // 1-ulp reciprocal: the quotients below sit >= 0.5/n from an integer
+        uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;  // (two named registers sets: an array here ends up in scratch)
+        int tvOff0 = -1, tvOff1 = -1;
+        if (a.srcAlign == 16) {
+            const int it0 = otid(), it1 = it0 + PF_NT;
+            if (it0 < nVec) {
+                const int r = (int)(((float)it0 + 0.5f) * invNV), c = it0 - r * nV;
+                tv0 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+                tvOff0 = r * tp + PF_XO + c * 16;
+            }
+            if (it1 < nVec) {
+                const int r = (int)(((float)it1 + 0.5f) * invNV), c = it1 - r * nV;
+                tv1 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+                tvOff1 = r * tp + PF_XO + c * 16;
+            }
         }
-    } else if (a.srcAlign == 4) {
-        const int nDw = (lx1 - ax0 + 3) >> 2;
-#pragma nounroll
-        for (int r = wave; r < nRowsL; r += PF_NW) {
-            const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0);
-            uint32_t *trow = (uint32_t *)(tile + r * tp + PF_XO);
-#pragma nounroll
-            for (int c = otid() & 63; c < nDw; c += 64) trow[c] = srow[c];
+        int xo_ = 0, xw_ = 0, yo_ = 0, yw_ = 0;  // first table entries of this thread
+        if (doResize) {
+            const int i = otid();
+            if (i < ndx) { xo_ = a.tabs.xofs[dx0 + i]; xw_ = a.tabs.xab[dx0 + i]; }
+            if (i < ndy) { yo_ = a.tabs.yofs[dy0 + i]; yw_ = a.tabs.yab[dy0 + i]; }
         }
-    } else {
-        const int nB = lx1 - ax0;
+        // zero the score tile and the per-cell NMS bitmaps (16-byte stores; the bitmaps follow the score tile)
+        {
+            uint4 z = make_uint4(0, 0, 0, 0);
+            uint4 *zs = (uint4 *)(lds + a.g.oScore);
+            const int nz = (a.g.oXt - a.g.oScore) >> 4;
 #pragma nounroll
-        for (int r = wave; r < nRowsL; r += PF_NW) {
-            const uint8_t *srow = srcF + (size_t)(ly0 + r) * a.srcPitch + ax0;
-            uint8_t *trow = tile + r * tp + PF_XO;
-#pragma nounroll
-            for (int c = otid() & 63; c < nB; c += 64) trow[c] = srow[c];
+            for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
         }
-    }
-    PF_STAMP(1);
-    if ((a.phases >> 4) == 1) return;
-    // resize coefficient tables of this tile's destination rows / columns -> LDS
-    if (doResize) {
-        auto xEntry = [&](int sx, int w2) { return make_int2(sx + colOf0, w2); };  // the right tap is always the next LDS column: where
-                                                                                  // cv::resize clamps sx to w - 1 its weight is 0
-        auto yEntry = [&](int sy, int w2) {  // LDS byte offsets of the two source rows
-            const int sy0 = min(max(sy, 0), g.h - 1) - ly0, sy1 = min(max(sy + 1, 0), g.h - 1) - ly0;
-            return make_int2((sy0 * tp) | ((sy1 * tp) << 16), w2);
-        };
-        const int i0 = otid();
-        if (i0 < dx1 - dx0) xt[i0] = xEntry(xo_, xw_);
-        if (i0 < dy1 - dy0) yt[i0] = yEntry(yo_, yw_);
+        if (tid < PF_MAX_GROUP_CELLS) cnt[tid] = 0;
+        if (tid < 2) { gqCountR[tid] = 0; cqCountR[tid] = 0; }
+        // per interior column: cell index | bit7 first column of its cell | bit6 last column
+        {
+            uint8_t *colInfo = lds + a.g.oColInfo;
+            const int wCell = a.g.wCell, TWi = t.TWi;
+            const float invWC = __builtin_amdgcn_rcpf((float)wCell);
 #pragma nounroll
-        for (int i = i0 + PF_NT; i < dx1 - dx0; i += PF_NT) xt[i] = xEntry(a.tabs.xofs[dx0 + i], a.tabs.xab[dx0 + i]);
+            for (int x = otid(); x < TWi; x += PF_NT) {
+                int cell = (int)(((float)x + 0.5f) * invWC), cx = x - cell * wCell;
+                int cw = min(wCell, TWi - cell * wCell);
+                colInfo[x] = (uint8_t)(cell | (cx == 0 ? 0x80 : 0) | (cx == cw - 1 ? 0x40 : 0));
+            }
+        }
+        // the tile
+        if (a.srcAlign == 16) {
+            if (tvOff0 >= 0) *(uint4 *)(tile + tvOff0) = tv0;
+            if (tvOff1 >= 0) *(uint4 *)(tile + tvOff1) = tv1;
 #pragma nounroll
-        for (int i = i0 + PF_NT; i < dy1 - dy0; i += PF_NT) yt[i] = yEntry(a.tabs.yofs[dy0 + i], a.tabs.yab[dy0 + i]);
+            for (int it = otid() + 2 * PF_NT; it < nVec; it += PF_NT) {  // tiles of more than 1024 vectors
+                const int r = (int)(((float)it + 0.5f) * invNV);
+                const int c = it - r * nV;
+                const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+                *(uint4 *)(tile + r * tp + PF_XO + c * 16) = v;
+            }
+        } else if (a.srcAlign == 4) {
+            const int nDw = (t.lx1 - ax0 + 3) >> 2;
+#pragma nounroll
+            for (int r = wave; r < nRowsL; r += PF_NW) {
+                const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0);
+                uint32_t *trow = (uint32_t *)(tile + r * tp + PF_XO);
+#pragma nounroll
+                for (int c = otid() & 63; c < nDw; c += 64) trow[c] = srow[c];
+            }
+        } else {
+            const int nB = t.lx1 - ax0;
+#pragma nounroll
+            for (int r = wave; r < nRowsL; r += PF_NW) {
+                const uint8_t *srow = srcF + (size_t)(ly0 + r) * a.srcPitch + ax0;
+                uint8_t *trow = tile + r * tp + PF_XO;
+#pragma nounroll
+                for (int c = otid() & 63; c < nB; c += 64) trow[c] = srow[c];
+            }
+        }
+        PF_STAMP(1);
+        if (DBG && (a.phases >> 4) == 1) return;
+        // resize coefficient tables of this tile's destination rows / columns -> LDS
+        if (doResize) {
+            int2 *xt = (int2 *)(lds + a.g.oXt), *yt = (int2 *)(lds + a.g.oYt);
+            const int colOf0 = t.colOf0, hm1 = a.g.h - 1;
+            auto xEntry = [&](int sx, int w2) { return make_int2(sx + colOf0, w2); };  // the right tap is always the next LDS column: where
+                                                                                      // cv::resize clamps sx to w - 1 its weight is 0
+            auto yEntry = [&](int sy, int w2) {  // LDS byte offsets of the two source rows
+                const int sy0 = min(max(sy, 0), hm1) - ly0, sy1 = min(max(sy + 1, 0), hm1) - ly0;
+                return make_int2((sy0 * tp) | ((sy1 * tp) << 16), w2);
+            };
+            const int i0 = otid();
+            if (i0 < ndx) xt[i0] = xEntry(xo_, xw_);
+            if (i0 < ndy) yt[i0] = yEntry(yo_, yw_);
+#pragma nounroll
+            for (int i = i0 + PF_NT; i < ndx; i += PF_NT) xt[i] = xEntry(a.tabs.xofs[dx0 + i], a.tabs.xab[dx0 + i]);
+#pragma nounroll
+            for (int i = i0 + PF_NT; i < ndy; i += PF_NT) yt[i] = yEntry(a.tabs.yofs[dy0 + i], a.tabs.yab[dy0 + i]);
+        }
     }
     __syncthreads();
     PF_STAMP(2);
-    if ((a.phases >> 4) == 2) return;
+    if (DBG && (K().phases >> 4) == 2) return;
 
-    // ---- next pyramid level: cv::resize INTER_LINEAR fixed point; 4 px per lane -------
-    if (doResize) {
-        uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
-        const int q0 = dx0 >> 2, q1 = (dx1 + 3) >> 2;
-        const int nq = q1 - q0;  // 4-pixel groups of a destination row of this tile
-        // One pixel group per lane, kept for the whole phase (its four column entries stay in registers); the 512 lanes are dealt
-        // over (row class, group): lane t -> group t mod nq, rows dy0 + t / nq, + RC, + 2 RC ...  With the usual 45 - 53 groups per
-        // row a wave-per-row mapping left 20 - 30 % of the lanes idle; here 512 / nq row classes use all but 512 mod nq lanes.
-        // (Rows wider than 2048 pixels fall back to several groups per lane.)
-        const int RC = max(1, __builtin_amdgcn_readfirstlane((int)(512.5f * __builtin_amdgcn_rcpf((float)nq))));
-        const int t = otid();
-        const int rc = nq >= PF_NT ? 0 : (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)nq));
-        for (int q = q0 + (t - rc * nq); q < q1 && rc < RC; q += PF_NT) {
-            int ca[4], wa[4], wb[4];
-            bool ok[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int dx = q * 4 + j;
-                ok[j] = dx >= dx0 && dx < dx1;
-                const int2 e = xt[min(max(dx, dx0), dx1 - 1) - dx0];
-                ca[j] = e.x;
-                wa[j] = (short)(e.y & 0xFFFF);
-                wb[j] = e.y >> 16;
-            }
-            const bool full = ok[0] && ok[3];
-#pragma nounroll
-            for (int dy = dy0 + rc; dy < dy1; dy += RC) {
-                const int2 ye = yt[dy - dy0];
-                const int b0 = ye.y & 0xFFFF, b1 = (unsigned)ye.y >> 16;  // weights are in [0, 2048]
-                const uint8_t *r0 = tile + (ye.x & 0xFFFF);
-                const uint8_t *r1 = tile + ((unsigned)ye.x >> 16);
-                uint32_t packed = 0;
+    // ---- phase 1: next pyramid level: cv::resize INTER_LINEAR fixed point; 4 px per lane -------
+    {
+        KArgs &a = K();
+        if (a.dst && (!DBG || (a.phases & 1))) {
+            TileK &t = T();
+            const int2 *xt = (const int2 *)(lds + a.g.oXt), *yt = (const int2 *)(lds + a.g.oYt);
+            uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
+            const int dstPitch = a.dstPitch;
+            const int dx0 = t.dx0, dx1 = t.dx1, dy0 = t.dy0, dy1 = t.dy1;
+            const int q0 = t.q0, nq = t.nq, RC = t.RC, q1 = q0 + nq;
+            // One pixel group per lane, kept for the whole phase (its four column entries stay in registers); the 512 lanes are dealt
+            // over (row class, group): lane t -> group t mod nq, rows dy0 + t / nq, + RC, + 2 RC ...  With the usual 45 - 53 groups per
+            // row a wave-per-row mapping left 20 - 30 % of the lanes idle; here RC = 512 / nq row classes use all but 512 mod nq lanes.
+            // (Rows wider than 2048 pixels fall back to several groups per lane.)
+            const int tt = otid();
+            const int rc = nq >= PF_NT ? 0 : (int)(((float)tt + 0.5f) * __builtin_amdgcn_rcpf((float)nq));
+            for (int q = q0 + (tt - rc * nq); q < q1 && rc < RC; q += PF_NT) {
+                int ca[4], wa[4], wb[4];
+                bool ok[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int h0 = r0[ca[j]] * wa[j] + r0[ca[j] + 1] * wb[j];
-                    const int h1 = r1[ca[j]] * wa[j] + r1[ca[j] + 1] * wb[j];
-                    // <= 255: the weights of each axis sum to 2048
-                    const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
-                    packed |= v << (8 * j);
+                    const int dx = q * 4 + j;
+                    ok[j] = dx >= dx0 && dx < dx1;
+                    const int2 e = xt[min(max(dx, dx0), dx1 - 1) - dx0];
+                    ca[j] = e.x;
+                    wa[j] = (short)(e.y & 0xFFFF);
+                    wb[j] = e.y >> 16;
                 }
-                uint8_t *drow = dstF + (size_t)dy * a.dstPitch + q * 4;
-                if (full) *(uint32_t *)drow = packed;
-                else {
+                const bool full = ok[0] && ok[3];
+#pragma nounroll
+                for (int dy = dy0 + rc; dy < dy1; dy += RC) {
+                    const int2 ye = yt[dy - dy0];
+                    const int b0 = ye.y & 0xFFFF, b1 = (unsigned)ye.y >> 16;  // weights are in [0, 2048]
+                    const uint8_t *r0 = tile + (ye.x & 0xFFFF);
+                    const uint8_t *r1 = tile + ((unsigned)ye.x >> 16);
+                    uint32_t packed = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (ok[j]) drow[j] = (uint8_t)(packed >> (8 * j));
+                    for (int j = 0; j < 4; ++j) {
+                        const int h0 = r0[ca[j]] * wa[j] + r0[ca[j] + 1] * wb[j];
+                        const int h1 = r1[ca[j]] * wa[j] + r1[ca[j] + 1] * wb[j];
+                        // <= 255: the weights of each axis sum to 2048
+                        const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+                        packed |= v << (8 * j);
+                    }
+                    uint8_t *drow = dstF + (size_t)dy * dstPitch + q * 4;
+                    if (full) *(uint32_t *)drow = packed;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ok[j]) drow[j] = (uint8_t)(packed >> (8 * j));
+                    }
                 }
             }
         }
     }
 
     PF_STAMP(3);
-    if ((a.phases >> 4) == 3) return;
-    // ---- FAST-9/16 + cell-local NMS, in the reference's two rounds -----------------------------------------------
+    if (DBG && (K().phases >> 4) == 3) return;
+    // ---- phase 2: FAST-9/16 + cell-local NMS, in the reference's two rounds -----------------------------------------------
     // round 0: threshold iniThFAST everywhere; round 1: threshold minThFAST, only in cells that produced no keypoint
     // in round 0 (tileCalcKeypoints :908-925).  Each round: (A) 4-point pre-test on 8-pixel strips -> LDS queue of
     // 4-pixel groups; (B) dense full 16-position SWAR ring test, one queued group per lane -> LDS queue of corners;
     // (C) dense corner score; (D) dense cell-local strict 3x3 NMS -> per-cell row bitmaps; (E) per-cell counts.
-    const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
-    const int s0 = (cInt0 - 4) >> 3, s1 = (cInt1 - 1 - 4) >> 3;  // strips cover LDS columns [8s + 4, 8s + 12)
-    const int NS = s1 - s0 + 1;
-    const float invNS = __builtin_amdgcn_rcpf((float)NS);
-    const int nItems = NS * THi;
-    const int rowOff = ty0 - ly0;
-    for (int round = 0; round < 2; ++round) {
-        const int th = round == 0 ? iniTh : minTh;
-        const int thEff = max(th, 1);
-        unsigned eMask = 0;  // round 1: cells without a keypoint after round 0 (cnt is complete: barrier at the end of the NMS phase)
-        if (round == 1) {
-            for (int c = 0; c < nCells; ++c) eMask |= (unsigned)(cnt[c] == 0) << c;
-            eMask = __builtin_amdgcn_readfirstlane(eMask);
-            if (minTh >= iniTh || !eMask) break;  // uniform
-        }
-        const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
+    {
+        KArgs &a = K();
+        TileK &t = T();
+        const int tp = a.g.tilePitch, wCell = a.g.wCell, hCell = a.g.hCell, wpc = a.g.wpc;
+        uint8_t *score = lds + a.g.oScore;
+        uint32_t *bits = (uint32_t *)(lds + a.g.oBits);
+        uint16_t *gq = (uint16_t *)(lds + a.g.oGq), *cq = (uint16_t *)(lds + a.g.oCq);
+        uint8_t *colInfo = lds + a.g.oColInfo;
+        const int phases = DBG ? a.phases : 15;
+        const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
+        const int cInt0 = t.cInt0, cInt1 = t.cInt1, nCells = t.nCells, THi = t.THi, rowOff = t.rowOff;
+        const int s0 = t.s0, NS = t.NS;  // strips cover LDS columns [8s + 4, 8s + 12)
+        const float invNS = __builtin_amdgcn_rcpf((float)NS);
+        const int nItems = NS * THi;
+        for (int round = 0; round < 2; ++round) {
+            const int th = round == 0 ? iniTh : minTh;
+            const int thEff = max(th, 1);
+            unsigned eMask = 0;  // round 1: cells without a keypoint after round 0 (cnt is complete: barrier at the end of the NMS phase)
+            if (round == 1) {
+                for (int c = 0; c < nCells; ++c) eMask |= (unsigned)(cnt[c] == 0) << c;
+                eMask = __builtin_amdgcn_readfirstlane(eMask);
+                if (minTh >= iniTh || !eMask) break;  // uniform
+            }
+            const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
 
-        // (A) pre-test of one 8-pixel strip (row r, strip sI of the tile, `valid` = its candidate pixels)
-        auto preTest = [&](int r, int sI, unsigned valid) {
-            const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * (s0 + sI);
-            uint32_t w0[4], w3[4], w6[4];
-            {
-                const uint2 a0 = *(const uint2 *)(wp), a1 = *(const uint2 *)(wp + 8);
-                const uint2 b0 = *(const uint2 *)(wp + 3 * tp), b1 = *(const uint2 *)(wp + 3 * tp + 8);
-                const uint2 c0 = *(const uint2 *)(wp + 6 * tp), c1 = *(const uint2 *)(wp + 6 * tp + 8);
-                w0[0] = a0.x; w0[1] = a0.y; w0[2] = a1.x; w0[3] = a1.y;
-                w3[0] = b0.x; w3[1] = b0.y; w3[2] = b1.x; w3[3] = b1.y;
-                w6[0] = c0.x; w6[1] = c0.y; w6[2] = c1.x; w6[3] = c1.y;
-            }
-            const uint32_t f0 = fast_group_pretest<0>(w0, w3, w6, T4, C4);
-            const uint32_t f1 = fast_group_pretest<1>(w0, w3, w6, T4, C4);
-            const unsigned m = (((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4)) & valid;
-            const bool g0 = (m & 0x0F) != 0, g1 = (m & 0xF0) != 0;
-            // queue slots: one LDS atomic per wave and ballot prefix counts (a per-lane atomicAdd on one address is expanded by
-            // the compiler into a readlane loop over the active lanes: ~9 scalar instructions per passing strip)
-            const unsigned long long bg0 = __ballot(g0), bg1 = __ballot(g1);
-            if (bg0 | bg1) {
-                unsigned pos = wave_queue_alloc(&gqCountR[round], (unsigned)(__popcll(bg0) + __popcll(bg1))) + mbcnt64(bg0) + mbcnt64(bg1);
-                const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
-                if (g0) gq[pos++] = (uint16_t)e;
-                if (g1) gq[pos] = (uint16_t)(e | 1u);
-            }
-        };
-        if (!(a.phases & 2)) {
-        } else if (round == 0) {
-            for (int it = otid(); it < nItems; it += PF_NT) {
-                const int r = (int)(((float)it + 0.5f) * invNS);
-                const int sI = it - r * NS;
-                const int cbase = 8 * (s0 + sI) + 4;
-                const int plo = max(cInt0 - cbase, 0), phi = min(cInt1 - cbase, 8);
-                preTest(r, sI, (0xFFu >> (8 - phi)) & (0xFFu << plo));          // interior pixels of the strip
-            }
-        } else {
-            // only the strips of still-empty cells, one cell at a time (cell geometry in SGPRs).  A strip that straddles two
-            // empty cells is tested once, with the left one.
-            int visit = 0;
-            for (unsigned em = eMask; em; em &= em - 1, ++visit) {
-                const int c = __ffs(em) - 1;
-                const bool prevEmpty = c > 0 && ((eMask >> (c - 1)) & 1u), nextEmpty = ((eMask >> 1) >> c) & 1u;
-                const int cc0 = cInt0 + c * g.wCell, cc1 = min(cc0 + g.wCell, cInt1);
-                int sF = (cc0 - 4) >> 3;
-                const int sL = (cc1 - 1 - 4) >> 3;
-                if (prevEmpty && 8 * sF + 4 < cc0) ++sF;
-                const int vhi = nextEmpty ? min(cc1 + g.wCell, cInt1) : cc1;
-                const int nS = sL - sF + 1;
-                if (nS <= 0) continue;
-                const float invS = __builtin_amdgcn_rcpf((float)nS);
-                // alternate the half of the workgroup that takes a cell's (usually < 256) strips
-                for (int it = (otid() + visit * (PF_NT / 2)) & (PF_NT - 1); it < nS * THi; it += PF_NT) {
-                    const int r = (int)(((float)it + 0.5f) * invS);
-                    const int s = sF + (it - r * nS);
-                    const int cbase = 8 * s + 4;
-                    const int plo = max(cc0 - cbase, 0), phi = min(vhi - cbase, 8);
-                    preTest(r, s - s0, (0xFFu >> (8 - phi)) & (0xFFu << plo));
+            // (A) pre-test of one 8-pixel strip (row r, strip sI of the tile, `valid` = its candidate pixels)
+            auto preTest = [&](int r, int sI, unsigned valid) {
+                const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * (s0 + sI);
+                uint32_t w0[4], w3[4], w6[4];
+                {
+                    const uint2 a0 = *(const uint2 *)(wp), a1 = *(const uint2 *)(wp + 8);
+                    const uint2 b0 = *(const uint2 *)(wp + 3 * tp), b1 = *(const uint2 *)(wp + 3 * tp + 8);
+                    const uint2 c0 = *(const uint2 *)(wp + 6 * tp), c1 = *(const uint2 *)(wp + 6 * tp + 8);
+                    w0[0] = a0.x; w0[1] = a0.y; w0[2] = a1.x; w0[3] = a1.y;
+                    w3[0] = b0.x; w3[1] = b0.y; w3[2] = b1.x; w3[3] = b1.y;
+                    w6[0] = c0.x; w6[1] = c0.y; w6[2] = c1.x; w6[3] = c1.y;
                 }
-            }
-        }
-        __syncthreads();
-        PF_STAMP(4 + 4 * round);
-        if ((a.phases >> 4) == 4) return;
-
-        // (B) full ring test of the queued groups -> corner queue
-        const unsigned gn = gqCountR[round];
-        for (unsigned i = otid(); i < gn; i += PF_NT) {
-            const unsigned e = gq[i];
-            const int r = e >> 9, sg = e & 511;
-            const int cb = 8 * s0 + 4 * sg;                       // window start: the group's pixels are bytes 4..7
-            const uint32_t fl = fast_group_flags_lds(tile + (rowOff + r - 3) * tp + cb, tp, T4, C4);
-            const int c4 = cb + 4;
-            const int plo = max(cInt0 - c4, 0), phi = min(cInt1 - c4, 4);
-            unsigned m = ((fl * 0x00204081u) >> 28) & (0xFu >> (4 - phi)) & (0xFu << plo);
-            if (round == 1 && m) {
-                // keep the pixels that lie in a still-empty cell; a group overlaps at most two cells (cells are >= 35 px wide)
-                const int x0 = c4 + plo - cInt0, n = phi - plo;
-                const int cl = colInfo[x0] & 0x3F, ch = colInfo[x0 + n - 1] & 0x3F;
-                const int b = min(max(ch * g.wCell - x0, 0), n);  // first pixel of cell ch (0 when cl == ch)
-                const unsigned all = (1u << n) - 1u, lo = (1u << b) - 1u;
-                const unsigned keep = (((eMask >> cl) & 1u) ? lo : 0u) | (((eMask >> ch) & 1u) ? all & ~lo : 0u);
-                m &= keep << plo;
-            }
-            const unsigned nc = __popc(m);  // 0..4
-            const unsigned long long n1 = __ballot((nc & 1u) != 0), n2 = __ballot((nc & 2u) != 0), n4 = __ballot((nc & 4u) != 0);
-            if (n1 | n2 | n4) {
-                unsigned pos = wave_queue_alloc(&cqCountR[round], (unsigned)(__popcll(n1) + 2 * __popcll(n2) + 4 * __popcll(n4))) +
-                               mbcnt64(n1) + 2u * mbcnt64(n2) + 4u * mbcnt64(n4);
-                while (m) {
-                    const int k = __ffs(m) - 1;
-                    m &= m - 1;
-                    if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
-                    else pf_score_one(tile, score, tp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
-                    ++pos;
+                const uint32_t f0 = fast_group_pretest<0>(w0, w3, w6, T4, C4);
+                const uint32_t f1 = fast_group_pretest<1>(w0, w3, w6, T4, C4);
+                const unsigned m = (((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4)) & valid;
+                const bool g0 = (m & 0x0F) != 0, g1 = (m & 0xF0) != 0;
+                // queue slots: one LDS atomic per wave and ballot prefix counts (a per-lane atomicAdd on one address is expanded by
+                // the compiler into a readlane loop over the active lanes: ~9 scalar instructions per passing strip)
+                const unsigned long long bg0 = __ballot(g0), bg1 = __ballot(g1);
+                if (bg0 | bg1) {
+                    unsigned pos = wave_queue_alloc(&gqCountR[round], (unsigned)(__popcll(bg0) + __popcll(bg1))) + mbcnt64(bg0) + mbcnt64(bg1);
+                    const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
+                    if (g0) gq[pos++] = (uint16_t)e;
+                    if (g1) gq[pos] = (uint16_t)(e | 1u);
                 }
-            }
-        }
-        __syncthreads();
-        PF_STAMP(5 + 4 * round);
-        if ((a.phases >> 4) == 5) return;
-
-        // (C) dense corner score (merging it into (B) measured slower: 3.26 vs 3.0 ms — divergent scoring loops)
-        const unsigned qn = cqCountR[round];
-        for (unsigned i = otid(); i < min(qn, (unsigned)PF_QCAP); i += PF_NT) {
-            const unsigned e = cq[i];
-            pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
-        }
-        __syncthreads();
-        PF_STAMP(6 + 4 * round);
-        if ((a.phases >> 4) == 6) return;
-
-        // (D) cell-local NMS -> bitmaps; (E) per-cell counts by LDS atomics
-        if (qn <= PF_QCAP) {
-            if (a.phases & 4)
-            for (unsigned i = otid(); i < qn; i += PF_NT) {
-                const unsigned e = cq[i];
-                pf_nms_one(score, colInfo, bits, cnt, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, g.wCell, g.hCell, wpc);
-            }
-        } else {
-            // corner queue overflow (pathological corner density): NMS over every scored pixel of the queued groups
-            for (unsigned i = otid(); i < gn; i += PF_NT) {
-                const unsigned e = gq[i];
-                const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
-                for (int k = 0; k < 4; ++k)
-                    if (c4 + k >= cInt0 && c4 + k < cInt1)
-                        pf_nms_one(score, colInfo, bits, cnt, tp, r, c4 + k, cInt0, g.wCell, g.hCell, wpc);
-            }
-        }
-        __syncthreads();
-        PF_STAMP(7 + 4 * round);
-        if ((a.phases >> 4) == 7) return;
-    }
-    if (!(a.phases & 8)) return;
-
-    // ---- ordered emission: cells in order, raster inside a cell (== tileCalcKeypoints emission order) ----
-    uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + g.candBase +
-                     (size_t)(crow * g.nGroups + grp) * g.slotCap;
-    if (tid == 0) {
-        int tot = 0;
-        for (int c = 0; c < nCells; ++c) tot += cnt[c];
-        a.tileCount[(size_t)f * a.tilesPerFrame + g.tileBase + crow * g.nGroups + grp] = tot;
-    }
-    for (int c = wave; c < nCells; c += PF_NW) {
-        const uint32_t *cbits = bits + (size_t)c * cellWords;
-        int base = 0;
-        for (int q = 0; q < c; ++q) base += cnt[q];
-        const int cellC0 = cInt0 + c * g.wCell;
-        for (int rb = 0; rb < THi; rb += 64) {
-            const int r = rb + lane;
-            int n = 0;
-            if (r < THi)
-                for (int k = 0; k < wpc; ++k) n += __popc(cbits[r * wpc + k]);
-            int total;
-            int o = base + wave_excl_scan(n, total);
-            if (r < THi) {
-                for (int k = 0; k < wpc; ++k) {
-                    uint32_t wd = cbits[r * wpc + k];
-                    while (wd) {
-                        const int b = __ffs(wd) - 1;
-                        wd &= wd - 1;
-                        const int cc = cellC0 + k * 32 + b;
-                        slot[o++] = ORBX_PACK(cc - colOf0 - ORBX_BORDER, ty0 + r - ORBX_BORDER, score[(r + 1) * tp + cc]);
+            };
+            if (!(phases & 2)) {
+            } else if (round == 0) {
+                for (int it = otid(); it < nItems; it += PF_NT) {
+                    const int r = (int)(((float)it + 0.5f) * invNS);
+                    const int sI = it - r * NS;
+                    const int cbase = 8 * (s0 + sI) + 4;
+                    const int plo = max(cInt0 - cbase, 0), phi = min(cInt1 - cbase, 8);
+                    preTest(r, sI, (0xFFu >> (8 - phi)) & (0xFFu << plo));          // interior pixels of the strip
+                }
+            } else {
+                // only the strips of still-empty cells, one cell at a time (cell geometry in SGPRs).  A strip that straddles two
+                // empty cells is tested once, with the left one.
+                int visit = 0;
+                for (unsigned em = eMask; em; em &= em - 1, ++visit) {
+                    const int c = __ffs(em) - 1;
+                    const bool prevEmpty = c > 0 && ((eMask >> (c - 1)) & 1u), nextEmpty = ((eMask >> 1) >> c) & 1u;
+                    const int cc0 = cInt0 + c * wCell, cc1 = min(cc0 + wCell, cInt1);
+                    int sF = (cc0 - 4) >> 3;
+                    const int sL = (cc1 - 1 - 4) >> 3;
+                    if (prevEmpty && 8 * sF + 4 < cc0) ++sF;
+                    const int vhi = nextEmpty ? min(cc1 + wCell, cInt1) : cc1;
+                    const int nS = sL - sF + 1;
+                    if (nS <= 0) continue;
+                    const float invS = __builtin_amdgcn_rcpf((float)nS);
+                    // alternate the half of the workgroup that takes a cell's (usually < 256) strips
+                    for (int it = (otid() + visit * (PF_NT / 2)) & (PF_NT - 1); it < nS * THi; it += PF_NT) {
+                        const int r = (int)(((float)it + 0.5f) * invS);
+                        const int s = sF + (it - r * nS);
+                        const int cbase = 8 * s + 4;
+                        const int plo = max(cc0 - cbase, 0), phi = min(vhi - cbase, 8);
+                        preTest(r, s - s0, (0xFFu >> (8 - phi)) & (0xFFu << plo));
                     }
                 }
             }
-            base += total;
+            __syncthreads();
+            PF_STAMP(4 + 4 * round);
+            if (DBG && (phases >> 4) == 4) return;
+
+            // (B) full ring test of the queued groups -> corner queue
+            const unsigned gn = gqCountR[round];
+            for (unsigned i = otid(); i < gn; i += PF_NT) {
+                const unsigned e = gq[i];
+                const int r = e >> 9, sg = e & 511;
+                const int cb = 8 * s0 + 4 * sg;                       // window start: the group's pixels are bytes 4..7
+                const uint32_t fl = fast_group_flags_lds(tile + (rowOff + r - 3) * tp + cb, tp, T4, C4);
+                const int c4 = cb + 4;
+                const int plo = max(cInt0 - c4, 0), phi = min(cInt1 - c4, 4);
+                unsigned m = ((fl * 0x00204081u) >> 28) & (0xFu >> (4 - phi)) & (0xFu << plo);
+                if (round == 1 && m) {
+                    // keep the pixels that lie in a still-empty cell; a group overlaps at most two cells (cells are >= 35 px wide)
+                    const int x0 = c4 + plo - cInt0, n = phi - plo;
+                    const int cl = colInfo[x0] & 0x3F, ch = colInfo[x0 + n - 1] & 0x3F;
+                    const int b = min(max(ch * wCell - x0, 0), n);  // first pixel of cell ch (0 when cl == ch)
+                    const unsigned all = (1u << n) - 1u, lo = (1u << b) - 1u;
+                    const unsigned keep = (((eMask >> cl) & 1u) ? lo : 0u) | (((eMask >> ch) & 1u) ? all & ~lo : 0u);
+                    m &= keep << plo;
+                }
+                const unsigned nc = __popc(m);  // 0..4
+                const unsigned long long n1 = __ballot((nc & 1u) != 0), n2 = __ballot((nc & 2u) != 0), n4 = __ballot((nc & 4u) != 0);
+                if (n1 | n2 | n4) {
+                    unsigned pos = wave_queue_alloc(&cqCountR[round], (unsigned)(__popcll(n1) + 2 * __popcll(n2) + 4 * __popcll(n4))) +
+                                   mbcnt64(n1) + 2u * mbcnt64(n2) + 4u * mbcnt64(n4);
+                    while (m) {
+                        const int k = __ffs(m) - 1;
+                        m &= m - 1;
+                        if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
+                        else pf_score_one(tile, score, tp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
+                        ++pos;
+                    }
+                }
+            }
+            __syncthreads();
+            PF_STAMP(5 + 4 * round);
+            if (DBG && (phases >> 4) == 5) return;
+
+            // (C) dense corner score (merging it into (B) measured slower: 3.26 vs 3.0 ms — divergent scoring loops)
+            const unsigned qn = cqCountR[round];
+            for (unsigned i = otid(); i < min(qn, (unsigned)PF_QCAP); i += PF_NT) {
+                const unsigned e = cq[i];
+                pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
+            }
+            __syncthreads();
+            PF_STAMP(6 + 4 * round);
+            if (DBG && (phases >> 4) == 6) return;
+
+            // (D) cell-local NMS -> bitmaps; (E) per-cell counts by LDS atomics
+            if (qn <= PF_QCAP) {
+                if (phases & 4)
+                for (unsigned i = otid(); i < qn; i += PF_NT) {
+                    const unsigned e = cq[i];
+                    pf_nms_one(score, colInfo, bits, cnt, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, wCell, hCell, wpc);
+                }
+            } else {
+                // corner queue overflow (pathological corner density): NMS over every scored pixel of the queued groups
+                for (unsigned i = otid(); i < gn; i += PF_NT) {
+                    const unsigned e = gq[i];
+                    const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
+                    for (int k = 0; k < 4; ++k)
+                        if (c4 + k >= cInt0 && c4 + k < cInt1)
+                            pf_nms_one(score, colInfo, bits, cnt, tp, r, c4 + k, cInt0, wCell, hCell, wpc);
+                }
+            }
+            __syncthreads();
+            PF_STAMP(7 + 4 * round);
+            if (DBG && (phases >> 4) == 7) return;
+        }
+        if (!(phases & 8)) return;
+    }
+
+    // ---- phase 3: ordered emission: cells in order, raster inside a cell (== tileCalcKeypoints emission order) ----
+    {
+        KArgs &a = K();
+        TileK &t = T();
+        const int tp = a.g.tilePitch, wCell = a.g.wCell, wpc = a.g.wpc, cellWords = a.g.hCell * wpc;
+        const uint8_t *score = lds + a.g.oScore;
+        const uint32_t *bits = (const uint32_t *)(lds + a.g.oBits);
+        const int nCells = t.nCells, THi = t.THi, cInt0 = t.cInt0;
+        const int xBias = t.colOf0 + ORBX_BORDER, yBias = t.ty0 - ORBX_BORDER;
+        uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + a.g.candBase + (size_t)tileId * a.g.slotCap;
+        if (tid == 0) {
+            int tot = 0;
+            for (int c = 0; c < nCells; ++c) tot += cnt[c];
+            a.tileCount[(size_t)f * a.tilesPerFrame + a.g.tileBase + tileId] = tot;
+        }
+        for (int c = wave; c < nCells; c += PF_NW) {
+            const uint32_t *cbits = bits + (size_t)c * cellWords;
+            int base = 0;
+            for (int q = 0; q < c; ++q) base += cnt[q];
+            const int cellC0 = cInt0 + c * wCell;
+            for (int rb = 0; rb < THi; rb += 64) {
+                const int r = rb + lane;
+                int n = 0;
+                if (r < THi)
+                    for (int k = 0; k < wpc; ++k) n += __popc(cbits[r * wpc + k]);
+                int total;
+                int o = base + wave_excl_scan(n, total);
+                if (r < THi) {
+                    for (int k = 0; k < wpc; ++k) {
+                        uint32_t wd = cbits[r * wpc + k];
+                        while (wd) {
+                            const int b = __ffs(wd) - 1;
+                            wd &= wd - 1;
+                            const int cc = cellC0 + k * 32 + b;
+                            slot[o++] = ORBX_PACK(cc - xBias, yBias + r, score[(r + 1) * tp + cc]);
+                        }
+                    }
+                }
+                base += total;
+            }
         }
     }
     PF_STAMP(12);
@@ -708,6 +717,8 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
 {
     PyrFastArgs a;
     a.g = g;
+    a.tiles = tabs.pfTiles;
+    if (!a.tiles) return hipErrorInvalidValue;
     a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride;
     {
         const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride;
@@ -727,13 +738,14 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
     if (g.groupCells > PF_MAX_GROUP_CELLS) return hipErrorInvalidValue;
     if (getenv("ORBX_DEBUG")) {
         int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pyr_fast, PF_NT, g.ldsBytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pyr_fast<false>, PF_NT, g.ldsBytes);
         fprintf(stderr, "[orbx] k_pyr_fast level %dx%d: tiles/frame %d (%d groups x %d rows, %d cells/group), LDS %d B, %d threads, %d blocks/CU\n", g.w, g.h,
                 g.nTiles, g.nGroups, g.ncy, g.groupCells, g.ldsBytes, PF_NT, nb);
     }
     dim3 grid(xcd_grid(nframes, g.nTiles));
     static const int ldsPad = [] { const char *e = getenv("ORBX_PF_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments
-    hipLaunchKernelGGL(k_pyr_fast, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
+    if (a.phases == 15) hipLaunchKernelGGL(k_pyr_fast<false>, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
+    else hipLaunchKernelGGL(k_pyr_fast<true>, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
     return hipGetLastError();
 }
 
