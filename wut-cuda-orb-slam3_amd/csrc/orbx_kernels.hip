@@ -524,8 +524,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             const int thEff = max(th, 1);
             unsigned eMask = 0;  // round 1: cells without a keypoint after round 0 (cnt is complete: barrier at the end of the NMS phase)
             if (round == 1) {
-                for (int c = 0; c < nCells; ++c) eMask |= (unsigned)(cnt[c] == 0) << c;
-                eMask = __builtin_amdgcn_readfirstlane(eMask);
+                // lane c looks at cell c (a scalar loop over the cells is unrolled by the compiler into a chain of wave-uniform
+                // conditions that all stay live - and spilled - through the rounds)
+                eMask = (unsigned)__ballot(lane < nCells && cnt[lane & (PF_MAX_GROUP_CELLS - 1)] == 0);
                 if (minTh >= iniTh || !eMask) break;  // uniform
             }
             const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
@@ -675,15 +676,13 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
         const int nCells = t.nCells, THi = t.THi, cInt0 = t.cInt0;
         const int xBias = t.colOf0 + ORBX_BORDER, yBias = t.ty0 - ORBX_BORDER;
         uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + a.g.candBase + (size_t)tileId * a.g.slotCap;
-        if (tid == 0) {
-            int tot = 0;
-            for (int c = 0; c < nCells; ++c) tot += cnt[c];
-            a.tileCount[(size_t)f * a.tilesPerFrame + a.g.tileBase + tileId] = tot;
-        }
+        // keypoints of the cells before cell c: a wave scan over the per-cell counts (lane = cell)
+        int tot;
+        const int cellBase = wave_excl_scan(lane < nCells ? cnt[lane & (PF_MAX_GROUP_CELLS - 1)] : 0, tot);
+        if (tid == 0) a.tileCount[(size_t)f * a.tilesPerFrame + a.g.tileBase + tileId] = tot;
         for (int c = wave; c < nCells; c += PF_NW) {
             const uint32_t *cbits = bits + (size_t)c * cellWords;
-            int base = 0;
-            for (int q = 0; q < c; ++q) base += cnt[q];
+            int base = __builtin_amdgcn_readlane(cellBase, c);
             const int cellC0 = cInt0 + c * wCell;
             for (int rb = 0; rb < THi; rb += 64) {
                 const int r = rb + lane;
