@@ -51,7 +51,7 @@ CONFIGS = {
                     "Frame::ComputeStereoMatches per pair (BASELINE configs[2])"),
     "c4": dict(w=512, h=512, nf=1500, stereo=False, units=1024, match=None, lap=(0, 1000), stream=8192,
                name="batch of {u} synthetic 512x512 mono frames per GPU (TUM-VI geometry), nFeatures=1500 (BASELINE configs[3])"),
-    "c5": dict(w=1920, h=1080, nf=4000, stereo=True, units=64, match="knn2", lap=(0, 0), stream=1024,
+    "c5": dict(w=1920, h=1080, nf=4000, stereo=True, units=128, match="knn2", lap=(0, 0), stream=1024,
                name="batch of {u} synthetic 1920x1080 stereo pairs per GPU, nFeatures=4000: extract L + R, brute-force 256-bit "
                     "Hamming kNN-2 cross-match per pair (BASELINE configs[4])"),
 }

@@ -11,7 +11,7 @@ python3 - "$f" $k <<'PY'
 import csv,sys,collections
 agg=collections.defaultdict(float)
 for r in csv.DictReader(open(sys.argv[1])):
-    if r['Kernel_Name'].startswith('k_pyr_fast'): agg[r['Counter_Name']]+=float(r['Counter_Value'])
+    if 'k_pyr_fast' in r['Kernel_Name']: agg[r['Counter_Name']]+=float(r['Counter_Value'])
 print("stop", sys.argv[2], {c: f"{x/3:.4g}" for c,x in sorted(agg.items())})
 PY
 done

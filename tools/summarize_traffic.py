@@ -11,6 +11,15 @@ import sys
 
 root = sys.argv[1]
 batches = 3
+
+
+def norm(name):  # "void k_pyr_fast<false>(PyrFastArgs)" -> "k_pyr_fast"
+    name = name.split("(")[0]
+    if name.startswith("void "):
+        name = name[5:]
+    return name.split("<")[0]
+
+
 out = {}
 for d, counters, scale in (("FETCH_SIZE", ["FETCH_SIZE"], 1024.0), ("WRITE_SIZE", ["WRITE_SIZE"], 1024.0),
                            ("SQ", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], 1.0)):
@@ -22,7 +31,7 @@ for d, counters, scale in (("FETCH_SIZE", ["FETCH_SIZE"], 1024.0), ("WRITE_SIZE"
             c = r["Counter_Name"]
             if c not in counters:
                 continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = norm(r["Kernel_Name"])
             agg[k][c] += float(r["Counter_Value"])
             if c == counters[0]:
                 calls[k] += 1
@@ -35,7 +44,7 @@ for d, counters, scale in (("FETCH_SIZE", ["FETCH_SIZE"], 1024.0), ("WRITE_SIZE"
     if d == "SQ":
         for f in glob.glob(os.path.join(root, d, "**", "*kernel_trace.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0]
+                k = norm(r["Kernel_Name"])
                 out.setdefault(k, {})["ns_per_batch_profiled"] = out.get(k, {}).get("ns_per_batch_profiled", 0.0) + \
                     (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / batches
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
