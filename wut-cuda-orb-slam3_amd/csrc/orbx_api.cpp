@@ -1153,6 +1153,7 @@ struct orbx_matcher {
     DevBuf<uint32_t> d_part;      // kNN-2: per-split partial results
     DevBuf<int> d_bIdx, d_bDist, d_bSad;  // batched stereo matching: per-pair row-band results
     DevBuf<orbx_keypoint> d_bKps;         // batched tracking: undistorted keypoints
+    DevBuf<int> d_rowStart, d_rowItems;   // stereo row buckets (CSR) of the right image(s)
     hipEvent_t evWait = nullptr;  // ordering against the extractors' streams
     DevBuf<orbx_keypoint> d_kl, d_kr;
     DevBuf<float> d_scale, d_uRight, d_depth;
@@ -1195,7 +1196,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release(); m->d_part.release(); m->d_bIdx.release(); m->d_bDist.release(); m->d_bSad.release(); m->d_bKps.release();
+    m->d_q.release(); m->d_t.release(); m->d_idx.release(); m->d_dist.release(); m->d_mat.release(); m->d_part.release(); m->d_bIdx.release(); m->d_bDist.release(); m->d_bSad.release(); m->d_bKps.release(); m->d_rowStart.release(); m->d_rowItems.release();
     if (m->evWait) (void)hipEventDestroy(m->evWait);
     m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
     m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release(); m->d_sbpCand.release(); m->d_proj.release();
@@ -1300,8 +1301,12 @@ extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, 
     HIP_TRY(hipMemcpyAsync(m->d_kl.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
     if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    float maxScale = 1.f;
+    for (int i = 0; i < nlevels; ++i) maxScale = std::max(maxScale, scale_factors[i]);
+    const int itemStride = orbxStereoBandItems(nr, maxScale);
+    if ((rc = m->d_rowStart.ensure((size_t)n_rows + 1)) != ORBX_OK || (rc = m->d_rowItems.ensure((size_t)std::max(itemStride, 1))) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, n_rows, m->d_scale.p, min_d, max_d,
-                                 m->d_idx.p, m->d_dist.p, nullptr));
+                                 m->d_idx.p, m->d_dist.p, nullptr, m->d_rowStart.p, m->d_rowItems.p, itemStride));
     HIP_TRY(hipMemcpyAsync(best_idx, m->d_idx.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(best_dist, m->d_dist.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1607,8 +1612,10 @@ extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left
     HIP_TRY(hipMemcpyAsync(m->d_scale.p, left->scale.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, m->stream));
     const float minZ = mb, minD = 0.f, maxD = mbf / minZ;
     const int nRows = left->geom[0].h;  // mvImagePyramid[0].rows (:848)
+    const int itemStride = orbxStereoBandItems(nr, left->scale.back());
+    if ((rc = m->d_rowStart.ensure((size_t)nRows + 1)) != ORBX_OK || (rc = m->d_rowItems.ensure((size_t)std::max(itemStride, 1))) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, nRows, m->d_scale.p, minD, maxD,
-                                 m->d_idx.p, m->d_dist.p, nullptr));
+                                 m->d_idx.p, m->d_dist.p, nullptr, m->d_rowStart.p, m->d_rowItems.p, itemStride));
     OrbxStereoLevels lv;
     memset(&lv, 0, sizeof lv);
     for (int l = 0; l < nlev; ++l) {
@@ -1695,8 +1702,10 @@ extern "C" int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extracto
     const float minZ = mb, minD = 0.f, maxD = mbf / minZ;
     OrbxStereoBatch sb;
     sb.npairs = npairs; sb.kpStrideL = capL; sb.kpStrideR = capR; sb.outStride = capL; sb.nlDev = left->d_n.p; sb.nrDev = right->d_n.p;
-    HIP_TRY(orbxLaunchStereoRows(m->stream, left->d_kps.p, left->d_desc.p, capL, right->d_kps.p, right->d_desc.p, capR, left->geom[0].h, m->d_scale.p,
-                                 minD, maxD, m->d_bIdx.p, m->d_bDist.p, &sb));
+    const int nRowsB = left->geom[0].h, itemStride = orbxStereoBandItems(capR, left->scale.back());
+    if ((rc = m->d_rowStart.ensure((size_t)npairs * (nRowsB + 1))) != ORBX_OK || (rc = m->d_rowItems.ensure((size_t)npairs * itemStride)) != ORBX_OK) return rc;
+    HIP_TRY(orbxLaunchStereoRows(m->stream, left->d_kps.p, left->d_desc.p, capL, right->d_kps.p, right->d_desc.p, capR, nRowsB, m->d_scale.p,
+                                 minD, maxD, m->d_bIdx.p, m->d_bDist.p, &sb, m->d_rowStart.p, m->d_rowItems.p, itemStride));
     OrbxStereoLevels lv;
     memset(&lv, 0, sizeof lv);
     for (int l = 0; l < nlev; ++l) {

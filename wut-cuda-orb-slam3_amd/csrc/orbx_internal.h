@@ -136,7 +136,9 @@ struct OrbxStereoBatch {
 };
 hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *dl, int nl, const void *kr,
                                 const uint8_t *dr, int nr, int nRows, const float *scaleDev, float minD, float maxD,
-                                int *bestIdx, int *bestDist, const OrbxStereoBatch *batch);
+                                int *bestIdx, int *bestDist, const OrbxStereoBatch *batch, int *rowStart, int *rowItems, int itemStride);
+// scratch of the row buckets: (nRows + 1) ints of row starts and itemStride = orbxStereoBandItems(nr, max scale) ints of items per pair
+static inline int orbxStereoBandItems(int nr, float maxScale) { return nr * ((int)(4.0f * maxScale) + 4); }
 
 // stereo refinement (orbx_match.hip); `levels` points to a host StereoLevelsHost with the layout below
 struct OrbxStereoLevels {

@@ -187,66 +187,99 @@ struct StereoBatch {
     const int *nlDev, *nrDev;
 };
 
+// Row buckets of the right image (vRowIndices, reference src/Frame.cc:858-868) as CSR, built on the device: one workgroup per pair counts
+// the band [floor(y - r), ceil(y + r)] of every right keypoint into LDS row counters, scans them, and fills the lists with LDS cursors.
+// The lists are unordered - the search below does not depend on the visiting order (see there).
+__global__ __launch_bounds__(256) void k_stereo_buckets(const MtKp *kr, int nr, int nRows, const float *scale, int *rowStart, int *rowItems,
+                                                        int itemStride, StereoBatch sb)
+{
+    extern __shared__ int bk[];  // [nRows] counters, then cursors; + 256 partial sums
+    {
+        const size_t p = blockIdx.x;
+        kr += p * sb.kpStrideR; rowStart += p * (size_t)(nRows + 1); rowItems += p * (size_t)itemStride;
+        if (sb.nrDev) nr = min(nr, sb.nrDev[p]);
+    }
+    int *cnt = bk, *part = bk + nRows;
+    const int tid = threadIdx.x;
+    for (int y = tid; y < nRows; y += 256) cnt[y] = 0;
+    __syncthreads();
+    auto band = [&](int i, int &lo, int &hi) {
+        const MtKp k = kr[i];
+        const float r = __fmul_rn(2.0f, scale[k.octave]);
+        hi = min((int)ceilf(__fadd_rn(k.y, r)), nRows - 1);
+        lo = max((int)floorf(__fsub_rn(k.y, r)), 0);
+    };
+    for (int i = tid; i < nr; i += 256) {
+        int lo, hi;
+        band(i, lo, hi);
+        for (int y = lo; y <= hi; ++y) atomicAdd(&cnt[y], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the rows: each thread a contiguous chunk, partial sums through LDS
+    const int per = (nRows + 255) / 256, y0 = tid * per, y1 = min(y0 + per, nRows);
+    int sum = 0;
+    for (int y = y0; y < y1; ++y) sum += cnt[y];
+    part[tid] = sum;
+    __syncthreads();
+    int base = 0;
+    for (int t = 0; t < tid; ++t) base += part[t];
+    for (int y = y0; y < y1; ++y) { const int c = cnt[y]; rowStart[y] = base; cnt[y] = base; base += c; }
+    if (tid == 255) rowStart[nRows] = base;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        int lo, hi;
+        band(i, lo, hi);
+        for (int y = lo; y <= hi; ++y) {
+            const int pos = atomicAdd(&cnt[y], 1);
+            if (pos < itemStride) rowItems[pos] = i;
+        }
+    }
+}
+
+// One lane per left keypoint: the candidates are the right keypoints in the bucket of its row (:884-886), filtered by |octave difference|
+// <= 1 and uR in [uL - maxD, uL - minD]; the reference visits them in increasing iR with a strict `<` starting from TH_HIGH, i.e. it keeps
+// the candidate with the smallest (distance, iR) among those with distance < TH_HIGH - a minimum that does not depend on the order.
 __global__ __launch_bounds__(64) void k_stereo_rows(const MtKp *kl, const uint8_t *dl, int nl, const MtKp *kr,
-                                                    const uint8_t *dr, int nr, int nRows, const float *scale,
-                                                    float minD, float maxD, int *bestIdx, int *bestDist, StereoBatch sb)
+                                                    const uint8_t *dr, int nr, int nRows, const int *rowStart, const int *rowItems,
+                                                    int itemStride, float minD, float maxD, int *bestIdx, int *bestDist, StereoBatch sb)
 {
     {
         const size_t p = blockIdx.y;
         kl += p * sb.kpStrideL; dl += p * sb.kpStrideL * 32; kr += p * sb.kpStrideR; dr += p * sb.kpStrideR * 32;
         bestIdx += p * sb.outStride; bestDist += p * sb.outStride;
+        rowStart += p * (size_t)(nRows + 1); rowItems += p * (size_t)itemStride;
         if (sb.nlDev) nl = min(nl, sb.nlDev[p]);
-        if (sb.nrDev) nr = min(nr, sb.nrDev[p]);
         if ((int)(blockIdx.x * 64) >= nl) return;
     }
-    __shared__ uint32_t tt[MT_TILE * 8];
-    __shared__ int tMinR[MT_TILE], tMaxR[MT_TILE], tOct[MT_TILE];
-    __shared__ float tU[MT_TILE];
     const int li = blockIdx.x * 64 + threadIdx.x;
-    uint32_t qq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int levelL = 0, row = -1;
-    float minU = 0.f, maxU = -1.f;
-    bool live = false;
-    if (li < nl) {
+    if (li >= nl) return;
+    uint32_t qq[8];
+    {
         const uint4 *qs = (const uint4 *)(dl + (size_t)li * 32);
-        uint4 v0 = qs[0], v1 = qs[1];
+        const uint4 v0 = qs[0], v1 = qs[1];
         qq[0] = v0.x; qq[1] = v0.y; qq[2] = v0.z; qq[3] = v0.w; qq[4] = v1.x; qq[5] = v1.y; qq[6] = v1.z; qq[7] = v1.w;
-        const MtKp k = kl[li];
-        levelL = k.octave;
-        row = (int)k.y;
-        minU = __fsub_rn(k.x, maxD);
-        maxU = __fsub_rn(k.x, minD);
-        live = row >= 0 && row < nRows && !(maxU < 0);
     }
-    int best = 100, bi = -1;  // ORBmatcher::TH_HIGH (reference src/ORBmatcher1.cc:37)
-    for (int t0 = 0; t0 < nr; t0 += MT_TILE) {
-        const int ntile = min(MT_TILE, nr - t0);
-        __syncthreads();
-        const uint4 *tsrc = (const uint4 *)(dr + (size_t)t0 * 32);
-        for (int i = threadIdx.x; i < ntile * 2; i += 64) ((uint4 *)tt)[i] = tsrc[i];
-        for (int i = threadIdx.x; i < ntile; i += 64) {
-            const MtKp k = kr[t0 + i];
-            const float r = __fmul_rn(2.0f, scale[k.octave]);
-            tMaxR[i] = (int)ceilf(__fadd_rn(k.y, r));
-            tMinR[i] = (int)floorf(__fsub_rn(k.y, r));
-            tOct[i] = k.octave;
-            tU[i] = k.x;
-        }
-        __syncthreads();
-        if (live) {
-            for (int j = 0; j < ntile; ++j) {
-                if (row < tMinR[j] || row > tMaxR[j]) continue;
-                const int o = tOct[j];
-                if (o < levelL - 1 || o > levelL + 1) continue;
-                const float uR = tU[j];
-                if (uR >= minU && uR <= maxU) {
-                    const int d = ham256(qq, tt + j * 8);
-                    if (d < best) { best = d; bi = t0 + j; }
-                }
-            }
+    const MtKp k = kl[li];
+    const int levelL = k.octave, row = (int)k.y;
+    const float minU = __fsub_rn(k.x, maxD), maxU = __fsub_rn(k.x, minD);
+    uint32_t bestKey = (100u << 20);  // ORBmatcher::TH_HIGH (reference src/ORBmatcher1.cc:37): only smaller distances are taken
+    if (row >= 0 && row < nRows && !(maxU < 0)) {
+        const int e0 = rowStart[row], e1 = min(rowStart[row + 1], itemStride);
+        for (int e = e0; e < e1; ++e) {
+            const int iR = rowItems[e];
+            const MtKp c = kr[iR];
+            if (c.octave < levelL - 1 || c.octave > levelL + 1) continue;
+            if (!(c.x >= minU && c.x <= maxU)) continue;
+            const uint4 *ts = (const uint4 *)(dr + (size_t)iR * 32);
+            const uint4 t0 = ts[0], t1 = ts[1];
+            const uint32_t tw[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            const uint32_t d = (uint32_t)ham256(qq, tw);
+            bestKey = min(bestKey, (d << 20) | (uint32_t)iR);
         }
     }
-    if (li < nl) { bestIdx[li] = bi; bestDist[li] = best; }
+    const bool found = bestKey < (100u << 20);
+    bestIdx[li] = found ? (int)(bestKey & 0xFFFFF) : -1;
+    bestDist[li] = found ? (int)(bestKey >> 20) : 100;
 }
 
 static StereoBatch stereoBatch(const OrbxStereoBatch *b)
@@ -259,11 +292,16 @@ static StereoBatch stereoBatch(const OrbxStereoBatch *b)
 
 hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *dl, int nl, const void *kr,
                                 const uint8_t *dr, int nr, int nRows, const float *scaleDev, float minD, float maxD,
-                                int *bestIdx, int *bestDist, const OrbxStereoBatch *batch)
+                                int *bestIdx, int *bestDist, const OrbxStereoBatch *batch, int *rowStart, int *rowItems, int itemStride)
 {
     if (nl <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_stereo_rows, dim3((nl + 63) / 64, batch ? batch->npairs : 1), dim3(64), 0, st, (const MtKp *)kl, dl, nl, (const MtKp *)kr,
-                       dr, nr, nRows, scaleDev, minD, maxD, bestIdx, bestDist, stereoBatch(batch));
+    if (nRows <= 0 || nRows > 8192 || nr >= (1 << 20) || !rowStart || !rowItems) return hipErrorInvalidValue;
+    const int npairs = batch ? batch->npairs : 1;
+    const StereoBatch sb = stereoBatch(batch);
+    hipLaunchKernelGGL(k_stereo_buckets, dim3(npairs), dim3(256), (size_t)(nRows + 256) * sizeof(int), st, (const MtKp *)kr, nr, nRows, scaleDev, rowStart,
+                       rowItems, itemStride, sb);
+    hipLaunchKernelGGL(k_stereo_rows, dim3((nl + 63) / 64, npairs), dim3(64), 0, st, (const MtKp *)kl, dl, nl, (const MtKp *)kr,
+                       dr, nr, nRows, rowStart, rowItems, itemStride, minD, maxD, bestIdx, bestDist, sb);
     return hipGetLastError();
 }
 
