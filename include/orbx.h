@@ -299,6 +299,14 @@ int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor *ex, int nf
                                      const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward, int backward,
                                      int check_orientation, void *d_kps_un, void *d_assign, void *d_nmatches);
 
+/* The same batch pipeline for Tracking::SearchLocalPoints' matcher, ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &, th,
+ * bFarPoints, thFarPoints) (reference src/ORBmatcher1.cc:45-215): d_map_points[p][..] are the records of orbx_search_by_projection_points. */
+int orbx_search_by_projection_points_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
+                                            const float *knew4, float min_x, float max_x, float min_y, float max_y,
+                                            const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_map_points,
+                                            const uint8_t *d_map_point_desc, const int32_t *d_np, int max_np, float th, float nnratio,
+                                            void *d_kps_un, void *d_assign, void *d_nmatches);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference
  * src/ORBmatcher1.cc:225-427 (decl include/ORBmatcher.h:62), F.Nleft == -1 / pKF->mpCamera2 == NULL; Tracking::TrackReferenceKeyFrame
  * and Relocalization.  Both FeatureVectors (pKF->mFeatVec, F.mFeatVec) as orbx_vocabulary_transform returns them: ascending node

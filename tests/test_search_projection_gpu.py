@@ -187,3 +187,29 @@ def test_search_by_projection_frames_batch(pkg, orc, distorted, stereo):
         assert nm[p] == rn and np.array_equal(assign[p, : nc[p]], rassign), p
         assert rn > 50
     m.close(); ex.close()
+
+
+def test_search_by_projection_points_frames_batch(pkg, orc):
+    """orbx_search_by_projection_points_frames: Tracking::SearchLocalPoints' matcher for a batch of frames on the extractor's device outputs ==
+    the oracle's search_by_projection_points per frame."""
+    P, w, h = 4, 640, 480
+    rng = np.random.default_rng(31)
+    imgs = np.stack([pkg.synth_frame(700 + i, w, h) for i in range(P)])
+    other = np.stack([np.roll(imgs[i], 3 + i, axis=1) for i in range(P)])
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=P)
+    no, _, ko, do = ex.extract_batch(other, (0, 0)); ko, do = ko.copy(), do.copy()
+    nc, _, kc, dc = ex.extract_batch(imgs, (0, 0))
+    sf = ex.GetScaleFactors().copy()
+    k4, dist = (500.0, 500.0, 320.0, 240.0), ()
+    bounds = (0.0, float(w), 0.0, float(h))
+    mps = [_map_points(pkg, ko[p, : no[p]], rng, -(3 + p), 0) for p in range(P)]
+    descs = [do[p, : no[p]] for p in range(P)]
+    m = pkg.ORBmatcher(4096, 4096)
+    nm, assign, kun = m.SearchByProjectionFrames(ex, P, k4, dist, bounds, 0.0, mps, descs, 3.0, map_points_nnratio=0.8)
+    for p in range(P):
+        assert kun[p, : nc[p]].tobytes() == kc[p, : nc[p]].tobytes()       # no distortion: mvKeysUn = mvKeys
+        state = np.full(nc[p], -1, np.int8)
+        rn, rassign = orc.search_by_projection_points(kc[p, : nc[p]], dc[p, : nc[p]], state, bounds, sf, mps[p], descs[p], 3.0, 0.8)
+        assert nm[p] == rn and np.array_equal(assign[p, : nc[p]], rassign), p
+        assert rn > 30
+    m.close(); ex.close()

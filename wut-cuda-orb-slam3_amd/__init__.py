@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
-    "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_search_by_projection_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
+    "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_search_by_projection_frames", "orbx_search_by_projection_points_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points",
@@ -133,6 +133,8 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_match_knn2_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_compute_stereo_matches_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p]
     lib.orbx_matcher_download.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
+    lib.orbx_search_by_projection_points_frames.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float,
+                                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]
     lib.orbx_search_by_projection_frames.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float,
                                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int,
                                                      c_void_p, c_void_p, c_void_p]
@@ -462,7 +464,7 @@ class ORBmatcher:
 
     def SearchByProjectionFrames(self, ex: "ORBextractor", nframes: int, k4, dist, bounds, mbf: float, proj, proj_desc, th: float,
                                  forward: bool = False, backward: bool = False, checkOrientation: bool = True, u_right=None, cur_state=None,
-                                 download: bool = True):
+                                 download: bool = True, map_points_nnratio=None):
         """Batched, device-resident tracking matcher: UndistortKeyPoints -> AssignFeaturesToGrid -> SearchByProjection(Frame, Frame) for the
         first `nframes` frames of the extractor's last batch.  proj[p] / proj_desc[p]: the projections of frame p (lists of arrays of
         PROJECTION_DTYPE / [n, 32] uint8).  Returns (nmatches[P], assign[P, cap], kps_un[P, cap])."""
@@ -480,12 +482,20 @@ class ORBmatcher:
         assign = self._dev_empty((nframes, cap), torch.int32, dev); nm = self._dev_empty((nframes,), torch.int32, dev)
         k4 = np.ascontiguousarray(k4, np.float32); dist = np.ascontiguousarray(dist, np.float32).ravel()
         torch.cuda.synchronize()
-        _check(self._lib.orbx_search_by_projection_frames(self._h, ex._h, nframes, k4.ctypes.data, dist.ctypes.data if len(dist) else None, len(dist), None,
-                                                          bounds[0], bounds[1], bounds[2], bounds[3], mbf, c_void_p(d_ur.data_ptr()) if d_ur is not None else None,
-                                                          c_void_p(d_cs.data_ptr()) if d_cs is not None else None, c_void_p(d_p.data_ptr()),
-                                                          c_void_p(d_d.data_ptr()), c_void_p(d_n.data_ptr()), max_np, th, int(forward), int(backward),
-                                                          int(checkOrientation), c_void_p(kun.data_ptr()), c_void_p(assign.data_ptr()),
-                                                          c_void_p(nm.data_ptr())), "orbx_search_by_projection_frames")
+        ur_p = c_void_p(d_ur.data_ptr()) if d_ur is not None else None
+        cs_p = c_void_p(d_cs.data_ptr()) if d_cs is not None else None
+        if map_points_nnratio is None:
+            _check(self._lib.orbx_search_by_projection_frames(self._h, ex._h, nframes, k4.ctypes.data, dist.ctypes.data if len(dist) else None, len(dist), None,
+                                                              bounds[0], bounds[1], bounds[2], bounds[3], mbf, ur_p, cs_p, c_void_p(d_p.data_ptr()),
+                                                              c_void_p(d_d.data_ptr()), c_void_p(d_n.data_ptr()), max_np, th, int(forward), int(backward),
+                                                              int(checkOrientation), c_void_p(kun.data_ptr()), c_void_p(assign.data_ptr()),
+                                                              c_void_p(nm.data_ptr())), "orbx_search_by_projection_frames")
+        else:  # SearchByProjection(Frame, vector<MapPoint*>): `proj` holds the map-point records
+            _check(self._lib.orbx_search_by_projection_points_frames(self._h, ex._h, nframes, k4.ctypes.data, dist.ctypes.data if len(dist) else None, len(dist),
+                                                                     None, bounds[0], bounds[1], bounds[2], bounds[3], ur_p, cs_p, c_void_p(d_p.data_ptr()),
+                                                                     c_void_p(d_d.data_ptr()), c_void_p(d_n.data_ptr()), max_np, th, float(map_points_nnratio),
+                                                                     c_void_p(kun.data_ptr()), c_void_p(assign.data_ptr()), c_void_p(nm.data_ptr())),
+                   "orbx_search_by_projection_points_frames")
         if not download:
             return nm, assign, kun
         hk = np.empty((nframes, cap), KEYPOINT_DTYPE)

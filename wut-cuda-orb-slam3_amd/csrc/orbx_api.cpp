@@ -1729,13 +1729,12 @@ extern "C" int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extracto
 // Frame::UndistortKeyPoints -> Frame::AssignFeaturesToGrid -> ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
 // (reference src/Frame.cc:777-811, 387-418; src/ORBmatcher3.cc:256-467, Nleft == -1).  Frame p of the batch = frame p of the
 // extractor's last batch; the projected map points of "its" last frame come as device arrays.  Six launches for the whole batch.
-extern "C" int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
-                                                const float *knew4, float min_x, float max_x, float min_y, float max_y, float mbf,
-                                                const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_proj,
-                                                const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward, int backward,
-                                                int check_orientation, void *d_kps_un, void *d_assign, void *d_nmatches)
+static int searchByProjectionFramesImpl(const char *fn, int mode, float nnratio, orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4,
+                                        const float *dist, int ndist, const float *knew4, float min_x, float max_x, float min_y, float max_y, float mbf,
+                                        const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_proj,
+                                        const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward, int backward,
+                                        int check_orientation, void *d_kps_un, void *d_assign, void *d_nmatches)
 {
-    const char *fn = "orbx_search_by_projection_frames";
     if (!m || !ex) return setError(ORBX_ERR_INVALID_ARG, "%s: null handle", fn);
     if (ex->prm.device != m->device) return setError(ORBX_ERR_INVALID_ARG, "%s: matcher and extractor must live on the same device", fn);
     if (nframes < 0 || nframes > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "%s: %d frames, the extractor's last batch holds %d", fn, nframes, ex->lastFrames);
@@ -1770,11 +1769,34 @@ extern "C" int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor 
     OrbxSbpBatch b;
     b.nframes = nframes; b.kcStride = cap; b.projStride = max_np; b.ncDev = ex->d_n.p; b.npDev = d_np;
     HIP_TRY(orbxLaunchSearchByProjection(m->stream, d_kps_un, ex->d_desc.p, d_u_right, d_cur_state, cap, cs, it, min_x, max_x, min_y, max_y,
-                                         m->d_scale.p, mbf, d_proj, d_proj_desc, max_np, th, forward != 0, backward != 0, check_orientation != 0, 0, 0.f,
+                                         m->d_scale.p, mbf, d_proj, d_proj_desc, max_np, th, forward != 0, backward != 0, check_orientation != 0, mode, nnratio,
                                          m->d_sbpCand.p, count, choice, owner, (int *)d_assign, result, &b));
     // nmatches[p] = result[2 p]; a window with more than SBP_CAP candidates is reported as -1 for that frame
     HIP_TRY(orbxLaunchGatherResults(m->stream, result, nframes, (int *)d_nmatches));
     return orderExtractorsAfter(m, ex, ex);
+}
+
+extern "C" int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
+                                                const float *knew4, float min_x, float max_x, float min_y, float max_y, float mbf,
+                                                const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_proj,
+                                                const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward, int backward,
+                                                int check_orientation, void *d_kps_un, void *d_assign, void *d_nmatches)
+{
+    return searchByProjectionFramesImpl("orbx_search_by_projection_frames", 0, 0.f, m, ex, nframes, k4, dist, ndist, knew4, min_x, max_x, min_y, max_y, mbf,
+                                        d_u_right, d_cur_state, d_proj, d_proj_desc, d_np, max_np, th, forward, backward, check_orientation, d_kps_un, d_assign,
+                                        d_nmatches);
+}
+
+// Tracking::SearchLocalPoints' matcher (ORBmatcher::SearchByProjection(Frame &, const vector<MapPoint*> &, th, ..), reference
+// src/ORBmatcher1.cc:45-215, Nleft == -1) over a batch of frames: the same pipeline with the map-point records of orbx_search_by_projection_points
+extern "C" int orbx_search_by_projection_points_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
+                                                       const float *knew4, float min_x, float max_x, float min_y, float max_y,
+                                                       const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_map_points,
+                                                       const uint8_t *d_map_point_desc, const int32_t *d_np, int max_np, float th, float nnratio,
+                                                       void *d_kps_un, void *d_assign, void *d_nmatches)
+{
+    return searchByProjectionFramesImpl("orbx_search_by_projection_points_frames", 1, nnratio, m, ex, nframes, k4, dist, ndist, knew4, min_x, max_x, min_y, max_y,
+                                        0.f, d_u_right, d_cur_state, d_map_points, d_map_point_desc, d_np, max_np, th, 0, 0, 0, d_kps_un, d_assign, d_nmatches);
 }
 
 // Frame::ComputeStereoFishEyeMatches — reference src/Frame.cc:1156-1196: knnMatch on the lapping-area rows, Lowe's ratio, TriangulateMatches
