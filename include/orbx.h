@@ -284,6 +284,19 @@ int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *kc, const ui
                               float mbf, const orbx_projection *proj, const uint8_t *proj_desc, int np, float th, int forward,
                               int backward, int check_orientation, int32_t *assign);
 
+/* The CurrentFrame.Nleft != -1 branch of the same function (two KB8 fisheye cameras, reference src/ORBmatcher3.cc:300-436): per map point
+ * of the last frame the left window search on mGrid / mvKeys (no mvuRight test) and then the right one on mGridRight / mvKeysRight
+ * (:373-436), which writes CurrentFrame.mvpMapPoints[bestIdx2 + Nleft].  kc / dc = mvKeys followed by mvKeysRight / mDescriptors (the
+ * vconcat of both sides, src/Frame.cc:1138-1142); cur_state / assign run over n_left + n_right.  proj_left[i] = the projection with
+ * mpCamera as above, flags / octave / angle from the last frame's keypoint i (mvKeys or mvKeysRight, :300-301, :358-360); of
+ * proj_right[i] only u, v are read = mpCamera->project(GetRelativePoseTrl() * x3Dc) (:374-375).  The `continue`s of the left part
+ * (invzc < 0, uv outside the bounds, an empty left window :315) skip the right part too, as in the reference. */
+int orbx_search_by_projection_fisheye(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, int n_left, int n_right,
+                                      const int8_t *cur_state, float min_x, float max_x, float min_y, float max_y, const float *scale_factors,
+                                      int nlevels, const orbx_projection *proj_left, const orbx_projection *proj_right,
+                                      const uint8_t *proj_desc, int np, float th, int forward, int backward, int check_orientation,
+                                      int32_t *assign);
+
 /* The tracker's every-frame matcher over a BATCH of frames, device-resident end to end (nothing crosses PCIe between the extractor and
  * the match result): frame p = frame p of `ex`'s last batch; its keypoints go through Frame::UndistortKeyPoints (src/Frame.cc:777-811;
  * k4 / dist / knew4 as in orbx_undistort_keypoints, knew4 NULL = k4), Frame::AssignFeaturesToGrid (:387-418) over [min_x, max_x) x
@@ -355,6 +368,21 @@ int orbx_search_by_projection_points(orbx_matcher *m, const orbx_keypoint *kc, c
                                      const int8_t *cur_state, int nc, float min_x, float max_x, float min_y, float max_y,
                                      const float *scale_factors, int nlevels, const orbx_projection *map_points,
                                      const uint8_t *map_point_desc, int np, float th, float nnratio, int32_t *assign);
+
+/* The F.Nleft != -1 branch of the same function (two KB8 fisheye cameras, reference src/ORBmatcher1.cc:45-215): per map point the left
+ * search (mbTrackInView; mTrackProjX / Y, mTrackViewCos, mnTrackScaleLevel) and then the right one (mbTrackInViewR; mTrackProjXR / YR,
+ * mTrackViewCosR, mnTrackScaleLevelR != -1; radius without the th factor, :147) on mGridRight / mvKeysRight.  A match on one side is
+ * also written to the keypoint's stereo partner (left_to_right = F.mvLeftToRightMatch [n_left], right_to_left = F.mvRightToLeftMatch
+ * [n_right], -1 = none; :133-137, :198-202) and counted; a left ratio-test failure skips the point's right search (:126-127).
+ * kc / dc / cur_state / assign as in orbx_search_by_projection_fisheye.  map_points_left[i] / map_points_right[i]: u, v, angle (viewing
+ * cosine), octave (predicted level) of each side; flags bit 0 = mbTrackInView / mbTrackInViewR with the isBad() and far-point tests
+ * folded in, bit 1 (read from the left record) = Observations() > 0. */
+int orbx_search_by_projection_points_fisheye(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, int n_left, int n_right,
+                                             const int8_t *cur_state, float min_x, float max_x, float min_y, float max_y,
+                                             const float *scale_factors, int nlevels, const orbx_projection *map_points_left,
+                                             const orbx_projection *map_points_right, const uint8_t *map_point_desc, int np,
+                                             const int32_t *left_to_right, const int32_t *right_to_left, float th, float nnratio,
+                                             int32_t *assign);
 
 /* Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011: the row-band Hamming
  * stage above, then for every accepted left keypoint the 11x11 L1 sliding-window refinement (+-5 px) on

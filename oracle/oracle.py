@@ -71,6 +71,11 @@ def lib() -> ctypes.CDLL:
                                                   c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
         L.oracle_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
                                                          c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]
+        L.oracle_search_by_projection_fisheye.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
+                                                          c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
+        L.oracle_search_by_projection_points_fisheye.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float,
+                                                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                                 c_float, c_float, c_void_p]
         L.oracle_undistort_keypoints.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.oracle_compute_image_bounds.argtypes = [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         L.oracle_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -317,6 +322,47 @@ def search_by_projection_points(kc, dc, cur_state, bounds, scale_factors, mps, m
     n = lib().oracle_search_by_projection_points(kc.ctypes.data, dc.ctypes.data, None if ur is None else ur.ctypes.data, st.ctypes.data,
                                                  len(kc), *[float(b) for b in bounds], sf.ctypes.data, len(sf), pr.ctypes.data,
                                                  pd.ctypes.data, len(pr), float(th), float(nnratio), assign.ctypes.data)
+    return n, assign
+
+
+def search_by_projection_fisheye(kc, dc, n_left, cur_state, bounds, scale_factors, proj_l, proj_r, proj_desc, th, forward=False,
+                                 backward=False, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), CurrentFrame.Nleft != -1 (reference src/ORBmatcher3.cc:256-467).
+    kc / dc: mvKeys then mvKeysRight / mDescriptors; -> (nmatches, assign[n_left + n_right])."""
+    kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+    dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+    st = np.ascontiguousarray(cur_state, np.int8)
+    pl = np.ascontiguousarray(proj_l, PROJECTION_DTYPE)
+    pr = np.ascontiguousarray(proj_r, PROJECTION_DTYPE)
+    pd = np.ascontiguousarray(proj_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    assert len(pl) == len(pr) == len(pd) and len(st) == len(kc) == len(dc)
+    assign = np.full(len(kc), -1, np.int32)
+    n = lib().oracle_search_by_projection_fisheye(kc.ctypes.data, dc.ctypes.data, int(n_left), len(kc) - int(n_left), st.ctypes.data,
+                                                  *[float(b) for b in bounds], sf.ctypes.data, len(sf), pl.ctypes.data, pr.ctypes.data,
+                                                  pd.ctypes.data, len(pl), float(th), int(forward), int(backward),
+                                                  int(bool(check_orientation)), assign.ctypes.data)
+    return n, assign
+
+
+def search_by_projection_points_fisheye(kc, dc, n_left, cur_state, bounds, scale_factors, mp_l, mp_r, mp_desc, left_to_right, right_to_left,
+                                        th=1.0, nnratio=0.6):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ..), F.Nleft != -1 (reference src/ORBmatcher1.cc:45-215) -> (nmatches, assign)."""
+    kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+    dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+    st = np.ascontiguousarray(cur_state, np.int8)
+    pl = np.ascontiguousarray(mp_l, PROJECTION_DTYPE)
+    pr = np.ascontiguousarray(mp_r, PROJECTION_DTYPE)
+    pd = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    l2r = np.ascontiguousarray(left_to_right, np.int32)
+    r2l = np.ascontiguousarray(right_to_left, np.int32)
+    assert len(pl) == len(pr) == len(pd) and len(st) == len(kc) == len(dc) and len(l2r) == n_left and len(r2l) == len(kc) - n_left
+    assign = np.full(len(kc), -1, np.int32)
+    n = lib().oracle_search_by_projection_points_fisheye(kc.ctypes.data, dc.ctypes.data, int(n_left), len(kc) - int(n_left), st.ctypes.data,
+                                                         *[float(b) for b in bounds], sf.ctypes.data, len(sf), pl.ctypes.data,
+                                                         pr.ctypes.data, pd.ctypes.data, len(pl), l2r.ctypes.data, r2l.ctypes.data,
+                                                         float(th), float(nnratio), assign.ctypes.data)
     return n, assign
 
 

@@ -1247,6 +1247,167 @@ int oracle_search_by_projection_points(const oracle_keypoint *kc, const uint8_t 
     return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) — reference src/ORBmatcher3.cc:256-467,
+// branch CurrentFrame.Nleft != -1 (KB8 fisheye stereo rig): per last-frame map point the left window search (:300-372, on mGrid /
+// mvKeys, no mvuRight test) and then the right one (:373-436, on mGridRight / mvKeysRight, keypoint index + Nleft).  kc / dc =
+// mvKeys followed by mvKeysRight / mDescriptors (vconcat of both, Frame.cc:1138-1142), nc = n_left + n_right; cur_state / assign index
+// that combined range.  proj_l[i] = the projection with mpCamera (u, v, invzc, angle, octave, flags), proj_r[i].u / .v =
+// mpCamera->project(GetRelativePoseTrl() * x3Dc) (the reference projects the right side with mpCamera too, :375).  The `continue`s of
+// the left part (invzc < 0, uv outside the bounds, an empty left window :315) skip the right part as the reference does.
+int oracle_search_by_projection_fisheye(const oracle_keypoint *kc, const uint8_t *dc, int n_left, int n_right, const int8_t *cur_state,
+                                        float minX, float maxX, float minY, float maxY, const float *scale_factors, int nlevels,
+                                        const oracle_projection *proj_l, const oracle_projection *proj_r, const uint8_t *dproj, int np,
+                                        float th, int forward, int backward, int check_orientation, int32_t *assign)
+{
+    (void)nlevels;
+    const int TH_HIGH = 100, HISTO_LENGTH = 30, nc = n_left + n_right;
+    const oracle_keypoint *kr = kc + n_left;
+    const FrameGrid G = assignFeaturesToGrid(kc, n_left, minX, maxX, minY, maxY);
+    const FrameGrid GR = assignFeaturesToGrid(kr, n_right, minX, maxX, minY, maxY);
+    std::vector<int> mp(nc), obs(nc);
+    for (int i = 0; i < nc; ++i) { mp[i] = cur_state[i] < 0 ? -1 : -3; obs[i] = cur_state[i] > 0; }
+    int nmatches = 0;
+    std::vector<int> rotHist[30];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < np; i++) {
+        const oracle_projection &P = proj_l[i];
+        if (!(P.flags & 1)) continue;
+        if (P.invz < 0) continue;
+        if (P.u < minX || P.u > maxX) continue;
+        if (P.v < minY || P.v > maxY) continue;
+        const int nLastOctave = P.octave;
+        const float radius = th * scale_factors[nLastOctave];
+        const uint8_t *dMP = dproj + (size_t)i * 32;
+        for (int side = 0; side < 2; ++side) {
+            const FrameGrid &g = side ? GR : G;
+            const oracle_keypoint *k = side ? kr : kc;
+            const int base = side ? n_left : 0;
+            const float u = side ? proj_r[i].u : P.u, v = side ? proj_r[i].v : P.v;
+            std::vector<size_t> vIndices2;
+            if (forward) vIndices2 = getFeaturesInArea(g, k, u, v, radius, nLastOctave, -1);
+            else if (backward) vIndices2 = getFeaturesInArea(g, k, u, v, radius, 0, nLastOctave);
+            else vIndices2 = getFeaturesInArea(g, k, u, v, radius, nLastOctave - 1, nLastOctave + 1);
+            if (side == 0 && vIndices2.empty()) break;  // :315 `continue` leaves the right part out as well
+            int bestDist = 256, bestIdx2 = -1;
+            for (size_t c = 0; c < vIndices2.size(); ++c) {
+                const size_t i2 = vIndices2[c] + base;
+                if (mp[i2] != -1 && mp[i2] != -2)
+                    if (obs[i2]) continue;
+                const int dist = oracle_hamming256(dMP, dc + i2 * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+            }
+            if (bestDist <= TH_HIGH) {
+                mp[bestIdx2] = i; obs[bestIdx2] = (P.flags >> 1) & 1;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = P.angle - kc[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdx2);
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[30];
+        for (int i = 0; i < HISTO_LENGTH; ++i) sizes[i] = (int)rotHist[i].size();
+        computeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { mp[rotHist[i][j]] = -2; nmatches--; }
+    }
+    for (int i = 0; i < nc; ++i) assign[i] = mp[i] == -3 ? -1 : mp[i];
+    return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, ..) — reference src/ORBmatcher1.cc:45-215, branch
+// F.Nleft != -1.  mp_l[i] = {mTrackProjX, mTrackProjY, -, mTrackViewCos, mnTrackScaleLevel, flags} (flag bit 0 = mbTrackInView), mp_r[i] =
+// {mTrackProjXR, mTrackProjYR, -, mTrackViewCosR, mnTrackScaleLevelR, flags} (bit 0 = mbTrackInViewR); the caller clears bit 0 on both
+// for isBad() / far points.  left_to_right / right_to_left = F.mvLeftToRightMatch / mvRightToLeftMatch: a match on one side is copied to
+// its stereo partner (:133-137, :198-202) without looking at what the partner slot held.  A left ratio-test failure `continue`s past the
+// right search (:126-127); the right radius takes no th factor (:147).
+int oracle_search_by_projection_points_fisheye(const oracle_keypoint *kc, const uint8_t *dc, int n_left, int n_right, const int8_t *cur_state,
+                                               float minX, float maxX, float minY, float maxY, const float *scale_factors, int nlevels,
+                                               const oracle_projection *mp_l, const oracle_projection *mp_r, const uint8_t *dmp, int np,
+                                               const int32_t *left_to_right, const int32_t *right_to_left, float th, float nnratio,
+                                               int32_t *assign)
+{
+    (void)nlevels;
+    const int TH_HIGH = 100, nc = n_left + n_right;
+    const oracle_keypoint *kr = kc + n_left;
+    const FrameGrid G = assignFeaturesToGrid(kc, n_left, minX, maxX, minY, maxY);
+    const FrameGrid GR = assignFeaturesToGrid(kr, n_right, minX, maxX, minY, maxY);
+    std::vector<int> mp(nc), obs(nc);
+    for (int i = 0; i < nc; ++i) { mp[i] = cur_state[i] < 0 ? -1 : -3; obs[i] = cur_state[i] > 0; }
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < np; iMP++) {
+        const oracle_projection &L = mp_l[iMP], &R = mp_r[iMP];
+        if (!(L.flags & 1) && !(R.flags & 1)) continue;
+        const uint8_t *MPdescriptor = dmp + (size_t)iMP * 32;
+        const int o = (L.flags >> 1) & 1;
+        if (L.flags & 1) {
+            const int nPredictedLevel = L.octave;
+            float r = L.angle > 0.998 ? 2.5 : 4.0;
+            if (bFactor) r *= th;
+            const std::vector<size_t> vIndices =
+                getFeaturesInArea(G, kc, L.u, L.v, r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+            if (!vIndices.empty()) {
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (size_t c = 0; c < vIndices.size(); ++c) {
+                    const size_t idx = vIndices[c];
+                    if (mp[idx] != -1)
+                        if (obs[idx]) continue;
+                    const int dist = oracle_hamming256(MPdescriptor, dc + idx * 32);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kc[idx].octave; bestIdx = (int)idx; }
+                    else if (dist < bestDist2) { bestLevel2 = kc[idx].octave; bestDist2 = dist; }
+                }
+                if (bestDist <= TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                    if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                        mp[bestIdx] = iMP; obs[bestIdx] = o;
+                        if (left_to_right[bestIdx] != -1) {
+                            mp[left_to_right[bestIdx] + n_left] = iMP; obs[left_to_right[bestIdx] + n_left] = o;
+                            nmatches++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+        }
+        if (R.flags & 1) {
+            const int nPredictedLevel = R.octave;
+            if (nPredictedLevel != -1) {
+                const float r = R.angle > 0.998 ? 2.5 : 4.0;
+                const std::vector<size_t> vIndices =
+                    getFeaturesInArea(GR, kr, R.u, R.v, r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+                if (vIndices.empty()) continue;
+                int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+                for (size_t c = 0; c < vIndices.size(); ++c) {
+                    const size_t idx = vIndices[c];
+                    if (mp[idx + n_left] != -1)
+                        if (obs[idx + n_left]) continue;
+                    const int dist = oracle_hamming256(MPdescriptor, dc + (idx + n_left) * 32);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kr[idx].octave; bestIdx = (int)idx; }
+                    else if (dist < bestDist2) { bestLevel2 = kr[idx].octave; bestDist2 = dist; }
+                }
+                if (bestDist <= TH_HIGH) {
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                    if (right_to_left[bestIdx] != -1) {
+                        mp[right_to_left[bestIdx]] = iMP; obs[right_to_left[bestIdx]] = o;
+                        nmatches++;
+                    }
+                    mp[bestIdx + n_left] = iMP; obs[bestIdx + n_left] = o;
+                    nmatches++;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < nc; ++i) assign[i] = mp[i] == -3 ? -1 : mp[i];
+    return nmatches;
+}
+
 // cv::undistortPoints(src, dst, cameraMatrix, distCoeffs, R = noArray(), P) as Frame::UndistortKeyPoints / ComputeImageBounds call it
 // (reference src/Frame.cc:777-811, :813-845; OpenCV is an external dependency of the reference, not vendored: 4.x, calib3d
 // cvUndistortPointsInternal restated here from its published source — parity unpinned): everything in double, five fixed-point

@@ -131,6 +131,18 @@ int oracle_search_by_projection_points(const oracle_keypoint *kc, const uint8_t 
                                        float min_x, float max_x, float min_y, float max_y, const float *scale_factors, int nlevels,
                                        const oracle_projection *mps, const uint8_t *dmp, int np, float th, float nnratio, int32_t *assign);
 
+/* The CurrentFrame.Nleft != -1 (KB8 fisheye rig) branches of the two functions above (src/ORBmatcher3.cc:300-436,
+ * src/ORBmatcher1.cc:45-215): kc / dc = mvKeys then mvKeysRight / mDescriptors, cur_state / assign over n_left + n_right. */
+int oracle_search_by_projection_fisheye(const oracle_keypoint *kc, const uint8_t *dc, int n_left, int n_right, const int8_t *cur_state,
+                                        float min_x, float max_x, float min_y, float max_y, const float *scale_factors, int nlevels,
+                                        const oracle_projection *proj_l, const oracle_projection *proj_r, const uint8_t *dproj, int np,
+                                        float th, int forward, int backward, int check_orientation, int32_t *assign);
+int oracle_search_by_projection_points_fisheye(const oracle_keypoint *kc, const uint8_t *dc, int n_left, int n_right, const int8_t *cur_state,
+                                               float min_x, float max_x, float min_y, float max_y, const float *scale_factors, int nlevels,
+                                               const oracle_projection *mp_l, const oracle_projection *mp_r, const uint8_t *dmp, int np,
+                                               const int32_t *left_to_right, const int32_t *right_to_left, float th, float nnratio,
+                                               int32_t *assign);
+
 /* Frame::UndistortKeyPoints / Frame::ComputeImageBounds (src/Frame.cc:777-845) over cv::undistortPoints (OpenCV 4.x, restated;
  * parity unpinned).  k4 / knew4 = fx, fy, cx, cy of toK() / mK; dist = mDistCoef (4, 5, 8 or 12 floats). */
 int oracle_undistort_keypoints(const oracle_keypoint *kps, int n, const float *k4, const float *dist, int ndist, const float *knew4,

@@ -479,3 +479,19 @@ def test_kb8_smallest_singular_vector_matches_numpy(orc):
         A = np.stack([r1[0] * T1[2] - T1[0], r1[1] * T1[2] - T1[1], r2[0] * T2[2] - T2[0], r2[1] * T2[2] - T2[1]])
         v = np.linalg.svd(A)[2][3]
         assert np.allclose(p, v[:3] / v[3], rtol=2e-3, atol=1e-3), i
+
+
+def test_fisheye_search_by_projection_known_answers(orc):
+    """The Nleft != -1 branches restated in the oracle, against hand-traced cases (tests/fisheye_sbp_kat.py): the stereo-partner write that
+    frees a keypoint, the `continue`s that skip the right search, the right radius without the th factor."""
+    import fisheye_sbp_kat as kat
+    for name, mode, kw, n_exp, a_exp in kat.cases(orc.KEYPOINT_DTYPE, orc.PROJECTION_DTYPE):
+        kw = dict(kw)
+        if mode == "points":
+            n, a = orc.search_by_projection_points_fisheye(kw.pop("kc"), kw.pop("dc"), kw.pop("n_left"), kw.pop("cur_state"), kat.BOUNDS, kat.SCALE,
+                                                           kw.pop("mp_l"), kw.pop("mp_r"), kw.pop("mp_desc"), kw.pop("left_to_right"),
+                                                           kw.pop("right_to_left"), **kw)
+        else:
+            n, a = orc.search_by_projection_fisheye(kw.pop("kc"), kw.pop("dc"), kw.pop("n_left"), kw.pop("cur_state"), kat.BOUNDS, kat.SCALE,
+                                                    kw.pop("proj_l"), kw.pop("proj_r"), kw.pop("proj_desc"), kw.pop("th"), **kw)
+        assert n == n_exp and np.array_equal(a, a_exp), (name, n, a)

@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_search_by_projection_frames", "orbx_search_by_projection_points_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
-    "orbx_search_by_projection_points",
+    "orbx_search_by_projection_points", "orbx_search_by_projection_fisheye", "orbx_search_by_projection_points_fisheye",
     "orbx_search_by_bow",
     "orbx_search_by_bow_keyframes",
     "orbx_undistort_keypoints",
@@ -152,6 +152,11 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_assign_features_to_grid.argtypes = [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p]
     lib.orbx_search_for_initialization.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
                                                    c_float, c_void_p, c_void_p, c_int, c_float, c_int]
+    lib.orbx_search_by_projection_fisheye.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
+                                                      c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
+    lib.orbx_search_by_projection_points_fisheye.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_float, c_float,
+                                                             c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
+                                                             c_float, c_void_p]
     lib.orbx_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
                                               c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
     lib.orbx_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
@@ -668,6 +673,51 @@ class ORBmatcher:
                                                        pr.ctypes.data, pd.ctypes.data, len(pr), float(th), float(nnratio), assign.ctypes.data)
         if n < 0:
             _check(n, "orbx_search_by_projection_points")
+        return n, assign
+
+    def SearchByProjectionFisheye(self, kc, dc, n_left: int, cur_state, bounds, scale_factors, proj_left, proj_right, proj_desc, th: float, *,
+                                  forward: bool = False, backward: bool = False, checkOrientation: bool = True):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), CurrentFrame.Nleft != -1 (reference src/ORBmatcher3.cc:300-436):
+        kc / dc = mvKeys then mvKeysRight / mDescriptors; proj_right[i].u / .v = the projection into the right camera.  Returns
+        (nmatches, assign[n_left + n_right])."""
+        kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+        dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+        st = np.ascontiguousarray(cur_state, np.int8)
+        pl = np.ascontiguousarray(proj_left, PROJECTION_DTYPE)
+        pr = np.ascontiguousarray(proj_right, PROJECTION_DTYPE)
+        pd = np.ascontiguousarray(proj_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        assert len(st) == len(kc) == len(dc) and len(pd) == len(pl) == len(pr) and 0 <= n_left <= len(kc)
+        assign = np.full(len(kc), -1, np.int32)
+        n = self._lib.orbx_search_by_projection_fisheye(self._h, kc.ctypes.data, dc.ctypes.data, int(n_left), len(kc) - int(n_left), st.ctypes.data,
+                                                        *[float(b) for b in bounds], sf.ctypes.data, len(sf), pl.ctypes.data, pr.ctypes.data,
+                                                        pd.ctypes.data, len(pl), float(th), int(forward), int(backward), int(checkOrientation),
+                                                        assign.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_projection_fisheye")
+        return n, assign
+
+    def SearchByProjectionPointsFisheye(self, kc, dc, n_left: int, cur_state, bounds, scale_factors, map_points_left, map_points_right, mp_desc,
+                                        left_to_right, right_to_left, th: float = 1.0, nnratio: float = 0.6):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th, ..), F.Nleft != -1 (reference src/ORBmatcher1.cc:45-215).  Returns
+        (nmatches, assign[n_left + n_right])."""
+        kc = np.ascontiguousarray(kc, KEYPOINT_DTYPE)
+        dc = np.ascontiguousarray(dc, np.uint8).reshape(-1, 32)
+        st = np.ascontiguousarray(cur_state, np.int8)
+        pl = np.ascontiguousarray(map_points_left, PROJECTION_DTYPE)
+        pr = np.ascontiguousarray(map_points_right, PROJECTION_DTYPE)
+        pd = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        l2r = np.ascontiguousarray(left_to_right, np.int32)
+        r2l = np.ascontiguousarray(right_to_left, np.int32)
+        assert len(st) == len(kc) == len(dc) and len(pd) == len(pl) == len(pr) and len(l2r) == n_left and len(r2l) == len(kc) - n_left
+        assign = np.full(len(kc), -1, np.int32)
+        n = self._lib.orbx_search_by_projection_points_fisheye(self._h, kc.ctypes.data, dc.ctypes.data, int(n_left), len(kc) - int(n_left),
+                                                               st.ctypes.data, *[float(b) for b in bounds], sf.ctypes.data, len(sf),
+                                                               pl.ctypes.data, pr.ctypes.data, pd.ctypes.data, len(pl), l2r.ctypes.data,
+                                                               r2l.ctypes.data, float(th), float(nnratio), assign.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_projection_points_fisheye")
         return n, assign
 
 

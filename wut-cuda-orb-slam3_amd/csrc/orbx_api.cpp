@@ -1580,6 +1580,108 @@ extern "C" int orbx_search_by_projection_points(orbx_matcher *m, const orbx_keyp
                                   map_point_desc, np, th, 0, 0, 0, 1, nnratio, assign);
 }
 
+// The CurrentFrame.Nleft != -1 branches (KB8 fisheye rig) of both SearchByProjection functions — reference src/ORBmatcher3.cc:300-436 and
+// src/ORBmatcher1.cc:45-215.
+static int searchByProjectionFisheyeImpl(const char *fn, orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, int n_left, int n_right,
+                                         const int8_t *cur_state, float min_x, float max_x, float min_y, float max_y,
+                                         const float *scale_factors, int nlevels, const orbx_projection *pl, const orbx_projection *pr,
+                                         const uint8_t *proj_desc, int np, const int32_t *left_to_right, const int32_t *right_to_left,
+                                         float th, int forward, int backward, int check_orientation, int mode, float nnratio, int32_t *assign)
+{
+    const long long ncl = (long long)n_left + n_right;
+    if (!m || n_left < 0 || n_right < 0 || np < 0 || (ncl > 0 && (!kc || !dc || !cur_state || !assign)) || (np > 0 && (!pl || !pr || !proj_desc)) ||
+        !scale_factors || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(th >= 0.f) || (mode == 1 && ((n_left > 0 && !left_to_right) || (n_right > 0 && !right_to_left))))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    if (2LL * np > m->maxQ || ncl > m->maxT)
+        return setError(ORBX_ERR_CAPACITY, "%s: %d steps x %lld keypoints exceed the matcher capacity %d x %d", fn, 2 * np, ncl, m->maxQ, m->maxT);
+    if (ncl >= 65536) return setError(ORBX_ERR_CAPACITY, "%s: at most 65535 keypoints in the current frame", fn);
+    const int nc = (int)ncl;
+    int rc = checkGridBounds(min_x, max_x, min_y, max_y, fn);
+    if (rc != ORBX_OK) return rc;
+    // the steps of point i: 2 i = its left record, 2 i + 1 = its right record
+    std::vector<orbx_projection> steps(2 * (size_t)np);
+    for (int i = 0; i < np; ++i) {
+        orbx_projection L = pl[i], R = pr[i];
+        if (mode == 0) { R.octave = L.octave; R.angle = L.angle; R.flags = L.flags; R.invz = L.invz; }  // one keypoint of the last frame behind both
+        else { if (R.octave == -1) R.flags &= ~1; R.flags = (R.flags & ~2) | (L.flags & 2); }          // one map point behind both
+        if (((L.flags & 1) && (L.octave < 0 || L.octave >= nlevels)) || ((R.flags & 1) && (R.octave < 0 || R.octave >= nlevels)))
+            return setError(ORBX_ERR_INVALID_ARG, "%s: point %d has a level outside [0,%d)", fn, i, nlevels);
+        steps[2 * (size_t)i] = L; steps[2 * (size_t)i + 1] = R;
+    }
+    std::vector<int> partner;
+    if (mode == 1) {
+        partner.assign((size_t)nc, -1);
+        for (int i = 0; i < n_left; ++i) {
+            if (left_to_right[i] < -1 || left_to_right[i] >= n_right) return setError(ORBX_ERR_INVALID_ARG, "%s: left_to_right[%d] = %d", fn, i, left_to_right[i]);
+            if (left_to_right[i] >= 0) partner[i] = n_left + left_to_right[i];
+        }
+        for (int i = 0; i < n_right; ++i) {
+            if (right_to_left[i] < -1 || right_to_left[i] >= n_left) return setError(ORBX_ERR_INVALID_ARG, "%s: right_to_left[%d] = %d", fn, i, right_to_left[i]);
+            if (right_to_left[i] >= 0) partner[(size_t)n_left + i] = right_to_left[i];
+        }
+    }
+    if (nc == 0) return 0;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, proj_desc, np, dc, nc)) != ORBX_OK) return rc;
+    const size_t gridInts = (size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT;  // cellStart, items, cellOf of one grid
+    if ((rc = m->d_grid.ensure(2 * gridInts)) != ORBX_OK) return rc;
+    // work: count[maxQ], choice[maxQ], next[2 maxQ], head[maxT], partner[maxT], assign[maxT], result[2], curState (maxT bytes)
+    const size_t workInts = 4 * (size_t)m->maxQ + 3 * (size_t)m->maxT + 2 + ((size_t)m->maxT + 3) / 4 + 4;
+    if ((rc = m->d_work.ensure(workInts)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_CAP)) != ORBX_OK) return rc;
+    if ((rc = m->d_proj.ensure((size_t)m->maxQ)) != ORBX_OK) return rc;
+    int *csL = m->d_grid.p, *itL = csL + ORBX_GRID_CELLS + 1, *coL = itL + m->maxT;
+    int *csR = m->d_grid.p + gridInts, *itR = csR + ORBX_GRID_CELLS + 1, *coR = itR + m->maxT;
+    int *count = m->d_work.p, *choice = count + m->maxQ, *next = choice + m->maxQ, *head = next + 2 * (size_t)m->maxQ, *dPartner = head + m->maxT,
+        *dAssign = dPartner + m->maxT, *result = dAssign + m->maxT;
+    signed char *dState = (signed char *)(result + 2);
+    HIP_TRY(hipMemcpyAsync(m->d_kr.p, kc, (size_t)nc * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(dState, cur_state, (size_t)nc, hipMemcpyHostToDevice, m->stream));
+    if (np > 0) HIP_TRY(hipMemcpyAsync(m->d_proj.p, steps.data(), steps.size() * sizeof(orbx_projection), hipMemcpyHostToDevice, m->stream));
+    if (mode == 1) HIP_TRY(hipMemcpyAsync(dPartner, partner.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n_left, min_x, max_x, min_y, max_y, csL, itL, coL));
+    HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p + n_left, n_right, min_x, max_x, min_y, max_y, csR, itR, coR));
+    OrbxSbpFisheye f;
+    f.kc = m->d_kr.p; f.dc = m->d_t.p; f.curState = dState; f.nLeft = n_left; f.nRight = n_right;
+    f.cellStartL = csL; f.itemsL = itL; f.cellStartR = csR; f.itemsR = itR;
+    f.minX = min_x; f.maxX = max_x; f.minY = min_y; f.maxY = max_y; f.scale = m->d_scale.p;
+    f.steps = m->d_proj.p; f.dproj = m->d_q.p; f.np = np;
+    f.th = th; f.forward = forward != 0; f.backward = backward != 0; f.checkOri = check_orientation != 0; f.mode = mode; f.nnratio = nnratio;
+    f.partner = mode == 1 ? dPartner : nullptr;
+    f.cand = m->d_sbpCand.p; f.count = count; f.choice = choice; f.head = head; f.next = next; f.assign = dAssign; f.result = result;
+    HIP_TRY(orbxLaunchSearchByProjectionFisheye(m->stream, f));
+    int res[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(assign, dAssign, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(res, result, sizeof res, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));  // (also keeps `steps` / `partner` alive until the uploads have been consumed)
+    if (res[1]) return setError(ORBX_ERR_CAPACITY, "%s: a search window holds more than %d candidates", fn, ORBX_SBP_CAP);
+    return res[0];
+}
+
+extern "C" int orbx_search_by_projection_fisheye(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, int n_left, int n_right,
+                                                 const int8_t *cur_state, float min_x, float max_x, float min_y, float max_y,
+                                                 const float *scale_factors, int nlevels, const orbx_projection *proj_left,
+                                                 const orbx_projection *proj_right, const uint8_t *proj_desc, int np, float th, int forward,
+                                                 int backward, int check_orientation, int32_t *assign)
+{
+    return searchByProjectionFisheyeImpl("orbx_search_by_projection_fisheye", m, kc, dc, n_left, n_right, cur_state, min_x, max_x, min_y, max_y,
+                                         scale_factors, nlevels, proj_left, proj_right, proj_desc, np, nullptr, nullptr, th, forward, backward,
+                                         check_orientation, 0, 0.f, assign);
+}
+
+extern "C" int orbx_search_by_projection_points_fisheye(orbx_matcher *m, const orbx_keypoint *kc, const uint8_t *dc, int n_left, int n_right,
+                                                        const int8_t *cur_state, float min_x, float max_x, float min_y, float max_y,
+                                                        const float *scale_factors, int nlevels, const orbx_projection *map_points_left,
+                                                        const orbx_projection *map_points_right, const uint8_t *map_point_desc, int np,
+                                                        const int32_t *left_to_right, const int32_t *right_to_left, float th, float nnratio,
+                                                        int32_t *assign)
+{
+    return searchByProjectionFisheyeImpl("orbx_search_by_projection_points_fisheye", m, kc, dc, n_left, n_right, cur_state, min_x, max_x, min_y,
+                                         max_y, scale_factors, nlevels, map_points_left, map_points_right, map_point_desc, np, left_to_right,
+                                         right_to_left, th, 0, 0, 0, 1, nnratio, assign);
+}
+
 // Frame::ComputeStereoMatches, complete — reference src/Frame.cc:841-1011.
 extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left, int frame_left, orbx_extractor *right, int frame_right,
                                            const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr, const uint8_t *dr,

@@ -200,5 +200,17 @@ hipError_t orbxLaunchGatherResults(hipStream_t st, const int *result, int n, int
 // a batch of frames through the SearchByProjection kernels: per-frame strides (records) and device-side counts
 struct OrbxSbpBatch { int nframes; long long kcStride, projStride; const int *ncDev, *npDev; };
 #define ORBX_SBP_CAP 512  // == SBP_CAP in orbx_match.hip
+// the CurrentFrame.Nleft != -1 (fisheye rig) branches: kc / dc = left then right keypoints, one grid per side, steps[2 np] = the left and
+// right record of every point interleaved, dproj[np]; partner[nLeft + nRight] (mode 1) or NULL
+struct OrbxSbpFisheye {
+    const void *kc; const uint8_t *dc; const signed char *curState; int nLeft, nRight;
+    const int *cellStartL, *itemsL, *cellStartR, *itemsR;
+    float minX, maxX, minY, maxY; const float *scale;
+    const void *steps; const uint8_t *dproj; int np;
+    float th; int forward, backward, checkOri, mode; float nnratio;
+    const int *partner;
+    uint32_t *cand; int *count, *choice, *head, *next, *assign, *result;
+};
+hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFisheye &f);
 
 #endif

@@ -975,6 +975,12 @@ struct SbpArgs {
     // batch of frames (blockIdx.y of k_sbp_candidates / blockIdx.x of k_sbp_resolve): per-frame strides in records, counts on the device
     long long kcStride, projStride;
     const int *ncDev, *npDev;
+    // CurrentFrame.Nleft != -1 (KB8 fisheye rig): kc / dc = mvKeys then mvKeysRight, nc = nLeft + nRight; a "step" 2 i / 2 i + 1 is the
+    // left / right window search of point i (proj[] holds the steps interleaved, dproj one descriptor per point); np = number of steps
+    int nLeft;                        // -1: not a fisheye frame
+    const int *cellStartR, *itemsR;   // mGridRight over kc + nLeft
+    const int *partner;               // [nc] mvLeftToRightMatch / mvRightToLeftMatch as combined indices, -1 none; NULL in mode 0
+    int *head, *next;                 // [nc], [2 np] work of k_sbp_resolve_fe: writers of a keypoint as linked lists
 };
 
 // frame p of a batch: every per-frame array advances by its stride, the counts come from the device arrays
@@ -998,9 +1004,13 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     if (i >= a.np) return;
     const SbpProj P = a.proj[i];
     int *cnt = a.count + i;
-    bool search = (P.flags & 1) != 0;
-    if (a.mode == 0) search = search && !(P.invz < 0) && !(P.u < a.minX || P.u > a.maxX) && !(P.v < a.minY || P.v > a.maxY);
+    const bool fe = a.nLeft >= 0;
+    const int side = fe ? (i & 1) : 0, base = side ? a.nLeft : 0;
+    bool search = (P.flags & 1) != 0 && P.octave >= 0;  // (mnTrackScaleLevelR == -1: src/ORBmatcher1.cc:145)
+    // the right step of a frame-to-frame search has no test of its own; k_sbp_resolve_fe drops it when the left one was skipped (:315)
+    if (a.mode == 0 && side == 0) search = search && !(P.invz < 0) && !(P.u < a.minX || P.u > a.maxX) && !(P.v < a.minY || P.v > a.maxY);
     if (!search) { if (lane == 0) *cnt = -1; return; }
+    if (side) { a.kc += a.nLeft; a.dc += (size_t)a.nLeft * 32; a.cellStart = a.cellStartR; a.items = a.itemsR; }
     const int lastOct = P.octave;
     float r;
     int minLevel, maxLevel;
@@ -1011,7 +1021,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
         else { minLevel = lastOct - 1; maxLevel = lastOct + 1; }
     } else {
         float rv = (double)P.angle > 0.998 ? 2.5f : 4.0f;  // ORBmatcher::RadiusByViewingCos (src/ORBmatcher1.cc:217-223), a double compare
-        if (a.th != 1.0f) rv = __fmul_rn(rv, a.th);
+        if (a.th != 1.0f && side == 0) rv = __fmul_rn(rv, a.th);  // (the right search of a fisheye frame takes no th factor, :147)
         r = __fmul_rn(rv, a.scale[lastOct]);
         minLevel = lastOct - 1; maxLevel = lastOct;
     }
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     if (cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0) { if (lane == 0) *cnt = 0; return; }
     uint32_t q[8];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.dproj + (size_t)i * 32))[w];
+    for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.dproj + (size_t)(fe ? i >> 1 : i) * 32))[w];
     const float ur = a.mode == 0 ? __fsub_rn(x, __fmul_rn(a.mbf, P.invz)) : P.invz;  // mode 1: mTrackProjXR
     const int ny = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny;
     uint32_t *out = a.cand + (size_t)i * SBP_CAP;
@@ -1070,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
             const unsigned long long m = __ballot(keep);
             const int pos = nOut + __popcll(m & ((1ull << lane) - 1ull));
             if (keep) {
-                if (pos < SBP_CAP) out[pos] = (uint32_t)i2 | ((uint32_t)dist << 16) | ((uint32_t)oct << 25);
+                if (pos < SBP_CAP) out[pos] = (uint32_t)(i2 + base) | ((uint32_t)dist << 16) | ((uint32_t)oct << 25);
                 else overflow = true;
             }
             nOut += __popcll(m);
@@ -1161,6 +1171,129 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
     if (tid == 0) a.result[0] = nAcc;
 }
 
+// The Nleft != -1 branches of both SearchByProjection functions (src/ORBmatcher3.cc:300-436, src/ORBmatcher1.cc:45-215).  The reference
+// walks the points in order and per point first the left, then the right search ("steps" 2 i, 2 i + 1); a step may not take a keypoint whose
+// CURRENT map point has Observations() > 0.  In the map-point variant a match is also written to the keypoint's stereo partner without
+// that test (:133-137, :198-202), so the holder of a keypoint can change to a point WITHOUT observations and free it again: what step s
+// sees is the LAST writer before s.  Same fixed point as k_sbp_resolve - every step recomputes its choice from the writers of the previous
+// round until nothing changes; step s depends only on steps < s, so the result is the sequential one - with the writers of a keypoint
+// kept as a linked list (head[k] -> node 2 s + {0 direct, 1 partner}).
+__global__ __launch_bounds__(1024) void k_sbp_resolve_fe(SbpArgs a)
+{
+    const int TH_HIGH = 100, HISTO_LENGTH = 30;
+    const int tid = threadIdx.x, S = a.np, nc = a.nc;
+    __shared__ int changed, hist[32], nAcc;
+    for (int i = tid; i < nc; i += 1024) { a.head[i] = -1; a.assign[i] = -1; }
+    for (int i = tid; i < S; i += 1024) a.choice[i] = -1;
+    if (tid < 32) hist[tid] = 0;
+    if (tid == 0) nAcc = 0;
+    __syncthreads();
+    for (int round = 0; round <= S + 1; ++round) {
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (int pt = tid; 2 * pt < S; pt += 1024) {
+            bool skipRight = false;
+            for (int side = 0; side < 2; ++side) {
+                const int s = 2 * pt + side;
+                const int n = a.count[s];
+                int ch = -1;
+                if (side == 0 && a.mode == 0 && n <= 0) skipRight = true;  // the left part's `continue`s leave the right part out
+                if (n > 0 && !(side && skipRight)) {
+                    int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1;
+                    const uint32_t *lst = a.cand + (size_t)s * SBP_CAP;
+                    for (int c = 0; c < n; ++c) {
+                        const uint32_t e = lst[c];
+                        const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
+                        int last = -1;  // the last step before s that wrote mvpMapPoints[i2]
+                        for (int nd = a.head[i2]; nd >= 0; nd = a.next[nd]) { const int w = nd >> 1; if (w < s && w > last) last = w; }
+                        if (last >= 0 ? (a.proj[last].flags & 2) != 0 : (a.curState && a.curState[i2] > 0)) continue;
+                        if (dist < best) { best2 = best; bestL2 = bestL; best = dist; bestL = lv; bestI = i2; }
+                        else if (dist < best2) { best2 = dist; bestL2 = lv; }
+                    }
+                    ch = best <= TH_HIGH ? bestI : -1;
+                    if (a.mode == 1 && ch >= 0 && bestL == bestL2 && (float)best > __fmul_rn(a.nnratio, (float)best2)) {
+                        ch = -1;
+                        if (side == 0) skipRight = true;  // src/ORBmatcher1.cc:126-127: `continue` to the next map point
+                    }
+                }
+                if (a.choice[s] != ch) { a.choice[s] = ch; changed = 1; }
+            }
+        }
+        __syncthreads();
+        const int chg = changed;
+        for (int i = tid; i < nc; i += 1024) a.head[i] = -1;
+        __syncthreads();
+        if (!chg) break;
+        for (int s = tid; s < S; s += 1024) {
+            const int ch = a.choice[s];
+            if (ch < 0) continue;
+            a.next[2 * s] = atomicExch(&a.head[ch], 2 * s);
+            const int pk = a.partner ? a.partner[ch] : -1;
+            if (pk >= 0) a.next[2 * s + 1] = atomicExch(&a.head[pk], 2 * s + 1);
+        }
+        __syncthreads();
+    }
+    // mvpMapPoints[k] = the map point of the last writer; nmatches counts every write
+    for (int s = tid; s < S; s += 1024) {
+        const int ch = a.choice[s];
+        if (ch < 0) continue;
+        atomicMax(&a.assign[ch], s >> 1);
+        int cntW = 1;
+        const int pk = a.partner ? a.partner[ch] : -1;
+        if (pk >= 0) { atomicMax(&a.assign[pk], s >> 1); ++cntW; }
+        atomicAdd(&nAcc, cntW);
+        if (a.checkOri) {
+            float rot = __fsub_rn(a.proj[s].angle, a.kc[ch].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+            if (bin == HISTO_LENGTH) bin = 0;
+            atomicAdd(&hist[bin], 1);
+            a.choice[s] = ch | (bin << 16);
+        }
+    }
+    __syncthreads();
+    if (a.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima
+            const int c = hist[i];
+            if (c > max1) { max3 = max2; max2 = max1; max1 = c; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (c > max2) { max3 = max2; max2 = c; ind3 = ind2; ind2 = i; }
+            else if (c > max3) { max3 = c; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        __syncthreads();
+        for (int s = tid; s < S; s += 1024) {
+            const int c = a.choice[s];
+            if (c < 0) continue;
+            const int bin = c >> 16, ch = c & 0xFFFF;
+            if (bin != ind1 && bin != ind2 && bin != ind3) { a.assign[ch] = -2; atomicSub(&nAcc, 1); }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) a.result[0] = nAcc;
+}
+
+hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFisheye &f)
+{
+    SbpArgs a;
+    a.kcStride = 0; a.projStride = 0; a.ncDev = nullptr; a.npDev = nullptr;
+    a.mode = f.mode; a.nnratio = f.nnratio;
+    a.kc = (const MtKp *)f.kc; a.dc = f.dc; a.uRight = nullptr; a.curState = f.curState; a.nc = f.nLeft + f.nRight;
+    a.cellStart = f.cellStartL; a.items = f.itemsL; a.cellStartR = f.cellStartR; a.itemsR = f.itemsR;
+    a.b.minX = f.minX; a.b.minY = f.minY; a.b.invW = (float)GRID_COLS / (f.maxX - f.minX); a.b.invH = (float)GRID_ROWS / (f.maxY - f.minY);
+    a.minX = f.minX; a.maxX = f.maxX; a.minY = f.minY; a.maxY = f.maxY;
+    a.scale = f.scale; a.mbf = 0.f; a.proj = (const SbpProj *)f.steps; a.dproj = f.dproj; a.np = 2 * f.np;
+    a.th = f.th; a.forward = f.forward; a.backward = f.backward; a.checkOri = f.checkOri;
+    a.cand = f.cand; a.count = f.count; a.choice = f.choice; a.owner = nullptr; a.assign = f.assign; a.result = f.result;
+    a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next;
+    hipError_t e = hipMemsetAsync(f.result, 0, 2 * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    if (f.np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(2 * f.np, 1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_sbp_resolve_fe, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const uint8_t *dc, const float *uRight, const signed char *curState,
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
                                         const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
@@ -1180,6 +1313,7 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
     a.scale = scale; a.mbf = mbf; a.proj = (const SbpProj *)proj; a.dproj = dproj; a.np = np;
     a.th = th; a.forward = forward; a.backward = backward; a.checkOri = checkOri;
     a.cand = cand; a.count = count; a.choice = choice; a.owner = owner; a.assign = assign; a.result = result;
+    a.nLeft = -1; a.cellStartR = nullptr; a.itemsR = nullptr; a.partner = nullptr; a.head = nullptr; a.next = nullptr;
     hipError_t e = hipMemsetAsync(result, 0, (size_t)nframes * 2 * sizeof(int), st);
     if (e != hipSuccess) return e;
     if (np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(np, nframes), dim3(64), 0, st, a);

@@ -227,6 +227,50 @@ public:
         return n;
     }
 
+    // The CurrentFrame.Nleft != -1 branch of SearchByProjection(CurrentFrame, LastFrame, th, bMono) — reference src/ORBmatcher3.cc:300-436
+    // (two KB8 fisheye cameras).  CurrentFrame.mvKeysUn carries mvKeys followed by mvKeysRight, mDescriptors the vconcat of both;
+    // vProjectionsRight[i].u / .v = mpCamera->project(GetRelativePoseTrl() * x3Dc); state / vnAssigned run over N = Nleft + Nright.
+    int SearchByProjection(const FrameView &CurrentFrame, int Nleft, const std::vector<int8_t> &mvpMapPointsState,
+                           const std::vector<float> &mvScaleFactors, const std::vector<orbx_projection> &vProjections,
+                           const std::vector<orbx_projection> &vProjectionsRight, const Descriptors &vMapPointDescriptors,
+                           std::vector<int> &vnAssigned, const float th, const bool bForward, const bool bBackward)
+    {
+        const int nc = (int)CurrentFrame.mvKeysUn->size(), np = (int)vProjections.size();
+        if ((int)mvpMapPointsState.size() != nc || (int)vProjectionsRight.size() != np || vMapPointDescriptors.rows != np || Nleft < 0 || Nleft > nc)
+            throw std::runtime_error("SearchByProjection: inconsistent array sizes");
+        vnAssigned.assign((size_t)nc, -1);
+        const int n = orbx_search_by_projection_fisheye(m_, (const orbx_keypoint *)CurrentFrame.mvKeysUn->data(), CurrentFrame.mDescriptors->data.data(),
+                                                        Nleft, nc - Nleft, mvpMapPointsState.data(), CurrentFrame.mnMinX, CurrentFrame.mnMaxX,
+                                                        CurrentFrame.mnMinY, CurrentFrame.mnMaxY, mvScaleFactors.data(), (int)mvScaleFactors.size(),
+                                                        vProjections.data(), vProjectionsRight.data(), vMapPointDescriptors.data.data(), np, th,
+                                                        bForward, bBackward, mbCheckOrientation ? 1 : 0, vnAssigned.data());
+        if (n < 0) check(n, "SearchByProjection");
+        return n;
+    }
+
+    // The F.Nleft != -1 branch of SearchByProjection(F, vpMapPoints, th, ..) — reference src/ORBmatcher1.cc:45-215.  vpMapPoints /
+    // vpMapPointsRight: the mTrack*/mTrack*R fields of every map point (flags bit 0 = mbTrackInView / mbTrackInViewR);
+    // mvLeftToRightMatch / mvRightToLeftMatch as Frame::ComputeStereoFishEyeMatches left them.
+    int SearchByProjection(const FrameView &F, int Nleft, const std::vector<int8_t> &mvpMapPointsState, const std::vector<float> &mvScaleFactors,
+                           const std::vector<orbx_projection> &vpMapPoints, const std::vector<orbx_projection> &vpMapPointsRight,
+                           const Descriptors &vMapPointDescriptors, const std::vector<int> &mvLeftToRightMatch,
+                           const std::vector<int> &mvRightToLeftMatch, std::vector<int> &vnAssigned, const float th = 3)
+    {
+        const int nc = (int)F.mvKeysUn->size(), np = (int)vpMapPoints.size();
+        if ((int)mvpMapPointsState.size() != nc || (int)vpMapPointsRight.size() != np || vMapPointDescriptors.rows != np || Nleft < 0 || Nleft > nc ||
+            (int)mvLeftToRightMatch.size() != Nleft || (int)mvRightToLeftMatch.size() != nc - Nleft)
+            throw std::runtime_error("SearchByProjection: inconsistent array sizes");
+        vnAssigned.assign((size_t)nc, -1);
+        const int n = orbx_search_by_projection_points_fisheye(m_, (const orbx_keypoint *)F.mvKeysUn->data(), F.mDescriptors->data.data(), Nleft,
+                                                               nc - Nleft, mvpMapPointsState.data(), F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY,
+                                                               mvScaleFactors.data(), (int)mvScaleFactors.size(), vpMapPoints.data(),
+                                                               vpMapPointsRight.data(), vMapPointDescriptors.data.data(), np,
+                                                               mvLeftToRightMatch.data(), mvRightToLeftMatch.data(), th, mfNNratio,
+                                                               vnAssigned.data());
+        if (n < 0) check(n, "SearchByProjection");
+        return n;
+    }
+
     // int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference include/ORBmatcher.h:62,
     // src/ORBmatcher1.cc:225-427 (F.Nleft == -1).  KF: mvKeysUn + mDescriptors of the keyframe, vbValidKF[i] = its map point i exists
     // and !isBad(); F: mvKeys + mDescriptors of the frame (FrameView::mvKeysUn carries them).  vnMatches[f] = keyframe feature
