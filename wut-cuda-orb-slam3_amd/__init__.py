@@ -22,7 +22,7 @@ from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbx.so")
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(_HERE, "liborbx.so")  # ORBX_LIB: an experimental build of the same library
 
 PROJECTION_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("invz", "<f4"), ("angle", "<f4"), ("octave", "<i4"), ("flags", "<i4")])  # orbx_projection
 KEYPOINT_DTYPE = np.dtype(

@@ -116,6 +116,7 @@ struct orbx_extractor {
     int generation = 0;                      // bumped whenever the geometry or a device buffer changes
     hipStream_t qtStream[ORBX_MAX_LEVELS] = {};  // one branch per level for the quadtree instances of a small batch
     hipEvent_t evQt[ORBX_MAX_LEVELS] = {};
+    hipEvent_t evPart[4] = {}, evStag[4] = {};   // front parts of a large batch (ORBX_FRONT_PARTS): end of a part's chain / of its level 0
     uint8_t *h_out = nullptr; size_t h_outBytes = 0;  // pinned staging for the single-frame download
 
     // level-0 source of the last batch (for orbx_get_pyramid_level)
@@ -266,6 +267,8 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i) {
         if (ex->qtStream[i]) { (void)hipStreamSynchronize(ex->qtStream[i]); (void)hipStreamDestroy(ex->qtStream[i]); }
         if (ex->evQt[i]) (void)hipEventDestroy(ex->evQt[i]);
+        if (i < 4 && ex->evPart[i]) (void)hipEventDestroy(ex->evPart[i]);
+        if (i < 4 && ex->evStag[i]) (void)hipEventDestroy(ex->evStag[i]);
     }
     if (ex->h_out) (void)hipHostFree(ex->h_out);
     ex->d_in.release();
@@ -851,9 +854,30 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
         }
         // ---- front: fused pyramid + FAST, one launch per level -----------------------------------------------
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 0) * 2], sFront));
+        // The eight launches of the chain depend on each other per FRAME only, so the chain can be cut into `nParts` groups of frames, each
+        // a chain on a stream of its own (optionally staggered by one level) whose kernels fill the draining tail of the other chain's
+        // launches.  Measured (1024 frames, tools/experiments/front_parts_sweep.sh): 1 part 1.883 ms, 2 parts 1.836 (staggered 1.881),
+        // 3 parts 1.956, 4 parts 1.935 - the tails are not where the time goes; default 1 (one chain: per-launch times stay readable).
+        static const int frontPartsEnv = [] { const char *e = getenv("ORBX_FRONT_PARTS"); return e ? atoi(e) : 1; }();
+        static const bool frontStagger = [] { const char *e = getenv("ORBX_FRONT_STAGGER"); return e ? atoi(e) != 0 : false; }();
+        int nParts = qtPerLevel == 1 || earlyBlur || nf < 256 ? 1 : std::min(std::max(frontPartsEnv, 1), 4);
+        for (int k = 1; k < nParts; ++k) {
+            if (!ex->qtStream[k] && hipStreamCreateWithFlags(&ex->qtStream[k], hipStreamNonBlocking) != hipSuccess) { nParts = 1; break; }
+            if (!ex->evPart[k] && hipEventCreateWithFlags(&ex->evPart[k], hipEventDisableTiming) != hipSuccess) { nParts = 1; break; }
+        }
+        for (int k = 0; k < nParts; ++k)
+            if (!ex->evStag[k] && hipEventCreateWithFlags(&ex->evStag[k], hipEventDisableTiming) != hipSuccess) { nParts = 1; break; }
+        const int partSize = ((nf + nParts - 1) / nParts + 7) / 8 * 8;
+        if (nParts > 1) HIP_TRY(hipEventRecord(ex->evStag[0], sFront));  // what the front stream is ordered after: every part waits for it
+        for (int part = 0; part < nParts; ++part) {
+        const int pf0 = part * partSize, pnf = std::min(partSize, nf - pf0);
+        if (pnf <= 0) break;
+        hipStream_t sPart = part == 0 ? sFront : ex->qtStream[part];
+        if (part > 0) HIP_TRY(hipStreamWaitEvent(sPart, ex->evStag[frontStagger ? part : 0], 0));
+        const int f0p = f0 + pf0;
         for (int l = 0; l < nl; ++l) {
             const OrbxLevelGeom &g = ex->geom[l];
-            const uint8_t *src = l == 0 ? src0 + (size_t)f0 * frame_stride : ex->d_raw[l].p + (size_t)f0 * g.frameStride;
+            const uint8_t *src = l == 0 ? src0 + (size_t)f0p * frame_stride : ex->d_raw[l].p + (size_t)f0p * g.frameStride;
             const int srcPitch = l == 0 ? (int)stride : g.pitch;
             const long long srcFS = l == 0 ? (long long)frame_stride : g.frameStride;
             uint8_t *dst = nullptr; int dw = 0, dh = 0, dPitch = 0; long long dFS = 0;
@@ -862,15 +886,16 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
             tabs.pfTiles = (const OrbxPfTile *)(ex->d_tabs.p + ex->tileOffsets[l]);
             if (l + 1 < nl) {
                 const OrbxLevelGeom &d = ex->geom[l + 1];
-                dst = ex->d_raw[l + 1].p + (size_t)f0 * d.frameStride; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;
+                dst = ex->d_raw[l + 1].p + (size_t)f0p * d.frameStride; dw = d.w; dh = d.h; dPitch = d.pitch; dFS = d.frameStride;
                 const int *o = &ex->tabOffsets[(size_t)l * 6];
                 tabs.xofs = ex->d_tabs.p + o[0]; tabs.xab = ex->d_tabs.p + o[1]; tabs.yofs = ex->d_tabs.p + o[2];
                 tabs.yab = ex->d_tabs.p + o[3]; tabs.rowBeg = ex->d_tabs.p + o[4]; tabs.colBeg = ex->d_tabs.p + o[5];
             }
-            HIP_TRY(orbxLaunchPyrFast(sFront, nf, g, src, srcPitch, srcFS, dst, dw, dh, dPitch, dFS, tabs,
-                                      ex->d_cand.p + (size_t)f0 * ex->candFrameStride, ex->candFrameStride,
-                                      ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame, ex->prm.ini_th_fast,
+            HIP_TRY(orbxLaunchPyrFast(sPart, pnf, g, src, srcPitch, srcFS, dst, dw, dh, dPitch, dFS, tabs,
+                                      ex->d_cand.p + (size_t)f0p * ex->candFrameStride, ex->candFrameStride,
+                                      ex->d_tileCount.p + (size_t)f0p * ex->tilesPerFrame, ex->tilesPerFrame, ex->prm.ini_th_fast,
                                       ex->prm.min_th_fast));
+            if (l == 0 && frontStagger && part + 1 < nParts) HIP_TRY(hipEventRecord(ex->evStag[part + 1], sPart));
             if (qtPerLevel == 1) {
                 // the quadtree of this level only needs this level's candidates: it runs on the back stream next to the
                 // pyramid + FAST launches of the smaller levels (latency-bound single waves under a throughput-bound kernel)
@@ -888,6 +913,9 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
                 HIP_TRY(hipEventRecord(ex->evLevel[l + 1], sFront));
             }
         }
+        if (part > 0) HIP_TRY(hipEventRecord(ex->evPart[part], sPart));
+        }
+        for (int part = 1; part < nParts; ++part) HIP_TRY(hipStreamWaitEvent(sFront, ex->evPart[part], 0));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 0) * 2 + 1], sFront));
         HIP_TRY(hipEventRecord(ex->evFront[sb], sFront));
 

@@ -1468,7 +1468,9 @@ __device__ __forceinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int 
 #define QT3_MAX_KEYS 8192   // first launch: run-start bitmap of 1 KB in LDS.  Larger candidate sets (levels of 1080p images) are deferred
 #define QT3_MAX_KEYS2 49152 // to a second launch of the same kernel with a 6 KB bitmap (key offsets are 16-bit, 0xFFFF is a sentinel);
                             // beyond that - and for everything when ORBX_QT_KERNEL=1 - the serial formulation takes over
-#define QT3_KCH 32         // 64-key chunks held in registers
+#ifndef QT3_KCH
+#define QT3_KCH 32         // 64-key chunks held in registers (sweep of 32 / 16 / 8: tools/experiments/qt_kch_sweep.sh)
+#endif
 
 struct Qt3 {
     qt_u64 *V;                 // [L] expandable nodes (count << 32 | UL.x << 16 | list position): vSizeAndPointerToNode
