@@ -1129,6 +1129,7 @@ struct QtArgs {
     int pass2;    // 1: second launch of the level-synchronous kernel - only the instances the first one deferred, larger run-start bitmap
     int nodeBytes;  // bytes of the node arrays of one instance (in LDS the keys follow)
     uint8_t *nodeScratch;  // != nullptr: node arrays in global memory, nodeBytes per instance of this launch (quotas beyond LDS)
+    int mwKeys;   // k_quadtree_mw: the candidate count its LDS layout (run-start bitmap, per-chunk arrays) is sized for
     int variant;  // 3: level-synchronous (default), 1: serial list walk (ORBX_QT_KERNEL; also taken for > QT3_MAX_KEYS candidates)
     int stop;     // debug (ORBX_QT_STOP): 1 return after the gather, 2 after the roots, 3 skip the sorted phase, 4 skip the sort only
 };
@@ -1484,7 +1485,7 @@ struct Qt3 {
 };
 #define QT3_NONE 0xFFFFu
 
-static size_t qt3NodeBytes(int L, int maxKeys = QT3_MAX_KEYS2) { return (((size_t)L * 46 + 8 + 216 * 4 + (size_t)(maxKeys / 32 + 2) * 4) + 15) & ~(size_t)15; }
+__host__ __device__ static inline size_t qt3NodeBytes(int L, int maxKeys = QT3_MAX_KEYS2) { return (((size_t)L * 46 + 8 + 216 * 4 + (size_t)(maxKeys / 32 + 2) * 4) + 15) & ~(size_t)15; }
 
 // A / B: key buffers.  With M <= QT3_KCH * 64 they are the same (LDS) buffer, larger sets ping-pong between two global ones.
 template <bool NG>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS
@@ -1938,6 +1939,553 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
     qt3_body<false>(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
 }
 
+// =====================================================================================================
+// The same level-synchronous formulation with ONE WORKGROUP OF QT4_NW WAVES per (frame, level) - for launches with few instances
+// (a single frame, a 1080p stereo pair): there an instance is latency-bound and its two key sweeps per pass are what it spends its
+// time in (a 1080p level holds 9 - 25 k candidates = up to 390 chunks per sweep on one wave).  The sweeps run on all waves, chunk c
+// on wave c mod QT4_NW; the list steps (a, c - g) stay on wave 0.  What made the scatter sequential - a write cursor per (node,
+// quadrant) that every chunk advances - is replaced by offsets known before the sweep: a key's rank inside its node's quadrant
+// = (keys of that quadrant in the node's earlier chunks) + (rank inside the chunk).  The first term is only non-zero for the run
+// that enters a chunk from the left; sweep (b) leaves the quadrant counts of every chunk's LAST run in Lc[], wave 1 turns them into
+// inclusive prefixes, and with cs[c] = the last chunk before c that holds a run start
+//      pre(c) = Lc[c - 1] - Lc[cs[c] - 1]
+// (all chunks between cs[c] and c are one run of that node).  cb[c] = number of run starts before chunk c replaces the running count.
+// =====================================================================================================
+#define QT4_NW 8
+#define QT4_NT (QT4_NW * WAVE)
+#define QT4_KCH 8          // 64-key chunks per wave held in registers: sets of up to QT4_NW * QT4_KCH * 64 = 4096 keys are scattered in place
+
+static size_t qt4NodeBytes(int L, int maxKeys)
+{
+    const size_t chunks = (size_t)maxKeys / 64 + 2;
+    return ((qt3NodeBytes(L, maxKeys) + 15) & ~(size_t)15) + ((chunks * (8 + 2 + 2) + 16 + 15) & ~(size_t)15);
+}
+
+template <bool NG>
+__device__ __forceinline__ void qt4_body(QtArgsK &a, const OrbxLevelGeom &g, int f, uint8_t *qlds, uint32_t *A, uint32_t *gB, int M,
+                                         const int *tc, uint32_t *selOut, int *selCnt)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long lt = lanemask_lt();
+    const int L = a.listCap;
+    const int nChunks = (M + 63) >> 6;
+    const bool inRegs = nChunks <= QT4_KCH * QT4_NW;
+    uint32_t *B = inRegs ? A : gB;
+    Qt3 S;
+    S.V = (qt_u64 *)qlds;
+    S.gx[0] = (uint32_t *)(S.V + L); S.gx[1] = S.gx[0] + L; S.gy[0] = S.gx[1] + L; S.gy[1] = S.gy[0] + L;
+    S.cc = S.gy[1] + L; S.aux = S.cc + 2 * L;
+    S.cnt[0] = (uint16_t *)(S.aux + L); S.cnt[1] = S.cnt[0] + L; S.beg[0] = S.cnt[1] + L; S.beg[1] = S.beg[0] + L + 2;
+    S.proc = S.beg[1] + L + 2;
+    S.sortStack = (int *)(S.proc + L);
+    S.starts = (uint32_t *)(S.sortStack + 216);
+    const int maxChunks = a.mwKeys / 64 + 2;
+    qt_u64 *Lc = (qt_u64 *)(qlds + ((qt3NodeBytes(L, a.mwKeys) + 15) & ~(size_t)15));  // [maxChunks] last-run quadrant counts -> inclusive prefix
+    uint16_t *cb = (uint16_t *)(Lc + maxChunks);                                       // [maxChunks] run starts before the chunk
+    uint16_t *cs = cb + maxChunks;                                                      // [maxChunks] last chunk before it that holds a start
+    int *bc = (int *)(cs + maxChunks);                                                  // [4] broadcast of wave 0's scalars
+    auto sync = [&]() { __syncthreads(); };
+
+    // ---- ordered gather of the FAST candidates (tile slots in cell-row-major order): a wave per tile, coalesced copies ------------
+    const int W = (g.w - ORBX_EDGE + 3) - ORBX_BORDER, H = (g.h - ORBX_EDGE + 3) - ORBX_BORDER;
+    const int N = g.quota;
+    const int nIni = (int)roundf(__fdiv_rn((float)W, (float)H));
+    const float hX = __fdiv_rn((float)W, (float)nIni);
+    const bool groupRoots = nIni > 1;
+    {
+        int *tileOff = (int *)qlds;  // nTiles + 1 prefix offsets; the node arrays are not in use yet
+        if (wv == 0) {
+            int base = 0;
+            for (int tb = 0; tb < g.nTiles; tb += WAVE) {
+                const int t = tb + lane;
+                const int myN = t < g.nTiles ? tc[t] : 0;
+                int total;
+                const int myOff = wave_excl_scan(myN, total);
+                if (t < g.nTiles) tileOff[t] = base + myOff;
+                base += total;
+            }
+            if (lane == 0) tileOff[g.nTiles] = base;
+        }
+        sync();
+        const uint32_t *slots = a.cand + (size_t)f * a.candFrameStride + g.candBase;
+        uint32_t *G = groupRoots ? gB : A;  // with several roots the keys are grouped by root on their way to A
+        for (int t0 = wv; t0 < g.nTiles; t0 += 2 * QT4_NW) {  // two tiles per step: both loads in flight
+            const int t1 = t0 + QT4_NW;
+            const int o0 = tileOff[t0], n0 = tileOff[t0 + 1] - o0;
+            const int o1 = t1 < g.nTiles ? tileOff[t1] : 0, n1 = t1 < g.nTiles ? tileOff[t1 + 1] - o1 : 0;
+            const uint32_t *s0 = slots + (size_t)t0 * g.slotCap, *s1 = slots + (size_t)t1 * g.slotCap;
+            for (int i = lane; i < max(n0, n1); i += WAVE) {
+                const uint32_t v0 = i < n0 ? s0[i] : 0u, v1 = i < n1 ? s1[i] : 0u;
+                if (i < n0) G[o0 + i] = v0;
+                if (i < n1) G[o1 + i] = v1;
+            }
+        }
+    }
+    sync();
+    if (a.stop == 1) { if (tid == 0) *selCnt = 0; return; }
+
+    // ---- roots (:589-626): push_back in order, keys stably grouped by root ---------------------------------------------------------
+    // One or two roots on camera images.  The grouping is a stable partition like the scatter of a pass: per chunk the counts per root
+    // (Lc), their prefix over the chunks (wave 1), then dest = start of the root + keys of that root in earlier chunks + rank in the chunk.
+    int cur = 0, size = 0;
+    if (!groupRoots) {
+        if (tid == 0) {
+            S.gx[0][0] = 0u | ((uint32_t)(int)__fmul_rn(hX, 1.0f) << 16);
+            S.gy[0][0] = 0u | ((uint32_t)H << 16);
+            S.cnt[0][0] = (uint16_t)M;
+        }
+        size = 1;
+    } else if (nIni <= 4) {
+        auto rootOf = [&](uint32_t key) { return (int)__fdiv_rn((float)(key & 0xFFF), hX); };
+        for (int c = wv; c < nChunks; c += QT4_NW) {
+            const int e = c * WAVE + lane;
+            const uint32_t key = e < M ? gB[e] : 0u;
+            const int r = e < M ? rootOf(key) : -1;
+            const qt_u64 v = (qt_u64)__popcll(__ballot(r == 0)) | ((qt_u64)__popcll(__ballot(r == 1)) << 16) |
+                             ((qt_u64)__popcll(__ballot(r == 2)) << 32) | ((qt_u64)__popcll(__ballot(r == 3)) << 48);
+            if (lane == 0) Lc[c] = v;
+        }
+        sync();
+        if (wv == 1) {
+            uint32_t blo = 0, bhi = 0;
+            for (int c0 = 0; c0 < nChunks; c0 += WAVE) {
+                const int c = c0 + lane;
+                const qt_u64 v = c < nChunks ? Lc[c] : 0ull;
+                int tlo, thi;
+                const uint32_t elo = (uint32_t)wave_excl_scan((int)(uint32_t)v, tlo), ehi = (uint32_t)wave_excl_scan((int)(uint32_t)(v >> 32), thi);
+                if (c < nChunks) Lc[c] = (qt_u64)(blo + elo + (uint32_t)v) | ((qt_u64)(bhi + ehi + (uint32_t)(v >> 32)) << 32);
+                blo += (uint32_t)tlo; bhi += (uint32_t)thi;
+            }
+        }
+        sync();
+        const qt_u64 tot = Lc[nChunks - 1];
+        int rootStart[4], off = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cnt = (int)((tot >> (16 * r)) & 0xFFFF);
+            rootStart[r] = off;
+            if (cnt > 0) {  // (roots without keys are not pushed, :621-626)
+                if (tid == 0) {
+                    S.gx[0][size] = (uint32_t)(int)__fmul_rn(hX, (float)r) | ((uint32_t)(int)__fmul_rn(hX, (float)(r + 1)) << 16);
+                    S.gy[0][size] = 0u | ((uint32_t)H << 16);
+                    S.cnt[0][size] = (uint16_t)cnt;
+                }
+                ++size;
+            }
+            off += cnt;
+        }
+        for (int c = wv; c < nChunks; c += QT4_NW) {
+            const int e = c * WAVE + lane;
+            const uint32_t key = e < M ? gB[e] : 0u;
+            const int r = e < M ? rootOf(key) : -1;
+            const unsigned long long m0 = __ballot(r == 0), m1 = __ballot(r == 1), m2 = __ballot(r == 2), m3 = __ballot(r == 3);
+            const unsigned long long mr = r == 0 ? m0 : (r == 1 ? m1 : (r == 2 ? m2 : m3));
+            const qt_u64 pre = c > 0 ? Lc[c - 1] : 0ull;
+            if (e < M) {
+                const int st = r == 0 ? rootStart[0] : (r == 1 ? rootStart[1] : (r == 2 ? rootStart[2] : rootStart[3]));
+                A[st + (int)((pre >> (16 * r)) & 0xFFFF) + __popcll(mr & lt)] = key;
+            }
+        }
+    } else {
+        // more than four roots (aspect ratio above 4.5): wave 0 groups them one after the other
+        int off = 0;
+        for (int r = 0; r < nIni; ++r) {
+            int cnt = 0;
+            if (wv == 0)
+                for (int base = 0; base < M; base += WAVE) {
+                    const bool act = base + lane < M;
+                    const uint32_t key = act ? gB[base + lane] : 0u;
+                    const bool mine = act && (int)__fdiv_rn((float)(key & 0xFFF), hX) == r;
+                    const unsigned long long m = __ballot(mine);
+                    if (mine) A[off + cnt + __popcll(m & lt)] = key;
+                    cnt += __popcll(m);
+                }
+            if (wv == 0 && cnt > 0 && lane == 0) {
+                S.gx[0][size] = (uint32_t)(int)__fmul_rn(hX, (float)r) | ((uint32_t)(int)__fmul_rn(hX, (float)(r + 1)) << 16);
+                S.gy[0][size] = 0u | ((uint32_t)H << 16);
+                S.cnt[0][size] = (uint16_t)cnt;
+            }
+            if (cnt > 0) ++size;
+            off += cnt;
+        }
+        if (tid == 0) bc[0] = size;  // (wave 0 counted: the other waves take the list size from it)
+        sync();
+        size = bc[0];
+    }
+    sync();
+    if (a.stop == 2) { if (tid == 0) *selCnt = 0; return; }
+
+    uint32_t kk[QT4_KCH];  // keys of chunks cb0 + u * QT4_NW + wv of the running batch
+    bool kkValid = false;
+    int nV = 0;  // entries of V after a pass
+    auto pass = [&](int nSorted) {
+        uint32_t *gx = S.gx[cur], *gy = S.gy[cur];
+        uint16_t *cn = S.cnt[cur], *bg = S.beg[cur];
+        uint32_t *gx2 = S.gx[cur ^ 1], *gy2 = S.gy[cur ^ 1];
+        uint16_t *cn2 = S.cnt[cur ^ 1], *bg2 = S.beg[cur ^ 1];
+        for (int i = tid; i < nChunks * 2 + 2; i += QT4_NT) S.starts[i] = 0;
+        sync();
+        if (wv == 0) {
+            // (a) run starts: exclusive prefix of the counts, bitmap of first keys; child counters to zero
+            int base = 0;
+            for (int pb0 = 0; pb0 < size; pb0 += 4 * WAVE) {
+                int c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int p = pb0 + u * WAVE + lane; c[u] = p < size ? (int)cn[p] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb0 + u * WAVE + lane;
+                    int total;
+                    const int o = base + wave_excl_scan(c[u], total);
+                    if (p < size) {
+                        bg[p] = (uint16_t)o;
+                        atomicOr(&S.starts[o >> 5], 1u << (o & 31));
+                        *(uint2 *)(S.cc + 2 * p) = make_uint2(0, 0);
+                        S.aux[p] = ~0u;
+                    }
+                    base += total;
+                }
+            }
+            if (lane == 0) bg[size] = (uint16_t)M;
+            qt_sync<!NG>();
+            // (a2) per chunk: run starts before it, last earlier chunk with a start
+            int nb = 0, lastS = 0;
+            for (int c0 = 0; c0 < nChunks; c0 += WAVE) {
+                const int c = c0 + lane;
+                const unsigned long long w = c < nChunks ? ((unsigned long long)S.starts[2 * c] | ((unsigned long long)S.starts[2 * c + 1] << 32)) : 0ull;
+                const int n = __popcll(w);
+                int total;
+                const int ex = wave_excl_scan(n, total);
+                const unsigned long long m = __ballot(n > 0), prev = m & lt;
+                if (c < nChunks) {
+                    cb[c] = (uint16_t)(nb + ex);
+                    cs[c] = (uint16_t)(prev ? c0 + (63 - __clzll(prev)) : lastS);
+                }
+                if (m) lastS = c0 + (63 - __clzll(m));
+                nb += total;
+            }
+        }
+        sync();
+        // key -> (node, quadrant, lane range of the node inside its 64-key chunk)
+        struct KeyInfo { uint32_t key; int p, q, lo, e0, c; bool act, big; unsigned long long R, w; };
+        auto classify = [&](int c, unsigned long long w, int p, uint32_t key, uint32_t ngx, uint32_t ngy, int nb, int nc) -> KeyInfo {
+            KeyInfo k;
+            const int base = c * WAVE, e = base + lane;
+            k.act = e < M; k.p = p; k.key = key; k.c = c; k.w = w;
+            const int ulx = ngx & 0xFFFF, urx = ngx >> 16, uly = ngy & 0xFFFF, bry = ngy >> 16;
+            const int mx = ulx + ((urx - ulx + 1) >> 1), my = uly + ((bry - uly + 1) >> 1);  // UL + ceil(extent / 2)
+            const int x = key & 0xFFF, y = (key >> 12) & 0xFFF;
+            k.q = x < mx ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+            k.big = k.act && nc > 1;
+            k.e0 = e - nb;
+            k.lo = max(nb - base, 0);
+            const int hi = min(nb + nc - base, 64);
+            k.R = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << k.lo) - 1ull);
+            return k;
+        };
+        // a sweep over all keys: wave wv takes chunks wv, wv + QT4_NW, ...; batches of QT4_KCH chunks per wave (keys -> registers),
+        // inside a batch 4 chunks per step (bitmap words, then owners, then node fields), then `body(KeyInfo)` chunk by chunk
+        auto sweep = [&](bool reload, auto &&body) {
+            for (int cb0 = 0; cb0 < nChunks; cb0 += QT4_KCH * QT4_NW) {
+                if (reload) {
+#pragma unroll
+                    for (int u = 0; u < QT4_KCH; ++u) {
+                        const int c = cb0 + u * QT4_NW + wv;
+                        const int e = c * WAVE + lane;
+                        if (c < nChunks) kk[u] = e < M ? A[e] : 0u;
+                    }
+                }
+#pragma unroll
+                for (int u0 = 0; u0 < QT4_KCH; u0 += 4) {
+                    if (cb0 + u0 * QT4_NW + wv < nChunks) {  // (no `break`: the loop must unroll completely, kk is indexed statically)
+                    unsigned long long w[4];
+                    int cbv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = cb0 + (u0 + u) * QT4_NW + wv;
+                        const bool in = c < nChunks;
+                        w[u] = in ? ((unsigned long long)S.starts[2 * c] | ((unsigned long long)S.starts[2 * c + 1] << 32)) : 0ull;
+                        cbv[u] = in ? (int)cb[c] : 0;
+                    }
+                    int pp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = cb0 + (u0 + u) * QT4_NW + wv;
+                        pp[u] = c * WAVE + lane < M ? cbv[u] + __popcll(w[u] & (lt | (1ull << lane))) - 1 : 0;
+                    }
+                    uint32_t ngx[4], ngy[4]; int nb[4], nc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { ngx[u] = gx[pp[u]]; ngy[u] = gy[pp[u]]; nb[u] = (int)bg[pp[u]]; nc[u] = (int)cn[pp[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = cb0 + (u0 + u) * QT4_NW + wv;
+                        if (c < nChunks) body(classify(c, w[u], pp[u], kk[u0 + u], ngx[u], ngy[u], nb[u], nc[u]));
+                    }
+                    }
+                }
+            }
+        };
+        // (b) child counts (LDS atomics, one per run and pair of quadrants) and the quadrant counts of every chunk's last run
+        sweep(!kkValid, [&](const KeyInfo &k) {
+            unsigned long long m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = __ballot(k.big && k.q == j);
+            if (k.big && lane == k.lo) {
+                const uint32_t lo2 = (uint32_t)__popcll(m[0] & k.R) | ((uint32_t)__popcll(m[1] & k.R) << 16);
+                const uint32_t hi2 = (uint32_t)__popcll(m[2] & k.R) | ((uint32_t)__popcll(m[3] & k.R) << 16);
+                if (lo2) atomicAdd(&S.cc[2 * k.p], lo2);
+                if (hi2) atomicAdd(&S.cc[2 * k.p + 1], hi2);
+            }
+            const int last = min(WAVE, M - k.c * WAVE) - 1;  // last key of the chunk (wave-uniform)
+            const unsigned long long Rl = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k.R, last)) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k.R >> 32), last) << 32);
+            if (lane == 0)
+                Lc[k.c] = (qt_u64)__popcll(m[0] & Rl) | ((qt_u64)__popcll(m[1] & Rl) << 16) | ((qt_u64)__popcll(m[2] & Rl) << 32) |
+                          ((qt_u64)__popcll(m[3] & Rl) << 48);
+        });
+        kkValid = inRegs;
+        sync();
+        int size2 = 0;
+        if (wv == 1) {
+            // inclusive prefix of Lc (four 16-bit fields: a quadrant's total is at most M < 65536, no carries between fields)
+            uint32_t blo = 0, bhi = 0;
+            for (int c0 = 0; c0 < nChunks; c0 += WAVE) {
+                const int c = c0 + lane;
+                const qt_u64 v = c < nChunks ? Lc[c] : 0ull;
+                int tlo, thi;
+                const uint32_t elo = (uint32_t)wave_excl_scan((int)(uint32_t)v, tlo), ehi = (uint32_t)wave_excl_scan((int)(uint32_t)(v >> 32), thi);
+                if (c < nChunks) Lc[c] = (qt_u64)(blo + elo + (uint32_t)v) | ((qt_u64)(bhi + ehi + (uint32_t)(v >> 32)) << 32);
+                blo += (uint32_t)tlo; bhi += (uint32_t)thi;
+            }
+        }
+        if (wv == 0) {
+            // (c) nodes to divide, in processing order
+            int nProc = 0;
+            if (nSorted < 0) {
+                for (int pb = 0; pb < size; pb += WAVE) {
+                    const int p = pb + lane;
+                    const bool big = p < size && cn[p] > 1;
+                    const unsigned long long m = __ballot(big);
+                    if (big) S.proc[nProc + __popcll(m & lt)] = (uint16_t)p;
+                    nProc += __popcll(m);
+                }
+            } else {
+                for (int t = lane; t < nSorted; t += WAVE) S.proc[t] = (uint16_t)(S.V[nSorted - 1 - t] & 0xFFFF);
+                nProc = nSorted;
+            }
+            qt_sync<!NG>();
+            // (d) prefix sums over the processing order: list size before each divide (a sorted round stops dividing once the
+            //     list holds N nodes), creation index of the first child, index of the first new V entry
+            int C = 0;
+            nV = 0;
+            {
+                int sz = size;
+                bool stop = false;
+                for (int tb = 0; tb < nProc && !stop; tb += WAVE) {
+                    const int t = tb + lane;
+                    const bool val = t < nProc;
+                    const int p = val ? S.proc[t] : 0;
+                    const uint2 c2 = *(const uint2 *)(S.cc + 2 * p);
+                    const uint32_t c0 = c2.x & 0xFFFF, c1 = c2.x >> 16, c2_ = c2.y & 0xFFFF, c3 = c2.y >> 16;
+                    const int ne = val ? (c0 > 0) + (c1 > 0) + (c2_ > 0) + (c3 > 0) : 0;
+                    const int nx = val ? (c0 > 1) + (c1 > 1) + (c2_ > 1) + (c3 > 1) : 0;
+                    int totNe, totNx, totG;
+                    const int cbx = wave_excl_scan(ne, totNe);
+                    const int vb = wave_excl_scan(nx, totNx);
+                    const int gEx = wave_excl_scan(val ? ne - 1 : 0, totG);
+                    bool take = val;
+                    if (nSorted >= 0) {
+                        // the reference divides node t and THEN breaks if size >= N: node t is divided iff the size before it is < N
+                        take = val && sz + gEx < N;
+                        const int nTake = __popcll(__ballot(take));  // a prefix of the chunk: sizes never decrease
+                        if (nTake < min(WAVE, nProc - tb)) stop = true;
+                        const int last = max(nTake - 1, 0);
+                        const int iNe = __shfl(cbx + ne, last), iNx = __shfl(vb + nx, last), iG = __shfl(gEx + ne - 1, last);
+                        totNe = nTake > 0 ? iNe : 0; totNx = nTake > 0 ? iNx : 0; totG = nTake > 0 ? iG : 0;
+                    }
+                    if (take) S.aux[p] = (uint32_t)(C + cbx) | ((uint32_t)(nV + vb) << 16);
+                    C += totNe; nV += totNx; sz += totG;
+                }
+            }
+            qt_sync<!NG>();
+            // (e) new list: children (reverse creation order) then the untouched nodes; new V in creation order.  The slots of cc
+            //     now hold the list position of the child (untouched node: its own new position in slot 0), QT3_NONE where there is none.
+            int nKeep = 0;
+            for (int pb0 = 0; pb0 < size; pb0 += 4 * WAVE) {
+                uint32_t ax[4], ogx[4], ogy[4], ocn[4]; uint2 c2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = min(pb0 + u * WAVE + lane, size - 1);
+                    ax[u] = S.aux[p]; ogx[u] = gx[p]; ogy[u] = gy[p]; ocn[u] = cn[p]; c2[u] = *(const uint2 *)(S.cc + 2 * p);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb0 + u * WAVE + lane;
+                    const bool val = p < size;
+                    const bool keep = val && ax[u] == ~0u;
+                    const unsigned long long mk = __ballot(keep);
+                    if (keep) {
+                        const int np = C + nKeep + __popcll(mk & lt);
+                        gx2[np] = ogx[u]; gy2[np] = ogy[u]; cn2[np] = (uint16_t)ocn[u];
+                        *(uint2 *)(S.cc + 2 * p) = make_uint2((uint32_t)np | (QT3_NONE << 16), QT3_NONE | (QT3_NONE << 16));
+                    } else if (val) {
+                        const int ulx = ogx[u] & 0xFFFF, urx = ogx[u] >> 16, uly = ogy[u] & 0xFFFF, bry = ogy[u] >> 16;
+                        const int mx = ulx + ((urx - ulx + 1) >> 1), my = uly + ((bry - uly + 1) >> 1);
+                        int ci = (int)(ax[u] & 0xFFFF), vi = (int)(ax[u] >> 16);
+                        const uint32_t cj[4] = {c2[u].x & 0xFFFF, c2[u].x >> 16, c2[u].y & 0xFFFF, c2[u].y >> 16};
+                        uint32_t slot[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {  // n1 (UL), n2 (UR), n3 (BL), n4 (BR) in push order
+                            slot[j] = QT3_NONE;
+                            if (cj[j] > 0) {
+                                const int np = C - 1 - ci;
+                                const int cul = (j & 1) ? mx : ulx, cur_ = (j & 1) ? urx : mx;
+                                const int cuy = (j & 2) ? my : uly, cby = (j & 2) ? bry : my;
+                                gx2[np] = (uint32_t)cul | ((uint32_t)cur_ << 16);
+                                gy2[np] = (uint32_t)cuy | ((uint32_t)cby << 16);
+                                cn2[np] = (uint16_t)cj[j];
+                                if (cj[j] > 1) S.V[vi++] = ((qt_u64)cj[j] << 32) | ((qt_u64)(unsigned)cul << 16) | (unsigned)np;
+                                slot[j] = (uint32_t)np;
+                                ++ci;
+                            }
+                        }
+                        *(uint2 *)(S.cc + 2 * p) = make_uint2(slot[0] | (slot[1] << 16), slot[2] | (slot[3] << 16));
+                    }
+                    nKeep += __popcll(mk);
+                }
+            }
+            size2 = C + nKeep;
+            qt_sync<!NG>();
+            // (f) prefix of the new counts; (g) list positions -> key offsets of the children's runs
+            {
+                int base = 0;
+                for (int pb0 = 0; pb0 < size2; pb0 += 4 * WAVE) {
+                    int c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int p = pb0 + u * WAVE + lane; c[u] = p < size2 ? (int)cn2[p] : 0; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = pb0 + u * WAVE + lane;
+                        int total;
+                        const int o = base + wave_excl_scan(c[u], total);
+                        if (p < size2) bg2[p] = (uint16_t)o;
+                        base += total;
+                    }
+                }
+            }
+            qt_sync<!NG>();
+            for (int pb0 = 0; pb0 < size; pb0 += 4 * WAVE) {
+                uint2 c2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c2[u] = *(const uint2 *)(S.cc + 2 * min(pb0 + u * WAVE + lane, size - 1));
+                uint32_t o[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t sj[4] = {c2[u].x & 0xFFFF, c2[u].x >> 16, c2[u].y & 0xFFFF, c2[u].y >> 16};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[u][j] = sj[j] != QT3_NONE ? (uint32_t)bg2[sj[j]] : QT3_NONE;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = pb0 + u * WAVE + lane;
+                    if (p < size) *(uint2 *)(S.cc + 2 * p) = make_uint2(o[u][0] | (o[u][1] << 16), o[u][2] | (o[u][3] << 16));
+                }
+            }
+            if (lane == 0) { bc[0] = size2; bc[1] = nV; }
+        }
+        sync();
+        size2 = bc[0]; nV = bc[1];
+        // (h) stable scatter of the keys to their new runs (in place when all keys are in registers): no cursor is advanced
+        sweep(!inRegs, [&](const KeyInfo &k) {
+            const bool div = k.act && S.aux[k.p] != ~0u;
+            unsigned long long m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = __ballot(div && k.q == j);
+            const unsigned long long mq = k.q == 0 ? m[0] : (k.q == 1 ? m[1] : (k.q == 2 ? m[2] : m[3]));
+            const int sl = div ? k.q : 0;
+            const uint32_t start = k.act ? (S.cc[2 * k.p + (sl >> 1)] >> (16 * (sl & 1))) & 0xFFFFu : 0u;
+            // keys of this quadrant in the node's earlier chunks: only for the run that enters the chunk from the left
+            qt_u64 pre = 0;
+            if (k.c > 0 && !(k.w & 1ull)) {
+                const int s = (int)cs[k.c];
+                pre = Lc[k.c - 1] - (s > 0 ? Lc[s - 1] : 0ull);
+            }
+            const bool head = (k.w & ((2ull << lane) - 1ull)) == 0ull;  // no run start at or before this lane
+            const uint32_t before = head ? (uint32_t)(pre >> (16 * k.q)) & 0xFFFFu : 0u;
+            const uint32_t dest = div ? start + before + (uint32_t)__popcll(mq & k.R & lt) : start + (uint32_t)k.e0;
+            if (k.act) B[dest] = k.key;
+        });
+        if (!inRegs) { uint32_t *t = A; A = B; B = t; }
+        kkValid = false;
+        cur ^= 1;
+        size = size2;
+        sync();
+    };
+
+    // ---- subdivision (:630-752): list walks until the next one could overshoot N, then sorted rounds (:701-751) until done
+    bool finish = false, sorted = false;
+    while (!finish) {
+        const int prevSize = size;
+        int nSorted = -1;
+        if (sorted) {
+            nSorted = nV;
+            if (tid == 0 && a.stop != 4) orbx_sort::sort(S.V, nSorted, QtSizedLess(), S.sortStack);
+            sync();
+        }
+        pass(nSorted);
+        if (size >= N || size == prevSize) finish = true;
+        else if (!sorted && size + nV * 3 > N) {
+            if (a.stop == 3) break;
+            sorted = true;
+        }
+    }
+
+    // ---- retain the best (first strictly greatest response) key of every node, in list order (:755-771) --
+    {
+        const uint16_t *cn = S.cnt[cur], *bg = S.beg[cur];
+        for (int p = tid; p < size; p += QT4_NT) {
+            const int n = (int)cn[p], b = (int)bg[p];
+            uint32_t best = A[b];
+            for (int i = 1; i < n; ++i) {
+                const uint32_t key = A[b + i];
+                if ((key >> 24) > (best >> 24)) best = key;
+            }
+            selOut[p] = best;
+        }
+    }
+    if (tid == 0) *selCnt = size;
+}
+
+__global__ __launch_bounds__(QT4_NT) void k_quadtree_mw(QtArgs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
+    QtArgsK &a = *(QtArgsK *)__builtin_amdgcn_kernarg_segment_ptr();
+    // level-major: all instances of the largest level first (their candidate sets are the largest: longest job first)
+    const int f = (int)(blockIdx.x % (unsigned)a.nframes);
+    const int level = (int)(blockIdx.x / (unsigned)a.nframes) + a.levelBase;
+    if (level >= a.levelBase + a.levelsRun) return;
+    const OrbxLevelGeom &g = a.geoms[level];
+    const int *tc = a.tileCount + (size_t)f * a.tilesPerFrame + g.tileBase;
+    int M = 0;
+    for (int tb = 0; tb < g.nTiles; tb += WAVE) {  // (every wave counts for itself)
+        int v = tb + (int)(threadIdx.x & 63) < g.nTiles ? tc[tb + (threadIdx.x & 63)] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        M += v;
+    }
+    uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
+    int *selCnt = a.selCount + (size_t)f * a.nlevels + level;
+    if (M == 0 || M > a.maxKeys) { if (threadIdx.x == 0) *selCnt = M == 0 ? 0 : QT_DEFERRED; return; }
+    uint32_t *gA = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
+    uint32_t *gB = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
+    if (a.nodeScratch) {  // list capacity beyond LDS: node arrays in global memory
+        uint8_t *nodes = a.nodeScratch + ((size_t)f * a.levelsRun + (level - a.levelBase)) * (size_t)a.nodeBytes;
+        qt4_body<true>(a, g, f, nodes, gA, gB, M, tc, selOut, selCnt);
+        return;
+    }
+    qt4_body<false>(a, g, f, qlds, gA, gB, M, tc, selOut, selCnt);
+}
+
 // serial formulation (one DivideNode at a time): every instance (a.variant == 1, A/B runs) or only those the kernel above
 // deferred.  One key buffer in LDS when it fits; the second one is only used while a node still holds more than 64 keys (the
 // first few divides), so it always lives in global scratch.
@@ -1978,7 +2526,7 @@ size_t orbxQuadtreeScratchBytes(int nframes, const OrbxLevelGeom *geomsHost, int
     const int listCap = (std::max(maxQuota + 16, 4 * maxRoots + 8) + 3) & ~3;
     const int pool = (2 * maxQuota + 64 + 4 * maxRoots + 3) & ~3;
     const size_t tileOffBytes = (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15;
-    const size_t nb = std::max(std::max(qt3NodeBytes(listCap), qtNodeBytes(pool, listCap)), tileOffBytes);
+    const size_t nb = std::max(std::max(std::max(qt3NodeBytes(listCap), qt4NodeBytes(listCap, QT3_MAX_KEYS2)), qtNodeBytes(pool, listCap)), tileOffBytes);
     if (nb + (size_t)QT_LDS_KEYS * sizeof(uint32_t) <= 160 * 1024) return 0;
     return nb * (size_t)nframes * (size_t)levelsRun;
 }
@@ -2034,7 +2582,33 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     const size_t tileOffBytes = (((size_t)maxTiles + 1) * 4 + 15) & ~(size_t)15;  // both kernels stage the tile prefix in the node area first
     const dim3 grid(xcd_grid(nframes, levelsRun));
     const size_t ldsMax = 160 * 1024;
-    if (a.variant == 3 && (which & ORBX_QT_LEVEL_SYNC)) {
+    a.mwKeys = 0;
+    // few instances (a single frame, a batch of 1080p pairs): a workgroup of QT4_NW waves per instance (the sweeps of a pass on all
+    // waves), one launch whatever the candidate count.  Many instances (the 1024-frame batches): one wave per instance - the chip is
+    // filled by instances, and a wave's registers / LDS go further that way.  ORBX_QT_MW=0 / 1 forces the choice.
+    static const int mwEnv = [] { const char *e = getenv("ORBX_QT_MW"); return e ? atoi(e) : -1; }();
+    const bool multiWave = mwEnv >= 0 ? mwEnv != 0 : (long long)nframes * levelsRun <= 1024;
+    if (a.variant == 3 && (which & ORBX_QT_LEVEL_SYNC) && multiWave) {
+        long long maxArea = 0;
+        for (int l = levelBase; l < levelBase + levelsRun; ++l) maxArea = std::max(maxArea, (long long)(geomsHost[l].w - 32) * (geomsHost[l].h - 32));
+        const bool large = mk2 > mk && (maxArea / 40 > mk || mk != QT3_MAX_KEYS);
+        a.maxKeys = large ? mk2 : mk;
+        a.mwKeys = large ? QT3_MAX_KEYS2 : QT3_MAX_KEYS;
+        a.nodeBytes = (int)std::max(qt4NodeBytes(a.listCap, a.mwKeys), tileOffBytes);
+        size_t lds = (size_t)a.nodeBytes;
+        a.nodeScratch = nullptr;
+        if (lds > ldsMax) {
+            if (!nodeScratch || nodeScratchBytes < (size_t)a.nodeBytes * nframes * levelsRun) return hipErrorInvalidValue;
+            a.nodeScratch = nodeScratch;
+            lds = 0;
+        }
+        static bool mwAttr[64] = {};
+        if (!mwAttr[devId & 63]) {
+            (void)hipFuncSetAttribute((const void *)k_quadtree_mw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            mwAttr[devId & 63] = true;
+        }
+        hipLaunchKernelGGL(k_quadtree_mw, dim3((unsigned)nframes * (unsigned)levelsRun), dim3(QT4_NT), lds, st, a);
+    } else if (a.variant == 3 && (which & ORBX_QT_LEVEL_SYNC)) {
         // a level of the size of a VGA image never holds more than a few thousand candidates on camera images; the second launch
         // (6 KB bitmap) is only issued where a level is large enough for > 8192 (2.5 % of the FAST region) - or in the tests
         long long maxArea = 0;
