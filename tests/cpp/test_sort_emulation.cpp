@@ -31,6 +31,14 @@ int main()
         orbx_sort::sort(c.data(), n, lessE);
         for (int i = 0; i < n; ++i)
             if (b[i].id != c[i].id) { printf("MISMATCH sort trial %d n %d at %d\n", trial, n, i); return 1; }
+        {   // the data-parallel formulation the multi-wave quadtree kernel runs (pairing partition + stable rank)
+            std::vector<E> g = a, tmp(n);
+            std::vector<int> lp(n), rp(n);
+            int stack[216];
+            orbx_sort::sort_pairing(g.data(), n, lessE, stack, lp.data(), rp.data(), tmp.data());
+            for (int i = 0; i < n; ++i)
+                if (b[i].id != g[i].id) { printf("MISMATCH pairing trial %d n %d at %d\n", trial, n, i); return 1; }
+        }
         // heap fallback: std::partial_sort(first, last, last) == heap_sort
         std::vector<E> d = a, e = a;
         std::partial_sort(d.begin(), d.end(), d.end(), lessE);
@@ -53,6 +61,12 @@ int main()
         orbx_sort::sort(c.data(), n, lessE);
         for (int i = 0; i < n; ++i)
             if (b[i].id != c[i].id) { printf("MISMATCH killer n %d at %d\n", n, i); return 1; }
+        std::vector<E> g = a, tmp(n);
+        std::vector<int> lp(n), rp(n);
+        int stack[216];
+        orbx_sort::sort_pairing(g.data(), n, lessE, stack, lp.data(), rp.data(), tmp.data());
+        for (int i = 0; i < n; ++i)
+            if (b[i].id != g[i].id) { printf("MISMATCH pairing killer n %d at %d\n", n, i); return 1; }
     }
     printf("OK %ld elements\n", checked);
     return 0;

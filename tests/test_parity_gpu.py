@@ -313,19 +313,33 @@ def test_quadtree_pool_compaction_path(pkg):
                           (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
 
 
-def test_quadtree_deferred_instances(pkg):
-    """Candidate sets above the capacity of the level-synchronous kernel are marked and taken by the serial kernel in a
+@pytest.mark.parametrize("mw", ["0", "1"])
+def test_quadtree_deferred_instances(pkg, mw):
+    """Candidate sets above the capacity of the level-synchronous kernels are marked and taken by the serial kernel in a
     second launch.  At VGA no set reaches the real limit (8192 keys): lower it so that the large levels are deferred while
-    the small ones stay on the parallel kernel, and check full parity of the mixed result."""
-    _gpu_check_subprocess({"ORBX_QT_MAX_KEYS": "600", "ORBX_QT_MAX_KEYS2": "0"}, (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
+    the small ones stay on the parallel kernel, and check full parity of the mixed result.  ORBX_QT_MW: one wave per instance
+    (k_quadtree, what large batches run) / a workgroup of 8 waves per instance (k_quadtree_mw, what small batches run)."""
+    _gpu_check_subprocess({"ORBX_QT_MW": mw, "ORBX_QT_MAX_KEYS": "600", "ORBX_QT_MAX_KEYS2": "0"},
+                          (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
 
 
-def test_quadtree_second_pass_instances(pkg):
-    """Sets between 8192 and 49152 keys (the large levels of 1080p frames) run in a second launch of the level-synchronous kernel
-    with a larger run-start bitmap, only what lies beyond goes to the serial kernel.  Lowered limits make all three contribute to
-    one result at VGA; the 1080p case runs the real limits."""
-    _gpu_check_subprocess({"ORBX_QT_MAX_KEYS": "500", "ORBX_QT_MAX_KEYS2": "1500"}, (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
-    _gpu_check_subprocess({}, (["1920", "1080", "4000", "2"],))
+@pytest.mark.parametrize("mw", ["0", "1"])
+def test_quadtree_second_pass_instances(pkg, mw):
+    """Sets between 8192 and 49152 keys (the large levels of 1080p frames): k_quadtree takes them in a second launch with a larger
+    run-start bitmap, k_quadtree_mw in its one launch; only what lies beyond goes to the serial kernel.  Lowered limits make all of
+    them contribute to one result at VGA; the 1080p case runs the real limits."""
+    _gpu_check_subprocess({"ORBX_QT_MW": mw, "ORBX_QT_MAX_KEYS": "500", "ORBX_QT_MAX_KEYS2": "1500"},
+                          (["640", "480", "1000", "2"], ["752", "480", "1200", "1"]))
+    _gpu_check_subprocess({"ORBX_QT_MW": mw}, (["1920", "1080", "4000", "2"],))
+
+
+@pytest.mark.parametrize("mw", ["0", "1"])
+def test_quadtree_kernels_on_other_shapes(pkg, mw):
+    """Both level-synchronous kernels forced on shapes their default choice would not give them: a batch of 40 frames on the 8-wave
+    kernel / single frames on the one-wave kernel, images with 1, 2, 3 and 5 root nodes (nIni = round(W / H): the 8-wave kernel groups
+    up to four roots chunk-parallel, more on one wave), and the 8-wave kernel's in-place scatter limit (4096 keys) crossed at 1080p."""
+    _gpu_check_subprocess({"ORBX_QT_MW": mw}, (["640", "480", "1000", "40"], ["752", "480", "1200", "1"], ["1000", "350", "1500", "2"],
+                                               ["1500", "300", "1200", "2"], ["333", "257", "600", "3"]))
 
 
 @pytest.mark.parametrize("env", [{"ORBX_BLUR_KERNEL": "2"}, {"ORBX_BLUR_KERNEL": "1"}, {"ORBX_BLUR_WAVES": "8"}])

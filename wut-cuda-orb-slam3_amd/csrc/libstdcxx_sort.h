@@ -185,6 +185,72 @@ ORBX_HD void sort_acc(A &a, int n, Less less, int *stack)
     }
 }
 
+template <class T, class Less>
+ORBX_HD void heap_sort(T *p, int n, Less less);
+
+// ---- the same result, data-parallel ------------------------------------------------------------------------------------------
+// A formulation whose steps are independent over the elements (k_quadtree_mw runs them on the lanes of a wave / the threads of a
+// workgroup; this plain C++ statement of it is what the host test pins against std::sort):
+//   * __unguarded_partition(first + 1, last, pivot): the k-th swap exchanges the k-th "left stopper" (position, ascending, whose
+//     element is not less than the pivot) with the k-th "right stopper" (position, descending, whose element the pivot is not
+//     less than); K = number of k with L_k < R_k (a prefix: L ascends, R descends).  The scan that ends the partition stops at
+//     the next original left stopper or at the position of the last swap's right element, whichever comes first:
+//     cut = (K < nL && L_K < Rprev) ? L_K : Rprev with Rprev = K ? R_{K-1} : last.
+//   * __final_insertion_sort is an insertion sort, i.e. a STABLE sort of whatever arrangement the introsort loop leaves:
+//     rank(i) = #{j : e_j < e_i} + #{j < i : e_j equivalent to e_i}.
+// `lp`, `rp`: scratch for n positions each; `tmp`: scratch for n elements.
+template <class T, class Less>
+inline void sort_pairing(T *p, int n, Less less, int *stack, int *lp, int *rp, T *tmp)
+{
+    if (n <= 1) return;
+    const int kThreshold = 16;
+    int lg = 0;
+    for (unsigned v = (unsigned)n; v > 1; v >>= 1) ++lg;
+    int *stFirst = stack, *stLast = stack + 72, *stDepth = stack + 144;
+    int sp = 0;
+    stFirst[0] = 0; stLast[0] = n; stDepth[0] = lg * 2; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stFirst[sp], last = stLast[sp], depth = stDepth[sp];
+        while (last - first > kThreshold) {
+            if (depth == 0) { heap_sort(p + first, last - first, less); break; }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            const int ia = first + 1, ib = mid, ic = last - 1;
+            const T vf = p[first], va = p[ia], vb = p[ib], vc = p[ic];
+            int im;
+            if (less(va, vb)) {
+                if (less(vb, vc)) im = ib;
+                else if (less(va, vc)) im = ic;
+                else im = ia;
+            } else if (less(va, vc)) im = ia;
+            else if (less(vb, vc)) im = ic;
+            else im = ib;
+            const T pivot = im == ia ? va : (im == ib ? vb : vc);
+            p[im] = vf;
+            p[first] = pivot;
+            int nL = 0, nR = 0;
+            for (int q = first + 1; q < last; ++q) {  // independent per position
+                if (!less(p[q], pivot)) lp[nL++] = q;
+                if (!less(pivot, p[q])) rp[nR++] = q;  // ascending: R_k = rp[nR - 1 - k]
+            }
+            int K = 0;
+            while (K < nL && K < nR && lp[K] < rp[nR - 1 - K]) ++K;  // (a prefix: evaluated for all k at once on the device)
+            for (int k = 0; k < K; ++k) { const T t = p[lp[k]]; p[lp[k]] = p[rp[nR - 1 - k]]; p[rp[nR - 1 - k]] = t; }
+            const int rprev = K > 0 ? rp[nR - K] : last;
+            const int cut = (K < nL && lp[K] < rprev) ? lp[K] : rprev;
+            stFirst[sp] = cut; stLast[sp] = last; stDepth[sp] = depth; ++sp;
+            last = cut;
+        }
+    }
+    for (int i = 0; i < n; ++i) {  // independent per element
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (less(p[j], p[i]) || (!less(p[i], p[j]) && j < i)) ? 1 : 0;
+        tmp[r] = p[i];
+    }
+    for (int i = 0; i < n; ++i) p[i] = tmp[i];
+}
+
 // pointer convenience wrappers (host tests, LDS fallback)
 template <class T, class Less>
 ORBX_HD void sort(T *p, int n, Less less, int *stack)
