@@ -532,7 +532,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
 
             // (A) pre-test of one 8-pixel strip (row r, strip sI of the tile, `valid` = its candidate pixels)
-            auto preTest = [&](int r, int sI, unsigned valid) {
+            auto preTest = [&](int r, int sI) {
                 const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * (s0 + sI);
                 uint32_t w0[4], w3[4], w6[4];
                 {
@@ -545,8 +545,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
                 }
                 const uint32_t f0 = fast_group_pretest<0>(w0, w3, w6, T4, C4);
                 const uint32_t f1 = fast_group_pretest<1>(w0, w3, w6, T4, C4);
-                const unsigned m = (((f0 * 0x00204081u) >> 28) | (((f1 * 0x00204081u) >> 28) << 4)) & valid;
-                const bool g0 = (m & 0x0F) != 0, g1 = (m & 0xF0) != 0;
+                // (pixels outside the interior columns / the still-empty cells are not masked here: the ring test clips its result to
+                // both anyway, and the mask cost every strip ~15 instructions to keep a few edge groups out of the queue)
+                const bool g0 = f0 != 0, g1 = f1 != 0;
                 // queue slots: one LDS atomic per wave and ballot prefix counts (a per-lane atomicAdd on one address is expanded by
                 // the compiler into a readlane loop over the active lanes: ~9 scalar instructions per passing strip)
                 const unsigned long long bg0 = __ballot(g0), bg1 = __ballot(g1);
@@ -561,10 +562,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
             } else if (round == 0) {
                 for (int it = otid(); it < nItems; it += PF_NT) {
                     const int r = (int)(((float)it + 0.5f) * invNS);
-                    const int sI = it - r * NS;
-                    const int cbase = 8 * (s0 + sI) + 4;
-                    const int plo = max(cInt0 - cbase, 0), phi = min(cInt1 - cbase, 8);
-                    preTest(r, sI, (0xFFu >> (8 - phi)) & (0xFFu << plo));          // interior pixels of the strip
+                    preTest(r, it - r * NS);
                 }
             } else {
                 // only the strips of still-empty cells, one cell at a time (cell geometry in SGPRs).  A strip that straddles two
@@ -572,22 +570,18 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
                 int visit = 0;
                 for (unsigned em = eMask; em; em &= em - 1, ++visit) {
                     const int c = __ffs(em) - 1;
-                    const bool prevEmpty = c > 0 && ((eMask >> (c - 1)) & 1u), nextEmpty = ((eMask >> 1) >> c) & 1u;
+                    const bool prevEmpty = c > 0 && ((eMask >> (c - 1)) & 1u);
                     const int cc0 = cInt0 + c * wCell, cc1 = min(cc0 + wCell, cInt1);
                     int sF = (cc0 - 4) >> 3;
                     const int sL = (cc1 - 1 - 4) >> 3;
                     if (prevEmpty && 8 * sF + 4 < cc0) ++sF;
-                    const int vhi = nextEmpty ? min(cc1 + wCell, cInt1) : cc1;
                     const int nS = sL - sF + 1;
                     if (nS <= 0) continue;
                     const float invS = __builtin_amdgcn_rcpf((float)nS);
                     // alternate the half of the workgroup that takes a cell's (usually < 256) strips
                     for (int it = (otid() + visit * (PF_NT / 2)) & (PF_NT - 1); it < nS * THi; it += PF_NT) {
                         const int r = (int)(((float)it + 0.5f) * invS);
-                        const int s = sF + (it - r * nS);
-                        const int cbase = 8 * s + 4;
-                        const int plo = max(cc0 - cbase, 0), phi = min(vhi - cbase, 8);
-                        preTest(r, s - s0, (0xFFu >> (8 - phi)) & (0xFFu << plo));
+                        preTest(r, sF + (it - r * nS) - s0);
                     }
                 }
             }
