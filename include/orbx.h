@@ -256,6 +256,18 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, con
                                    const uint8_t *d2, int n2, float min_x, float max_x, float min_y, float max_y, float *prev_matched,
                                    int32_t *matches12, int window_size, float nnratio, int check_orientation);
 
+/* The same search for a BATCH of frame pairs, device-resident (one wave per pair; the reference's loop is sequential inside a pair):
+ * pair p = (frame p of `ex1`'s last batch, frame p + frame2_offset of `ex2`'s - the same handle with offset 1 pairs consecutive frames of
+ * one batch).  Both frames' keypoints go through Frame::UndistortKeyPoints (src/Frame.cc:777-811; k4 / dist / knew4 as in
+ * orbx_undistort_keypoints) first.  d_prev_matched [npairs][cap1][2] floats = vbPrevMatched, in / out; with init_prev_matched != 0 it is
+ * first set to F1's undistorted keypoint positions (what MonocularInitialization passes on its first attempt, src/Tracking3.cc:717-720).
+ * d_matches12 [npairs][cap1] int32 = vnMatches12, d_nmatches [npairs] (-1: F2 holds more than 2048 octave-0 keypoints, the capacity of the
+ * LDS-resident search).  cap1 = orbx_max_keypoints(ex1).  Asynchronous on the matcher's stream. */
+int orbx_search_for_initialization_frames(orbx_matcher *m, orbx_extractor *ex1, orbx_extractor *ex2, int frame2_offset, int npairs,
+                                          const float *k4, const float *dist, int ndist, const float *knew4, float min_x, float max_x,
+                                          float min_y, float max_y, float *d_prev_matched, int init_prev_matched, int window_size,
+                                          float nnratio, int check_orientation, void *d_matches12, void *d_nmatches);
+
 /* One projected map point of the last frame, as ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, ..)
  * has it after `x3Dc = Tcw * x3Dw; invzc = 1.0 / x3Dc(2); uv = mpCamera->project(x3Dc)` (reference src/ORBmatcher3.cc:283-296). */
 typedef struct {

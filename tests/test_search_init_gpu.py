@@ -104,3 +104,45 @@ def test_generic_kernel_in_subprocess(pkg):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+def test_search_for_initialization_frames_batch(pkg, orc):
+    """A batch of frame pairs in one launch, device-resident: consecutive frames of one extractor batch (frame p with frame p + 1), with
+    a distorted camera so that Frame::UndistortKeyPoints runs in front, against the oracle pair by pair (undistort + search); then a second
+    round on the updated vbPrevMatched, and two extractors as the two sides."""
+    P = 6
+    base = pkg.synth_frame(11, 640, 480)
+    imgs = np.stack([_second_view(base, 4 * i, -3 * i, 20 + i) for i in range(P + 1)])
+    ex = pkg.ORBextractor(3000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=P + 1)
+    n, mono, kps, desc = ex.extract_batch(imgs, (0, 0))
+    cap = ex.capacity
+    k4 = np.float32([458.654, 457.296, 367.215, 248.375]); dist = np.float32([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05])
+    m = pkg.ORBmatcher(8192, 8192)
+    bounds = m.ComputeImageBounds(640, 480, k4, dist)
+    for dcoef in (dist, np.float32([])):
+        b = bounds if len(dcoef) else BOUNDS
+        nm, m12, prev = m.SearchForInitializationFrames(ex, ex, P, k4, dcoef, b, 100, 0.9, True, frame2_offset=1)
+        nm2, m12b, prev2 = m.SearchForInitializationFrames(ex, ex, P, k4, dcoef, b, 100, 0.9, True, frame2_offset=1, prev_matched=prev)
+        for p in range(P):
+            k1, d1 = kps[p, : n[p]], desc[p, : n[p]]
+            k2, d2 = kps[p + 1, : n[p + 1]], desc[p + 1, : n[p + 1]]
+            if len(dcoef):
+                k1, k2 = orc.undistort_keypoints(k1, k4, dcoef), orc.undistort_keypoints(k2, k4, dcoef)
+            pv0 = np.stack([k1["x"], k1["y"]], axis=1)
+            rn, rm12, rpv = orc.search_for_initialization(k1, d1, k2, d2, pv0, b, 100, 0.9, True)
+            assert nm[p] == rn and np.array_equal(m12[p, : n[p]], rm12), p
+            assert np.array_equal(prev[p, : n[p]].view(np.uint32), rpv.view(np.uint32)), p
+            rn2, rm12b, rpv2 = orc.search_for_initialization(k1, d1, k2, d2, rpv, b, 100, 0.9, True)
+            assert nm2[p] == rn2 and np.array_equal(m12b[p, : n[p]], rm12b) and np.array_equal(prev2[p, : n[p]].view(np.uint32), rpv2.view(np.uint32)), p
+        assert nm.min() > 50
+    # two extractors as the two sides (frame p of each), no orientation check, a tighter ratio
+    ex2 = pkg.ORBextractor(3000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=P + 1)
+    n2, _, kps2, desc2 = ex2.extract_batch(imgs[::-1].copy(), (0, 0))
+    nm, m12, prev = m.SearchForInitializationFrames(ex, ex2, 3, k4, np.float32([]), BOUNDS, 60, 0.7, False)
+    for p in range(3):
+        k1, d1, k2, d2 = kps[p, : n[p]], desc[p, : n[p]], kps2[p, : n2[p]], desc2[p, : n2[p]]
+        rn, rm12, rpv = orc.search_for_initialization(k1, d1, k2, d2, np.stack([k1["x"], k1["y"]], axis=1), BOUNDS, 60, 0.7, False)
+        assert nm[p] == rn and np.array_equal(m12[p, : n[p]], rm12) and np.array_equal(prev[p, : n[p]].view(np.uint32), rpv.view(np.uint32)), p
+    with pytest.raises(pkg.OrbxError):
+        m.SearchForInitializationFrames(ex, ex, P + 1, k4, np.float32([]), BOUNDS, 100, 0.9, True, frame2_offset=1)  # frame P + 1 does not exist
+    ex.close(); ex2.close(); m.close()

@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
-    "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_search_by_projection_frames", "orbx_search_by_projection_points_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
+    "orbx_matcher_download", "orbx_compute_stereo_fisheye_matches", "orbx_compute_stereo_fisheye_matches_frames", "orbx_search_by_projection_frames", "orbx_search_by_projection_points_frames", "orbx_search_for_initialization_frames", "orbx_matcher_sync", "orbx_match_stereo_rows", "orbx_device_count", "orbx_synth_frame",
     "orbx_level_sizes", "orbx_set_profiling", "orbx_get_stage_times", "orbx_compute_stereo_matches",
     "orbx_assign_features_to_grid", "orbx_search_for_initialization", "orbx_search_by_projection",
     "orbx_search_by_projection_points", "orbx_search_by_projection_fisheye", "orbx_search_by_projection_points_fisheye",
@@ -135,6 +135,8 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_matcher_download.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
     lib.orbx_search_by_projection_points_frames.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float,
                                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]
+    lib.orbx_search_for_initialization_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
+                                                          c_float, c_float, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p]
     lib.orbx_search_by_projection_frames.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float,
                                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int,
                                                      c_void_p, c_void_p, c_void_p]
@@ -506,6 +508,33 @@ class ORBmatcher:
         hk = np.empty((nframes, cap), KEYPOINT_DTYPE)
         _check(self._lib.orbx_matcher_download(self._h, c_void_p(kun.data_ptr()), hk.ctypes.data, hk.nbytes), "orbx_matcher_download")
         return self._download(nm), self._download(assign), hk
+
+    def SearchForInitializationFrames(self, ex1: "ORBextractor", ex2: "ORBextractor", npairs: int, k4, dist, bounds, windowSize: int = 100,
+                                      nnratio: float = 0.9, checkOrientation: bool = True, frame2_offset: int = 0, prev_matched=None,
+                                      download: bool = True):
+        """ORBmatcher::SearchForInitialization (reference src/ORBmatcher1.cc:650-765) for `npairs` frame pairs in one launch, on the
+        extractors' device-resident keypoints / descriptors: pair p = (frame p of ex1, frame p + frame2_offset of ex2).  prev_matched
+        [npairs, cap, 2] float32 (None: F1's undistorted keypoint positions).  Returns (nmatches[P], matches12[P, cap], prev[P, cap, 2])."""
+        import torch
+        dev = ex1.device
+        cap = ex1.capacity
+        if prev_matched is None:
+            prev = self._dev_empty((npairs, cap, 2), torch.float32, dev)
+        else:
+            prev = torch.from_numpy(np.ascontiguousarray(prev_matched, np.float32).reshape(npairs, cap, 2)).to(f"cuda:{dev}")
+        m12 = self._dev_empty((npairs, cap), torch.int32, dev); nm = self._dev_empty((npairs,), torch.int32, dev)
+        k4 = np.ascontiguousarray(k4, np.float32); dist = np.ascontiguousarray(dist, np.float32).ravel()
+        torch.cuda.synchronize()
+        _check(self._lib.orbx_search_for_initialization_frames(self._h, ex1._h, ex2._h, int(frame2_offset), int(npairs), k4.ctypes.data,
+                                                               dist.ctypes.data if len(dist) else None, len(dist), None, bounds[0], bounds[1], bounds[2],
+                                                               bounds[3], c_void_p(prev.data_ptr()), int(prev_matched is None), int(windowSize),
+                                                               float(nnratio), int(checkOrientation), c_void_p(m12.data_ptr()), c_void_p(nm.data_ptr())),
+               "orbx_search_for_initialization_frames")
+        if not download:
+            return nm, m12, prev
+        hp = np.empty((npairs, cap, 2), np.float32)
+        _check(self._lib.orbx_matcher_download(self._h, c_void_p(prev.data_ptr()), hp.ctypes.data, hp.nbytes), "orbx_matcher_download")
+        return self._download(nm), self._download(m12), hp
 
     def stereo_rows(self, kl, dl, kr, dr, n_rows: int, scale_factors, min_d: float, max_d: float):
         kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)

@@ -1917,6 +1917,49 @@ extern "C" int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor 
                                         d_nmatches);
 }
 
+// ORBmatcher::SearchForInitialization for a batch of frame pairs, device-resident - reference src/ORBmatcher1.cc:650-765 on
+// Frame::UndistortKeyPoints' output (src/Frame.cc:777-811) of both frames.
+extern "C" int orbx_search_for_initialization_frames(orbx_matcher *m, orbx_extractor *ex1, orbx_extractor *ex2, int frame2_offset, int npairs,
+                                                     const float *k4, const float *dist, int ndist, const float *knew4, float min_x, float max_x,
+                                                     float min_y, float max_y, float *d_prev_matched, int init_prev_matched, int window_size,
+                                                     float nnratio, int check_orientation, void *d_matches12, void *d_nmatches)
+{
+    const char *fn = "orbx_search_for_initialization_frames";
+    if (!m || !ex1 || !ex2) return setError(ORBX_ERR_INVALID_ARG, "%s: null handle", fn);
+    if (ex1->prm.device != m->device || ex2->prm.device != m->device)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: matcher and extractors must live on the same device", fn);
+    if (npairs < 0 || frame2_offset < 0 || npairs > ex1->lastFrames || npairs + frame2_offset > ex2->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: %d pairs (second frame + %d), the extractors' last batches hold %d / %d frames", fn, npairs,
+                        frame2_offset, ex1->lastFrames, ex2->lastFrames);
+    if (!d_prev_matched || !d_matches12 || !d_nmatches || window_size < 0)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    int rc = checkCamera(k4, dist, ndist, knew4 ? knew4 : k4, fn);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = checkGridBounds(min_x, max_x, min_y, max_y, fn)) != ORBX_OK) return rc;
+    const int cap1 = ex1->maxKeypoints, cap2 = ex2->maxKeypoints;
+    if (cap1 >= 65536 || cap2 >= 65536) return setError(ORBX_ERR_CAPACITY, "%s: at most 65535 keypoints per frame", fn);
+    if (npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t P = (size_t)npairs;
+    const orbx_keypoint *un1 = ex1->d_kps.p, *un2 = ex2->d_kps.p + (size_t)frame2_offset * cap2;
+    if ((rc = m->d_bin.ensure(P * cap1)) != ORBX_OK) return rc;
+    if ((rc = orderAfterExtractors(m, ex1, ex2)) != ORBX_OK) return rc;
+    if (!(ndist == 0 || dist[0] == 0.0)) {  // mvKeysUn of both frames (without distortion mvKeysUn = mvKeys, src/Frame.cc:779-783)
+        if ((rc = m->d_bKps.ensure(P * ((size_t)cap1 + cap2))) != ORBX_OK) return rc;
+        orbx_keypoint *u1 = m->d_bKps.p, *u2 = u1 + P * cap1;
+        HIP_TRY(orbxLaunchUndistort(m->stream, un1, u1, cap1, k4, dist, ndist, knew4 ? knew4 : k4, npairs, cap1, cap1, ex1->d_n.p));
+        HIP_TRY(orbxLaunchUndistort(m->stream, un2, u2, cap2, k4, dist, ndist, knew4 ? knew4 : k4, npairs, cap2, cap2, ex2->d_n.p + frame2_offset));
+        un1 = u1; un2 = u2;
+    }
+    const hipError_t e = orbxLaunchSearchInitBatch(m->stream, npairs, un1, ex1->d_desc.p, cap1, ex1->d_n.p, un2,
+                                                   ex2->d_desc.p + (size_t)frame2_offset * cap2 * 32, cap2, ex2->d_n.p + frame2_offset, cap1, cap2, min_x,
+                                                   max_x, min_y, max_y, d_prev_matched, init_prev_matched != 0, (int *)d_matches12, m->d_bin.p,
+                                                   (int *)d_nmatches, window_size, nnratio, check_orientation != 0);
+    if (e == hipErrorInvalidValue) return setError(ORBX_ERR_CAPACITY, "%s: %d keypoints per frame exceed what the search keeps in LDS", fn, cap1);
+    HIP_TRY(e);
+    return orderExtractorsAfter(m, ex1, ex2);
+}
+
 // Tracking::SearchLocalPoints' matcher (ORBmatcher::SearchByProjection(Frame &, const vector<MapPoint*> &, th, ..), reference
 // src/ORBmatcher1.cc:45-215, Nleft == -1) over a batch of frames: the same pipeline with the map-point records of orbx_search_by_projection_points
 extern "C" int orbx_search_by_projection_points_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,

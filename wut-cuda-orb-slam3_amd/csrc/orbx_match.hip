@@ -547,6 +547,10 @@ struct SearchInitArgs {
     signed char *binOf;            // [n1] rotation-histogram bin of the match recorded for i1, -1: none
     int *nmatches;
     int window; float nnratio; int checkOri;
+    // batch of (F1, F2) pairs (blockIdx.x of k_search_init_lds): per-pair strides in keypoint records, counts on the device
+    long long stride1, stride2;
+    const int *n1Dev, *n2Dev;
+    int initPrev;                  // 1: vbPrevMatched starts as the positions of F1's keypoints (what the initializer passes first)
 };
 
 __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
@@ -703,17 +707,31 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     __shared__ int hist[32];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    if (a.n1Dev) {  // pair p of a batch
+        const size_t p = blockIdx.x;
+        a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
+        a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32; a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32;
+        a.prev += p * a.stride1 * 2; a.m12 += p * a.stride1; a.binOf += p * a.stride1; a.nmatches += p;
+    }
     if (lane < 32) hist[lane] = 0;
     for (int i = lane; i < a.n1; i += 64) { a.m12[i] = -1; a.binOf[i] = -1; }
+    if (a.initPrev)
+        for (int i = lane; i < a.n1; i += 64) { a.prev[2 * i] = a.k1[i].x; a.prev[2 * i + 1] = a.k1[i].y; }
     // ---- octave-0 subsets ------------------------------------------------------------------------------------
     int n0 = 0, nL1 = 0;
     for (int ib = 0; ib < a.n2; ib += 64) {
         const int i = ib + lane;
         const bool z = i < a.n2 && a.k2[i].octave == 0;
         const unsigned long long m = __ballot(z);
-        if (z) orig[n0 + __popcll(m & lt)] = (uint16_t)i;
+        const int pos = n0 + __popcll(m & lt);
+        if (z && pos < SI_CAP2) orig[pos] = (uint16_t)i;
         n0 += __popcll(m);
     }
+    if (n0 > SI_CAP2) {  // (a single call never gets here: the host counted; a pair of a batch reports the capacity error)
+        if (lane == 0) *a.nmatches = -1;
+        return;
+    }
+    __threadfence_block();
     for (int ib = 0; ib < a.n1; ib += 64) {
         const int i = ib + lane;
         const bool z = i < a.n1 && !(a.k1[i].octave > 0);
@@ -909,12 +927,53 @@ bool orbxSearchInitInLds(int n1, int n2, int level0of2)
     return level0of2 >= 0 && level0of2 <= SI_CAP2 && n1 < 65536 && n2 < 65536 && searchInitLdsBytes(n1) <= 160 * 1024 - 1024;
 }
 
+static hipError_t searchInitLdsAttr(size_t lds)
+{
+    static size_t attrBytes[64] = {};  // per device (the kernel also has 128 B of static LDS: the dynamic part may not be set to the full 160 KB)
+    int devId = 0;
+    (void)hipGetDevice(&devId);
+    size_t &ab = attrBytes[devId & 63];
+    if (lds > ab) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_search_init_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        ab = lds;
+    }
+    return hipSuccess;
+}
+
+// SearchForInitialization for `npairs` (F1, F2) pairs, one wave (workgroup) each: F1 = pair p of k1 / d1 / prev / m12 (stride1 records),
+// F2 = pair p of k2 / d2 (stride2 records), counts from the device arrays.  A pair whose F2 has more than SI_CAP2 octave-0 keypoints gets
+// nmatches = -1.
+hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1, const uint8_t *d1, long long stride1, const int *n1Dev,
+                                     const void *k2, const uint8_t *d2, long long stride2, const int *n2Dev, int cap1, int cap2, float minX,
+                                     float maxX, float minY, float maxY, float *prev, int initPrev, int *m12, signed char *binOf, int *nmatches,
+                                     int window, float nnratio, int checkOri)
+{
+    if (npairs <= 0) return hipSuccess;
+    SearchInitArgs a;
+    a.k1 = (const MtKp *)k1; a.d1 = d1; a.n1 = cap1; a.k2 = (const MtKp *)k2; a.d2 = d2; a.n2 = cap2;
+    a.cellStart = nullptr; a.items = nullptr;
+    a.b.minX = minX; a.b.minY = minY;
+    a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);
+    a.prev = prev; a.m12 = m12; a.m21 = nullptr; a.mdist = nullptr; a.binOf = binOf; a.nmatches = nmatches;
+    a.window = window; a.nnratio = nnratio; a.checkOri = checkOri;
+    a.stride1 = stride1; a.stride2 = stride2; a.n1Dev = n1Dev; a.n2Dev = n2Dev; a.initPrev = initPrev;
+    if (cap1 >= 65536 || cap2 >= 65536) return hipErrorInvalidValue;
+    const size_t lds = searchInitLdsBytes(cap1);
+    if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
+    const hipError_t e = searchInitLdsAttr(lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), lds, st, a);
+    return hipGetLastError();
+}
+
 hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
                                 const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
                                 int checkOri, int level0of2)
 {
     SearchInitArgs a;
+    a.stride1 = 0; a.stride2 = 0; a.n1Dev = nullptr; a.n2Dev = nullptr; a.initPrev = 0;
     a.k1 = (const MtKp *)k1; a.d1 = d1; a.n1 = n1; a.k2 = (const MtKp *)k2; a.d2 = d2; a.n2 = n2;
     a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY;
@@ -924,15 +983,8 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     // level0of2 = number of octave-0 keypoints of F2 (counted by the caller on its host copy), < 0: unknown
     const size_t lds = searchInitLdsBytes(n1);
     if (orbxSearchInitInLds(n1, n2, level0of2)) {
-        static size_t attrBytes[64] = {};  // per device (the kernel also has 128 B of static LDS: the dynamic part may not be set to the full 160 KB)
-        int devId = 0;
-        (void)hipGetDevice(&devId);
-        size_t &ab = attrBytes[devId & 63];
-        if (lds > ab) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_search_init_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            ab = lds;
-        }
+        const hipError_t e = searchInitLdsAttr(lds);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_search_init_lds, dim3(1), dim3(64), lds, st, a);
     } else {
         hipLaunchKernelGGL(k_search_init, dim3(1), dim3(64), 0, st, a);
