@@ -191,6 +191,7 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
                                 int checkOri, int level0of2);
 
+hipError_t orbxLaunchUnpackFrames(hipStream_t st, const uint8_t *packed, uint8_t *dst, int w, int h, long long pitch, long long frameStride, int nf);
 hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1, const uint8_t *d1, long long stride1, const int *n1Dev,
                                      const void *k2, const uint8_t *d2, long long stride2, const int *n2Dev, int cap1, int cap2, float minX,
                                      float maxX, float minY, float maxY, float *prev, int initPrev, int *m12, signed char *binOf, int *nmatches,

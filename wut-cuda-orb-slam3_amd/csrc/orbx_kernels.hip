@@ -703,6 +703,27 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
     PF_STAMP(12);
 }
 
+// packed host frames [nf][h][w] (as they crossed the link in one linear copy) -> the pitched device layout k_pyr_fast reads
+__global__ __launch_bounds__(256) void k_unpack_frames(const uint8_t *src, uint8_t *dst, int w, int h, long long pitch, long long frameStride)
+{
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y, f = blockIdx.z;
+    if (c4 >= w) return;
+    const uint8_t *s = src + ((size_t)f * h + r) * w + c4;
+    uint8_t *d = dst + (size_t)f * frameStride + (size_t)r * pitch + c4;
+    if (c4 + 4 <= w) *(uint32_t *)d = *(const u32_unaligned *)s;
+    else
+        for (int k = 0; c4 + k < w; ++k) d[k] = s[k];
+}
+
+hipError_t orbxLaunchUnpackFrames(hipStream_t st, const uint8_t *packed, uint8_t *dst, int w, int h, long long pitch, long long frameStride, int nf)
+{
+    if (nf <= 0) return hipSuccess;
+    if ((pitch & 3) || (frameStride & 3) || ((uintptr_t)dst & 3) || h > 65535 || nf > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_unpack_frames, dim3((w + 1023) / 1024, h, nf), dim3(256), 0, st, packed, dst, w, h, pitch, frameStride);
+    return hipGetLastError();
+}
+
 hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch,
                              long long srcFrameStride, uint8_t *dst, int dw, int dh, int dstPitch,
                              long long dstFrameStride, OrbxResizeTabs tabs, uint32_t *cand, long long candFrameStride,
