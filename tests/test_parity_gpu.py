@@ -376,11 +376,13 @@ def test_trig_mode_parity(pkg, orc, trig_mode):
     ex.close()
 
 
-@pytest.mark.parametrize("env", [{"ORBX_GRAPH": "0"}, {"ORBX_GRAPH": "2"}, {"ORBX_GRAPH": "1"}])
+@pytest.mark.parametrize("env", [{"ORBX_GRAPH": "0"}, {"ORBX_GRAPH": "2"}, {"ORBX_GRAPH": "1"}, {"ORBX_SMALL_QT_BRANCHES": "2"},
+                                 {"ORBX_SMALL_QT_BRANCHES": "4", "ORBX_GRAPH": "2"}, {"ORBX_SMALL_QT_BRANCHES": "4"}])
 def test_small_batch_schedules(pkg, env):
-    """Batches of up to 16 frames run a schedule of their own (quadtree of level l right behind k_pyr_fast(l) on its own branch),
-    captured once as a hipGraph and replayed per call (ORBX_GRAPH=1, default); 2 = that schedule without capture, 0 = the batch
-    schedule.  Every stage of all three must be bit-identical to the oracle."""
+    """Batches of up to 16 frames run a schedule of their own (narrow tiles, one quadtree launch behind the pyramid chain or - with
+    ORBX_SMALL_QT_BRANCHES = 2 / 4 - groups of levels on branches of their own as soon as their candidates exist), captured once as a
+    hipGraph and replayed per call (ORBX_GRAPH=1, default); 2 = that schedule without capture, 0 = the batch schedule.  Every stage of
+    all of them must be bit-identical to the oracle."""
     _gpu_check_subprocess(env, (["640", "480", "1000", "1"], ["752", "480", "1200", "3"], ["333", "257", "600", "2"]))
 
 

@@ -6,8 +6,10 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/$tag
 mkdir -p $o
-timeout -k 10 600 python -m pytest tests -x -q -m gpu > $o/pytest_gpu.log 2>&1; echo "pytest exit=$?" >> $o/pytest_gpu.log
+if [ -z "$SKIP_TESTS" ]; then   # (SKIP_TESTS=1: the GPU tests ran in a call of their own)
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $o/pytest_gpu.log 2>&1; echo "pytest exit=$?" >> $o/pytest_gpu.log
 tail -3 $o/pytest_gpu.log
+fi
 bash tools/collect_traffic.sh > $o/traffic.log 2>&1
 cp gpurun_out/traffic/summary.json $o/hbm_traffic_pmc.json
 cp gpurun_out/traffic/pyr_fast_counters.json $o/pyr_fast_counters.json

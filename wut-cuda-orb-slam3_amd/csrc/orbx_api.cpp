@@ -667,7 +667,8 @@ static int stageHostFrames(orbx_extractor *ex, uint8_t *dst, ptrdiff_t dstPitch,
 // call: launched directly, the ~30 launches and ~15 event operations of a call keep the host behind the GPU (the k_pyr_fast chain
 // stalls waiting for its next launch).  Measured (MI355X, ROCm 7.2, 640x480, device-resident call + sync): batch schedule 0.34 ms,
 // this schedule launched directly 0.33 (1 - 2 branches) / 0.41 (4 branches), replayed as a graph 0.29 / 0.275 / 0.30 ms with
-// 1 / 2 / 4 quadtree branches - more branches than two cost more in cross-queue dependencies than they overlap.
+// 1 / 2 / 4 quadtree branches - with one-wave quadtree instances.  With the 8-wave instances (k_quadtree_mw, 0.06 instead of 0.15 ms
+// for the level-0 instance) nothing is left to overlap: 0.189 / 0.200 / 0.202 / 0.242 ms with 1 / 2 / 3 / 4 branches; default 1.
 // ORBX_GRAPH=0: batch schedule; 2: this schedule without capture (A/B runs, tools/experiments/single_frame_sweep.sh).
 
 static int smallBatchPrepare(orbx_extractor *ex)
@@ -690,11 +691,11 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
     hipError_t e;
 #define SB_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
     static const bool noBlur = getenv("ORBX_NO_BLUR") != nullptr;
-    // quadtree launches: the instance of level 0 is the longest single wave of the whole call (~150 us at VGA), level 1 the next.
-    // Default (2 branches): levels 0-1 start behind k_pyr_fast(1) on a branch of their own, the rest behind the last level on a
-    // second one (4 branches: {0}, {1}, {2, 3}, {4..}).  The branches launch the level-synchronous kernel only; the serial kernel
-    // for deferred instances (none on camera images) runs once, over all levels, after the join.
-    static const int branchEnv = [] { const char *q = getenv("ORBX_SMALL_QT_BRANCHES"); return q ? atoi(q) : 2; }();
+    // quadtree launches.  Default (1 branch): one launch for all levels behind the last k_pyr_fast.  2 branches: levels 0-1 start
+    // behind k_pyr_fast(1) on a branch of their own, the rest behind the last level on a second one (4 branches: {0}, {1}, {2, 3},
+    // {4..}) - what paid while the level-0 instance was a single 150-us wave.  The branches launch the level-synchronous kernel only;
+    // the serial kernel for deferred instances (none on camera images) runs once, over all levels, after the join.
+    static const int branchEnv = [] { const char *q = getenv("ORBX_SMALL_QT_BRANCHES"); return q ? atoi(q) : 1; }();
     int gEnd[4];  // last level of each group
     int ng = 0;
     if (branchEnv >= 4 && nl >= 5) { gEnd[0] = 0; gEnd[1] = 1; gEnd[2] = 3; gEnd[3] = nl - 1; ng = 4; }
