@@ -119,6 +119,12 @@ struct orbx_extractor {
     hipEvent_t evQt[ORBX_MAX_LEVELS] = {};
     hipEvent_t evPart[4] = {}, evStag[4] = {};   // front parts of a large batch (ORBX_FRONT_PARTS): end of a part's chain / of its level 0
     uint8_t *h_out = nullptr; size_t h_outBytes = 0;  // pinned staging for the single-frame download
+    // per-level argument blocks of k_pyr_fast<.., ML> (small batches: FAST of all levels in one launch), a few source buffers cached
+    struct LevelArgsKey { const void *src; int nframes; long long stride, frameStride; int generation, iniTh, minTh; };
+    DevBuf<uint8_t> d_pfArgs;
+    LevelArgsKey pfArgsKey[4] = {};
+    int pfArgsNext = 0;
+    const void *curLevelArgs = nullptr;      // the slot the next issueSmallBatch uses
 
     // level-0 source of the last batch (for orbx_get_pyramid_level)
     const uint8_t *lastSrc = nullptr; int lastSrcPitch = 0; long long lastSrcFrameStride = 0; int lastFrames = 0;
@@ -275,7 +281,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     ex->d_in.release(); ex->d_inPacked.release();
     for (auto &b : ex->d_raw) b.release();
     for (auto &b : ex->d_blur) b.release();
-    ex->d_qtNodes.release();
+    ex->d_qtNodes.release(); ex->d_pfArgs.release();
     ex->d_tabs.release(); ex->d_geom.release(); ex->d_cand.release(); ex->d_scratchA.release(); ex->d_scratchB.release();
     ex->d_sel.release(); ex->d_workKey.release(); ex->d_tileCount.release(); ex->d_selCount.release();
     ex->d_workPos.release(); ex->d_n.release(); ex->d_mono.release(); ex->d_kps.release(); ex->d_desc.release();
@@ -682,6 +688,41 @@ static int smallBatchPrepare(orbx_extractor *ex)
     return 1;
 }
 
+// Small batches run FAST of all levels in ONE launch behind a chain of resize-only launches (ORBX_SMALL_SPLIT=0: the fused per-level
+// chain): the device array of per-level argument blocks for this source buffer, uploaded when it is not cached.  Synchronous - must run
+// outside a stream capture.
+static const bool kSmallSplit = [] { const char *e = getenv("ORBX_SMALL_SPLIT"); return e ? atoi(e) != 0 : true; }();
+
+static int prepareLevelArgs(orbx_extractor *ex, const uint8_t *src0, int nf, ptrdiff_t stride, ptrdiff_t frame_stride)
+{
+    ex->curLevelArgs = nullptr;
+    if (!kSmallSplit) return ORBX_OK;
+    const int nl = ex->prm.nlevels;
+    const size_t blk = orbxPyrFastArgsBytes(), slotBytes = blk * ORBX_MAX_LEVELS;
+    int rc = ex->d_pfArgs.ensure(4 * slotBytes);
+    if (rc != ORBX_OK) return rc;
+    orbx_extractor::LevelArgsKey key;
+    memset(&key, 0, sizeof key);
+    key.src = src0; key.nframes = nf; key.stride = stride; key.frameStride = frame_stride; key.generation = ex->generation;
+    key.iniTh = ex->prm.ini_th_fast; key.minTh = ex->prm.min_th_fast;
+    for (int k = 0; k < 4; ++k)
+        if (memcmp(&key, &ex->pfArgsKey[k], sizeof key) == 0) { ex->curLevelArgs = ex->d_pfArgs.p + k * slotBytes; return ORBX_OK; }
+    const int slot = ex->pfArgsNext;
+    ex->pfArgsNext = (slot + 1) & 3;
+    std::vector<uint8_t> host(slotBytes, 0);
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeom &g = ex->geom[l];
+        orbxFillPyrFastLevelArgs(host.data() + l * blk, nf, g, l == 0 ? src0 : ex->d_raw[l].p, l == 0 ? (int)stride : g.pitch,
+                                 l == 0 ? (long long)frame_stride : g.frameStride, (const OrbxPfTile *)(ex->d_tabs.p + ex->tileOffsets[l]),
+                                 ex->d_cand.p, ex->candFrameStride, ex->d_tileCount.p, ex->tilesPerFrame, ex->prm.ini_th_fast, ex->prm.min_th_fast);
+    }
+    HIP_TRY(hipStreamSynchronize(ex->stream));  // (work in flight may still read the slot that is replaced)
+    HIP_TRY(hipMemcpy(ex->d_pfArgs.p + slot * slotBytes, host.data(), slotBytes, hipMemcpyHostToDevice));
+    ex->pfArgsKey[slot] = key;
+    ex->curLevelArgs = ex->d_pfArgs.p + slot * slotBytes;
+    return ORBX_OK;
+}
+
 static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1)
 {
     const int nl = ex->prm.nlevels;
@@ -707,7 +748,28 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
                                   ex->d_qtNodes.p, ex->d_qtNodes.n, which);
     };
     int gi = 0, gBegin = 0;
-    for (int l = 0; l < nl; ++l) {
+    const bool split = kSmallSplit && ex->curLevelArgs != nullptr;
+    if (split) {
+        // the pyramid by a chain of resize-only launches (a few microseconds each), then FAST of all levels in one launch: the chain of
+        // eight dependent fused launches was 106 of the ~195 us of a single-frame call; the blur starts right behind the resize chain
+        for (int l = 0; l + 1 < nl; ++l) {
+            const OrbxLevelGeom &g = ex->geom[l], &d = ex->geom[l + 1];
+            OrbxResizeTabs tabs;
+            memset(&tabs, 0, sizeof tabs);
+            const int *o = &ex->tabOffsets[(size_t)l * 6];
+            tabs.xofs = ex->d_tabs.p + o[0]; tabs.xab = ex->d_tabs.p + o[1]; tabs.yofs = ex->d_tabs.p + o[2]; tabs.yab = ex->d_tabs.p + o[3];
+            SB_TRY(orbxLaunchResizeLevel(sFront, nf, l == 0 ? src0 : ex->d_raw[l].p, l == 0 ? (int)stride : g.pitch,
+                                         l == 0 ? (long long)frame_stride : g.frameStride, g.h, ex->d_raw[l + 1].p, d.w, d.h, d.pitch, d.frameStride, tabs));
+        }
+        SB_TRY(hipEventRecord(ex->evFront[0], sFront));  // the pyramid exists
+        SB_TRY(orbxLaunchPyrFastLevels(sFront, nf, ex->geom.data(), nl, ex->curLevelArgs));
+        SB_TRY(hipEventRecord(ex->evLevel[nl - 1], sFront));
+        SB_TRY(hipStreamWaitEvent(ex->qtStream[0], ex->evLevel[nl - 1], 0));
+        SB_TRY(quadtree(ex->qtStream[0], 0, nl, ORBX_QT_LEVEL_SYNC));
+        SB_TRY(hipEventRecord(ex->evQt[0], ex->qtStream[0]));
+        ng = 1;
+    }
+    for (int l = 0; l < nl && !split; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
         const uint8_t *src = l == 0 ? src0 : ex->d_raw[l].p;
         const int srcPitch = l == 0 ? (int)stride : g.pitch;
@@ -734,7 +796,7 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
             ++gi;
         }
     }
-    SB_TRY(hipEventRecord(ex->evFront[0], sFront));
+    if (!split) SB_TRY(hipEventRecord(ex->evFront[0], sFront));
     // blur stream: every level, once the pyramid exists (short kernels; they run beside the quadtree)
     SB_TRY(hipStreamWaitEvent(sBlur, ex->evFront[0], 0));
     for (int l = 0; l < nl && !noBlur; ++l) {
@@ -768,6 +830,8 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
 static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1,
                          bool useGraph)
 {
+    int rcl = prepareLevelArgs(ex, src0, nf, stride, frame_stride);  // (before any capture: it may copy synchronously)
+    if (rcl != ORBX_OK) return rcl;
     if (!useGraph) { HIP_TRY(issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1)); return ORBX_OK; }
     const orbx_extractor::GraphKey key = {src0, nf, w, h, (long long)stride, (long long)frame_stride, lap0, lap1, ex->generation};
     if (!ex->graphExec || memcmp(&key, &ex->graphKey, sizeof key) != 0) {

@@ -191,6 +191,13 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
                                 int checkOri, int level0of2);
 
+hipError_t orbxLaunchResizeLevel(hipStream_t st, int nframes, const uint8_t *src, int srcPitch, long long srcFrameStride, int sh, uint8_t *dst,
+                                 int dw, int dh, int dstPitch, long long dstFrameStride, OrbxResizeTabs tabs);
+size_t orbxPyrFastArgsBytes();
+void orbxFillPyrFastLevelArgs(void *out, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch, long long srcFrameStride,
+                              const OrbxPfTile *tiles, uint32_t *cand, long long candFrameStride, int *tileCount, int tilesPerFrame, int iniTh,
+                              int minTh);
+hipError_t orbxLaunchPyrFastLevels(hipStream_t st, int nframes, const OrbxLevelGeom *geomsHost, int nlevels, const void *dLevelArgs);
 hipError_t orbxLaunchUnpackFrames(hipStream_t st, const uint8_t *packed, uint8_t *dst, int w, int h, long long pitch, long long frameStride, int nf);
 hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1, const uint8_t *d1, long long stride1, const int *n1Dev,
                                      const void *k2, const uint8_t *d2, long long stride2, const int *n2Dev, int cap1, int cap2, float minX,

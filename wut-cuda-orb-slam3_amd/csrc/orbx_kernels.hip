@@ -300,8 +300,21 @@ extern "C" int orbx_debug_pf_timing(unsigned long long *out) { return (int)hipMe
 #endif
 // DBG: the ablation mask / stop points of PyrFastArgs::phases (ORBX_PF_PHASES) are compiled in.  They are seven more wave-uniform
 // conditions that stay live through the FAST rounds (14 SGPRs, all spilled), so the production instance is built without them.
-template <bool DBG>
-__global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
+// ML (multi-level): FAST / NMS / ordered candidates of ALL levels of a (small) batch in one launch - the pyramid exists already
+// (k_resize_level chain), the per-level argument blocks (the same PyrFastArgs the per-level launches take, with dst = NULL) lie in a
+// device array and are read like the kernarg segment, through the constant address space (DESIGN 6 "One frame at a time").  The
+// per-level kernel (ML = false) reads its kernarg segment exactly as before: handing the block to a common body as a pointer cost it 12
+// spilled VGPRs and 0.23 ms per batch.
+struct PyrFastLevelsArgs {
+    const PyrFastArgs *levels;            // [nlevels]
+    int tileStart[ORBX_MAX_LEVELS + 1];   // prefix of the levels' tile counts
+    int nlevels, nframes;
+};
+template <bool ML> struct PyrFastKernArg { typedef PyrFastArgs type; };
+template <> struct PyrFastKernArg<true> { typedef PyrFastLevelsArgs type; };
+
+template <bool DBG, bool ML = false>
+__global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<ML>::type)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // Scalars are kept PER PHASE.  The kernel has four phases (stage, resize, FAST rounds, emission) and ~60 wave-uniform values
@@ -312,10 +325,26 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
     // the compiler cannot look through (`K()`, `T()`), with scalar loads, into registers that die with the phase.
     typedef const __attribute__((address_space(4))) PyrFastArgs KArgs;
     typedef const __attribute__((address_space(4))) OrbxPfTile TileK;
-    auto K = [&]() -> KArgs & { KArgs *p = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(p)); return *p; };
     int f, tileId;
+    KArgs *levelArgs = nullptr;
+    if constexpr (ML) {
+        typedef const __attribute__((address_space(4))) PyrFastLevelsArgs LArgs;
+        LArgs *la = (LArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        int unit;
+        if (!xcd_decode(la->nframes, la->tileStart[la->nlevels], f, unit)) return;
+        int level = 0;
+        for (int l = 1; l < la->nlevels; ++l) level += unit >= la->tileStart[l] ? 1 : 0;
+        tileId = unit - la->tileStart[level];
+        levelArgs = (KArgs *)(unsigned long long)(la->levels + level);
+    }
+    auto K = [&]() -> KArgs & {
+        KArgs *p;
+        if constexpr (ML) p = levelArgs; else p = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return *p;
+    };
     PF_STAMP(0);
-    {
+    if constexpr (!ML) {
         KArgs &a = K();
         if (!xcd_decode(a.nframes, a.g.nTiles, f, tileId)) return;
     }
@@ -703,6 +732,106 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(PyrFastArgs)
     PF_STAMP(12);
 }
 
+// cv::resize INTER_LINEAR fixed point (the same arithmetic as the resize phase of k_pyr_fast) from level l to level l + 1
+// in global memory: 4 destination pixels per lane.  Only used in front of k_pyr_fast_levels, where the launch chain - not the
+// arithmetic - is the cost.
+struct ResizeLevelArgs {
+    const uint8_t *src; int srcPitch; long long srcFrameStride; int sh;
+    uint8_t *dst; int dw, dh, dstPitch; long long dstFrameStride;
+    const int *xofs, *xab, *yofs, *yab;
+};
+__global__ __launch_bounds__(256) void k_resize_level(ResizeLevelArgs a)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y, f = blockIdx.z;
+    if (q * 4 >= a.dw) return;
+    const int sy = a.yofs[dy], wy = a.yab[dy];
+    const int b0 = wy & 0xFFFF, b1 = (unsigned)wy >> 16;
+    const int hm1 = a.sh - 1;
+    const uint8_t *r0 = a.src + (size_t)f * a.srcFrameStride + (size_t)min(max(sy, 0), hm1) * a.srcPitch;
+    const uint8_t *r1 = a.src + (size_t)f * a.srcFrameStride + (size_t)min(max(sy + 1, 0), hm1) * a.srcPitch;
+    uint32_t packed = 0;
+    const int n = min(4, a.dw - q * 4);
+    for (int j = 0; j < n; ++j) {
+        const int dx = q * 4 + j;
+        const int sx = a.xofs[dx], wx = a.xab[dx];
+        const int wa = (short)(wx & 0xFFFF), wb = wx >> 16;
+        // (where cv::resize clamps sx to w - 1 the right tap's weight is 0: it is not read)
+        const int h0 = r0[sx] * wa + (wb ? r0[sx + 1] * wb : 0);
+        const int h1 = r1[sx] * wa + (wb ? r1[sx + 1] * wb : 0);
+        const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        packed |= v << (8 * j);
+    }
+    uint8_t *d = a.dst + (size_t)f * a.dstFrameStride + (size_t)dy * a.dstPitch + q * 4;
+    if (n == 4) *(uint32_t *)d = packed;
+    else
+        for (int j = 0; j < n; ++j) d[j] = (uint8_t)(packed >> (8 * j));
+}
+
+hipError_t orbxLaunchResizeLevel(hipStream_t st, int nframes, const uint8_t *src, int srcPitch, long long srcFrameStride, int sh, uint8_t *dst,
+                                 int dw, int dh, int dstPitch, long long dstFrameStride, OrbxResizeTabs tabs)
+{
+    if (nframes <= 0) return hipSuccess;
+    if ((dstPitch & 3) || (dstFrameStride & 3) || dh > 65535 || nframes > 65535) return hipErrorInvalidValue;
+    ResizeLevelArgs a;
+    a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride; a.sh = sh;
+    a.dst = dst; a.dw = dw; a.dh = dh; a.dstPitch = dstPitch; a.dstFrameStride = dstFrameStride;
+    a.xofs = tabs.xofs; a.xab = tabs.xab; a.yofs = tabs.yofs; a.yab = tabs.yab;
+    hipLaunchKernelGGL(k_resize_level, dim3(((dw + 3) / 4 + 255) / 256, dh, nframes), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+static void fillPyrFastArgs(PyrFastArgs &a, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch, long long srcFrameStride,
+                            uint8_t *dst, int dw, int dh, int dstPitch, long long dstFrameStride, OrbxResizeTabs tabs, uint32_t *cand,
+                            long long candFrameStride, int *tileCount, int tilesPerFrame, int iniTh, int minTh)
+{
+    memset(&a, 0, sizeof a);
+    a.g = g;
+    a.tiles = tabs.pfTiles;
+    a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride;
+    {
+        const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride;
+        a.srcAlign = (bits & 15) == 0 ? 16 : ((bits & 3) == 0 ? 4 : 1);
+    }
+    a.dst = dst; a.dw = dw; a.dh = dh; a.dstPitch = dstPitch; a.dstFrameStride = dstFrameStride;
+    a.tabs = tabs;
+    a.cand = cand; a.candFrameStride = candFrameStride;
+    a.tileCount = tileCount; a.tilesPerFrame = tilesPerFrame;
+    a.iniTh = iniTh; a.minTh = minTh;
+    a.nframes = nframes;
+    a.phases = 15;
+}
+
+size_t orbxPyrFastArgsBytes() { return sizeof(PyrFastArgs); }
+
+// argument block of level `g` for k_pyr_fast_levels (no destination level), written to host memory `out` (orbxPyrFastArgsBytes() bytes)
+void orbxFillPyrFastLevelArgs(void *out, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch, long long srcFrameStride,
+                              const OrbxPfTile *tiles, uint32_t *cand, long long candFrameStride, int *tileCount, int tilesPerFrame, int iniTh,
+                              int minTh)
+{
+    OrbxResizeTabs tabs;
+    memset(&tabs, 0, sizeof tabs);
+    tabs.pfTiles = tiles;
+    fillPyrFastArgs(*(PyrFastArgs *)out, nframes, g, src, srcPitch, srcFrameStride, nullptr, 0, 0, 0, 0, tabs, cand, candFrameStride, tileCount,
+                    tilesPerFrame, iniTh, minTh);
+}
+
+hipError_t orbxLaunchPyrFastLevels(hipStream_t st, int nframes, const OrbxLevelGeom *geomsHost, int nlevels, const void *dLevelArgs)
+{
+    if (nlevels <= 0 || nlevels > ORBX_MAX_LEVELS) return hipErrorInvalidValue;
+    PyrFastLevelsArgs a;
+    memset(&a, 0, sizeof a);
+    a.levels = (const PyrFastArgs *)dLevelArgs;
+    a.nlevels = nlevels; a.nframes = nframes;
+    int lds = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        if (geomsHost[l].groupCells > PF_MAX_GROUP_CELLS) return hipErrorInvalidValue;
+        a.tileStart[l + 1] = a.tileStart[l] + geomsHost[l].nTiles;
+        lds = std::max(lds, geomsHost[l].ldsBytes);
+    }
+    hipLaunchKernelGGL((k_pyr_fast<false, true>), dim3(xcd_grid(nframes, a.tileStart[nlevels])), dim3(PF_NT), lds, st, a);
+    return hipGetLastError();
+}
+
 // packed host frames [nf][h][w] (as they crossed the link in one linear copy) -> the pitched device layout k_pyr_fast reads
 __global__ __launch_bounds__(256) void k_unpack_frames(const uint8_t *src, uint8_t *dst, int w, int h, long long pitch, long long frameStride)
 {
@@ -730,20 +859,9 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
                              int *tileCount, int tilesPerFrame, int iniTh, int minTh)
 {
     PyrFastArgs a;
-    a.g = g;
-    a.tiles = tabs.pfTiles;
-    if (!a.tiles) return hipErrorInvalidValue;
-    a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride;
-    {
-        const uintptr_t bits = (uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride;
-        a.srcAlign = (bits & 15) == 0 ? 16 : ((bits & 3) == 0 ? 4 : 1);
-    }
-    a.dst = dst; a.dw = dw; a.dh = dh; a.dstPitch = dstPitch; a.dstFrameStride = dstFrameStride;
-    a.tabs = tabs;
-    a.cand = cand; a.candFrameStride = candFrameStride;
-    a.tileCount = tileCount; a.tilesPerFrame = tilesPerFrame;
-    a.iniTh = iniTh; a.minTh = minTh;
-    a.nframes = nframes;
+    if (!tabs.pfTiles) return hipErrorInvalidValue;
+    fillPyrFastArgs(a, nframes, g, src, srcPitch, srcFrameStride, dst, dw, dh, dstPitch, dstFrameStride, tabs, cand, candFrameStride, tileCount,
+                    tilesPerFrame, iniTh, minTh);
     {
         static int phases = -1;
         if (phases < 0) { const char *e = getenv("ORBX_PF_PHASES"); phases = e ? atoi(e) : 15; }
