@@ -799,7 +799,22 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
     if (!split) SB_TRY(hipEventRecord(ex->evFront[0], sFront));
     // blur stream: every level, once the pyramid exists (short kernels; they run beside the quadtree)
     SB_TRY(hipStreamWaitEvent(sBlur, ex->evFront[0], 0));
-    for (int l = 0; l < nl && !noBlur; ++l) {
+    bool blurDone = noBlur;
+    static const bool blurOneLaunch = [] { const char *q = getenv("ORBX_SMALL_BLUR_LEVELS"); return q ? atoi(q) != 0 : true; }();
+    if (!blurDone && blurOneLaunch) {  // all levels in one launch (eight short launches in a row were the longest branch of the call)
+        int lw[ORBX_MAX_LEVELS], lh[ORBX_MAX_LEVELS], sp[ORBX_MAX_LEVELS], dp[ORBX_MAX_LEVELS];
+        long long sfs[ORBX_MAX_LEVELS], dfs[ORBX_MAX_LEVELS];
+        const uint8_t *sp0[ORBX_MAX_LEVELS]; uint8_t *dp0[ORBX_MAX_LEVELS];
+        for (int l = 0; l < nl; ++l) {
+            const OrbxLevelGeom &g = ex->geom[l];
+            lw[l] = g.w; lh[l] = g.h; sp0[l] = l == 0 ? src0 : ex->d_raw[l].p; sp[l] = l == 0 ? (int)stride : g.pitch;
+            sfs[l] = l == 0 ? (long long)frame_stride : g.frameStride; dp0[l] = ex->d_blur[l].p; dp[l] = blurTilesX(g); dfs[l] = blurFrameBytes(g);
+        }
+        e = orbxLaunchBlurLevels(sBlur, nf, nl, lw, lh, sp0, sp, sfs, dp0, dp, dfs, ex->taps);
+        if (e == hipSuccess) blurDone = true;
+        else if (e != hipErrorNotSupported) return e;
+    }
+    for (int l = 0; l < nl && !blurDone; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
         SB_TRY(orbxLaunchBlur(sBlur, nf, g.w, g.h, l == 0 ? src0 : ex->d_raw[l].p, l == 0 ? (int)stride : g.pitch,
                               l == 0 ? (long long)frame_stride : g.frameStride, ex->d_blur[l].p, blurTilesX(g), blurFrameBytes(g), ex->taps));

@@ -191,6 +191,9 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
                                 int checkOri, int level0of2);
 
+hipError_t orbxLaunchBlurLevels(hipStream_t st, int nframes, int nlevels, const int *w, const int *h, const uint8_t *const *src, const int *srcPitch,
+                                const long long *srcFrameStride, uint8_t *const *dst, const int *dstPitch, const long long *dstFrameStride,
+                                const int taps[7]);
 hipError_t orbxLaunchResizeLevel(hipStream_t st, int nframes, const uint8_t *src, int srcPitch, long long srcFrameStride, int sh, uint8_t *dst,
                                  int dw, int dh, int dstPitch, long long dstFrameStride, OrbxResizeTabs tabs);
 size_t orbxPyrFastArgsBytes();

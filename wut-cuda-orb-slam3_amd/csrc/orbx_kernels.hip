@@ -1089,12 +1089,10 @@ __device__ __forceinline__ int bl3_reflect(int p, int len)  // REFLECT_101 for -
 // with coalesced 16-byte loads (each 128-byte line is fetched once per workgroup; per-wave 8-byte gathers straight from global
 // memory fetched every line ~5 times through a thrashing L1) and the A operands are read from there.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
+__device__ __forceinline__ void blur3_body(const BlurArgs &a, const int f, const int unit)
 {
     constexpr int TW = 16 * NW, NVEC = NW + 2, LP = 16 * (NW + 3), NT = 64 * NW, ROWS = 16 * (BL3_SEG + 1);
     __shared__ __attribute__((aligned(16))) uint8_t tile[ROWS * LP];  // image columns [tx0, tx0 + TW + 32), REFLECT_101 rows
-    int f, unit;
-    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, unit)) return;
     const int sgx = unit % a.tilesX, seg = unit / a.tilesX;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tx0 = sgx * TW - 16;
@@ -1191,6 +1189,75 @@ __global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
         }
         loPrev = lo; hiPrev = hi;
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
+{
+    int f, unit;
+    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, unit)) return;
+    blur3_body<NW>(a, f, unit);
+}
+
+// every level of a (small) batch in one launch: eight launches of a few microseconds each were the longest branch of a single-frame call
+struct BlurLevelsArgs {
+    BlurArgs lv[ORBX_MAX_LEVELS];
+    int tileStart[ORBX_MAX_LEVELS + 1];
+    int nlevels, nframes;
+};
+__global__ __launch_bounds__(256) void k_blur3_levels(BlurLevelsArgs la)
+{
+    int f, unit;
+    if (!xcd_decode(la.nframes, la.tileStart[la.nlevels], f, unit)) return;
+    int level = 0;
+    for (int l = 1; l < la.nlevels; ++l) level += unit >= la.tileStart[l] ? 1 : 0;
+    const BlurArgs a = la.lv[level];
+    blur3_body<4>(a, f, unit - la.tileStart[level]);
+}
+
+static bool blur3Eligible(const int taps[7], int w, int h, const uint8_t *dst, long long dstFrameStride)
+{
+    static const int variant = [] { const char *e = getenv("ORBX_BLUR_KERNEL"); return e ? atoi(e) : 3; }();
+    static const int nw = [] { const char *e = getenv("ORBX_BLUR_WAVES"); return e ? atoi(e) : 4; }();
+    bool i8ok = true;
+    for (int k = 0; k < 7; ++k) i8ok = i8ok && taps[k] >= 0 && taps[k] <= 127;
+    const bool small = (taps[0] + taps[1] + taps[2]) * 2 + taps[3] <= 257;
+    return variant == 3 && nw == 4 && small && i8ok && (((uintptr_t)dst | (uintptr_t)dstFrameStride) & 3) == 0 && w >= 32 && h >= 16;
+}
+
+static void fillBlur3Args(BlurArgs &a, int nframes, int w, int h, const uint8_t *src, int srcPitch, long long srcFrameStride, uint8_t *dst,
+                          int dstPitch, long long dstFrameStride, const int taps[7])
+{
+    memset(&a, 0, sizeof a);
+    a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride;
+    a.dst = dst; a.dstPitch = dstPitch; a.dstFrameStride = dstFrameStride;
+    a.w = w; a.h = h;
+    for (int k = 0; k < 7; ++k) a.taps[k] = taps[k];
+    a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 15) == 0;
+    const int S = taps[0] + taps[1] + taps[2] + taps[3] + taps[4] + taps[5] + taps[6];
+    a.biasH = bl3_bias_bytes(128 * S);
+    a.biasL = bl3_bias_bytes(128 * S);
+    a.biasHi = bl3_bias_bytes(128 * S + 128);
+    a.nframes = nframes; a.tilesY = ((h + 15) / 16 + BL3_SEG - 1) / BL3_SEG;
+    a.tilesX = (w + 63) / 64;
+}
+
+// GaussianBlur of `nlevels` levels in one launch (k_blur3, 4 waves); hipErrorNotSupported when a level needs another kernel
+hipError_t orbxLaunchBlurLevels(hipStream_t st, int nframes, int nlevels, const int *w, const int *h, const uint8_t *const *src, const int *srcPitch,
+                                const long long *srcFrameStride, uint8_t *const *dst, const int *dstPitch, const long long *dstFrameStride,
+                                const int taps[7])
+{
+    if (nlevels <= 0 || nlevels > ORBX_MAX_LEVELS) return hipErrorInvalidValue;
+    BlurLevelsArgs la;
+    memset(&la, 0, sizeof la);
+    for (int l = 0; l < nlevels; ++l) {
+        if (!blur3Eligible(taps, w[l], h[l], dst[l], dstFrameStride[l])) return hipErrorNotSupported;
+        fillBlur3Args(la.lv[l], nframes, w[l], h[l], src[l], srcPitch[l], srcFrameStride[l], dst[l], dstPitch[l], dstFrameStride[l], taps);
+        la.tileStart[l + 1] = la.tileStart[l] + la.lv[l].tilesX * la.lv[l].tilesY;
+    }
+    la.nlevels = nlevels; la.nframes = nframes;
+    hipLaunchKernelGGL(k_blur3_levels, dim3(xcd_grid(nframes, la.tileStart[nlevels])), dim3(256), 0, st, la);
+    return hipGetLastError();
 }
 
 hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8_t *src, int srcPitch,
