@@ -377,12 +377,16 @@ def test_trig_mode_parity(pkg, orc, trig_mode):
 
 
 @pytest.mark.parametrize("env", [{"ORBX_GRAPH": "0"}, {"ORBX_GRAPH": "2"}, {"ORBX_GRAPH": "1"}, {"ORBX_SMALL_QT_BRANCHES": "2"},
-                                 {"ORBX_SMALL_QT_BRANCHES": "4", "ORBX_GRAPH": "2"}, {"ORBX_SMALL_QT_BRANCHES": "4"}])
+                                 {"ORBX_SMALL_QT_BRANCHES": "4", "ORBX_GRAPH": "2"}, {"ORBX_SMALL_QT_BRANCHES": "4"},
+                                 {"ORBX_SMALL_SPLIT": "0"}, {"ORBX_SMALL_SPLIT": "0", "ORBX_SMALL_QT_BRANCHES": "2"},
+                                 {"ORBX_SMALL_BLUR_LEVELS": "0"}, {"ORBX_SMALL_SPLIT": "1", "ORBX_GRAPH": "2"}])
 def test_small_batch_schedules(pkg, env):
     """Batches of up to 16 frames run a schedule of their own (narrow tiles, one quadtree launch behind the pyramid chain or - with
     ORBX_SMALL_QT_BRANCHES = 2 / 4 - groups of levels on branches of their own as soon as their candidates exist), captured once as a
-    hipGraph and replayed per call (ORBX_GRAPH=1, default); 2 = that schedule without capture, 0 = the batch schedule.  Every stage of
-    all of them must be bit-identical to the oracle."""
+    hipGraph and replayed per call (ORBX_GRAPH=1, default); 2 = that schedule without capture, 0 = the batch schedule.  By default the
+    pyramid comes from a chain of resize-only launches and FAST of all levels / the blur of all levels are one launch each
+    (ORBX_SMALL_SPLIT=0: the fused per-level chain, ORBX_SMALL_BLUR_LEVELS=0: a blur launch per level).  Every stage of all of them must
+    be bit-identical to the oracle."""
     _gpu_check_subprocess(env, (["640", "480", "1000", "1"], ["752", "480", "1200", "3"], ["333", "257", "600", "2"]))
 
 
@@ -405,4 +409,16 @@ def test_graph_replay_and_recapture(pkg, orc):
         for f in range(3):
             rmono, rk, rd = ref.extract(imgs[f], (0, 0))
             assert n[f] == len(rk) and kps[f, : n[f]].tobytes() == rk.tobytes() and desc[f, : n[f]].tobytes() == rd.tobytes()
+    # device-resident frames in six different buffers, visited round-robin: the per-level argument blocks of the one-launch FAST are
+    # cached for four source buffers, so slots are replaced and graphs re-captured all the time
+    import torch
+    frames = [pkg.synth_frame(90 + i, 640, 480) for i in range(6)]
+    dev = [torch.from_numpy(f[None]).to(f"cuda:{ex.device}") for f in frames]
+    refs = [ref.extract(f, (0, 0)) for f in frames]
+    for rnd in range(3):
+        for i in (0, 1, 2, 3, 4, 5, 2, 0):
+            ex.extract_batch_device(dev[i].data_ptr(), 1, 640, 480, 640, 640 * 480, (0, 0))
+            n, mono, kps, desc = ex.download_outputs(1)
+            rmono, rk, rd = refs[i]
+            assert n[0] == len(rk) and mono[0] == rmono and kps[0, : n[0]].tobytes() == rk.tobytes() and desc[0, : n[0]].tobytes() == rd.tobytes(), (rnd, i)
     ex.close()
