@@ -2782,7 +2782,10 @@ __global__ __launch_bounds__(QT4_NT) void k_quadtree_mw(QtArgs)
         qt4_body<true>(a, g, f, nodes, gA, gB, M, tc, selOut, selCnt);
         return;
     }
-    qt4_body<false>(a, g, f, qlds, gA, gB, M, tc, selOut, selCnt);
+    // launches with very few instances keep candidate sets that are scattered in place (<= 4096 keys) in LDS behind the node arrays:
+    // every pass re-reads the keys, and a single frame's level-0 instance is the longest item of the call
+    uint32_t *lK = (uint32_t *)(qlds + a.nodeBytes);
+    qt4_body<false>(a, g, f, qlds, M <= a.ldsKeys ? lK : gA, gB, M, tc, selOut, selCnt);
 }
 
 // serial formulation (one DivideNode at a time): every instance (a.variant == 1, A/B runs) or only those the kernel above
@@ -2894,7 +2897,10 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
         a.maxKeys = large ? mk2 : mk;
         a.mwKeys = large ? QT3_MAX_KEYS2 : QT3_MAX_KEYS;
         a.nodeBytes = (int)std::max(qt4NodeBytes(a.listCap, a.mwKeys), tileOffBytes);
-        size_t lds = (size_t)a.nodeBytes;
+        static const int mwLdsKeys = [] { const char *e = getenv("ORBX_QT_MW_LDS_KEYS"); return e ? atoi(e) : QT4_NW * QT4_KCH * WAVE; }();
+        a.ldsKeys = (long long)nframes * levelsRun <= 128 ? std::min(mwLdsKeys, QT4_NW * QT4_KCH * WAVE) : 0;
+        if ((size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t) > ldsMax) a.ldsKeys = 0;
+        size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
         a.nodeScratch = nullptr;
         if (lds > ldsMax) {
             if (!nodeScratch || nodeScratchBytes < (size_t)a.nodeBytes * nframes * levelsRun) return hipErrorInvalidValue;
