@@ -90,6 +90,7 @@ struct orbx_extractor {
     int tilesPerFrame = 0, selFrameStride = 0;
     std::vector<int> tabOffsets;  // per level transition: offsets into d_tabs for xofs,xab,yofs,yab,rowBeg,colBeg
     std::vector<int> tileOffsets; // per level: offset (ints) of the OrbxPfTile records of k_pyr_fast in d_tabs
+    int chainOffset = 0, chainTiles = 0, chainBufBytes = 0, chainTabBytes = 0;  // k_pyr_chain (small batches): tile rectangles in d_tabs, tiles per frame, LDS per buffer / for the table slices
 
     // device memory
     DevBuf<uint8_t> d_in;                       // staging for host-pointer input (level 0)
@@ -507,6 +508,58 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         const int *ri = (const int *)recs.data();
         tabs.insert(tabs.end(), ri, ri + recs.size() * (sizeof(OrbxPfTile) / sizeof(int)));
     }
+    // k_pyr_chain (the whole pyramid of a small batch in one launch): the pixels of every level are dealt over one grid of tiles (32 x 32
+    // at level 1, ORBX_CHAIN_TILE); per tile and level the rectangle it owns and the rectangle it needs = owned + the sources of what it needs one level up
+    int chainOffset = 0, chainTiles = 0, chainBufBytes = 0, chainTabBytes = 0;
+    if (nl >= 2 && ex->prm.max_batch <= ORBX_GRAPH_MAX_FRAMES) {
+        static const int chainTile = [] { const char *e = getenv("ORBX_CHAIN_TILE"); return e ? std::min(std::max(atoi(e), 16), 128) : 32; }();
+        const int nTx = (geom[1].w + chainTile - 1) / chainTile, nTy = (geom[1].h + chainTile - 1) / chainTile;
+        auto cut = [](int extent, int i, int n, bool align4) {
+            if (i <= 0) return 0;
+            if (i >= n) return extent;
+            const int c = (int)((long long)extent * i / n);
+            return align4 ? c & ~3 : c;
+        };
+        while (tabs.size() % 4) tabs.push_back(0);
+        chainOffset = (int)tabs.size();
+        chainTiles = nTx * nTy;
+        std::vector<int> rects((size_t)chainTiles * nl * 8, 0);
+        for (int j = 0; j < nTy; ++j)
+            for (int i = 0; i < nTx; ++i) {
+                int *rt = &rects[((size_t)j * nTx + i) * nl * 8];
+                for (int l = 1; l < nl; ++l) {
+                    int *q = rt + l * 8;
+                    q[4] = cut(geom[l].w, i, nTx, true); q[5] = cut(geom[l].w, i + 1, nTx, true);
+                    q[6] = cut(geom[l].h, j, nTy, false); q[7] = cut(geom[l].h, j + 1, nTy, false);
+                }
+                int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;  // needed one level up (empty)
+                int tabEntries = 0;
+                for (int l = nl - 1; l >= 0; --l) {
+                    int *q = rt + l * 8;
+                    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+                    if (l + 1 < nl && nx1 > nx0 && ny1 > ny0) {  // sources of needed[l + 1] in level l (transition tables l -> l + 1)
+                        const int *xo = &tabs[offs[(size_t)l * 6 + 0]], *yo = &tabs[offs[(size_t)l * 6 + 2]];
+                        const int wm1 = geom[l].w - 1, hm1 = geom[l].h - 1;
+                        x0 = std::min(std::max(xo[nx0], 0), wm1); x1 = std::min(std::max(xo[nx1 - 1], 0) + 1, wm1) + 1;
+                        y0 = std::min(std::max(yo[ny0], 0), hm1); y1 = std::min(std::max(yo[ny1 - 1] + 1, 0), hm1) + 1;
+                    }
+                    if (l >= 1 && q[5] > q[4] && q[7] > q[6]) {  // + what the tile owns at this level
+                        if (x1 > x0 && y1 > y0) { x0 = std::min(x0, q[4]); x1 = std::max(x1, q[5]); y0 = std::min(y0, q[6]); y1 = std::max(y1, q[7]); }
+                        else { x0 = q[4]; x1 = q[5]; y0 = q[6]; y1 = q[7]; }
+                    }
+                    q[0] = x0; q[1] = x1; q[2] = y0; q[3] = y1;
+                    const int pitch = l == 0 ? ((x1 - x0) + 3) & ~3 : (((x1 + 3) >> 2) - (x0 >> 2)) * 4;
+                    chainBufBytes = std::max(chainBufBytes, pitch * (y1 - y0));
+                    if (l >= 1) tabEntries += pitch + (y1 - y0);
+                    nx0 = x0; nx1 = x1; ny0 = y0; ny1 = y1;
+                }
+                chainTabBytes = std::max(chainTabBytes, tabEntries * 8);
+            }
+        chainBufBytes = (int)roundUp((size_t)chainBufBytes + 16, 16);
+        chainTabBytes = (int)roundUp((size_t)chainTabBytes + 16, 16);
+        tabs.insert(tabs.end(), rects.begin(), rects.end());
+        if (2 * (size_t)chainBufBytes + chainTabBytes > 64 * 1024) chainTiles = 0;  // (does not happen with tiles of this size)
+    }
     if (tabs.empty()) tabs.push_back(0);
     (void)hipSetDevice(ex->prm.device);
     int rc = ex->d_tabs.ensure(tabs.size());
@@ -519,6 +572,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
     ex->geom.swap(geom);
     ex->tabOffsets.swap(offs);
     ex->tileOffsets.swap(tileOffs);
+    ex->chainOffset = chainOffset; ex->chainTiles = chainTiles; ex->chainBufBytes = chainBufBytes; ex->chainTabBytes = chainTabBytes;
     ex->candFrameStride = candOff;
     ex->tilesPerFrame = tileOff;
     ex->selFrameStride = selOff;
@@ -752,7 +806,27 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
     if (split) {
         // the pyramid by a chain of resize-only launches (a few microseconds each), then FAST of all levels in one launch: the chain of
         // eight dependent fused launches was 106 of the ~195 us of a single-frame call; the blur starts right behind the resize chain
-        for (int l = 0; l + 1 < nl; ++l) {
+        static const bool pyrOneLaunch = [] { const char *q = getenv("ORBX_SMALL_PYR_CHAIN"); return q ? atoi(q) != 0 : true; }();
+        bool pyramidDone = false;
+        if (pyrOneLaunch && ex->chainTiles > 0) {  // the whole pyramid in one launch (k_pyr_chain)
+            uint8_t *dp[ORBX_MAX_LEVELS] = {}; int dpitch[ORBX_MAX_LEVELS] = {}, lw[ORBX_MAX_LEVELS] = {}, lh[ORBX_MAX_LEVELS] = {};
+            long long dfs[ORBX_MAX_LEVELS] = {};
+            const int *xo[ORBX_MAX_LEVELS] = {}, *xa[ORBX_MAX_LEVELS] = {}, *yo[ORBX_MAX_LEVELS] = {}, *ya[ORBX_MAX_LEVELS] = {};
+            for (int l = 0; l < nl; ++l) {
+                const OrbxLevelGeom &g = ex->geom[l];
+                lw[l] = g.w; lh[l] = g.h;
+                if (l > 0) {
+                    dp[l] = ex->d_raw[l].p; dpitch[l] = g.pitch; dfs[l] = g.frameStride;
+                    const int *o = &ex->tabOffsets[(size_t)(l - 1) * 6];
+                    xo[l] = ex->d_tabs.p + o[0]; xa[l] = ex->d_tabs.p + o[1]; yo[l] = ex->d_tabs.p + o[2]; ya[l] = ex->d_tabs.p + o[3];
+                }
+            }
+            e = orbxLaunchPyrChain(sFront, nf, nl, src0, (int)stride, (long long)frame_stride, dp, dpitch, dfs, lw, lh, xo, xa, yo, ya,
+                                   ex->d_tabs.p + ex->chainOffset, ex->chainTiles, ex->chainBufBytes, ex->chainTabBytes);
+            if (e == hipSuccess) pyramidDone = true;
+            else if (e != hipErrorInvalidValue) return e;
+        }
+        for (int l = 0; l + 1 < nl && !pyramidDone; ++l) {
             const OrbxLevelGeom &g = ex->geom[l], &d = ex->geom[l + 1];
             OrbxResizeTabs tabs;
             memset(&tabs, 0, sizeof tabs);

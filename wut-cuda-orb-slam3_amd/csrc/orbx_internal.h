@@ -194,6 +194,10 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
 hipError_t orbxLaunchBlurLevels(hipStream_t st, int nframes, int nlevels, const int *w, const int *h, const uint8_t *const *src, const int *srcPitch,
                                 const long long *srcFrameStride, uint8_t *const *dst, const int *dstPitch, const long long *dstFrameStride,
                                 const int taps[7]);
+hipError_t orbxLaunchPyrChain(hipStream_t st, int nframes, int nlevels, const uint8_t *src, int srcPitch, long long srcFrameStride,
+                              uint8_t *const *dst, const int *dstPitch, const long long *dstFrameStride, const int *w, const int *h,
+                              const int *const *xofs, const int *const *xab, const int *const *yofs, const int *const *yab, const int *rects,
+                              int nTiles, int bufBytes, int tabBytes);
 hipError_t orbxLaunchResizeLevel(hipStream_t st, int nframes, const uint8_t *src, int srcPitch, long long srcFrameStride, int sh, uint8_t *dst,
                                  int dw, int dh, int dstPitch, long long dstFrameStride, OrbxResizeTabs tabs);
 size_t orbxPyrFastArgsBytes();

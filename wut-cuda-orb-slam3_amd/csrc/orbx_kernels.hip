@@ -767,6 +767,126 @@ __global__ __launch_bounds__(256) void k_resize_level(ResizeLevelArgs a)
         for (int j = 0; j < n; ++j) d[j] = (uint8_t)(packed >> (8 * j));
 }
 
+// The whole pyramid of a (small) batch in ONE launch, without any synchronisation between workgroups: a workgroup owns one tile of every
+// level (the levels' pixels dealt over the same tile grid) and computes, level by level in LDS, the region of each level it needs for
+// its own tiles of all further levels (host-computed `needed` rectangles: needed[l] = owned[l] + the sources of needed[l + 1]).  Halo
+// pixels are computed by several workgroups - the arithmetic is exact integer, so every copy is the same value - and only owned pixels
+// are written.  Seven dependent resize launches were 57 us of a single-frame call.
+struct PyrChainArgs {
+    const uint8_t *src; int srcPitch; long long srcFrameStride;
+    uint8_t *dst[ORBX_MAX_LEVELS]; int dstPitch[ORBX_MAX_LEVELS]; long long dstFrameStride[ORBX_MAX_LEVELS];  // [1 .. nlevels)
+    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS];
+    const int *xofs[ORBX_MAX_LEVELS], *xab[ORBX_MAX_LEVELS], *yofs[ORBX_MAX_LEVELS], *yab[ORBX_MAX_LEVELS];  // transition l - 1 -> l at [l]
+    const int *rects;       // [nTiles][nlevels][8]: needed x0, x1, y0, y1 (exclusive ends), owned x0, x1, y0, y1
+    int nTiles, nlevels, nframes, bufBytes, tabBytes;
+};
+
+__global__ __launch_bounds__(256) void k_pyr_chain(PyrChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t pc_lds[];
+    int f, tile;
+    if (!xcd_decode(a.nframes, a.nTiles, f, tile)) return;
+    const int tid = threadIdx.x;
+    const int *rt = a.rects + (size_t)tile * a.nlevels * 8;
+    uint8_t *prev = pc_lds, *cur = pc_lds + a.bufBytes;
+    int2 *tabs = (int2 *)(pc_lds + 2 * (size_t)a.bufBytes);  // per level: (xofs, xab) of the needed columns, then (yofs, yab) of the needed rows
+    // all table slices and the level-0 region are requested at once: one global round trip for the whole chain
+    {
+        int toff = 0;
+        for (int l = 1; l < a.nlevels; ++l) {
+            const int *q = rt + l * 8;
+            const int gx0 = q[0] & ~3, nX = (((q[1] + 3) >> 2) << 2) - gx0, nY = q[3] - q[2];
+            const int *xofs = a.xofs[l], *xab = a.xab[l], *yofs = a.yofs[l], *yab = a.yab[l];
+            const int wl = a.w[l];
+            for (int i = tid; i < nX + nY; i += 256) {
+                int2 e = make_int2(0, 0);
+                if (i < nX) { const int dx = gx0 + i; if (dx < wl) e = make_int2(xofs[dx], xab[dx]); }
+                else { const int dy = q[2] + (i - nX); e = make_int2(yofs[dy], yab[dy]); }
+                tabs[toff + i] = e;
+            }
+            toff += nX + nY;
+        }
+    }
+    int px0 = rt[0], px1 = rt[1], py0 = rt[2], py1 = rt[3];
+    int pp = ((px1 - px0) + 3) & ~3;  // LDS pitch of the previous level's region
+    {
+        const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
+        const int wr = px1 - px0, nr = py1 - py0;
+        const float invW = __builtin_amdgcn_rcpf((float)max(wr, 1));
+        for (int it = tid; it < wr * nr; it += 256) {
+            const int r = (int)(((float)it + 0.5f) * invW), c = it - r * wr;
+            prev[r * pp + c] = srcF[(size_t)(py0 + r) * a.srcPitch + px0 + c];
+        }
+    }
+    __syncthreads();
+    int toff = 0;
+    for (int l = 1; l < a.nlevels; ++l) {
+        const int *q = rt + l * 8;
+        const int x0 = q[0], x1 = q[1], y0 = q[2], y1 = q[3], ox0 = q[4], ox1 = q[5], oy0 = q[6], oy1 = q[7];
+        const int gx0 = x0 & ~3, ng = ((x1 + 3) >> 2) - (gx0 >> 2), nr = y1 - y0;
+        const int cp = ng * 4;  // LDS pitch of this level's region (column gx0 at offset 0)
+        const int2 *tx = tabs + toff, *ty = tx + cp;
+        toff += cp + nr;
+        const int hm1 = a.h[l - 1] - 1;
+        uint8_t *dstF = a.dst[l] + (size_t)f * a.dstFrameStride[l];
+        const float invG = __builtin_amdgcn_rcpf((float)max(ng, 1));
+        for (int it = tid; it < ng * nr; it += 256) {
+            const int r = (int)(((float)it + 0.5f) * invG), gq = it - r * ng;
+            const int dy = y0 + r, dx0 = gx0 + 4 * gq;
+            const int2 ye = ty[r];
+            const int sy = ye.x, b0 = ye.y & 0xFFFF, b1 = (unsigned)ye.y >> 16;
+            const uint8_t *r0 = prev + (min(max(sy, 0), hm1) - py0) * pp - px0;
+            const uint8_t *r1 = prev + (min(max(sy + 1, 0), hm1) - py0) * pp - px0;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dx = dx0 + j;
+                if (dx >= x0 && dx < x1) {
+                    const int2 xe = tx[4 * gq + j];
+                    const int sx = xe.x, wa = (short)(xe.y & 0xFFFF), wb = xe.y >> 16;
+                    const int h0 = r0[sx] * wa + (wb ? r0[sx + 1] * wb : 0);
+                    const int h1 = r1[sx] * wa + (wb ? r1[sx + 1] * wb : 0);
+                    packed |= (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) << (8 * j);
+                }
+            }
+            *(uint32_t *)(cur + r * cp + 4 * gq) = packed;
+            if (dy >= oy0 && dy < oy1) {
+                uint8_t *d = dstF + (size_t)dy * a.dstPitch[l] + dx0;
+                if (dx0 >= ox0 && dx0 + 4 <= ox1) *(uint32_t *)d = packed;
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (dx0 + j >= ox0 && dx0 + j < ox1) d[j] = (uint8_t)(packed >> (8 * j));
+            }
+        }
+        __syncthreads();
+        uint8_t *t = prev; prev = cur; cur = t;
+        px0 = gx0; py0 = y0; pp = cp;
+    }
+}
+
+hipError_t orbxLaunchPyrChain(hipStream_t st, int nframes, int nlevels, const uint8_t *src, int srcPitch, long long srcFrameStride,
+                              uint8_t *const *dst, const int *dstPitch, const long long *dstFrameStride, const int *w, const int *h,
+                              const int *const *xofs, const int *const *xab, const int *const *yofs, const int *const *yab, const int *rects,
+                              int nTiles, int bufBytes, int tabBytes)
+{
+    if (nframes <= 0 || nlevels < 2) return hipSuccess;
+    if (nlevels > ORBX_MAX_LEVELS || 2 * (size_t)bufBytes + (size_t)tabBytes > 64 * 1024 || (bufBytes & 7)) return hipErrorInvalidValue;
+    PyrChainArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride;
+    for (int l = 0; l < nlevels; ++l) {
+        a.w[l] = w[l]; a.h[l] = h[l];
+        if (l > 0) {
+            if ((dstPitch[l] & 3) || (dstFrameStride[l] & 3) || ((uintptr_t)dst[l] & 3)) return hipErrorInvalidValue;
+            a.dst[l] = dst[l]; a.dstPitch[l] = dstPitch[l]; a.dstFrameStride[l] = dstFrameStride[l];
+            a.xofs[l] = xofs[l]; a.xab[l] = xab[l]; a.yofs[l] = yofs[l]; a.yab[l] = yab[l];
+        }
+    }
+    a.rects = rects; a.nTiles = nTiles; a.nlevels = nlevels; a.nframes = nframes; a.bufBytes = bufBytes; a.tabBytes = tabBytes;
+    hipLaunchKernelGGL(k_pyr_chain, dim3(xcd_grid(nframes, nTiles)), dim3(256), 2 * (size_t)bufBytes + (size_t)tabBytes, st, a);
+    return hipGetLastError();
+}
+
 hipError_t orbxLaunchResizeLevel(hipStream_t st, int nframes, const uint8_t *src, int srcPitch, long long srcFrameStride, int sh, uint8_t *dst,
                                  int dw, int dh, int dstPitch, long long dstFrameStride, OrbxResizeTabs tabs)
 {
