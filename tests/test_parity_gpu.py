@@ -379,14 +379,16 @@ def test_trig_mode_parity(pkg, orc, trig_mode):
 @pytest.mark.parametrize("env", [{"ORBX_GRAPH": "0"}, {"ORBX_GRAPH": "2"}, {"ORBX_GRAPH": "1"}, {"ORBX_SMALL_QT_BRANCHES": "2"},
                                  {"ORBX_SMALL_QT_BRANCHES": "4", "ORBX_GRAPH": "2"}, {"ORBX_SMALL_QT_BRANCHES": "4"},
                                  {"ORBX_SMALL_SPLIT": "0"}, {"ORBX_SMALL_SPLIT": "0", "ORBX_SMALL_QT_BRANCHES": "2"},
-                                 {"ORBX_SMALL_BLUR_LEVELS": "0"}, {"ORBX_SMALL_SPLIT": "1", "ORBX_GRAPH": "2"}])
+                                 {"ORBX_SMALL_BLUR_LEVELS": "0"}, {"ORBX_SMALL_SPLIT": "1", "ORBX_GRAPH": "2"}, {"ORBX_SMALL_PYR_CHAIN": "0"},
+                                 {"ORBX_CHAIN_TILE": "64"}, {"ORBX_CHAIN_TILE": "16"}])
 def test_small_batch_schedules(pkg, env):
     """Batches of up to 16 frames run a schedule of their own (narrow tiles, one quadtree launch behind the pyramid chain or - with
     ORBX_SMALL_QT_BRANCHES = 2 / 4 - groups of levels on branches of their own as soon as their candidates exist), captured once as a
     hipGraph and replayed per call (ORBX_GRAPH=1, default); 2 = that schedule without capture, 0 = the batch schedule.  By default the
     pyramid comes from a chain of resize-only launches and FAST of all levels / the blur of all levels are one launch each
-    (ORBX_SMALL_SPLIT=0: the fused per-level chain, ORBX_SMALL_BLUR_LEVELS=0: a blur launch per level).  Every stage of all of them must
-    be bit-identical to the oracle."""
+    (ORBX_SMALL_SPLIT=0: the fused per-level chain, ORBX_SMALL_BLUR_LEVELS=0: a blur launch per level, ORBX_SMALL_PYR_CHAIN=0: a resize
+    launch per level instead of the one-launch pyramid, ORBX_CHAIN_TILE: its tile size).  Every stage of all of them must be bit-identical
+    to the oracle."""
     _gpu_check_subprocess(env, (["640", "480", "1000", "1"], ["752", "480", "1200", "3"], ["333", "257", "600", "2"]))
 
 
