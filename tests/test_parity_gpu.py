@@ -293,6 +293,45 @@ def test_two_handles_concurrently(pkg, orc):
     [e.close() for e in exs]
 
 
+def test_two_threads_recapturing_all_the_time(pkg, orc):
+    """Two single-frame handles in two threads while both keep re-capturing their launch graphs (the image size changes every call) and
+    a third thread creates / destroys handles and matchers (allocations, synchronous copies): a thread in the default stream-capture mode
+    may not make a synchronising call while ANY capture is open, so every entry point runs in relaxed mode.  Results equal the oracle."""
+    import threading
+    sizes = [(640, 480), (752, 480), (400, 300)]
+    imgs = {(i, s): pkg.synth_frame(200 + 10 * i + k, *s) for i in range(2) for k, s in enumerate(sizes)}
+    refs = {key: orc.Oracle(800, 1.2, 8, 20, 7).extract(im, (0, 0)) for key, im in imgs.items()}
+    exs = [pkg.ORBextractor(800, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=1) for _ in range(2)]
+    errors = []
+
+    def work(i):
+        try:
+            for it in range(24):
+                s = sizes[it % 3]
+                mono, kps, desc = exs[i](imgs[(i, s)], None, (0, 0))
+                rmono, rk, rd = refs[(i, s)]
+                if mono != rmono or kps.tobytes() != rk.tobytes() or desc.tobytes() != rd.tobytes():
+                    errors.append(f"thread {i} iteration {it}: result differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {e}")
+
+    def churn():
+        try:
+            for _ in range(12):
+                ex = pkg.ORBextractor(500, 1.2, 8, 20, 7, max_width=320, max_height=240, max_batch=1)
+                ex(pkg.synth_frame(5, 320, 240), None, (0, 0))
+                m = pkg.ORBmatcher(2048, 2048)
+                m.close(); ex.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"churn: {e}")
+
+    th = [threading.Thread(target=work, args=(0,)), threading.Thread(target=work, args=(1,)), threading.Thread(target=churn)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    [e.close() for e in exs]
+    assert not errors, errors[:3]
+
+
 def _gpu_check_subprocess(extra_env, arg_sets):
     import os
     import subprocess

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,12 @@
 // errors
 // ---------------------------------------------------------------------------------------------------------
 static thread_local std::string g_lastError;
+// Setup work - allocations, synchronous uploads, handle creation / destruction, the capture + instantiation of a launch graph - is
+// serialised over all handles of the process: a synchronising call must not fall into another thread's open stream capture (it
+// invalidates the capture, and the runtime does not survive the two racing), and it is rare (first call, new image size, new source
+// buffer).  Steady-state calls - graph replay or kernel launches on the handle's own streams, asynchronous downloads - take no lock.
+static std::recursive_mutex g_setupMutex;
+#define ORBX_SETUP_LOCK std::lock_guard<std::recursive_mutex> orbxSetupLock__(g_setupMutex)
 
 static int setError(int code, const char *fmt, ...)
 {
@@ -42,6 +49,22 @@ static int setError(int code, const char *fmt, ...)
 
 extern "C" const char *orbx_last_error(void) { return g_lastError.c_str(); }
 
+// Every entry point runs with the calling thread's stream-capture mode set to "relaxed".  A handle for single frames captures its
+// launch sequence as a hipGraph; while ANY capture is open in the process, a thread in the default (global) mode may not make a
+// synchronising call - an allocation, a synchronous copy - even on unrelated streams, so a second handle used from another thread (the
+// reference extracts the left and the right image in two threads, src/Frame.cc:124-127) failed with "operation would make the legacy
+// stream depend on a capturing blocking stream" and invalidated the first thread's capture.  All streams of this library are
+// non-blocking and never depend on the legacy stream, which is what makes the relaxed mode safe here.
+struct RelaxedCaptureMode {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    bool ok;
+    RelaxedCaptureMode() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; }
+    ~RelaxedCaptureMode() { if (ok) (void)hipThreadExchangeStreamCaptureMode(&mode); }
+    RelaxedCaptureMode(const RelaxedCaptureMode &) = delete;
+    RelaxedCaptureMode &operator=(const RelaxedCaptureMode &) = delete;
+};
+#define ORBX_API_ENTRY RelaxedCaptureMode orbxCaptureModeGuard__
+
 // OpenCV scalar helpers
 static inline int cvRoundF(float v) { return (int)lrintf(v); }
 static inline int cvRoundD(double v) { return (int)lrint(v); }
@@ -56,13 +79,14 @@ template <class T> struct DevBuf {
     int ensure(size_t count)
     {
         if (count <= n) return ORBX_OK;
+        ORBX_SETUP_LOCK;
         if (p) { (void)hipFree(p); p = nullptr; n = 0; }
         hipError_t e = hipMalloc((void **)&p, count * sizeof(T) + 256);
         if (e != hipSuccess) return setError(ORBX_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
         n = count;
         return ORBX_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) { ORBX_SETUP_LOCK; (void)hipFree(p); } p = nullptr; n = 0; }
 };
 
 #define ORBX_GRAPH_MAX_FRAMES 16  // "small batch": schedule, tile width and download path for a front end that feeds single frames
@@ -136,6 +160,7 @@ struct orbx_extractor {
 // ---------------------------------------------------------------------------------------------------------
 extern "C" void orbx_default_params(orbx_params *p)
 {
+    ORBX_API_ENTRY;
     if (!p) return;
     p->nfeatures = 1000; p->scale_factor = 1.2f; p->nlevels = 8; p->ini_th_fast = 20; p->min_th_fast = 7;
     p->device = 0; p->max_width = 640; p->max_height = 480; p->max_batch = 1;
@@ -144,6 +169,7 @@ extern "C" void orbx_default_params(orbx_params *p)
 
 extern "C" int orbx_device_count(void)
 {
+    ORBX_API_ENTRY;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -158,6 +184,8 @@ static int ensureBuffers(orbx_extractor *ex);
 
 extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!p || !out) return setError(ORBX_ERR_INVALID_ARG, "orbx_create: null argument");
     *out = nullptr;
     if (p->nfeatures <= 0 || p->nlevels <= 0 || p->nlevels > ORBX_MAX_LEVELS || !(p->scale_factor > 1.0f))
@@ -256,6 +284,8 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
 
 extern "C" void orbx_destroy(orbx_extractor *ex)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!ex) return;
     (void)hipSetDevice(ex->prm.device);
     if (ex->streamCopy) { (void)hipStreamSynchronize(ex->streamCopy); (void)hipStreamDestroy(ex->streamCopy); }
@@ -312,6 +342,7 @@ extern "C" void *orbx_stream(orbx_extractor *ex) { return ex ? (void *)ex->strea
 
 extern "C" int orbx_level_sizes(const orbx_extractor *ex, int w, int h, int32_t *lw, int32_t *lh)
 {
+    ORBX_API_ENTRY;
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_level_sizes: null handle");
     for (int l = 0; l < ex->prm.nlevels; ++l) {
         if (lw) lw[l] = cvRoundF((float)w * ex->invScale[l]);
@@ -326,6 +357,7 @@ extern "C" int orbx_level_sizes(const orbx_extractor *ex, int w, int h, int32_t 
 static int computeGeometry(orbx_extractor *ex, int w, int h)
 {
     if (w == ex->curW && h == ex->curH && !ex->geom.empty()) return ORBX_OK;
+    ORBX_SETUP_LOCK;
     ++ex->generation;  // captured launch sequences of the old geometry are stale
     const int nl = ex->prm.nlevels;
     std::vector<OrbxLevelGeom> geom(nl);
@@ -624,6 +656,8 @@ static const int PROF_EVENTS = ORBX_MAX_SUB * ORBX_NUM_STAGES * 2;  // [sub-batc
 
 extern "C" int orbx_set_profiling(orbx_extractor *ex, int enable)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_set_profiling: null handle");
     HIP_TRY(hipSetDevice(ex->prm.device));
     if (enable && ex->events.empty()) {
@@ -638,6 +672,7 @@ extern "C" int orbx_set_profiling(orbx_extractor *ex, int enable)
 
 extern "C" int orbx_get_stage_times(orbx_extractor *ex, float *ms)
 {
+    ORBX_API_ENTRY;
     if (!ex || !ms) return setError(ORBX_ERR_INVALID_ARG, "orbx_get_stage_times: null argument");
     for (int s = 0; s < ORBX_NUM_STAGES; ++s) ms[s] = 0.f;
     HIP_TRY(hipSetDevice(ex->prm.device));
@@ -735,6 +770,8 @@ static int smallBatchPrepare(orbx_extractor *ex)
 {
     // the quadtree branches run concurrently: not when a quota is so large that the node arrays live in the one global scratch area
     if (orbxQuadtreeScratchBytes(ex->prm.max_batch, ex->geom.data(), 0, ex->prm.nlevels) != 0) return 0;
+    if (ex->qtStream[3] && ex->evQt[3]) return 1;
+    ORBX_SETUP_LOCK;
     for (int k = 0; k < 4; ++k) {
         if (!ex->qtStream[k] && hipStreamCreateWithFlags(&ex->qtStream[k], hipStreamNonBlocking) != hipSuccess) return 0;
         if (!ex->evQt[k] && hipEventCreateWithFlags(&ex->evQt[k], hipEventDisableTiming) != hipSuccess) return 0;
@@ -761,6 +798,7 @@ static int prepareLevelArgs(orbx_extractor *ex, const uint8_t *src0, int nf, ptr
     key.iniTh = ex->prm.ini_th_fast; key.minTh = ex->prm.min_th_fast;
     for (int k = 0; k < 4; ++k)
         if (memcmp(&key, &ex->pfArgsKey[k], sizeof key) == 0) { ex->curLevelArgs = ex->d_pfArgs.p + k * slotBytes; return ORBX_OK; }
+    ORBX_SETUP_LOCK;
     const int slot = ex->pfArgsNext;
     ex->pfArgsNext = (slot + 1) & 3;
     std::vector<uint8_t> host(slotBytes, 0);
@@ -924,6 +962,7 @@ static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w,
     if (!useGraph) { HIP_TRY(issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1)); return ORBX_OK; }
     const orbx_extractor::GraphKey key = {src0, nf, w, h, (long long)stride, (long long)frame_stride, lap0, lap1, ex->generation};
     if (!ex->graphExec || memcmp(&key, &ex->graphKey, sizeof key) != 0) {
+        ORBX_SETUP_LOCK;
         if (ex->graphExec) { (void)hipGraphExecDestroy(ex->graphExec); ex->graphExec = nullptr; }
         HIP_TRY(hipStreamBeginCapture(ex->stream, hipStreamCaptureModeRelaxed));
         const hipError_t ie = issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1);
@@ -949,6 +988,7 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
 extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride,
                                          ptrdiff_t frame_stride, int lap0, int lap1)
 {
+    ORBX_API_ENTRY;
     return runBatch(ex, d_imgs, nframes, w, h, stride, frame_stride, lap0, lap1, nullptr);
 }
 
@@ -1151,6 +1191,7 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
 
 extern "C" int orbx_sync(orbx_extractor *ex)
 {
+    ORBX_API_ENTRY;
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_sync: null handle");
     HIP_TRY(hipSetDevice(ex->prm.device));
     HIP_TRY(hipStreamSynchronize(ex->stream));
@@ -1159,6 +1200,7 @@ extern "C" int orbx_sync(orbx_extractor *ex)
 
 extern "C" int orbx_device_outputs(orbx_extractor *ex, void **d_kps, void **d_desc, void **d_n, void **d_mono)
 {
+    ORBX_API_ENTRY;
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_device_outputs: null handle");
     if (d_kps) *d_kps = ex->d_kps.p;
     if (d_desc) *d_desc = ex->d_desc.p;
@@ -1170,6 +1212,7 @@ extern "C" int orbx_device_outputs(orbx_extractor *ex, void **d_kps, void **d_de
 extern "C" int orbx_download_outputs(orbx_extractor *ex, int nframes, orbx_keypoint *kps, uint8_t *desc, int capacity,
                                      int32_t *n_out, int32_t *mono_out)
 {
+    ORBX_API_ENTRY;
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_download_outputs: null handle");
     if (nframes <= 0 || nframes > ex->prm.max_batch) return setError(ORBX_ERR_INVALID_ARG, "orbx_download_outputs: bad nframes");
     HIP_TRY(hipSetDevice(ex->prm.device));
@@ -1210,6 +1253,7 @@ static int downloadSmall(orbx_extractor *ex, int nframes, orbx_keypoint *kps, ui
     const size_t bN = (size_t)nframes * sizeof(int32_t), bK = (size_t)nframes * cap * sizeof(orbx_keypoint), bD = (size_t)nframes * cap * 32;
     const size_t need = 2 * bN + bK + bD + 64;
     if (ex->h_outBytes < need) {
+        ORBX_SETUP_LOCK;
         if (ex->h_out) { (void)hipHostFree(ex->h_out); ex->h_out = nullptr; ex->h_outBytes = 0; }
         HIP_TRY(hipHostMalloc((void **)&ex->h_out, need, hipHostMallocDefault));
         ex->h_outBytes = need;
@@ -1237,6 +1281,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
                                   ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
                                   int32_t *n_out, int32_t *mono_out)
 {
+    ORBX_API_ENTRY;
     if (!ex || !imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: null argument");
     if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
@@ -1257,6 +1302,7 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
 extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
                             orbx_keypoint *kps, uint8_t *desc, int capacity, int *n_out)
 {
+    ORBX_API_ENTRY;
     if (n_out) *n_out = 0;
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract: null handle") - 100;
     if (!img || w <= 0 || h <= 0) return -1;  // `if (_image.empty()) return -1;` (reference src/ORBextractor.cc:1231-1232)
@@ -1272,6 +1318,7 @@ extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *img, int w, int h
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int orbx_get_level_size(const orbx_extractor *ex, int level, int *w, int *h)
 {
+    ORBX_API_ENTRY;
     if (!ex || level < 0 || level >= ex->prm.nlevels || ex->geom.empty()) return setError(ORBX_ERR_INVALID_ARG, "orbx_get_level_size: bad argument");
     if (w) *w = ex->geom[level].w;
     if (h) *h = ex->geom[level].h;
@@ -1280,6 +1327,7 @@ extern "C" int orbx_get_level_size(const orbx_extractor *ex, int level, int *w, 
 
 extern "C" int orbx_get_pyramid_level(orbx_extractor *ex, int frame, int level, int blurred, uint8_t *out)
 {
+    ORBX_API_ENTRY;
     if (!ex || !out || level < 0 || level >= ex->prm.nlevels || frame < 0 || frame >= ex->lastFrames)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_get_pyramid_level: bad argument");
     HIP_TRY(hipSetDevice(ex->prm.device));
@@ -1303,6 +1351,7 @@ extern "C" int orbx_get_pyramid_level(orbx_extractor *ex, int frame, int level, 
 
 extern "C" int orbx_debug_get_candidates(orbx_extractor *ex, int frame, int level, uint32_t *out, int cap)
 {
+    ORBX_API_ENTRY;
     if (!ex || level < 0 || level >= ex->prm.nlevels || frame < 0 || frame >= ex->lastFrames)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_debug_get_candidates: bad argument");
     HIP_TRY(hipSetDevice(ex->prm.device));
@@ -1325,6 +1374,7 @@ extern "C" int orbx_debug_get_candidates(orbx_extractor *ex, int frame, int leve
 
 extern "C" int orbx_debug_get_selected(orbx_extractor *ex, int frame, int level, uint32_t *out, int cap)
 {
+    ORBX_API_ENTRY;
     if (!ex || level < 0 || level >= ex->prm.nlevels || frame < 0 || frame >= ex->lastFrames)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_debug_get_selected: bad argument");
     HIP_TRY(hipSetDevice(ex->prm.device));
@@ -1339,6 +1389,7 @@ extern "C" int orbx_debug_get_selected(orbx_extractor *ex, int frame, int level,
 
 extern "C" void orbx_synth_frame(uint64_t frame_index, int w, int h, uint8_t *out, ptrdiff_t stride)
 {
+    ORBX_API_ENTRY;
     orbx_synth_frame_impl(frame_index, w, h, out, stride);
 }
 
@@ -1367,6 +1418,8 @@ struct orbx_matcher {
 
 extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orbx_matcher **out)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!out || max_query <= 0 || max_train <= 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_create: bad argument");
     *out = nullptr;
     int ndev = 0;
@@ -1393,6 +1446,8 @@ extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orb
 
 extern "C" void orbx_matcher_destroy(orbx_matcher *m)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
@@ -1405,6 +1460,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
 
 extern "C" int orbx_matcher_sync(orbx_matcher *m)
 {
+    ORBX_API_ENTRY;
     if (!m) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_sync: null handle");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1421,6 +1477,7 @@ static int uploadQT(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t,
 
 extern "C" int orbx_hamming_matrix(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *dist)
 {
+    ORBX_API_ENTRY;
     if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || !dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_hamming_matrix: bad argument");
     if (nq == 0 || nt == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
@@ -1451,6 +1508,7 @@ static int knn2Launch(orbx_matcher *m, int npairs, const uint8_t *q, long long q
 
 extern "C" int orbx_match_knn2_device(orbx_matcher *m, const void *d_q, int nq, const void *d_t, int nt, void *d_idx, void *d_dist)
 {
+    ORBX_API_ENTRY;
     if (!m || nq < 0 || nt < 0 || !d_idx || !d_dist || (nq > 0 && !d_q) || (nt > 0 && !d_t))
         return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_device: bad argument");
     if (nq == 0) return ORBX_OK;
@@ -1462,6 +1520,7 @@ extern "C" int orbx_match_knn2_batch_device(orbx_matcher *m, int npairs, const v
                                             const int32_t *d_q_begin, int max_nq, const void *d_t, int64_t t_pair_stride,
                                             const int32_t *d_nt, const int32_t *d_t_begin, int max_nt, void *d_idx, void *d_dist)
 {
+    ORBX_API_ENTRY;
     if (!m || npairs < 0 || max_nq < 0 || max_nt < 0 || !d_idx || !d_dist || (max_nq > 0 && !d_q) || (max_nt > 0 && !d_t) || q_pair_stride < 0 ||
         t_pair_stride < 0)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_batch_device: bad argument");
@@ -1473,6 +1532,7 @@ extern "C" int orbx_match_knn2_batch_device(orbx_matcher *m, int npairs, const v
 
 extern "C" int orbx_match_knn2(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
 {
+    ORBX_API_ENTRY;
     if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || !idx || !dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2: bad argument");
     if (nq == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
@@ -1489,6 +1549,7 @@ extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, 
                                       const uint8_t *dr, int nr, int n_rows, const float *scale_factors, int nlevels, float min_d,
                                       float max_d, int32_t *best_idx, int32_t *best_dist)
 {
+    ORBX_API_ENTRY;
     if (!m || nl < 0 || nr < 0 || (nl > 0 && (!kl || !dl)) || (nr > 0 && (!kr || !dr)) || !scale_factors || nlevels <= 0 ||
         nlevels > ORBX_MAX_LEVELS || !best_idx || !best_dist)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_match_stereo_rows: bad argument");
@@ -1592,6 +1653,7 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const int32_t *kf_fv_node, co
                                   const orbx_keypoint *f_keys, const uint8_t *f_desc, int f_n, float nnratio, int check_orientation,
                                   int32_t *matches)
 {
+    ORBX_API_ENTRY;
     return searchByBowImpl(m, kf_fv_node, kf_fv_start, kf_fv_feature, kf_nfv, kf_keys, kf_desc, kf_valid, kf_n, f_fv_node, f_fv_start,
                            f_fv_feature, f_nfv, f_keys, f_desc, nullptr, f_n, nnratio, check_orientation, 0, matches);
 }
@@ -1603,6 +1665,7 @@ extern "C" int orbx_search_by_bow_keyframes(orbx_matcher *m, const int32_t *fv1_
                                             const orbx_keypoint *keys2, const uint8_t *desc2, const uint8_t *valid2, int n2, float nnratio,
                                             int check_orientation, int32_t *matches12)
 {
+    ORBX_API_ENTRY;
     return searchByBowImpl(m, fv1_node, fv1_start, fv1_feature, nfv1, keys1, desc1, valid1, n1, fv2_node, fv2_start, fv2_feature, nfv2, keys2,
                            desc2, valid2, n2, nnratio, check_orientation, 1, matches12);
 }
@@ -1618,6 +1681,7 @@ static int checkCamera(const float *k4, const float *dist, int ndist, const floa
 extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_keypoint *kps, int n, const float *k4, const float *dist, int ndist,
                                         const float *knew4, orbx_keypoint *out)
 {
+    ORBX_API_ENTRY;
     if (!m || n < 0 || (n > 0 && (!kps || !out))) return setError(ORBX_ERR_INVALID_ARG, "orbx_undistort_keypoints: bad argument");
     int rc = checkCamera(k4, dist, ndist, knew4, "orbx_undistort_keypoints");
     if (rc != ORBX_OK) return rc;
@@ -1639,6 +1703,7 @@ extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_keypoint *kp
 extern "C" int orbx_compute_image_bounds(orbx_matcher *m, int cols, int rows, const float *k4, const float *dist, int ndist,
                                          const float *knew4, float *bounds)
 {
+    ORBX_API_ENTRY;
     if (!m || !bounds || cols <= 0 || rows <= 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_image_bounds: bad argument");
     int rc = checkCamera(k4, dist, ndist, knew4, "orbx_compute_image_bounds");
     if (rc != ORBX_OK) return rc;
@@ -1656,6 +1721,7 @@ extern "C" int orbx_compute_image_bounds(orbx_matcher *m, int cols, int rows, co
 extern "C" int orbx_assign_features_to_grid(orbx_matcher *m, const orbx_keypoint *kps, int n, float min_x, float max_x, float min_y,
                                             float max_y, int32_t *cell_start, int32_t *items)
 {
+    ORBX_API_ENTRY;
     if (!m || n < 0 || (n > 0 && !kps) || !cell_start || (n > 0 && !items))
         return setError(ORBX_ERR_INVALID_ARG, "orbx_assign_features_to_grid: bad argument");
     if (n > m->maxT) return setError(ORBX_ERR_CAPACITY, "%d keypoints exceed the matcher capacity %d", n, m->maxT);
@@ -1679,6 +1745,7 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
                                               float *prev_matched, int32_t *matches12, int window_size, float nnratio,
                                               int check_orientation)
 {
+    ORBX_API_ENTRY;
     if (!m || n1 < 0 || n2 < 0 || (n1 > 0 && (!k1 || !d1 || !prev_matched || !matches12)) || (n2 > 0 && (!k2 || !d2)) || window_size < 0)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_search_for_initialization: bad argument");
     if (n1 > m->maxQ || n2 > m->maxT) return setError(ORBX_ERR_CAPACITY, "%d x %d keypoints exceed the matcher capacity %d x %d", n1, n2, m->maxQ, m->maxT);
@@ -1766,6 +1833,7 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *k
                                          const uint8_t *proj_desc, int np, float th, int forward, int backward, int check_orientation,
                                          int32_t *assign)
 {
+    ORBX_API_ENTRY;
     return searchByProjectionImpl(m, kc, dc, u_right, cur_state, nc, min_x, max_x, min_y, max_y, scale_factors, nlevels, mbf, proj, proj_desc,
                                   np, th, forward, backward, check_orientation, 0, 0.f, assign);
 }
@@ -1776,6 +1844,7 @@ extern "C" int orbx_search_by_projection_points(orbx_matcher *m, const orbx_keyp
                                                 const float *scale_factors, int nlevels, const orbx_projection *map_points,
                                                 const uint8_t *map_point_desc, int np, float th, float nnratio, int32_t *assign)
 {
+    ORBX_API_ENTRY;
     return searchByProjectionImpl(m, kc, dc, u_right, cur_state, nc, min_x, max_x, min_y, max_y, scale_factors, nlevels, 0.f, map_points,
                                   map_point_desc, np, th, 0, 0, 0, 1, nnratio, assign);
 }
@@ -1865,6 +1934,7 @@ extern "C" int orbx_search_by_projection_fisheye(orbx_matcher *m, const orbx_key
                                                  const orbx_projection *proj_right, const uint8_t *proj_desc, int np, float th, int forward,
                                                  int backward, int check_orientation, int32_t *assign)
 {
+    ORBX_API_ENTRY;
     return searchByProjectionFisheyeImpl("orbx_search_by_projection_fisheye", m, kc, dc, n_left, n_right, cur_state, min_x, max_x, min_y, max_y,
                                          scale_factors, nlevels, proj_left, proj_right, proj_desc, np, nullptr, nullptr, th, forward, backward,
                                          check_orientation, 0, 0.f, assign);
@@ -1877,6 +1947,7 @@ extern "C" int orbx_search_by_projection_points_fisheye(orbx_matcher *m, const o
                                                         const int32_t *left_to_right, const int32_t *right_to_left, float th, float nnratio,
                                                         int32_t *assign)
 {
+    ORBX_API_ENTRY;
     return searchByProjectionFisheyeImpl("orbx_search_by_projection_points_fisheye", m, kc, dc, n_left, n_right, cur_state, min_x, max_x, min_y,
                                          max_y, scale_factors, nlevels, map_points_left, map_points_right, map_point_desc, np, left_to_right,
                                          right_to_left, th, 0, 0, 0, 1, nnratio, assign);
@@ -1887,6 +1958,7 @@ extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left
                                            const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr, const uint8_t *dr,
                                            int nr, float mb, float mbf, float *u_right, float *depth)
 {
+    ORBX_API_ENTRY;
     if (!m || !left || !right || nl < 0 || nr < 0 || (nl > 0 && (!kl || !dl)) || (nr > 0 && (!kr || !dr)) || !u_right || !depth)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches: bad argument");
     if (frame_left < 0 || frame_left >= left->lastFrames || frame_right < 0 || frame_right >= right->lastFrames)
@@ -1973,6 +2045,7 @@ static int checkFramePairs(const char *fn, orbx_matcher *m, orbx_extractor *a, o
 extern "C" int orbx_match_knn2_frames(orbx_matcher *m, orbx_extractor *query, orbx_extractor *train, int npairs, int lapping_only,
                                       void *d_idx, void *d_dist)
 {
+    ORBX_API_ENTRY;
     int rc = checkFramePairs("orbx_match_knn2_frames", m, query, train, npairs);
     if (rc != ORBX_OK) return rc;
     if (!d_idx || !d_dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2_frames: null output");
@@ -1989,6 +2062,7 @@ extern "C" int orbx_match_knn2_frames(orbx_matcher *m, orbx_extractor *query, or
 extern "C" int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int npairs, float mb, float mbf,
                                                   void *d_u_right, void *d_depth)
 {
+    ORBX_API_ENTRY;
     int rc = checkFramePairs("orbx_compute_stereo_matches_frames", m, left, right, npairs);
     if (rc != ORBX_OK) return rc;
     if (!d_u_right || !d_depth) return setError(ORBX_ERR_INVALID_ARG, "orbx_compute_stereo_matches_frames: null output");
@@ -2084,6 +2158,7 @@ extern "C" int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor 
                                                 const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward, int backward,
                                                 int check_orientation, void *d_kps_un, void *d_assign, void *d_nmatches)
 {
+    ORBX_API_ENTRY;
     return searchByProjectionFramesImpl("orbx_search_by_projection_frames", 0, 0.f, m, ex, nframes, k4, dist, ndist, knew4, min_x, max_x, min_y, max_y, mbf,
                                         d_u_right, d_cur_state, d_proj, d_proj_desc, d_np, max_np, th, forward, backward, check_orientation, d_kps_un, d_assign,
                                         d_nmatches);
@@ -2096,6 +2171,7 @@ extern "C" int orbx_search_for_initialization_frames(orbx_matcher *m, orbx_extra
                                                      float min_y, float max_y, float *d_prev_matched, int init_prev_matched, int window_size,
                                                      float nnratio, int check_orientation, void *d_matches12, void *d_nmatches)
 {
+    ORBX_API_ENTRY;
     const char *fn = "orbx_search_for_initialization_frames";
     if (!m || !ex1 || !ex2) return setError(ORBX_ERR_INVALID_ARG, "%s: null handle", fn);
     if (ex1->prm.device != m->device || ex2->prm.device != m->device)
@@ -2140,6 +2216,7 @@ extern "C" int orbx_search_by_projection_points_frames(orbx_matcher *m, orbx_ext
                                                        const uint8_t *d_map_point_desc, const int32_t *d_np, int max_np, float th, float nnratio,
                                                        void *d_kps_un, void *d_assign, void *d_nmatches)
 {
+    ORBX_API_ENTRY;
     return searchByProjectionFramesImpl("orbx_search_by_projection_points_frames", 1, nnratio, m, ex, nframes, k4, dist, ndist, knew4, min_x, max_x, min_y, max_y,
                                         0.f, d_u_right, d_cur_state, d_map_points, d_map_point_desc, d_np, max_np, th, 0, 0, 0, d_kps_un, d_assign, d_nmatches);
 }
@@ -2166,6 +2243,7 @@ extern "C" int orbx_compute_stereo_fisheye_matches(orbx_matcher *m, const orbx_k
                                                    const float *level_sigma2, int nlevels, int32_t *left_to_right, int32_t *right_to_left,
                                                    float *depth, float *p3d)
 {
+    ORBX_API_ENTRY;
     const char *fn = "orbx_compute_stereo_fisheye_matches";
     if (!m || nl < 0 || nr < 0 || mono_left < 0 || mono_right < 0 || mono_left > nl || mono_right > nr || (nl > 0 && (!kl || !dl || !left_to_right || !depth || !p3d)) ||
         (nr > 0 && (!kr || !dr || !right_to_left)))
@@ -2211,6 +2289,7 @@ extern "C" int orbx_compute_stereo_fisheye_matches_frames(orbx_matcher *m, orbx_
                                                           const float *cam2, float precision, const float *R12, const float *t12,
                                                           void *d_left_to_right, void *d_right_to_left, void *d_depth, void *d_p3d, void *d_nmatches)
 {
+    ORBX_API_ENTRY;
     const char *fn = "orbx_compute_stereo_fisheye_matches_frames";
     int rc = checkFramePairs(fn, m, left, right, npairs);
     if (rc != ORBX_OK) return rc;
@@ -2240,6 +2319,7 @@ extern "C" int orbx_compute_stereo_fisheye_matches_frames(orbx_matcher *m, orbx_
 
 extern "C" int orbx_matcher_download(orbx_matcher *m, const void *d_src, void *h_dst, size_t bytes)
 {
+    ORBX_API_ENTRY;
     if (!m || (bytes > 0 && (!d_src || !h_dst))) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_download: bad argument");
     HIP_TRY(hipSetDevice(m->device));
     if (bytes > 0) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, m->stream));
@@ -2265,6 +2345,8 @@ struct orbx_vocabulary {
 
 extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!v) return;
     (void)hipSetDevice(v->device);
     if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
@@ -2279,6 +2361,8 @@ extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
 extern "C" int orbx_vocabulary_create(int device, int k, int L, int scoring, int weighting, int n_nodes, const int32_t *parent,
                                       const uint8_t *is_leaf, const uint8_t *desc, const double *weight, orbx_vocabulary **out)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!out) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_create: null output");
     *out = nullptr;
     if (k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3)  // the loader's own check (:1359)
@@ -2334,6 +2418,8 @@ extern "C" int orbx_vocabulary_create(int device, int k, int L, int scoring, int
 // unspecified descriptor, is skipped.)
 extern "C" int orbx_vocabulary_load_text(int device, const char *path, orbx_vocabulary **out)
 {
+    ORBX_API_ENTRY;
+    ORBX_SETUP_LOCK;
     if (!out) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_load_text: null output");
     *out = nullptr;
     if (!path) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_load_text: null path");
@@ -2405,6 +2491,7 @@ extern "C" int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *desc
                                          int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start,
                                          int32_t *fv_feature, int32_t *n_fv)
 {
+    ORBX_API_ENTRY;
     return vocabularyTransformImpl(v, desc, false, n, levelsup, feat_word, feat_node, bow_word, bow_value, n_bow, fv_node, fv_start, fv_feature, n_fv);
 }
 
@@ -2414,6 +2501,7 @@ extern "C" int orbx_vocabulary_transform_frame(orbx_vocabulary *v, orbx_extracto
                                                int32_t *feat_node, int32_t *bow_word, double *bow_value, int32_t *n_bow, int32_t *fv_node,
                                                int32_t *fv_start, int32_t *fv_feature, int32_t *n_fv)
 {
+    ORBX_API_ENTRY;
     if (!v || !ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_frame: null handle");
     if (ex->prm.device != v->device) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_frame: extractor and vocabulary on different devices");
     if (frame < 0 || frame >= ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_frame: frame %d of %d", frame, ex->lastFrames);
@@ -2431,6 +2519,7 @@ extern "C" int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extracto
                                                double *bow_value, int32_t *n_bow, int32_t *fv_node, int32_t *fv_start, int32_t *fv_feature,
                                                int32_t *n_fv)
 {
+    ORBX_API_ENTRY;
     if (!v || !ex || !bow_word || !bow_value || !n_bow || !fv_node || !fv_start || !fv_feature || !n_fv)
         return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_batch: null argument");
     if (ex->prm.device != v->device) return setError(ORBX_ERR_INVALID_ARG, "orbx_vocabulary_transform_batch: extractor and vocabulary on different devices");
