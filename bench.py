@@ -210,11 +210,21 @@ def main() -> None:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    # (rehearsal on a box with fewer GPUs than ranks: ORBX_BENCH_BACKEND=gloo, ranks share the devices round-robin; the result gather
+    # is then not available - RCCL needs one device per rank)
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            if args.gather:
+                raise SystemExit("--gather needs the nccl (RCCL) backend")
+            dist.init_process_group(backend)
 
     pkg = graft.load_package()
     import importlib
@@ -320,7 +330,7 @@ def main() -> None:
     stage_ms, nb = exl.stage_times()
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
