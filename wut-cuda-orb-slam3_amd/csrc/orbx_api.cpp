@@ -395,6 +395,32 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         int gmax = std::max(1, tileWl / g.wCell);
         g.nGroups = (g.ncx + gmax - 1) / gmax;
         g.groupCells = (g.ncx + g.nGroups - 1) / g.nGroups;
+        // four workgroups per CU need <= 40 KB of LDS each (160 KB; a fifth of the levels of the bench workloads sat just above that and
+        // ran three per CU): give up to two cells of tile width for it - an estimate of the layout below with the resize tables at their
+        // nominal size; narrower than that the fixed cost per tile weighs more than the fourth workgroup
+        static const bool ldsFit = [] { const char *e = getenv("ORBX_PF_LDS_FIT"); return e ? atoi(e) != 0 : true; }();
+        if (ldsFit && tileWEnv <= 0 && ex->prm.max_batch > ORBX_GRAPH_MAX_FRAMES) {
+            auto estimate = [&](int cells) {  // the LDS layout below for `cells` cells per group (resize tables at their nominal size)
+                const int tw = cells * g.wCell, ng = (g.ncx + cells - 1) / cells;
+                const size_t maxCols = ng == 1 ? (size_t)g.w : (size_t)tw + 3 + ORBX_FAST_MARGIN;   // edge groups hold the image margin
+                const size_t rows = g.ncy == 1 ? (size_t)g.h : (size_t)g.hCell + 3 + ORBX_FAST_MARGIN;
+                const size_t tp = roundUp(maxCols + 32, 16), sp = roundUp((size_t)tw, 16);
+                const size_t dx = roundUp((size_t)((tw + ORBX_FAST_MARGIN) / ex->prm.scale_factor) + 4, 2);
+                const size_t dy = roundUp((size_t)((g.hCell + ORBX_FAST_MARGIN) / ex->prm.scale_factor) + 4, 2);
+                const size_t gq = roundUp((size_t)2 * ((tw + 7) / 8 + 1) * g.hCell, 8);
+                return rows * tp + (g.hCell + 2) * sp + roundUp((size_t)cells * g.hCell * ((g.wCell + 31) / 32) * 4, 16) +
+                       roundUp(std::max((dx + dy) * 8, (size_t)2048), 16) + gq * 2 + roundUp((size_t)tw, 16);
+            };
+            const size_t limit = 40960 - 512;  // (static LDS of the kernel, allocation granularity)
+            const int wide = g.groupCells;
+            for (int drop = 0; drop <= 2 && wide - drop >= 4; ++drop) {
+                const int ng = (g.ncx + wide - drop - 1) / (wide - drop), balanced = (g.ncx + ng - 1) / ng;
+                if (balanced < wide - 2) break;  // (a narrow level would fall apart into much smaller tiles)
+                if (estimate(balanced) <= limit) { g.groupCells = balanced; break; }
+            }
+        }
+        g.nGroups = (g.ncx + g.groupCells - 1) / g.groupCells;
+        g.groupCells = (g.ncx + g.nGroups - 1) / g.nGroups;  // (balanced over the groups)
         g.nGroups = (g.ncx + g.groupCells - 1) / g.groupCells;
         if (g.groupCells > 32) return setError(ORBX_ERR_CAPACITY, "level %d: %d cells per tile group exceeds 32", l, g.groupCells);
         g.nTiles = g.nGroups * g.ncy;
@@ -420,6 +446,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         g.tileRows = maxRows;
         // LDS column 16 holds image column ax0; strip windows / 16-byte loads may overshoot by up to 16 bytes
         g.tilePitch = (int)roundUp(maxCols + 32, 16);  // XO (16) + widest overshoot of strip windows (24) / 16-byte loads (31 - 16)
+        g.scorePitch = (int)roundUp((size_t)g.groupCells * g.wCell, 16);  // scores exist for interior columns only (cell-local NMS)
         g.wpc = (g.wCell + 31) / 32;
         g.rsMaxDx = g.rsMaxDy = 0;  // filled in with the resize tables below
     }
@@ -494,14 +521,20 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         // LDS sub-buffers: pixel tile | score tile | NMS bitmaps (zeroed together with the score tile: 16-byte multiple) | resize
         // tables | group queue | corner queue (1024 entries) | group masks | per-column cell info
         g.oScore = g.tileRows * g.tilePitch;
-        g.oBits = g.oScore + (g.hCell + 2) * g.tilePitch;
+        g.oBits = g.oScore + (g.hCell + 2) * g.scorePitch;
         g.oXt = g.oBits + (int)roundUp((size_t)g.groupCells * g.hCell * g.wpc * 4, 16);
         g.oYt = g.oXt + g.rsMaxDx * 8;
-        g.oGq = g.oYt + g.rsMaxDy * 8;
-        g.oCq = g.oGq + g.gqCap * 2;
-        g.oGqm = g.oCq + 1024 * 2;
-        g.oColInfo = g.oGqm + g.gqCap;
+        // the corner queue lives in the bytes of the resize tables: the tables are last read in the resize phase, the queue is first
+        // written in the ring-test phase, behind the barrier that ends the pre-test - every wave has left the resize phase by then
+        g.oCq = g.oXt;
+        g.oGq = g.oXt + (int)roundUp(std::max((size_t)(g.rsMaxDx + g.rsMaxDy) * 8, (size_t)1024 * 2), 16);
+        g.oGqm = 0;
+        g.oColInfo = g.oGq + g.gqCap * 2;
         g.ldsBytes = (int)roundUp((size_t)g.oColInfo + roundUp(g.groupCells * g.wCell, 16), 16);
+        if (getenv("ORBX_DEBUG"))
+            fprintf(stderr, "[orbx] level %d LDS layout: tile %d x %d = %d | score %d x %d | bits %d | tables %d + %d / corner queue | group queue %d x 2 | "
+                            "columns %d -> %d B\n", l, g.tileRows, g.tilePitch, g.oScore, g.hCell + 2, g.scorePitch, g.oXt - g.oBits, g.rsMaxDx * 8,
+                    g.rsMaxDy * 8, g.gqCap, g.groupCells * g.wCell, g.ldsBytes);
         if (g.ldsBytes > 64 * 1024)
             return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
     }

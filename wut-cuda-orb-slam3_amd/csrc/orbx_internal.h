@@ -32,14 +32,16 @@ struct OrbxLevelGeom {
     int quota;             // mnFeaturesPerLevel[level]
     int selBase;           // offset of this level's selected keypoints inside a frame's selection area
     // LDS layout of the fused kernel
-    int tilePitch;         // bytes per LDS tile row (multiple of 16; shared by the pixel and the score tile)
+    int tilePitch;         // bytes per LDS tile row of the pixel tile (multiple of 16)
+    int scorePitch;        // bytes per row of the score tile: interior columns only (multiple of 16)
     int tileRows;          // max rows held in LDS
     int wpc;               // 32-bit words per cell row in the NMS bitmaps
     int rsMaxDx, rsMaxDy;  // max destination columns / rows of the next level produced by one tile
     int gqCap;             // capacity of the pre-test group queue (2 groups per strip, all strips of the tile)
     int ldsBytes;
     // byte offsets of the LDS sub-buffers (the pixel tile starts at 0): score tile, NMS bitmaps (directly behind the score tile: one
-    // zeroing loop), resize x / y tables, group queue, corner queue, group masks, per-column cell info
+    // zeroing loop), resize x / y tables and - in the same bytes, first written after the barrier behind the pre-test - the corner
+    // queue, group queue, per-column cell info (oGqm: unused)
     int oScore, oBits, oXt, oYt, oGq, oCq, oGqm, oColInfo;
 };
 

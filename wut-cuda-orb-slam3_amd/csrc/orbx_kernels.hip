@@ -263,12 +263,13 @@ struct PyrFastArgs {
 #define PF_QCAP 1024  // corner queue entries (u16: row << 9 | interior column)
 
 // score + cell-local NMS of one ring-test survivor at tile row r, LDS column c
-__device__ __forceinline__ void pf_score_one(const uint8_t *tile, uint8_t *score, int tp, int rowOff, int r, int c, int minEff)
+// (`score` points at interior column 0 minus cInt0: it is indexed with LDS columns like the pixel tile, with its own pitch `sp`)
+__device__ __forceinline__ void pf_score_one(const uint8_t *tile, uint8_t *score, int tp, int sp, int rowOff, int r, int c, int minEff)
 {
     const int sc = fast_corner_score(tile + (rowOff + r) * tp + c, tp);
-    score[(r + 1) * tp + c] = (uint8_t)(sc >= minEff ? sc : 0);
+    score[(r + 1) * sp + c] = (uint8_t)(sc >= minEff ? sc : 0);
 }
-__device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *colInfo, uint32_t *bits, int *cnt, int tp, int r, int c,
+__device__ __forceinline__ void pf_nms_one(const uint8_t *score, const uint8_t *colInfo, uint32_t *bits, int *cnt, int tp /* score pitch */, int r, int c,
                                            int cInt0, int wCell, int hCell, int wpc)
 {
     const uint8_t *s1p = score + (r + 1) * tp + c, *s0p = s1p - tp, *s2p = s1p + tp;
@@ -538,7 +539,8 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         KArgs &a = K();
         TileK &t = T();
         const int tp = a.g.tilePitch, wCell = a.g.wCell, hCell = a.g.hCell, wpc = a.g.wpc;
-        uint8_t *score = lds + a.g.oScore;
+        const int sp = a.g.scorePitch;
+        uint8_t *score = lds + a.g.oScore - t.cInt0;  // interior column x of the tile = LDS column cInt0 + x
         uint32_t *bits = (uint32_t *)(lds + a.g.oBits);
         uint16_t *gq = (uint16_t *)(lds + a.g.oGq), *cq = (uint16_t *)(lds + a.g.oCq);
         uint8_t *colInfo = lds + a.g.oColInfo;
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                         const int k = __ffs(m) - 1;
                         m &= m - 1;
                         if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
-                        else pf_score_one(tile, score, tp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
+                        else pf_score_one(tile, score, tp, sp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
                         ++pos;
                     }
                 }
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
             const unsigned qn = cqCountR[round];
             for (unsigned i = otid(); i < min(qn, (unsigned)PF_QCAP); i += PF_NT) {
                 const unsigned e = cq[i];
-                pf_score_one(tile, score, tp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
+                pf_score_one(tile, score, tp, sp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
             }
             __syncthreads();
             PF_STAMP(6 + 4 * round);
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                 if (phases & 4)
                 for (unsigned i = otid(); i < qn; i += PF_NT) {
                     const unsigned e = cq[i];
-                    pf_nms_one(score, colInfo, bits, cnt, tp, e >> 9, (int)(e & 511) + cInt0, cInt0, wCell, hCell, wpc);
+                    pf_nms_one(score, colInfo, bits, cnt, sp, e >> 9, (int)(e & 511) + cInt0, cInt0, wCell, hCell, wpc);
                 }
             } else {
                 // corner queue overflow (pathological corner density): NMS over every scored pixel of the queued groups
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                     const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
                     for (int k = 0; k < 4; ++k)
                         if (c4 + k >= cInt0 && c4 + k < cInt1)
-                            pf_nms_one(score, colInfo, bits, cnt, tp, r, c4 + k, cInt0, wCell, hCell, wpc);
+                            pf_nms_one(score, colInfo, bits, cnt, sp, r, c4 + k, cInt0, wCell, hCell, wpc);
                 }
             }
             __syncthreads();
@@ -693,8 +695,8 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
     {
         KArgs &a = K();
         TileK &t = T();
-        const int tp = a.g.tilePitch, wCell = a.g.wCell, wpc = a.g.wpc, cellWords = a.g.hCell * wpc;
-        const uint8_t *score = lds + a.g.oScore;
+        const int sp = a.g.scorePitch, wCell = a.g.wCell, wpc = a.g.wpc, cellWords = a.g.hCell * wpc;
+        const uint8_t *score = lds + a.g.oScore - t.cInt0;
         const uint32_t *bits = (const uint32_t *)(lds + a.g.oBits);
         const int nCells = t.nCells, THi = t.THi, cInt0 = t.cInt0;
         const int xBias = t.colOf0 + ORBX_BORDER, yBias = t.ty0 - ORBX_BORDER;
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                             const int b = __ffs(wd) - 1;
                             wd &= wd - 1;
                             const int cc = cellC0 + k * 32 + b;
-                            slot[o++] = ORBX_PACK(cc - xBias, yBias + r, score[(r + 1) * tp + cc]);
+                            slot[o++] = ORBX_PACK(cc - xBias, yBias + r, score[(r + 1) * sp + cc]);
                         }
                     }
                 }
