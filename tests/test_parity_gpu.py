@@ -379,6 +379,9 @@ def test_quadtree_kernels_on_other_shapes(pkg, mw):
     up to four roots chunk-parallel, more on one wave), and the 8-wave kernel's in-place scatter limit (4096 keys) crossed at 1080p."""
     _gpu_check_subprocess({"ORBX_QT_MW": mw}, (["640", "480", "1000", "40"], ["752", "480", "1200", "1"], ["1000", "350", "1500", "2"],
                                                ["1500", "300", "1200", "2"], ["333", "257", "600", "3"]))
+    if mw == "0":  # the one-wave kernel exists with 32 and with 8 key chunks in registers (chosen by the launch's largest quota)
+        for kch in ("32", "8"):
+            _gpu_check_subprocess({"ORBX_QT_MW": "0", "ORBX_QT_KCH": kch}, (["640", "480", "1000", "24"], ["752", "480", "2500", "2"]))
 
 
 @pytest.mark.parametrize("env", [{"ORBX_BLUR_KERNEL": "2"}, {"ORBX_BLUR_KERNEL": "1"}, {"ORBX_BLUR_WAVES": "8"}])

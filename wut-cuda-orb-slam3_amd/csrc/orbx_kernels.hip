@@ -1786,14 +1786,17 @@ __device__ __forceinline__ void qt_body(QtArgsK &a, const OrbxLevelGeom &g, int 
 //   3. key sweep:   stable scatter of every key to its node's new run (children by quadrant, untouched nodes verbatim).
 // Only the std::sort emulation (the tie order of libstdc++'s introsort is observable) still runs on one lane.
 // A single wave runs these sweeps as chains of LDS round trips, so they keep several independent reads in flight: lists of
-// up to 256 nodes are handled as 4 entries per lane (loads first, then the scans), up to QT3_KCH * 64 keys stay in registers for
+// up to 256 nodes are handled as 4 entries per lane (loads first, then the scans), up to KCH * 64 keys stay in registers for
 // a whole pass (the scatter is then in place, in one LDS buffer), and counters advance with fire-and-forget LDS atomics.
 #define QT3_MAX_KEYS 8192   // first launch: run-start bitmap of 1 KB in LDS.  Larger candidate sets (levels of 1080p images) are deferred
 #define QT3_MAX_KEYS2 49152 // to a second launch of the same kernel with a 6 KB bitmap (key offsets are 16-bit, 0xFFFF is a sentinel);
                             // beyond that - and for everything when ORBX_QT_KERNEL=1 - the serial formulation takes over
-#ifndef QT3_KCH
-#define QT3_KCH 32         // 64-key chunks held in registers (sweep of 32 / 16 / 8: tools/experiments/qt_kch_sweep.sh)
-#endif
+// 64-key chunks held in registers (template parameter of the kernel).  32 chunks: 158 VGPRs = 3 waves per SIMD, 12 instances per CU;
+// 8 chunks: 105 VGPRs = 4 per SIMD, 16 per CU where the level pair's LDS allows it (quotas up to ~170).  Candidate sets beyond the
+// chunks are re-read from (L2-resident) scratch in every sweep, so the small variant is for launches whose largest quota is <= 300
+// (c2: quadtree 0.91 -> 0.79 ms per batch; at 1500 features per frame, quota 326, it is 3 % slower).
+#define QT3_KCH_LARGE 32
+#define QT3_KCH_SMALL 8
 
 struct Qt3 {
     qt_u64 *V;                 // [L] expandable nodes (count << 32 | UL.x << 16 | list position): vSizeAndPointerToNode
@@ -1810,7 +1813,8 @@ struct Qt3 {
 __host__ __device__ static inline size_t qt3NodeBytes(int L, int maxKeys = QT3_MAX_KEYS2) { return (((size_t)L * 46 + 8 + 216 * 4 + (size_t)(maxKeys / 32 + 2) * 4) + 15) & ~(size_t)15; }
 
 // A / B: key buffers.  With M <= QT3_KCH * 64 they are the same (LDS) buffer, larger sets ping-pong between two global ones.
-template <bool NG>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS
+template <bool NG, int QT3_KCH>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS;
+                                 // QT3_KCH: 64-key chunks held in registers
 __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int f, uint8_t *qlds, uint32_t *A, uint32_t *B, int M,
                          const int *tc, uint32_t *selOut, int *selCnt)
 {
@@ -2232,6 +2236,7 @@ __device__ __forceinline__ bool qt_instance(QtArgsK &a, int &f, int &level, int 
     return true;
 }
 
+template <int KCH>
 __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
@@ -2249,16 +2254,16 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
     if (M == 0 || M > a.maxKeys) { if (threadIdx.x == 0) *selCnt = M == 0 ? 0 : QT_DEFERRED; return; }
     uint32_t *gA = a.scratchA + (size_t)f * a.candFrameStride + g.candBase;
     uint32_t *gB = a.scratchB + (size_t)f * a.candFrameStride + g.candBase;
-    const bool inRegs = M <= QT3_KCH * WAVE;
+    const bool inRegs = M <= KCH * WAVE;
     if (a.nodeScratch) {  // list capacity beyond LDS: node arrays (and keys) in global memory
         uint8_t *nodes = a.nodeScratch + ((size_t)f * a.levelsRun + (level - a.levelBase)) * (size_t)a.nodeBytes;
-        qt3_body<true>(a, g, f, nodes, gA, inRegs ? gA : gB, M, tc, selOut, selCnt);
+        qt3_body<true, KCH>(a, g, f, nodes, gA, inRegs ? gA : gB, M, tc, selOut, selCnt);
         return;
     }
     // all keys in registers for a pass + one LDS buffer behind the node arrays; larger sets ping-pong in global scratch
     uint32_t *lK = (uint32_t *)(qlds + a.nodeBytes);
     uint32_t *kA = inRegs && M <= a.ldsKeys ? lK : gA;
-    qt3_body<false>(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
+    qt3_body<false, KCH>(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
 }
 
 // =====================================================================================================
@@ -2999,7 +3004,8 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
     (void)hipGetDevice(&devId);
     bool &attrSet = attrSetDev[devId & 63];
     if (!attrSet) {
-        (void)hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_quadtree<QT3_KCH_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_quadtree<QT3_KCH_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_quadtree_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSet = true;
     }
@@ -3052,12 +3058,18 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
                 a.nodeScratch = nodeScratch;
                 lds = 0;
             }
+            // fewer keys in registers = more instances per CU: for launches whose lists are short (ORBX_QT_KCH = 32 / 8 forces one)
+            static const int kchEnv = [] { const char *e = getenv("ORBX_QT_KCH"); return e ? atoi(e) : 0; }();
+            const bool smallKch = kchEnv ? kchEnv <= QT3_KCH_SMALL : maxQuota <= 300;
             if (getenv("ORBX_DEBUG")) {
                 int nb = 0;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree, 64, lds);
-                fprintf(stderr, "[orbx] k_quadtree levels %d..%d pass %d: list %d, LDS %zu B, %d instances/CU\n", levelBase, levelBase + levelsRun - 1, pass, a.listCap, lds, nb);
+                if (smallKch) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree<QT3_KCH_SMALL>, 64, lds);
+                else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_quadtree<QT3_KCH_LARGE>, 64, lds);
+                fprintf(stderr, "[orbx] k_quadtree<%d> levels %d..%d pass %d: list %d, LDS %zu B, %d instances/CU\n", smallKch ? QT3_KCH_SMALL : QT3_KCH_LARGE,
+                        levelBase, levelBase + levelsRun - 1, pass, a.listCap, lds, nb);
             }
-            hipLaunchKernelGGL(k_quadtree, grid, dim3(64), lds, st, a);
+            if (smallKch) hipLaunchKernelGGL(k_quadtree<QT3_KCH_SMALL>, grid, dim3(64), lds, st, a);
+            else hipLaunchKernelGGL(k_quadtree<QT3_KCH_LARGE>, grid, dim3(64), lds, st, a);
         }
         a.pass2 = 0;
     }
@@ -3424,7 +3436,8 @@ hipError_t orbxInitDevice()
     if (dev < 0 || dev >= 64 || done[dev]) return hipSuccess;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kOrbxPattern31, 1024);
     if (e != hipSuccess) return e;
-    (void)hipFuncSetAttribute((const void *)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_quadtree<QT3_KCH_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_quadtree<QT3_KCH_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_quadtree_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done[dev] = true;
     return hipSuccess;
