@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_blur2(BlurArgs a)
 // and each lane ends up with 4 horizontally adjacent output pixels of one row: one dword store.  BORDER_REFLECT_101 is applied
 // when the A operand is loaded (interior strips take aligned 8-byte loads, the strips at the left / right image border gather
 // reflected bytes).  About 25 VALU + 3 MFMA instructions per 256 pixels, against ~150 VALU in the SWAR version.
-#define BL3_SEG 4  // 16-row output blocks per wave (plus one extra chunk of rows); 4 measured best next to the quadtree (8: +2 %, 2: +4 %)
+#define BL3_SEG 4  // 16-row output blocks per wave (plus one extra chunk of rows) in the all-levels launch of small batches
 typedef int bl3_v4i __attribute__((ext_vector_type(4)));
 
 // The constant terms (128 * sum(taps) from the signed-byte operands, + 32768 rounding) ride in K slots whose taps are zero
@@ -1207,32 +1207,72 @@ __device__ __forceinline__ int bl3_reflect(int p, int len)  // REFLECT_101 for -
     return max(q, 0);
 }
 
-// NW waves per workgroup = NW adjacent 16-column strips of one row segment.  The source rows of the segment are staged in LDS
-// with coalesced 16-byte loads (each 128-byte line is fetched once per workgroup; per-wave 8-byte gathers straight from global
-// memory fetched every line ~5 times through a thrashing L1) and the A operands are read from there.
-template <int NW>
-__device__ __forceinline__ void blur3_body(const BlurArgs &a, const int f, const int unit)
+// Per-lane B operands of the two products (the tap matrices), computed once on the host and read from the kernarg segment: a lane's
+// operands depend on its position in the wave and on the taps only, and building them from shifted tap words cost every wave ~75
+// instructions.  K slot (g, jj) of the horizontal product is window column 8g + jj (image column x0 - 4 + 8g + jj), tap
+// 8g + jj - n - 1 for output column n; of the vertical product it is row 4g + jj of the previous chunk (jj < 4), tap 4g + jj - n for
+// output row n, or row 4g + jj - 4 of this one, tap 16 + 4g + jj - 4 - n.  Lanes 48..63 hold the constant terms (above).
+struct BlurLaneTab { uint32_t v[64][4]; };  // {Bh low, Bh high, Bv low, Bv high}
+typedef const __attribute__((address_space(4))) BlurLaneTab BlurLaneTabK;
+
+static void fillBlurLaneTab(BlurLaneTab &t, const int taps[7])
 {
-    constexpr int TW = 16 * NW, NVEC = NW + 2, LP = 16 * (NW + 3), NT = 64 * NW, ROWS = 16 * (BL3_SEG + 1);
+    auto tapWin = [&](int k0) -> uint32_t {  // bytes tap[k0 .. k0 + 3], zero outside 0 .. 6
+        uint32_t r = 0;
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j >= 0 && k0 + j < 7) r |= (uint32_t)taps[k0 + j] << (8 * j);
+        return r;
+    };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int n = lane & 15, g = lane >> 4;
+        const bool biasLane = g == 3;
+        t.v[lane][0] = biasLane ? BL3_BIAS_B : tapWin(8 * g - n - 1);
+        t.v[lane][1] = biasLane ? 0u : tapWin(8 * g + 4 - n - 1);
+        t.v[lane][2] = tapWin(4 * g - n);
+        t.v[lane][3] = biasLane ? BL3_BIAS_B : tapWin(16 + 4 * g - n);
+    }
+}
+
+// NW waves per workgroup = NW adjacent 16-column strips of one row segment of SEG 16-row blocks.  The source rows of the segment are
+// staged in LDS with coalesced 16-byte loads (each 128-byte line is fetched once per workgroup; per-wave 8-byte gathers straight from
+// global memory fetched every line ~5 times through a thrashing L1) and the A operands are read from there.
+// The kernel is bound by instruction issue, not by the matrix cores or HBM (the products are 3 of ~40 instructions per block), so what
+// a wave does once - decode, staging, operands - is kept short and spread over as many blocks as the LDS tile allows.
+template <int NW, int SEG>
+__device__ __forceinline__ void blur3_body(const BlurArgs &a, BlurLaneTabK *tab, const int f, const int unit)
+{
+    constexpr int TW = 16 * NW, NVEC = NW + 2, LP = 16 * (NW + 3), NT = 64 * NW, ROWS = 16 * (SEG + 1);
+    constexpr int RPP = NT / NVEC, NIT = (ROWS + RPP - 1) / RPP;  // rows per staging pass (NVEC threads per row), passes
     __shared__ __attribute__((aligned(16))) uint8_t tile[ROWS * LP];  // image columns [tx0, tx0 + TW + 32), REFLECT_101 rows
     const int sgx = unit % a.tilesX, seg = unit / a.tilesX;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx0 = sgx * TW - 16;
-    const int x0 = sgx * TW + wv * 16;  // wave-uniform
+    const int x0 = sgx * TW + wv * 16;
     const int n = lane & 15, g = lane >> 4;
     const int nBlk = (a.h + 15) >> 4;
-    const int b0 = seg * BL3_SEG, b1 = min(b0 + BL3_SEG, nBlk);
+    const int b0 = seg * SEG, b1 = min(b0 + SEG, nBlk);
     const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
     uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
     const int nRows = 16 * (b1 - b0 + 1);
     if (a.srcAligned) {
-        for (int it = tid; it < nRows * NVEC; it += NT) {
-            const int r = it / NVEC, v = it - r * NVEC;
-            const int col = tx0 + 16 * v;
-            if (col >= 0 && col + 16 <= a.srcPitch)
-                *(uint4 *)(tile + r * LP + 16 * v) =
-                    *(const uint4 *)(srcF + (size_t)bl3_reflect(16 * b0 - 3 + r, a.h) * a.srcPitch + col);
-        }
+        // A thread keeps its 16-byte column and walks down the rows, RPP at a time.  All its loads are issued before the first one is
+        // waited for (one memory latency per workgroup, not one per pass): unconditional loads from clamped, always valid addresses,
+        // only the LDS writes are predicated.
+        const int r0 = tid / NVEC, v = tid - r0 * NVEC;
+        const int col = tx0 + 16 * v;
+        const bool colOk = tid < RPP * NVEC && col >= 0 && col + 16 <= a.srcPitch;
+        const uint8_t *colPtr = srcF + min(max(col, 0), a.srcPitch - 16);
+        uint4 stage[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            stage[k] = *(const uint4 *)(colPtr + (size_t)bl3_reflect(16 * b0 - 3 + min(r0 + RPP * k, nRows - 1), a.h) * a.srcPitch);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)  // (keeps the compiler from sinking each load into the predicated block of its LDS write)
+            asm volatile("" : "+v"(stage[k].x), "+v"(stage[k].y), "+v"(stage[k].z), "+v"(stage[k].w));
+        uint8_t *my = tile + r0 * LP + 16 * v;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (colOk && r0 + RPP * k < nRows) *(uint4 *)(my + RPP * k * LP) = stage[k];
     } else {
         for (int it = tid; it < nRows * (TW + 32); it += NT) {
             const int r = it / (TW + 32), cx = it - r * (TW + 32);
@@ -1243,31 +1283,18 @@ __device__ __forceinline__ void blur3_body(const BlurArgs &a, const int f, const
     __syncthreads();
     if (x0 >= a.w) return;
 
-    unsigned long T64 = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) T64 |= (unsigned long)(unsigned)a.taps[k] << (8 * k);
-    auto tapWin = [&](int k0) -> uint32_t {  // bytes tap[k0 .. k0 + 3], zero outside 0 .. 6
-        const int sh = 8 * k0;
-        const unsigned long v = sh >= 0 ? T64 >> min(sh, 63) : T64 << min(-sh, 63);
-        return (sh >= 64 || sh <= -32) ? 0u : (uint32_t)v;
-    };
-    // tap matrices.  K slot (g, jj) of the horizontal product is window column 8g + jj (image column x0 - 4 + 8g + jj), tap
-    // 8g + jj - n - 1 for output column n; of the vertical product it is row 4g + jj of the previous chunk (jj < 4), tap
-    // 4g + jj - n for output row n, or row 4g + jj - 4 of this one, tap 16 + 4g + jj - 4 - n.
+    const __attribute__((address_space(4))) uint32_t *tv = &tab->v[lane][0];
+    const long Bh = (long)(((unsigned long)tv[1] << 32) | tv[0]), Bv = (long)(((unsigned long)tv[3] << 32) | tv[2]);
     const bool biasLane = g == 3;
-    const uint32_t bh0 = biasLane ? BL3_BIAS_B : tapWin(8 * g - n - 1), bh1 = biasLane ? 0u : tapWin(8 * g + 4 - n - 1);
-    const uint32_t bv0 = tapWin(4 * g - n), bv1 = biasLane ? BL3_BIAS_B : tapWin(16 + 4 * g - n);
-    const long Bh = (long)(((unsigned long)bh1 << 32) | bh0), Bv = (long)(((unsigned long)bv1 << 32) | bv0);
-    const bool fast = x0 >= 4 && x0 + 28 <= a.w;  // the whole window lies inside the image
+    const bool fast = x0 >= 4 && x0 + 28 <= a.w;  // the whole window lies inside the image (wave-uniform)
     // LDS byte offsets of this lane's 8 window columns (strips at the image border: REFLECT_101, clamped where the tap is 0)
     int colOff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (!fast) {  // wave-uniform: only the strips at the left / right image border pay for the reflections
+    if (!fast) {  // only the strips at the left / right image border pay for the reflections
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) colOff[jj] = min(max(bl3_reflect(x0 - 4 + 8 * g + jj, a.w) - tx0, 0), TW + 31);
     }
     const uint8_t *myRow = tile + n * LP + (x0 - 4 + 8 * g - tx0);
     auto loadA = [&](int i) -> uint2 {  // rows 16 (b0 + i) - 3 + (lane & 15) of the extended image, pixels - 128
-        if (biasLane) return make_uint2(a.biasH, 0);
         uint2 v;
         if (fast) {
             const uint32_t *q = (const uint32_t *)(myRow + 16 * i * LP);
@@ -1279,16 +1306,24 @@ __device__ __forceinline__ void blur3_body(const BlurArgs &a, const int f, const
             for (int jj = 0; jj < 8; ++jj) t[jj >> 2] |= (uint32_t)row[colOff[jj]] << (8 * (jj & 3));
             v = make_uint2(t[0], t[1]);
         }
-        return make_uint2(v.x ^ 0x80808080u, v.y ^ 0x80808080u);
+        return biasLane ? make_uint2(a.biasH, 0) : make_uint2(v.x ^ 0x80808080u, v.y ^ 0x80808080u);
     };
     const bl3_v4i zero = {0, 0, 0, 0};
     const int xo = x0 + 4 * g;
+    // output row n of block c lies 2 c tile rows below row n of block 0: one address per lane, a scalar step per block
+    const size_t blockBytes = (size_t)a.dstPitch * 256;
+    uint8_t *dstLane = dstF + orbx_blur_tiled_offset(xo, n, a.dstPitch) + (size_t)b0 * blockBytes;
+    const bool xOk = xo < a.w;
+    // Straight-line code over the chunks (no early exit: blocks beyond the image compute on stale LDS rows and fail the `y < a.h` test
+    // of the store), so that the LDS reads of all chunks are in flight before the first product and the products of a chunk overlap
+    // the VALU work of the previous one.
+    uint2 avAll[SEG + 1];
+#pragma unroll
+    for (int i = 0; i <= SEG; ++i) avAll[i] = loadA(i);
     uint32_t loPrev = 0, hiPrev = 0;
 #pragma unroll
-    for (int i = 0; i <= BL3_SEG; ++i) {
-        const int c = b0 + i;
-        if (c > b1) break;  // wave-uniform
-        const uint2 av = loadA(i);
+    for (int i = 0; i <= SEG; ++i) {
+        const uint2 av = avAll[i];
         const long A = (long)(((unsigned long)av.y << 32) | av.x);
         const bl3_v4i H = __builtin_amdgcn_mfma_i32_16x16x32_i8(A, Bh, zero, 0, 0, 0);  // exact row sums, 0 .. 255 * S <= 65535
         const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)H[1], (uint32_t)H[0], 0x05010400u);
@@ -1300,25 +1335,28 @@ __device__ __forceinline__ void blur3_body(const BlurArgs &a, const int f, const
             const long Ahi = (long)(((unsigned long)(biasLane ? a.biasHi : hi) << 32) | hiPrev);
             const bl3_v4i Dl = __builtin_amdgcn_mfma_i32_16x16x32_i8(Alo, Bv, zero, 0, 0, 0);
             const bl3_v4i Dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(Ahi, Bv, zero, 0, 0, 0);  // includes the rounding term >> 8
-            const int y = 16 * (c - 1) + n;
-            if (y < a.h && xo < a.w) {
+            const int y = 16 * (b0 + i - 1) + n;
+            if (y < a.h && xOk) {
                 uint32_t packed = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);
-                *(uint32_t *)(dstF + orbx_blur_tiled_offset(xo, y, a.dstPitch)) = packed;  // (a tile row holds all 4 pixels)
+                    packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);  // (the 4.5.0 taps sum to 257: 255 needs the clamp)
+                *(uint32_t *)(dstLane + (size_t)(i - 1) * blockBytes) = packed;  // (a tile row holds all 4 pixels)
             }
         }
         loPrev = lo; hiPrev = hi;
     }
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_blur3(BlurArgs a)
+struct Blur3KArgs { BlurArgs a; BlurLaneTab t; };
+
+template <int NW, int SEG>
+__global__ __launch_bounds__(NW * 64) void k_blur3(Blur3KArgs ka)
 {
     int f, unit;
-    if (!xcd_decode(a.nframes, a.tilesX * a.tilesY, f, unit)) return;
-    blur3_body<NW>(a, f, unit);
+    if (!xcd_decode(ka.a.nframes, ka.a.tilesX * ka.a.tilesY, f, unit)) return;
+    const __attribute__((address_space(4))) char *kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    blur3_body<NW, SEG>(ka.a, (BlurLaneTabK *)(kp + offsetof(Blur3KArgs, t)), f, unit);
 }
 
 // every level of a (small) batch in one launch: eight launches of a few microseconds each were the longest branch of a single-frame call
@@ -1326,6 +1364,7 @@ struct BlurLevelsArgs {
     BlurArgs lv[ORBX_MAX_LEVELS];
     int tileStart[ORBX_MAX_LEVELS + 1];
     int nlevels, nframes;
+    BlurLaneTab t;
 };
 __global__ __launch_bounds__(256) void k_blur3_levels(BlurLevelsArgs la)
 {
@@ -1334,7 +1373,8 @@ __global__ __launch_bounds__(256) void k_blur3_levels(BlurLevelsArgs la)
     int level = 0;
     for (int l = 1; l < la.nlevels; ++l) level += unit >= la.tileStart[l] ? 1 : 0;
     const BlurArgs a = la.lv[level];
-    blur3_body<4>(a, f, unit - la.tileStart[level]);
+    const __attribute__((address_space(4))) char *kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    blur3_body<4, BL3_SEG>(a, (BlurLaneTabK *)(kp + offsetof(BlurLevelsArgs, t)), f, unit - la.tileStart[level]);
 }
 
 static bool blur3Eligible(const int taps[7], int w, int h, const uint8_t *dst, long long dstFrameStride)
@@ -1378,6 +1418,7 @@ hipError_t orbxLaunchBlurLevels(hipStream_t st, int nframes, int nlevels, const 
         la.tileStart[l + 1] = la.tileStart[l] + la.lv[l].tilesX * la.lv[l].tilesY;
     }
     la.nlevels = nlevels; la.nframes = nframes;
+    fillBlurLaneTab(la.t, taps);
     hipLaunchKernelGGL(k_blur3_levels, dim3(xcd_grid(nframes, la.tileStart[nlevels])), dim3(256), 0, st, la);
     return hipGetLastError();
 }
@@ -1399,20 +1440,27 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
     for (int k = 0; k < 7; ++k) i8ok = i8ok && taps[k] >= 0 && taps[k] <= 127;
     const uintptr_t dbits = (uintptr_t)dst | (uintptr_t)dstFrameStride;
     a.srcAligned = (((uintptr_t)src | (uintptr_t)srcPitch | (uintptr_t)srcFrameStride) & 15) == 0;
+    const int S = taps[0] + taps[1] + taps[2] + taps[3] + taps[4] + taps[5] + taps[6];
     if (variant == 3 && small && i8ok && (dbits & 3) == 0 && w >= 32 && h >= 16) {
-        const int S = taps[0] + taps[1] + taps[2] + taps[3] + taps[4] + taps[5] + taps[6];
         a.biasH = bl3_bias_bytes(128 * S);         // pixels - 128
         a.biasL = bl3_bias_bytes(128 * S);         // low byte plane - 128
         a.biasHi = bl3_bias_bytes(128 * S + 128);  // high byte plane - 128, + 32768 >> 8 for the final rounding
         static const int nw = [] { const char *e = getenv("ORBX_BLUR_WAVES"); return e ? atoi(e) : 4; }();
-        a.nframes = nframes; a.tilesY = ((h + 15) / 16 + BL3_SEG - 1) / BL3_SEG;
-        if (nw == 8) {
-            a.tilesX = (w + 127) / 128;
-            hipLaunchKernelGGL(k_blur3<8>, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(512), 0, st, a);
-        } else {
-            a.tilesX = (w + 63) / 64;
-            hipLaunchKernelGGL(k_blur3<4>, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
-        }
+        // 16-row blocks per workgroup.  8 spreads what a wave does once over twice the blocks and is 11 % faster alone (0.61 against
+        // 0.66 ms per 1024-frame batch), but its 16 KB tiles take the LDS from the quadtree next to it: within 1 % either way on the
+        // four workloads (tools/experiments/blur_seg_sweep.sh), so the small tile stays.
+        static const int segEnv = [] { const char *e = getenv("ORBX_BLUR_SEG"); return e ? atoi(e) : 0; }();
+        const int seg = segEnv == 8 ? 8 : 4;
+        Blur3KArgs ka;
+        ka.a = a;
+        fillBlurLaneTab(ka.t, taps);
+        ka.a.nframes = nframes; ka.a.tilesY = ((h + 15) / 16 + seg - 1) / seg;
+        ka.a.tilesX = nw == 8 ? (w + 127) / 128 : (w + 63) / 64;
+        const dim3 grid(xcd_grid(nframes, ka.a.tilesX * ka.a.tilesY));
+        if (nw == 8 && seg == 8) hipLaunchKernelGGL((k_blur3<8, 8>), grid, dim3(512), 0, st, ka);
+        else if (nw == 8) hipLaunchKernelGGL((k_blur3<8, 4>), grid, dim3(512), 0, st, ka);
+        else if (seg == 8) hipLaunchKernelGGL((k_blur3<4, 8>), grid, dim3(256), 0, st, ka);
+        else hipLaunchKernelGGL((k_blur3<4, 4>), grid, dim3(256), 0, st, ka);
     } else if (variant >= 2 && symmetric && small && (bits & 3) == 0) {
         a.nframes = nframes; a.tilesX = (w + BL2_GW * 4 - 1) / (BL2_GW * 4); a.tilesY = (h + BL2_TH - 1) / BL2_TH;
         hipLaunchKernelGGL(k_blur2, dim3(xcd_grid(nframes, a.tilesX * a.tilesY)), dim3(256), 0, st, a);
