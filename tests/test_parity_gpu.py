@@ -384,12 +384,14 @@ def test_quadtree_kernels_on_other_shapes(pkg, mw):
             _gpu_check_subprocess({"ORBX_QT_MW": "0", "ORBX_QT_KCH": kch}, (["640", "480", "1000", "24"], ["752", "480", "2500", "2"]))
 
 
-@pytest.mark.parametrize("env", [{"ORBX_BLUR_KERNEL": "2"}, {"ORBX_BLUR_KERNEL": "1"}, {"ORBX_BLUR_WAVES": "8"}])
+@pytest.mark.parametrize("env", [{"ORBX_BLUR_KERNEL": "2"}, {"ORBX_BLUR_KERNEL": "1"}, {"ORBX_BLUR_WAVES": "8"}, {"ORBX_BLUR_SEG": "8"},
+                                 {"ORBX_BLUR_SEG": "8", "ORBX_BLUR_WAVES": "8"}])
 def test_blur_fallback_kernels(pkg, env):
-    """The GaussianBlur normally runs on the matrix cores (k_blur3, 4 waves per workgroup); taps that do not fit int8 or
-    unaligned buffers take the byte-SWAR kernel (k_blur2) or the generic one (k_blur), and k_blur3 has an 8-wave shape.  Force
-    each in a subprocess (the switch is read once per process) and check every stage against the oracle."""
-    _gpu_check_subprocess(env, (["640", "480", "1000", "2"], ["333", "257", "600", "1"]))
+    """The GaussianBlur normally runs on the matrix cores (k_blur3, 4 waves x 4 row blocks per workgroup); taps that do not fit int8
+    or unaligned buffers take the byte-SWAR kernel (k_blur2) or the generic one (k_blur), and k_blur3 has an 8-wave and an 8-block
+    shape.  Force each in a subprocess (the switch is read once per process) and check every stage against the oracle - on a frame
+    whose height is not a multiple of the 16-row blocks, too."""
+    _gpu_check_subprocess(env, (["640", "480", "1000", "2"], ["333", "257", "600", "1"], ["752", "473", "900", "17"]))
 
 
 @pytest.mark.parametrize("env,args", [({"ORBX_QT_PER_LEVEL": "1"}, ["640", "480", "1000", "3"]), ({"ORBX_QT_PER_LEVEL": "3"}, ["640", "480", "1000", "3"]),
