@@ -236,12 +236,25 @@ __global__ __launch_bounds__(256) void k_stereo_buckets(const MtKp *kr, int nr, 
     }
 }
 
-// One lane per left keypoint: the candidates are the right keypoints in the bucket of its row (:884-886), filtered by |octave difference|
-// <= 1 and uR in [uL - maxD, uL - minD]; the reference visits them in increasing iR with a strict `<` starting from TH_HIGH, i.e. it keeps
-// the candidate with the smallest (distance, iR) among those with distance < TH_HIGH - a minimum that does not depend on the order.
-__global__ __launch_bounds__(64) void k_stereo_rows(const MtKp *kl, const uint8_t *dl, int nl, const MtKp *kr,
-                                                    const uint8_t *dr, int nr, int nRows, const int *rowStart, const int *rowItems,
-                                                    int itemStride, float minD, float maxD, int *bestIdx, int *bestDist, StereoBatch sb)
+// minimum over the 16 lanes of a DPP row (every lane ends up with it): lane pairs, quad halves, mirrored halves of 8, mirrored row
+__device__ __forceinline__ uint32_t mt_row_min_u32(uint32_t x)
+{
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false));
+    return x;
+}
+
+// Sixteen lanes per left keypoint (four keypoints per wave), one candidate per lane and step: the candidates are the right keypoints in
+// the bucket of its row (:884-886), filtered by |octave difference| <= 1 and uR in [uL - maxD, uL - minD]; the reference visits them in
+// increasing iR with a strict `<` starting from TH_HIGH, i.e. it keeps the candidate with the smallest (distance, iR) among those with
+// distance < TH_HIGH - a minimum that does not depend on the order, taken here over the lanes.  (One lane per left keypoint walking its
+// bucket paid the three dependent loads bucket entry -> keypoint -> descriptor once per candidate, and a wave ran until the longest
+// of its 64 buckets was done: 0.42 ms per 512 pairs of 1200 keypoints against 0.0x now.)
+__global__ __launch_bounds__(256) void k_stereo_rows(const MtKp *kl, const uint8_t *dl, int nl, const MtKp *kr,
+                                                     const uint8_t *dr, int nr, int nRows, const int *rowStart, const int *rowItems,
+                                                     int itemStride, float minD, float maxD, int *bestIdx, int *bestDist, StereoBatch sb)
 {
     {
         const size_t p = blockIdx.y;
@@ -249,37 +262,45 @@ __global__ __launch_bounds__(64) void k_stereo_rows(const MtKp *kl, const uint8_
         bestIdx += p * sb.outStride; bestDist += p * sb.outStride;
         rowStart += p * (size_t)(nRows + 1); rowItems += p * (size_t)itemStride;
         if (sb.nlDev) nl = min(nl, sb.nlDev[p]);
-        if ((int)(blockIdx.x * 64) >= nl) return;
+        if ((int)(blockIdx.x * 16) >= nl) return;
     }
-    const int li = blockIdx.x * 64 + threadIdx.x;
-    if (li >= nl) return;
+    const int sub = threadIdx.x & 15;
+    const int li = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = li < nl;
+    const int lic = min(li, nl - 1);
     uint32_t qq[8];
     {
-        const uint4 *qs = (const uint4 *)(dl + (size_t)li * 32);
+        const uint4 *qs = (const uint4 *)(dl + (size_t)lic * 32);
         const uint4 v0 = qs[0], v1 = qs[1];
         qq[0] = v0.x; qq[1] = v0.y; qq[2] = v0.z; qq[3] = v0.w; qq[4] = v1.x; qq[5] = v1.y; qq[6] = v1.z; qq[7] = v1.w;
     }
-    const MtKp k = kl[li];
-    const int levelL = k.octave, row = (int)k.y;
-    const float minU = __fsub_rn(k.x, maxD), maxU = __fsub_rn(k.x, minD);
+    const float kx = kl[lic].x, ky = kl[lic].y;
+    const int levelL = kl[lic].octave, row = (int)ky;
+    const float minU = __fsub_rn(kx, maxD), maxU = __fsub_rn(kx, minD);
     uint32_t bestKey = (100u << 20);  // ORBmatcher::TH_HIGH (reference src/ORBmatcher1.cc:37): only smaller distances are taken
-    if (row >= 0 && row < nRows && !(maxU < 0)) {
-        const int e0 = rowStart[row], e1 = min(rowStart[row + 1], itemStride);
-        for (int e = e0; e < e1; ++e) {
+    int e = 0, e1 = 0;
+    if (live && row >= 0 && row < nRows && !(maxU < 0)) { e = rowStart[row] + sub; e1 = min(rowStart[row + 1], itemStride); }
+    while (__ballot(e < e1) != 0ull) {
+        if (e < e1) {
             const int iR = rowItems[e];
-            const MtKp c = kr[iR];
-            if (c.octave < levelL - 1 || c.octave > levelL + 1) continue;
-            if (!(c.x >= minU && c.x <= maxU)) continue;
-            const uint4 *ts = (const uint4 *)(dr + (size_t)iR * 32);
-            const uint4 t0 = ts[0], t1 = ts[1];
-            const uint32_t tw[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            const uint32_t d = (uint32_t)ham256(qq, tw);
-            bestKey = min(bestKey, (d << 20) | (uint32_t)iR);
+            const int octR = kr[iR].octave;
+            const float xR = kr[iR].x;
+            if (octR >= levelL - 1 && octR <= levelL + 1 && xR >= minU && xR <= maxU) {
+                const uint4 *ts = (const uint4 *)(dr + (size_t)iR * 32);
+                const uint4 t0 = ts[0], t1 = ts[1];
+                const uint32_t tw[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                const uint32_t d = (uint32_t)ham256(qq, tw);
+                bestKey = min(bestKey, (d << 20) | (uint32_t)iR);
+            }
         }
+        e += 16;
     }
-    const bool found = bestKey < (100u << 20);
-    bestIdx[li] = found ? (int)(bestKey & 0xFFFFF) : -1;
-    bestDist[li] = found ? (int)(bestKey >> 20) : 100;
+    bestKey = mt_row_min_u32(bestKey);
+    if (live && sub == 0) {
+        const bool found = bestKey < (100u << 20);
+        bestIdx[li] = found ? (int)(bestKey & 0xFFFFF) : -1;
+        bestDist[li] = found ? (int)(bestKey >> 20) : 100;
+    }
 }
 
 static StereoBatch stereoBatch(const OrbxStereoBatch *b)
@@ -300,7 +321,7 @@ hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *d
     const StereoBatch sb = stereoBatch(batch);
     hipLaunchKernelGGL(k_stereo_buckets, dim3(npairs), dim3(256), (size_t)(nRows + 256) * sizeof(int), st, (const MtKp *)kr, nr, nRows, scaleDev, rowStart,
                        rowItems, itemStride, sb);
-    hipLaunchKernelGGL(k_stereo_rows, dim3((nl + 63) / 64, npairs), dim3(64), 0, st, (const MtKp *)kl, dl, nl, (const MtKp *)kr,
+    hipLaunchKernelGGL(k_stereo_rows, dim3((nl + 15) / 16, npairs), dim3(256), 0, st, (const MtKp *)kl, dl, nl, (const MtKp *)kr,
                        dr, nr, nRows, rowStart, rowItems, itemStride, minD, maxD, bestIdx, bestDist, sb);
     return hipGetLastError();
 }
@@ -308,7 +329,7 @@ hipError_t orbxLaunchStereoRows(hipStream_t st, const void *kl, const uint8_t *d
 // =====================================================================================================
 // Sub-pixel stereo refinement — Frame::ComputeStereoMatches, reference src/Frame.cc:926-1011
 // (the step right after the row-band Hamming stage; it reads mvImagePyramid of both extractors,
-// which stays on the device here).  One wave per left keypoint: 11x11 L1 (cv::norm NORM_L1) between the left patch and
+// which stays on the device here).  Sixteen lanes per left keypoint: 11x11 L1 (cv::norm NORM_L1) between the left patch and
 // 11 shifted right patches, parabola fit through the best three, re-scale, disparity test.
 // =====================================================================================================
 struct StereoLevels {
@@ -329,6 +350,21 @@ __device__ __forceinline__ int mt_wave_sum(int x)
            __builtin_amdgcn_readlane(x, 48);
 }
 
+// sum over the 16 lanes of a DPP row (every lane ends up with it)
+__device__ __forceinline__ int mt_row_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);
+    return x;
+}
+
+// Sixteen lanes per left keypoint (four keypoints per wave); lane r < 11 owns row r of the 11 x 11 patch: 11 left bytes in three dwords,
+// the 21 right bytes of all eleven shifts in six (loads from the exact, byte-unaligned addresses - nothing beyond the patch rows is
+// read), a shifted window is three v_alignbyte and its row SAD three v_sad_u8; the rows are summed over the lanes of the DPP row.
+// (A wave per keypoint with one or two pixels per lane issued 24 byte loads and 88 lane reductions per keypoint: 0.54 ms per 512 pairs
+// of 1200 keypoints.)
 __global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp *kl, int nl, const MtKp *kr, const int *bestIdx,
                                                     const int *bestDist, float mbf, float minD, float maxD, float *uRight, float *depth,
                                                     int *sadDist, StereoBatch sb)
@@ -338,20 +374,23 @@ __global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp 
     bestIdx += pair * sb.outStride; bestDist += pair * sb.outStride;
     uRight += pair * sb.outStride; depth += pair * sb.outStride; sadDist += pair * sb.outStride;
     if (sb.nlDev) nl = min(nl, sb.nlDev[pair]);
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= nl) return;
+    if ((int)(blockIdx.x * 16) >= nl) return;
+    const int sub = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = i < nl;
+    const int ic = min(i, nl - 1);
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
     float outU = -1.0f, outD = -1.0f;
     int outS = -1;
-    const int bi = bestIdx[i], bd = bestDist[i];
-    if (bi >= 0 && bd < (100 + 50) / 2) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2  (:846, :927)
-        const MtKp kpL = kl[i];
-        const int oct = kpL.octave;
-        const float uL = kpL.x;
+    const int bi = bestIdx[ic], bd = bestDist[ic];
+    if (live && bi >= 0 && bd < (100 + 50) / 2) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2  (:846, :927)
+        const float kx = kl[ic].x, ky = kl[ic].y;
+        const int oct = kl[ic].octave;
+        const float uL = kx;
         const float uR0 = kr[bi].x;
         const float sf = lv.invScale[oct];
-        const float scaleduL = roundf(__fmul_rn(kpL.x, sf));
-        const float scaledvL = roundf(__fmul_rn(kpL.y, sf));
+        const float scaleduL = roundf(__fmul_rn(kx, sf));
+        const float scaledvL = roundf(__fmul_rn(ky, sf));
         const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
         const int w = 5, L = 5;
         const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)L), (float)w);
@@ -359,29 +398,34 @@ __global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp 
         if (!(iniu < 0 || endu >= (float)lv.colsR[oct])) {
             const int y0 = (int)__fsub_rn(scaledvL, (float)w), xL0 = (int)__fsub_rn(scaleduL, (float)w);
             const int xRb = (int)scaleduR0 - w;  // first column of the unshifted right patch
-            const uint8_t *pl = lv.left[oct] + pair * lv.frameStrideL[oct] + (size_t)y0 * lv.pitchL[oct] + xL0;
-            const uint8_t *pr = lv.right[oct] + pair * lv.frameStrideR[oct] + (size_t)y0 * lv.pitchR[oct] + xRb;
-            // lane handles patch pixels p0 = lane and p1 = lane + 64 (121 pixels)
-            const int p0 = lane, p1 = lane + 64;
-            const int y0p = p0 / 11, x0p = p0 - y0p * 11, y1p = p1 / 11, x1p = p1 - y1p * 11;
-            const bool has1 = p1 < 121;
-            const int a0 = pl[y0p * lv.pitchL[oct] + x0p];
-            const int a1 = has1 ? pl[y1p * lv.pitchL[oct] + x1p] : 0;
-            int sad[11];
+            const int r = min(sub, 10);
+            const uint8_t *pl = lv.left[oct] + pair * lv.frameStrideL[oct] + (size_t)(y0 + r) * lv.pitchL[oct] + xL0;
+            const uint8_t *pr = lv.right[oct] + pair * lv.frameStrideR[oct] + (size_t)(y0 + r) * lv.pitchR[oct] + xRb - L;
+            const bool rowLane = sub < 11;
+            // left row: bytes 0..10; right row R[0..20] = columns xRb - 5 .. xRb + 15
+            uint32_t a0 = *(const u32_unaligned *)pl, a1 = *(const u32_unaligned *)(pl + 4), a2 = *(const u32_unaligned *)(pl + 7) >> 8;
+            uint32_t rw[7];
 #pragma unroll
-            for (int inc = 0; inc < 11; ++inc) {
-                const int b0 = pr[y0p * lv.pitchR[oct] + x0p + inc - L];
-                const int b1 = has1 ? pr[y1p * lv.pitchR[oct] + x1p + inc - L] : 0;
-                const int d0 = a0 - b0, d1 = a1 - b1;
-                sad[inc] = (d0 < 0 ? -d0 : d0) + (has1 ? (d1 < 0 ? -d1 : d1) : 0);
-            }
-            int best = INT_MAX, bestInc = 0;
+            for (int k = 0; k < 5; ++k) rw[k] = *(const u32_unaligned *)(pr + 4 * k);
+            rw[5] = *(const u32_unaligned *)(pr + 17) >> 24;  // R[20] (R[21..23] are never part of a window: masked below)
+            rw[6] = 0;
+            if (!rowLane) { a0 = a1 = a2 = 0; rw[0] = rw[1] = rw[2] = rw[3] = rw[4] = rw[5] = 0; }
             int tot[11];
 #pragma unroll
             for (int inc = 0; inc < 11; ++inc) {
-                tot[inc] = mt_wave_sum(sad[inc]);
-                if (tot[inc] < best) { best = tot[inc]; bestInc = inc - L; }
+                const int q = inc >> 2, sh = inc & 3;
+                const uint32_t W0 = sh ? __builtin_amdgcn_alignbyte(rw[q + 1], rw[q], sh) : rw[q];
+                const uint32_t W1 = sh ? __builtin_amdgcn_alignbyte(rw[q + 2], rw[q + 1], sh) : rw[q + 1];
+                const uint32_t W2 = (sh ? __builtin_amdgcn_alignbyte(rw[q + 3], rw[q + 2], sh) : rw[q + 2]) & 0x00FFFFFFu;
+                uint32_t sd = __builtin_amdgcn_sad_u8(a0, W0, 0u);
+                sd = __builtin_amdgcn_sad_u8(a1, W1, sd);
+                sd = __builtin_amdgcn_sad_u8(a2, W2, sd);
+                tot[inc] = mt_row_sum((int)sd);
             }
+            int best = INT_MAX, bestInc = 0;
+#pragma unroll
+            for (int inc = 0; inc < 11; ++inc)
+                if (tot[inc] < best) { best = tot[inc]; bestInc = inc - L; }
             if (!(bestInc == -L || bestInc == L)) {
                 float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
 #pragma unroll
@@ -405,7 +449,7 @@ __global__ __launch_bounds__(256) void k_stereo_sad(StereoLevels lv, const MtKp 
             }
         }
     }
-    if (lane == 0) { uRight[i] = outU; depth[i] = outD; sadDist[i] = outS; }
+    if (live && sub == 0) { uRight[i] = outU; depth[i] = outD; sadDist[i] = outS; }
 }
 
 // median-based outlier rejection (:996-1010): median = SAD at rank size/2 of the accepted matches (a k-th order
@@ -453,7 +497,7 @@ hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void
     static_assert(sizeof(StereoLevels) == sizeof(OrbxStereoLevels), "host / device level tables differ");
     const StereoLevels &lv = *(const StereoLevels *)levels;
     const int npairs = batch ? batch->npairs : 1;
-    hipLaunchKernelGGL(k_stereo_sad, dim3((nl + 3) / 4, npairs), dim3(256), 0, st, lv, (const MtKp *)kl, nl, (const MtKp *)kr, bestIdx, bestDist,
+    hipLaunchKernelGGL(k_stereo_sad, dim3((nl + 15) / 16, npairs), dim3(256), 0, st, lv, (const MtKp *)kl, nl, (const MtKp *)kr, bestIdx, bestDist,
                        mbf, minD, maxD, uRight, depth, sadDist, stereoBatch(batch));
     hipLaunchKernelGGL(k_stereo_outliers, dim3(npairs), dim3(256), 0, st, nl, uRight, depth, sadDist, stereoBatch(batch));
     return hipGetLastError();
