@@ -398,11 +398,16 @@ def test_blur_fallback_kernels(pkg, env):
                                       ({"ORBX_QT_PER_LEVEL": "4"}, ["752", "480", "1200", "2"]), ({"ORBX_EARLY_BLUR": "1"}, ["640", "480", "1000", "3"]),
                                       ({"ORBX_SUBBATCHES": "3"}, ["640", "480", "1000", "200"]), ({"ORBX_PF_LDS_FIT": "0"}, ["752", "480", "1200", "20"]),
                                       ({"ORBX_FRONT_PARTS": "2"}, ["640", "480", "1000", "300"]),
+                                      ({"ORBX_QT_STREAMS": "2", "ORBX_QT_PER_LEVEL": "3"}, ["640", "480", "1000", "24"]),
+                                      ({"ORBX_QT_STREAMS": "3", "ORBX_QT_PER_LEVEL": "2"}, ["752", "480", "1200", "5"]),
+                                      ({}, ["512", "512", "1500", "648"]),
                                       ({"ORBX_FRONT_PARTS": "3", "ORBX_FRONT_STAGGER": "1"}, ["640", "480", "1000", "300"])])
 def test_launch_schedules(pkg, env, args):
     """The launch sequence has measured alternatives behind environment switches (quadtree per level / per group of levels, blur
     of a level as soon as it exists, device batches cut into sub-batches, the k_pyr_fast chain cut into frame groups on their own
-    streams, tile widths that ignore the 40 KB LDS limit of four workgroups per CU): every one of them must give the same bytes."""
+    streams, tile widths that ignore the 40 KB LDS limit of four workgroups per CU, the quadtree launch groups dealt over several
+    streams - which is also what a large batch with many features per pixel does by itself, the last case): every one of them must
+    give the same bytes."""
     _gpu_check_subprocess(env, (args,))
 
 

@@ -1075,7 +1075,12 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
     // where the launches of a stream run one after the other and each costs an instance's latency (1 frame: 0.37 ms per call with
     // one launch, 0.67 ms with pairs; 512 frames: 2.05 vs 2.10 ms; tools/experiments/qt_mode_sweep.sh)
     static const int qtPerLevelEnv = [] { const char *e = getenv("ORBX_QT_PER_LEVEL"); return e ? atoi(e) : -1; }();
-    const int qtPerLevel = qtPerLevelEnv >= 0 ? qtPerLevelEnv : (subSize >= 640 ? 3 : 0);
+    // Many features per pixel (512 x 512 / 1500: 5.7 per 1000 pixels; VGA / 1000: 3.3): the quadtree, not the blur beside it, is the longer
+    // branch - groups of three levels, dealt over two streams so that the thin tails of the launches overlap (3.60 -> 3.36 ms per
+    // 1024 frames; the same schedule costs the VGA workload 1 %, because there it takes LDS from the blur, which is its longer branch;
+    // tools/experiments/qt_streams_sweep.sh)
+    const bool qtHeavy = (double)ex->prm.nfeatures > 0.0045 * (double)w * (double)h;
+    const int qtPerLevel = qtPerLevelEnv >= 0 ? qtPerLevelEnv : (subSize >= 640 ? (qtHeavy ? 4 : 3) : 0);
     static const bool earlyBlur = [] { const char *e = getenv("ORBX_EARLY_BLUR"); return e ? atoi(e) != 0 : false; }();  // measured: 6.37 ms with early blur vs 6.02 ms with blur || quadtree
     hipEvent_t *prof = ex->profiling ? &ex->events[(size_t)(ex->profCount % PROF_RING) * PROF_EVENTS] : nullptr;
     if (earlyBlur) {
@@ -1184,14 +1189,27 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
         HIP_TRY(hipStreamWaitEvent(sBack, ex->evFront[sb], 0));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2], sBack));
         if (qtPerLevel != 1) {
-            // one launch per group of `qtPerLevel` levels (0: all levels in one launch): LDS per instance follows the quota
+            // one launch per group of `qtPerLevel` levels (0: all levels in one launch): LDS per instance follows the quota.  The groups
+            // are independent (a level's instances read that level's candidates only), so each goes on a stream of its own: a launch of
+            // latency-bound single-wave instances ends in a long thin tail, and behind each other on one stream the tails add up.
             const int step = qtPerLevel >= 2 ? qtPerLevel - 1 : nl;
-            for (int l0 = 0; l0 < nl; l0 += step)
-                HIP_TRY(orbxLaunchQuadtree(sBack, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
+            static const int qtStreamsEnv = [] { const char *e = getenv("ORBX_QT_STREAMS"); return e ? std::min(std::max(atoi(e), 0), 3) : -1; }();
+            const int qtWant = qtStreamsEnv >= 0 ? qtStreamsEnv : (qtHeavy ? 1 : 0);
+            const int qtExtra = qtWant > 0 && step < nl && smallBatchPrepare(ex) != 0 ? qtWant : 0;  // streams beside the back stream
+            int gi = 0;
+            bool used[4] = {false, false, false, false};
+            for (int l0 = 0; l0 < nl; l0 += step, ++gi) {
+                const int si = gi % (qtExtra + 1);  // groups dealt round-robin: 0 = the back stream itself
+                hipStream_t sq = si ? ex->qtStream[si] : sBack;
+                if (si && !used[si]) { HIP_TRY(hipStreamWaitEvent(sq, ex->evFront[sb], 0)); used[si] = true; }
+                HIP_TRY(orbxLaunchQuadtree(sq, nf, nl, ex->geom.data(), ex->d_geom.p, ex->d_cand.p + (size_t)f0 * ex->candFrameStride,
                                            ex->candFrameStride, ex->d_tileCount.p + (size_t)f0 * ex->tilesPerFrame, ex->tilesPerFrame,
                                            ex->d_scratchA.p + (size_t)f0 * ex->candFrameStride, ex->d_scratchB.p + (size_t)f0 * ex->candFrameStride,
                                            ex->d_sel.p + (size_t)f0 * ex->selFrameStride, ex->selFrameStride,
                                            ex->d_selCount.p + (size_t)f0 * nl, ex->maxQuota, l0, std::min(step, nl - l0), ex->d_qtNodes.p, ex->d_qtNodes.n));
+            }
+            for (int k = 1; k < 4; ++k)
+                if (used[k]) { HIP_TRY(hipEventRecord(ex->evQt[k], ex->qtStream[k])); HIP_TRY(hipStreamWaitEvent(sBack, ex->evQt[k], 0)); }
         }
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 1) * 2 + 1], sBack));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 3) * 2], sBack));
