@@ -1464,6 +1464,7 @@ struct orbx_matcher {
     DevBuf<float> d_prev;
     DevBuf<signed char> d_bin;
     DevBuf<uint32_t> d_sbpCand;   // SearchByProjection: candidate lists [maxQ][ORBX_SBP_CAP]
+    DevBuf<uint8_t> d_siWork;     // SearchForInitialization: octave-0 subset of F2 and the shortest candidates of every F1 keypoint
     DevBuf<orbx_projection> d_proj;
 };
 
@@ -1809,6 +1810,7 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     if ((rc = m->d_work.ensure((size_t)m->maxQ + 2 * (size_t)m->maxT + 4)) != ORBX_OK) return rc;
     if ((rc = m->d_prev.ensure(2 * (size_t)m->maxQ)) != ORBX_OK) return rc;
     if ((rc = m->d_bin.ensure((size_t)m->maxQ)) != ORBX_OK) return rc;
+    if ((rc = m->d_siWork.ensure(orbxSearchInitWorkBytes(1, m->maxQ))) != ORBX_OK) return rc;
     int level0of2 = 0;  // the LDS-resident kernel takes F2 subsets of limited size; ORBX_SEARCH_INIT_GENERIC forces the generic one
     for (int i = 0; i < n2; ++i) level0of2 += k2[i].octave == 0;
     static const bool forceGeneric = getenv("ORBX_SEARCH_INIT_GENERIC") != nullptr;
@@ -1820,7 +1822,7 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     HIP_TRY(hipMemcpyAsync(m->d_prev.p, prev_matched, 2 * (size_t)n1 * sizeof(float), hipMemcpyHostToDevice, m->stream));
     if (!orbxSearchInitInLds(n1, n2, level0of2)) HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n2, min_x, max_x, min_y, max_y, cs, it, co));
     HIP_TRY(orbxLaunchSearchInit(m->stream, m->d_kl.p, m->d_q.p, n1, m->d_kr.p, m->d_t.p, n2, cs, it, min_x, max_x, min_y, max_y,
-                                 m->d_prev.p, m12, m21, md, m->d_bin.p, nm, window_size, nnratio, check_orientation, level0of2));
+                                 m->d_prev.p, m12, m21, md, m->d_bin.p, nm, window_size, nnratio, check_orientation, level0of2, m->d_siWork.p));
     int nmatches = 0;
     HIP_TRY(hipMemcpyAsync(matches12, m12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(prev_matched, m->d_prev.p, 2 * (size_t)n1 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
@@ -2242,6 +2244,7 @@ extern "C" int orbx_search_for_initialization_frames(orbx_matcher *m, orbx_extra
     const size_t P = (size_t)npairs;
     const orbx_keypoint *un1 = ex1->d_kps.p, *un2 = ex2->d_kps.p + (size_t)frame2_offset * cap2;
     if ((rc = m->d_bin.ensure(P * cap1)) != ORBX_OK) return rc;
+    if ((rc = m->d_siWork.ensure(orbxSearchInitWorkBytes(npairs, cap1))) != ORBX_OK) return rc;
     if ((rc = orderAfterExtractors(m, ex1, ex2)) != ORBX_OK) return rc;
     if (!(ndist == 0 || dist[0] == 0.0)) {  // mvKeysUn of both frames (without distortion mvKeysUn = mvKeys, src/Frame.cc:779-783)
         if ((rc = m->d_bKps.ensure(P * ((size_t)cap1 + cap2))) != ORBX_OK) return rc;
@@ -2253,7 +2256,7 @@ extern "C" int orbx_search_for_initialization_frames(orbx_matcher *m, orbx_extra
     const hipError_t e = orbxLaunchSearchInitBatch(m->stream, npairs, un1, ex1->d_desc.p, cap1, ex1->d_n.p, un2,
                                                    ex2->d_desc.p + (size_t)frame2_offset * cap2 * 32, cap2, ex2->d_n.p + frame2_offset, cap1, cap2, min_x,
                                                    max_x, min_y, max_y, d_prev_matched, init_prev_matched != 0, (int *)d_matches12, m->d_bin.p,
-                                                   (int *)d_nmatches, window_size, nnratio, check_orientation != 0);
+                                                   (int *)d_nmatches, window_size, nnratio, check_orientation != 0, m->d_siWork.p);
     if (e == hipErrorInvalidValue) return setError(ORBX_ERR_CAPACITY, "%s: %d keypoints per frame exceed what the search keeps in LDS", fn, cap1);
     HIP_TRY(e);
     return orderExtractorsAfter(m, ex1, ex2);

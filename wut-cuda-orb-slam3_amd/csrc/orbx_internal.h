@@ -191,7 +191,7 @@ bool orbxSearchInitInLds(int n1, int n2, int level0of2);
 hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
                                 const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
-                                int checkOri, int level0of2);
+                                int checkOri, int level0of2, void *work);
 
 hipError_t orbxLaunchBlurLevels(hipStream_t st, int nframes, int nlevels, const int *w, const int *h, const uint8_t *const *src, const int *srcPitch,
                                 const long long *srcFrameStride, uint8_t *const *dst, const int *dstPitch, const long long *dstFrameStride,
@@ -208,10 +208,12 @@ void orbxFillPyrFastLevelArgs(void *out, int nframes, const OrbxLevelGeom &g, co
                               int minTh);
 hipError_t orbxLaunchPyrFastLevels(hipStream_t st, int nframes, const OrbxLevelGeom *geomsHost, int nlevels, const void *dLevelArgs);
 hipError_t orbxLaunchUnpackFrames(hipStream_t st, const uint8_t *packed, uint8_t *dst, int w, int h, long long pitch, long long frameStride, int nf);
+// `work`: orbxSearchInitWorkBytes(npairs, cap1) bytes for the candidate pre-pass of SearchForInitialization (nullptr: no pre-pass)
+size_t orbxSearchInitWorkBytes(int npairs, int cap1);
 hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1, const uint8_t *d1, long long stride1, const int *n1Dev,
                                      const void *k2, const uint8_t *d2, long long stride2, const int *n2Dev, int cap1, int cap2, float minX,
                                      float maxX, float minY, float maxY, float *prev, int initPrev, int *m12, signed char *binOf, int *nmatches,
-                                     int window, float nnratio, int checkOri);
+                                     int window, float nnratio, int checkOri, void *work);
 
 hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const uint8_t *dc, const float *uRight, const signed char *curState,
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,

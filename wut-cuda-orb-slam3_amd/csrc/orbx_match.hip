@@ -595,6 +595,8 @@ struct SearchInitArgs {
     long long stride1, stride2;
     const int *n1Dev, *n2Dev;
     int initPrev;                  // 1: vbPrevMatched starts as the positions of F1's keypoints (what the initializer passes first)
+    // k_search_init_lds: per F1 keypoint the SI_TOPK smallest candidate keys (k_si_topk), nullptr: none; topUse: entries the walk looks at
+    const uint32_t *top; int topUse;
 };
 
 __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
@@ -723,13 +725,117 @@ __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
     if (lane == 0) *a.nmatches = cntM;
 }
 
+#define SI_CAP2 2048   // octave-0 keypoints of F2 held in LDS (48 B each)
+#define SI_CAND 1024   // staged candidates per F1 keypoint (more are evaluated straight from the cells)
+
+// ---- SearchForInitialization, the part that does not depend on the walk ------------------------------------------------------------
+// What keypoint i1 sees of the earlier ones is only `vMatchedDistance[i2] <= dist` (candidates an earlier keypoint matched at least as
+// well are skipped) - the candidate set itself and every distance are fixed.  So they are computed for all i1 at once, a wave each, and
+// the SI_TOPK candidates with the smallest (distance, visiting order) are handed to the sequential walk, which then, for nearly every
+// keypoint, only looks at those: the first one not skipped is the reference's best, the next one its second best.
+// key = dist << 23 | cell column << 17 | cell row << 11 | index in the octave-0 subset of F2: ascending keys = ascending distance, ties in
+// Frame::GetFeaturesInArea's visiting order (cells column-major, push order = index order inside a cell).
+#define SI_TOPK 8
+#define SI_KEY_NONE 0xFFFFFFFFu
+
+// octave-0 subset of F2 in index order (what k_search_init_lds compacts for itself): orig[c2] = index in F2, n0
+__global__ __launch_bounds__(64) void k_si_subset(const MtKp *k2, int n2, long long stride2, const int *n2Dev, uint16_t *orig, int *n0Out)
+{
+    const size_t p = blockIdx.x;
+    if (n2Dev) n2 = min(n2, n2Dev[p]);
+    k2 += p * stride2; orig += p * (size_t)SI_CAP2;
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int n0 = 0;
+    for (int ib = 0; ib < n2; ib += 64) {
+        const int i = ib + lane;
+        const bool z = i < n2 && k2[i].octave == 0;
+        const unsigned long long m = __ballot(z);
+        const int pos = n0 + __popcll(m & lt);
+        if (z && pos < SI_CAP2) orig[pos] = (uint16_t)i;
+        n0 += __popcll(m);
+    }
+    if (lane == 0) n0Out[p] = n0;
+}
+
+// one wave per keypoint of F1 (blockIdx.x) and pair (blockIdx.y)
+__global__ __launch_bounds__(64) void k_si_topk(SearchInitArgs a, const uint16_t *origAll, const int *n0All, uint32_t *topAll)
+{
+    __shared__ uint32_t keys[SI_CAP2];
+    const int lane = threadIdx.x;
+    const size_t p = blockIdx.y;
+    const int i1 = blockIdx.x;
+    if (a.n1Dev) {
+        a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
+        a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32; a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32;
+        a.prev += p * a.stride1 * 2;
+        topAll += p * (size_t)a.stride1 * SI_TOPK;
+    }
+    if (i1 >= a.n1) return;
+    const int n0 = n0All[p];
+    if (a.k1[i1].octave > 0 || n0 > SI_CAP2) return;  // (the walk never reads these entries)
+    const uint16_t *orig = origAll + p * (size_t)SI_CAP2;
+    uint32_t *top = topAll + (size_t)i1 * SI_TOPK;
+    const float x = a.initPrev ? a.k1[i1].x : a.prev[2 * i1], y = a.initPrev ? a.k1[i1].y : a.prev[2 * i1 + 1];
+    const float r = (float)a.window;
+    // Frame::GetFeaturesInArea(x, y, r, 0, 0): the cell range, and "no candidates" where the reference returns early
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+    const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+    const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+    int cnt = 0;
+    if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int c0 = 0; c0 < n0; c0 += 64) {
+            const int c2 = c0 + lane;
+            bool in = false;
+            uint32_t key = 0;
+            if (c2 < n0) {
+                const int i2 = orig[c2];
+                const float kx = a.k2[i2].x, ky = a.k2[i2].y;
+                const int px = (int)roundf(__fmul_rn(__fsub_rn(kx, a.b.minX), a.b.invW));  // Frame::PosInGrid
+                const int py = (int)roundf(__fmul_rn(__fsub_rn(ky, a.b.minY), a.b.invH));
+                in = px >= cx0 && px <= cx1 && py >= cy0 && py <= cy1 && fabsf(__fsub_rn(kx, x)) < r && fabsf(__fsub_rn(ky, y)) < r;
+                if (in) {
+                    const uint32_t *t = (const uint32_t *)(a.d2 + (size_t)i2 * 32);
+                    int dist = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+                    key = ((uint32_t)dist << 23) | ((uint32_t)px << 17) | ((uint32_t)py << 11) | (uint32_t)c2;
+                }
+            }
+            const unsigned long long m = __ballot(in);
+            if (in) keys[cnt + __popcll(m & lt)] = key;
+            cnt += __popcll(m);
+        }
+    }
+    __syncthreads();
+    uint32_t last = 0;
+    for (int k = 0; k < SI_TOPK; ++k) {  // the k-th smallest key (keys are distinct: the subset index is part of them)
+        uint32_t mn = SI_KEY_NONE;
+        for (int j = lane; j < cnt; j += 64) {
+            const uint32_t v = keys[j];
+            if ((k == 0 || v > last) && v < mn) mn = v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        if (lane == 0) top[k] = mn;
+        last = mn;
+        if (mn == SI_KEY_NONE) {
+            if (lane > k && lane < SI_TOPK) top[lane] = SI_KEY_NONE;
+            break;
+        }
+    }
+}
+
 // The same search with everything the candidate loop touches in LDS.  Only octave-0 keypoints take part (F1: `level1 > 0` is
 // skipped; F2: GetFeaturesInArea(.., level1, level1)), so the kernel compacts both sides to their octave-0 subsets, rebuilds
 // the grid over the F2 subset (same PosInGrid cells, same push order) and keeps positions, angles, descriptors, vMatchedDistance
 // and vnMatches21 of that subset in LDS: a global round trip per dependent step made the generic kernel above take ~21 us per
 // keypoint of F1.  Used when F2 has at most SI_CAP2 octave-0 keypoints and both frames have fewer than 65536 keypoints.
-#define SI_CAP2 2048   // octave-0 keypoints of F2 held in LDS (48 B each)
-#define SI_CAND 1024   // staged candidates per F1 keypoint (more are evaluated straight from the cells)
 
 __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
 {
@@ -756,6 +862,7 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
         a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32; a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32;
         a.prev += p * a.stride1 * 2; a.m12 += p * a.stride1; a.binOf += p * a.stride1; a.nmatches += p;
+        if (a.top) a.top += p * (size_t)a.stride1 * SI_TOPK;
     }
     if (lane < 32) hist[lane] = 0;
     for (int i = lane; i < a.n1; i += 64) { a.m12[i] = -1; a.binOf[i] = -1; }
@@ -833,12 +940,15 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     // registers of the NEXT keypoint are requested while the current one is matched
     float nx = 0.f, ny = 0.f, nang = 0.f;
     uint32_t nq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t ntop = SI_KEY_NONE;  // lane k < topUse: k-th smallest candidate key of the next keypoint
+    const int topUse = a.top ? min(max(a.topUse, 0), SI_TOPK) : 0;
     auto fetch = [&](int t) {
         if (t < nL1) {
             const int i1 = list1[t];
             nx = a.prev[2 * i1]; ny = a.prev[2 * i1 + 1]; nang = a.k1[i1].angle;
 #pragma unroll
             for (int w = 0; w < 8; ++w) nq[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
+            ntop = lane < topUse ? a.top[(size_t)i1 * SI_TOPK + lane] : SI_KEY_NONE;
         }
     };
     fetch(0);
@@ -848,7 +958,49 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         uint32_t q[8];
 #pragma unroll
         for (int w = 0; w < 8; ++w) q[w] = nq[w];
+        const uint32_t tkey = ntop;
         fetch(t + 1);
+        // ---- the short way: the precomputed candidates with the smallest (distance, order) ------------------------------------------
+        // first one not skipped = best, next one = second best; undecided (-> the full scan below) only when fewer than two of an
+        // incomplete list survive and the ratio test could still fail against a candidate beyond the list
+        if (topUse > 0) {
+            const int td = (int)(tkey >> 23), tc = (int)(tkey & (SI_CAP2 - 1));
+            const bool liveK = tkey != SI_KEY_NONE && !((int)mdist[tc] <= td);
+            const unsigned long long mlive = __ballot(liveK);
+            const bool complete = (uint32_t)__shfl((int)tkey, topUse - 1) == SI_KEY_NONE;
+            const int lastD = __shfl(td, topUse - 1);
+            int decided = 0, fBestD = 0, fBestC = 0, fSecond = INT_MAX;  // decided: 1 no match, 2 test (best, second)
+            if (mlive == 0ull) decided = complete ? 1 : 0;
+            else {
+                const int l0 = __ffsll((long long)mlive) - 1;
+                fBestD = __shfl(td, l0); fBestC = __shfl(tc, l0);
+                const unsigned long long m2 = mlive & (mlive - 1ull);
+                if (fBestD > TH_LOW) decided = 1;
+                else if (m2) { fSecond = __shfl(td, __ffsll((long long)m2) - 1); decided = 2; }
+                else if (complete) { fSecond = INT_MAX; decided = 2; }
+                else if (a.nnratio > 0.0f && (float)fBestD < __fmul_rn((float)lastD, a.nnratio)) { fSecond = lastD; decided = 2; }  // every later candidate is at least lastD away
+            }
+            if (decided == 1) continue;
+            if (decided == 2) {
+                if ((float)fBestD < __fmul_rn((float)fSecond, a.nnratio)) {
+                    if (lane == 0) {
+                        const int old = m21[fBestC];
+                        if (old >= 0) a.m12[old] = -1;
+                        a.m12[i1] = orig[fBestC]; m21[fBestC] = i1; mdist[fBestC] = (uint16_t)fBestD;
+                        if (a.checkOri) {
+                            float rot = __fsub_rn(ang1, kang[fBestC]);
+                            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                            int bin = (int)roundf(__fmul_rn(rot, factor));
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            a.binOf[i1] = (signed char)bin;
+                            hist[bin] += 1;
+                        }
+                    }
+                    __syncthreads();
+                }
+                continue;
+            }
+        }
         // Frame::GetFeaturesInArea(x, y, r, 0, 0)
         const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
         if (cx0 >= GRID_COLS) continue;
@@ -988,10 +1140,41 @@ static hipError_t searchInitLdsAttr(size_t lds)
 // SearchForInitialization for `npairs` (F1, F2) pairs, one wave (workgroup) each: F1 = pair p of k1 / d1 / prev / m12 (stride1 records),
 // F2 = pair p of k2 / d2 (stride2 records), counts from the device arrays.  A pair whose F2 has more than SI_CAP2 octave-0 keypoints gets
 // nmatches = -1.
+// Work space of the candidate pre-pass (k_si_subset, k_si_topk) for `npairs` pairs of frames with up to cap1 keypoints in F1, in bytes
+size_t orbxSearchInitWorkBytes(int npairs, int cap1)
+{
+    const size_t P = (size_t)std::max(npairs, 1);
+    return P * ((size_t)SI_CAP2 * 2 + 64) + P * (size_t)cap1 * SI_TOPK * 4 + 256;
+}
+
+// ORBX_SI_TOPK: entries of the precomputed candidate lists the walk looks at (0: none - every keypoint takes the full scan; the tests
+// run 1 and 2 so that the full scan behind an undecided short list is exercised)
+static int searchInitTopUse()
+{
+    static const int v = [] { const char *e = getenv("ORBX_SI_TOPK"); return e ? std::min(std::max(atoi(e), 0), SI_TOPK) : SI_TOPK; }();
+    return v;
+}
+
+// the pre-pass of `npairs` pairs described by `a` into `work`; fills a.top / a.topUse
+static void searchInitPrepass(hipStream_t st, SearchInitArgs &a, int npairs, int cap1, void *work)
+{
+    a.top = nullptr; a.topUse = 0;
+    const int use = searchInitTopUse();
+    if (!work || use <= 0 || cap1 <= 0) return;
+    const size_t P = (size_t)npairs;
+    uint8_t *w = (uint8_t *)work;
+    uint16_t *orig = (uint16_t *)w;
+    int *n0 = (int *)(w + ((P * SI_CAP2 * 2 + 63) & ~(size_t)63));
+    uint32_t *top = (uint32_t *)((uint8_t *)n0 + ((P * 4 + 63) & ~(size_t)63));
+    hipLaunchKernelGGL(k_si_subset, dim3(npairs), dim3(64), 0, st, a.k2, a.n2, a.stride2, a.n2Dev, orig, n0);
+    hipLaunchKernelGGL(k_si_topk, dim3(cap1, npairs), dim3(64), 0, st, a, (const uint16_t *)orig, (const int *)n0, top);
+    a.top = top; a.topUse = use;
+}
+
 hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1, const uint8_t *d1, long long stride1, const int *n1Dev,
                                      const void *k2, const uint8_t *d2, long long stride2, const int *n2Dev, int cap1, int cap2, float minX,
                                      float maxX, float minY, float maxY, float *prev, int initPrev, int *m12, signed char *binOf, int *nmatches,
-                                     int window, float nnratio, int checkOri)
+                                     int window, float nnratio, int checkOri, void *work)
 {
     if (npairs <= 0) return hipSuccess;
     SearchInitArgs a;
@@ -1007,6 +1190,7 @@ hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1,
     if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
     const hipError_t e = searchInitLdsAttr(lds);
     if (e != hipSuccess) return e;
+    searchInitPrepass(st, a, npairs, cap1, work);
     hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), lds, st, a);
     return hipGetLastError();
 }
@@ -1014,10 +1198,11 @@ hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1,
 hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
                                 const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
-                                int checkOri, int level0of2)
+                                int checkOri, int level0of2, void *work)
 {
     SearchInitArgs a;
     a.stride1 = 0; a.stride2 = 0; a.n1Dev = nullptr; a.n2Dev = nullptr; a.initPrev = 0;
+    a.top = nullptr; a.topUse = 0;
     a.k1 = (const MtKp *)k1; a.d1 = d1; a.n1 = n1; a.k2 = (const MtKp *)k2; a.d2 = d2; a.n2 = n2;
     a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY;
@@ -1029,6 +1214,7 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     if (orbxSearchInitInLds(n1, n2, level0of2)) {
         const hipError_t e = searchInitLdsAttr(lds);
         if (e != hipSuccess) return e;
+        searchInitPrepass(st, a, 1, n1, work);
         hipLaunchKernelGGL(k_search_init_lds, dim3(1), dim3(64), lds, st, a);
     } else {
         hipLaunchKernelGGL(k_search_init, dim3(1), dim3(64), 0, st, a);
