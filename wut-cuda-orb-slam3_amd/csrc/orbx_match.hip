@@ -595,8 +595,10 @@ struct SearchInitArgs {
     long long stride1, stride2;
     const int *n1Dev, *n2Dev;
     int initPrev;                  // 1: vbPrevMatched starts as the positions of F1's keypoints (what the initializer passes first)
-    // k_search_init_lds: per F1 keypoint the SI_TOPK smallest candidate keys (k_si_topk), nullptr: none; topUse: entries the walk looks at
-    const uint32_t *top; int topUse;
+    // k_search_init_lds: the pre-pass results (nullptr: none).  top[t][SI_TOPK]: smallest candidate keys of the t-th octave-0 keypoint of
+    // F1 (k_si_topk), topAng[t] its angle, list1G[t] its index, nL1G their number; origG / n0G: the octave-0 subset of F2 (k_si_subset);
+    // all per pair (cap1 = stride of the t-indexed arrays).  topUse: entries of a list the walk looks at.
+    const uint32_t *top; const float *topAng; const uint16_t *list1G, *origG; const int *nL1G, *n0G; int topUse, cap1;
 };
 
 __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
@@ -738,44 +740,63 @@ __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
 #define SI_TOPK 8
 #define SI_KEY_NONE 0xFFFFFFFFu
 
-// octave-0 subset of F2 in index order (what k_search_init_lds compacts for itself): orig[c2] = index in F2, n0
-__global__ __launch_bounds__(64) void k_si_subset(const MtKp *k2, int n2, long long stride2, const int *n2Dev, uint16_t *orig, int *n0Out)
+// octave-0 subsets of both frames in index order, one wave per pair and frame: orig[c2] = index in F2 (n0 of them), list1[t] = index in F1 (nL1)
+__global__ __launch_bounds__(64) void k_si_subset(SearchInitArgs a, uint16_t *orig, int *n0Out, uint16_t *list1, int *nL1Out)
 {
     const size_t p = blockIdx.x;
-    if (n2Dev) n2 = min(n2, n2Dev[p]);
-    k2 += p * stride2; orig += p * (size_t)SI_CAP2;
+    if (a.n1Dev) {
+        a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
+        a.k1 += p * a.stride1; a.k2 += p * a.stride2;
+    }
+    orig += p * (size_t)SI_CAP2; list1 += p * (size_t)a.cap1;
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int n0 = 0;
-    for (int ib = 0; ib < n2; ib += 64) {
-        const int i = ib + lane;
-        const bool z = i < n2 && k2[i].octave == 0;
-        const unsigned long long m = __ballot(z);
-        const int pos = n0 + __popcll(m & lt);
-        if (z && pos < SI_CAP2) orig[pos] = (uint16_t)i;
-        n0 += __popcll(m);
+    int n0 = 0, nL1 = 0;
+    if (blockIdx.y == 0) a.n1 = 0; else a.n2 = 0;  // blockIdx.y: 0 the subset of F2, 1 the list of F1
+    for (int ib = 0; ib < a.n2; ib += 256) {  // four independent loads per step
+        bool z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = ib + 64 * u + lane; z[u] = i < a.n2 && a.k2[min(i, a.n2 - 1)].octave == 0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long m = __ballot(z[u]);
+            const int pos = n0 + __popcll(m & lt);
+            if (z[u] && pos < SI_CAP2) orig[pos] = (uint16_t)(ib + 64 * u + lane);
+            n0 += __popcll(m);
+        }
     }
-    if (lane == 0) n0Out[p] = n0;
+    for (int ib = 0; ib < a.n1; ib += 256) {
+        bool z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = ib + 64 * u + lane; z[u] = i < a.n1 && !(a.k1[min(i, a.n1 - 1)].octave > 0); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long m = __ballot(z[u]);
+            if (z[u]) list1[nL1 + __popcll(m & lt)] = (uint16_t)(ib + 64 * u + lane);
+            nL1 += __popcll(m);
+        }
+    }
+    if (lane == 0) { if (blockIdx.y == 0) n0Out[p] = n0; else nL1Out[p] = nL1; }
 }
 
-// one wave per keypoint of F1 (blockIdx.x) and pair (blockIdx.y)
-__global__ __launch_bounds__(64) void k_si_topk(SearchInitArgs a, const uint16_t *origAll, const int *n0All, uint32_t *topAll)
+// one wave per octave-0 keypoint of F1 (blockIdx.x = its position t in list1) and pair (blockIdx.y)
+__global__ __launch_bounds__(64) void k_si_topk(SearchInitArgs a, uint32_t *topAll, float *angAll)
 {
     __shared__ uint32_t keys[SI_CAP2];
     const int lane = threadIdx.x;
     const size_t p = blockIdx.y;
-    const int i1 = blockIdx.x;
+    const int t = blockIdx.x;
+    if (t >= a.nL1G[p]) return;
+    const int n0 = a.n0G[p];
+    if (n0 > SI_CAP2) return;  // (the walk reports the capacity error and never reads the lists)
     if (a.n1Dev) {
-        a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
         a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32; a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32;
         a.prev += p * a.stride1 * 2;
-        topAll += p * (size_t)a.stride1 * SI_TOPK;
     }
-    if (i1 >= a.n1) return;
-    const int n0 = n0All[p];
-    if (a.k1[i1].octave > 0 || n0 > SI_CAP2) return;  // (the walk never reads these entries)
-    const uint16_t *orig = origAll + p * (size_t)SI_CAP2;
-    uint32_t *top = topAll + (size_t)i1 * SI_TOPK;
+    const uint16_t *orig = a.origG + p * (size_t)SI_CAP2;
+    const int i1 = a.list1G[p * (size_t)a.cap1 + t];
+    uint32_t *top = topAll + (p * (size_t)a.cap1 + t) * SI_TOPK;
+    if (lane == 0) angAll[p * (size_t)a.cap1 + t] = a.k1[i1].angle;
     const float x = a.initPrev ? a.k1[i1].x : a.prev[2 * i1], y = a.initPrev ? a.k1[i1].y : a.prev[2 * i1 + 1];
     const float r = (float)a.window;
     // Frame::GetFeaturesInArea(x, y, r, 0, 0): the cell range, and "no candidates" where the reference returns early
@@ -800,10 +821,10 @@ __global__ __launch_bounds__(64) void k_si_topk(SearchInitArgs a, const uint16_t
                 const int py = (int)roundf(__fmul_rn(__fsub_rn(ky, a.b.minY), a.b.invH));
                 in = px >= cx0 && px <= cx1 && py >= cy0 && py <= cy1 && fabsf(__fsub_rn(kx, x)) < r && fabsf(__fsub_rn(ky, y)) < r;
                 if (in) {
-                    const uint32_t *t = (const uint32_t *)(a.d2 + (size_t)i2 * 32);
+                    const uint32_t *tt = (const uint32_t *)(a.d2 + (size_t)i2 * 32);
                     int dist = 0;
 #pragma unroll
-                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ tt[w]);
                     key = ((uint32_t)dist << 23) | ((uint32_t)px << 17) | ((uint32_t)py << 11) | (uint32_t)c2;
                 }
             }
@@ -852,7 +873,9 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     uint16_t *cellOf = items0 + SI_CAP2;                    // [SI_CAP2] (setup only)
     uint16_t *cs0 = cellOf + SI_CAP2;                       // [GRID_CELLS + 2] cell starts of the subset grid
     uint16_t *cand = cs0 + GRID_CELLS + 2;                  // [SI_CAND]
-    uint16_t *list1 = cand + SI_CAND;                       // [n1 rounded] octave-0 keypoints of F1 in index order
+    uint16_t *list1 = cand + SI_CAND;                       // [n1 + 64] octave-0 keypoints of F1 in index order (position t)
+    uint16_t *m12L = list1 + (a.n1 + 64);                   // [n1 + 64] vnMatches12 by position t: subset index of the partner, 0xFFFF none
+    signed char *binL = (signed char *)(m12L + (a.n1 + 64)); // [n1 + 64] rotation-histogram bin of the match recorded for t, -1 none
     int *cnt = (int *)desc;                                 // [GRID_CELLS] setup only: aliases the descriptors (loaded last)
     __shared__ int hist[32];
     const int lane = threadIdx.x;
@@ -862,44 +885,75 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
         a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32; a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32;
         a.prev += p * a.stride1 * 2; a.m12 += p * a.stride1; a.binOf += p * a.stride1; a.nmatches += p;
-        if (a.top) a.top += p * (size_t)a.stride1 * SI_TOPK;
+        if (a.top) {
+            a.top += p * (size_t)a.cap1 * SI_TOPK; a.topAng += p * (size_t)a.cap1; a.list1G += p * (size_t)a.cap1;
+            a.origG += p * (size_t)SI_CAP2; a.nL1G += p; a.n0G += p;
+        }
     }
     if (lane < 32) hist[lane] = 0;
-    for (int i = lane; i < a.n1; i += 64) { a.m12[i] = -1; a.binOf[i] = -1; }
+    for (int i = lane; i < a.n1; i += 64) a.m12[i] = -1;
+    // (one wave walks these arrays: eight independent loads per step, or every step costs a memory latency)
     if (a.initPrev)
-        for (int i = lane; i < a.n1; i += 64) { a.prev[2 * i] = a.k1[i].x; a.prev[2 * i + 1] = a.k1[i].y; }
+        for (int i0 = 0; i0 < a.n1; i0 += 512) {
+            float vx[8], vy[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = min(i0 + 64 * u + lane, a.n1 - 1); vx[u] = a.k1[i].x; vy[u] = a.k1[i].y; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u + lane; if (i < a.n1) { a.prev[2 * i] = vx[u]; a.prev[2 * i + 1] = vy[u]; } }
+        }
     // ---- octave-0 subsets ------------------------------------------------------------------------------------
     int n0 = 0, nL1 = 0;
-    for (int ib = 0; ib < a.n2; ib += 64) {
-        const int i = ib + lane;
-        const bool z = i < a.n2 && a.k2[i].octave == 0;
-        const unsigned long long m = __ballot(z);
-        const int pos = n0 + __popcll(m & lt);
-        if (z && pos < SI_CAP2) orig[pos] = (uint16_t)i;
-        n0 += __popcll(m);
+    if (a.top) {  // the pre-pass compacted both frames already (k_si_subset): copy
+        n0 = a.n0G[0]; nL1 = a.nL1G[0];
+        for (int c = lane; c < min(n0, SI_CAP2); c += 64) orig[c] = a.origG[c];
+        for (int t = lane; t < nL1; t += 64) list1[t] = a.list1G[t];
+    } else {
+        for (int ib = 0; ib < a.n2; ib += 64) {
+            const int i = ib + lane;
+            const bool z = i < a.n2 && a.k2[i].octave == 0;
+            const unsigned long long m = __ballot(z);
+            const int pos = n0 + __popcll(m & lt);
+            if (z && pos < SI_CAP2) orig[pos] = (uint16_t)i;
+            n0 += __popcll(m);
+        }
     }
     if (n0 > SI_CAP2) {  // (a single call never gets here: the host counted; a pair of a batch reports the capacity error)
         if (lane == 0) *a.nmatches = -1;
         return;
     }
     __threadfence_block();
-    for (int ib = 0; ib < a.n1; ib += 64) {
-        const int i = ib + lane;
-        const bool z = i < a.n1 && !(a.k1[i].octave > 0);
-        const unsigned long long m = __ballot(z);
-        if (z) list1[nL1 + __popcll(m & lt)] = (uint16_t)i;
-        nL1 += __popcll(m);
+    if (!a.top) {
+        for (int ib = 0; ib < a.n1; ib += 64) {
+            const int i = ib + lane;
+            const bool z = i < a.n1 && !(a.k1[i].octave > 0);
+            const unsigned long long m = __ballot(z);
+            if (z) list1[nL1 + __popcll(m & lt)] = (uint16_t)i;
+            nL1 += __popcll(m);
+        }
     }
-    for (int c = lane; c < GRID_CELLS; c += 64) cnt[c] = 0;
+    for (int t = lane; t < nL1; t += 64) { m12L[t] = 0xFFFF; binL[t] = -1; }
+    int *occ = cnt + GRID_CELLS;                            // [GRID_CELLS] setup only: keypoints of the current 64 per cell
+    for (int c = lane; c < 2 * GRID_CELLS; c += 64) cnt[c] = 0;
     __syncthreads();
-    for (int c = lane; c < n0; c += 64) {  // Frame::PosInGrid of the subset
-        const MtKp kp = a.k2[orig[c]];
-        kx[c] = kp.x; ky[c] = kp.y; kang[c] = kp.angle; m21[c] = -1; mdist[c] = 0xFFFF;
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, a.b.minX), a.b.invW));
-        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, a.b.minY), a.b.invH));
-        const int cl = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? 0xFFFF : px * GRID_ROWS + py;
-        cellOf[c] = (uint16_t)cl;
-        if (cl != 0xFFFF) atomicAdd(&cnt[cl], 1);
+    for (int cb = 0; cb < n0; cb += 256) {  // Frame::PosInGrid of the subset
+        float px_[4], py_[4], pa_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const MtKp *kp = a.k2 + orig[min(cb + 64 * u + lane, n0 - 1)];
+            px_[u] = kp->x; py_[u] = kp->y; pa_[u] = kp->angle;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = cb + 64 * u + lane;
+            if (c < n0) {
+                kx[c] = px_[u]; ky[c] = py_[u]; kang[c] = pa_[u]; m21[c] = -1; mdist[c] = 0xFFFF;
+                const int px = (int)roundf(__fmul_rn(__fsub_rn(px_[u], a.b.minX), a.b.invW));
+                const int py = (int)roundf(__fmul_rn(__fsub_rn(py_[u], a.b.minY), a.b.invH));
+                const int cl = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? 0xFFFF : px * GRID_ROWS + py;
+                cellOf[c] = (uint16_t)cl;
+                if (cl != 0xFFFF) atomicAdd(&cnt[cl], 1);
+            }
+        }
     }
     __syncthreads();
     {
@@ -918,7 +972,14 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     for (int ib = 0; ib < n0; ib += 64) {  // stable placement, 64 keypoints per step in index order
         const int c = ib + lane;
         const int cl = c < n0 ? (int)cellOf[c] : 0xFFFF;
-        unsigned long long todo = __ballot(cl != 0xFFFF);
+        // keypoints that are alone in their cell among these 64 (nearly all of them) go straight to the cell's cursor
+        if (cl != 0xFFFF) atomicAdd(&occ[cl], 1);
+        __syncthreads();
+        const bool alone = cl != 0xFFFF && occ[cl] == 1;
+        if (alone) { items0[cnt[cl]] = (uint16_t)c; cnt[cl] += 1; }
+        __syncthreads();
+        if (cl != 0xFFFF) occ[cl] = 0;
+        unsigned long long todo = __ballot(cl != 0xFFFF && !alone);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int cll = __shfl(cl, leader);
@@ -931,85 +992,58 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         }
     }
     __syncthreads();
-    for (int i = lane; i < n0 * 8; i += 64) desc[i] = ((const uint32_t *)(a.d2 + (size_t)orig[i >> 3] * 32))[i & 7];  // (over cnt[])
+    for (int i0 = 0; i0 < n0 * 2; i0 += 512) {  // descriptors, 16 bytes per lane and load, eight loads in flight (over cnt[])
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + 64 * u + lane, n0 * 2 - 1);
+            v[u] = ((const uint4 *)(a.d2 + (size_t)orig[i >> 1] * 32))[i & 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)  // (keeps the compiler from sinking each load into the predicated block of its LDS write)
+            asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u + lane;
+            if (i < n0 * 2) ((uint4 *)desc)[i] = v[u];
+        }
+    }
     __syncthreads();
 
     // ---- the sequential walk over the octave-0 keypoints of F1 ---------------------------------------------------
     const float factor = 1.0f / HISTO_LENGTH;
     const float r = (float)a.window;
-    // registers of the NEXT keypoint are requested while the current one is matched
-    float nx = 0.f, ny = 0.f, nang = 0.f;
-    uint32_t nq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t ntop = SI_KEY_NONE;  // lane k < topUse: k-th smallest candidate key of the next keypoint
-    const int topUse = a.top ? min(max(a.topUse, 0), SI_TOPK) : 0;
-    auto fetch = [&](int t) {
-        if (t < nL1) {
-            const int i1 = list1[t];
-            nx = a.prev[2 * i1]; ny = a.prev[2 * i1 + 1]; nang = a.k1[i1].angle;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) nq[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
-            ntop = lane < topUse ? a.top[(size_t)i1 * SI_TOPK + lane] : SI_KEY_NONE;
+    // an accepted match: vnMatches21's previous owner loses it (:725-729), the rotation histogram gets its vote (:736-746)
+    // Everything the walk writes stays in LDS (matches by position t, written out behind the walk): a global store per accepted match
+    // would have to be acknowledged before the next block's prefetch can be waited for.
+    auto accept = [&](int t, int bD, int bC, float ang1) {
+        if (lane == 0) {
+            const int old = m21[bC];
+            const float ang2 = kang[bC];  // (both reads in one LDS round trip; the histogram itself is counted behind the walk)
+            if (old >= 0) m12L[old] = 0xFFFF;
+            m12L[t] = (uint16_t)bC; m21[bC] = t; mdist[bC] = (uint16_t)bD;
+            if (a.checkOri) {
+                float rot = __fsub_rn(ang1, ang2);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, factor));
+                if (bin == HISTO_LENGTH) bin = 0;
+                binL[t] = (signed char)bin;
+            }
         }
+        // One wave: its LDS accesses execute in order, so the next step sees lane 0's writes without a barrier
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
-    fetch(0);
-    for (int t = 0; t < nL1; ++t) {
-        const int i1 = list1[t];
-        const float x = nx, y = ny, ang1 = nang;
-        uint32_t q[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) q[w] = nq[w];
-        const uint32_t tkey = ntop;
-        fetch(t + 1);
-        // ---- the short way: the precomputed candidates with the smallest (distance, order) ------------------------------------------
-        // first one not skipped = best, next one = second best; undecided (-> the full scan below) only when fewer than two of an
-        // incomplete list survive and the ratio test could still fail against a candidate beyond the list
-        if (topUse > 0) {
-            const int td = (int)(tkey >> 23), tc = (int)(tkey & (SI_CAP2 - 1));
-            const bool liveK = tkey != SI_KEY_NONE && !((int)mdist[tc] <= td);
-            const unsigned long long mlive = __ballot(liveK);
-            const bool complete = (uint32_t)__shfl((int)tkey, topUse - 1) == SI_KEY_NONE;
-            const int lastD = __shfl(td, topUse - 1);
-            int decided = 0, fBestD = 0, fBestC = 0, fSecond = INT_MAX;  // decided: 1 no match, 2 test (best, second)
-            if (mlive == 0ull) decided = complete ? 1 : 0;
-            else {
-                const int l0 = __ffsll((long long)mlive) - 1;
-                fBestD = __shfl(td, l0); fBestC = __shfl(tc, l0);
-                const unsigned long long m2 = mlive & (mlive - 1ull);
-                if (fBestD > TH_LOW) decided = 1;
-                else if (m2) { fSecond = __shfl(td, __ffsll((long long)m2) - 1); decided = 2; }
-                else if (complete) { fSecond = INT_MAX; decided = 2; }
-                else if (a.nnratio > 0.0f && (float)fBestD < __fmul_rn((float)lastD, a.nnratio)) { fSecond = lastD; decided = 2; }  // every later candidate is at least lastD away
-            }
-            if (decided == 1) continue;
-            if (decided == 2) {
-                if ((float)fBestD < __fmul_rn((float)fSecond, a.nnratio)) {
-                    if (lane == 0) {
-                        const int old = m21[fBestC];
-                        if (old >= 0) a.m12[old] = -1;
-                        a.m12[i1] = orig[fBestC]; m21[fBestC] = i1; mdist[fBestC] = (uint16_t)fBestD;
-                        if (a.checkOri) {
-                            float rot = __fsub_rn(ang1, kang[fBestC]);
-                            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                            int bin = (int)roundf(__fmul_rn(rot, factor));
-                            if (bin == HISTO_LENGTH) bin = 0;
-                            a.binOf[i1] = (signed char)bin;
-                            hist[bin] += 1;
-                        }
-                    }
-                    __syncthreads();
-                }
-                continue;
-            }
-        }
-        // Frame::GetFeaturesInArea(x, y, r, 0, 0)
+    // every candidate of one keypoint, in Frame::GetFeaturesInArea(x, y, r, 0, 0)'s order
+    auto fullScan = [&](int t, float x, float y, const uint32_t (&q)[8], float ang1) {
         const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
-        if (cx0 >= GRID_COLS) continue;
+        if (cx0 >= GRID_COLS) return;
         const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
-        if (cx1 < 0) continue;
+        if (cx1 < 0) return;
         const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
-        if (cy0 >= GRID_ROWS) continue;
+        if (cy0 >= GRID_ROWS) return;
         const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
-        if (cy1 < 0) continue;
+        if (cy1 < 0) return;
         const int ny_ = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny_;
         int bestD = INT_MAX, best2 = INT_MAX, bestC = -1, bestOrd = INT_MAX;
         auto consider = [&](int c2, int ord) {
@@ -1047,32 +1081,109 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         unsigned kmin = key;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
-        if (kmin == 0xFFFFFFFFu) continue;
+        if (kmin == 0xFFFFFFFFu) return;
         const int wl = __ffsll((long long)__ballot(key == kmin)) - 1;
         const int gBestD = __shfl(bestD, wl), gBestC = __shfl(bestC, wl);
         int second = lane == wl ? best2 : bestD;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
-        if (gBestD <= TH_LOW && (float)gBestD < __fmul_rn((float)second, a.nnratio)) {
-            if (lane == 0) {
-                const int old = m21[gBestC];
-                if (old >= 0) a.m12[old] = -1;
-                a.m12[i1] = orig[gBestC]; m21[gBestC] = i1; mdist[gBestC] = (uint16_t)gBestD;
-                if (a.checkOri) {
-                    float rot = __fsub_rn(ang1, kang[gBestC]);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    int bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == HISTO_LENGTH) bin = 0;
-                    a.binOf[i1] = (signed char)bin;
-                    hist[bin] += 1;
+        if (gBestD <= TH_LOW && (float)gBestD < __fmul_rn((float)second, a.nnratio)) accept(t, gBestD, gBestC, ang1);
+    };
+    const int topUse = a.top ? min(max(a.topUse, 0), SI_TOPK) : 0;
+    if (topUse > 0) {
+        // The short way: eight keypoints per block, lane 8 s + k holds the k-th smallest candidate key of the s-th of them (one coalesced
+        // load per block, requested a block ahead - a load per step would put a memory latency into every step of the walk).  The
+        // first candidate not skipped is the reference's best, the next one its second best; undecided (-> the full scan) only when
+        // fewer than two of an incomplete list survive and the ratio test could still fail against a candidate beyond the list.
+        const int sub = lane & 7, grp = lane >> 3;
+        // four blocks are in flight: a block of eight steps is shorter than the latency of its load
+        uint32_t rk[4];
+        float ra[4];
+        auto fetchBlock = [&](int tb, uint32_t &keys, float &angs) {
+            const int t = tb + grp;
+            keys = (t < nL1 && sub < topUse) ? a.top[(size_t)t * SI_TOPK + sub] : SI_KEY_NONE;
+            angs = t < nL1 ? a.topAng[t] : 0.f;
+        };
+        // (lane indices below are wave-uniform: v_readlane, not a ds_bpermute round trip per value)
+        auto rl = [&](int v, int idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx)); };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetchBlock(8 * j, rk[j], ra[j]);
+        for (int tb0 = 0; tb0 < nL1; tb0 += 32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int tb = tb0 + 8 * j;
+            if (tb >= nL1) break;
+            const uint32_t bkeys = rk[j];
+            const float bangs = ra[j];
+            fetchBlock(tb + 32, rk[j], ra[j]);
+            const int td = (int)(bkeys >> 23), tc = (int)(bkeys & (SI_CAP2 - 1));
+            // vMatchedDistance of the block's 64 candidates in one LDS read; what the block's own matches change is patched in registers
+            int md = (int)mdist[tc];
+            for (int sI = 0; sI < 8 && tb + sI < nL1; ++sI) {
+                const bool liveK = grp == sI && bkeys != SI_KEY_NONE && !(md <= td);
+                const unsigned mlive = (unsigned)((__ballot(liveK) >> (8 * sI)) & 0xFFull);
+                const int lastLane = 8 * sI + topUse - 1;
+                const bool complete = (uint32_t)rl((int)bkeys, lastLane) == SI_KEY_NONE;
+                const int lastD = rl(td, lastLane);
+                int decided = 0, fBestD = 0, fBestC = 0, fSecond = INT_MAX;  // decided: 1 no match, 2 test (best, second)
+                if (mlive == 0u) decided = complete ? 1 : 0;
+                else {
+                    const int l0 = 8 * sI + __ffs((int)mlive) - 1;
+                    fBestD = rl(td, l0); fBestC = rl(tc, l0);
+                    const unsigned m2 = mlive & (mlive - 1u);
+                    if (fBestD > TH_LOW) decided = 1;
+                    else if (m2) { fSecond = rl(td, 8 * sI + __ffs((int)m2) - 1); decided = 2; }
+                    else if (complete) { fSecond = INT_MAX; decided = 2; }
+                    else if (a.nnratio > 0.0f && (float)fBestD < __fmul_rn((float)lastD, a.nnratio)) { fSecond = lastD; decided = 2; }  // every later candidate is at least lastD away
+                }
+                const float ang1 = __int_as_float(rl(__float_as_int(bangs), 8 * sI));
+                if (decided == 2) {
+                    if ((float)fBestD < __fmul_rn((float)fSecond, a.nnratio)) {
+                        accept(tb + sI, fBestD, fBestC, ang1);
+                        if (tc == fBestC) md = fBestD;
+                    }
+                } else if (decided == 0) {
+                    const int i1 = list1[tb + sI];
+                    uint32_t q[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
+                    fullScan(tb + sI, a.prev[2 * i1], a.prev[2 * i1 + 1], q, ang1);
+                    md = (int)mdist[tc];
                 }
             }
-            __syncthreads();
+          }
+        }
+    } else {
+        // registers of the NEXT keypoint are requested while the current one is matched
+        float nx = 0.f, ny = 0.f, nang = 0.f;
+        uint32_t nq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto fetch = [&](int t) {
+            if (t < nL1) {
+                const int i1 = list1[t];
+                nx = a.prev[2 * i1]; ny = a.prev[2 * i1 + 1]; nang = a.k1[i1].angle;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) nq[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
+            }
+        };
+        fetch(0);
+        for (int t = 0; t < nL1; ++t) {
+            const float x = nx, y = ny, ang1 = nang;
+            uint32_t q[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) q[w] = nq[w];
+            fetch(t + 1);
+            fullScan(t, x, y, q, ang1);
         }
     }
     __threadfence_block();
     __syncthreads();
     if (a.checkOri) {
+        // rotHist sizes (:742-746): every match that was recorded votes, also one that was stolen later
+        for (int t = lane; t < nL1; t += 64) {
+            const int b = binL[t];
+            if (b >= 0) atomicAdd(&hist[b], 1);
+        }
+        __syncthreads();
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima (every lane, uniform)
             const int s = hist[i];
@@ -1082,20 +1193,24 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         }
         if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-        for (int i = lane; i < a.n1; i += 64) {
-            const int b = a.binOf[i];
-            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && a.m12[i] >= 0) a.m12[i] = -1;
+        for (int t = lane; t < nL1; t += 64) {
+            const int b = binL[t];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3) m12L[t] = 0xFFFF;
         }
-        __threadfence_block();
         __syncthreads();
     }
+    // write-out: vnMatches12 (already -1 everywhere), the updated vbPrevMatched (:759-762) - stores only, the partner's position is in LDS
     int cntM = 0;
-    for (int i = lane; i < a.n1; i += 64) {
-        const int m = a.m12[i];
-        if (m >= 0) { a.prev[2 * i] = a.k2[m].x; a.prev[2 * i + 1] = a.k2[m].y; ++cntM; }
+    for (int t = lane; t < nL1; t += 64) {
+        const int c2 = m12L[t];
+        if (c2 != 0xFFFF) {
+            const int i1 = list1[t];
+            a.m12[i1] = orig[c2]; a.prev[2 * i1] = kx[c2]; a.prev[2 * i1 + 1] = ky[c2]; ++cntM;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cntM += __shfl_xor(cntM, o);
+    // nmatches as the reference counts it (++ per accepted match, -- per stolen or rotation-filtered one) = entries still >= 0
     if (lane == 0) *a.nmatches = cntM;
 }
 
@@ -1104,7 +1219,7 @@ bool orbxSearchInitInLds(int n1, int n2, int level0of2);
 
 static size_t searchInitLdsBytes(int n1)
 {
-    return (size_t)SI_CAP2 * (32 + 4 * 4 + 2 * 4) + (GRID_CELLS + 2) * 2 + SI_CAND * 2 + ((size_t)n1 + 64) * 2;
+    return (size_t)SI_CAP2 * (32 + 4 * 4 + 2 * 4) + (GRID_CELLS + 2) * 2 + SI_CAND * 2 + ((size_t)n1 + 64) * 5;
 }
 
 hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX, float maxX, float minY, float maxY, int *cellStart,
@@ -1141,10 +1256,11 @@ static hipError_t searchInitLdsAttr(size_t lds)
 // F2 = pair p of k2 / d2 (stride2 records), counts from the device arrays.  A pair whose F2 has more than SI_CAP2 octave-0 keypoints gets
 // nmatches = -1.
 // Work space of the candidate pre-pass (k_si_subset, k_si_topk) for `npairs` pairs of frames with up to cap1 keypoints in F1, in bytes
+static size_t siAlign(size_t b) { return (b + 255) & ~(size_t)255; }
 size_t orbxSearchInitWorkBytes(int npairs, int cap1)
 {
-    const size_t P = (size_t)std::max(npairs, 1);
-    return P * ((size_t)SI_CAP2 * 2 + 64) + P * (size_t)cap1 * SI_TOPK * 4 + 256;
+    const size_t P = (size_t)std::max(npairs, 1), C = (size_t)std::max(cap1, 1);
+    return siAlign(P * SI_CAP2 * 2) + siAlign(P * C * 2) + 2 * siAlign(P * 4) + siAlign(P * C * SI_TOPK * 4) + siAlign(P * C * 4);
 }
 
 // ORBX_SI_TOPK: entries of the precomputed candidate lists the walk looks at (0: none - every keypoint takes the full scan; the tests
@@ -1155,20 +1271,24 @@ static int searchInitTopUse()
     return v;
 }
 
-// the pre-pass of `npairs` pairs described by `a` into `work`; fills a.top / a.topUse
+// the pre-pass of `npairs` pairs described by `a` into `work`; fills the pre-pass fields of `a`
 static void searchInitPrepass(hipStream_t st, SearchInitArgs &a, int npairs, int cap1, void *work)
 {
-    a.top = nullptr; a.topUse = 0;
+    a.top = nullptr; a.topAng = nullptr; a.list1G = nullptr; a.origG = nullptr; a.nL1G = nullptr; a.n0G = nullptr; a.topUse = 0; a.cap1 = cap1;
     const int use = searchInitTopUse();
     if (!work || use <= 0 || cap1 <= 0) return;
-    const size_t P = (size_t)npairs;
+    const size_t P = (size_t)npairs, C = (size_t)cap1;
     uint8_t *w = (uint8_t *)work;
-    uint16_t *orig = (uint16_t *)w;
-    int *n0 = (int *)(w + ((P * SI_CAP2 * 2 + 63) & ~(size_t)63));
-    uint32_t *top = (uint32_t *)((uint8_t *)n0 + ((P * 4 + 63) & ~(size_t)63));
-    hipLaunchKernelGGL(k_si_subset, dim3(npairs), dim3(64), 0, st, a.k2, a.n2, a.stride2, a.n2Dev, orig, n0);
-    hipLaunchKernelGGL(k_si_topk, dim3(cap1, npairs), dim3(64), 0, st, a, (const uint16_t *)orig, (const int *)n0, top);
-    a.top = top; a.topUse = use;
+    uint16_t *orig = (uint16_t *)w; w += siAlign(P * SI_CAP2 * 2);
+    uint16_t *list1 = (uint16_t *)w; w += siAlign(P * C * 2);
+    int *n0 = (int *)w; w += siAlign(P * 4);
+    int *nL1 = (int *)w; w += siAlign(P * 4);
+    uint32_t *top = (uint32_t *)w; w += siAlign(P * C * SI_TOPK * 4);
+    float *ang = (float *)w;
+    hipLaunchKernelGGL(k_si_subset, dim3(npairs, 2), dim3(64), 0, st, a, orig, n0, list1, nL1);
+    a.list1G = list1; a.origG = orig; a.nL1G = nL1; a.n0G = n0;
+    hipLaunchKernelGGL(k_si_topk, dim3(cap1, npairs), dim3(64), 0, st, a, top, ang);
+    a.top = top; a.topAng = ang; a.topUse = use;
 }
 
 hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1, const uint8_t *d1, long long stride1, const int *n1Dev,
@@ -1202,7 +1322,7 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
 {
     SearchInitArgs a;
     a.stride1 = 0; a.stride2 = 0; a.n1Dev = nullptr; a.n2Dev = nullptr; a.initPrev = 0;
-    a.top = nullptr; a.topUse = 0;
+    a.top = nullptr; a.topAng = nullptr; a.list1G = nullptr; a.origG = nullptr; a.nL1G = nullptr; a.n0G = nullptr; a.topUse = 0; a.cap1 = n1;
     a.k1 = (const MtKp *)k1; a.d1 = d1; a.n1 = n1; a.k2 = (const MtKp *)k2; a.d2 = d2; a.n2 = n2;
     a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY;
