@@ -517,15 +517,18 @@ hipError_t orbxLaunchStereoRefine(hipStream_t st, const void *levels, const void
 
 struct GridBounds { float minX, minY, invW, invH; };
 
-__device__ __forceinline__ int mt_excl_scan(int v, int &total)  // all 64 lanes active
+// exclusive prefix sum over the wave (all 64 lanes active): Kogge-Stone inside the rows of 16 lanes with DPP row shifts, then the row
+// totals with the two row broadcasts - six VALU operations instead of six ds_bpermute round trips
+__device__ __forceinline__ int mt_excl_scan(int v, int &total)
 {
     int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o);
-        if ((int)(threadIdx.x & 63) >= o) x += y;
-    }
-    total = __shfl(x, 63);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 
@@ -541,15 +544,25 @@ __global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBou
         if (nDev) n = min(n, nDev[p]);
     }
     __shared__ int cnt[GRID_CELLS];
+    __shared__ int occ[GRID_CELLS];  // keypoints of the current 64 per cell
     const int lane = threadIdx.x;
-    for (int c = lane; c < GRID_CELLS; c += 64) cnt[c] = 0;
+    for (int c = lane; c < GRID_CELLS; c += 64) { cnt[c] = 0; occ[c] = 0; }
     __syncthreads();
-    for (int i = lane; i < n; i += 64) {
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(k[i].x, b.minX), b.invW));
-        const int py = (int)roundf(__fmul_rn(__fsub_rn(k[i].y, b.minY), b.invH));
-        const int c = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
-        cellOf[i] = c;
-        if (c >= 0) atomicAdd(&cnt[c], 1);
+    for (int i0 = 0; i0 < n; i0 += 256) {  // (one wave: four independent loads per step instead of a memory latency per 64 keypoints)
+        float vx[4], vy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = min(i0 + 64 * u + lane, n - 1); vx[u] = k[i].x; vy[u] = k[i].y; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane;
+            if (i < n) {
+                const int px = (int)roundf(__fmul_rn(__fsub_rn(vx[u], b.minX), b.invW));
+                const int py = (int)roundf(__fmul_rn(__fsub_rn(vy[u], b.minY), b.invH));
+                const int c = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+                cellOf[i] = c;
+                if (c >= 0) atomicAdd(&cnt[c], 1);
+            }
+        }
     }
     __syncthreads();
     int base = 0;
@@ -563,11 +576,18 @@ __global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBou
     }
     if (lane == 0) cellStart[GRID_CELLS] = base;
     __syncthreads();
-    // stable placement: 64 keypoints per step in index order; lanes that share a cell are ranked by lane
+    // stable placement: 64 keypoints per step in index order.  A keypoint that is alone in its cell among these 64 (nearly all of them)
+    // goes straight to the cell's cursor; lanes that share a cell are ranked by lane, one cell per round.
     for (int ib = 0; ib < n; ib += 64) {
         const int i = ib + lane;
         const int c = i < n ? cellOf[i] : -1;
-        unsigned long long todo = __ballot(c >= 0);
+        if (c >= 0) atomicAdd(&occ[c], 1);
+        __syncthreads();
+        const bool alone = c >= 0 && occ[c] == 1;
+        if (alone) { items[cnt[c]] = i; cnt[c] += 1; }
+        __syncthreads();
+        if (c >= 0) occ[c] = 0;
+        unsigned long long todo = __ballot(c >= 0 && !alone);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int cl = __shfl(c, leader);
