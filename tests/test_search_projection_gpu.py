@@ -213,3 +213,18 @@ def test_search_by_projection_points_frames_batch(pkg, orc):
         assert nm[p] == rn and np.array_equal(assign[p, : nc[p]], rassign), p
         assert rn > 30
     m.close(); ex.close()
+
+
+def test_global_resolve_kernel_in_subprocess(pkg):
+    """k_sbp_resolve keeps the owner arrays of frames up to 12288 keypoints in LDS and works on global memory beyond;
+    ORBX_SBP_RESOLVE_GLOBAL (read once per process) forces the global variant: run this file's parity tests once more under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ORBX_SBP_RESOLVE_GLOBAL"):
+        pytest.skip("already the forced run")
+    env = dict(os.environ, ORBX_SBP_RESOLVE_GLOBAL="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not subprocess"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]

@@ -1513,13 +1513,22 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     if (lane == 0) *cnt = nOut;
 }
 
-__global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
+// LDS: the owner arrays and the "holds a map point with observations" flags of the current frame's keypoints live in LDS (ldsNc entries
+// each; frames of up to SBP_LDS_NC keypoints) - a thread walks its candidate list with two dependent reads per entry, and from global
+// memory that was 95 us of a 156 us tracking step
+#define SBP_LDS_NC 12288
+template <bool LDS>
+__global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc)
 {
     const int TH_HIGH = 100, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
+    extern __shared__ int sbpL[];
     sbp_select_frame(a, blockIdx.x);
     const int tid = threadIdx.x;
     __shared__ int changed, hist[32], nAcc;
-    int *own = a.owner, *ownNew = a.owner + a.nc;
+    int *own = LDS ? sbpL : a.owner, *ownNew = LDS ? sbpL + ldsNc : a.owner + a.nc;
+    signed char *heldL = (signed char *)(sbpL + 2 * ldsNc);
+    if (LDS)
+        for (int i = tid; i < a.nc; i += 1024) heldL[i] = a.curState ? (a.curState[i] > 0 ? 1 : 0) : 0;
     for (int i = tid; i < a.nc; i += 1024) { own[i] = INT_MAX; a.assign[i] = -1; }
     if (tid < 32) hist[tid] = 0;
     if (tid == 0) nAcc = 0;
@@ -1535,7 +1544,8 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a)
             for (int c = 0; c < n; ++c) {
                 const uint32_t e = lst[c];
                 const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
-                if ((a.curState && a.curState[i2] > 0) || own[i2] < i) continue;  // mvpMapPoints[i2]->Observations() > 0: before the call / taken earlier
+                const bool held = LDS ? heldL[i2] != 0 : (a.curState && a.curState[i2] > 0);
+                if (held || own[i2] < i) continue;  // mvpMapPoints[i2]->Observations() > 0: before the call / taken earlier
                 if (dist < best) { best2 = best; bestL2 = bestL; best = dist; bestL = lv; bestI = i2; }
                 else if (dist < best2) { best2 = dist; bestL2 = lv; }
             }
@@ -1739,7 +1749,22 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
     hipError_t e = hipMemsetAsync(result, 0, (size_t)nframes * 2 * sizeof(int), st);
     if (e != hipSuccess) return e;
     if (np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(np, nframes), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_sbp_resolve, dim3(nframes), dim3(1024), 0, st, a);
+    static const bool forceGlobal = getenv("ORBX_SBP_RESOLVE_GLOBAL") != nullptr;  // tests: the variant for frames beyond SBP_LDS_NC keypoints
+    if (a.nc <= SBP_LDS_NC && !forceGlobal) {
+        const int ldsNc = (a.nc + 3) & ~3;
+        const size_t lds = (size_t)ldsNc * 9 + 16;
+        static size_t attrBytes[64] = {};  // per device
+        int devId = 0;
+        (void)hipGetDevice(&devId);
+        if (lds > attrBytes[devId & 63]) {
+            const hipError_t e = hipFuncSetAttribute((const void *)k_sbp_resolve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SBP_LDS_NC * 9 + 16));
+            if (e != hipSuccess) return e;
+            attrBytes[devId & 63] = (size_t)SBP_LDS_NC * 9 + 16;
+        }
+        hipLaunchKernelGGL(k_sbp_resolve<true>, dim3(nframes), dim3(1024), lds, st, a, ldsNc);
+    } else {
+        hipLaunchKernelGGL(k_sbp_resolve<false>, dim3(nframes), dim3(1024), 0, st, a, 0);
+    }
     return hipGetLastError();
 }
 
