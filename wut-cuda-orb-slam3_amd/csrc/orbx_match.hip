@@ -11,6 +11,7 @@
 #include "orbx_internal.h"
 #include <limits.h>
 #include <algorithm>
+#include <type_traits>
 
 #define MT_TILE 256  // train descriptors per LDS tile (8 KB)
 
@@ -143,6 +144,146 @@ __global__ __launch_bounds__(256) void k_knn2_merge(Knn2Args a)
     kn_store(a.idx, a.dist, ((size_t)pair * a.nq + qi) * 2, k0, k1);
 }
 
+// ---- the same scan on the matrix cores ------------------------------------------------------------------------------------------
+// With the bits of a descriptor written as +1 / -1 bytes, q . t = 256 - 2 * Hamming(q, t): a 256-deep int8 dot product, exact in int32.
+// The scan above is bound by vector-instruction issue (16 xor / popcount instructions per train row and 64 queries, 0.66 of that
+// peak); v_mfma_i32_16x16x64_i8 does 16 x 16 pairs x 64 bits in 16 cycles - four products per tile of 16 train rows x 16 queries.
+//   * workgroup = 4 waves = 256 queries x one split of the train rows; a wave holds its 64 queries (4 tiles of 16) expanded in
+//     registers as the B operand of all four k-steps (64 VGPRs) for the whole scan;
+//   * the train rows pass through LDS 16 at a time: every thread expands 16 bits of the tile to 16 bytes (a nibble -> four +-1 bytes:
+//     multiply by 0x00204081, mask, then 1 -> 0x01 / 0 -> 0xFF with a shift, a subtraction and an or-not), double-buffered, one barrier per tile; the packed bits of the tile after
+//     the next are already requested; rows are padded to 272 bytes so that the 16-byte operand reads of the 16 rows spread over the banks;
+//   * the result tile has the query on the lane (column) and four train rows in the lane's registers, so a lane folds four keys of
+//     ONE query: key = (256 - dot) << 22 | row = (Hamming << 23 | row), one v_mad_i32_i24 each; two minimum instructions decide whether
+//     any of them can enter the pair kept so far (after the first rows they almost never do) and only then the four insertions run;
+//   * at the end the four lane groups of a query (train rows 4g .. 4g + 3 of every tile) merge their pairs.
+// Same keys, same order, same splits and merge kernel as the scan above: bit-identical results (tests/test_matcher_gpu.py runs both).
+typedef int kn_v4i __attribute__((ext_vector_type(4)));
+#define KNM_ROWB 272  // bytes of an expanded train row in LDS (256 + 16 of padding)
+
+// bits 0..3 -> bytes 0..3, bit value b -> byte tab[b] (tab = 0x....[b = 1][b = 0]): the multiplication puts bit i at bit 0 of byte i,
+// v_perm_b32 looks the four 0 / 1 bytes up in the two-entry table
+__device__ __forceinline__ uint32_t knm_expand4(uint32_t bits4, uint32_t tab)
+{
+    const uint32_t b01 = __umul24(bits4, 0x00204081u) & 0x01010101u;
+    return __builtin_amdgcn_perm(0u, tab, b01);
+}
+__device__ __forceinline__ kn_v4i knm_expand16(uint32_t w16, uint32_t tab)
+{
+    kn_v4i v;
+    v[0] = (int)knm_expand4(w16 & 15u, tab); v[1] = (int)knm_expand4((w16 >> 4) & 15u, tab);
+    v[2] = (int)knm_expand4((w16 >> 8) & 15u, tab); v[3] = (int)knm_expand4((w16 >> 12) & 15u, tab);
+    return v;
+}
+#define KNM_TAB_Q 0x000001FFu  // queries: 1 -> +1, 0 -> -1
+#define KNM_TAB_T 0x0000FF01u  // train rows: 1 -> -1, 0 -> +1, so that the product is 2 * Hamming - 256 and the key one shift-add
+
+__global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tileL[2][16 * KNM_ROWB];
+    const int pair = blockIdx.z, split = blockIdx.y;
+    const int qb = a.qBeginDev ? a.qBeginDev[pair] : 0, tb = a.tBeginDev ? a.tBeginDev[pair] : 0;
+    const int nq = min(a.nqDev ? a.nqDev[pair] - qb : a.nq, a.nq);
+    const int nt = min(a.ntDev ? a.ntDev[pair] - tb : a.nt, a.nt);
+    if ((int)(blockIdx.x * 256) >= nq) return;  // workgroup-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 256 + wv * 64;  // this wave's queries q0 .. q0 + 63: tile qt = queries q0 + 16 qt + n
+    const uint8_t *qBase = a.q + (size_t)pair * a.qPairStride + (size_t)qb * 32;
+    const uint8_t *tBase = a.t + (size_t)pair * a.tPairStride + (size_t)tb * 32;
+    // B operands: k-step s of tile qt = bits 64 s + 16 g .. + 15 of query q0 + 16 qt + n = the 16-bit word 4 s + g of its descriptor
+    kn_v4i B[4][4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int qi = q0 + 16 * qt + n;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (qi < nq) {
+#pragma unroll
+            for (int sK = 0; sK < 4; ++sK) w[sK] = ((const uint16_t *)(qBase + (size_t)qi * 32))[4 * sK + g];
+        }
+#pragma unroll
+        for (int sK = 0; sK < 4; ++sK) B[qt][sK] = knm_expand16(w[sK], KNM_TAB_Q);
+    }
+    const int j0 = split * a.splitRows, j1 = min(j0 + a.splitRows, nt);
+    // expansion duty of this thread: row tid >> 4 of the tile, 16-bit word tid & 15
+    const int er = tid >> 4, ew = tid & 15;
+    auto loadBits = [&](int jt) -> uint32_t {  // packed bits of tile jt (rows beyond the split read row j1 - 1: masked below)
+        const int j = min(jt + er, max(j1 - 1, 0));
+        return ((const uint16_t *)(tBase + (size_t)j * 32))[ew];
+    };
+    auto expandTo = [&](int buf, uint32_t w16) {
+        // word ew = 4 s + g' -> bytes s * 64 + g' * 16 of the row
+        *(kn_v4i *)(tileL[buf] + er * KNM_ROWB + (ew >> 2) * 64 + (ew & 3) * 16) = knm_expand16(w16, KNM_TAB_T);
+    };
+    uint32_t k0[4], k1[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) { k0[qt] = KN_NONE; k1[qt] = KN_NONE; }
+    if (j0 < j1) {
+        uint32_t bitsNext = loadBits(j0);
+        expandTo(0, bitsNext);
+        bitsNext = loadBits(j0 + 16);
+        __syncthreads();
+        int buf = 0;
+        auto tile = [&](int jt, auto tailTag) {
+            constexpr bool TAIL = decltype(tailTag)::value;
+            // next tile into the other buffer, the one after it into the register
+            if (jt + 16 < j1) expandTo(buf ^ 1, bitsNext);
+            bitsNext = loadBits(jt + 32);
+            kn_v4i acc[4];
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) acc[qt] = kn_v4i{0, 0, 0, 0};
+#pragma unroll
+            for (int sK = 0; sK < 4; ++sK) {
+                const kn_v4i A = *(const kn_v4i *)(tileL[buf] + n * KNM_ROWB + sK * 64 + g * 16);  // train row n of the tile
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[qt][sK], acc[qt], 0, 0, 0);
+            }
+            // lane: query n of every tile qt, train rows jt + 4 g + r; acc = 2 * Hamming - 256
+            const int jr = jt + 4 * g;
+            uint32_t base[4];  // 256 << 22 | row: one add per row and tile, then a shift-add per key
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { base[r] = (uint32_t)((1 << 30) + jr + r); asm volatile("" : "+v"(base[r])); }
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                uint32_t key[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    key[r] = ((uint32_t)acc[qt][r] << 22) + base[r];  // (256 + acc) << 22 | row = Hamming << 23 | row
+                    if (TAIL && jr + r >= j1) key[r] = KN_NONE;
+                }
+                const uint32_t m = min(min(key[0], key[1]), min(key[2], key[3]));
+                if (__ballot(m < k1[qt]) != 0ull) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kn_insert(k0[qt], k1[qt], key[r]);
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+        };
+        int jt = j0;
+        for (; jt + 16 <= j1; jt += 16) tile(jt, std::false_type{});
+        if (jt < j1) tile(jt, std::true_type{});  // the last rows of the split: keys of rows beyond it are masked
+    }
+    // the four lane groups of a query hold the pairs of disjoint train rows: merge (same rule as the split merge)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const uint32_t c0 = (uint32_t)__shfl_xor((int)k0[qt], o), c1 = (uint32_t)__shfl_xor((int)k1[qt], o);
+            kn_insert(k0[qt], k1[qt], c0);
+            kn_insert(k0[qt], k1[qt], c1);
+        }
+        const int qi = q0 + 16 * qt + n;
+        if (g == 0 && qi < nq) {
+            if (a.nSplit == 1) kn_store(a.idx, a.dist, ((size_t)pair * a.nq + qi) * 2, k0[qt], k1[qt]);
+            else {
+                uint32_t *p = a.part + (((size_t)pair * a.nSplit + split) * a.nq + qi) * 2;
+                p[0] = k0[qt]; p[1] = k1[qt];
+            }
+        }
+    }
+}
+
 // Number of train splits for `npairs` pairs of nq x nt rows: enough waves to fill 1024 SIMDs a few times over, splits of at
 // least 64 rows.  `forceSplit` > 0 overrides it (tests of the merge).
 int orbxKnn2Splits(int npairs, int nq, int nt, int forceSplit)
@@ -168,7 +309,10 @@ hipError_t orbxLaunchKnn2Batch(hipStream_t st, int npairs, const uint8_t *q, lon
     a.nSplit = std::max(nSplit, 1);
     a.splitRows = nt > 0 ? (nt + a.nSplit - 1) / a.nSplit : 1;
     a.part = part; a.idx = idx; a.dist = dist;
-    hipLaunchKernelGGL(k_knn2_scan, dim3((nq + 63) / 64, a.nSplit, npairs), dim3(64), 0, st, a);
+    // ORBX_KNN_MFMA=0: the scan on the vector ALU (A/B timing, tests); default: the matrix-core scan
+    static const bool mfma = [] { const char *e = getenv("ORBX_KNN_MFMA"); return e ? atoi(e) != 0 : true; }();
+    if (mfma) hipLaunchKernelGGL(k_knn2_scan_mfma, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_knn2_scan, dim3((nq + 63) / 64, a.nSplit, npairs), dim3(64), 0, st, a);
     if (a.nSplit > 1) hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256, npairs), dim3(256), 0, st, a);
     return hipGetLastError();
 }
