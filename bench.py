@@ -418,10 +418,14 @@ def main() -> None:
         if cfg["match"] == "knn2":
             nq = float(total_kps) / n_last
             dpairs = nq * nq * n0
-            # 8 v_xor (2.5 cycles) + 8 v_bcnt (4.1) + key, min, med3 (4.2 each) = 65 cycles per wave-row of 64 descriptor pairs
-            peak = N_SIMD * 64 * CLOCK_GHZ * 1e9 / 65.0
-            blk.update({"descriptor_pairs_per_s": round(dpairs / mt, 0), "valu_issue_peak_descriptor_pairs_per_s": round(peak, 0),
-                        "frac_of_valu_issue_peak": round(dpairs / mt / peak, 3)})
+            # k_knn2_scan_mfma: a 16 x 16 tile of (train row, query) pairs = 4 x v_mfma_i32_16x16x64_i8 of 16 cycles on one SIMD's
+            # matrix core -> 256 pairs per 64 cycles.  (The vector-ALU scan it replaced: 8 v_xor + 8 v_bcnt + key, min, med3 = 65 issue
+            # cycles per 64 pairs, ORBX_KNN_MFMA=0.)
+            peak = N_SIMD * 256 * CLOCK_GHZ * 1e9 / 64.0
+            valu_peak = N_SIMD * 64 * CLOCK_GHZ * 1e9 / 65.0
+            blk.update({"descriptor_pairs_per_s": round(dpairs / mt, 0), "mfma_peak_descriptor_pairs_per_s": round(peak, 0),
+                        "frac_of_mfma_peak": round(dpairs / mt / peak, 3),
+                        "valu_scan_issue_peak_descriptor_pairs_per_s": round(valu_peak, 0)})
         out["matcher"] = blk
     if not args.no_pcie and world == 1:  # (host legs on rank 0 at N = 1 only)
         hl, hr = host_first

@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256) void k_knn2_merge(Knn2Args a)
 //   * workgroup = 4 waves = 256 queries x one split of the train rows; a wave holds its 64 queries (4 tiles of 16) expanded in
 //     registers as the B operand of all four k-steps (64 VGPRs) for the whole scan;
 //   * the train rows pass through LDS 16 at a time: every thread expands 16 bits of the tile to 16 bytes (a nibble -> four +-1 bytes:
-//     multiply by 0x00204081, mask, then 1 -> 0x01 / 0 -> 0xFF with a shift, a subtraction and an or-not), double-buffered, one barrier per tile; the packed bits of the tile after
-//     the next are already requested; rows are padded to 272 bytes so that the 16-byte operand reads of the 16 rows spread over the banks;
+//     multiply by 0x00204081, mask, then 1 -> 0x01 / 0 -> 0xFF with a shift, a subtraction and an or-not), double-buffered, one barrier per tile; the packed bits of the next four
+//     tiles are already requested (a register ring); rows are padded to 272 bytes so that the 16-byte operand reads of the 16 rows spread over the banks;
 //   * the result tile has the query on the lane (column) and four train rows in the lane's registers, so a lane folds four keys of
-//     ONE query: key = (256 - dot) << 22 | row = (Hamming << 23 | row), one v_mad_i32_i24 each; two minimum instructions decide whether
-//     any of them can enter the pair kept so far (after the first rows they almost never do) and only then the four insertions run;
+//     ONE query (train rows are expanded with the opposite sign, so the product is 2 * Hamming - 256 and a key is one shift-add:
+//     (256 + acc) << 22 | row = Hamming << 23 | row); two minimum instructions and a compare on the raw products decide whether any of the
+//     four can enter the pair kept so far (after the first rows they almost never do) - only then keys are formed and inserted;
 //   * at the end the four lane groups of a query (train rows 4g .. 4g + 3 of every tile) merge their pairs.
 // Same keys, same order, same splits and merge kernel as the scan above: bit-identical results (tests/test_matcher_gpu.py runs both).
 typedef int kn_v4i __attribute__((ext_vector_type(4)));
@@ -216,27 +217,35 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
         *(kn_v4i *)(tileL[buf] + er * KNM_ROWB + (ew >> 2) * 64 + (ew & 3) * 16) = knm_expand16(w16, KNM_TAB_T);
     };
     uint32_t k0[4], k1[4];
+    int thr[4];  // k1 >> 22
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) { k0[qt] = KN_NONE; k1[qt] = KN_NONE; }
+    for (int qt = 0; qt < 4; ++qt) { k0[qt] = KN_NONE; k1[qt] = KN_NONE; thr[qt] = (int)(KN_NONE >> 22); }
     if (j0 < j1) {
-        uint32_t bitsNext = loadBits(j0);
-        expandTo(0, bitsNext);
-        bitsNext = loadBits(j0 + 16);
+        // packed bits of the next four tiles in a register ring (a tile takes ~500 cycles, an L2 round trip more)
+        uint32_t ring[4];
+        expandTo(0, loadBits(j0));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ring[u] = loadBits(j0 + 16 * (u + 1));
         __syncthreads();
         int buf = 0;
-        auto tile = [&](int jt, auto tailTag) {
+        auto tile = [&](int jt, auto slotTag, auto tailTag) {
+            constexpr int U = decltype(slotTag)::value;
             constexpr bool TAIL = decltype(tailTag)::value;
-            // next tile into the other buffer, the one after it into the register
-            if (jt + 16 < j1) expandTo(buf ^ 1, bitsNext);
-            bitsNext = loadBits(jt + 32);
+            // next tile into the other buffer, the fifth from here into its ring slot
+            if (jt + 16 < j1) expandTo(buf ^ 1, ring[U]);
+            ring[U] = loadBits(jt + 80);
             kn_v4i acc[4];
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) acc[qt] = kn_v4i{0, 0, 0, 0};
+            kn_v4i A[4];  // train row n of the tile, all four k-steps requested before the first product
+#pragma unroll
+            for (int sK = 0; sK < 4; ++sK) A[sK] = *(const kn_v4i *)(tileL[buf] + n * KNM_ROWB + sK * 64 + g * 16);
+#pragma unroll
+            for (int sK = 0; sK < 4; ++sK) asm volatile("" : "+v"(A[sK]));
 #pragma unroll
             for (int sK = 0; sK < 4; ++sK) {
-                const kn_v4i A = *(const kn_v4i *)(tileL[buf] + n * KNM_ROWB + sK * 64 + g * 16);  // train row n of the tile
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[qt][sK], acc[qt], 0, 0, 0);
+                for (int qt = 0; qt < 4; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sK], B[qt][sK], acc[qt], 0, 0, 0);
             }
             // lane: query n of every tile qt, train rows jt + 4 g + r; acc = 2 * Hamming - 256
             const int jr = jt + 4 * g;
@@ -245,24 +254,35 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
             for (int r = 0; r < 4; ++r) { base[r] = (uint32_t)((1 << 30) + jr + r); asm volatile("" : "+v"(base[r])); }
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
-                uint32_t key[4];
+                // A key can only enter the pair if its distance field is SMALLER than the second key's, 256 + acc < k1 >> 22: the rows
+                // of a scan come in increasing order, so at equal distance the new row is the larger one.  Tested on the smallest of the
+                // four products; the keys are formed behind the test only.
+                const int mAcc = min(min(acc[qt][0], acc[qt][1]), min(acc[qt][2], acc[qt][3]));
+                if (__ballot(mAcc + 256 < thr[qt]) != 0ull) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    key[r] = ((uint32_t)acc[qt][r] << 22) + base[r];  // (256 + acc) << 22 | row = Hamming << 23 | row
-                    if (TAIL && jr + r >= j1) key[r] = KN_NONE;
-                }
-                const uint32_t m = min(min(key[0], key[1]), min(key[2], key[3]));
-                if (__ballot(m < k1[qt]) != 0ull) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) kn_insert(k0[qt], k1[qt], key[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        uint32_t key = ((uint32_t)acc[qt][r] << 22) + base[r];  // (256 + acc) << 22 | row = Hamming << 23 | row
+                        if (TAIL && jr + r >= j1) key = KN_NONE;
+                        kn_insert(k0[qt], k1[qt], key);
+                    }
+                    thr[qt] = (int)(k1[qt] >> 22);
                 }
             }
             __syncthreads();
             buf ^= 1;
         };
         int jt = j0;
-        for (; jt + 16 <= j1; jt += 16) tile(jt, std::false_type{});
-        if (jt < j1) tile(jt, std::true_type{});  // the last rows of the split: keys of rows beyond it are masked
+        for (; jt + 64 <= j1; jt += 64) {
+            tile(jt, std::integral_constant<int, 0>{}, std::false_type{});
+            tile(jt + 16, std::integral_constant<int, 1>{}, std::false_type{});
+            tile(jt + 32, std::integral_constant<int, 2>{}, std::false_type{});
+            tile(jt + 48, std::integral_constant<int, 3>{}, std::false_type{});
+        }
+        // up to three whole tiles and the last rows of the split (keys of rows beyond it are masked)
+        if (jt + 16 <= j1) { tile(jt, std::integral_constant<int, 0>{}, std::false_type{}); jt += 16; } else if (jt < j1) { tile(jt, std::integral_constant<int, 0>{}, std::true_type{}); jt = j1; }
+        if (jt + 16 <= j1) { tile(jt, std::integral_constant<int, 1>{}, std::false_type{}); jt += 16; } else if (jt < j1) { tile(jt, std::integral_constant<int, 1>{}, std::true_type{}); jt = j1; }
+        if (jt + 16 <= j1) { tile(jt, std::integral_constant<int, 2>{}, std::false_type{}); jt += 16; } else if (jt < j1) { tile(jt, std::integral_constant<int, 2>{}, std::true_type{}); jt = j1; }
+        if (jt < j1) tile(jt, std::integral_constant<int, 3>{}, std::true_type{});
     }
     // the four lane groups of a query hold the pairs of disjoint train rows: merge (same rule as the split merge)
 #pragma unroll
