@@ -262,7 +262,8 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, con
  * orbx_undistort_keypoints) first.  d_prev_matched [npairs][cap1][2] floats = vbPrevMatched, in / out; with init_prev_matched != 0 it is
  * first set to F1's undistorted keypoint positions (what MonocularInitialization passes on its first attempt, src/Tracking3.cc:717-720).
  * d_matches12 [npairs][cap1] int32 = vnMatches12, d_nmatches [npairs] (-1: F2 holds more than 2048 octave-0 keypoints, the capacity of the
- * LDS-resident search).  cap1 = orbx_max_keypoints(ex1).  Asynchronous on the matcher's stream. */
+ * LDS-resident search).  cap1 = orbx_max_keypoints(ex1); ORBX_ERR_CAPACITY when cap1 exceeds what the search keeps in LDS per F1 keypoint
+ * (5 bytes each beside the 2048-keypoint subset of F2: about 7000 keypoints).  Asynchronous on the matcher's stream. */
 int orbx_search_for_initialization_frames(orbx_matcher *m, orbx_extractor *ex1, orbx_extractor *ex2, int frame2_offset, int npairs,
                                           const float *k4, const float *dist, int ndist, const float *knew4, float min_x, float max_x,
                                           float min_y, float max_y, float *d_prev_matched, int init_prev_matched, int window_size,
