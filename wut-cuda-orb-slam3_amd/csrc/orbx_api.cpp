@@ -1813,6 +1813,8 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     if ((rc = m->d_siWork.ensure(orbxSearchInitWorkBytes(1, m->maxQ))) != ORBX_OK) return rc;
     int level0of2 = 0;  // the LDS-resident kernel takes F2 subsets of limited size; ORBX_SEARCH_INIT_GENERIC forces the generic one
     for (int i = 0; i < n2; ++i) level0of2 += k2[i].octave == 0;
+    int level0of1 = 0;
+    for (int i = 0; i < n1; ++i) level0of1 += !(k1[i].octave > 0);
     static const bool forceGeneric = getenv("ORBX_SEARCH_INIT_GENERIC") != nullptr;
     if (forceGeneric) level0of2 = -1;
     int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
@@ -1820,9 +1822,9 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     HIP_TRY(hipMemcpyAsync(m->d_kl.p, k1, (size_t)n1 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
     if (n2 > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, k2, (size_t)n2 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemcpyAsync(m->d_prev.p, prev_matched, 2 * (size_t)n1 * sizeof(float), hipMemcpyHostToDevice, m->stream));
-    if (!orbxSearchInitInLds(n1, n2, level0of2)) HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n2, min_x, max_x, min_y, max_y, cs, it, co));
+    if (!(orbxSearchInitInLds(level0of1, n2, level0of2) && n1 < 65536)) HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n2, min_x, max_x, min_y, max_y, cs, it, co));
     HIP_TRY(orbxLaunchSearchInit(m->stream, m->d_kl.p, m->d_q.p, n1, m->d_kr.p, m->d_t.p, n2, cs, it, min_x, max_x, min_y, max_y,
-                                 m->d_prev.p, m12, m21, md, m->d_bin.p, nm, window_size, nnratio, check_orientation, level0of2, m->d_siWork.p));
+                                 m->d_prev.p, m12, m21, md, m->d_bin.p, nm, window_size, nnratio, check_orientation, level0of2, m->d_siWork.p, level0of1));
     int nmatches = 0;
     HIP_TRY(hipMemcpyAsync(matches12, m12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(prev_matched, m->d_prev.p, 2 * (size_t)n1 * sizeof(float), hipMemcpyDeviceToHost, m->stream));

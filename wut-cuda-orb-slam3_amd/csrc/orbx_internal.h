@@ -191,7 +191,7 @@ bool orbxSearchInitInLds(int n1, int n2, int level0of2);
 hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
                                 const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
-                                int checkOri, int level0of2, void *work);
+                                int checkOri, int level0of2, void *work, int level0of1 = -1);
 
 hipError_t orbxLaunchBlurLevels(hipStream_t st, int nframes, int nlevels, const int *w, const int *h, const uint8_t *const *src, const int *srcPitch,
                                 const long long *srcFrameStride, uint8_t *const *dst, const int *dstPitch, const long long *dstFrameStride,

@@ -783,6 +783,7 @@ struct SearchInitArgs {
     // F1 (k_si_topk), topAng[t] its angle, list1G[t] its index, nL1G their number; origG / n0G: the octave-0 subset of F2 (k_si_subset);
     // all per pair (cap1 = stride of the t-indexed arrays).  topUse: entries of a list the walk looks at.
     const uint32_t *top; const float *topAng; const uint16_t *list1G, *origG; const int *nL1G, *n0G; int topUse, cap1;
+    int ldsN1;                     // k_search_init_lds: octave-0 keypoints of F1 its LDS arrays are sized for (n1 when unknown)
 };
 
 __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
@@ -1057,9 +1058,9 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     uint16_t *cellOf = items0 + SI_CAP2;                    // [SI_CAP2] (setup only)
     uint16_t *cs0 = cellOf + SI_CAP2;                       // [GRID_CELLS + 2] cell starts of the subset grid
     uint16_t *cand = cs0 + GRID_CELLS + 2;                  // [SI_CAND]
-    uint16_t *list1 = cand + SI_CAND;                       // [n1 + 64] octave-0 keypoints of F1 in index order (position t)
-    uint16_t *m12L = list1 + (a.n1 + 64);                   // [n1 + 64] vnMatches12 by position t: subset index of the partner, 0xFFFF none
-    signed char *binL = (signed char *)(m12L + (a.n1 + 64)); // [n1 + 64] rotation-histogram bin of the match recorded for t, -1 none
+    uint16_t *list1 = cand + SI_CAND;                       // [ldsN1 + 64] octave-0 keypoints of F1 in index order (position t)
+    uint16_t *m12L = list1 + (a.ldsN1 + 64);                // [ldsN1 + 64] vnMatches12 by position t: subset index of the partner, 0xFFFF none
+    signed char *binL = (signed char *)(m12L + (a.ldsN1 + 64));  // [ldsN1 + 64] rotation-histogram bin of the match recorded for t, -1 none
     int *cnt = (int *)desc;                                 // [GRID_CELLS] setup only: aliases the descriptors (loaded last)
     __shared__ int hist[32];
     const int lane = threadIdx.x;
@@ -1494,6 +1495,7 @@ hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1,
     if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
     const hipError_t e = searchInitLdsAttr(lds);
     if (e != hipSuccess) return e;
+    a.ldsN1 = cap1;
     searchInitPrepass(st, a, npairs, cap1, work);
     hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), lds, st, a);
     return hipGetLastError();
@@ -1502,7 +1504,7 @@ hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1,
 hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d1, int n1, const void *k2, const uint8_t *d2, int n2,
                                 const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, float *prev,
                                 int *m12, int *m21, int *mdist, signed char *binOf, int *nmatches, int window, float nnratio,
-                                int checkOri, int level0of2, void *work)
+                                int checkOri, int level0of2, void *work, int level0of1)
 {
     SearchInitArgs a;
     a.stride1 = 0; a.stride2 = 0; a.n1Dev = nullptr; a.n2Dev = nullptr; a.initPrev = 0;
@@ -1514,8 +1516,11 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     a.prev = prev; a.m12 = m12; a.m21 = m21; a.mdist = mdist; a.binOf = binOf; a.nmatches = nmatches;
     a.window = window; a.nnratio = nnratio; a.checkOri = checkOri;
     // level0of2 = number of octave-0 keypoints of F2 (counted by the caller on its host copy), < 0: unknown
-    const size_t lds = searchInitLdsBytes(n1);
-    if (orbxSearchInitInLds(n1, n2, level0of2)) {
+    // level0of1 = number of octave-0 keypoints of F1 (< 0: unknown, then n1): what the LDS arrays by list position are sized for
+    const int l1 = level0of1 >= 0 ? std::min(level0of1, n1) : n1;
+    a.ldsN1 = l1;
+    const size_t lds = searchInitLdsBytes(l1);
+    if (orbxSearchInitInLds(l1, n2, level0of2) && n1 < 65536) {
         const hipError_t e = searchInitLdsAttr(lds);
         if (e != hipSuccess) return e;
         searchInitPrepass(st, a, 1, n1, work);
