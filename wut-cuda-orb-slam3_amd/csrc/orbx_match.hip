@@ -150,9 +150,10 @@ __global__ __launch_bounds__(256) void k_knn2_merge(Knn2Args a)
 // peak); v_mfma_i32_16x16x64_i8 does 16 x 16 pairs x 64 bits in 16 cycles - four products per tile of 16 train rows x 16 queries.
 //   * workgroup = 4 waves = 256 queries x one split of the train rows; a wave holds its 64 queries (4 tiles of 16) expanded in
 //     registers as the B operand of all four k-steps (64 VGPRs) for the whole scan;
-//   * the train rows pass through LDS 16 at a time: every thread expands 16 bits of the tile to 16 bytes (a nibble -> four +-1 bytes:
-//     multiply by 0x00204081, mask, then 1 -> 0x01 / 0 -> 0xFF with a shift, a subtraction and an or-not), double-buffered, one barrier per tile; the packed bits of the next four
-//     tiles are already requested (a register ring); rows are padded to 272 bytes so that the 16-byte operand reads of the 16 rows spread over the banks;
+//   * the train rows pass through LDS 16 at a time: every thread expands 16 bits of the tile to 16 bytes - two 8-byte reads of a
+//     256-entry table in LDS (byte -> eight -+1 bytes; 16 vector instructions when computed: a nibble -> four 0 / 1 bytes by a 24-bit
+//     multiply and a mask, v_perm_b32 as a two-entry lookup) -, double-buffered, one barrier per tile; the packed bits of the next
+//     four tiles are already requested (a register ring); rows are padded to 272 bytes so that the 16-byte operand reads of the 16 rows spread over the banks;
 //   * the result tile has the query on the lane (column) and four train rows in the lane's registers, so a lane folds four keys of
 //     ONE query (train rows are expanded with the opposite sign, so the product is 2 * Hamming - 256 and a key is one shift-add:
 //     (256 + acc) << 22 | row = Hamming << 23 | row); two minimum instructions and a compare on the raw products decide whether any of the
@@ -212,10 +213,16 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
         const int j = min(jt + er, max(j1 - 1, 0));
         return ((const uint16_t *)(tBase + (size_t)j * 32))[ew];
     };
+    // byte -> eight -+1 bytes through a 2 KB table in LDS: two 8-byte reads instead of 16 vector instructions per thread and tile
+    __shared__ uint2 lutT[256];
+    lutT[tid] = make_uint2(knm_expand4((uint32_t)tid & 15u, KNM_TAB_T), knm_expand4((uint32_t)tid >> 4, KNM_TAB_T));
     auto expandTo = [&](int buf, uint32_t w16) {
-        // word ew = 4 s + g' -> bytes s * 64 + g' * 16 of the row
-        *(kn_v4i *)(tileL[buf] + er * KNM_ROWB + (ew >> 2) * 64 + (ew & 3) * 16) = knm_expand16(w16, KNM_TAB_T);
+        const uint2 lo = lutT[w16 & 255u], hi = lutT[w16 >> 8];
+        kn_v4i v;
+        v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)hi.x; v[3] = (int)hi.y;
+        *(kn_v4i *)(tileL[buf] + er * KNM_ROWB + (ew >> 2) * 64 + (ew & 3) * 16) = v;
     };
+    __syncthreads();
     uint32_t k0[4], k1[4];
     int thr[4];  // k1 >> 22
 #pragma unroll
