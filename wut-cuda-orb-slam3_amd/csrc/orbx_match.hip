@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void k_knn2_merge(Knn2Args a)
 //     registers as the B operand of all four k-steps (64 VGPRs) for the whole scan;
 //   * the train rows pass through LDS 16 at a time: every thread expands 16 bits of the tile to 16 bytes - two 8-byte reads of a
 //     256-entry table in LDS (byte -> eight -+1 bytes; 16 vector instructions when computed: a nibble -> four 0 / 1 bytes by a 24-bit
-//     multiply and a mask, v_perm_b32 as a two-entry lookup) -, double-buffered, one barrier per tile; the packed bits of the next
-//     four tiles are already requested (a register ring); rows are padded to 272 bytes so that the 16-byte operand reads of the 16 rows spread over the banks;
+//     multiply and a mask, v_perm_b32 as a two-entry lookup) -, double-buffered in blocks of four tiles, one barrier per block; the
+//     packed bits of the next block but one are already requested; rows are padded to 272 bytes so that the 16-byte operand reads of the 16 rows spread over the banks;
 //   * the result tile has the query on the lane (column) and four train rows in the lane's registers, so a lane folds four keys of
 //     ONE query (train rows are expanded with the opposite sign, so the product is 2 * Hamming - 256 and a key is one shift-add:
 //     (256 + acc) << 22 | row = Hamming << 23 | row); two minimum instructions and a compare on the raw products decide whether any of the
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void k_knn2_merge(Knn2Args a)
 // Same keys, same order, same splits and merge kernel as the scan above: bit-identical results (tests/test_matcher_gpu.py runs both).
 typedef int kn_v4i __attribute__((ext_vector_type(4)));
 #define KNM_ROWB 272  // bytes of an expanded train row in LDS (256 + 16 of padding)
+#define KNM_BLK 64    // train rows per LDS buffer = per barrier (four tiles of 16)
 
 // bits 0..3 -> bytes 0..3, bit value b -> byte tab[b] (tab = 0x....[b = 1][b = 0]): the multiplication puts bit i at bit 0 of byte i,
 // v_perm_b32 looks the four 0 / 1 bytes up in the two-entry table
@@ -182,7 +183,7 @@ __device__ __forceinline__ kn_v4i knm_expand16(uint32_t w16, uint32_t tab)
 
 __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tileL[2][16 * KNM_ROWB];
+    __shared__ __attribute__((aligned(16))) uint8_t tileL[2][KNM_BLK * KNM_ROWB];
     const int pair = blockIdx.z, split = blockIdx.y;
     const int qb = a.qBeginDev ? a.qBeginDev[pair] : 0, tb = a.tBeginDev ? a.tBeginDev[pair] : 0;
     const int nq = min(a.nqDev ? a.nqDev[pair] - qb : a.nq, a.nq);
@@ -209,18 +210,26 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
     const int j0 = split * a.splitRows, j1 = min(j0 + a.splitRows, nt);
     // expansion duty of this thread: row tid >> 4 of the tile, 16-bit word tid & 15
     const int er = tid >> 4, ew = tid & 15;
-    auto loadBits = [&](int jt) -> uint32_t {  // packed bits of tile jt (rows beyond the split read row j1 - 1: masked below)
-        const int j = min(jt + er, max(j1 - 1, 0));
-        return ((const uint16_t *)(tBase + (size_t)j * 32))[ew];
+    auto loadBits = [&](int jb, uint32_t (&w)[4]) {  // packed bits of the block at row jb (rows beyond the split read row j1 - 1: masked below)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(jb + 16 * u + er, max(j1 - 1, 0));
+            w[u] = ((const uint16_t *)(tBase + (size_t)j * 32))[ew];
+        }
     };
     // byte -> eight -+1 bytes through a 2 KB table in LDS: two 8-byte reads instead of 16 vector instructions per thread and tile
     __shared__ uint2 lutT[256];
     lutT[tid] = make_uint2(knm_expand4((uint32_t)tid & 15u, KNM_TAB_T), knm_expand4((uint32_t)tid >> 4, KNM_TAB_T));
-    auto expandTo = [&](int buf, uint32_t w16) {
-        const uint2 lo = lutT[w16 & 255u], hi = lutT[w16 >> 8];
-        kn_v4i v;
-        v[0] = (int)lo.x; v[1] = (int)lo.y; v[2] = (int)hi.x; v[3] = (int)hi.y;
-        *(kn_v4i *)(tileL[buf] + er * KNM_ROWB + (ew >> 2) * 64 + (ew & 3) * 16) = v;
+    auto expandTo = [&](int buf, const uint32_t (&w)[4]) {  // rows 16 u + er of the block, word ew = 4 s + g' -> bytes s * 64 + g' * 16
+        uint2 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { lo[u] = lutT[w[u] & 255u]; hi[u] = lutT[w[u] >> 8]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kn_v4i v;
+            v[0] = (int)lo[u].x; v[1] = (int)lo[u].y; v[2] = (int)hi[u].x; v[3] = (int)hi[u].y;
+            *(kn_v4i *)(tileL[buf] + (16 * u + er) * KNM_ROWB + (ew >> 2) * 64 + (ew & 3) * 16) = v;
+        }
     };
     __syncthreads();
     uint32_t k0[4], k1[4];
@@ -228,25 +237,22 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) { k0[qt] = KN_NONE; k1[qt] = KN_NONE; thr[qt] = (int)(KN_NONE >> 22); }
     if (j0 < j1) {
-        // packed bits of the next four tiles in a register ring (a tile takes ~500 cycles, an L2 round trip more)
-        uint32_t ring[4];
-        expandTo(0, loadBits(j0));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ring[u] = loadBits(j0 + 16 * (u + 1));
+        // One barrier per block of KNM_BLK rows, not per tile: a barrier couples the four SIMDs a workgroup's waves run on, and every
+        // 500 cycles was too often.  The packed bits of the next block but one are already requested.
+        uint32_t wNext[4];
+        loadBits(j0, wNext);
+        expandTo(0, wNext);
+        loadBits(j0 + KNM_BLK, wNext);
         __syncthreads();
         int buf = 0;
-        auto tile = [&](int jt, auto slotTag, auto tailTag) {
-            constexpr int U = decltype(slotTag)::value;
+        auto tile = [&](int jt, int u, auto tailTag) {
             constexpr bool TAIL = decltype(tailTag)::value;
-            // next tile into the other buffer, the fifth from here into its ring slot
-            if (jt + 16 < j1) expandTo(buf ^ 1, ring[U]);
-            ring[U] = loadBits(jt + 80);
             kn_v4i acc[4];
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) acc[qt] = kn_v4i{0, 0, 0, 0};
             kn_v4i A[4];  // train row n of the tile, all four k-steps requested before the first product
 #pragma unroll
-            for (int sK = 0; sK < 4; ++sK) A[sK] = *(const kn_v4i *)(tileL[buf] + n * KNM_ROWB + sK * 64 + g * 16);
+            for (int sK = 0; sK < 4; ++sK) A[sK] = *(const kn_v4i *)(tileL[buf] + (16 * u + n) * KNM_ROWB + sK * 64 + g * 16);
 #pragma unroll
             for (int sK = 0; sK < 4; ++sK) asm volatile("" : "+v"(A[sK]));
 #pragma unroll
@@ -275,21 +281,22 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
                     thr[qt] = (int)(k1[qt] >> 22);
                 }
             }
+        };
+        for (int jb = j0; jb < j1; jb += KNM_BLK) {
+            if (jb + KNM_BLK < j1) expandTo(buf ^ 1, wNext);  // the next block into the other buffer
+            loadBits(jb + 2 * KNM_BLK, wNext);
+            if (jb + KNM_BLK <= j1) {  // four whole tiles
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tile(jb + 16 * u, u, std::false_type{});
+            } else {                   // the last rows of the split: keys of rows beyond it are masked
+                for (int u = 0; u < 4 && jb + 16 * u < j1; ++u) {
+                    if (jb + 16 * u + 16 <= j1) tile(jb + 16 * u, u, std::false_type{});
+                    else tile(jb + 16 * u, u, std::true_type{});
+                }
+            }
             __syncthreads();
             buf ^= 1;
-        };
-        int jt = j0;
-        for (; jt + 64 <= j1; jt += 64) {
-            tile(jt, std::integral_constant<int, 0>{}, std::false_type{});
-            tile(jt + 16, std::integral_constant<int, 1>{}, std::false_type{});
-            tile(jt + 32, std::integral_constant<int, 2>{}, std::false_type{});
-            tile(jt + 48, std::integral_constant<int, 3>{}, std::false_type{});
         }
-        // up to three whole tiles and the last rows of the split (keys of rows beyond it are masked)
-        if (jt + 16 <= j1) { tile(jt, std::integral_constant<int, 0>{}, std::false_type{}); jt += 16; } else if (jt < j1) { tile(jt, std::integral_constant<int, 0>{}, std::true_type{}); jt = j1; }
-        if (jt + 16 <= j1) { tile(jt, std::integral_constant<int, 1>{}, std::false_type{}); jt += 16; } else if (jt < j1) { tile(jt, std::integral_constant<int, 1>{}, std::true_type{}); jt = j1; }
-        if (jt + 16 <= j1) { tile(jt, std::integral_constant<int, 2>{}, std::false_type{}); jt += 16; } else if (jt < j1) { tile(jt, std::integral_constant<int, 2>{}, std::true_type{}); jt = j1; }
-        if (jt < j1) tile(jt, std::integral_constant<int, 3>{}, std::true_type{});
     }
     // the four lane groups of a query hold the pairs of disjoint train rows: merge (same rule as the split merge)
 #pragma unroll
