@@ -1,13 +1,15 @@
 // orbx_match.hip — 256-bit Hamming matcher kernels for gfx950.
 //
 //   k_hamming_matrix  all-pairs ORBmatcher::DescriptorDistance (reference src/ORBmatcher3.cc:637-653)
-//   k_knn2            cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) (reference src/Frame.cc:45,1174)
-//   k_stereo_rows     Hamming stage of Frame::ComputeStereoMatches (reference src/Frame.cc:841-925)
+//   k_knn2_scan_mfma  cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) (reference src/Frame.cc:45,1174) on the matrix cores
+//   k_knn2_scan       the same scan on the vector ALU (ORBX_KNN_MFMA=0), k_knn2_merge: the per-split pairs merged
+//   k_stereo_rows     Hamming stage of Frame::ComputeStereoMatches (reference src/Frame.cc:841-925), then the SAD refinement,
+//                     the frame grid, SearchForInitialization, both SearchByProjection functions and their fisheye branches
 //
-// Integer xor + v_bcnt_u32_b32 popcount; a query lives in 8 VGPRs.  k_knn2_scan splits the train rows over the grid
-// and reads them through the scalar cache; the tie rule of knnMatch (strict `<` insertion, lower train index first) is
-// the lexicographic (distance, index) order, kept by packed keys inside a split and by k_knn2_merge across splits.
-// k_hamming_matrix / k_stereo_rows stage train descriptors through LDS tiles.
+// Distances are integer xor + v_bcnt_u32_b32 popcounts (a query lives in 8 VGPRs) - except in the kNN-2 scan, where descriptors
+// become +-1 bytes and the distance a 256-deep int8 dot product.  The train rows are split over the grid; the tie rule of knnMatch
+// (strict `<` insertion, lower train index first) is the lexicographic (distance, index) order, kept by packed keys inside a split
+// and by k_knn2_merge across splits.  k_hamming_matrix stages train descriptors through LDS tiles.
 #include "orbx_internal.h"
 #include <limits.h>
 #include <algorithm>
