@@ -25,7 +25,8 @@ def test_hamming_matrix(pkg, orc, nq, nt):
     m.close()
 
 
-@pytest.mark.parametrize("nq,nt", [(5, 0), (5, 1), (3, 2), (64, 65), (500, 777), (4000, 4000)])
+@pytest.mark.parametrize("nq,nt", [(5, 0), (5, 1), (3, 2), (64, 65), (500, 777), (4000, 4000), (257, 15), (1, 16), (300, 17), (70, 63),
+                                   (1000, 129), (255, 64), (513, 1025)])
 def test_knn2_matches_bfmatcher_semantics(pkg, orc, nq, nt):
     rng = np.random.default_rng(nq + 7 * nt)
     q, t = _desc(rng, nq), _desc(rng, nt, dup=0.3)
