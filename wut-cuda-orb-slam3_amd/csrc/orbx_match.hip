@@ -370,48 +370,78 @@ struct StereoBatch {
 // Row buckets of the right image (vRowIndices, reference src/Frame.cc:858-868) as CSR, built on the device: one workgroup per pair counts
 // the band [floor(y - r), ceil(y + r)] of every right keypoint into LDS row counters, scans them, and fills the lists with LDS cursors.
 // The lists are unordered - the search below does not depend on the visiting order (see there).
+__device__ __forceinline__ int mt_excl_scan(int v, int &total);
+
 __global__ __launch_bounds__(256) void k_stereo_buckets(const MtKp *kr, int nr, int nRows, const float *scale, int *rowStart, int *rowItems,
                                                         int itemStride, StereoBatch sb)
 {
     extern __shared__ int bk[];  // [nRows] counters, then cursors; + 256 partial sums
+    __shared__ float sc[ORBX_MAX_LEVELS];
+    __shared__ int waveBase[4];
     {
         const size_t p = blockIdx.x;
         kr += p * sb.kpStrideR; rowStart += p * (size_t)(nRows + 1); rowItems += p * (size_t)itemStride;
         if (sb.nrDev) nr = min(nr, sb.nrDev[p]);
     }
-    int *cnt = bk, *part = bk + nRows;
-    const int tid = threadIdx.x;
+    int *cnt = bk;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int y = tid; y < nRows; y += 256) cnt[y] = 0;
+    if (tid < ORBX_MAX_LEVELS) sc[tid] = scale[tid];
     __syncthreads();
-    auto band = [&](int i, int &lo, int &hi) {
-        const MtKp k = kr[i];
-        const float r = __fmul_rn(2.0f, scale[k.octave]);
-        hi = min((int)ceilf(__fadd_rn(k.y, r)), nRows - 1);
-        lo = max((int)floorf(__fsub_rn(k.y, r)), 0);
+    // A workgroup per pair is a latency chain: the keypoints are read ONCE, four loads in flight, and their bands stay in registers
+    // for the fill (up to 8 x 256 keypoints; beyond that the band is computed again), the level scales come from LDS.
+    constexpr int KEEP = 8;
+    uint32_t bandOf[KEEP];  // lo | hi << 16, 0xFFFFFFFF: no keypoint
+    auto band = [&](float y, int octave) -> uint32_t {
+        const float r = __fmul_rn(2.0f, sc[min(max(octave, 0), ORBX_MAX_LEVELS - 1)]);
+        const int hi = min((int)ceilf(__fadd_rn(y, r)), nRows - 1);
+        const int lo = max((int)floorf(__fsub_rn(y, r)), 0);
+        return lo <= hi ? (uint32_t)lo | ((uint32_t)hi << 16) : 0xFFFFFFFFu;  // (a band outside the image holds no row)
     };
-    for (int i = tid; i < nr; i += 256) {
-        int lo, hi;
-        band(i, lo, hi);
-        for (int y = lo; y <= hi; ++y) atomicAdd(&cnt[y], 1);
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) bandOf[k] = 0xFFFFFFFFu;
+    for (int i0 = 0; i0 < nr; i0 += 1024) {
+        float ky[4];
+        int ko[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = min(i0 + 256 * u + tid, nr - 1); ky[u] = kr[i].y; ko[u] = kr[i].octave; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u + tid;
+            if (i < nr) {
+                const uint32_t b = band(ky[u], ko[u]);
+                if (i0 == 0) bandOf[u] = b; else if (i0 == 1024) bandOf[4 + u] = b;
+                if (b != 0xFFFFFFFFu)
+                    for (int y = (int)(b & 0xFFFF); y <= (int)(b >> 16); ++y) atomicAdd(&cnt[y], 1);
+            }
+        }
     }
     __syncthreads();
-    // exclusive scan over the rows: each thread a contiguous chunk, partial sums through LDS
+    // exclusive scan over the rows: each thread a contiguous chunk, a wave scan over the chunk sums, the four wave totals through LDS
     const int per = (nRows + 255) / 256, y0 = tid * per, y1 = min(y0 + per, nRows);
     int sum = 0;
     for (int y = y0; y < y1; ++y) sum += cnt[y];
-    part[tid] = sum;
+    int waveTotal;
+    int base = mt_excl_scan(sum, waveTotal);
+    if (lane == 0) waveBase[wv] = waveTotal;
     __syncthreads();
-    int base = 0;
-    for (int t = 0; t < tid; ++t) base += part[t];
+    for (int w = 0; w < wv; ++w) base += waveBase[w];
     for (int y = y0; y < y1; ++y) { const int c = cnt[y]; rowStart[y] = base; cnt[y] = base; base += c; }
     if (tid == 255) rowStart[nRows] = base;
     __syncthreads();
-    for (int i = tid; i < nr; i += 256) {
-        int lo, hi;
-        band(i, lo, hi);
-        for (int y = lo; y <= hi; ++y) {
-            const int pos = atomicAdd(&cnt[y], 1);
-            if (pos < itemStride) rowItems[pos] = i;
+    for (int i0 = 0; i0 < nr; i0 += 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u + tid;
+            if (i < nr) {
+                uint32_t b;
+                if (i0 == 0) b = bandOf[u]; else if (i0 == 1024) b = bandOf[4 + u]; else b = band(kr[i].y, kr[i].octave);
+                if (b != 0xFFFFFFFFu)
+                    for (int y = (int)(b & 0xFFFF); y <= (int)(b >> 16); ++y) {
+                        const int pos = atomicAdd(&cnt[y], 1);
+                        if (pos < itemStride) rowItems[pos] = i;
+                    }
+            }
         }
     }
 }
