@@ -58,6 +58,17 @@ CONFIGS = {
 MB, MBF = 0.11, 47.9  # stereo baseline [m] and baseline x fx (EuRoC-like) for ComputeStereoMatches
 
 
+def kernel_source_sha256():
+    """Hash of the HIP sources liborbx.so is built from: stamps PMC summaries (tools/summarize_traffic.py) and tells bench.py whether a
+    committed counter file still describes the kernels it is about to time."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "wut-cuda-orb-slam3_amd", "csrc")
+    for name in ("orbx_kernels.hip", "orbx_internal.h"):
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 def level_pixels(ex):
     return [ex.level_size(l)[0] * ex.level_size(l)[1] for l in range(NLEVELS)]
 
@@ -177,6 +188,34 @@ def cpu_child(tmp, cfg_key, budget_s):
     print(json.dumps({"fps": round(n_units * fpu / wall, 2), "ms1": round(w1 / (n1 * fpu) * 1e3, 3)}))
 
 
+def self_launch(ngpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a
+    CHILD process (never exec: the driver's own process may have initialised the GPU) on a free local port and pass its output through."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 # ---- main ------------------------------------------------------------------------------------------------------------------
 def main() -> None:
     ap = argparse.ArgumentParser()
@@ -197,6 +236,10 @@ def main() -> None:
     if args.cpu_child:
         cpu_child(args.cpu_child, args.config, args.cpu_budget)
         return
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process never touches the GPU (no torch / HIP import so far); it starts the N ranks as
+        # child processes under torch.distributed.run, forwards rank 0's JSON line and returns the launcher's exit code
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -207,12 +250,14 @@ def main() -> None:
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1 (RANK is set: launched by something that is not torch.distributed.run?)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
-    # (rehearsal on a box with fewer GPUs than ranks: ORBX_BENCH_BACKEND=gloo, ranks share the devices round-robin; the result gather
-    # is then not available - RCCL needs one device per rank)
-    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+    # (rehearsal on a box with fewer GPUs than ranks: the ranks share the devices round-robin and rendezvous over gloo - RCCL needs one
+    # device per rank, so the result gather is then not available; chosen automatically, or forced with ORBX_BENCH_BACKEND=gloo)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+    rehearsal = backend != "nccl" and world > 1
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -362,29 +407,38 @@ def main() -> None:
     algo_bytes_frame = sum(px) + sum(px[1:])  # read every level once, write levels 1..7 once
     pyr_ms = float(solo_ms[0])
     achieved = algo_bytes_frame * n0 / (pyr_ms * 1e-3) / 1e9 if pyr_ms > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": "k_pyr_fast (8 per-level launches = one pyramid+FAST pass over the batch)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch_set": algo_bytes_frame * n0, "avg_duration_ms": round(pyr_ms, 4), "batches_timed": int(solo_nb),
-            "binding_bound": "valu_issue"}
-    # HBM bytes and VALU instruction count of the same launch set from the committed PMC passes (tools/collect_traffic.sh,
-    # tools/pmc.sh: separate rocprofv3 runs; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md)
+    hbm = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+    roof = {"bound": "hbm", "kernel": "k_pyr_fast (8 per-level launches = one pyramid+FAST pass over the batch)", **hbm,
+            "algorithmic_bytes_per_launch_set": algo_bytes_frame * n0, "avg_duration_ms": round(pyr_ms, 4), "batches_timed": int(solo_nb)}
+    # HBM bytes and VALU instruction count of the same launch set from the committed PMC passes (tools/collect_traffic.sh: separate
+    # rocprofv3 runs; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  They are NOT measured in this run, so they
+    # carry their source, and they are dropped when the kernel sources have changed since they were taken (sha256 recorded by
+    # tools/summarize_traffic.py): a stale file must not dress up a new kernel.
     cpath = os.path.join(ROOT, "profiles", "pyr_fast_counters_latest.json")
-    if args.config == "c2" and n0 == 1024 and os.path.exists(cpath):
+    if args.config == "c2" and n0 == 1024:
         try:
             c = json.load(open(cpath))
+            if c.get("kernel_source_sha256") != kernel_source_sha256():
+                raise ValueError(f"counters were taken on other kernel sources ({str(c.get('kernel_source_sha256'))[:12]} != "
+                                 f"{kernel_source_sha256()[:12]}): re-run tools/collect_traffic.sh")
+            src = {"source": "profiles/pyr_fast_counters_latest.json", "taken_at_commit": c.get("commit"),
+                   "kernel_source_sha256": c["kernel_source_sha256"][:16], "note": "PMC passes of an earlier run of the same command, not this run"}
             roof["traffic"] = int(2 * c["FETCH_SIZE_bytes_per_batch"] + c["WRITE_SIZE_bytes_per_batch"])
+            roof["traffic_source"] = src
             valu = float(c["SQ_INSTS_VALU_per_batch"])
             cyc = float(c.get("valu_cycles_per_instr_mix", 3.0))
-            # the kernel is bound by vector-instruction issue, not by HBM: wave-instructions per second against what 1024 SIMDs issue
-            # at the measured cost of this instruction mix (profiles/r01_valu_microbench.txt: 2.4-2.7 cycles for add/and/bitop3/shift,
-            # 4.1-4.5 for min/max/mul/alignbyte/SDWA forms) and at the best case of 2 cycles per instruction
+            # the kernel is bound by vector-instruction issue, not by HBM: wave-instructions per second against what 1024 SIMDs issue at
+            # 2 cycles per instruction (the best case; at the measured cost of this instruction mix, profiles/r01_valu_microbench.txt:
+            # 2.4-2.7 cycles for add/and/bitop3/shift, 4.1-4.5 for min/max/mul/alignbyte/SDWA forms, the peak is lower: `peak_mix`)
             ach = valu / (pyr_ms * 1e-3) / 1e9
-            roof["valu_issue"] = {"achieved": round(ach, 1), "unit": "G wave-instr/s",
-                                  "peak_mix": round(N_SIMD * CLOCK_GHZ / cyc, 1), "frac_mix": round(ach / (N_SIMD * CLOCK_GHZ / cyc), 3),
-                                  "peak_2cycle": round(N_SIMD * CLOCK_GHZ / 2.0, 1), "frac_2cycle": round(ach / (N_SIMD * CLOCK_GHZ / 2.0), 3),
-                                  "valu_wave_instr_per_launch_set": int(valu), "cycles_per_instr_mix": cyc, "clock_ghz": CLOCK_GHZ}
-        except Exception:
-            pass
+            roof["hbm"] = dict(hbm, traffic=roof["traffic"])
+            roof.update({"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(N_SIMD * CLOCK_GHZ / 2.0, 1), "unit": "G wave-instr/s",
+                         "frac": round(ach / (N_SIMD * CLOCK_GHZ / 2.0), 4), "peak_mix": round(N_SIMD * CLOCK_GHZ / cyc, 1),
+                         "frac_mix": round(ach / (N_SIMD * CLOCK_GHZ / cyc), 3), "valu_wave_instr_per_launch_set": int(valu),
+                         "cycles_per_instr_mix": cyc, "clock_ghz": CLOCK_GHZ, "valu_source": src,
+                         "frac_hbm": hbm["frac"]})
+        except Exception as e:  # the HBM block above stands (it is measured live); say why the counter-based part is missing
+            roof["counters_dropped"] = f"{type(e).__name__}: {e}"[:240]
 
     frames_total = global_units * fpu * args.steps
     fps = frames_total / dt
@@ -397,7 +451,8 @@ def main() -> None:
         "config": {"workload": cfg["name"].format(u=B), "config_id": args.config, "units_per_gpu_per_step": int(len(my_units)),
                    "frames_per_unit": fpu, "keypoints_per_frame": round(total_kps / n_last, 1),
                    "parallelism": f"frame-sharded x{world}" + (f", stream of {global_units} units dealt f mod {world}" if args.scaling == "strong" else ""),
-                   "gather": bool(gather_state is not None)},
+                   "gather": bool(gather_state is not None),
+                   **({"rehearsal": f"{world} ranks share {ndev} device(s), gloo rendezvous (not a scaling measurement)"} if rehearsal else {})},
         "stages_ms": {name: round(float(ms), 4) for name, ms in zip(pkg.STAGE_NAMES, stage_ms)},
         "roofline": roof,
     }

@@ -229,6 +229,9 @@ def run_all(cv2, orc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--exhaustive-trig", action="store_true")
+    ap.add_argument("--json", action="store_true", help="(the report is always JSON on stdout; accepted so that the acceptance step of "
+                                                        "INTEGRATION.md section 5 reads the same everywhere)")
+    ap.add_argument("--out", default=None, help="also write the report to this file (attach it to the integration change)")
     args = ap.parse_args()
     try:
         import cv2
@@ -244,7 +247,15 @@ def main():
     rep["status"] = "pinned" if not failed else "mismatch"
     rep["failed"] = failed
     rep["use_blur_variant"] = rep["gaussian_blur"].get("matching_blur_variant")
-    print(json.dumps(rep, indent=1, default=str))
+    # what to pass to orbx_create: blur_variant from the Gaussian check; trig_mode cannot be read from cv2 (it is a property of how the
+    # reference's own translation unit resolves cos/sin) - the report says how to find it
+    rep["orbx_params"] = {"blur_variant": rep["use_blur_variant"],
+                          "trig_mode": "nm -C ORBextractor.o | grep -w 'cosf\\|cos'  ->  cos: 0 (ORBX_TRIG_DOUBLE), cosf: 1 (ORBX_TRIG_FLOAT)"}
+    text = json.dumps(rep, indent=1, default=str)
+    print(text)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(text + "\n")
     return 1 if failed else 0
 
 

@@ -55,6 +55,11 @@ if "GRBM_GUI_ACTIVE_per_batch" in pf and pf.get("ns_per_batch_profiled"):
 # weighted with the per-class issue costs of profiles/r01_valu_microbench.txt
 pf["valu_cycles_per_instr_mix"] = 3.0
 pf["kernel"] = "k_pyr_fast"
+# provenance: bench.py drops these numbers when the kernel sources have changed since (bench.kernel_source_sha256)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (no torch import at module level)
+pf["kernel_source_sha256"] = bench.kernel_source_sha256()
+pf["commit"] = os.environ.get("ORBX_COMMIT", "")  # .git does not travel to the GPU box: tools/profile_round.sh is given the commit
 pf["bench"] = "bench.py --config c2 --steps 2 --warmup 1 (3 batches of 1024 frames)"
 json.dump(pf, open(os.path.join(root, "pyr_fast_counters.json"), "w"), indent=1)
 print(json.dumps(pf, indent=1))

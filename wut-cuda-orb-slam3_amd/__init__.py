@@ -398,15 +398,30 @@ class ORBmatcher:
 
     def sync(self) -> None:
         _check(self._lib.orbx_matcher_sync(self._h), "orbx_matcher_sync")
+        self._inflight = []  # the matcher's stream has drained: nothing reads the stashed inputs any more
 
     # ---- device-resident, batched forms: pair p = frame p of the two extractors' last batches -----------------------
-    def _dev_empty(self, shape, dtype, device: int):
+    # Stream contract of the *Frames methods.  The kernels run on the MATCHER's stream, the tensors are allocated by torch:
+    #  * outputs are filled with their "no match" value on torch's stream and the device is synchronised BEFORE the call, so rows beyond a
+    #    frame's keypoint count (which the kernels do not write) are defined, and nothing torch queued races the matcher's kernels;
+    #  * with download=False the call returns while the kernels still run.  The input tensors (projections, descriptors, counts ...) are
+    #    kept alive in self._inflight until the next sync() - released to torch's caching allocator earlier, their blocks could be handed
+    #    out and overwritten mid-search - and the returned tensors must not be touched by any torch operation before m.sync().
+    def _dev_out(self, shape, dtype, device: int, fill):
         import torch  # device memory only
-        return torch.empty(shape, dtype=dtype, device=f"cuda:{device}")
+        return torch.full(shape, fill, dtype=dtype, device=f"cuda:{device}")
+
+    def _launch_fence(self, *inputs) -> None:
+        import torch
+        torch.cuda.synchronize()
+        if not hasattr(self, "_inflight"):
+            self._inflight = []
+        self._inflight.extend(t for t in inputs if t is not None)
 
     def _download(self, tensor) -> np.ndarray:
         out = np.empty(tuple(tensor.shape), {4: np.int32}.get(tensor.element_size(), np.int32) if not tensor.is_floating_point() else np.float32)
         _check(self._lib.orbx_matcher_download(self._h, c_void_p(tensor.data_ptr()), out.ctypes.data, out.nbytes), "orbx_matcher_download")
+        self._inflight = []  # the download waited for the matcher's stream
         return out
 
     def knnMatchFrames(self, query: "ORBextractor", train: "ORBextractor", npairs: int, lapping_only: bool = False, download: bool = True):
@@ -415,8 +430,9 @@ class ORBmatcher:
         form).  Returns (idx, dist) as [npairs, query.capacity, 2] - numpy arrays, or torch device tensors with download=False."""
         import torch
         dev = query.device
-        idx = self._dev_empty((npairs, query.capacity, 2), torch.int32, dev)
-        dist = self._dev_empty((npairs, query.capacity, 2), torch.int32, dev)
+        idx = self._dev_out((npairs, query.capacity, 2), torch.int32, dev, -1)
+        dist = self._dev_out((npairs, query.capacity, 2), torch.int32, dev, np.iinfo(np.int32).max)
+        self._launch_fence(idx, dist)
         _check(self._lib.orbx_match_knn2_frames(self._h, query._h, train._h, npairs, int(lapping_only), c_void_p(idx.data_ptr()),
                                                 c_void_p(dist.data_ptr())), "orbx_match_knn2_frames")
         if not download:
@@ -428,8 +444,9 @@ class ORBmatcher:
         extractors' keypoints, descriptors and pyramids where they lie in HBM -> (mvuRight, mvDepth) as [npairs, left.capacity]."""
         import torch
         dev = left.device
-        ur = self._dev_empty((npairs, left.capacity), torch.float32, dev)
-        dp = self._dev_empty((npairs, left.capacity), torch.float32, dev)
+        ur = self._dev_out((npairs, left.capacity), torch.float32, dev, -1.0)
+        dp = self._dev_out((npairs, left.capacity), torch.float32, dev, -1.0)
+        self._launch_fence(ur, dp)
         _check(self._lib.orbx_compute_stereo_matches_frames(self._h, left._h, right._h, npairs, mb, mbf, c_void_p(ur.data_ptr()),
                                                             c_void_p(dp.data_ptr())), "orbx_compute_stereo_matches_frames")
         if not download:
@@ -460,9 +477,10 @@ class ORBmatcher:
         dev = left.device
         c1 = np.ascontiguousarray(cam1, np.float32); c2 = np.ascontiguousarray(cam2, np.float32)
         R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32)
-        l2r = self._dev_empty((npairs, left.capacity), torch.int32, dev); r2l = self._dev_empty((npairs, right.capacity), torch.int32, dev)
-        depth = self._dev_empty((npairs, left.capacity), torch.float32, dev); p3d = self._dev_empty((npairs, left.capacity, 3), torch.float32, dev)
-        nm = self._dev_empty((npairs,), torch.int32, dev)
+        l2r = self._dev_out((npairs, left.capacity), torch.int32, dev, -1); r2l = self._dev_out((npairs, right.capacity), torch.int32, dev, -1)
+        depth = self._dev_out((npairs, left.capacity), torch.float32, dev, -1.0); p3d = self._dev_out((npairs, left.capacity, 3), torch.float32, dev, 0.0)
+        nm = self._dev_out((npairs,), torch.int32, dev, 0)
+        self._launch_fence(l2r, r2l, depth, p3d, nm)
         _check(self._lib.orbx_compute_stereo_fisheye_matches_frames(self._h, left._h, right._h, npairs, c1.ctypes.data, c2.ctypes.data, precision,
                                                                     R.ctypes.data, t.ctypes.data, c_void_p(l2r.data_ptr()), c_void_p(r2l.data_ptr()),
                                                                     c_void_p(depth.data_ptr()), c_void_p(p3d.data_ptr()), c_void_p(nm.data_ptr())),
@@ -485,10 +503,10 @@ class ORBmatcher:
         d_p = torch.from_numpy(hp.view(np.uint8)).to(f"cuda:{dev}"); d_d = torch.from_numpy(hd).to(f"cuda:{dev}"); d_n = torch.from_numpy(hn).to(f"cuda:{dev}")
         d_ur = torch.from_numpy(np.ascontiguousarray(u_right, np.float32)).to(f"cuda:{dev}") if u_right is not None else None
         d_cs = torch.from_numpy(np.ascontiguousarray(cur_state, np.int8)).to(f"cuda:{dev}") if cur_state is not None else None
-        kun = self._dev_empty((nframes, cap * 28), torch.uint8, dev)
-        assign = self._dev_empty((nframes, cap), torch.int32, dev); nm = self._dev_empty((nframes,), torch.int32, dev)
+        kun = self._dev_out((nframes, cap * 28), torch.uint8, dev, 0)
+        assign = self._dev_out((nframes, cap), torch.int32, dev, -1); nm = self._dev_out((nframes,), torch.int32, dev, 0)
         k4 = np.ascontiguousarray(k4, np.float32); dist = np.ascontiguousarray(dist, np.float32).ravel()
-        torch.cuda.synchronize()
+        self._launch_fence(d_p, d_d, d_n, d_ur, d_cs, kun, assign, nm)
         ur_p = c_void_p(d_ur.data_ptr()) if d_ur is not None else None
         cs_p = c_void_p(d_cs.data_ptr()) if d_cs is not None else None
         if map_points_nnratio is None:
@@ -519,12 +537,12 @@ class ORBmatcher:
         dev = ex1.device
         cap = ex1.capacity
         if prev_matched is None:
-            prev = self._dev_empty((npairs, cap, 2), torch.float32, dev)
+            prev = self._dev_out((npairs, cap, 2), torch.float32, dev, 0.0)
         else:
             prev = torch.from_numpy(np.ascontiguousarray(prev_matched, np.float32).reshape(npairs, cap, 2)).to(f"cuda:{dev}")
-        m12 = self._dev_empty((npairs, cap), torch.int32, dev); nm = self._dev_empty((npairs,), torch.int32, dev)
+        m12 = self._dev_out((npairs, cap), torch.int32, dev, -1); nm = self._dev_out((npairs,), torch.int32, dev, 0)
         k4 = np.ascontiguousarray(k4, np.float32); dist = np.ascontiguousarray(dist, np.float32).ravel()
-        torch.cuda.synchronize()
+        self._launch_fence(prev, m12, nm)
         _check(self._lib.orbx_search_for_initialization_frames(self._h, ex1._h, ex2._h, int(frame2_offset), int(npairs), k4.ctypes.data,
                                                                dist.ctypes.data if len(dist) else None, len(dist), None, bounds[0], bounds[1], bounds[2],
                                                                bounds[3], c_void_p(prev.data_ptr()), int(prev_matched is None), int(windowSize),

@@ -253,6 +253,10 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     }
     static const int t450[7] = {18, 34, 49, 55, 49, 34, 18}, t451[7] = {18, 34, 48, 56, 48, 34, 18};
     memcpy(ex->taps, p->blur_variant == ORBX_BLUR_OPENCV_451 ? t451 : t450, sizeof ex->taps);
+    if (getenv("ORBX_DEBUG"))  // the two OpenCV / libm dependent choices an integrator pins with tests/tools/validate_against_opencv.py
+        fprintf(stderr, "[orbx] orbx_create: blur_variant %d (%s Gaussian taps %d %d %d %d), trig_mode %d (%s)\n", p->blur_variant,
+                p->blur_variant == ORBX_BLUR_OPENCV_451 ? "OpenCV >= 4.5.1" : "OpenCV <= 4.5.0", ex->taps[0], ex->taps[1], ex->taps[2], ex->taps[3],
+                p->trig_mode, p->trig_mode == ORBX_TRIG_FLOAT ? "cosf / sinf" : "cos / sin (double) narrowed to float");
 
     hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
     {
