@@ -41,6 +41,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PCIE_PEAK_GBS = 63.0        # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
 N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 CONFIGS = {
     # units = what one GPU processes per step; a stereo unit is a pair (2 frames)
@@ -483,24 +484,47 @@ def main() -> None:
                         "valu_scan_issue_peak_descriptor_pairs_per_s": round(valu_peak, 0)})
         out["matcher"] = blk
     if not args.no_pcie and world == 1:  # (host legs on rank 0 at N = 1 only)
+        # SURVEY 8(d)'s metric: orbx_extract_batch with host frames in (H2D) and keypoints + descriptors out (D2H) inside the call.  Three
+        # callers: everything pageable; frames page-locked; frames AND result arrays page-locked (orbx_host_alloc).  Result arrays are the
+        # caller's and reused between calls, as the reference's caller reuses its containers.
         hl, hr = host_first
         np_units = min(len(hl), n0)
+        hl, hr = hl[:np_units], (hr[:np_units] if stereo else None)
 
-        def host_call(a, b):
-            exl.extract_batch(a[:np_units], cfg["lap"])
+        def locked(a):
+            p = pkg.host_array(a.shape, a.dtype)
+            p[...] = a
+            return p
+
+        pl, pr = locked(hl), (locked(hr) if stereo else None)
+        outs = {False: (exl.output_arrays(np_units), exr.output_arrays(np_units) if stereo else None),
+                True: (exl.output_arrays(np_units, page_locked=True), exr.output_arrays(np_units, page_locked=True) if stereo else None)}
+
+        def host_call(a, b, lockedOut):
+            exl.extract_batch(a, cfg["lap"], out=outs[lockedOut][0])
             if stereo:
-                exr.extract_batch(b[:np_units], cfg["lap"])
+                exr.extract_batch(b, cfg["lap"], out=outs[lockedOut][1])
 
         res = {}
-        for tag, (a, b) in (("pageable", (hl, hr)),
-                            ("pinned", (torch.from_numpy(hl).pin_memory().numpy(), torch.from_numpy(hr).pin_memory().numpy() if stereo else None))):
-            host_call(a, b)
+        reps = 5
+        for tag, (a, b, lo) in (("pageable", (hl, hr, False)), ("pinned_input", (pl, pr, False)), ("page_locked", (pl, pr, True))):
+            host_call(a, b, lo)
             t1 = time.perf_counter()
-            for _ in range(3):
-                host_call(a, b)
-            res[tag] = 3 * np_units * fpu / (time.perf_counter() - t1)
+            for _ in range(reps):
+                host_call(a, b, lo)
+            res[tag] = reps * np_units * fpu / (time.perf_counter() - t1)
         out["pcie_inclusive_frames_per_s"] = round(res["pageable"], 1)
-        out["pcie_inclusive_pinned_input_frames_per_s"] = round(res["pinned"], 1)
+        out["pcie_inclusive_pinned_input_frames_per_s"] = round(res["pinned_input"], 1)
+        out["pcie_inclusive_page_locked_frames_per_s"] = round(res["page_locked"], 1)
+        bytes_in = W * H
+        bytes_out = float(total_kps) / n_last * 60.0 + 8.0  # keypoints (28 B) + descriptors (32 B) per feature, two counts per frame
+        link = {}
+        for tag in res:
+            gbs = res[tag] * bytes_in / 1e9
+            link[tag] = {"frames_per_s": round(res[tag], 1), "achieved": round(gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s H2D",
+                         "frac": round(gbs / PCIE_PEAK_GBS, 3), "d2h_gbs": round(res[tag] * bytes_out / 1e9, 2)}
+        out["pcie_roofline"] = {"bound": "pcie_h2d", "peak_note": "PCIe Gen5 x16, 63 GB/s per direction (MI355X_MICROARCH.md); frames cross H2D "
+                                "while results cross D2H (full duplex), so the input direction is the bound", **link}
         out["pcie_inclusive_note"] = ("orbx_extract_batch: host frames in (H2D), keypoints + descriptors out (D2H), per call; extraction only"
                                       + (" (both images of a pair)" if stereo else ""))
     if not args.no_cpu_baseline and world == 1:

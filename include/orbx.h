@@ -127,6 +127,24 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int
                        ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
                        int32_t *n_out, int32_t *mono_out);
 
+/* The same batch dealt over several handles - normally one per GPU of the node (orbx_params.device) - from ONE host process: block b of
+ * `block` consecutive frames goes to handles[b mod nhandles] (block = 1: frame f -> GPU f mod G, the partition of SURVEY 8(e); larger
+ * blocks keep each handle's host copies long), every handle runs on a host thread of its own - the reference drives its left and right
+ * extractor from two std::threads in the same way (src/Frame.cc:124-127, 1089-1092) - in batches of at most its max_batch frames, and
+ * every result lands at its frame index in the caller's arrays, laid out as for orbx_extract_batch.  No collective: frames are
+ * independent (multi-process use over RCCL: wut-cuda-orb-slam3_amd/sharding.py).  All handles must have been created with the same
+ * five extractor parameters; a handle may appear only once. */
+int orbx_extract_batch_sharded(orbx_extractor *const *handles, int nhandles, int block, const uint8_t *imgs, int nframes, int w, int h,
+                               ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc,
+                               int capacity, int32_t *n_out, int32_t *mono_out);
+
+/* Page-locked host memory for frames and result arrays.  orbx_extract_batch works from any host memory; frames in page-locked memory
+ * cross the link asynchronously without a helper thread, and result arrays in page-locked memory (with capacity == orbx_max_keypoints)
+ * are written by the device directly.  (The reference has no counterpart: its cv::Mat / std::vector buffers are pageable and
+ * re-allocated per call, src/ORBextractor.cc:1251,1257,1315.) */
+void *orbx_host_alloc(size_t bytes);
+void orbx_host_free(void *p);
+
 /* Device-resident batch: d_imgs is a device pointer (frames already in HBM); results stay in HBM in the
  * handle's own output buffers, retrievable with orbx_device_outputs().  Launches asynchronously on the
  * handle's stream; orbx_sync() waits.  This is the path bench.py times. */

@@ -239,6 +239,58 @@ def test_host_batch_in_sub_batches(pkg, orc):
     ex.close()
 
 
+def _same_valid_rows(a, b):
+    (n, mono, kps, desc), (n2, mono2, kps2, desc2) = a, b
+    assert np.array_equal(n, n2) and np.array_equal(mono, mono2)
+    for f in range(len(n)):
+        assert kps[f][: n[f]].tobytes() == kps2[f][: n[f]].tobytes() and desc[f][: n[f]].tobytes() == desc2[f][: n[f]].tobytes(), f"frame {f}"
+
+
+def test_host_batch_page_locked_and_reused_arrays(pkg):
+    """The host pipeline's four routes give the same bytes: pageable frames (copy thread) / page-locked frames (asynchronous copies) x
+    results through the handle's staging / written by the device straight into page-locked result arrays; result arrays are reused
+    between calls (rows below n[f] are overwritten, the call does not depend on what they held)."""
+    B, w, h = 200, 752, 480  # (pitch 768 != width: packed rows go through the unpack kernel)
+    imgs = np.stack([pkg.synth_frame(7000 + i, w, h) for i in range(B)])
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    ref = ex.extract_batch(imgs, (0, 0))
+    pimgs = pkg.host_array(imgs.shape, np.uint8)
+    pimgs[...] = imgs
+    out = ex.output_arrays(B)
+    for a in out:
+        a.view(np.uint8)[...] = 0xA5
+    _same_valid_rows(ref, ex.extract_batch(pimgs, (0, 0), out=out))
+    pout = ex.output_arrays(B, page_locked=True)
+    _same_valid_rows(ref, ex.extract_batch(pimgs, (0, 0), out=pout))
+    _same_valid_rows(ref, ex.extract_batch(imgs, (0, 0), out=pout))
+    ex.extract_batch(imgs[::-1].copy(), (0, 0), out=pout)  # (a different batch in between)
+    _same_valid_rows(ref, ex.extract_batch(pimgs, (0, 0), out=pout))
+    ex.close()
+
+
+def test_sharded_host_batch_two_handles(pkg):
+    """orbx_extract_batch_sharded: frames dealt over two handles (here on one device; one per GPU on a node) in blocks of 1 and of 8
+    frames, more frames than the handles hold at once, a ragged tail - every frame's result at its index, equal to one handle's."""
+    w, h, B = 640, 480, 77
+    imgs = np.stack([pkg.synth_frame(8000 + i, w, h) for i in range(B)])
+    one = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    ref = one.extract_batch(imgs, (50, 300))
+    one.close()
+    for max_batch, block in ((64, 1), (24, 8), (16, 3)):  # 16: each handle's calls take the small-batch (graph) route
+        exs = [pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=max_batch) for _ in range(2)]
+        got = pkg.extract_batch_sharded(exs, imgs, (50, 300), block=block)
+        _same_valid_rows(ref, got)
+        for e in exs:
+            e.close()
+    # error behaviour: a handle listed twice, a block larger than max_batch
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=8)
+    with pytest.raises(pkg.OrbxError):
+        pkg.extract_batch_sharded([ex, ex], imgs[:8], (0, 0))
+    with pytest.raises(pkg.OrbxError):
+        pkg.extract_batch_sharded([ex], imgs[:32], (0, 0), block=16)
+    ex.close()
+
+
 def test_full_size_batch_properties(pkg, orc):
     """BASELINE configs[1] at full size (1024 frames, device-resident): size-independent properties."""
     import torch

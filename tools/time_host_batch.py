@@ -42,22 +42,17 @@ def main():
           f"{rate(lambda: dev.copy_(pin, non_blocking=True)):.1f} GB/s, D2H pageable {rate(lambda: page.copy_(dev)):.1f} GB/s, "
           f"D2H page-locked {rate(lambda: pin.copy_(dev, non_blocking=True)):.1f} GB/s")
     ex = pkg.ORBextractor(cfg["nf"], 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B)
-    pinned_in = pin.numpy().reshape(left.shape)
-    for tag, arr in (("pageable", left), ("page-locked input", pinned_in)):
-        ex.extract_batch(arr, cfg["lap"])
+    pinned_in = pkg.host_array(left.shape, np.uint8)
+    pinned_in[...] = left
+    out_page, out_lock = ex.output_arrays(B), ex.output_arrays(B, page_locked=True)
+    for tag, arr, out in (("pageable in / out", left, out_page), ("page-locked in, pageable out", pinned_in, out_page),
+                          ("page-locked in / out", pinned_in, out_lock), ("pageable in, fresh result arrays per call", left, None)):
+        ex.extract_batch(arr, cfg["lap"], out=out)
         t0 = time.perf_counter()
         for _ in range(args.reps):
-            ex.extract_batch(arr, cfg["lap"])
+            ex.extract_batch(arr, cfg["lap"], out=out)
         dt = (time.perf_counter() - t0) / args.reps
-        print(f"orbx_extract_batch {tag}: {dt * 1e3:.2f} ms per {B} frames = {B / dt:.0f} frames/s, input {nbytes / dt / 1e9:.1f} GB/s")
-    if hasattr(ex, "extract_batch_pinned"):
-        for _ in range(2):
-            ex.extract_batch_pinned(pinned_in, cfg["lap"])
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
-            ex.extract_batch_pinned(pinned_in, cfg["lap"])
-        dt = (time.perf_counter() - t0) / args.reps
-        print(f"orbx_extract_batch page-locked in AND out: {dt * 1e3:.2f} ms per {B} frames = {B / dt:.0f} frames/s, input {nbytes / dt / 1e9:.1f} GB/s")
+        print(f"orbx_extract_batch {tag}: {dt * 1e3:.2f} ms per {B} frames = {B / dt:.0f} frames/s, input {nbytes / dt / 1e9:.1f} GB/s", flush=True)
     # device-resident for comparison
     d = torch.from_numpy(left).cuda()
     ex.extract_batch_device(d.data_ptr(), B, W, H, W, W * H, cfg["lap"]); ex.sync()

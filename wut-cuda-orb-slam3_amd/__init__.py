@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_get_scale_factors", "orbx_get_inverse_scale_factors", "orbx_get_scale_sigma_squares",
     "orbx_get_inverse_scale_sigma_squares", "orbx_get_features_per_level", "orbx_get_umax", "orbx_max_keypoints",
-    "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
+    "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_sharded", "orbx_host_alloc", "orbx_host_free", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
@@ -111,6 +111,12 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_extract.argtypes = [c_void_p, c_void_p, c_int, c_int, c_ssize_t, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]
     lib.orbx_extract_batch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int, c_void_p,
                                        c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_extract_batch_sharded.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int,
+                                               c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_host_alloc.argtypes = [c_size_t]
+    lib.orbx_host_alloc.restype = c_void_p
+    lib.orbx_host_free.argtypes = [c_void_p]
+    lib.orbx_host_free.restype = None
     lib.orbx_extract_batch_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int]
     lib.orbx_sync.argtypes = [c_void_p]
     lib.orbx_device_outputs.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]
@@ -200,6 +206,47 @@ def device_count() -> int:
     return int(load_library().orbx_device_count())
 
 
+class _HostBlock:
+    """Owner of one orbx_host_alloc block; numpy arrays made by host_array() keep it alive through their .base chain."""
+
+    def __init__(self, nbytes: int):
+        self._lib = load_library()
+        self.ptr = self._lib.orbx_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise OrbxError("orbx_host_alloc: " + self._lib.orbx_last_error().decode())
+        self.buf = (ctypes.c_uint8 * max(int(nbytes), 1)).from_address(self.ptr)
+        self.buf._orbx_owner = self  # the ctypes array (numpy's base) holds the owner
+
+    def __del__(self):
+        try:
+            self._lib.orbx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def host_array(shape, dtype) -> np.ndarray:
+    """A numpy array in page-locked host memory (orbx_host_alloc): frames read from it cross the link asynchronously, results are
+    written into it by the device."""
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    blk = _HostBlock(nbytes)
+    return np.frombuffer(blk.buf, dtype=np.uint8, count=nbytes).view(dt).reshape(shape)
+
+
+def extract_batch_sharded(extractors, images: np.ndarray, vLappingArea=(0, 0), block: int = 1, out=None):
+    """orbx_extract_batch_sharded: images [B, H, W] dealt over the extractors (normally one per GPU) in blocks of `block` frames, from
+    one process, one host thread per handle -> (n[B], mono[B], kps[B, cap], desc[B, cap, 32]) in frame order."""
+    images = np.ascontiguousarray(images, np.uint8)
+    b, h, w = images.shape
+    ex0 = extractors[0]
+    n, mono, kps, desc = out if out is not None else ex0.output_arrays(b)
+    hs = (c_void_p * len(extractors))(*[e._h for e in extractors])
+    _check(ex0._lib.orbx_extract_batch_sharded(hs, len(extractors), int(block), images.ctypes.data, b, w, h, images.strides[1], images.strides[0],
+                                               int(vLappingArea[0]), int(vLappingArea[1]), kps.ctypes.data, desc.ctypes.data, ex0.capacity,
+                                               n.ctypes.data, mono.ctypes.data), "orbx_extract_batch_sharded")
+    return n, mono, kps, desc
+
+
 class ORBextractor:
     """Mirror of ``ORB_SLAM3::ORBextractor`` (reference include/ORBextractor.h:58-92)."""
 
@@ -275,18 +322,27 @@ class ORBextractor:
             _check(mono + 100, "orbx_extract")
         return int(mono), kps[: n.value].copy(), desc[: n.value].copy()
 
-    def extract_batch(self, images: np.ndarray, vLappingArea=(0, 0)):
-        """images: [B, H, W] uint8 host array -> (n[B], mono[B], kps[B, cap], desc[B, cap, 32])."""
+    def extract_batch(self, images: np.ndarray, vLappingArea=(0, 0), out=None):
+        """images: [B, H, W] uint8 host array -> (n[B], mono[B], kps[B, cap], desc[B, cap, 32]).  out = (n, mono, kps, desc) of an earlier
+        call (or output_arrays()) is reused instead of allocating 60 KB per frame anew - the reference's caller owns and reuses its
+        output containers the same way; rows beyond n[f] are then whatever the arrays held."""
         images = np.ascontiguousarray(images, np.uint8)
         b, h, w = images.shape
-        kps = np.zeros((b, self.capacity), KEYPOINT_DTYPE)
-        desc = np.zeros((b, self.capacity, 32), np.uint8)
-        n = np.zeros(b, np.int32)
-        mono = np.zeros(b, np.int32)
+        n, mono, kps, desc = out if out is not None else self.output_arrays(b)
+        assert kps.shape == (b, self.capacity) and desc.shape == (b, self.capacity, 32) and len(n) == b and len(mono) == b
         _check(self._lib.orbx_extract_batch(self._h, images.ctypes.data, b, w, h, images.strides[1], images.strides[0],
                                             int(vLappingArea[0]), int(vLappingArea[1]), kps.ctypes.data, desc.ctypes.data,
                                             self.capacity, n.ctypes.data, mono.ctypes.data), "orbx_extract_batch")
         return n, mono, kps, desc
+
+    def output_arrays(self, b: int, page_locked: bool = False):
+        """(n[b], mono[b], kps[b, cap], desc[b, cap, 32]) zero-filled host arrays; page_locked: in orbx_host_alloc memory, which the
+        device writes directly (no staging copy)."""
+        mk = host_array if page_locked else (lambda shape, dtype: np.zeros(shape, dtype))
+        out = mk((b,), np.int32), mk((b,), np.int32), mk((b, self.capacity), KEYPOINT_DTYPE), mk((b, self.capacity, 32), np.uint8)
+        for a in out:
+            a[...] = 0
+        return out
 
     def extract_batch_device(self, d_ptr: int, nframes: int, w: int, h: int, stride: int, frame_stride: int, vLappingArea=(0, 0)):
         """Asynchronous device-resident batch (the path bench.py times); d_ptr is a raw device address."""

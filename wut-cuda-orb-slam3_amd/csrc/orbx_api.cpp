@@ -14,9 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <new>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------------------
@@ -105,6 +107,9 @@ struct orbx_extractor {
     hipEvent_t evFront[8] = {}, evBlur[8] = {};  // per sub-batch hand-offs between the streams
     hipStream_t streamCopy = nullptr;       // host-pointer API: H2D of sub-batch i + 1 under the kernels of sub-batch i
     hipEvent_t evCopy[8] = {};
+    hipStream_t streamOut = nullptr;        // host-pointer API: D2H of sub-batch i's results under the kernels / H2D of the following ones
+    hipEvent_t evBack[8] = {}, evOut[8] = {}, evIn = nullptr;
+    uint8_t *h_stage = nullptr; size_t h_stageBytes = 0;  // page-locked staging of a whole batch's results (counts, keypoints, descriptors)
     hipEvent_t evLevel[ORBX_MAX_LEVELS] = {};    // level l of the pyramid is complete (recorded after pyr_fast(l-1))
 
     // geometry of the current image size
@@ -273,8 +278,12 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
         e = hipEventCreateWithFlags(&ex->evFront[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBlur[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evCopy[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBack[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evOut[i], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evIn, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->streamCopy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->streamOut, hipStreamNonBlocking);
     for (int i = 0; i < ORBX_MAX_LEVELS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ex->evLevel[i], hipEventDisableTiming);
     if (e != hipSuccess) { orbx_destroy(ex); return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     ex->d_raw.resize(nl); ex->d_blur.resize(nl);
@@ -293,6 +302,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     if (!ex) return;
     (void)hipSetDevice(ex->prm.device);
     if (ex->streamCopy) { (void)hipStreamSynchronize(ex->streamCopy); (void)hipStreamDestroy(ex->streamCopy); }
+    if (ex->streamOut) { (void)hipStreamSynchronize(ex->streamOut); (void)hipStreamDestroy(ex->streamOut); }
     if (ex->stream3) { (void)hipStreamSynchronize(ex->stream3); (void)hipStreamDestroy(ex->stream3); }
     if (ex->stream2) { (void)hipStreamSynchronize(ex->stream2); (void)hipStreamDestroy(ex->stream2); }
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
@@ -301,7 +311,11 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
         if (ex->evFront[i]) (void)hipEventDestroy(ex->evFront[i]);
         if (ex->evBlur[i]) (void)hipEventDestroy(ex->evBlur[i]);
         if (ex->evCopy[i]) (void)hipEventDestroy(ex->evCopy[i]);
+        if (ex->evBack[i]) (void)hipEventDestroy(ex->evBack[i]);
+        if (ex->evOut[i]) (void)hipEventDestroy(ex->evOut[i]);
     }
+    if (ex->evIn) (void)hipEventDestroy(ex->evIn);
+    if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i)
         if (ex->evLevel[i]) (void)hipEventDestroy(ex->evLevel[i]);
     for (auto &e : ex->events) (void)hipEventDestroy(e);
@@ -758,33 +772,140 @@ static OrbxTables makeTables(const orbx_extractor *ex)
 // stream) of sub-batch s.  No buffer is shared between sub-batches (everything is indexed by frame), so no double
 // buffering is needed.  The front stream finally waits for the back stream: orbx_sync() and the next batch order
 // themselves after all work of this batch.
-struct HostFrames { const uint8_t *imgs; ptrdiff_t stride, frameStride; };  // host-pointer API: frames still to be staged into d_imgs
+// Host-pointer API (orbx_extract_batch and the sharded form): where the frames of this handle's batch lie in host memory, and where its
+// results go.  Local frame i of the handle is host frame hostIndex(i): runs of `run` consecutive frames, `runStep` frames from one run's
+// start to the next (a plain batch: one run; the sharded call deals blocks of frames round-robin over the handles, so handle g of G sees
+// run = block, runStep = G * block and pointers that start at its first block).  Results use the same mapping into the caller's arrays.
+struct HostPipe;
+struct HostFrames {
+    const uint8_t *imgs; ptrdiff_t stride, frameStride;
+    int run, runStep;
+    HostPipe *pipe;
+    size_t hostIndex(int i) const { return (size_t)(i / run) * (size_t)runStep + (size_t)(i % run); }
+};
+
+static bool isPageLocked(const void *p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // plain malloc'ed memory: "invalid value"
+    return a.type == hipMemoryTypeHost;
+}
 
 // H2D of frames [f0, f0 + nf) of a host batch into the pitched device buffer.  A host-to-device copy whose two pitches differ is a 2-D
 // copy, which the runtime executes row by row: 3.0 ms for ONE 1242 x 375 frame (KITTI) against 0.03 ms for a 1024-wide one whose pitch
-// happens to equal its width.  Packed host frames therefore cross the link as one linear copy into a packed device buffer, and the
-// pitch is applied by a device-to-device 2-D copy behind it on the same stream.
+// happens to equal its width.  Packed host frames therefore cross the link as linear copies into a packed device buffer, and the
+// pitch is applied by a small kernel behind them on the same stream.  One copy per run of consecutive host frames.
 static int stageHostFrames(orbx_extractor *ex, uint8_t *dst, ptrdiff_t dstPitch, ptrdiff_t dstFrameStride, const HostFrames *host, int f0, int nf,
                            int nframesTotal, int w, int h, hipStream_t st)
 {
-    const uint8_t *srcH = host->imgs + (size_t)f0 * host->frameStride;
-    uint8_t *dstF = dst + (size_t)f0 * dstFrameStride;
-    const bool contiguous = host->frameStride == host->stride * h && dstFrameStride == dstPitch * h;
-    if (contiguous && host->stride == dstPitch) {  // identical layouts
-        HIP_TRY(hipMemcpyAsync(dstF, srcH, (size_t)nf * h * dstPitch - (dstPitch - w), hipMemcpyHostToDevice, st));
-    } else if (host->stride == w && host->frameStride == (ptrdiff_t)w * h && h <= 65535 && nf <= 65535) {  // packed rows and frames
-        const size_t frameBytes = (size_t)w * h;
+    const bool rowsAlike = host->stride == dstPitch && host->frameStride == host->stride * h && dstFrameStride == dstPitch * h;
+    const bool packed = host->stride == w && host->frameStride == (ptrdiff_t)w * h && h <= 65535 && nf <= 65535;
+    const size_t frameBytes = (size_t)w * h;
+    if (!rowsAlike && packed) {
         int rc = ex->d_inPacked.ensure((size_t)std::max(nframesTotal, ex->prm.max_batch) * frameBytes + 64);
         if (rc != ORBX_OK) return rc;
-        uint8_t *packed = ex->d_inPacked.p + (size_t)f0 * frameBytes;
-        HIP_TRY(hipMemcpyAsync(packed, srcH, (size_t)nf * frameBytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(orbxLaunchUnpackFrames(st, packed, dstF, w, h, dstPitch, dstFrameStride, nf));
-    } else if (contiguous) {
-        HIP_TRY(hipMemcpy2DAsync(dstF, dstPitch, srcH, host->stride, w, (size_t)h * nf, hipMemcpyHostToDevice, st));
-    } else {
-        for (int f = 0; f < nf; ++f)
-            HIP_TRY(hipMemcpy2DAsync(dstF + (size_t)f * dstFrameStride, dstPitch, srcH + (size_t)f * host->frameStride, host->stride, w, h,
-                                     hipMemcpyHostToDevice, st));
+    }
+    for (int i = f0; i < f0 + nf;) {
+        const int len = std::min(f0 + nf - i, host->run - i % host->run);  // frames up to the end of this run
+        const uint8_t *srcH = host->imgs + host->hostIndex(i) * (size_t)host->frameStride;
+        uint8_t *dstF = dst + (size_t)i * dstFrameStride;
+        if (rowsAlike) {  // identical layouts
+            HIP_TRY(hipMemcpyAsync(dstF, srcH, (size_t)len * h * dstPitch - (dstPitch - w), hipMemcpyHostToDevice, st));
+        } else if (packed) {
+            HIP_TRY(hipMemcpyAsync(ex->d_inPacked.p + (size_t)i * frameBytes, srcH, (size_t)len * frameBytes, hipMemcpyHostToDevice, st));
+        } else if (host->frameStride == host->stride * h && dstFrameStride == dstPitch * h) {
+            HIP_TRY(hipMemcpy2DAsync(dstF, dstPitch, srcH, host->stride, w, (size_t)h * len, hipMemcpyHostToDevice, st));
+        } else {
+            for (int f = 0; f < len; ++f)
+                HIP_TRY(hipMemcpy2DAsync(dstF + (size_t)f * dstFrameStride, dstPitch, srcH + (size_t)f * host->frameStride, host->stride, w, h,
+                                         hipMemcpyHostToDevice, st));
+        }
+        i += len;
+    }
+    if (!rowsAlike && packed)
+        HIP_TRY(orbxLaunchUnpackFrames(st, ex->d_inPacked.p + (size_t)f0 * frameBytes, dst + (size_t)f0 * dstFrameStride, w, h, dstPitch, dstFrameStride, nf));
+    return ORBX_OK;
+}
+
+// The host side of one host-pointer batch (H2D of the frames and D2H of the results are part of the metric).  The link
+// moves 55 - 57 GB/s in each direction on the GPU box, from pageable memory too - but a copy from or to PAGEABLE memory blocks the calling
+// thread until it is done (the runtime stages or pins behind the call), and with the copies and the launches on one thread the copy
+// engine idled while the thread enqueued a sub-batch's kernels and the kernels idled during the next copy (timeline of round 2's call,
+// tools/experiments/host_batch_trace.sh: 11.5 ms per 1024 VGA frames for 5.7 ms of copy time).  So:
+//  * frames in pageable memory are fed by a helper thread that does nothing but the blocking copies, sub-batch after sub-batch, and
+//    signals each one; the calling thread enqueues a sub-batch's kernels as soon as its copy has been issued.  Page-locked frames
+//    (orbx_host_alloc, hipHostMalloc, hipHostRegister) need no thread: their copies are asynchronous;
+//  * the results of sub-batch s leave on a third stream as soon as its last kernel is done - into the caller's arrays if those are
+//    page-locked and laid out like the handle's (same capacity, consecutive frames), else into page-locked staging of the handle, from
+//    where the calling thread copies exactly n[f] rows per frame while later sub-batches are still in flight.
+struct HostPipe {
+    orbx_keypoint *kps; uint8_t *desc; int capacity; int32_t *nOut, *monoOut;
+    bool feeder = false, direct = false;
+    int nsub = 0, f0[ORBX_MAX_SUB], nf[ORBX_MAX_SUB], drained = 0;
+    std::mutex mu; std::condition_variable cv; int staged = 0, feederRc = ORBX_OK; std::string feederErr;
+    std::thread thread;
+    ~HostPipe() { if (thread.joinable()) thread.join(); }
+};
+
+static int ensureStage(orbx_extractor *ex)
+{
+    const size_t B = (size_t)ex->prm.max_batch, cap = (size_t)ex->maxKeypoints;
+    const size_t need = ((2 * B * sizeof(int32_t) + 63) & ~(size_t)63) + B * cap * (sizeof(orbx_keypoint) + 32) + 64;
+    if (ex->h_stageBytes >= need) return ORBX_OK;
+    ORBX_SETUP_LOCK;
+    if (ex->h_stage) { (void)hipHostFree(ex->h_stage); ex->h_stage = nullptr; ex->h_stageBytes = 0; }
+    HIP_TRY(hipHostMalloc((void **)&ex->h_stage, need, hipHostMallocDefault));
+    ex->h_stageBytes = need;
+    return ORBX_OK;
+}
+static inline int32_t *stageN(orbx_extractor *ex) { return (int32_t *)ex->h_stage; }
+static inline int32_t *stageMono(orbx_extractor *ex) { return (int32_t *)ex->h_stage + ex->prm.max_batch; }
+static inline orbx_keypoint *stageKps(orbx_extractor *ex) { return (orbx_keypoint *)(ex->h_stage + ((2 * (size_t)ex->prm.max_batch * sizeof(int32_t) + 63) & ~(size_t)63)); }
+static inline uint8_t *stageDesc(orbx_extractor *ex) { return (uint8_t *)(stageKps(ex) + (size_t)ex->prm.max_batch * ex->maxKeypoints); }
+
+// results of sub-batch sb: D2H on the output stream behind the back stream's last kernel of that sub-batch
+static int pipeSendResults(orbx_extractor *ex, HostPipe *pp, int sb)
+{
+    const int f0 = pp->f0[sb], nf = pp->nf[sb];
+    const size_t cap = (size_t)ex->maxKeypoints;
+    HIP_TRY(hipEventRecord(ex->evBack[sb], ex->stream3));
+    HIP_TRY(hipStreamWaitEvent(ex->streamOut, ex->evBack[sb], 0));
+    HIP_TRY(hipMemcpyAsync(stageN(ex) + f0, ex->d_n.p + f0, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, ex->streamOut));
+    HIP_TRY(hipMemcpyAsync(stageMono(ex) + f0, ex->d_mono.p + f0, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, ex->streamOut));
+    orbx_keypoint *hk = pp->direct ? pp->kps : stageKps(ex);
+    uint8_t *hd = pp->direct ? pp->desc : stageDesc(ex);
+    if (pp->kps) HIP_TRY(hipMemcpyAsync(hk + (size_t)f0 * cap, ex->d_kps.p + (size_t)f0 * cap, (size_t)nf * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->streamOut));
+    if (pp->desc) HIP_TRY(hipMemcpyAsync(hd + (size_t)f0 * cap * 32, ex->d_desc.p + (size_t)f0 * cap * 32, (size_t)nf * cap * 32, hipMemcpyDeviceToHost, ex->streamOut));
+    HIP_TRY(hipEventRecord(ex->evOut[sb], ex->streamOut));
+    return ORBX_OK;
+}
+
+// hands the finished sub-batches to the caller's arrays, in order; wait = false: only those whose copies have landed already
+static int pipeDrain(orbx_extractor *ex, const HostFrames *host, bool wait, int upTo)
+{
+    HostPipe *pp = host->pipe;
+    const size_t cap = (size_t)ex->maxKeypoints;
+    while (pp->drained < upTo) {
+        const int sb = pp->drained;
+        if (wait) HIP_TRY(hipEventSynchronize(ex->evOut[sb]));
+        else {
+            const hipError_t q = hipEventQuery(ex->evOut[sb]);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); return ORBX_OK; }
+            if (q != hipSuccess) return setError(ORBX_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+        }
+        const int32_t *hn = stageN(ex), *hm = stageMono(ex);
+        for (int f = pp->f0[sb]; f < pp->f0[sb] + pp->nf[sb]; ++f) {
+            if (hn[f] > pp->capacity) return setError(ORBX_ERR_CAPACITY, "frame %d has %d keypoints, output capacity is %d", f, hn[f], pp->capacity);
+            const size_t o = host->hostIndex(f);
+            if (!pp->direct && hn[f] > 0) {
+                if (pp->kps) memcpy(pp->kps + o * pp->capacity, stageKps(ex) + (size_t)f * cap, (size_t)hn[f] * sizeof(orbx_keypoint));
+                if (pp->desc) memcpy(pp->desc + o * pp->capacity * 32, stageDesc(ex) + (size_t)f * cap * 32, (size_t)hn[f] * 32);
+            }
+            if (pp->nOut) pp->nOut[o] = hn[f];
+            if (pp->monoOut) pp->monoOut[o] = hm[f];
+        }
+        ++pp->drained;
     }
     return ORBX_OK;
 }
@@ -1068,10 +1189,17 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
     static const int maxSub = [] { const char *e = getenv("ORBX_SUBBATCHES"); int v = e ? atoi(e) : 1; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
     int nsub = std::min(maxSub, std::max(1, nframes / 64));
     // frames arriving from the host: sub-batches of >= 128 frames, so that the copy of the next one runs under this one's kernels
-    static const int hostSub = [] { const char *e = getenv("ORBX_HOST_SUBBATCHES"); int v = e ? atoi(e) : 4; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
-    if (host) nsub = std::max(nsub, std::min(hostSub, std::max(1, nframes / 128)));
+    // (up to 8 sub-batches of at least 16 MB of pixels and 8 frames: what is not hidden is the first sub-batch's copy and the last one's
+    // kernels and results)
+    static const int hostSub = [] { const char *e = getenv("ORBX_HOST_SUBBATCHES"); int v = e ? atoi(e) : 8; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
+    if (host) nsub = std::max(nsub, std::min(hostSub, std::max(1, (int)std::min((long long)nframes / 8, (long long)nframes * w * h / (16 << 20)))));
     const int subSize = ((nframes + nsub - 1) / nsub + 7) / 8 * 8;
     nsub = (nframes + subSize - 1) / subSize;
+    HostPipe *pipe = host ? host->pipe : nullptr;
+    if (pipe) {
+        pipe->nsub = nsub;
+        for (int sb = 0; sb < nsub; ++sb) { pipe->f0[sb] = sb * subSize; pipe->nf[sb] = std::min(subSize, nframes - sb * subSize); }
+    }
 
     // 0: one quadtree launch for all levels; 1: one launch per level, next to k_pyr_fast of the following level; k >= 2: groups
     // of k - 1 levels per launch after k_pyr_fast (LDS per instance sized by the group's largest quota)
@@ -1096,13 +1224,35 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
         const int f0 = sb * subSize, nf = std::min(subSize, nframes - f0);
         if (host) {
             // stage this sub-batch's frames
+            uint8_t *dIn = (uint8_t *)const_cast<void *>(d_imgs);
             if (sb == 0) {  // the staging buffer is free once everything ordered before this call on the front stream is done
-                HIP_TRY(hipEventRecord(ex->evCopy[0], sFront));
-                HIP_TRY(hipStreamWaitEvent(ex->streamCopy, ex->evCopy[0], 0));
+                HIP_TRY(hipEventRecord(ex->evIn, sFront));
+                HIP_TRY(hipStreamWaitEvent(ex->streamCopy, ex->evIn, 0));
+                if (pipe && pipe->feeder) {
+                    // pageable frames: the blocking copies run on a helper thread, one sub-batch after the other (joined by ~HostPipe)
+                    pipe->thread = std::thread([=]() {
+                        ORBX_API_ENTRY;
+                        int rcf = hipSetDevice(ex->prm.device) == hipSuccess ? ORBX_OK : setError(ORBX_ERR_HIP, "hipSetDevice failed in the copy thread");
+                        for (int k = 0; k < nsub; ++k) {
+                            if (rcf == ORBX_OK) rcf = stageHostFrames(ex, dIn, stride, frame_stride, host, pipe->f0[k], pipe->nf[k], nframes, w, h, ex->streamCopy);
+                            if (rcf == ORBX_OK && hipEventRecord(ex->evCopy[k], ex->streamCopy) != hipSuccess) rcf = setError(ORBX_ERR_HIP, "hipEventRecord failed in the copy thread");
+                            std::lock_guard<std::mutex> lk(pipe->mu);
+                            if (rcf != ORBX_OK && pipe->feederRc == ORBX_OK) { pipe->feederRc = rcf; pipe->feederErr = g_lastError; }
+                            pipe->staged = k + 1;
+                            pipe->cv.notify_all();
+                        }
+                    });
+                }
             }
-            const int rcs = stageHostFrames(ex, (uint8_t *)const_cast<void *>(d_imgs), stride, frame_stride, host, f0, nf, nframes, w, h, ex->streamCopy);
-            if (rcs != ORBX_OK) return rcs;
-            HIP_TRY(hipEventRecord(ex->evCopy[sb], ex->streamCopy));
+            if (pipe && pipe->feeder) {
+                std::unique_lock<std::mutex> lk(pipe->mu);
+                pipe->cv.wait(lk, [&] { return pipe->staged > sb; });
+                if (pipe->feederRc != ORBX_OK) { g_lastError = pipe->feederErr; return pipe->feederRc; }
+            } else {
+                const int rcs = stageHostFrames(ex, dIn, stride, frame_stride, host, f0, nf, nframes, w, h, ex->streamCopy);
+                if (rcs != ORBX_OK) return rcs;
+                HIP_TRY(hipEventRecord(ex->evCopy[sb], ex->streamCopy));
+            }
             HIP_TRY(hipStreamWaitEvent(sFront, ex->evCopy[sb], 0));
             HIP_TRY(hipStreamWaitEvent(sBlur, ex->evCopy[sb], 0));
         }
@@ -1236,6 +1386,11 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
         HIP_TRY(orbxLaunchOrientDesc(sBack, nf, tb, lv, ex->d_workKey.p + (size_t)f0 * cap, ex->d_workPos.p + (size_t)f0 * cap,
                                      ex->d_n.p + f0, ex->d_kps.p + (size_t)f0 * cap, ex->d_desc.p + (size_t)f0 * cap * 32, cap));
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 4) * 2 + 1], sBack));
+        if (pipe) {  // this sub-batch's results start for the host; those of earlier ones that have landed go to the caller's arrays
+            int rcp = pipeSendResults(ex, pipe, sb);
+            if (rcp == ORBX_OK) rcp = pipeDrain(ex, host, false, sb);
+            if (rcp != ORBX_OK) return rcp;
+        }
     }
     // join: everything of this batch is ordered before whatever follows on the front stream
     HIP_TRY(hipEventRecord(ex->evJoin, sBack));
@@ -1302,7 +1457,8 @@ extern "C" int orbx_download_outputs(orbx_extractor *ex, int nframes, orbx_keypo
 
 // Small batches: everything (counts, keypoints, descriptors at full capacity) in four asynchronous copies into page-locked staging
 // and ONE synchronisation, instead of counts first and exact-size copies afterwards (two round trips).
-static int downloadSmall(orbx_extractor *ex, int nframes, orbx_keypoint *kps, uint8_t *desc, int capacity, int32_t *n_out, int32_t *mono_out)
+static int downloadSmall(orbx_extractor *ex, const HostFrames *host, int nframes, orbx_keypoint *kps, uint8_t *desc, int capacity, int32_t *n_out,
+                         int32_t *mono_out)
 {
     const int cap = ex->maxKeypoints;
     const size_t bN = (size_t)nframes * sizeof(int32_t), bK = (size_t)nframes * cap * sizeof(orbx_keypoint), bD = (size_t)nframes * cap * 32;
@@ -1324,21 +1480,21 @@ static int downloadSmall(orbx_extractor *ex, int nframes, orbx_keypoint *kps, ui
     for (int f = 0; f < nframes; ++f)
         if (hn[f] > capacity) return setError(ORBX_ERR_CAPACITY, "frame %d has %d keypoints, output capacity is %d", f, hn[f], capacity);
     for (int f = 0; f < nframes; ++f) {
-        if (kps && hn[f] > 0) memcpy(kps + (size_t)f * capacity, hk + (size_t)f * cap, (size_t)hn[f] * sizeof(orbx_keypoint));
-        if (desc && hn[f] > 0) memcpy(desc + (size_t)f * capacity * 32, hd + (size_t)f * cap * 32, (size_t)hn[f] * 32);
-        if (n_out) n_out[f] = hn[f];
-        if (mono_out) mono_out[f] = hm[f];
+        const size_t o = host->hostIndex(f);
+        if (kps && hn[f] > 0) memcpy(kps + o * capacity, hk + (size_t)f * cap, (size_t)hn[f] * sizeof(orbx_keypoint));
+        if (desc && hn[f] > 0) memcpy(desc + o * capacity * 32, hd + (size_t)f * cap * 32, (size_t)hn[f] * 32);
+        if (n_out) n_out[o] = hn[f];
+        if (mono_out) mono_out[o] = hm[f];
     }
     return ORBX_OK;
 }
 
-extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
-                                  ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
-                                  int32_t *n_out, int32_t *mono_out)
+// One handle's share of a host batch: frames and results at the run mapping of `hf` (see HostFrames).
+static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int w, int h, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc,
+                            int capacity, int32_t *n_out, int32_t *mono_out)
 {
-    ORBX_API_ENTRY;
-    if (!ex || !imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: null argument");
-    if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: bad shape");
+    if (!ex || !hf.imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: null argument");
+    if (nframes <= 0 || w <= 0 || h <= 0 || hf.stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
     if (w > ex->prm.max_width || h > ex->prm.max_height)
         return setError(ORBX_ERR_CAPACITY, "image %dx%d exceeds the handle's max_width x max_height = %dx%d", w, h, ex->prm.max_width, ex->prm.max_height);
@@ -1346,12 +1502,93 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
     int rc = computeGeometry(ex, w, h);
     if (rc != ORBX_OK) return rc;
     if ((rc = ensureBuffers(ex)) != ORBX_OK) return rc;
-    // H2D staging happens inside the launch sequence, sub-batch by sub-batch on the copy stream
-    const HostFrames host = {imgs, stride, frame_stride};
-    rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &host);
-    if (rc != ORBX_OK) return rc;
-    if (nframes <= ORBX_GRAPH_MAX_FRAMES) return downloadSmall(ex, nframes, kps, desc, capacity, n_out, mono_out);
-    return orbx_download_outputs(ex, nframes, kps, desc, capacity, n_out, mono_out);
+    if (nframes <= ORBX_GRAPH_MAX_FRAMES) {  // small batches: one replayed graph, one round trip for the results
+        hf.pipe = nullptr;
+        rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
+        if (rc != ORBX_OK) return rc;
+        return downloadSmall(ex, &hf, nframes, kps, desc, capacity, n_out, mono_out);
+    }
+    if ((rc = ensureStage(ex)) != ORBX_OK) return rc;
+    // H2D staging and the D2H of the results happen inside the launch sequence, sub-batch by sub-batch
+    HostPipe pipe;
+    pipe.kps = kps; pipe.desc = desc; pipe.capacity = capacity; pipe.nOut = n_out; pipe.monoOut = mono_out;
+    static const int feederEnv = [] { const char *e = getenv("ORBX_HOST_FEEDER"); return e ? atoi(e) : -1; }();  // A/B: 0 no helper thread, 1 always
+    pipe.feeder = feederEnv >= 0 ? feederEnv != 0 : !isPageLocked(hf.imgs);
+    pipe.direct = capacity == ex->maxKeypoints && hf.run >= nframes && (!kps || isPageLocked(kps)) && (!desc || isPageLocked(desc));
+    hf.pipe = &pipe;
+    rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
+    if (rc == ORBX_OK) rc = pipeDrain(ex, &hf, true, pipe.nsub);
+    if (rc != ORBX_OK) (void)hipStreamSynchronize(ex->streamOut);  // nothing of this call may still be writing into the caller's arrays
+    return rc;  // (~HostPipe joins the copy thread)
+}
+
+extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
+                                  ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
+                                  int32_t *n_out, int32_t *mono_out)
+{
+    ORBX_API_ENTRY;
+    const HostFrames hf = {imgs, stride, frame_stride, std::max(nframes, 1), std::max(nframes, 1), nullptr};
+    return extractBatchHost(ex, hf, nframes, w, h, lap0, lap1, kps, desc, capacity, n_out, mono_out);
+}
+
+// The C++-side sharding entry (frames shard over the GPUs, no data-path collective): block b of `block` consecutive
+// frames goes to handle b mod nhandles (block = 1: frame f -> GPU f mod G), every handle works through its blocks on a thread of its own
+// - the reference drives its two extractors from two std::threads the same way (src/Frame.cc:124-127) - in batches of at most its
+// max_batch frames, and every result lands in the caller's arrays at its frame index.
+extern "C" int orbx_extract_batch_sharded(orbx_extractor *const *handles, int nhandles, int block, const uint8_t *imgs, int nframes, int w, int h,
+                                          ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc,
+                                          int capacity, int32_t *n_out, int32_t *mono_out)
+{
+    ORBX_API_ENTRY;
+    if (!handles || nhandles <= 0 || !imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_sharded: null argument");
+    if (block <= 0 || nframes <= 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_sharded: block and nframes must be positive");
+    for (int g = 0; g < nhandles; ++g) {
+        if (!handles[g]) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_sharded: handle %d is null", g);
+        for (int k = 0; k < g; ++k)
+            if (handles[k] == handles[g]) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_sharded: handle %d is listed twice (one handle is never entered concurrently)", g);
+        if (handles[g]->prm.max_batch < block) return setError(ORBX_ERR_CAPACITY, "orbx_extract_batch_sharded: handle %d has max_batch %d < block %d", g, handles[g]->prm.max_batch, block);
+    }
+    std::vector<int> rcs(nhandles, ORBX_OK);
+    std::vector<std::string> errs(nhandles);
+    auto work = [&](int g) {
+        ORBX_API_ENTRY;
+        orbx_extractor *ex = handles[g];
+        // this handle's frames: blocks g, g + G, g + 2 G ... ; local frame i = frame (i / block) * G * block + g * block + i % block
+        const int nblocksAll = (nframes + block - 1) / block;
+        int mine = 0;
+        for (int b = g; b < nblocksAll; b += nhandles) mine += std::min(block, nframes - b * block);
+        const int perCall = ex->prm.max_batch / block * block;  // whole blocks per call
+        for (int done = 0; done < mine && rcs[g] == ORBX_OK; done += perCall) {
+            const int cnt = std::min(perCall, mine - done);
+            const size_t first = (size_t)(done / block) * nhandles * block + (size_t)g * block;  // frame index of local frame `done`
+            const HostFrames hf = {imgs + first * (size_t)frame_stride, stride, frame_stride, block, nhandles * block, nullptr};
+            rcs[g] = extractBatchHost(ex, hf, cnt, w, h, lap0, lap1, kps ? kps + first * capacity : nullptr,
+                                      desc ? desc + first * (size_t)capacity * 32 : nullptr, capacity, n_out ? n_out + first : nullptr,
+                                      mono_out ? mono_out + first : nullptr);
+        }
+        if (rcs[g] != ORBX_OK) errs[g] = g_lastError;
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < nhandles; ++g) threads.emplace_back(work, g);
+    work(0);
+    for (auto &t : threads) t.join();
+    for (int g = 0; g < nhandles; ++g)
+        if (rcs[g] != ORBX_OK) return setError(rcs[g], "handle %d (device %d): %s", g, handles[g]->prm.device, errs[g].c_str());
+    return ORBX_OK;
+}
+
+// Page-locked host memory for frames and results: copies from / to it are asynchronous and need no staging (see HostPipe).
+extern "C" void *orbx_host_alloc(size_t bytes)
+{
+    ORBX_API_ENTRY;
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); setError(ORBX_ERR_OUT_OF_MEMORY, "orbx_host_alloc(%zu bytes) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void orbx_host_free(void *p)
+{
+    ORBX_API_ENTRY;
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
