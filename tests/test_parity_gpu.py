@@ -396,6 +396,14 @@ def _gpu_check_subprocess(extra_env, arg_sets):
         assert out.returncode == 0 and "ALL STAGES BIT-IDENTICAL" in out.stdout, out.stdout[-2000:]
 
 
+@pytest.mark.parametrize("clcap", ["192", "8"])
+def test_pyr_fast_wave_per_cell_kernel(pkg, clcap):
+    """k_pyr_fast_cw (ORBX_PF_KERNEL=2: a wave per FAST cell, corners as an order-preserving list per cell) must give the bytes of the
+    phase-organised kernel.  clcap 8: every cell with more than 8 corners takes the scanning path for NMS and emission."""
+    _gpu_check_subprocess({"ORBX_PF_KERNEL": "2", "ORBX_PF_CLCAP": clcap},
+                          (["640", "480", "1000", "2"], ["752", "480", "1200", "1"], ["512", "512", "1500", "20"]))
+
+
 def test_quadtree_pool_compaction_path(pkg):
     """The serial quadtree formulation (k_quadtree_serial) recycles node ids by compacting its tombstoned list when the node
     pool runs low.  With the default pool (2 * quota + 64) that path is rare; force the serial kernel with a tiny pool in a

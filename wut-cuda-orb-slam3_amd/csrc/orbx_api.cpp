@@ -555,6 +555,17 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                     g.rsMaxDy * 8, g.gqCap, g.groupCells * g.wCell, g.ldsBytes);
         if (g.ldsBytes > 64 * 1024)
             return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
+        // k_pyr_fast_cw: 8 rings of 128 u16 (one per wave), a list of cwClCap u16 per cell (ring-test survivors in raster order, compacted in
+        // place to the keypoints of the cell; a cell with more corners than that takes the scanning path - ORBX_PF_CLCAP lowers it for tests)
+        static const int clCapEnv = [] { const char *e = getenv("ORBX_PF_CLCAP"); return e ? std::min(std::max(atoi(e), 8), 2048) : 192; }();
+        g.cwClCap = (clCapEnv + 7) & ~7;
+        g.cwXt = g.oScore + (g.hCell + 2) * g.scorePitch;
+        g.cwYt = g.cwXt + g.rsMaxDx * 8;
+        g.cwGq = g.cwYt + (int)roundUp((size_t)g.rsMaxDy * 8, 16);
+        g.cwCl = g.cwGq + 8 * 128 * 2;
+        g.cwLdsBytes = (int)roundUp((size_t)g.cwCl + (size_t)g.groupCells * g.cwClCap * 2, 16);
+        if (g.cwLdsBytes > 64 * 1024)
+            return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.cwLdsBytes);
     }
     // tile records of k_pyr_fast (OrbxPfTile): everything that depends only on (cell-row, cell group) of a level
     std::vector<int> tileOffs(nl, 0);
@@ -585,7 +596,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                 if (rowBeg) {
                     t.dy0 = rowBeg[crow]; t.dy1 = rowBeg[crow + 1]; t.dx0 = colBeg[grp]; t.dx1 = colBeg[grp + 1];
                     t.q0 = t.dx0 >> 2; t.nq = ((t.dx1 + 3) >> 2) - t.q0;
-                    t.RC = t.nq > 0 ? std::max(1, 512 / t.nq) : 1;  // resize row classes: 512 lanes over (row class, 4-pixel group)
+                    t.RC = t.nq > 0 ? std::max(1, orbxPyrFastThreads() / t.nq) : 1;  // resize row classes: 512 lanes over (row class, 4-pixel group)
                 }
             }
         const int *ri = (const int *)recs.data();

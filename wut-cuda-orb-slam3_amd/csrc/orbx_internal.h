@@ -43,6 +43,9 @@ struct OrbxLevelGeom {
     // zeroing loop), resize x / y tables and - in the same bytes, first written after the barrier behind the pre-test - the corner
     // queue, group queue, per-column cell info (oGqm: unused)
     int oScore, oBits, oXt, oYt, oGq, oCq, oGqm, oColInfo;
+    // LDS layout of k_pyr_fast_cw (a wave per FAST cell): pixel tile | score tile | resize tables (never aliased: no barrier separates the
+    // resize from the cell phase) | one ring of pre-test survivors per wave | one corner / keypoint list per cell
+    int cwXt, cwYt, cwGq, cwCl, cwClCap, cwLdsBytes;
 };
 
 // One tile of the fused pyramid+FAST kernel (cell-row x group of cells), built by the host per level and image size: everything
@@ -203,6 +206,7 @@ hipError_t orbxLaunchPyrChain(hipStream_t st, int nframes, int nlevels, const ui
 hipError_t orbxLaunchResizeLevel(hipStream_t st, int nframes, const uint8_t *src, int srcPitch, long long srcFrameStride, int sh, uint8_t *dst,
                                  int dw, int dh, int dstPitch, long long dstFrameStride, OrbxResizeTabs tabs);
 size_t orbxPyrFastArgsBytes();
+int orbxPyrFastThreads();  // threads per workgroup of k_pyr_fast (the resize phase deals that many lanes over row classes x pixel groups)
 void orbxFillPyrFastLevelArgs(void *out, int nframes, const OrbxLevelGeom &g, const uint8_t *src, int srcPitch, long long srcFrameStride,
                               const OrbxPfTile *tiles, uint32_t *cand, long long candFrameStride, int *tileCount, int tilesPerFrame, int iniTh,
                               int minTh);

@@ -256,9 +256,12 @@ struct PyrFastArgs {
 };
 
 #define PF_MAX_GROUP_CELLS 32
+#ifndef PF_NT
 #define PF_NT 512           // threads per workgroup: 8 waves x 3 workgroups/CU (LDS-limited); with the queue-based two-round
                             // FAST the kernel is barrier/latency-bound and 512 threads measured 3.79 -> 3.14 ms per batch
+#endif
 #define PF_NW (PF_NT / 64)
+int orbxPyrFastThreads() { return PF_NT; }
 #define PF_XO 16      // LDS column of image column ax0 (keeps every strip window inside the tile row)
 #define PF_QCAP 1024  // corner queue entries (u16: row << 9 | interior column)
 
@@ -734,6 +737,392 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
     PF_STAMP(12);
 }
 
+// =====================================================================================================
+// k_pyr_fast_cw — the same fused pyramid level + tileCalcKeypoints, with the FAST rounds organised by CELL instead of by phase.
+//
+// tileCalcKeypoints (reference src/ORBextractor.cc:867-950) is independent per 35-px cell: cv::FAST on the cell's ROI, NMS inside the
+// ROI, the retry with minThFAST if THAT cell found nothing (:908-925), emission cell by cell in raster order (:941-944).  k_pyr_fast runs
+// every step of that as a phase of the whole workgroup (pre-test | ring test | score | NMS, with a barrier and shared LDS queues
+// between them, a second set of phases for the empty cells, then an emission pass over per-cell bitmaps): the sparse phases keep 2 - 5
+// of the 8 waves busy, and a workgroup lived 33 k cycles for ~1070 vector instructions per wave (tools/pf_timing.py).
+// Here, once the tile and the resize tables are in LDS, nothing is shared any more:
+//   * all waves resize (dense, as before), then wave c takes cell c - no barrier in between;
+//   * a cell is ONE order-preserving stream through one wave: 4-pixel groups in raster order -> pre-test -> ring of survivors (wave
+//     private, 128 entries) -> full ring test whenever 64 are queued (always a full wave) -> list of corners of the cell, still in
+//     raster order -> scores (dense, 64 at a time) -> cell-local 3x3 NMS compacts the list in place.  Queue slots are ballot prefix
+//     counts on wave-uniform counters: no LDS atomics, no bitmaps, no per-column cell table;
+//   * an empty cell simply runs again with minThFAST on its own wave, while the other waves are done;
+//   * what is left of the list IS the cell's keypoints in emission order: after the one barrier that makes the per-cell counts
+//     visible, every wave copies its cells' lists to the tile's candidate slot at the cells' prefix offsets.
+// Three barriers per workgroup instead of six (ten with a second round).  A cell with more corners than the list holds (cwClCap,
+// pathological density) scores in place and takes NMS + emission by scanning its score rows (same order, same result).
+// =====================================================================================================
+#define PFC_GQ 128  // entries of a wave's ring of pre-test survivors (row << 9 | LDS column / 4)
+
+// pre-test of ONE 4-pixel group (see fast_group_pretest): centre dword V with its left / right neighbours in the row, the dwords three
+// rows below (ring position 0) and above (8)
+__device__ __forceinline__ uint32_t fast_group_pretest1(uint32_t V, uint32_t Vl_, uint32_t Vr_, uint32_t Pdn, uint32_t Pup, uint32_t T4, uint32_t C4)
+{
+    const uint32_t Vl = V & SW_L;
+    const uint32_t tS = (V | SW_H) - (T4 & SW_L);
+    const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
+    const uint32_t ltVT = (~V & T4) | (~(V ^ T4) & ~tS);
+    const uint32_t HI = (Vl + (T4 & SW_L)) ^ ((V ^ T4) & SW_H);
+    const uint32_t tC = (C4 | SW_H) - Vl;
+    const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);
+    const uint32_t Kd = SW_H - (LO & SW_L);
+    const uint32_t HIh = HI | SW_H;
+    uint32_t D[4], B[4];
+    const uint32_t P[4] = {Pdn, __builtin_amdgcn_alignbyte(Vr_, V, 3), Pup, __builtin_amdgcn_alignbyte(V, Vl_, 1)};  // k = 0, 4, 8, 12
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t Pl = P[j] & SW_L;
+        const uint32_t td = Pl + Kd;
+        const uint32_t tb = HIh - Pl;
+        D[j] = (~P[j] & LO) | (~(P[j] ^ LO) & ~td);
+        B[j] = (~HI & P[j]) | (~(HI ^ P[j]) & ~tb);
+    }
+    const uint32_t d = (D[0] | D[2]) & (D[1] | D[3]);
+    const uint32_t b = (B[0] | B[2]) & (B[1] | B[3]);
+    return ((d & ~ltVT) | (b & ~ltCV)) & SW_H;
+}
+
+// strict 3x3 maximum inside the cell's columns [cc0, cc1) (cv::FAST's nonmax suppression on the cell's ROI): score row r + 1 of the
+// score tile is tile row r; rows 0 and THi + 1 stay zero
+__device__ __forceinline__ bool pfc_is_max(const uint8_t *score, int sp, int r, int c, int cc0, int cc1)
+{
+    const uint8_t *s1p = score + (r + 1) * sp + c, *s0p = s1p - sp, *s2p = s1p + sp;
+    const int sc = s1p[0];
+    if (sc <= 0) return false;
+    int mx = max(s0p[0], s2p[0]);
+    if (c != cc0) mx = max(mx, max(s0p[-1], max(s1p[-1], s2p[-1])));
+    if (c != cc1 - 1) mx = max(mx, max(s0p[1], max(s1p[1], s2p[1])));
+    return sc > mx;
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast_cw(PyrFastArgs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typedef const __attribute__((address_space(4))) PyrFastArgs KArgs;
+    typedef const __attribute__((address_space(4))) OrbxPfTile TileK;
+    int f, tileId;
+    auto K = [&]() -> KArgs & {
+        KArgs *p = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return *p;
+    };
+    {
+        KArgs &a = K();
+        if (!xcd_decode(a.nframes, a.g.nTiles, f, tileId)) return;
+    }
+    auto T = [&]() -> TileK & { TileK *p = (TileK *)(unsigned long long)K().tiles + tileId; asm volatile("" : "+s"(p)); return *p; };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: everything per cell stays in SGPRs
+    auto otid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    __shared__ int cnt[PF_MAX_GROUP_CELLS];  // keypoints per cell (bit 31: the cell took the scanning path), written by the cell's wave
+    uint8_t *const tile = lds;
+
+    // ---- phase 0: stage the tile and the resize tables (as k_pyr_fast) ------------------------------------------------------------
+    {
+        KArgs &a = K();
+        TileK &t = T();
+        const int tp = a.g.tilePitch;
+        const int ly0 = t.ly0, nRowsL = t.nRowsL, ax0 = t.ax0, nV = t.nV, nVec = t.nVec;
+        const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
+        const bool doResize = a.dst != nullptr;
+        const int ndx = doResize ? t.dx1 - t.dx0 : 0, ndy = doResize ? t.dy1 - t.dy0 : 0, dx0 = t.dx0, dy0 = t.dy0;
+        const float invNV = __builtin_amdgcn_rcpf((float)nV);
+        uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;
+        int tvOff0 = -1, tvOff1 = -1;
+        if (a.srcAlign == 16) {
+            const int it0 = otid(), it1 = it0 + PF_NT;
+            if (it0 < nVec) {
+                const int r = (int)(((float)it0 + 0.5f) * invNV), c = it0 - r * nV;
+                tv0 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+                tvOff0 = r * tp + PF_XO + c * 16;
+            }
+            if (it1 < nVec) {
+                const int r = (int)(((float)it1 + 0.5f) * invNV), c = it1 - r * nV;
+                tv1 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+                tvOff1 = r * tp + PF_XO + c * 16;
+            }
+        }
+        int xo_ = 0, xw_ = 0, yo_ = 0, yw_ = 0;
+        if (doResize) {
+            const int i = otid();
+            if (i < ndx) { xo_ = a.tabs.xofs[dx0 + i]; xw_ = a.tabs.xab[dx0 + i]; }
+            if (i < ndy) { yo_ = a.tabs.yofs[dy0 + i]; yw_ = a.tabs.yab[dy0 + i]; }
+        }
+        {   // zero the score tile (under the latency of the loads above)
+            uint4 z = make_uint4(0, 0, 0, 0);
+            uint4 *zs = (uint4 *)(lds + a.g.oScore);
+            const int nz = (a.g.cwXt - a.g.oScore) >> 4;
+#pragma nounroll
+            for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
+        }
+        if (a.srcAlign == 16) {
+            if (tvOff0 >= 0) *(uint4 *)(tile + tvOff0) = tv0;
+            if (tvOff1 >= 0) *(uint4 *)(tile + tvOff1) = tv1;
+#pragma nounroll
+            for (int it = otid() + 2 * PF_NT; it < nVec; it += PF_NT) {
+                const int r = (int)(((float)it + 0.5f) * invNV);
+                const int c = it - r * nV;
+                const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
+                *(uint4 *)(tile + r * tp + PF_XO + c * 16) = v;
+            }
+        } else if (a.srcAlign == 4) {
+            const int nDw = (t.lx1 - ax0 + 3) >> 2;
+#pragma nounroll
+            for (int r = wave; r < nRowsL; r += PF_NW) {
+                const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0);
+                uint32_t *trow = (uint32_t *)(tile + r * tp + PF_XO);
+#pragma nounroll
+                for (int c = otid() & 63; c < nDw; c += 64) trow[c] = srow[c];
+            }
+        } else {
+            const int nB = t.lx1 - ax0;
+#pragma nounroll
+            for (int r = wave; r < nRowsL; r += PF_NW) {
+                const uint8_t *srow = srcF + (size_t)(ly0 + r) * a.srcPitch + ax0;
+                uint8_t *trow = tile + r * tp + PF_XO;
+#pragma nounroll
+                for (int c = otid() & 63; c < nB; c += 64) trow[c] = srow[c];
+            }
+        }
+        if (DBG && (a.phases >> 4) == 1) return;
+        if (doResize) {
+            int2 *xt = (int2 *)(lds + a.g.cwXt), *yt = (int2 *)(lds + a.g.cwYt);
+            const int colOf0 = t.colOf0, hm1 = a.g.h - 1;
+            auto xEntry = [&](int sx, int w2) { return make_int2(sx + colOf0, w2); };
+            auto yEntry = [&](int sy, int w2) {
+                const int sy0 = min(max(sy, 0), hm1) - ly0, sy1 = min(max(sy + 1, 0), hm1) - ly0;
+                return make_int2((sy0 * tp) | ((sy1 * tp) << 16), w2);
+            };
+            const int i0 = otid();
+            if (i0 < ndx) xt[i0] = xEntry(xo_, xw_);
+            if (i0 < ndy) yt[i0] = yEntry(yo_, yw_);
+#pragma nounroll
+            for (int i = i0 + PF_NT; i < ndx; i += PF_NT) xt[i] = xEntry(a.tabs.xofs[dx0 + i], a.tabs.xab[dx0 + i]);
+#pragma nounroll
+            for (int i = i0 + PF_NT; i < ndy; i += PF_NT) yt[i] = yEntry(a.tabs.yofs[dy0 + i], a.tabs.yab[dy0 + i]);
+        }
+    }
+    __syncthreads();
+    if (DBG && (K().phases >> 4) == 2) return;
+
+    // ---- phase 1: next pyramid level (as k_pyr_fast) ------------------------------------------------------------------------------
+    {
+        KArgs &a = K();
+        if (a.dst) {
+            TileK &t = T();
+            const int2 *xt = (const int2 *)(lds + a.g.cwXt), *yt = (const int2 *)(lds + a.g.cwYt);
+            uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
+            const int dstPitch = a.dstPitch;
+            const int dx0 = t.dx0, dx1 = t.dx1, dy0 = t.dy0, dy1 = t.dy1;
+            const int q0 = t.q0, nq = t.nq, RC = t.RC, q1 = q0 + nq;
+            const int tt = otid();
+            const int rc = nq >= PF_NT ? 0 : (int)(((float)tt + 0.5f) * __builtin_amdgcn_rcpf((float)nq));
+            for (int q = q0 + (tt - rc * nq); q < q1 && rc < RC; q += PF_NT) {
+                int ca[4], wa[4], wb[4];
+                bool ok[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int dx = q * 4 + j;
+                    ok[j] = dx >= dx0 && dx < dx1;
+                    const int2 e = xt[min(max(dx, dx0), dx1 - 1) - dx0];
+                    ca[j] = e.x;
+                    wa[j] = (short)(e.y & 0xFFFF);
+                    wb[j] = e.y >> 16;
+                }
+                const bool full = ok[0] && ok[3];
+#pragma nounroll
+                for (int dy = dy0 + rc; dy < dy1; dy += RC) {
+                    const int2 ye = yt[dy - dy0];
+                    const int b0 = ye.y & 0xFFFF, b1 = (unsigned)ye.y >> 16;
+                    const uint8_t *r0 = tile + (ye.x & 0xFFFF);
+                    const uint8_t *r1 = tile + ((unsigned)ye.x >> 16);
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int h0 = r0[ca[j]] * wa[j] + r0[ca[j] + 1] * wb[j];
+                        const int h1 = r1[ca[j]] * wa[j] + r1[ca[j] + 1] * wb[j];
+                        const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+                        packed |= v << (8 * j);
+                    }
+                    uint8_t *drow = dstF + (size_t)dy * dstPitch + q * 4;
+                    if (full) *(uint32_t *)drow = packed;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ok[j]) drow[j] = (uint8_t)(packed >> (8 * j));
+                    }
+                }
+            }
+        }
+    }
+    if (DBG && (K().phases >> 4) == 3) return;
+
+    // ---- phase 2: FAST-9/16 + NMS, a wave per cell, both rounds ---------------------------------------------------------------------
+    {
+        KArgs &a = K();
+        TileK &t = T();
+        const int tp = a.g.tilePitch, sp = a.g.scorePitch, wCell = a.g.wCell, clCap = a.g.cwClCap;
+        uint8_t *score = lds + a.g.oScore - t.cInt0;  // indexed with LDS columns like the pixel tile
+        uint16_t *gq = (uint16_t *)(lds + a.g.cwGq) + wave * PFC_GQ;
+        const int cInt0 = t.cInt0, cInt1 = t.cInt1, nCells = t.nCells, THi = t.THi, rowOff = t.rowOff;
+        const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
+        const int stop = DBG ? a.phases >> 4 : 0;
+        for (int c = wave; c < nCells; c += PF_NW) {
+            uint16_t *cl = (uint16_t *)(lds + a.g.cwCl) + c * clCap;
+            const int cc0 = cInt0 + c * wCell, cc1 = min(cc0 + wCell, cInt1);
+            const int gF = cc0 >> 2, nG = ((cc1 - 1) >> 2) - gF + 1;  // the cell's 4-pixel groups per row (LDS columns [4 g, 4 g + 4))
+            const int nItems = nG * THi;
+            const float invG = __builtin_amdgcn_rcpf((float)nG);
+            int nk = 0;
+            bool ovf = false;
+            for (int round = 0; round < 2; ++round) {
+                const int th = round == 0 ? iniTh : minTh;
+                const int thEff = max(th, 1);
+                const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
+                int it0 = 0, nc = 0, scored = 0;
+                unsigned qh = 0, qt = 0;
+                ovf = false;
+                for (;;) {
+                    // (A) pre-test of the next 64 groups (raster order) while fewer than 64 survivors are queued
+                    while (it0 < nItems && (int)(qt - qh) < 64) {
+                        const int it = it0 + lane;
+                        bool pass = false;
+                        unsigned e = 0;
+                        if (it < nItems) {
+                            const int r = (int)(((float)it + 0.5f) * invG), g = gF + (it - r * nG);
+                            const uint8_t *wp = tile + (rowOff + r - 3) * tp + 4 * g;
+                            const uint32_t *q = (const uint32_t *)(wp + 3 * tp);
+                            pass = fast_group_pretest1(q[0], q[-1], q[1], *(const uint32_t *)(wp + 6 * tp), *(const uint32_t *)wp, T4, C4) != 0;
+                            e = ((unsigned)r << 9) | (unsigned)g;
+                        }
+                        const unsigned long long b = __ballot(pass);
+                        if (b) {
+                            if (pass) gq[(qt + mbcnt64(b)) & (PFC_GQ - 1)] = (uint16_t)e;
+                            qt += (unsigned)__popcll(b);
+                        }
+                        it0 += 64;
+                    }
+                    const int avail = (int)(qt - qh);
+                    const bool last = it0 >= nItems;
+                    // (B) full ring test of up to 64 queued groups -> corners of the cell, appended in raster order
+                    if (avail >= 64 || (last && avail > 0)) {
+                        const int m = min(avail, 64);
+                        if (!(DBG && stop == 4)) {
+                            unsigned msk = 0;
+                            int r = 0, c4 = 0;
+                            if (lane < m) {
+                                const unsigned e = gq[(qh + lane) & (PFC_GQ - 1)];
+                                r = e >> 9;
+                                c4 = 4 * (int)(e & 511);
+                                const uint32_t fl = fast_group_flags_lds(tile + (rowOff + r - 3) * tp + c4 - 4, tp, T4, C4);
+                                const int plo = max(cc0 - c4, 0), phi = min(cc1 - c4, 4);
+                                msk = ((fl * 0x00204081u) >> 28) & (0xFu >> (4 - phi)) & (0xFu << plo);
+                            }
+                            const unsigned ncn = __popc(msk);  // 0..4
+                            const unsigned long long n1 = __ballot((ncn & 1u) != 0), n2 = __ballot((ncn & 2u) != 0), n4 = __ballot((ncn & 4u) != 0);
+                            if (n1 | n2 | n4) {
+                                int pos = nc + (int)(mbcnt64(n1) + 2u * mbcnt64(n2) + 4u * mbcnt64(n4));
+                                nc += __popcll(n1) + 2 * __popcll(n2) + 4 * __popcll(n4);
+                                while (msk) {
+                                    const int k = __ffs(msk) - 1;
+                                    msk &= msk - 1;
+                                    if (pos < clCap) cl[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
+                                    else pf_score_one(tile, score, tp, sp, rowOff, r, c4 + k, thEff);  // list full: score in place
+                                    ++pos;
+                                }
+                                if (nc > clCap) ovf = true;
+                            }
+                        }
+                        qh += (unsigned)m;
+                    }
+                    // (C) scores of the listed corners, 64 at a time
+                    const int listed = min(nc, clCap);
+                    const bool drained = last && qt == qh;
+                    if (listed - scored >= 64 || (drained && listed > scored)) {
+                        const int m = min(listed - scored, 64);
+                        if (!(DBG && (stop == 4 || stop == 5)) && lane < m) {
+                            const unsigned e = cl[scored + lane];
+                            pf_score_one(tile, score, tp, sp, rowOff, e >> 9, (int)(e & 511) + cInt0, thEff);
+                        }
+                        scored += m;
+                    }
+                    if (drained && scored >= listed) break;
+                }
+                // (D) cell-local NMS: the list shrinks to the cell's keypoints, order kept
+                nk = 0;
+                if (DBG && stop >= 4 && stop <= 6) break;
+                if (!ovf) {
+                    for (int i = 0; i < nc; i += 64) {
+                        bool keep = false;
+                        unsigned e = 0;
+                        if (i + lane < nc) {
+                            e = cl[i + lane];
+                            keep = pfc_is_max(score, sp, e >> 9, (int)(e & 511) + cInt0, cc0, cc1);
+                        }
+                        const unsigned long long b = __ballot(keep);
+                        if (keep) cl[nk + (int)mbcnt64(b)] = (uint16_t)e;  // (at or below every slot this iteration read)
+                        nk += __popcll(b);
+                    }
+                } else {
+                    for (int r = 0; r < THi; ++r)
+                        for (int x0 = cc0; x0 < cc1; x0 += 64) {
+                            const int cc = x0 + lane;
+                            nk += __popcll(__ballot(cc < cc1 && pfc_is_max(score, sp, r, cc, cc0, cc1)));
+                        }
+                }
+                if (nk > 0 || minTh >= iniTh || (DBG && stop)) break;  // the cell found nothing: once more with minThFAST (:925)
+            }
+            if (lane == 0) cnt[c] = nk | (ovf ? (int)0x80000000 : 0);
+        }
+        if (DBG && stop) return;
+    }
+    __syncthreads();
+
+    // ---- phase 3: emission: cells in order, raster inside a cell (== tileCalcKeypoints' emission order) -----------------------------
+    {
+        KArgs &a = K();
+        TileK &t = T();
+        const int sp = a.g.scorePitch, wCell = a.g.wCell, clCap = a.g.cwClCap;
+        const uint8_t *score = lds + a.g.oScore - t.cInt0;
+        const int nCells = t.nCells, THi = t.THi, cInt0 = t.cInt0, cInt1 = t.cInt1;
+        const int xBias = t.colOf0 + ORBX_BORDER, yBias = t.ty0 - ORBX_BORDER;
+        uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + a.g.candBase + (size_t)tileId * a.g.slotCap;
+        const int mine = lane < nCells ? cnt[lane & (PF_MAX_GROUP_CELLS - 1)] : 0;
+        int tot;
+        const int cellBase = wave_excl_scan(mine & 0x7FFFFFFF, tot);
+        if (tid == 0) a.tileCount[(size_t)f * a.tilesPerFrame + a.g.tileBase + tileId] = tot;
+        for (int c = wave; c < nCells; c += PF_NW) {
+            const int base = __builtin_amdgcn_readlane(cellBase, c), cw = __builtin_amdgcn_readlane(mine, c);
+            const int n = cw & 0x7FFFFFFF;
+            if (cw >= 0) {
+                const uint16_t *cl = (const uint16_t *)(lds + a.g.cwCl) + c * clCap;
+                for (int i = lane; i < n; i += 64) {
+                    const unsigned e = cl[i];
+                    const int r = e >> 9, cc = (int)(e & 511) + cInt0;
+                    slot[base + i] = ORBX_PACK(cc - xBias, yBias + r, score[(r + 1) * sp + cc]);
+                }
+            } else {
+                const int cc0 = cInt0 + c * wCell, cc1 = min(cc0 + wCell, cInt1);
+                int o = base;
+                for (int r = 0; r < THi; ++r)
+                    for (int x0 = cc0; x0 < cc1; x0 += 64) {
+                        const int cc = x0 + lane;
+                        const bool keep = cc < cc1 && pfc_is_max(score, sp, r, cc, cc0, cc1);
+                        const unsigned long long b = __ballot(keep);
+                        if (keep) slot[o + (int)mbcnt64(b)] = ORBX_PACK(cc - xBias, yBias + r, score[(r + 1) * sp + cc]);
+                        o += __popcll(b);
+                    }
+            }
+        }
+    }
+}
+
 // cv::resize INTER_LINEAR fixed point (the same arithmetic as the resize phase of k_pyr_fast) from level l to level l + 1
 // in global memory: 4 destination pixels per lane.  Only used in front of k_pyr_fast_levels, where the launch chain - not the
 // arithmetic - is the cost.
@@ -998,6 +1387,16 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
     }
     dim3 grid(xcd_grid(nframes, g.nTiles));
     static const int ldsPad = [] { const char *e = getenv("ORBX_PF_LDS_PAD"); return e ? atoi(e) : 0; }();  // occupancy experiments
+    // ORBX_PF_KERNEL: 1 (default) the phase-organised kernel; 2 a wave per cell (k_pyr_fast_cw: three barriers instead of six to ten, no
+    // atomics, no bitmaps - and 16 % MORE vector instructions, because every sparse stage runs per cell at a fraction of a wave: 2.34
+    // against 1.80 ms per 1024 VGA frames.  The kernel sits at the practical issue rate of its instruction mix either way
+    // (tools/experiments/ring_rate.hip), so the instruction count decides; kept as the measured alternative)
+    static const int pfKernel = [] { const char *e = getenv("ORBX_PF_KERNEL"); return e ? atoi(e) : 1; }();
+    if (pfKernel == 2) {
+        if (a.phases == 15) hipLaunchKernelGGL(k_pyr_fast_cw<false>, grid, dim3(PF_NT), g.cwLdsBytes + ldsPad, st, a);
+        else hipLaunchKernelGGL(k_pyr_fast_cw<true>, grid, dim3(PF_NT), g.cwLdsBytes + ldsPad, st, a);
+        return hipGetLastError();
+    }
     if (a.phases == 15) hipLaunchKernelGGL(k_pyr_fast<false>, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
     else hipLaunchKernelGGL(k_pyr_fast<true>, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
     return hipGetLastError();
