@@ -645,14 +645,24 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                 const unsigned nc = __popc(m);  // 0..4
                 const unsigned long long n1 = __ballot((nc & 1u) != 0), n2 = __ballot((nc & 2u) != 0), n4 = __ballot((nc & 4u) != 0);
                 if (n1 | n2 | n4) {
-                    unsigned pos = wave_queue_alloc(&cqCountR[round], (unsigned)(__popcll(n1) + 2 * __popcll(n2) + 4 * __popcll(n4))) +
-                                   mbcnt64(n1) + 2u * mbcnt64(n2) + 4u * mbcnt64(n4);
-                    while (m) {
-                        const int k = __ffs(m) - 1;
-                        m &= m - 1;
-                        if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
-                        else pf_score_one(tile, score, tp, sp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
-                        ++pos;
+                    const unsigned total = (unsigned)(__popcll(n1) + 2 * __popcll(n2) + 4 * __popcll(n4));
+                    const unsigned base = wave_queue_alloc(&cqCountR[round], total);
+                    unsigned pos = base + mbcnt64(n1) + 2u * mbcnt64(n2) + 4u * mbcnt64(n4);
+                    if (base + total <= PF_QCAP) {
+                        // (the usual case, wave-uniform) four predicated stores: a loop over the set bits runs as often as the lane
+                        // with the most corners needs, ~24 vector instructions per turn
+                        const int e0 = (r << 9) + (c4 - cInt0);  // (c4 - cInt0 may be negative for a group that straddles the left edge)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (m & (1u << k)) cq[pos++] = (uint16_t)(e0 + k);
+                    } else {
+                        while (m) {
+                            const int k = __ffs(m) - 1;
+                            m &= m - 1;
+                            if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
+                            else pf_score_one(tile, score, tp, sp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
+                            ++pos;
+                        }
                     }
                 }
             }
