@@ -310,6 +310,38 @@ static int runComputeBoW()
     return 0;
 }
 
+// frames dealt over several handles from one process; one handle per GPU where the box has several, two on GPU 0 otherwise
+static int runShardedBatch()
+{
+    const int w = 640, h = 480, B = 21;
+    std::vector<uint8_t> imgs((size_t)B * w * h);
+    for (int f = 0; f < B; ++f) orbx_synth_frame_impl(9000 + f, w, h, imgs.data() + (size_t)f * w * h, w);
+    const int ndev = orbx_device_count();
+    std::vector<int> devices;
+    for (int d = 0; d < (ndev >= 2 ? std::min(ndev, 4) : 2); ++d) devices.push_back(ndev >= 2 ? d : 0);
+    printf("sharded batch: %d frames over %zu handles on %d device(s)\n", B, devices.size(), ndev);
+    orbx::ShardedExtractor sharded(devices, 1000, 1.2f, 8, 20, 7, w, h, /*maxBatchPerDevice=*/8, /*block=*/2);
+    std::vector<orbx::KeyPoint> kps;
+    std::vector<uint8_t> desc;
+    std::vector<int32_t> n, mono;
+    std::vector<int> lap = {100, 400};
+    sharded.extract(imgs.data(), B, w, h, w, (ptrdiff_t)w * h, lap, kps, desc, n, mono);
+    const int cap = sharded.capacity();
+    oracle_handle *ref = oracle_create(1000, 1.2f, 8, 20, 7, 0, 0);
+    std::vector<oracle_keypoint> rk(oracle_max_keypoints(ref) + 64);
+    std::vector<uint8_t> rd(rk.size() * 32);
+    for (int f = 0; f < B; f += 4) {  // every 4th frame against the oracle: blocks of both / all handles, first and later rounds
+        int rn = 0;
+        const int rmono = oracle_extract(ref, imgs.data() + (size_t)f * w * h, w, h, w, lap[0], lap[1], rk.data(), rd.data(), &rn);
+        ASSERT_EQ(mono[f], rmono);
+        ASSERT_EQ(n[f], rn);
+        ASSERT_TRUE(memcmp(kps.data() + (size_t)f * cap, rk.data(), (size_t)rn * 28) == 0);
+        ASSERT_TRUE(memcmp(desc.data() + (size_t)f * cap * 32, rd.data(), (size_t)rn * 32) == 0);
+    }
+    oracle_destroy(ref);
+    return 0;
+}
+
 int main()
 {
     // empty image -> -1 (reference src/ORBextractor.cc:1231-1232)
@@ -331,6 +363,7 @@ int main()
     if (runSearchForInitialization()) return 1;
     if (runSearchByProjection()) return 1;                           // SURVEY 8(f) rank 2, tracking searches
     if (runComputeBoW()) return 1;
+    if (runShardedBatch()) return 1;                                 // SURVEY 8(e), one process
     printf("OK host mirror\n");
     return 0;
 }

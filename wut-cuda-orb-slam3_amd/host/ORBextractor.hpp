@@ -136,6 +136,62 @@ private:
     orbx_extractor *h_ = nullptr;
 };
 
+// A stream of frames dealt over the GPUs of one node from ONE host process (frames are independent, so they shard with no
+// data-path collective): one extractor handle per device, block b of `block` consecutive frames on handle b mod G, every handle
+// driven by a std::thread of its own inside orbx_extract_batch_sharded - the way the reference runs its left and right extractor
+// side by side (src/Frame.cc:124-127) - and every frame's keypoints and descriptors at its frame index.
+class ShardedExtractor {
+public:
+    // devices: HIP ordinals, one handle each (the same ordinal may appear twice: two handles share that GPU)
+    ShardedExtractor(const std::vector<int> &devices, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int maxWidth,
+                     int maxHeight, int maxBatchPerDevice, int block = 1, int blurVariant = ORBX_BLUR_OPENCV_450, int trigMode = ORBX_TRIG_DOUBLE)
+        : block_(block)
+    {
+        for (size_t i = 0; i < devices.size(); ++i) {
+            orbx_params p;
+            orbx_default_params(&p);
+            p.nfeatures = nfeatures; p.scale_factor = scaleFactor; p.nlevels = nlevels;
+            p.ini_th_fast = iniThFAST; p.min_th_fast = minThFAST;
+            p.device = devices[i]; p.max_width = maxWidth; p.max_height = maxHeight; p.max_batch = maxBatchPerDevice;
+            p.blur_variant = blurVariant; p.trig_mode = trigMode;
+            orbx_extractor *h = nullptr;
+            if (orbx_create(&p, &h) != ORBX_OK) {
+                const std::string why = orbx_last_error();
+                for (size_t k = 0; k < h_.size(); ++k) orbx_destroy(h_[k]);
+                throw std::runtime_error("ShardedExtractor: " + why);
+            }
+            h_.push_back(h);
+        }
+        if (h_.empty()) throw std::runtime_error("ShardedExtractor: no device given");
+    }
+    ~ShardedExtractor() { for (size_t k = 0; k < h_.size(); ++k) orbx_destroy(h_[k]); }
+    ShardedExtractor(const ShardedExtractor &) = delete;
+    ShardedExtractor &operator=(const ShardedExtractor &) = delete;
+
+    int capacity() const { return orbx_max_keypoints(h_[0]); }  // rows per frame in the output arrays
+    size_t devices() const { return h_.size(); }
+
+    // nframes images of cols x rows, `step` bytes per row, `frameStep` bytes from one image to the next -> per frame f: n[f], mono[f]
+    // (= operator()'s return value), keypoints [f * capacity() ..) and descriptors [f * capacity() * 32 ..)
+    void extract(const uint8_t *images, int nframes, int cols, int rows, ptrdiff_t step, ptrdiff_t frameStep, const std::vector<int> &vLappingArea,
+                 std::vector<KeyPoint> &keypoints, std::vector<uint8_t> &descriptors, std::vector<int32_t> &n, std::vector<int32_t> &mono)
+    {
+        const int cap = capacity();
+        keypoints.resize((size_t)nframes * cap);
+        descriptors.resize((size_t)nframes * cap * 32);
+        n.assign(nframes, 0);
+        mono.assign(nframes, 0);
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        check(orbx_extract_batch_sharded(h_.data(), (int)h_.size(), block_, images, nframes, cols, rows, step, frameStep, lap0, lap1,
+                                         reinterpret_cast<orbx_keypoint *>(keypoints.data()), descriptors.data(), cap, n.data(), mono.data()),
+              "ShardedExtractor::extract");
+    }
+
+private:
+    std::vector<orbx_extractor *> h_;
+    int block_;
+};
+
 // DBoW2::BowVector / DBoW2::FeatureVector — reference Thirdparty/DBoW2/DBoW2/BowVector.h, FeatureVector.h
 typedef std::map<unsigned int, double> BowVector;
 typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
