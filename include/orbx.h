@@ -375,6 +375,53 @@ int orbx_search_by_bow_keyframes(orbx_matcher *m, const int32_t *fv1_node, const
                                  const uint8_t *desc2, const uint8_t *valid2, int n2, float nnratio, int check_orientation,
                                  int32_t *matches12);
 
+/* What the BoW-guided keyframe searches read of one KeyFrame (reference include/KeyFrame.h): keys = mvKeysUn when NLeft == -1, else
+ * mvKeys (the n_left keypoints of the left image) followed by mvKeysRight - the keypoint the reference picks with
+ * `(idx < NLeft) ? mvKeys[idx] : mvKeysRight[idx - NLeft]` (src/ORBmatcher2.cc:259-261) is then keys[idx]; desc = mDescriptors;
+ * u_right = mvuRight (NULL: no stereo keypoints); has_map_point[i] = (GetMapPoint(i) != NULL); the FeatureVector mFeatVec as
+ * orbx_vocabulary_transform returns it; scale_factors / level_sigma2 = mvScaleFactors / mvLevelSigma2. */
+typedef struct orbx_keyframe_view {
+    const orbx_keypoint *keys;
+    const uint8_t *desc;
+    int32_t n, n_left;              /* N, NLeft (-1: one camera) */
+    const float *u_right;
+    const uint8_t *has_map_point;
+    const int32_t *fv_node, *fv_start, *fv_feature;
+    int32_t nfv;
+    const float *scale_factors, *level_sigma2;
+    int32_t nlevels;
+} orbx_keyframe_view;
+
+/* The two-view geometry ORBmatcher::SearchForTriangulation derives from the keyframes' poses before its loop (src/ORBmatcher2.cc:185-214):
+ * the host computes it exactly as the reference does (Sophus / Eigen) and hands it over.
+ *   ep      = pKF2->mpCamera->project(T2w * Cw), the epipole in the second image (:189-191);
+ *   model 0 = Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:107-129): F12 = K1^-T [t12]x R12 K2^-1 (:109-112), row-major;
+ *   model 1 = KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-220): TriangulateMatches(...) > 0.0001 with
+ *             cam_left / cam_right = mvParameters of mpCamera / mpCamera2 (fx fy cx cy k0..k3), precision, and R / t:
+ *             rig == 0: R[0], t[0] = T12 = T1w * Tw2 (:200-202), both keypoints seen by cam_left;
+ *             rig != 0 (both keyframes have mpCamera2): R[2 * bRight1 + bRight2], t[...] = Tll, Tlr, Trl, Trr (:205-214), camera of a
+ *             keypoint = cam_right iff its index is >= NLeft (:319-351). */
+typedef struct orbx_triangulation_geometry {
+    float ep[2];
+    int32_t model, rig;
+    float F12[9];
+    float cam_left[8], cam_right[8], precision;
+    float R[4][9], t[4][3];
+} orbx_triangulation_geometry;
+
+/* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vector<pair<size_t, size_t>> &vMatchedPairs, bool bOnlyStereo,
+ * bool bCoarse) — reference src/ORBmatcher2.cc:179-418 (decl include/ORBmatcher.h:79-80; LocalMapping::CreateNewMapPoints).  Inside
+ * every vocabulary node the two keyframes share, each feature of pKF1 without a map point takes the feature of pKF2 without a map
+ * point at the smallest descriptor distance <= TH_LOW (the LAST one on ties: `dist > bestDist` at :293 is strict) among those that lie
+ * further than 10 sqrt(scale) px from the epipole (monocular pairs, :305-313) and satisfy the epipolar constraint (bCoarse skips it),
+ * then the rotation-histogram check.  (vbMatched2 is never set in this function: the features of pKF1 do not compete.)
+ * matches12[idx1] = idx2 or -1 (kf1->n entries); pairs (optional, 2 * kf1->n ints): vMatchedPairs as (idx1, idx2) in increasing idx1.
+ * Returns nmatches (>= 0) or a negative status. */
+int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyframe_view *kf1, const orbx_keyframe_view *kf2,
+                                  const orbx_triangulation_geometry *geometry, int only_stereo, int coarse, int check_orientation,
+                                  int32_t *matches12, int32_t *pairs);
+
+
 /* void Frame::UndistortKeyPoints() — reference src/Frame.cc:777-811 (decl include/Frame.h): mvKeysUn from mvKeys.
  * k4 = fx, fy, cx, cy of static_cast<Pinhole*>(mpCamera)->toK(); dist = mDistCoef (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]], up to
  * 12 floats); knew4 = fx, fy, cx, cy of mK.  dist[0] == 0 (or ndist == 0) copies, as the reference does; otherwise

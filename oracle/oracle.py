@@ -88,6 +88,7 @@ def lib() -> ctypes.CDLL:
                                            c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
         L.oracle_search_by_bow_keyframes.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                      c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
+        L.oracle_search_for_triangulation.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
         _lib = L
@@ -484,3 +485,16 @@ def search_by_bow_keyframes(fv1, keys1, desc1, valid1, fv2, keys2, desc2, valid2
                                              k2.ctypes.data, d2.ctypes.data, v2.ctypes.data, len(k2), float(nnratio),
                                              int(bool(check_orientation)), matches.ctypes.data)
     return n, matches
+
+
+def search_for_triangulation(kf1, kf2, geometry, only_stereo=False, coarse=False, check_orientation=True):
+    """ORBmatcher::SearchForTriangulation (reference src/ORBmatcher2.cc:179-418) -> (nmatches, pairs[nmatches, 2], matches12[n1]).
+    kf1 / kf2 / geometry: the ctypes structures of the package's keyframe_view() / triangulation_geometry() - oracle_keyframe_view and
+    oracle_triangulation_geometry have the same layout."""
+    import ctypes
+    v1, v2 = kf1[0], kf2[0]
+    matches = np.full(v1.n, -1, np.int32)
+    pairs = np.zeros((max(v1.n, 1), 2), np.int32)
+    n = lib().oracle_search_for_triangulation(ctypes.addressof(v1), ctypes.addressof(v2), ctypes.addressof(geometry), int(bool(only_stereo)),
+                                              int(bool(coarse)), int(bool(check_orientation)), matches.ctypes.data, pairs.ctypes.data)
+    return n, pairs[:n].copy(), matches

@@ -1876,3 +1876,111 @@ void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t str
 }
 
 }  // extern "C"
+
+// =====================================================================================================================================
+// ORBmatcher::SearchForTriangulation — reference src/ORBmatcher2.cc:179-418, with Pinhole::epipolarConstrain
+// (src/CameraModels/Pinhole.cpp:107-129) and KannalaBrandt8::epipolarConstrain (src/CameraModels/KannalaBrandt8.cpp:216-220).  The pose
+// algebra in front of the loop (:185-214: epipole, T12 / Tll .. Trr, F12 = K1^-T [t12]x R12 K2^-1) is Sophus / Eigen code of the caller
+// and arrives as `g`; everything per feature pair is restated here in the reference's float operations, in source order, un-fused.
+// =====================================================================================================================================
+extern "C" int oracle_search_for_triangulation(const oracle_keyframe_view *kf1, const oracle_keyframe_view *kf2,
+                                               const oracle_triangulation_geometry *g, int only_stereo, int coarse, int check_orientation,
+                                               int32_t *matches12, int32_t *pairs)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    const bool rig = g->rig != 0;  // pKF1->mpCamera2 && pKF2->mpCamera2
+    int nmatches = 0;
+    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;     // vector<int> vMatches12(pKF1->N, -1)   (:223)
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int f1it = 0, f2it = 0;
+    const int f1end = kf1->nfv, f2end = kf2->nfv;
+    while (f1it != f1end && f2it != f2end) {
+        if (kf1->fv_node[f1it] == kf2->fv_node[f2it]) {
+            for (int i1 = kf1->fv_start[f1it]; i1 < kf1->fv_start[f1it + 1]; i1++) {
+                const int idx1 = kf1->fv_feature[i1];
+                if (kf1->has_map_point[idx1]) continue;                                   // :246-252
+                const bool bStereo1 = !rig && kf1->u_right && kf1->u_right[idx1] >= 0;     // :254 (!pKF1->mpCamera2 && mvuRight[idx1] >= 0)
+                if (only_stereo && !bStereo1) continue;
+                const oracle_keypoint &kp1 = kf1->keys[idx1];                              // :259-261
+                const bool bRight1 = !(kf1->n_left == -1 || idx1 < kf1->n_left);
+                const uint8_t *d1 = kf1->desc + (size_t)idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = kf2->fv_start[f2it]; i2 < kf2->fv_start[f2it + 1]; i2++) {
+                    const int idx2 = kf2->fv_feature[i2];
+                    if (kf2->has_map_point[idx2]) continue;                               // :275-279 (vbMatched2 is never set)
+                    const bool bStereo2 = !rig && kf2->u_right && kf2->u_right[idx2] >= 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = oracle_hamming256(d1, kf2->desc + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;                       // :293
+                    const oracle_keypoint &kp2 = kf2->keys[idx2];
+                    const bool bRight2 = !(kf2->n_left == -1 || idx2 < kf2->n_left);
+                    if (!bStereo1 && !bStereo2 && !rig) {                                 // :302-311
+                        const float distex = g->ep[0] - kp2.x;
+                        const float distey = g->ep[1] - kp2.y;
+                        if (distex * distex + distey * distey < 100 * kf2->scale_factors[kp2.octave]) continue;
+                    }
+                    bool ok = coarse != 0;
+                    if (!ok) {
+                        const float sigmaLevel = kf1->level_sigma2[kp1.octave], unc = kf2->level_sigma2[kp2.octave];
+                        if (g->model == 0) {  // Pinhole::epipolarConstrain
+                            const float *F = g->F12;  // F12(i, j) = F[3 * i + j]
+                            const float a = kp1.x * F[0] + kp1.y * F[3] + F[6];
+                            const float b = kp1.x * F[1] + kp1.y * F[4] + F[7];
+                            const float c = kp1.x * F[2] + kp1.y * F[5] + F[8];
+                            const float num = a * kp2.x + b * kp2.y + c;
+                            const float den = a * a + b * b;
+                            if (den == 0) ok = false;
+                            else {
+                                const float dsqr = num * num / den;
+                                ok = dsqr < 3.84 * unc;
+                            }
+                        } else {  // KannalaBrandt8::epipolarConstrain: TriangulateMatches(...) > 0.0001f
+                            const int k = rig ? 2 * (int)bRight1 + (int)bRight2 : 0;
+                            const float *camA = rig && bRight1 ? g->cam_right : g->cam_left, *camB = rig && bRight2 ? g->cam_right : g->cam_left;
+                            float p3D[3];
+                            ok = oracle_kb8_triangulate_matches(camA, camB, g->precision, kp1.x, kp1.y, kp2.x, kp2.y, g->R[k], g->t[k], sigmaLevel, unc,
+                                                                p3D) > 0.0001f;
+                        }
+                    }
+                    if (ok) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    const oracle_keypoint &kp2 = kf2->keys[bestIdx2];
+                    matches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = kp1.angle - kp2.angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            f1it++; f2it++;
+        } else if (kf1->fv_node[f1it] < kf2->fv_node[f2it]) {
+            f1it = (int)(std::lower_bound(kf1->fv_node, kf1->fv_node + f1end, kf2->fv_node[f2it]) - kf1->fv_node);
+        } else {
+            f2it = (int)(std::lower_bound(kf2->fv_node, kf2->fv_node + f2end, kf1->fv_node[f1it]) - kf2->fv_node);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        computeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    if (pairs) {
+        int k = 0;
+        for (int i = 0; i < kf1->n; i++) {
+            if (matches12[i] < 0) continue;
+            pairs[2 * k] = i; pairs[2 * k + 1] = matches12[i]; ++k;
+        }
+    }
+    return nmatches;
+}

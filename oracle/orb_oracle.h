@@ -182,6 +182,18 @@ int oracle_search_by_bow_keyframes(const int32_t *node1, const int32_t *start1, 
                                    const int32_t *feat2, int nfv2, const oracle_keypoint *keys2, const uint8_t *desc2, const uint8_t *valid2,
                                    int n2, float nnratio, int check_orientation, int32_t *matches12);
 
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher2.cc:179-418).  kf1 / kf2 / geometry: structs with the layout of orbx_keyframe_view /
+ * orbx_triangulation_geometry (include/orbx.h), restated here so that the oracle stays self-contained. */
+typedef struct oracle_keyframe_view {
+    const oracle_keypoint *keys; const uint8_t *desc; int32_t n, n_left; const float *u_right; const uint8_t *has_map_point;
+    const int32_t *fv_node, *fv_start, *fv_feature; int32_t nfv; const float *scale_factors, *level_sigma2; int32_t nlevels;
+} oracle_keyframe_view;
+typedef struct oracle_triangulation_geometry {
+    float ep[2]; int32_t model, rig; float F12[9]; float cam_left[8], cam_right[8], precision; float R[4][9], t[4][3];
+} oracle_triangulation_geometry;
+int oracle_search_for_triangulation(const oracle_keyframe_view *kf1, const oracle_keyframe_view *kf2, const oracle_triangulation_geometry *g,
+                                    int only_stereo, int coarse, int check_orientation, int32_t *matches12, int32_t *pairs);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

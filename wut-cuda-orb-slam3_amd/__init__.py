@@ -65,6 +65,7 @@ ABI_SYMBOLS = [
     "orbx_search_by_projection_points", "orbx_search_by_projection_fisheye", "orbx_search_by_projection_points_fisheye",
     "orbx_search_by_bow",
     "orbx_search_by_bow_keyframes",
+    "orbx_search_for_triangulation",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
     "orbx_vocabulary_create",
@@ -173,6 +174,7 @@ def load_library() -> ctypes.CDLL:
                                        c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
     lib.orbx_search_by_bow_keyframes.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
+    lib.orbx_search_for_triangulation.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
@@ -204,6 +206,55 @@ def synth_frame(frame_index: int, w: int = 640, h: int = 480) -> np.ndarray:
 
 def device_count() -> int:
     return int(load_library().orbx_device_count())
+
+
+class KeyFrameViewC(ctypes.Structure):  # orbx_keyframe_view
+    _fields_ = [("keys", c_void_p), ("desc", c_void_p), ("n", c_int), ("n_left", c_int), ("u_right", c_void_p), ("has_map_point", c_void_p),
+                ("fv_node", c_void_p), ("fv_start", c_void_p), ("fv_feature", c_void_p), ("nfv", c_int), ("scale_factors", c_void_p),
+                ("level_sigma2", c_void_p), ("nlevels", c_int)]
+
+
+class TriangulationGeometryC(ctypes.Structure):  # orbx_triangulation_geometry
+    _fields_ = [("ep", c_float * 2), ("model", c_int), ("rig", c_int), ("F12", c_float * 9), ("cam_left", c_float * 8), ("cam_right", c_float * 8),
+                ("precision", c_float), ("R", (c_float * 9) * 4), ("t", (c_float * 3) * 4)]
+
+
+def keyframe_view(keys, desc, has_map_point, fv, scale_factors, level_sigma2, u_right=None, n_left=-1):
+    """(orbx_keyframe_view, keep-alive list): keys = mvKeysUn (n_left == -1) or mvKeys ++ mvKeysRight; fv = the FeatureVector dict of
+    ORBVocabulary.transform; the arrays must stay alive while the view is used (the second value holds them)."""
+    k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    h = np.ascontiguousarray(has_map_point, np.uint8)
+    assert len(k) == len(d) == len(h)
+    f = [np.ascontiguousarray(fv[key], np.int32) for key in ("fv_node", "fv_start", "fv_feature")]
+    sf = np.ascontiguousarray(scale_factors, np.float32); ls = np.ascontiguousarray(level_sigma2, np.float32)
+    assert len(sf) == len(ls)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    v = KeyFrameViewC(k.ctypes.data, d.ctypes.data, len(k), int(n_left), None if ur is None else ur.ctypes.data, h.ctypes.data, f[0].ctypes.data,
+                      f[1].ctypes.data, f[2].ctypes.data, len(f[0]), sf.ctypes.data, ls.ctypes.data, len(sf))
+    return v, [k, d, h, f, sf, ls, ur]
+
+
+def triangulation_geometry(ep, F12=None, model=0, rig=False, cam_left=None, cam_right=None, precision=1e-6, R=None, t=None):
+    """orbx_triangulation_geometry: ep (2,), F12 (3, 3) for the pinhole model; KannalaBrandt8: camera parameter vectors (8,), R [4][3][3]
+    or [3][3], t [4][3] or [3]."""
+    g = TriangulationGeometryC()
+    g.ep[0], g.ep[1] = float(ep[0]), float(ep[1])
+    g.model, g.rig, g.precision = int(model), int(bool(rig)), float(precision)
+    if F12 is not None:
+        for i, v in enumerate(np.asarray(F12, np.float32).reshape(9)):
+            g.F12[i] = float(v)
+    for name, arr in (("cam_left", cam_left), ("cam_right", cam_right if cam_right is not None else cam_left)):
+        if arr is not None:
+            for i, v in enumerate(np.asarray(arr, np.float32).reshape(8)):
+                getattr(g, name)[i] = float(v)
+    if R is not None:
+        Rs = np.asarray(R, np.float32).reshape(-1, 9); ts = np.asarray(t, np.float32).reshape(-1, 3)
+        for k in range(4):
+            for i in range(9):
+                g.R[k][i] = float(Rs[min(k, len(Rs) - 1)][i])
+            for i in range(3):
+                g.t[k][i] = float(ts[min(k, len(ts) - 1)][i])
+    return g
 
 
 class _HostBlock:
@@ -676,6 +727,19 @@ class ORBmatcher:
         if n < 0:
             _check(n, "orbx_search_by_bow_keyframes")
         return n, matches
+
+    def SearchForTriangulation(self, kf1, kf2, geometry, bOnlyStereo: bool = False, bCoarse: bool = False, checkOrientation: bool = True):
+        """ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (reference src/ORBmatcher2.cc:179-418).
+        kf1 / kf2: keyframe_view(...) results (view, keep-alive), geometry: triangulation_geometry(...).
+        Returns (nmatches, vMatchedPairs[nmatches, 2], matches12[n1])."""
+        v1, v2 = kf1[0], kf2[0]
+        matches = np.full(v1.n, -1, np.int32)
+        pairs = np.zeros((max(v1.n, 1), 2), np.int32)
+        n = self._lib.orbx_search_for_triangulation(self._h, byref(v1), byref(v2), byref(geometry), int(bool(bOnlyStereo)), int(bool(bCoarse)),
+                                                    int(bool(checkOrientation)), matches.ctypes.data, pairs.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_for_triangulation")
+        return n, pairs[:n].copy(), matches
 
     @staticmethod
     def _camera(k4, dist, knew4):

@@ -1974,6 +1974,79 @@ extern "C" int orbx_search_by_bow_keyframes(orbx_matcher *m, const int32_t *fv1_
                            desc2, valid2, n2, nnratio, check_orientation, 1, matches12);
 }
 
+// int ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) — reference src/ORBmatcher2.cc:179-418.
+static int checkKeyFrameView(const orbx_keyframe_view *kf, const char *which, int maxN)
+{
+    if (!kf || kf->n < 0 || (kf->n > 0 && (!kf->keys || !kf->desc || !kf->has_map_point)) || kf->nlevels <= 0 || kf->nlevels > ORBX_MAX_LEVELS ||
+        !kf->scale_factors || !kf->level_sigma2 || kf->n_left < -1 || kf->n_left > kf->n)
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_search_for_triangulation: bad %s keyframe view", which);
+    if (kf->n > maxN || kf->n > 65535) return setError(ORBX_ERR_CAPACITY, "%s keyframe: %d features exceed the matcher capacity %d", which, kf->n, std::min(maxN, 65535));
+    for (int i = 0; i < kf->n; ++i)
+        if (kf->keys[i].octave < 0 || kf->keys[i].octave >= kf->nlevels)
+            return setError(ORBX_ERR_INVALID_ARG, "orbx_search_for_triangulation: %s keypoint %d has octave %d outside [0, %d)", which, i, kf->keys[i].octave, kf->nlevels);
+    return checkFeatureVector(kf->fv_node, kf->fv_start, kf->fv_feature, kf->nfv, kf->n, which);
+}
+
+extern "C" int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyframe_view *kf1, const orbx_keyframe_view *kf2,
+                                             const orbx_triangulation_geometry *g, int only_stereo, int coarse, int check_orientation,
+                                             int32_t *matches12, int32_t *pairs)
+{
+    ORBX_API_ENTRY;
+    if (!m || !g || !kf1 || !kf2 || (kf1->n > 0 && !matches12)) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_for_triangulation: null argument");
+    if (g->model != 0 && g->model != 1) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_for_triangulation: model must be 0 (pinhole) or 1 (KannalaBrandt8)");
+    if (g->rig && g->model != 1) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_for_triangulation: a two-camera rig needs the KannalaBrandt8 model");
+    int rc;
+    if ((rc = checkKeyFrameView(kf1, "first", m->maxQ)) != ORBX_OK) return rc;
+    if ((rc = checkKeyFrameView(kf2, "second", m->maxT)) != ORBX_OK) return rc;
+    const int n1 = kf1->n, n2 = kf2->n;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    if (kf1->nfv == 0 || kf2->nfv == 0 || n1 == 0 || n2 == 0) return 0;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, kf1->desc, n1, kf2->desc, n2)) != ORBX_OK) return rc;
+    const size_t Q = (size_t)m->maxQ, T = (size_t)m->maxT;
+    if ((rc = m->d_work.ensure(3 * Q + 3 * T + 2 * Q + 2 + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_bin.ensure(Q + T)) != ORBX_OK) return rc;
+    if ((rc = m->d_prev.ensure(Q + T + 3 * ORBX_MAX_LEVELS)) != ORBX_OK) return rc;
+    int *node1 = m->d_work.p, *start1 = node1 + Q, *feat1 = start1 + Q + 1, *node2 = feat1 + Q, *start2 = node2 + T, *feat2 = start2 + T + 1,
+        *dMatches = feat2 + T, *binOf = dMatches + Q, *result = binOf + Q;
+    float *uR1 = m->d_prev.p, *uR2 = uR1 + Q, *scale2 = uR2 + T, *sigma1 = scale2 + ORBX_MAX_LEVELS, *sigma2 = sigma1 + ORBX_MAX_LEVELS;
+    hipStream_t st = m->stream;
+    auto up = [&](void *dst, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
+    HIP_TRY(up(node1, kf1->fv_node, (size_t)kf1->nfv * 4)); HIP_TRY(up(start1, kf1->fv_start, ((size_t)kf1->nfv + 1) * 4));
+    HIP_TRY(up(feat1, kf1->fv_feature, (size_t)kf1->fv_start[kf1->nfv] * 4));
+    HIP_TRY(up(node2, kf2->fv_node, (size_t)kf2->nfv * 4)); HIP_TRY(up(start2, kf2->fv_start, ((size_t)kf2->nfv + 1) * 4));
+    HIP_TRY(up(feat2, kf2->fv_feature, (size_t)kf2->fv_start[kf2->nfv] * 4));
+    HIP_TRY(up(m->d_kl.p, kf1->keys, (size_t)n1 * sizeof(orbx_keypoint))); HIP_TRY(up(m->d_kr.p, kf2->keys, (size_t)n2 * sizeof(orbx_keypoint)));
+    HIP_TRY(up(m->d_bin.p, kf1->has_map_point, (size_t)n1)); HIP_TRY(up(m->d_bin.p + Q, kf2->has_map_point, (size_t)n2));
+    if (kf1->u_right) HIP_TRY(up(uR1, kf1->u_right, (size_t)n1 * 4));
+    if (kf2->u_right) HIP_TRY(up(uR2, kf2->u_right, (size_t)n2 * 4));
+    HIP_TRY(up(scale2, kf2->scale_factors, (size_t)kf2->nlevels * 4));
+    HIP_TRY(up(sigma1, kf1->level_sigma2, (size_t)kf1->nlevels * 4)); HIP_TRY(up(sigma2, kf2->level_sigma2, (size_t)kf2->nlevels * 4));
+    OrbxSftHost h;
+    memset(&h, 0, sizeof h);
+    h.node1 = node1; h.start1 = start1; h.feat1 = feat1; h.nfv1 = kf1->nfv; h.keys1 = m->d_kl.p; h.desc1 = m->d_q.p; h.hasMp1 = m->d_bin.p;
+    h.uRight1 = kf1->u_right ? uR1 : nullptr; h.nLeft1 = kf1->n_left; h.n1 = n1;
+    h.node2 = node2; h.start2 = start2; h.feat2 = feat2; h.nfv2 = kf2->nfv; h.keys2 = m->d_kr.p; h.desc2 = m->d_t.p; h.hasMp2 = m->d_bin.p + Q;
+    h.uRight2 = kf2->u_right ? uR2 : nullptr; h.nLeft2 = kf2->n_left;
+    h.scale2 = scale2; h.sigma1 = sigma1; h.sigma2 = sigma2;
+    memcpy(h.ep, g->ep, sizeof h.ep); memcpy(h.F, g->F12, sizeof h.F);
+    h.model = g->model; h.rig = g->rig != 0; h.onlyStereo = only_stereo != 0; h.coarse = coarse != 0; h.checkOri = check_orientation != 0;
+    memcpy(h.camL, g->cam_left, sizeof h.camL); memcpy(h.camR, g->cam_right, sizeof h.camR); h.precision = g->precision;
+    memcpy(h.R, g->R, sizeof h.R); memcpy(h.t, g->t, sizeof h.t);
+    h.matches = dMatches; h.binOf = binOf; h.result = result;
+    HIP_TRY(orbxLaunchSearchForTriangulation(st, h));
+    int nmatches = 0;
+    HIP_TRY(hipMemcpyAsync(matches12, dMatches, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&nmatches, result, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (pairs) {  // vMatchedPairs (:405-413): (idx1, idx2) in increasing idx1
+        int k = 0;
+        for (int i = 0; i < n1; ++i)
+            if (matches12[i] >= 0) { pairs[2 * k] = i; pairs[2 * k + 1] = matches12[i]; ++k; }
+    }
+    return nmatches;
+}
+
 // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811.
 static int checkCamera(const float *k4, const float *dist, int ndist, const float *knew4, const char *fn)
 {

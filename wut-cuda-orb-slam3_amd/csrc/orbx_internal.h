@@ -165,6 +165,16 @@ hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *k
                                  const uint8_t *kfDesc, const signed char *kfValid, const int *fNode, const int *fStart, const int *fFeat,
                                  int fNfv, const void *fKeys, const uint8_t *fDesc, int nF, int maxNodeF, float nnratio, int checkOri,
                                  int mode, const signed char *fValid, int nOut, int *matches, int *binOf, int *result);
+// ORBmatcher::SearchForTriangulation (orbx_match.hip): all pointers are device pointers
+struct OrbxSftHost {
+    const int *node1, *start1, *feat1; int nfv1; const void *keys1; const uint8_t *desc1; const signed char *hasMp1; const float *uRight1; int nLeft1, n1;
+    const int *node2, *start2, *feat2; int nfv2; const void *keys2; const uint8_t *desc2; const signed char *hasMp2; const float *uRight2; int nLeft2;
+    const float *scale2, *sigma1, *sigma2;
+    float ep[2], F[9]; int model, rig, onlyStereo, coarse, checkOri;
+    float camL[8], camR[8], precision, R[4][9], t[4][3];
+    int *matches, *binOf, *result;
+};
+hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h);
 hipError_t orbxLaunchBowTransformBatch(hipStream_t st, const int *childStart, const int *childNode, const void *childDesc, const int *wordOfNode,
                                        const double *weightOfNode, int L, int scoring, int weighting, const void *feat, const int *nPerFrame,
                                        int nframes, int cap, int levelsup, int *featWord, int *featNode, double *featWeight, int *bowWord,

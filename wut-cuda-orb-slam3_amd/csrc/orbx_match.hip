@@ -11,6 +11,7 @@
 // (strict `<` insertion, lower train index first) is the lexicographic (distance, index) order, kept by packed keys inside a split
 // and by k_knn2_merge across splits.  k_hamming_matrix stages train descriptors through LDS tiles.
 #include "orbx_internal.h"
+#include <cstring>
 #include <limits.h>
 #include <algorithm>
 #include <type_traits>
@@ -2162,7 +2163,9 @@ __device__ void fe_null_vector4(const float A[16], float v[4])
     for (int i = 0; i < 4; ++i) v[i] = (float)(best == 0 ? V[i][0] : best == 1 ? V[i][1] : best == 2 ? V[i][2] : V[i][3]);
 }
 
-__device__ float fe_triangulate(const FisheyeArgs &a, float x1, float y1, float x2, float y2, float sigmaLevel, float unc, float p3D[3])
+// (any argument block with cam1[8], cam2[8], precision, R12[9], t12[3]: FisheyeArgs, and the per-pair view of SearchForTriangulation)
+template <class Rig>
+__device__ float fe_triangulate(const Rig &a, float x1, float y1, float x2, float y2, float sigmaLevel, float unc, float p3D[3])
 {
     float r1[3], r2[3];
     fe_unproject(a.cam1, a.precision, x1, y1, r1);
@@ -2396,6 +2399,140 @@ hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *k
         const size_t lds = ((size_t)std::max(maxNodeF, 1) + 63) & ~(size_t)63;
         hipLaunchKernelGGL(k_sbow_match, dim3(kfNfv), dim3(64), lds, st, a);
         hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+
+// ---- ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vMatchedPairs, bOnlyStereo, bCoarse) ------------------------
+// reference src/ORBmatcher2.cc:179-418 (LocalMapping::CreateNewMapPoints): inside every vocabulary node the keyframes share, a feature
+// of pKF1 without a map point takes the feature of pKF2 without a map point at the smallest descriptor distance <= TH_LOW that is far
+// enough from the epipole (:305-313) and passes the epipolar constraint (:353) - the LAST one in node order on equal distances
+// (`dist > bestDist`, :293, is strict).  Nothing is marked as taken (vbMatched2 is never set in this function), so the features of pKF1
+// are independent: one wave per shared node, keyframe-1 features of the node one after the other, lanes over the node's keyframe-2
+// features, one wave reduction of (distance << 16 | 0xFFFF - position) keys.  The rotation histogram is k_sbow_finish's.
+// Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:107-129) on the host-built F12; KannalaBrandt8::epipolarConstrain
+// (KannalaBrandt8.cpp:216-220) = TriangulateMatches(...) > 0.0001 with the device function Frame::ComputeStereoFishEyeMatches uses.
+struct SftRig { float cam1[8], cam2[8], precision, R12[9], t12[3]; };
+struct SftArgs {
+    const int *node1, *start1, *feat1; int nfv1;
+    const MtKp *keys1; const uint8_t *desc1; const signed char *hasMp1; const float *uRight1; int nLeft1;
+    const int *node2, *start2, *feat2; int nfv2;
+    const MtKp *keys2; const uint8_t *desc2; const signed char *hasMp2; const float *uRight2; int nLeft2;
+    const float *scale2, *sigma1, *sigma2;   // mvScaleFactors of pKF2, mvLevelSigma2 of pKF1 / pKF2 (device arrays)
+    float ep[2], F[9];
+    int model, rig, onlyStereo, coarse, checkOri;
+    float camL[8], camR[8], precision, R[4][9], t[4][3];
+    int *matches, *binOf, *result;
+};
+
+__global__ __launch_bounds__(64) void k_sft_match(SftArgs a)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const int node = a.node1[j];
+    int lo = 0, hi = a.nfv2;  // the merge of the two maps only ever pairs equal node ids
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.node2[mid] < node) lo = mid + 1; else hi = mid; }
+    if (lo >= a.nfv2 || a.node2[lo] != node) return;
+    const int s2 = a.start2[lo], n2 = a.start2[lo + 1] - s2;
+    const bool rig = a.rig != 0;
+    const float factor = 1.0f / HISTO_LENGTH;
+    const unsigned NONE = 0xFFFFFFFFu;
+    for (int i1 = a.start1[j]; i1 < a.start1[j + 1]; ++i1) {
+        const int idx1 = a.feat1[i1];
+        if (a.hasMp1[idx1]) continue;
+        const bool bStereo1 = !rig && a.uRight1 && a.uRight1[idx1] >= 0.f;
+        if (a.onlyStereo && !bStereo1) continue;
+        const MtKp kp1 = a.keys1[idx1];
+        const bool bRight1 = !(a.nLeft1 == -1 || idx1 < a.nLeft1);
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.desc1 + (size_t)idx1 * 32))[w];
+        // epipolar line of kp1 in the second image (Pinhole.cpp:115-117)
+        const float la = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[0]), __fmul_rn(kp1.y, a.F[3])), a.F[6]);
+        const float lb = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[1]), __fmul_rn(kp1.y, a.F[4])), a.F[7]);
+        const float lc = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[2]), __fmul_rn(kp1.y, a.F[5])), a.F[8]);
+        const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+        const float sigmaLevel = a.sigma1[kp1.octave];
+        unsigned key = NONE;
+        for (int c0 = 0; c0 < n2; c0 += 64) {
+            const int p2 = c0 + lane;
+            if (p2 >= n2) continue;
+            const int idx2 = a.feat2[s2 + p2];
+            if (a.hasMp2[idx2]) continue;
+            const bool bStereo2 = !rig && a.uRight2 && a.uRight2[idx2] >= 0.f;
+            if (a.onlyStereo && !bStereo2) continue;
+            const uint32_t *t = (const uint32_t *)(a.desc2 + (size_t)idx2 * 32);
+            int dist = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+            if (dist > TH_LOW) continue;
+            const MtKp kp2 = a.keys2[idx2];
+            if (!bStereo1 && !bStereo2 && !rig) {
+                const float dex = __fsub_rn(a.ep[0], kp2.x), dey = __fsub_rn(a.ep[1], kp2.y);
+                if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.f, a.scale2[kp2.octave])) continue;
+            }
+            bool ok = a.coarse != 0;
+            if (!ok) {
+                const float unc = a.sigma2[kp2.octave];
+                if (a.model == 0) {
+                    const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp2.x), __fmul_rn(lb, kp2.y)), lc);
+                    if (den == 0.f) ok = false;
+                    else ok = (double)__fdiv_rn(__fmul_rn(num, num), den) < __dmul_rn(3.84, (double)unc);
+                } else {
+                    const bool bRight2 = !(a.nLeft2 == -1 || idx2 < a.nLeft2);
+                    const int k = rig ? 2 * (int)bRight1 + (int)bRight2 : 0;
+                    SftRig r;
+                    for (int i = 0; i < 8; ++i) { r.cam1[i] = rig && bRight1 ? a.camR[i] : a.camL[i]; r.cam2[i] = rig && bRight2 ? a.camR[i] : a.camL[i]; }
+                    r.precision = a.precision;
+                    for (int i = 0; i < 9; ++i) r.R12[i] = a.R[k][i];
+                    for (int i = 0; i < 3; ++i) r.t12[i] = a.t[k][i];
+                    float p3D[3];
+                    ok = fe_triangulate(r, kp1.x, kp1.y, kp2.x, kp2.y, sigmaLevel, unc, p3D) > 0.0001f;
+                }
+            }
+            if (ok) key = min(key, ((unsigned)dist << 16) | (unsigned)(0xFFFF - p2));
+        }
+        const unsigned best = sbow_wave_min(key);
+        if (best != NONE && lane == 0) {
+            const int bestIdx2 = a.feat2[s2 + (0xFFFF - (int)(best & 0xFFFFu))];
+            a.matches[idx1] = bestIdx2;
+            if (a.checkOri) {
+                float rot = __fsub_rn(kp1.angle, a.keys2[bestIdx2].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, factor));
+                if (bin == HISTO_LENGTH) bin = 0;
+                a.binOf[idx1] = bin;
+                atomicAdd(&a.result[1 + bin], 1);
+            }
+            atomicAdd(&a.result[0], 1);
+        }
+    }
+}
+
+hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h)
+{
+    SftArgs a;
+    memset(&a, 0, sizeof a);
+    a.node1 = h.node1; a.start1 = h.start1; a.feat1 = h.feat1; a.nfv1 = h.nfv1;
+    a.keys1 = (const MtKp *)h.keys1; a.desc1 = h.desc1; a.hasMp1 = h.hasMp1; a.uRight1 = h.uRight1; a.nLeft1 = h.nLeft1;
+    a.node2 = h.node2; a.start2 = h.start2; a.feat2 = h.feat2; a.nfv2 = h.nfv2;
+    a.keys2 = (const MtKp *)h.keys2; a.desc2 = h.desc2; a.hasMp2 = h.hasMp2; a.uRight2 = h.uRight2; a.nLeft2 = h.nLeft2;
+    a.scale2 = h.scale2; a.sigma1 = h.sigma1; a.sigma2 = h.sigma2;
+    memcpy(a.ep, h.ep, sizeof a.ep); memcpy(a.F, h.F, sizeof a.F);
+    a.model = h.model; a.rig = h.rig; a.onlyStereo = h.onlyStereo; a.coarse = h.coarse; a.checkOri = h.checkOri;
+    memcpy(a.camL, h.camL, sizeof a.camL); memcpy(a.camR, h.camR, sizeof a.camR); a.precision = h.precision;
+    memcpy(a.R, h.R, sizeof a.R); memcpy(a.t, h.t, sizeof a.t);
+    a.matches = h.matches; a.binOf = h.binOf; a.result = h.result;
+    hipError_t e = hipMemsetAsync(h.result, 0, 32 * sizeof(int), st);
+    if (e == hipSuccess && h.n1 > 0) e = hipMemsetAsync(h.matches, 0xFF, (size_t)h.n1 * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    if (h.nfv1 > 0 && h.nfv2 > 0) {
+        hipLaunchKernelGGL(k_sft_match, dim3(h.nfv1), dim3(64), 0, st, a);
+        SbowArgs f;
+        memset(&f, 0, sizeof f);
+        f.checkOri = h.checkOri; f.nOut = h.n1; f.matches = h.matches; f.binOf = h.binOf; f.result = h.result;
+        hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, f);
     }
     return hipGetLastError();
 }

@@ -382,6 +382,57 @@ public:
         return n;
     }
 
+    // The part of `ORB_SLAM3::KeyFrame` SearchForTriangulation reads (reference include/KeyFrame.h): keys = mvKeysUn (NLeft == -1) or
+    // mvKeys followed by mvKeysRight, mDescriptors, mvuRight (empty: none), vbHasMapPoint[i] = (GetMapPoint(i) != NULL), mFeatVec,
+    // mvScaleFactors, mvLevelSigma2.
+    struct KeyFrameView {
+        const std::vector<KeyPoint> *keys = nullptr;
+        const Descriptors *mDescriptors = nullptr;
+        int NLeft = -1;
+        const std::vector<float> *mvuRight = nullptr;
+        const std::vector<uint8_t> *vbHasMapPoint = nullptr;
+        const FeatureVector *mFeatVec = nullptr;
+        const std::vector<float> *mvScaleFactors = nullptr, *mvLevelSigma2 = nullptr;
+    };
+
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool
+    // bOnlyStereo, const bool bCoarse = false) — reference include/ORBmatcher.h:79-80, src/ORBmatcher2.cc:179-418.  `geometry`: what the
+    // reference derives from the two poses in front of its loop (:185-214), see orbx_triangulation_geometry.
+    int SearchForTriangulation(const KeyFrameView &KF1, const KeyFrameView &KF2, const orbx_triangulation_geometry &geometry,
+                               std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo, const bool bCoarse = false)
+    {
+        std::vector<int32_t> node[2], start[2], feat[2];
+        orbx_keyframe_view v[2];
+        const KeyFrameView *kf[2] = {&KF1, &KF2};
+        for (int s = 0; s < 2; ++s) {
+            const KeyFrameView &k = *kf[s];
+            if (!k.keys || !k.mDescriptors || !k.vbHasMapPoint || !k.mFeatVec || !k.mvScaleFactors || !k.mvLevelSigma2 ||
+                k.vbHasMapPoint->size() != k.keys->size() || (k.mvuRight && !k.mvuRight->empty() && k.mvuRight->size() != k.keys->size()))
+                throw std::runtime_error("SearchForTriangulation: incomplete keyframe view");
+            start[s].push_back(0);
+            for (FeatureVector::const_iterator it = k.mFeatVec->begin(); it != k.mFeatVec->end(); ++it) {
+                node[s].push_back((int32_t)it->first);
+                feat[s].insert(feat[s].end(), it->second.begin(), it->second.end());
+                start[s].push_back((int32_t)feat[s].size());
+            }
+            v[s].keys = (const orbx_keypoint *)k.keys->data(); v[s].desc = k.mDescriptors->data.data();
+            v[s].n = (int32_t)k.keys->size(); v[s].n_left = k.NLeft;
+            v[s].u_right = k.mvuRight && !k.mvuRight->empty() ? k.mvuRight->data() : nullptr;
+            v[s].has_map_point = k.vbHasMapPoint->data();
+            v[s].fv_node = node[s].data(); v[s].fv_start = start[s].data(); v[s].fv_feature = feat[s].data(); v[s].nfv = (int32_t)node[s].size();
+            v[s].scale_factors = k.mvScaleFactors->data(); v[s].level_sigma2 = k.mvLevelSigma2->data();
+            v[s].nlevels = (int32_t)std::min(k.mvScaleFactors->size(), k.mvLevelSigma2->size());
+        }
+        std::vector<int32_t> matches12((size_t)v[0].n + 1, -1), pairs(2 * (size_t)v[0].n + 2);
+        const int n = orbx_search_for_triangulation(m_, &v[0], &v[1], &geometry, bOnlyStereo ? 1 : 0, bCoarse ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                                    matches12.data(), pairs.data());
+        if (n < 0) check(n, "SearchForTriangulation");
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve((size_t)n);
+        for (int i = 0; i < n; ++i) vMatchedPairs.push_back(std::make_pair((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]));
+        return n;
+    }
+
     // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811: mvKeysUn from mvKeys.  K = toK() and mK as {fx, fy, cx, cy},
     // mDistCoef as the reference's 4 / 5 / 8 / 12 floats (copies when mDistCoef[0] == 0).
     void UndistortKeyPoints(const std::vector<KeyPoint> &mvKeys, const float (&K)[4], const std::vector<float> &mDistCoef, const float (&mK)[4],
