@@ -421,6 +421,51 @@ int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyframe_view *kf1
                                   const orbx_triangulation_geometry *geometry, int only_stereo, int coarse, int check_orientation,
                                   int32_t *matches12, int32_t *pairs);
 
+/* One map point projected into a keyframe, as ORBmatcher::Fuse / SearchBySim3 have it when they reach `GetFeaturesInArea`: the pose
+ * algebra and the visibility tests in front (Tcw * p3Dw, project, IsInImage, the distance and viewing-angle tests, PredictScale -
+ * src/ORBmatcher2.cc:469-520, 645-688, src/ORBmatcher3.cc:82-118) are the caller's Sophus / Eigen code; a point that failed one of them
+ * is passed with search = 0. */
+typedef struct {
+    float u, v;       /* uv(0), uv(1) */
+    float ur;         /* uv(0) - bf * invz (Fuse with stereo keypoints, :489); unused otherwise */
+    float radius;     /* th * mvScaleFactors[nPredictedLevel] */
+    int32_t level;    /* nPredictedLevel */
+    int32_t search;   /* 0: skipped by the caller's tests */
+} orbx_window_point;
+
+/* The search every one of these functions runs per projected map point (src/ORBmatcher2.cc:522-579 and 690-714, src/ORBmatcher3.cc:
+ * 120-145 and 188-213): KeyFrame::GetFeaturesInArea(u, v, radius) (src/KeyFrame.cc:704-748: cells ix outer / iy inner, push order inside a
+ * cell, |dx| < r && |dy| < r) over the keyframe's 64 x 48 grid on [min_x, max_x) x [min_y, max_y), keypoints of level nPredictedLevel - 1
+ * or nPredictedLevel only, with chi2_test != 0 the reprojection test of Fuse (:545-569: e2 * mvInvLevelSigma2[level] > 7.8 with
+ * mvuRight >= 0, > 5.99 without), then the FIRST keypoint at the smallest DescriptorDistance to the point's descriptor.
+ * keys / desc / u_right: the keyframe's mvKeysUn / mDescriptors / mvuRight - for a rig the side being searched (mvKeys or mvKeysRight and
+ * its descriptor rows; add NLeft to the result for the right side as :571 does).  best_idx[i] = that keypoint or -1, best_dist[i] its
+ * distance (INT32_MAX when none).  Returns 0 or a negative status.  The points do not interact: one wave each. */
+int orbx_search_keyframe_windows(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, const float *u_right, int n, float min_x,
+                                 float max_x, float min_y, float max_y, const float *inv_level_sigma2, int nlevels,
+                                 const orbx_window_point *points, const uint8_t *point_desc, int np, int chi2_test, int32_t *best_idx,
+                                 int32_t *best_dist);
+
+/* int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th, const bool bRight) — reference
+ * src/ORBmatcher2.cc:420-610 (chi2_test = 1) and Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) :612-770 (chi2_test = 0): the search part.
+ * fused_idx[i] = keypoint bestIdx with bestDist <= TH_LOW (50) that map point i fuses into, -1 otherwise; what happens then
+ * (Replace / AddObservation / AddMapPoint, :581-600) is map bookkeeping and stays with the caller, who walks fused_idx in order.
+ * Returns the number of points with fused_idx >= 0 (nFused when no pMPinKF is bad) or a negative status. */
+int orbx_fuse(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, const float *u_right, int n, float min_x, float max_x,
+              float min_y, float max_y, const float *inv_level_sigma2, int nlevels, const orbx_window_point *points,
+              const uint8_t *point_desc, int np, int chi2_test, int32_t *fused_idx);
+
+/* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const Sim3f &S12, const float th) —
+ * reference src/ORBmatcher3.cc:37-254 (loop closing): the map points of pKF1 projected into pKF2 (points_1in2, one per feature of pKF1,
+ * search = 0 for a feature without a usable map point, an already matched one (:70-82) or a failed visibility test) search pKF2's
+ * windows, those of pKF2 search pKF1's (points_2in1), both with TH_HIGH (100), and a pair is kept when the two searches agree
+ * (:236-250).  desc1[i] / desc2[i] = MapPoint::GetDescriptor() of feature i's map point.  matches12[i1] = i2 whose map point
+ * vpMatches12[i1] becomes, -1 = left as it was.  Returns nFound or a negative status. */
+int orbx_search_by_sim3(orbx_matcher *m, const orbx_keypoint *keys1, const uint8_t *kf_desc1, int n1, const float *bounds1,
+                        const orbx_keypoint *keys2, const uint8_t *kf_desc2, int n2, const float *bounds2,
+                        const orbx_window_point *points_1in2, const uint8_t *mp_desc1, const orbx_window_point *points_2in1,
+                        const uint8_t *mp_desc2, int nlevels, int32_t *matches12);
+
 
 /* void Frame::UndistortKeyPoints() — reference src/Frame.cc:777-811 (decl include/Frame.h): mvKeysUn from mvKeys.
  * k4 = fx, fy, cx, cy of static_cast<Pinhole*>(mpCamera)->toK(); dist = mDistCoef (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]], up to

@@ -88,6 +88,10 @@ def lib() -> ctypes.CDLL:
                                            c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
         L.oracle_search_by_bow_keyframes.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                      c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
+        L.oracle_search_keyframe_windows.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                                     c_int, c_int, c_void_p, c_void_p]
+        L.oracle_search_by_sim3.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]
         L.oracle_search_for_triangulation.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
@@ -498,3 +502,34 @@ def search_for_triangulation(kf1, kf2, geometry, only_stereo=False, coarse=False
     n = lib().oracle_search_for_triangulation(ctypes.addressof(v1), ctypes.addressof(v2), ctypes.addressof(geometry), int(bool(only_stereo)),
                                               int(bool(coarse)), int(bool(check_orientation)), matches.ctypes.data, pairs.ctypes.data)
     return n, pairs[:n].copy(), matches
+
+
+WINDOW_POINT_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("ur", np.float32), ("radius", np.float32), ("level", np.int32),
+                               ("search", np.int32)])
+
+
+def search_keyframe_windows(keys, desc, bounds, points, point_desc, u_right=None, inv_level_sigma2=None, chi2_test=False):
+    """The window search of ORBmatcher::Fuse / SearchBySim3 (reference src/ORBmatcher2.cc:522-579, 690-714; src/ORBmatcher3.cc:120-145) ->
+    (best_idx[np], best_dist[np])."""
+    k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points, WINDOW_POINT_DTYPE); pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    bi = np.full(len(p), -1, np.int32); bd = np.full(len(p), np.iinfo(np.int32).max, np.int32)
+    lib().oracle_search_keyframe_windows(k.ctypes.data, d.ctypes.data, None if ur is None else ur.ctypes.data, len(k), bounds[0], bounds[1], bounds[2],
+                                         bounds[3], None if sg is None else sg.ctypes.data, p.ctypes.data, pd.ctypes.data, len(p), int(bool(chi2_test)),
+                                         bi.ctypes.data, bd.ctypes.data)
+    return bi, bd
+
+
+def search_by_sim3(keys1, kf_desc1, bounds1, keys2, kf_desc2, bounds2, points_1in2, mp_desc1, points_2in1, mp_desc2):
+    """ORBmatcher::SearchBySim3 (reference src/ORBmatcher3.cc:37-254) -> (nFound, matches12[n1])."""
+    k1 = np.ascontiguousarray(keys1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(keys2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(kf_desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(kf_desc2, np.uint8).reshape(-1, 32)
+    p12 = np.ascontiguousarray(points_1in2, WINDOW_POINT_DTYPE); p21 = np.ascontiguousarray(points_2in1, WINDOW_POINT_DTYPE)
+    m1 = np.ascontiguousarray(mp_desc1, np.uint8).reshape(-1, 32); m2 = np.ascontiguousarray(mp_desc2, np.uint8).reshape(-1, 32)
+    b1 = np.ascontiguousarray(bounds1, np.float32); b2 = np.ascontiguousarray(bounds2, np.float32)
+    out = np.full(len(k1), -1, np.int32)
+    n = lib().oracle_search_by_sim3(k1.ctypes.data, d1.ctypes.data, len(k1), b1.ctypes.data, k2.ctypes.data, d2.ctypes.data, len(k2), b2.ctypes.data,
+                                    p12.ctypes.data, m1.ctypes.data, p21.ctypes.data, m2.ctypes.data, out.ctypes.data)
+    return n, out

@@ -1984,3 +1984,75 @@ extern "C" int oracle_search_for_triangulation(const oracle_keyframe_view *kf1, 
     }
     return nmatches;
 }
+
+// =====================================================================================================================================
+// The window search of ORBmatcher::Fuse (src/ORBmatcher2.cc:522-579 with the reprojection test, :690-714 without) and of both halves of
+// ORBmatcher::SearchBySim3 (src/ORBmatcher3.cc:120-145, 188-213), on KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:704-748 = the frame's
+// grid walk without a level filter).  The keyframe's grid is the frame's (KeyFrame copies F.mGrid, src/KeyFrame.cc:67-75).
+// =====================================================================================================================================
+extern "C" int oracle_search_keyframe_windows(const oracle_keypoint *keys, const uint8_t *desc, const float *u_right, int n, float min_x,
+                                              float max_x, float min_y, float max_y, const float *inv_level_sigma2,
+                                              const oracle_window_point *points, const uint8_t *point_desc, int np, int chi2_test,
+                                              int32_t *best_idx, int32_t *best_dist)
+{
+    const FrameGrid G = assignFeaturesToGrid(keys, n, min_x, max_x, min_y, max_y);
+    for (int i = 0; i < np; ++i) {
+        best_idx[i] = -1; best_dist[i] = INT_MAX;
+        const oracle_window_point &P = points[i];
+        if (!P.search) continue;
+        const int nPredictedLevel = P.level;
+        const std::vector<size_t> vIndices = getFeaturesInArea(G, keys, P.u, P.v, P.radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t *dMP = point_desc + (size_t)i * 32;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
+            const size_t idx = *vit;
+            const oracle_keypoint &kp = keys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (chi2_test) {  // Fuse(pKF, vpMapPoints, th, bRight) only (:545-569)
+                if (u_right && u_right[idx] >= 0) {
+                    const float ex = P.u - kp.x, ey = P.v - kp.y, er = P.ur - u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = P.u - kp.x, ey = P.v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = oracle_hamming256(dMP, desc + idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+    }
+    return 0;
+}
+
+// ORBmatcher::SearchBySim3 — reference src/ORBmatcher3.cc:37-254: both directed searches with TH_HIGH, then the agreement check (:236-250).
+extern "C" int oracle_search_by_sim3(const oracle_keypoint *keys1, const uint8_t *kf_desc1, int n1, const float *bounds1,
+                                     const oracle_keypoint *keys2, const uint8_t *kf_desc2, int n2, const float *bounds2,
+                                     const oracle_window_point *points_1in2, const uint8_t *mp_desc1, const oracle_window_point *points_2in1,
+                                     const uint8_t *mp_desc2, int32_t *matches12)
+{
+    const int TH_HIGH = 100;
+    std::vector<int32_t> vnMatch1((size_t)n1, -1), vnMatch2((size_t)n2, -1), bi((size_t)std::max(n1, n2)), bd((size_t)std::max(n1, n2));
+    oracle_search_keyframe_windows(keys2, kf_desc2, nullptr, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3], nullptr, points_1in2, mp_desc1, n1, 0,
+                                   bi.data(), bd.data());
+    for (int i1 = 0; i1 < n1; i1++)
+        if (bd[i1] <= TH_HIGH) vnMatch1[i1] = bi[i1];
+    oracle_search_keyframe_windows(keys1, kf_desc1, nullptr, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3], nullptr, points_2in1, mp_desc2, n2, 0,
+                                   bi.data(), bd.data());
+    for (int i2 = 0; i2 < n2; i2++)
+        if (bd[i2] <= TH_HIGH) vnMatch2[i2] = bi[i2];
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { matches12[i1] = idx2; nFound++; }
+        }
+    }
+    return nFound;
+}

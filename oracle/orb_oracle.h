@@ -194,6 +194,16 @@ typedef struct oracle_triangulation_geometry {
 int oracle_search_for_triangulation(const oracle_keyframe_view *kf1, const oracle_keyframe_view *kf2, const oracle_triangulation_geometry *g,
                                     int only_stereo, int coarse, int check_orientation, int32_t *matches12, int32_t *pairs);
 
+/* The per-map-point window search of ORBmatcher::Fuse (src/ORBmatcher2.cc:522-579, 690-714) and SearchBySim3 (src/ORBmatcher3.cc:120-145,
+ * 188-213) over KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:704-748).  points: {u, v, ur, radius, level, search} as orbx_window_point. */
+typedef struct { float u, v, ur, radius; int32_t level, search; } oracle_window_point;
+int oracle_search_keyframe_windows(const oracle_keypoint *keys, const uint8_t *desc, const float *u_right, int n, float min_x, float max_x,
+                                   float min_y, float max_y, const float *inv_level_sigma2, const oracle_window_point *points,
+                                   const uint8_t *point_desc, int np, int chi2_test, int32_t *best_idx, int32_t *best_dist);
+int oracle_search_by_sim3(const oracle_keypoint *keys1, const uint8_t *kf_desc1, int n1, const float *bounds1, const oracle_keypoint *keys2,
+                          const uint8_t *kf_desc2, int n2, const float *bounds2, const oracle_window_point *points_1in2, const uint8_t *mp_desc1,
+                          const oracle_window_point *points_2in1, const uint8_t *mp_desc2, int32_t *matches12);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

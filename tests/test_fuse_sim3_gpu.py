@@ -1,0 +1,127 @@
+"""ORBmatcher::Fuse (reference src/ORBmatcher2.cc:420-610 and the Sim3 overload :612-770) and ORBmatcher::SearchBySim3
+(src/ORBmatcher3.cc:37-254): the per-map-point window search over KeyFrame::GetFeaturesInArea.  Hand-traced cases for the oracle (no GPU),
+then the HIP path through the C ABI against the oracle."""
+import numpy as np
+import pytest
+
+LEVELS = 8
+SF = np.float32(1.2) ** np.arange(LEVELS, dtype=np.float32)
+INV_SIGMA2 = (1.0 / (SF * SF)).astype(np.float32)
+BOUNDS = (0.0, 752.0, 0.0, 480.0)
+
+
+def _keys(pkg, pts, octaves):
+    k = np.zeros(len(pts), pkg.KEYPOINT_DTYPE)
+    p = np.asarray(pts, np.float32).reshape(-1, 2)
+    k["x"], k["y"], k["octave"], k["size"] = p[:, 0], p[:, 1], octaves, 31
+    return k
+
+
+def _flip(d, bits):
+    d = d.copy()
+    for b in bits:
+        d[b >> 3] ^= np.uint8(1 << (b & 7))
+    return d
+
+
+def _points(orc, rows):
+    p = np.zeros(len(rows), orc.WINDOW_POINT_DTYPE)
+    for i, r in enumerate(rows):
+        p[i] = r
+    return p
+
+
+def test_oracle_hand_traced_window_search(pkg, orc):
+    """One map point at (100, 100), level 2, radius 10: candidates by grid order (cells are 11.75 x 10 px: ix outer, iy inner).
+    Worked out by hand from src/ORBmatcher2.cc:522-579 and src/KeyFrame.cc:704-748."""
+    rng = np.random.default_rng(3)
+    D = rng.integers(0, 256, 32, dtype=np.uint8)
+    #   idx 0: exact twin but level 0 (outside [1, 2]);  1: distance 4, level 2, e2 = 5, cell (9, 10);  2: distance 4, level 1, e2 = 2, cell
+    #   (8, 10) - the EARLIER cell, so it wins the tie;  3: distance 2 but 10.5 px away in x (|dx| < r fails);  4: distance 3, level 2, fails
+    #   the chi2 test only (4 px off: 16 / 2.0736 = 7.7 > 5.99);  5: distance 60 (never the best)
+    k = _keys(pkg, [(100, 100), (102, 101), (99, 99), (110.5, 100), (104, 100), (99.5, 100)], [0, 2, 1, 2, 2, 2])
+    d = np.stack([D, _flip(D, [1, 2, 3, 4]), _flip(D, [9, 10, 11, 12]), _flip(D, [5, 6]), _flip(D, [20, 21, 22]), _flip(D, range(60))])
+    pts = _points(orc, [(100, 100, 0, 10, 2, 1)])
+    bi, bd = orc.search_keyframe_windows(k, d, BOUNDS, pts, D[None], inv_level_sigma2=INV_SIGMA2, chi2_test=True)
+    assert (bi[0], bd[0]) == (2, 4)
+    bi, bd = orc.search_keyframe_windows(k, d, BOUNDS, pts, D[None], chi2_test=False)   # the Sim3 overload has no reprojection test
+    assert (bi[0], bd[0]) == (4, 3)
+    # stereo keypoint: er enters e2 and the bound becomes 7.8: keypoint 2 (1 px, 1 px off, level 1) with ur 5 px off: (1 + 1 + 25) / 1.44 = 18.75
+    ur = np.full(6, -1, np.float32); ur[2] = 90
+    pts = _points(orc, [(100, 100, 95, 10, 2, 1)])
+    bi, bd = orc.search_keyframe_windows(k, d, BOUNDS, pts, D[None], u_right=ur, inv_level_sigma2=INV_SIGMA2, chi2_test=True)
+    assert (bi[0], bd[0]) == (1, 4)
+    pts = _points(orc, [(100, 100, 0, 10, 2, 0), (400, 400, 0, 10, 2, 1)])              # not searched / an empty window
+    bi, bd = orc.search_keyframe_windows(k, d, BOUNDS, pts, np.stack([D, D]))
+    assert bi.tolist() == [-1, -1] and (bd == np.iinfo(np.int32).max).all()
+
+
+def _scene(pkg, orc, n, np_, seed, dense=False):
+    rng = np.random.default_rng(seed)
+    pos = np.stack([rng.uniform(5, 747, n), rng.uniform(5, 475, n)], 1)
+    if dense:
+        pos[: n // 2] = np.stack([rng.uniform(300, 340, n // 2), rng.uniform(200, 240, n // 2)], 1)  # hundreds of keypoints in a few cells
+    octs = rng.integers(0, LEVELS, n)
+    k = _keys(pkg, pos, octs)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d[rng.integers(0, n, n // 10)] = d[rng.integers(0, n, n // 10)]   # twins: equal distances inside a window
+    src = rng.integers(0, n, np_)
+    pts = np.zeros(np_, orc.WINDOW_POINT_DTYPE)
+    pts["u"] = pos[src, 0] + rng.normal(0, 2.0, np_); pts["v"] = pos[src, 1] + rng.normal(0, 2.0, np_)
+    pts["level"] = np.clip(octs[src] + rng.integers(0, 2, np_), 0, LEVELS - 1)
+    pts["radius"] = (rng.choice([3.0, 4.0, 7.5, 30.0], np_) * SF[pts["level"]]).astype(np.float32)
+    pts["ur"] = pts["u"] - rng.uniform(1, 30, np_)
+    pts["search"] = rng.random(np_) < 0.9
+    far = rng.random(np_) < 0.05
+    pts["u"][far] += 2000   # outside the grid
+    pd = np.stack([_flip(d[s], rng.integers(0, 256, int(rng.integers(0, 70)))) for s in src])
+    ur = np.where(rng.random(n) < 0.5, pos[:, 0] - rng.uniform(1, 30, n), -1).astype(np.float32)
+    return k, d, ur, pts, pd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,np_,dense", [(2000, 1500, False), (3000, 800, True), (1, 5, False), (300, 1, False)])
+def test_window_search_and_fuse_match_oracle(pkg, orc, n, np_, dense):
+    k, d, ur, pts, pd = _scene(pkg, orc, n, np_, seed=n + np_, dense=dense)
+    m = pkg.ORBmatcher(8192, 8192)
+    for chi2, u in ((False, None), (True, None), (True, ur)):
+        got = m.SearchKeyFrameWindows(k, d, BOUNDS, pts, pd, LEVELS, u_right=u, inv_level_sigma2=INV_SIGMA2, chi2_test=chi2)
+        ref = orc.search_keyframe_windows(k, d, BOUNDS, pts, pd, u_right=u, inv_level_sigma2=INV_SIGMA2, chi2_test=chi2)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        nf, fi = m.Fuse(k, d, BOUNDS, pts, pd, LEVELS, u_right=u, inv_level_sigma2=INV_SIGMA2, chi2_test=chi2)
+        exp = np.where(ref[1] <= 50, ref[0], -1)
+        assert np.array_equal(fi, exp) and nf == int((exp >= 0).sum())
+    if n >= 2000:
+        assert (got[0] >= 0).sum() > np_ // 4
+    m.close()
+
+
+@pytest.mark.gpu
+def test_search_by_sim3_matches_oracle(pkg, orc):
+    """Two keyframes that see the same points: every feature carries a map point whose descriptor is near the feature's; projections of
+    KF1's points into KF2 land near their partner keypoint (and vice versa), some partners are missing or at the wrong level."""
+    rng = np.random.default_rng(21)
+    n = 1800
+    pos1 = np.stack([rng.uniform(5, 747, n), rng.uniform(5, 475, n)], 1)
+    perm = rng.permutation(n)
+    pos2 = pos1[perm] + rng.normal(0, 1.5, (n, 2))
+    oct1 = rng.integers(0, LEVELS, n); oct2 = np.clip(oct1[perm] + (rng.random(n) < 0.15), 0, LEVELS - 1)
+    k1, k2 = _keys(pkg, pos1, oct1), _keys(pkg, pos2, oct2)
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    fl = lambda D, mx: np.stack([_flip(x, rng.integers(0, 256, int(rng.integers(0, mx)))) for x in D])
+    d1, d2 = fl(base, 30), fl(base[perm], 30)
+    mp1, mp2 = fl(base, 20), fl(base[perm], 20)
+    inv = np.argsort(perm)
+    p12 = np.zeros(n, orc.WINDOW_POINT_DTYPE); p21 = np.zeros(n, orc.WINDOW_POINT_DTYPE)
+    p12["u"], p12["v"] = (pos2[inv] + rng.normal(0, 2, (n, 2))).T   # where KF1's map point i falls in KF2
+    p21["u"], p21["v"] = (pos1[perm] + rng.normal(0, 2, (n, 2))).T
+    p12["level"] = oct1; p21["level"] = oct1[perm]
+    p12["radius"] = 7.5 * SF[p12["level"]]; p21["radius"] = 7.5 * SF[p21["level"]]
+    p12["search"] = rng.random(n) < 0.85; p21["search"] = rng.random(n) < 0.85
+    m = pkg.ORBmatcher(8192, 8192)
+    got = m.SearchBySim3(k1, d1, BOUNDS, k2, d2, BOUNDS, p12, mp1, p21, mp2, LEVELS)
+    ref = orc.search_by_sim3(k1, d1, BOUNDS, k2, d2, BOUNDS, p12, mp1, p21, mp2)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[0] > n // 4
+    ok = got[1] >= 0
+    assert np.array_equal(perm[got[1][ok]], np.flatnonzero(ok)) or (perm[got[1][ok]] == np.flatnonzero(ok)).mean() > 0.95
+    m.close()

@@ -28,6 +28,9 @@ PROJECTION_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("invz", "<f4"), ("angl
 KEYPOINT_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
 )
+# orbx_window_point: a map point projected into a keyframe (ORBmatcher::Fuse / SearchBySim3)
+WINDOW_POINT_DTYPE = np.dtype([("u", np.float32), ("v", np.float32), ("ur", np.float32), ("radius", np.float32), ("level", np.int32),
+                               ("search", np.int32)])
 assert KEYPOINT_DTYPE.itemsize == 28
 
 TH_HIGH = 100  # reference src/ORBmatcher1.cc:37
@@ -66,6 +69,9 @@ ABI_SYMBOLS = [
     "orbx_search_by_bow",
     "orbx_search_by_bow_keyframes",
     "orbx_search_for_triangulation",
+    "orbx_search_keyframe_windows",
+    "orbx_fuse",
+    "orbx_search_by_sim3",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
     "orbx_vocabulary_create",
@@ -175,6 +181,12 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_search_by_bow_keyframes.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]
     lib.orbx_search_for_triangulation.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_search_keyframe_windows.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_int,
+                                                 c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_fuse.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_int, c_void_p, c_void_p,
+                              c_int, c_int, c_void_p]
+    lib.orbx_search_by_sim3.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
@@ -727,6 +739,51 @@ class ORBmatcher:
         if n < 0:
             _check(n, "orbx_search_by_bow_keyframes")
         return n, matches
+
+    def SearchKeyFrameWindows(self, keys, desc, bounds, points, point_desc, nlevels: int = 8, u_right=None, inv_level_sigma2=None, chi2_test: bool = False):
+        """The per-map-point search of ORBmatcher::Fuse / SearchBySim3 (reference src/ORBmatcher2.cc:522-579, 690-714; src/ORBmatcher3.cc:
+        120-145, 188-213): points = WINDOW_POINT_DTYPE records -> (best_idx[np], best_dist[np])."""
+        k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        p = np.ascontiguousarray(points, WINDOW_POINT_DTYPE); pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+        assert len(k) == len(d) and len(p) == len(pd)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        bi = np.full(len(p), -1, np.int32); bd = np.full(len(p), np.iinfo(np.int32).max, np.int32)
+        _check(self._lib.orbx_search_keyframe_windows(self._h, k.ctypes.data, d.ctypes.data, None if ur is None else ur.ctypes.data, len(k), bounds[0],
+                                                      bounds[1], bounds[2], bounds[3], None if sg is None else sg.ctypes.data, int(nlevels),
+                                                      p.ctypes.data, pd.ctypes.data, len(p), int(bool(chi2_test)), bi.ctypes.data, bd.ctypes.data),
+               "orbx_search_keyframe_windows")
+        return bi, bd
+
+    def Fuse(self, keys, desc, bounds, points, point_desc, nlevels: int = 8, u_right=None, inv_level_sigma2=None, chi2_test: bool = True):
+        """ORBmatcher::Fuse, the search part (reference src/ORBmatcher2.cc:420-610; chi2_test=False: the Sim3 overload :612-770) ->
+        (nFused, fused_idx[np]): keypoint each map point fuses into (bestDist <= TH_LOW) or -1."""
+        k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        p = np.ascontiguousarray(points, WINDOW_POINT_DTYPE); pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        sg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        fi = np.full(len(p), -1, np.int32)
+        n = self._lib.orbx_fuse(self._h, k.ctypes.data, d.ctypes.data, None if ur is None else ur.ctypes.data, len(k), bounds[0], bounds[1], bounds[2],
+                                bounds[3], None if sg is None else sg.ctypes.data, int(nlevels), p.ctypes.data, pd.ctypes.data, len(p),
+                                int(bool(chi2_test)), fi.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_fuse")
+        return n, fi
+
+    def SearchBySim3(self, keys1, kf_desc1, bounds1, keys2, kf_desc2, bounds2, points_1in2, mp_desc1, points_2in1, mp_desc2, nlevels: int = 8):
+        """ORBmatcher::SearchBySim3 (reference src/ORBmatcher3.cc:37-254) -> (nFound, matches12[n1])."""
+        k1 = np.ascontiguousarray(keys1, KEYPOINT_DTYPE); k2 = np.ascontiguousarray(keys2, KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(kf_desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(kf_desc2, np.uint8).reshape(-1, 32)
+        p12 = np.ascontiguousarray(points_1in2, WINDOW_POINT_DTYPE); p21 = np.ascontiguousarray(points_2in1, WINDOW_POINT_DTYPE)
+        m1 = np.ascontiguousarray(mp_desc1, np.uint8).reshape(-1, 32); m2 = np.ascontiguousarray(mp_desc2, np.uint8).reshape(-1, 32)
+        assert len(p12) == len(k1) == len(m1) and len(p21) == len(k2) == len(m2)
+        b1 = np.ascontiguousarray(bounds1, np.float32); b2 = np.ascontiguousarray(bounds2, np.float32)
+        out = np.full(len(k1), -1, np.int32)
+        n = self._lib.orbx_search_by_sim3(self._h, k1.ctypes.data, d1.ctypes.data, len(k1), b1.ctypes.data, k2.ctypes.data, d2.ctypes.data, len(k2),
+                                          b2.ctypes.data, p12.ctypes.data, m1.ctypes.data, p21.ctypes.data, m2.ctypes.data, int(nlevels), out.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_sim3")
+        return n, out
 
     def SearchForTriangulation(self, kf1, kf2, geometry, bOnlyStereo: bool = False, bCoarse: bool = False, checkOrientation: bool = True):
         """ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (reference src/ORBmatcher2.cc:179-418).

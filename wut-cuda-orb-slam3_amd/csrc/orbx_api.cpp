@@ -2047,6 +2047,98 @@ extern "C" int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyfram
     return nmatches;
 }
 
+// The window search of ORBmatcher::Fuse (src/ORBmatcher2.cc:420-610, 612-770) and ORBmatcher::SearchBySim3 (src/ORBmatcher3.cc:37-254).
+static int keyframeWindowsImpl(const char *fn, orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, const float *u_right, int n,
+                               float min_x, float max_x, float min_y, float max_y, const float *inv_level_sigma2, int nlevels,
+                               const orbx_window_point *points, const uint8_t *point_desc, int np, int chi2_test, int32_t *best_idx,
+                               int32_t *best_dist)
+{
+    static_assert(sizeof(orbx_window_point) == 24, "orbx_window_point layout");
+    if (!m || n < 0 || np < 0 || (n > 0 && (!keys || !desc)) || (np > 0 && (!points || !point_desc || !best_idx || !best_dist)) || nlevels <= 0 ||
+        nlevels > ORBX_MAX_LEVELS || (chi2_test && !inv_level_sigma2))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    if (np > m->maxQ || n > m->maxT) return setError(ORBX_ERR_CAPACITY, "%s: %d points x %d keypoints exceed the matcher capacity %d x %d", fn, np, n, m->maxQ, m->maxT);
+    int rc = checkGridBounds(min_x, max_x, min_y, max_y, fn);
+    if (rc != ORBX_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        if (keys[i].octave < 0 || keys[i].octave >= nlevels) return setError(ORBX_ERR_INVALID_ARG, "%s: keypoint %d has octave %d outside [0, %d)", fn, i, keys[i].octave, nlevels);
+    for (int i = 0; i < np; ++i) { best_idx[i] = -1; best_dist[i] = INT32_MAX; }
+    if (n == 0 || np == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, point_desc, np, desc, n)) != ORBX_OK) return rc;
+    if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
+    if ((rc = m->d_work.ensure(2 * (size_t)m->maxQ + 6 * (size_t)m->maxQ + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_prev.ensure((size_t)m->maxT + ORBX_MAX_LEVELS)) != ORBX_OK) return rc;
+    int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
+    int *dIdx = m->d_work.p, *dDist = dIdx + m->maxQ;
+    orbx_window_point *dPts = (orbx_window_point *)(dDist + m->maxQ);
+    float *dUR = u_right ? m->d_prev.p : nullptr, *dSig = m->d_prev.p + m->maxT;
+    hipStream_t st = m->stream;
+    HIP_TRY(hipMemcpyAsync(m->d_kr.p, keys, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dPts, points, (size_t)np * sizeof(orbx_window_point), hipMemcpyHostToDevice, st));
+    if (u_right) HIP_TRY(hipMemcpyAsync(dUR, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    if (inv_level_sigma2) HIP_TRY(hipMemcpyAsync(dSig, inv_level_sigma2, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(orbxLaunchGridBuild(st, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
+    HIP_TRY(orbxLaunchKeyframeWindowSearch(st, m->d_kr.p, m->d_t.p, dUR, dSig, cs, it, min_x, max_x, min_y, max_y, dPts, m->d_q.p, np, chi2_test != 0,
+                                           dIdx, dDist));
+    HIP_TRY(hipMemcpyAsync(best_idx, dIdx, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(best_dist, dDist, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_keyframe_windows(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, const float *u_right, int n, float min_x,
+                                            float max_x, float min_y, float max_y, const float *inv_level_sigma2, int nlevels,
+                                            const orbx_window_point *points, const uint8_t *point_desc, int np, int chi2_test, int32_t *best_idx,
+                                            int32_t *best_dist)
+{
+    ORBX_API_ENTRY;
+    return keyframeWindowsImpl("orbx_search_keyframe_windows", m, keys, desc, u_right, n, min_x, max_x, min_y, max_y, inv_level_sigma2, nlevels, points,
+                               point_desc, np, chi2_test, best_idx, best_dist);
+}
+
+extern "C" int orbx_fuse(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, const float *u_right, int n, float min_x, float max_x,
+                         float min_y, float max_y, const float *inv_level_sigma2, int nlevels, const orbx_window_point *points,
+                         const uint8_t *point_desc, int np, int chi2_test, int32_t *fused_idx)
+{
+    ORBX_API_ENTRY;
+    if (np > 0 && !fused_idx) return setError(ORBX_ERR_INVALID_ARG, "orbx_fuse: null output");
+    std::vector<int32_t> dist((size_t)std::max(np, 1));
+    const int rc = keyframeWindowsImpl("orbx_fuse", m, keys, desc, u_right, n, min_x, max_x, min_y, max_y, inv_level_sigma2, nlevels, points, point_desc, np,
+                                       chi2_test, fused_idx, dist.data());
+    if (rc != ORBX_OK) return rc;
+    int nFused = 0;
+    for (int i = 0; i < np; ++i) {
+        if (dist[i] <= 50) ++nFused;  // bestDist <= TH_LOW (:581, :716)
+        else fused_idx[i] = -1;
+    }
+    return nFused;
+}
+
+extern "C" int orbx_search_by_sim3(orbx_matcher *m, const orbx_keypoint *keys1, const uint8_t *kf_desc1, int n1, const float *bounds1,
+                                   const orbx_keypoint *keys2, const uint8_t *kf_desc2, int n2, const float *bounds2,
+                                   const orbx_window_point *points_1in2, const uint8_t *mp_desc1, const orbx_window_point *points_2in1,
+                                   const uint8_t *mp_desc2, int nlevels, int32_t *matches12)
+{
+    ORBX_API_ENTRY;
+    if (!bounds1 || !bounds2 || (n1 > 0 && !matches12)) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_sim3: null argument");
+    const int TH_HIGH = 100;
+    std::vector<int32_t> m1((size_t)std::max(n1, 1)), d1((size_t)std::max(n1, 1)), m2((size_t)std::max(n2, 1)), d2((size_t)std::max(n2, 1));
+    int rc = keyframeWindowsImpl("orbx_search_by_sim3", m, keys2, kf_desc2, nullptr, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3], nullptr, nlevels,
+                                 points_1in2, mp_desc1, n1, 0, m1.data(), d1.data());
+    if (rc != ORBX_OK) return rc;
+    rc = keyframeWindowsImpl("orbx_search_by_sim3", m, keys1, kf_desc1, nullptr, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3], nullptr, nlevels,
+                             points_2in1, mp_desc2, n2, 0, m2.data(), d2.data());
+    if (rc != ORBX_OK) return rc;
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {  // check agreement (:236-250)
+        matches12[i1] = -1;
+        const int idx2 = d1[i1] <= TH_HIGH ? m1[i1] : -1;
+        if (idx2 >= 0 && d2[idx2] <= TH_HIGH && m2[idx2] == i1) { matches12[i1] = idx2; ++nFound; }
+    }
+    return nFound;
+}
+
 // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811.
 static int checkCamera(const float *k4, const float *dist, int ndist, const float *knew4, const char *fn)
 {

@@ -175,6 +175,9 @@ struct OrbxSftHost {
     int *matches, *binOf, *result;
 };
 hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h);
+hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
+                                          const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, const void *pts,
+                                          const uint8_t *ptDesc, int np, int chi2, int *bestIdx, int *bestDist);
 hipError_t orbxLaunchBowTransformBatch(hipStream_t st, const int *childStart, const int *childNode, const void *childDesc, const int *wordOfNode,
                                        const double *weightOfNode, int L, int scoring, int weighting, const void *feat, const int *nPerFrame,
                                        int nframes, int cap, int levelsup, int *featWord, int *featNode, double *featWeight, int *bowWord,

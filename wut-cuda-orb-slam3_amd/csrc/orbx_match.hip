@@ -2536,3 +2536,117 @@ hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h
     }
     return hipGetLastError();
 }
+
+
+// ---- the window search of ORBmatcher::Fuse / SearchBySim3 ----------------------------------------------------------------------------
+// reference src/ORBmatcher2.cc:522-579, 690-714 and src/ORBmatcher3.cc:120-145, 188-213 on KeyFrame::GetFeaturesInArea
+// (src/KeyFrame.cc:704-748).  The projected map points do not interact (what Fuse does with a result is map bookkeeping of the caller),
+// so one wave per point walks the window's cells in the reference's order (ix outer, iy inner, push order inside a cell) 64 keypoints at
+// a time; "the first keypoint at the smallest distance" = the minimum of (distance << 32 | position in that order).
+struct KfwPoint { float u, v, ur, radius; int level, search; };
+struct KfwArgs {
+    const MtKp *keys; const uint8_t *desc; const float *uRight; const float *invSigma2;
+    const int *cellStart, *items; GridBounds b;
+    const KfwPoint *pts; const uint8_t *ptDesc; int np, chi2;
+    int *bestIdx, *bestDist;
+};
+
+__global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= a.np) return;
+    const KfwPoint P = a.pts[i];
+    int outIdx = -1, outDist = INT_MAX;
+    const float x = P.u, y = P.v, r = P.radius;
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+    const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+    const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+    if (P.search && !(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.ptDesc + (size_t)i * 32))[w];
+        const int ny = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny;
+        __shared__ int stage[64];
+        unsigned long long best = ~0ull;
+        unsigned seqBase = 0;
+        for (int cb = 0; cb < nCells; cb += 64) {  // cells in (ix outer, iy inner) order, 64 at a time
+            const int ci = cb + lane;
+            int s = 0, e = 0;
+            if (ci < nCells) {
+                const int cell = (cx0 + ci / ny) * GRID_ROWS + cy0 + ci % ny;
+                s = a.cellStart[cell]; e = a.cellStart[cell + 1];
+            }
+            int total;
+            const int off = mt_excl_scan(e - s, total);
+            // the keypoints of these cells in order, 64 per pass: lane -> the cell that holds position p (its lane range covers p)
+            for (int pb = 0; pb < total; pb += 64) {
+                __syncthreads();
+                // every lane publishes the keypoints of its cell that fall into [pb, pb + 64)
+                for (int j = max(s, s + (pb - off)); j < e && off + (j - s) < pb + 64; ++j) stage[off + (j - s) - pb] = a.items[j];
+                __syncthreads();
+                const int p = pb + lane;
+                if (p < total) {
+                    const int idx = stage[lane];
+                    const MtKp kp = a.keys[idx];
+                    bool keep = fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;   // GetFeaturesInArea (:738-742)
+                    const int kpLevel = kp.octave;
+                    if (kpLevel < P.level - 1 || kpLevel > P.level) keep = false;
+                    if (keep && a.chi2) {
+                        const float ex = __fsub_rn(P.u, kp.x), ey = __fsub_rn(P.v, kp.y);
+                        const float urc = a.uRight ? a.uRight[idx] : -1.f;
+                        if (urc >= 0.f) {
+                            const float er = __fsub_rn(P.ur, urc);
+                            const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                            if ((double)__fmul_rn(e2, a.invSigma2[kpLevel]) > 7.8) keep = false;
+                        } else {
+                            const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                            if ((double)__fmul_rn(e2, a.invSigma2[kpLevel]) > 5.99) keep = false;
+                        }
+                    }
+                    if (keep) {
+                        const uint32_t *t = (const uint32_t *)(a.desc + (size_t)idx * 32);
+                        int dist = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+                        const unsigned long long key = ((unsigned long long)(unsigned)dist << 32) | (unsigned long long)(seqBase + (unsigned)p);
+                        best = min(best, key);
+                    }
+                }
+            }
+            seqBase += (unsigned)total;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, o), hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), o);
+            best = min(best, ((unsigned long long)hi << 32) | lo);
+        }
+        if (best != ~0ull) {
+            // position -> keypoint: walk the cells again on lane 0 (rare relative to the scan: once per point)
+            outDist = (int)(best >> 32);
+            unsigned pos = (unsigned)best;
+            if (lane == 0) {
+                for (int ci = 0; ci < nCells; ++ci) {
+                    const int cell = (cx0 + ci / ny) * GRID_ROWS + cy0 + ci % ny;
+                    const unsigned cnt = (unsigned)(a.cellStart[cell + 1] - a.cellStart[cell]);
+                    if (pos < cnt) { outIdx = a.items[a.cellStart[cell] + (int)pos]; break; }
+                    pos -= cnt;
+                }
+            }
+        }
+    }
+    if (lane == 0) { a.bestIdx[i] = outIdx; a.bestDist[i] = outDist; }
+}
+
+hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
+                                          const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, const void *pts,
+                                          const uint8_t *ptDesc, int np, int chi2, int *bestIdx, int *bestDist)
+{
+    if (np <= 0) return hipSuccess;
+    KfwArgs a;
+    a.keys = (const MtKp *)keys; a.desc = desc; a.uRight = uRight; a.invSigma2 = invSigma2; a.cellStart = cellStart; a.items = items;
+    a.b.minX = minX; a.b.minY = minY; a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);
+    a.pts = (const KfwPoint *)pts; a.ptDesc = ptDesc; a.np = np; a.chi2 = chi2; a.bestIdx = bestIdx; a.bestDist = bestDist;
+    hipLaunchKernelGGL(k_kf_window_search, dim3(np), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
