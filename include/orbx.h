@@ -466,6 +466,25 @@ int orbx_search_by_sim3(orbx_matcher *m, const orbx_keypoint *keys1, const uint8
                         const orbx_window_point *points_1in2, const uint8_t *mp_desc1, const orbx_window_point *points_2in1,
                         const uint8_t *mp_desc2, int nlevels, int32_t *matches12);
 
+/* void MapPoint::ComputeDistinctiveDescriptors() — reference src/MapPoint.cc:329-403 (decl include/MapPoint.h), for a batch of map points:
+ * the observed descriptors of point p are rows [start[p], start[p + 1]) of `desc` (vDescriptors in the order the reference collects
+ * them, :346-362); best[p] = the row (relative to start[p]) with the least median DescriptorDistance to all of them - the median being
+ * element (int)(0.5 * (N - 1)) of the sorted distances including the 0 to itself (:386-389), the FIRST such row on ties (:391) - or -1 for
+ * a point without observations.  mDescriptor = that row.  LocalMapping / Tracking call it after every change of a point's observations
+ * (12 call sites); one wave per map point here.  Returns 0 or a negative status. */
+int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc, const int32_t *start, int npoints, int32_t *best);
+
+/* int ORBmatcher::SearchByProjection(KeyFrame *pKF, Sim3f &Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th,
+ * float ratioHamming) — reference src/ORBmatcher1.cc:429-533 (decl include/ORBmatcher.h:59-60), and the overload that also records the
+ * points' keyframes (:535-648): the same window search as orbx_search_keyframe_windows (no reprojection test), but a keypoint that
+ * already holds a match - matched[idx] != 0 on entry (vpMatched[idx] != NULL), or taken by an EARLIER accepted point of this call - is
+ * skipped (:500-501), and a point is accepted when bestDist <= TH_LOW * ratioHamming (:520).  points[i].search = 0 for a point that is
+ * bad, already found (spAlreadyFound, :444-453) or fails a visibility test.  new_match[idx] = the point i whose map point
+ * vpMatched[idx] (and vpMatchedKF[idx] = vpPointsKFs[i]) becomes, -1 = unchanged.  Returns nmatches or a negative status. */
+int orbx_search_by_projection_sim3(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x, float min_y,
+                                   float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc, int np,
+                                   const uint8_t *matched, float ratio_hamming, int32_t *new_match);
+
 
 /* void Frame::UndistortKeyPoints() — reference src/Frame.cc:777-811 (decl include/Frame.h): mvKeysUn from mvKeys.
  * k4 = fx, fy, cx, cy of static_cast<Pinhole*>(mpCamera)->toK(); dist = mDistCoef (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]], up to

@@ -92,6 +92,9 @@ def lib() -> ctypes.CDLL:
                                                      c_int, c_int, c_void_p, c_void_p]
         L.oracle_search_by_sim3.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p]
+        L.oracle_search_by_projection_sim3.argtypes = [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_int, c_void_p,
+                                                       c_float, c_void_p]
+        L.oracle_distinctive_descriptors.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
         L.oracle_search_for_triangulation.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
         L.oracle_synth_frame.restype = None
@@ -532,4 +535,24 @@ def search_by_sim3(keys1, kf_desc1, bounds1, keys2, kf_desc2, bounds2, points_1i
     out = np.full(len(k1), -1, np.int32)
     n = lib().oracle_search_by_sim3(k1.ctypes.data, d1.ctypes.data, len(k1), b1.ctypes.data, k2.ctypes.data, d2.ctypes.data, len(k2), b2.ctypes.data,
                                     p12.ctypes.data, m1.ctypes.data, p21.ctypes.data, m2.ctypes.data, out.ctypes.data)
+    return n, out
+
+
+def distinctive_descriptors(desc, start):
+    """MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:329-403), batched -> best[npoints]."""
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); st = np.ascontiguousarray(start, np.int32)
+    best = np.full(len(st) - 1, -1, np.int32)
+    lib().oracle_distinctive_descriptors(d.ctypes.data, st.ctypes.data, len(st) - 1, best.ctypes.data)
+    return best
+
+
+def search_by_projection_sim3(keys, desc, bounds, points, point_desc, matched, ratio_hamming=1.0):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (reference src/ORBmatcher1.cc:429-533) -> (nmatches,
+    new_match[n])."""
+    k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points, WINDOW_POINT_DTYPE); pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+    mt = np.ascontiguousarray(matched, np.uint8)
+    out = np.full(len(k), -1, np.int32)
+    n = lib().oracle_search_by_projection_sim3(k.ctypes.data, d.ctypes.data, len(k), bounds[0], bounds[1], bounds[2], bounds[3], p.ctypes.data,
+                                               pd.ctypes.data, len(p), mt.ctypes.data, float(ratio_hamming), out.ctypes.data)
     return n, out

@@ -2056,3 +2056,68 @@ extern "C" int oracle_search_by_sim3(const oracle_keypoint *keys1, const uint8_t
     }
     return nFound;
 }
+
+// MapPoint::ComputeDistinctiveDescriptors — reference src/MapPoint.cc:364-398 (the part after the observations have been collected)
+extern "C" int oracle_distinctive_descriptors(const uint8_t *desc, const int32_t *start, int npoints, int32_t *best)
+{
+    for (int p = 0; p < npoints; ++p) {
+        const size_t N = (size_t)(start[p + 1] - start[p]);
+        best[p] = -1;
+        if (N == 0) continue;                                        // if(vDescriptors.empty()) return;
+        const uint8_t *D = desc + (size_t)start[p] * 32;
+        std::vector<float> Distances(N * N);                          // float Distances[N][N];
+        for (size_t i = 0; i < N; i++) {
+            Distances[i * N + i] = 0;
+            for (size_t j = i + 1; j < N; j++) {
+                const int distij = oracle_hamming256(D + i * 32, D + j * 32);
+                Distances[i * N + j] = distij;
+                Distances[j * N + i] = distij;
+            }
+        }
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (size_t i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+            std::sort(vDists.begin(), vDists.end());
+            const int median = vDists[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = (int)i; }
+        }
+        best[p] = BestIdx;
+    }
+    return 0;
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame *pKF, Sim3f &Scw, vpPoints, vpMatched, th, ratioHamming) — reference src/ORBmatcher1.cc:429-533
+// (and :535-648, which only adds vpMatchedKF): the loop from GetFeaturesInArea on; vpMatched is updated while the points are walked.
+extern "C" int oracle_search_by_projection_sim3(const oracle_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x, float min_y,
+                                                float max_y, const oracle_window_point *points, const uint8_t *point_desc, int np,
+                                                const uint8_t *matched, float ratio_hamming, int32_t *new_match)
+{
+    const int TH_LOW = 50;
+    const FrameGrid G = assignFeaturesToGrid(keys, n, min_x, max_x, min_y, max_y);
+    std::vector<char> vpMatched((size_t)n);
+    for (int i = 0; i < n; ++i) { vpMatched[i] = matched && matched[i] ? 1 : 0; new_match[i] = -1; }
+    int nmatches = 0;
+    for (int iMP = 0; iMP < np; iMP++) {
+        const oracle_window_point &P = points[iMP];
+        if (!P.search) continue;
+        const int nPredictedLevel = P.level;
+        const std::vector<size_t> vIndices = getFeaturesInArea(G, keys, P.u, P.v, P.radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t *dMP = point_desc + (size_t)iMP * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (std::vector<size_t>::const_iterator vit = vIndices.begin(), vend = vIndices.end(); vit != vend; vit++) {
+            const size_t idx = *vit;
+            if (vpMatched[idx]) continue;
+            const int kpLevel = keys[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = oracle_hamming256(dMP, desc + idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        if (bestDist <= TH_LOW * ratio_hamming) {
+            vpMatched[bestIdx] = 1;
+            new_match[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}

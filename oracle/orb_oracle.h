@@ -204,6 +204,14 @@ int oracle_search_by_sim3(const oracle_keypoint *keys1, const uint8_t *kf_desc1,
                           const uint8_t *kf_desc2, int n2, const float *bounds2, const oracle_window_point *points_1in2, const uint8_t *mp_desc1,
                           const oracle_window_point *points_2in1, const uint8_t *mp_desc2, int32_t *matches12);
 
+/* ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, vpPoints, vpMatched, th, ratioHamming) (src/ORBmatcher1.cc:429-533; :535-648). */
+int oracle_search_by_projection_sim3(const oracle_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x, float min_y, float max_y,
+                                     const oracle_window_point *points, const uint8_t *point_desc, int np, const uint8_t *matched,
+                                     float ratio_hamming, int32_t *new_match);
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403) for a batch of map points (CSR rows of `desc`). */
+int oracle_distinctive_descriptors(const uint8_t *desc, const int32_t *start, int npoints, int32_t *best);
+
 /* Deterministic synthetic frame (tools: same integer generator as the product's orbx_synth_frame; kept
  * here so the oracle library is self-contained for CPU-only tests). */
 void oracle_synth_frame(uint64_t seed, int w, int h, uint8_t *out, ptrdiff_t stride);

@@ -125,3 +125,65 @@ def test_search_by_sim3_matches_oracle(pkg, orc):
     ok = got[1] >= 0
     assert np.array_equal(perm[got[1][ok]], np.flatnonzero(ok)) or (perm[got[1][ok]] == np.flatnonzero(ok)).mean() > 0.95
     m.close()
+
+
+def test_oracle_distinctive_descriptor_hand_traced(orc):
+    """MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:364-398).  Four descriptors A, A^1bit, A^2bits (disjoint from the
+    first), B far away: distance rows sorted = A: [0 1 2 128+], A1: [0 1 3 ..], A2: [0 2 3 ..], B: [0 x x x]; the median is element
+    (int)(0.5 * 3) = 1 -> 1, 1, 2, big: the FIRST row with median 1 wins."""
+    A = np.zeros(32, np.uint8)
+    rows = np.stack([A, _flip(A, [0]), _flip(A, [8, 9]), np.full(32, 0xFF, np.uint8)])
+    assert orc.distinctive_descriptors(rows, [0, 4]).tolist() == [0]
+    assert orc.distinctive_descriptors(rows[[3, 2, 1, 0]], [0, 4]).tolist() == [2]      # order reversed: A1 (median 1) comes before A
+    assert orc.distinctive_descriptors(rows, [0, 0, 1, 4]).tolist() == [-1, 0, 0]       # no observation / one / three ([A1 A2 B]: medians 3 3 254)
+    assert orc.distinctive_descriptors(rows, [0, 2]).tolist() == [0]                    # N = 2: median = element 0 = 0 for both rows
+
+
+@pytest.mark.gpu
+def test_distinctive_descriptors_match_oracle(pkg, orc):
+    rng = np.random.default_rng(31)
+    counts = np.concatenate([rng.integers(0, 12, 400), [64, 65, 130, 1, 0, 300]])
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    base = rng.integers(0, 256, (len(counts), 32), dtype=np.uint8)
+    desc = np.concatenate([np.stack([_flip(base[p], rng.integers(0, 256, int(rng.integers(0, 40)))) for _ in range(c)]) if c else
+                           np.zeros((0, 32), np.uint8) for p, c in enumerate(counts)])
+    desc[start[3]:start[4]] = desc[start[3]]   # a point whose observations are all equal: every median 0 -> row 0
+    m = pkg.ORBmatcher(64, 64)
+    got = m.ComputeDistinctiveDescriptors(desc, start)
+    assert np.array_equal(got, orc.distinctive_descriptors(desc, start))
+    assert got[3] <= 0 and (got[counts == 0] == -1).all()
+    m.close()
+
+
+def test_oracle_projection_sim3_hand_traced(pkg, orc):
+    """src/ORBmatcher1.cc:494-523: three points want keypoint 1 (the twin of their descriptor).  Point 0 takes it; point 1 then takes its
+    second choice (keypoint 2, distance 5); point 2 finds both taken and its third choice is at distance 60 > TH_LOW -> no match.  With
+    keypoint 1 matched on entry, point 0 takes keypoint 2 and the others nothing; ratioHamming 0.09 (bound 4.5) accepts distance <= 4."""
+    rng = np.random.default_rng(5)
+    D = rng.integers(0, 256, 32, dtype=np.uint8)
+    k = _keys(pkg, [(200, 200), (201, 200), (202, 201), (203, 199)], [1, 1, 1, 1])
+    d = np.stack([_flip(D, range(60)), D, _flip(D, [1, 2, 3, 4, 5]), _flip(D, range(100, 170))])
+    pts = _points(orc, [(201, 200, 0, 8, 1, 1)] * 3)
+    pd = np.stack([D, D, D])
+    n, nm = orc.search_by_projection_sim3(k, d, BOUNDS, pts, pd, [0, 0, 0, 0])
+    assert n == 2 and nm.tolist() == [-1, 0, 1, -1]
+    n, nm = orc.search_by_projection_sim3(k, d, BOUNDS, pts, pd, [0, 1, 0, 0])
+    assert n == 1 and nm.tolist() == [-1, -1, 0, -1]
+    n, nm = orc.search_by_projection_sim3(k, d, BOUNDS, pts, pd, [0, 0, 0, 0], ratio_hamming=0.09)
+    assert n == 1 and nm.tolist() == [-1, 0, -1, -1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,np_,dense,ratio", [(2000, 1500, False, 1.0), (1500, 3000, True, 1.0), (800, 800, False, 0.6)])
+def test_projection_sim3_matches_oracle(pkg, orc, n, np_, dense, ratio):
+    """Many points per keypoint (np > n, dense clusters): chains of "an earlier point took it" that the fixed-point iteration must resolve
+    exactly like the reference's in-order walk."""
+    k, d, ur, pts, pd = _scene(pkg, orc, n, np_, seed=7 * n + np_, dense=dense)
+    rng = np.random.default_rng(n)
+    matched = (rng.random(n) < 0.2).astype(np.uint8)
+    m = pkg.ORBmatcher(8192, 8192)
+    got = m.SearchByProjectionSim3(k, d, BOUNDS, pts, pd, matched, ratio, LEVELS)
+    ref = orc.search_by_projection_sim3(k, d, BOUNDS, pts, pd, matched, ratio)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+    assert got[0] > 50 and not (got[1][matched == 1] >= 0).any()
+    m.close()

@@ -72,6 +72,8 @@ ABI_SYMBOLS = [
     "orbx_search_keyframe_windows",
     "orbx_fuse",
     "orbx_search_by_sim3",
+    "orbx_distinctive_descriptors",
+    "orbx_search_by_projection_sim3",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
     "orbx_vocabulary_create",
@@ -187,6 +189,9 @@ def load_library() -> ctypes.CDLL:
                               c_int, c_int, c_void_p]
     lib.orbx_search_by_sim3.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_void_p]
+    lib.orbx_distinctive_descriptors.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+    lib.orbx_search_by_projection_sim3.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
+                                                   c_int, c_void_p, c_float, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
@@ -739,6 +744,28 @@ class ORBmatcher:
         if n < 0:
             _check(n, "orbx_search_by_bow_keyframes")
         return n, matches
+
+    def SearchByProjectionSim3(self, keys, desc, bounds, points, point_desc, matched, ratioHamming: float = 1.0, nlevels: int = 8):
+        """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (reference src/ORBmatcher1.cc:429-533, 535-648), from
+        GetFeaturesInArea on -> (nmatches, new_match[n]): the point that now matches keypoint idx, -1 = unchanged."""
+        k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        p = np.ascontiguousarray(points, WINDOW_POINT_DTYPE); pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+        mt = np.ascontiguousarray(matched, np.uint8)
+        assert len(k) == len(d) == len(mt) and len(p) == len(pd)
+        out = np.full(len(k), -1, np.int32)
+        n = self._lib.orbx_search_by_projection_sim3(self._h, k.ctypes.data, d.ctypes.data, len(k), bounds[0], bounds[1], bounds[2], bounds[3], int(nlevels),
+                                                     p.ctypes.data, pd.ctypes.data, len(p), mt.ctypes.data, float(ratioHamming), out.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_projection_sim3")
+        return n, out
+
+    def ComputeDistinctiveDescriptors(self, desc, start):
+        """MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:329-403) for a batch of map points: the observed descriptors of
+        point p are rows start[p] .. start[p + 1] of desc -> best[p] = row (relative) that becomes mDescriptor, -1 without observations."""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); st = np.ascontiguousarray(start, np.int32)
+        best = np.full(len(st) - 1, -1, np.int32)
+        _check(self._lib.orbx_distinctive_descriptors(self._h, d.ctypes.data, st.ctypes.data, len(st) - 1, best.ctypes.data), "orbx_distinctive_descriptors")
+        return best
 
     def SearchKeyFrameWindows(self, keys, desc, bounds, points, point_desc, nlevels: int = 8, u_right=None, inv_level_sigma2=None, chi2_test: bool = False):
         """The per-map-point search of ORBmatcher::Fuse / SearchBySim3 (reference src/ORBmatcher2.cc:522-579, 690-714; src/ORBmatcher3.cc:

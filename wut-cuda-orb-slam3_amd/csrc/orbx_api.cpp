@@ -2139,6 +2139,95 @@ extern "C" int orbx_search_by_sim3(orbx_matcher *m, const orbx_keypoint *keys1, 
     return nFound;
 }
 
+// int ORBmatcher::SearchByProjection(KeyFrame *pKF, Sim3f &Scw, vpPoints, vpMatched, th, ratioHamming) — reference src/ORBmatcher1.cc:429-533
+// (:535-648 with vpMatchedKF).  Point i may not take a keypoint that an earlier accepted point took, and nothing else couples the points: the
+// choice of point i depends on the points j < i only.  So the window search runs for ALL points at once against "the earliest accepted
+// taker of every keypoint" of the previous round and is repeated until no choice changes - after k rounds the first k points are final;
+// in practice two or three rounds (a conflict needs two points that want the same keypoint).
+extern "C" int orbx_search_by_projection_sim3(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x,
+                                              float min_y, float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc,
+                                              int np, const uint8_t *matched, float ratio_hamming, int32_t *new_match)
+{
+    ORBX_API_ENTRY;
+    const char *fn = "orbx_search_by_projection_sim3";
+    if (!m || n < 0 || np < 0 || (n > 0 && (!keys || !desc || !new_match)) || (np > 0 && (!points || !point_desc)) || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    if (np > m->maxQ || n > m->maxT) return setError(ORBX_ERR_CAPACITY, "%s: %d points x %d keypoints exceed the matcher capacity %d x %d", fn, np, n, m->maxQ, m->maxT);
+    int rc = checkGridBounds(min_x, max_x, min_y, max_y, fn);
+    if (rc != ORBX_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (keys[i].octave < 0 || keys[i].octave >= nlevels) return setError(ORBX_ERR_INVALID_ARG, "%s: keypoint %d has octave %d outside [0, %d)", fn, i, keys[i].octave, nlevels);
+        new_match[i] = -1;
+    }
+    if (n == 0 || np == 0) return 0;
+    HIP_TRY(hipSetDevice(m->device));
+    if ((rc = uploadQT(m, point_desc, np, desc, n)) != ORBX_OK) return rc;
+    if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
+    if ((rc = m->d_work.ensure(8 * (size_t)m->maxQ + (size_t)m->maxT + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_bin.ensure((size_t)m->maxQ + (size_t)m->maxT)) != ORBX_OK) return rc;
+    int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
+    int *dIdx = m->d_work.p, *dDist = dIdx + m->maxQ;
+    orbx_window_point *dPts = (orbx_window_point *)(dDist + m->maxQ);
+    int *dOwner = (int *)(dPts + m->maxQ);
+    signed char *dBlocked = m->d_bin.p;
+    hipStream_t st = m->stream;
+    std::vector<signed char> blocked((size_t)n, 0);
+    if (matched) for (int i = 0; i < n; ++i) blocked[i] = matched[i] ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(m->d_kr.p, keys, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dPts, points, (size_t)np * sizeof(orbx_window_point), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dBlocked, blocked.data(), (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(orbxLaunchGridBuild(st, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
+    std::vector<int32_t> idx((size_t)np), dist((size_t)np), choice((size_t)np, -2), owner((size_t)n, -1);
+    const float bound = 50 * ratio_hamming;  // TH_LOW * ratioHamming (:520), int * float in float
+    for (int round = 0; round <= np; ++round) {
+        HIP_TRY(hipMemcpyAsync(dOwner, owner.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(orbxLaunchKeyframeWindowSearch(st, m->d_kr.p, m->d_t.p, nullptr, nullptr, cs, it, min_x, max_x, min_y, max_y, dPts, m->d_q.p, np, 0, dIdx,
+                                               dDist, dBlocked, dOwner));
+        HIP_TRY(hipMemcpyAsync(idx.data(), dIdx, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(dist.data(), dDist, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool changed = false;
+        std::fill(owner.begin(), owner.end(), -1);
+        for (int i = 0; i < np; ++i) {  // accepted choices of this round; the earliest taker owns a keypoint
+            const int c = idx[i] >= 0 && (float)dist[i] <= bound ? idx[i] : -1;
+            if (c != choice[i]) { changed = true; choice[i] = c; }
+            if (c >= 0 && owner[c] < 0) owner[c] = i;
+        }
+        if (!changed) break;
+    }
+    int nmatches = 0;
+    for (int i = 0; i < np; ++i)
+        if (choice[i] >= 0 && owner[choice[i]] == i) { new_match[choice[i]] = i; ++nmatches; }
+    return nmatches;
+}
+
+// void MapPoint::ComputeDistinctiveDescriptors() — reference src/MapPoint.cc:329-403, batched over map points.
+extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc, const int32_t *start, int npoints, int32_t *best)
+{
+    ORBX_API_ENTRY;
+    if (!m || npoints < 0 || (npoints > 0 && (!start || !best))) return setError(ORBX_ERR_INVALID_ARG, "orbx_distinctive_descriptors: bad argument");
+    if (npoints == 0) return ORBX_OK;
+    if (start[0] != 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_distinctive_descriptors: start[0] must be 0");
+    for (int p = 0; p < npoints; ++p) {
+        if (start[p + 1] < start[p]) return setError(ORBX_ERR_INVALID_ARG, "orbx_distinctive_descriptors: start is not ascending at point %d", p);
+        if (start[p + 1] - start[p] > 65535) return setError(ORBX_ERR_CAPACITY, "orbx_distinctive_descriptors: point %d has more than 65535 observations", p);
+    }
+    const size_t total = (size_t)start[npoints];
+    if (total > 0 && !desc) return setError(ORBX_ERR_INVALID_ARG, "orbx_distinctive_descriptors: null descriptors");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->d_siWork.ensure(total * 32 + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_mat.ensure(2 * (size_t)npoints + 2)) != ORBX_OK) return rc;
+    int *dStart = m->d_mat.p, *dBest = dStart + npoints + 1;
+    hipStream_t st = m->stream;
+    if (total) HIP_TRY(hipMemcpyAsync(m->d_siWork.p, desc, total * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dStart, start, ((size_t)npoints + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(orbxLaunchDistinctive(st, m->d_siWork.p, dStart, npoints, dBest));
+    HIP_TRY(hipMemcpyAsync(best, dBest, (size_t)npoints * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ORBX_OK;
+}
+
 // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811.
 static int checkCamera(const float *k4, const float *dist, int ndist, const float *knew4, const char *fn)
 {

@@ -2549,6 +2549,9 @@ struct KfwArgs {
     const int *cellStart, *items; GridBounds b;
     const KfwPoint *pts; const uint8_t *ptDesc; int np, chi2;
     int *bestIdx, *bestDist;
+    // SearchByProjection(KeyFrame, Sim3, ..): keypoints that hold a match on entry, and the earliest accepted point that wants a keypoint
+    // in the current round of the fixed-point iteration (a point skips the keypoints an EARLIER point took) - NULL for Fuse / SearchBySim3
+    const signed char *blocked; const int *owner;
 };
 
 __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
@@ -2592,6 +2595,8 @@ __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
                     bool keep = fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;   // GetFeaturesInArea (:738-742)
                     const int kpLevel = kp.octave;
                     if (kpLevel < P.level - 1 || kpLevel > P.level) keep = false;
+                    if (keep && a.blocked && a.blocked[idx]) keep = false;
+                    if (keep && a.owner) { const int o = a.owner[idx]; if (o >= 0 && o < i) keep = false; }
                     if (keep && a.chi2) {
                         const float ex = __fsub_rn(P.u, kp.x), ey = __fsub_rn(P.v, kp.y);
                         const float urc = a.uRight ? a.uRight[idx] : -1.f;
@@ -2640,13 +2645,61 @@ __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
 
 hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
                                           const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, const void *pts,
-                                          const uint8_t *ptDesc, int np, int chi2, int *bestIdx, int *bestDist)
+                                          const uint8_t *ptDesc, int np, int chi2, int *bestIdx, int *bestDist, const signed char *blocked,
+                                          const int *owner)
 {
     if (np <= 0) return hipSuccess;
     KfwArgs a;
+    a.blocked = blocked; a.owner = owner;
     a.keys = (const MtKp *)keys; a.desc = desc; a.uRight = uRight; a.invSigma2 = invSigma2; a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY; a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);
     a.pts = (const KfwPoint *)pts; a.ptDesc = ptDesc; a.np = np; a.chi2 = chi2; a.bestIdx = bestIdx; a.bestDist = bestDist;
     hipLaunchKernelGGL(k_kf_window_search, dim3(np), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---- MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:329-403) -------------------------------------------------------
+// One wave per map point, a lane per observed descriptor i (rows beyond 64 in further passes): the median of row i of the distance
+// matrix is the order statistic k = (int)(0.5 (N - 1)) of its N distances (its own 0 included), found without storing or sorting the row:
+// the smallest v in [0, 256] with #{j : dist(i, j) <= v} > k (a bisection over v, every step one sweep over the point's descriptors,
+// which all lanes read at the same address).  BestIdx = the first row with the least median = min over (median << 16 | i).
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t *desc, const int *start, int npoints, int *best)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= npoints) return;
+    const int s = start[p], N = start[p + 1] - s;
+    if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    const uint8_t *D = desc + (size_t)s * 32;
+    const int k = (int)(0.5 * (double)(N - 1));
+    unsigned key = 0xFFFFFFFFu;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        if (i >= N) continue;
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(D + (size_t)i * 32))[w];
+        int lo = 0, hi = 256;  // invariant: #{dist <= hi} > k; answer in [lo, hi]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; ++j) {
+                const uint32_t *t = (const uint32_t *)(D + (size_t)j * 32);
+                int dist = 0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
+                cnt += dist <= mid ? 1 : 0;
+            }
+            if (cnt > k) hi = mid; else lo = mid + 1;
+        }
+        key = min(key, ((unsigned)lo << 16) | (unsigned)min(i, 0xFFFF));
+    }
+    key = sbow_wave_min(key);
+    if (lane == 0) best[p] = (int)(key & 0xFFFFu);
+}
+
+hipError_t orbxLaunchDistinctive(hipStream_t st, const uint8_t *desc, const int *start, int npoints, int *best)
+{
+    if (npoints <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_distinctive, dim3(npoints), dim3(64), 0, st, desc, start, npoints, best);
     return hipGetLastError();
 }
