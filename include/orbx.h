@@ -485,6 +485,19 @@ int orbx_search_by_projection_sim3(orbx_matcher *m, const orbx_keypoint *keys, c
                                    float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc, int np,
                                    const uint8_t *matched, float ratio_hamming, int32_t *new_match);
 
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int
+ * ORBdist) — reference src/ORBmatcher3.cc:469-590 (decl include/ORBmatcher.h:57; Tracking::Relocalization), from GetFeaturesInArea on:
+ * keys / desc / has_map_point = CurrentFrame.mvKeysUn / mDescriptors / (mvpMapPoints[i] != NULL); points[i] = the keyframe's map point i
+ * projected with the frame's pose (search = 0: NULL, bad, in sAlreadyFound, outside the bounds or the distance range, :485-508),
+ * level = nPredictedLevel - the window takes levels nPredictedLevel - 1 .. + 1 (:513); point_angle[i] = pKF->mvKeysUn[i].angle.  A keypoint
+ * that holds a map point - on entry or from an earlier accepted point - is skipped (:525-526); accepted: bestDist <= ORBdist (:537); then the
+ * rotation histogram when check_orientation != 0 (:544-584).  new_match[i2] = i, the keyframe feature whose map point
+ * CurrentFrame.mvpMapPoints[i2] becomes, -1 = unchanged.  Returns nmatches or a negative status. */
+int orbx_search_by_projection_keyframe(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x,
+                                       float min_y, float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc,
+                                       const float *point_angle, int np, const uint8_t *has_map_point, int orb_dist, int check_orientation,
+                                       int32_t *new_match);
+
 
 /* void Frame::UndistortKeyPoints() — reference src/Frame.cc:777-811 (decl include/Frame.h): mvKeysUn from mvKeys.
  * k4 = fx, fy, cx, cy of static_cast<Pinhole*>(mpCamera)->toK(); dist = mDistCoef (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]], up to

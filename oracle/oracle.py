@@ -94,6 +94,8 @@ def lib() -> ctypes.CDLL:
                                             c_void_p]
         L.oracle_search_by_projection_sim3.argtypes = [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_int, c_void_p,
                                                        c_float, c_void_p]
+        L.oracle_search_by_projection_keyframe.argtypes = [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int,
+                                                           c_void_p, c_int, c_int, c_void_p]
         L.oracle_distinctive_descriptors.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
         L.oracle_search_for_triangulation.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
         L.oracle_synth_frame.argtypes = [c_uint64, c_int, c_int, c_void_p, c_ssize_t]
@@ -555,4 +557,16 @@ def search_by_projection_sim3(keys, desc, bounds, points, point_desc, matched, r
     out = np.full(len(k), -1, np.int32)
     n = lib().oracle_search_by_projection_sim3(k.ctypes.data, d.ctypes.data, len(k), bounds[0], bounds[1], bounds[2], bounds[3], p.ctypes.data,
                                                pd.ctypes.data, len(p), mt.ctypes.data, float(ratio_hamming), out.ctypes.data)
+    return n, out
+
+
+def search_by_projection_keyframe(keys, desc, bounds, points, point_desc, point_angle, has_map_point, orb_dist=100, check_orientation=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (reference src/ORBmatcher3.cc:469-590) -> (nmatches, new_match[n])."""
+    k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points, WINDOW_POINT_DTYPE); pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+    pa = np.ascontiguousarray(point_angle, np.float32); hm = np.ascontiguousarray(has_map_point, np.uint8)
+    out = np.full(len(k), -1, np.int32)
+    n = lib().oracle_search_by_projection_keyframe(k.ctypes.data, d.ctypes.data, len(k), bounds[0], bounds[1], bounds[2], bounds[3], p.ctypes.data,
+                                                   pd.ctypes.data, pa.ctypes.data, len(p), hm.ctypes.data, int(orb_dist), int(bool(check_orientation)),
+                                                   out.ctypes.data)
     return n, out

@@ -2121,3 +2121,56 @@ extern "C" int oracle_search_by_projection_sim3(const oracle_keypoint *keys, con
     }
     return nmatches;
 }
+
+// ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) — reference src/ORBmatcher3.cc:469-590, from
+// `GetFeaturesInArea(uv(0), uv(1), radius, nPredictedLevel-1, nPredictedLevel+1)` (:513) on.
+extern "C" int oracle_search_by_projection_keyframe(const oracle_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x, float min_y,
+                                                    float max_y, const oracle_window_point *points, const uint8_t *point_desc,
+                                                    const float *point_angle, int np, const uint8_t *has_map_point, int orb_dist,
+                                                    int check_orientation, int32_t *new_match)
+{
+    const int HISTO_LENGTH = 30;
+    const FrameGrid G = assignFeaturesToGrid(keys, n, min_x, max_x, min_y, max_y);
+    std::vector<char> mvpMapPoints((size_t)n);
+    for (int i = 0; i < n; ++i) { mvpMapPoints[i] = has_map_point && has_map_point[i] ? 1 : 0; new_match[i] = -1; }
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < np; i++) {
+        const oracle_window_point &P = points[i];
+        if (!P.search) continue;
+        const int nPredictedLevel = P.level;
+        const std::vector<size_t> vIndices2 = getFeaturesInArea(G, keys, P.u, P.v, P.radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t *dMP = point_desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (std::vector<size_t>::const_iterator vit = vIndices2.begin(); vit != vIndices2.end(); vit++) {
+            const size_t i2 = *vit;
+            if (mvpMapPoints[i2]) continue;
+            const int dist = oracle_hamming256(dMP, desc + i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= orb_dist) {
+            mvpMapPoints[bestIdx2] = 1;
+            new_match[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = point_angle[i] - keys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        computeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { new_match[rotHist[i][j]] = -1; nmatches--; }
+    }
+    return nmatches;
+}

@@ -209,6 +209,11 @@ int oracle_search_by_projection_sim3(const oracle_keypoint *keys, const uint8_t 
                                      const oracle_window_point *points, const uint8_t *point_desc, int np, const uint8_t *matched,
                                      float ratio_hamming, int32_t *new_match);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher3.cc:469-590). */
+int oracle_search_by_projection_keyframe(const oracle_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x, float min_y,
+                                         float max_y, const oracle_window_point *points, const uint8_t *point_desc, const float *point_angle,
+                                         int np, const uint8_t *has_map_point, int orb_dist, int check_orientation, int32_t *new_match);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403) for a batch of map points (CSR rows of `desc`). */
 int oracle_distinctive_descriptors(const uint8_t *desc, const int32_t *start, int npoints, int32_t *best);
 

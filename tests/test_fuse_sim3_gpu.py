@@ -187,3 +187,20 @@ def test_projection_sim3_matches_oracle(pkg, orc, n, np_, dense, ratio):
     assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
     assert got[0] > 50 and not (got[1][matched == 1] >= 0).any()
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,np_,dense,dist,check", [(2000, 1500, False, 100, True), (1500, 2500, True, 64, True), (900, 900, False, 100, False)])
+def test_projection_keyframe_matches_oracle(pkg, orc, n, np_, dense, dist, check):
+    """Tracking::Relocalization's SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): levels nPredictedLevel - 1 .. + 1, taken
+    keypoints skipped in walk order, rotation histogram."""
+    k, d, ur, pts, pd = _scene(pkg, orc, n, np_, seed=11 * n + np_, dense=dense)
+    rng = np.random.default_rng(n + 1)
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    pa = ((rng.normal(10, 4, np_) + np.where(rng.random(np_) < 0.2, rng.uniform(0, 360, np_), 0)) % 360).astype(np.float32)
+    has = (rng.random(n) < 0.25).astype(np.uint8)
+    m = pkg.ORBmatcher(8192, 8192)
+    got = m.SearchByProjectionKeyFrame(k, d, BOUNDS, pts, pd, pa, has, dist, check, LEVELS)
+    ref = orc.search_by_projection_keyframe(k, d, BOUNDS, pts, pd, pa, has, dist, check)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[0] == int((got[1] >= 0).sum()) and got[0] > 30
+    m.close()

@@ -74,6 +74,7 @@ ABI_SYMBOLS = [
     "orbx_search_by_sim3",
     "orbx_distinctive_descriptors",
     "orbx_search_by_projection_sim3",
+    "orbx_search_by_projection_keyframe",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
     "orbx_vocabulary_create",
@@ -192,6 +193,8 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_distinctive_descriptors.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p]
     lib.orbx_search_by_projection_sim3.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
                                                    c_int, c_void_p, c_float, c_void_p]
+    lib.orbx_search_by_projection_keyframe.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
+                                                       c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
@@ -757,6 +760,22 @@ class ORBmatcher:
                                                      p.ctypes.data, pd.ctypes.data, len(p), mt.ctypes.data, float(ratioHamming), out.ctypes.data)
         if n < 0:
             _check(n, "orbx_search_by_projection_sim3")
+        return n, out
+
+    def SearchByProjectionKeyFrame(self, keys, desc, bounds, points, point_desc, point_angle, has_map_point, ORBdist: int = 100,
+                                   checkOrientation: bool = True, nlevels: int = 8):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (reference src/ORBmatcher3.cc:469-590), from
+        GetFeaturesInArea on -> (nmatches, new_match[n]): keyframe feature whose map point the frame's keypoint i2 now holds, -1 = unchanged."""
+        k = np.ascontiguousarray(keys, KEYPOINT_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        p = np.ascontiguousarray(points, WINDOW_POINT_DTYPE); pd = np.ascontiguousarray(point_desc, np.uint8).reshape(-1, 32)
+        pa = np.ascontiguousarray(point_angle, np.float32); hm = np.ascontiguousarray(has_map_point, np.uint8)
+        assert len(k) == len(d) == len(hm) and len(p) == len(pd) == len(pa)
+        out = np.full(len(k), -1, np.int32)
+        n = self._lib.orbx_search_by_projection_keyframe(self._h, k.ctypes.data, d.ctypes.data, len(k), bounds[0], bounds[1], bounds[2], bounds[3],
+                                                         int(nlevels), p.ctypes.data, pd.ctypes.data, pa.ctypes.data, len(p), hm.ctypes.data, int(ORBdist),
+                                                         int(bool(checkOrientation)), out.ctypes.data)
+        if n < 0:
+            _check(n, "orbx_search_by_projection_keyframe")
         return n, out
 
     def ComputeDistinctiveDescriptors(self, desc, start):

@@ -2144,12 +2144,11 @@ extern "C" int orbx_search_by_sim3(orbx_matcher *m, const orbx_keypoint *keys1, 
 // choice of point i depends on the points j < i only.  So the window search runs for ALL points at once against "the earliest accepted
 // taker of every keypoint" of the previous round and is repeated until no choice changes - after k rounds the first k points are final;
 // in practice two or three rounds (a conflict needs two points that want the same keypoint).
-extern "C" int orbx_search_by_projection_sim3(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x,
-                                              float min_y, float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc,
-                                              int np, const uint8_t *matched, float ratio_hamming, int32_t *new_match)
+static int projectionRoundsImpl(const char *fn, orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x,
+                                float min_y, float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc, int np,
+                                const uint8_t *matched, float bound, int level_hi, const float *point_angle, int check_orientation,
+                                int32_t *new_match)
 {
-    ORBX_API_ENTRY;
-    const char *fn = "orbx_search_by_projection_sim3";
     if (!m || n < 0 || np < 0 || (n > 0 && (!keys || !desc || !new_match)) || (np > 0 && (!points || !point_desc)) || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS)
         return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
     if (np > m->maxQ || n > m->maxT) return setError(ORBX_ERR_CAPACITY, "%s: %d points x %d keypoints exceed the matcher capacity %d x %d", fn, np, n, m->maxQ, m->maxT);
@@ -2178,11 +2177,10 @@ extern "C" int orbx_search_by_projection_sim3(orbx_matcher *m, const orbx_keypoi
     HIP_TRY(hipMemcpyAsync(dBlocked, blocked.data(), (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(orbxLaunchGridBuild(st, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
     std::vector<int32_t> idx((size_t)np), dist((size_t)np), choice((size_t)np, -2), owner((size_t)n, -1);
-    const float bound = 50 * ratio_hamming;  // TH_LOW * ratioHamming (:520), int * float in float
     for (int round = 0; round <= np; ++round) {
         HIP_TRY(hipMemcpyAsync(dOwner, owner.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_TRY(orbxLaunchKeyframeWindowSearch(st, m->d_kr.p, m->d_t.p, nullptr, nullptr, cs, it, min_x, max_x, min_y, max_y, dPts, m->d_q.p, np, 0, dIdx,
-                                               dDist, dBlocked, dOwner));
+                                               dDist, dBlocked, dOwner, level_hi));
         HIP_TRY(hipMemcpyAsync(idx.data(), dIdx, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(dist.data(), dDist, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -2198,7 +2196,53 @@ extern "C" int orbx_search_by_projection_sim3(orbx_matcher *m, const orbx_keypoi
     int nmatches = 0;
     for (int i = 0; i < np; ++i)
         if (choice[i] >= 0 && owner[choice[i]] == i) { new_match[choice[i]] = i; ++nmatches; }
+    if (check_orientation && point_angle) {  // rotation consistency (src/ORBmatcher3.cc:544-584)
+        const int HISTO_LENGTH = 30;
+        const float factor = 1.0f / HISTO_LENGTH;
+        std::vector<int> rotHist[HISTO_LENGTH];
+        for (int i = 0; i < np; ++i) {  // in the order of the reference's walk over the map points
+            if (choice[i] < 0 || owner[choice[i]] != i) continue;
+            float rot = point_angle[i] - keys[choice[i]].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back(choice[i]);
+        }
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima (src/ORBmatcher3.cc:592-633)
+            const int sz = (int)rotHist[i].size();
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { new_match[rotHist[i][j]] = -1; nmatches--; }
+    }
     return nmatches;
+}
+
+extern "C" int orbx_search_by_projection_sim3(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x,
+                                              float min_y, float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc,
+                                              int np, const uint8_t *matched, float ratio_hamming, int32_t *new_match)
+{
+    ORBX_API_ENTRY;
+    // bestDist <= TH_LOW * ratioHamming (:520), int * float in float
+    return projectionRoundsImpl("orbx_search_by_projection_sim3", m, keys, desc, n, min_x, max_x, min_y, max_y, nlevels, points, point_desc, np, matched,
+                                50 * ratio_hamming, 0, nullptr, 0, new_match);
+}
+
+extern "C" int orbx_search_by_projection_keyframe(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, int n, float min_x, float max_x,
+                                                  float min_y, float max_y, int nlevels, const orbx_window_point *points, const uint8_t *point_desc,
+                                                  const float *point_angle, int np, const uint8_t *has_map_point, int orb_dist, int check_orientation,
+                                                  int32_t *new_match)
+{
+    ORBX_API_ENTRY;
+    if (check_orientation && np > 0 && !point_angle) return setError(ORBX_ERR_INVALID_ARG, "orbx_search_by_projection_keyframe: check_orientation needs point_angle");
+    return projectionRoundsImpl("orbx_search_by_projection_keyframe", m, keys, desc, n, min_x, max_x, min_y, max_y, nlevels, points, point_desc, np,
+                                has_map_point, (float)orb_dist, 1, point_angle, check_orientation, new_match);
 }
 
 // void MapPoint::ComputeDistinctiveDescriptors() — reference src/MapPoint.cc:329-403, batched over map points.

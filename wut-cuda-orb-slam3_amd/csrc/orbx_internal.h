@@ -178,7 +178,7 @@ hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h
 hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
                                           const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, const void *pts,
                                           const uint8_t *ptDesc, int np, int chi2, int *bestIdx, int *bestDist, const signed char *blocked = nullptr,
-                                          const int *owner = nullptr);
+                                          const int *owner = nullptr, int levelHi = 0);
 hipError_t orbxLaunchDistinctive(hipStream_t st, const uint8_t *desc, const int *start, int npoints, int *best);
 hipError_t orbxLaunchBowTransformBatch(hipStream_t st, const int *childStart, const int *childNode, const void *childDesc, const int *wordOfNode,
                                        const double *weightOfNode, int L, int scoring, int weighting, const void *feat, const int *nPerFrame,

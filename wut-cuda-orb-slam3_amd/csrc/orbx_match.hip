@@ -2552,6 +2552,7 @@ struct KfwArgs {
     // SearchByProjection(KeyFrame, Sim3, ..): keypoints that hold a match on entry, and the earliest accepted point that wants a keypoint
     // in the current round of the fixed-point iteration (a point skips the keypoints an EARLIER point took) - NULL for Fuse / SearchBySim3
     const signed char *blocked; const int *owner;
+    int levelHi;  // keypoint levels nPredictedLevel - 1 .. nPredictedLevel + levelHi (0; 1 for SearchByProjection(Frame, KeyFrame, ..))
 };
 
 __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
@@ -2594,7 +2595,7 @@ __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
                     const MtKp kp = a.keys[idx];
                     bool keep = fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r;   // GetFeaturesInArea (:738-742)
                     const int kpLevel = kp.octave;
-                    if (kpLevel < P.level - 1 || kpLevel > P.level) keep = false;
+                    if (kpLevel < P.level - 1 || kpLevel > P.level + a.levelHi) keep = false;
                     if (keep && a.blocked && a.blocked[idx]) keep = false;
                     if (keep && a.owner) { const int o = a.owner[idx]; if (o >= 0 && o < i) keep = false; }
                     if (keep && a.chi2) {
@@ -2646,11 +2647,11 @@ __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
 hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
                                           const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, const void *pts,
                                           const uint8_t *ptDesc, int np, int chi2, int *bestIdx, int *bestDist, const signed char *blocked,
-                                          const int *owner)
+                                          const int *owner, int levelHi)
 {
     if (np <= 0) return hipSuccess;
     KfwArgs a;
-    a.blocked = blocked; a.owner = owner;
+    a.blocked = blocked; a.owner = owner; a.levelHi = levelHi;
     a.keys = (const MtKp *)keys; a.desc = desc; a.uRight = uRight; a.invSigma2 = invSigma2; a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY; a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);
     a.pts = (const KfwPoint *)pts; a.ptDesc = ptDesc; a.np = np; a.chi2 = chi2; a.bestIdx = bestIdx; a.bestDist = bestDist;
