@@ -189,16 +189,17 @@ def test_compute_stereo_matches_frames_batch(pkg, orc):
     m.close(); exl.close(); exr.close()
 
 
-def test_knn2_vector_alu_scan_in_subprocess(pkg):
-    """The kNN-2 scan runs on the matrix cores (k_knn2_scan_mfma: +-1 bytes, q . t = 256 - 2 Hamming); ORBX_KNN_MFMA=0 (read once per
-    process) takes the vector-ALU scan it replaced.  Both must give the oracle's results bit for bit: run this file's kNN tests once
-    more under the switch."""
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_knn2_other_scans_in_subprocess(pkg, variant):
+    """The kNN-2 scan runs on the matrix cores (k_knn2_scan_mfma: +-1 bytes, q . t = 256 - 2 Hamming, 16 x 16 x 64 products); ORBX_KNN_MFMA
+    (read once per process) = 0 takes the vector-ALU scan it replaced, = 2 the 32 x 32 x 32 form (k_knn2_scan_mfma32, measured slower).
+    All must give the oracle's results bit for bit: run this file's kNN tests once more under the switch."""
     import os
     import subprocess
     import sys
     if os.environ.get("ORBX_KNN_MFMA"):
         pytest.skip("already the forced run")
-    env = dict(os.environ, ORBX_KNN_MFMA="0")
+    env = dict(os.environ, ORBX_KNN_MFMA=variant)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "knn2 and not subprocess"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

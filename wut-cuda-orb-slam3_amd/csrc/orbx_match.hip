@@ -321,6 +321,197 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
     }
 }
 
+// ---- the matrix-core scan with 32 x 32 tiles -----------------------------------------------------------------------------------------
+// k_knn2_scan_mfma spends ~70 vector instructions per 16 products (16 train rows x 64 queries): a lane holds FOUR train rows of a query
+// per tile, so every 16 x 16 tile costs it a minimum of four, a compare and a ballot - the vector ALU, not the matrix core, set its pace
+// (0.40 of the matrix peak).  v_mfma_i32_32x32x32_i8 leaves SIXTEEN train rows of one query in a lane: the same test is one minimum tree
+// over 16 values per 32 x 32 tile, i.e. a quarter of the vector work per descriptor pair (8 products of 32 x 32 x 32 per tile of 32 rows
+// x 32 queries).  MEASURED SLOWER than the 16 x 16 form (2.06 against 1.80 ms per 512 pairs of 4000 x 4000; round 2 saw the same): 64
+// registers of query operands + 64 of accumulators leave two waves per SIMD, and the block barrier then idles the SIMD.  Kept behind
+// ORBX_KNN_MFMA=2 as the measured alternative; the default stays k_knn2_scan_mfma.  Same expanded LDS tile (rows of +-1 bytes in bit order, 272-byte pitch: the 16-byte
+// operand reads of rows r and r + 16 fall into different lane groups of ds_read_b128), same keys, same splits and merge.
+typedef int kn_v16i __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_knn2_scan_mfma32(Knn2Args a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tileL[2][KNM_BLK * KNM_ROWB];
+    const int pair = blockIdx.z, split = blockIdx.y;
+    const int qb = a.qBeginDev ? a.qBeginDev[pair] : 0, tb = a.tBeginDev ? a.tBeginDev[pair] : 0;
+    const int nq = min(a.nqDev ? a.nqDev[pair] - qb : a.nq, a.nq);
+    const int nt = min(a.ntDev ? a.ntDev[pair] - tb : a.nt, a.nt);
+    if ((int)(blockIdx.x * 256) >= nq) return;  // workgroup-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 256 + wv * 64;  // this wave's queries: tile qt = queries q0 + 32 qt + n
+    const uint8_t *qBase = a.q + (size_t)pair * a.qPairStride + (size_t)qb * 32;
+    const uint8_t *tBase = a.t + (size_t)pair * a.tPairStride + (size_t)tb * 32;
+    // B operands: k-step s of tile qt = bits 32 s + 16 h .. + 15 of query q0 + 32 qt + n = the 16-bit word 2 s + h of its descriptor
+    kn_v4i B[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = q0 + 32 * qt + n;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (qi < nq) {
+#pragma unroll
+            for (int sK = 0; sK < 8; ++sK) w[sK] = ((const uint16_t *)(qBase + (size_t)qi * 32))[2 * sK + h];
+        }
+#pragma unroll
+        for (int sK = 0; sK < 8; ++sK) B[qt][sK] = knm_expand16(w[sK], KNM_TAB_Q);
+    }
+    const int j0 = split * a.splitRows, j1 = min(j0 + a.splitRows, nt);
+    const int er = tid >> 4, ew = tid & 15;  // expansion duty of this thread: row tid >> 4 of a 16-row group, 16-bit word tid & 15
+    auto loadBits = [&](int jb, uint32_t (&w)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(jb + 16 * u + er, max(j1 - 1, 0));
+            w[u] = ((const uint16_t *)(tBase + (size_t)j * 32))[ew];
+        }
+    };
+    __shared__ uint2 lutT[256];
+    lutT[tid] = make_uint2(knm_expand4((uint32_t)tid & 15u, KNM_TAB_T), knm_expand4((uint32_t)tid >> 4, KNM_TAB_T));
+    auto expandTo = [&](int buf, const uint32_t (&w)[4]) {  // rows 16 u + er of the block, word ew -> bytes 16 ew .. 16 ew + 15 (bit order)
+        uint2 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { lo[u] = lutT[w[u] & 255u]; hi[u] = lutT[w[u] >> 8]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kn_v4i v;
+            v[0] = (int)lo[u].x; v[1] = (int)lo[u].y; v[2] = (int)hi[u].x; v[3] = (int)hi[u].y;
+            *(kn_v4i *)(tileL[buf] + (16 * u + er) * KNM_ROWB + ew * 16) = v;
+        }
+    };
+    __syncthreads();
+    uint32_t k0[2], k1[2];
+    int thr[2];  // k1 >> 22
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) { k0[qt] = KN_NONE; k1[qt] = KN_NONE; thr[qt] = (int)(KN_NONE >> 22); }
+    if (j0 < j1) {
+        uint32_t wNext[4];
+        loadBits(j0, wNext);
+        expandTo(0, wNext);
+        loadBits(j0 + KNM_BLK, wNext);
+        __syncthreads();
+        int buf = 0;
+        auto tile = [&](int jt, int u, auto tailTag) {  // train rows jt .. jt + 31 = rows 32 u .. of the buffer
+            constexpr bool TAIL = decltype(tailTag)::value;
+            kn_v16i acc[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[qt][i] = 0;
+            const uint8_t *rowp = tileL[buf] + (32 * u + n) * KNM_ROWB + h * 16;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                kn_v4i A[4];  // four k-steps of train row n requested before the first product
+#pragma unroll
+                for (int sK = 0; sK < 4; ++sK) A[sK] = *(const kn_v4i *)(rowp + (4 * half + sK) * 32);
+#pragma unroll
+                for (int sK = 0; sK < 4; ++sK) asm volatile("" : "+v"(A[sK]));
+#pragma unroll
+                for (int sK = 0; sK < 4; ++sK) {
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[sK], B[qt][4 * half + sK], acc[qt], 0, 0, 0);
+                }
+            }
+            // lane: query n of tile qt, train rows jt + (i & 3) + 8 (i >> 2) + 4 h; acc = 2 * Hamming - 256
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                int m4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m4[c] = min(min(acc[qt][4 * c], acc[qt][4 * c + 1]), min(acc[qt][4 * c + 2], acc[qt][4 * c + 3]));
+                const int mAcc = min(min(m4[0], m4[1]), min(m4[2], m4[3]));
+                if (__ballot(mAcc + 256 < thr[qt]) != 0ull) {  // (rows come in increasing order: an equal distance cannot enter the pair)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = jt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        uint32_t key = ((uint32_t)acc[qt][i] << 22) + (uint32_t)((1 << 30) + row);  // (256 + acc) << 22 | row = Hamming << 23 | row
+                        if (TAIL && row >= j1) key = KN_NONE;
+                        kn_insert(k0[qt], k1[qt], key);
+                    }
+                    thr[qt] = (int)(k1[qt] >> 22);
+                }
+            }
+        };
+        // a whole block of 64 rows: both 32-row tiles together, so that four independent accumulator chains (2 row tiles x 2 query tiles)
+        // are in flight per wave - with two, the dependent products of a chain waited for each other
+        auto test16 = [&](const kn_v16i &acc, int qt, int jt) {
+            int m4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m4[c] = min(min(acc[4 * c], acc[4 * c + 1]), min(acc[4 * c + 2], acc[4 * c + 3]));
+            const int mAcc = min(min(m4[0], m4[1]), min(m4[2], m4[3]));
+            if (__ballot(mAcc + 256 < thr[qt]) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = jt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    kn_insert(k0[qt], k1[qt], ((uint32_t)acc[i] << 22) + (uint32_t)((1 << 30) + row));
+                }
+                thr[qt] = (int)(k1[qt] >> 22);
+            }
+        };
+        auto block = [&](int jb) {
+            kn_v16i acc[2][2];  // [row tile][query tile]
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[u][qt][i] = 0;
+            const uint8_t *rowp = tileL[buf] + n * KNM_ROWB + h * 16;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {  // two k-steps of both row tiles per round of operand reads
+                kn_v4i A[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int sK = 0; sK < 2; ++sK) A[u][sK] = *(const kn_v4i *)(rowp + 32 * u * KNM_ROWB + (2 * q4 + sK) * 32);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int sK = 0; sK < 2; ++sK) asm volatile("" : "+v"(A[u][sK]));
+#pragma unroll
+                for (int sK = 0; sK < 2; ++sK)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt)
+                            acc[u][qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[u][sK], B[qt][2 * q4 + sK], acc[u][qt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) test16(acc[u][qt], qt, jb + 32 * u);
+        };
+        for (int jb = j0; jb < j1; jb += KNM_BLK) {
+            if (jb + KNM_BLK < j1) expandTo(buf ^ 1, wNext);  // the next block into the other buffer
+            loadBits(jb + 2 * KNM_BLK, wNext);
+            if (jb + KNM_BLK <= j1) block(jb);
+            else {  // the last rows of the split: keys of rows beyond it are masked
+                for (int u = 0; u < 2 && jb + 32 * u < j1; ++u) {
+                    if (jb + 32 * u + 32 <= j1) tile(jb + 32 * u, u, std::false_type{});
+                    else tile(jb + 32 * u, u, std::true_type{});
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // the two lane halves of a query hold the pairs of disjoint train rows: merge (same rule as the split merge)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const uint32_t c0 = (uint32_t)__shfl_xor((int)k0[qt], 32), c1 = (uint32_t)__shfl_xor((int)k1[qt], 32);
+        kn_insert(k0[qt], k1[qt], c0);
+        kn_insert(k0[qt], k1[qt], c1);
+        const int qi = q0 + 32 * qt + n;
+        if (h == 0 && qi < nq) {
+            if (a.nSplit == 1) kn_store(a.idx, a.dist, ((size_t)pair * a.nq + qi) * 2, k0[qt], k1[qt]);
+            else {
+                uint32_t *p = a.part + (((size_t)pair * a.nSplit + split) * a.nq + qi) * 2;
+                p[0] = k0[qt]; p[1] = k1[qt];
+            }
+        }
+    }
+}
+
 // Number of train splits for `npairs` pairs of nq x nt rows: enough waves to fill 1024 SIMDs a few times over, splits of at
 // least 64 rows.  `forceSplit` > 0 overrides it (tests of the merge).
 int orbxKnn2Splits(int npairs, int nq, int nt, int forceSplit)
@@ -347,8 +538,12 @@ hipError_t orbxLaunchKnn2Batch(hipStream_t st, int npairs, const uint8_t *q, lon
     a.splitRows = nt > 0 ? (nt + a.nSplit - 1) / a.nSplit : 1;
     a.part = part; a.idx = idx; a.dist = dist;
     // ORBX_KNN_MFMA=0: the scan on the vector ALU (A/B timing, tests); default: the matrix-core scan
-    static const bool mfma = [] { const char *e = getenv("ORBX_KNN_MFMA"); return e ? atoi(e) != 0 : true; }();
-    if (mfma) hipLaunchKernelGGL(k_knn2_scan_mfma, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
+    // ORBX_KNN_MFMA: 0 the scan on the vector ALU, 1 (default) matrix cores with 16 x 16 x 64 products, 2 with 32 x 32 x 32 products - a
+    // quarter of the vector instructions per descriptor pair and a 23 % lower matrix floor (34 cycles per 32768 products against 22 per
+    // 16384, tools/experiments/mfma_i8_rate.hip), but 202 VGPRs = two waves per SIMD: 2.06 against 1.80 ms per 512 pairs of 4000 x 4000
+    static const int mfma = [] { const char *e = getenv("ORBX_KNN_MFMA"); return e ? atoi(e) : 1; }();
+    if (mfma == 2) hipLaunchKernelGGL(k_knn2_scan_mfma32, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
+    else if (mfma) hipLaunchKernelGGL(k_knn2_scan_mfma, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_knn2_scan, dim3((nq + 63) / 64, a.nSplit, npairs), dim3(64), 0, st, a);
     if (a.nSplit > 1) hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256, npairs), dim3(256), 0, st, a);
     return hipGetLastError();
