@@ -351,6 +351,26 @@ int orbx_search_by_projection_points_frames(orbx_matcher *m, orbx_extractor *ex,
                                             const uint8_t *d_map_point_desc, const int32_t *d_np, int max_np, float th, float nnratio,
                                             void *d_kps_un, void *d_assign, void *d_nmatches);
 
+/* The CurrentFrame.Nleft != -1 branches of both functions (two KB8 fisheye cameras: reference src/ORBmatcher3.cc:300-436 and
+ * src/ORBmatcher1.cc:45-215, see orbx_search_by_projection_fisheye / orbx_search_by_projection_points_fisheye) for a BATCH of frames,
+ * device-resident: frame p = frame p of `left`'s last batch (mvKeys) + frame p of `right`'s (mvKeysRight); no undistortion (KB8 frames
+ * search on mvKeys).  Combined keypoint indices - rows of d_cur_state and d_assign, [nframes][capL + capR] with cap = orbx_max_keypoints -
+ * are i for left keypoint i and capL + j for right keypoint j (rows beyond a frame's counts are not written).  d_proj_left / d_proj_right
+ * [nframes][max_np] and d_proj_desc [nframes][max_np][32] as proj_left / proj_right / proj_desc of the single-frame calls, d_np [nframes].
+ * The map-point variant takes mvLeftToRightMatch / mvRightToLeftMatch as d_left_to_right [nframes][capL] / d_right_to_left
+ * [nframes][capR] (what orbx_compute_stereo_fisheye_matches_frames writes).  d_nmatches [nframes] (-1: a window held more than 512
+ * candidates).  Asynchronous on the matcher's stream. */
+int orbx_search_by_projection_fisheye_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int nframes, float min_x, float max_x,
+                                             float min_y, float max_y, const int8_t *d_cur_state, const orbx_projection *d_proj_left,
+                                             const orbx_projection *d_proj_right, const uint8_t *d_proj_desc, const int32_t *d_np, int max_np,
+                                             float th, int forward, int backward, int check_orientation, void *d_assign, void *d_nmatches);
+int orbx_search_by_projection_points_fisheye_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int nframes, float min_x,
+                                                    float max_x, float min_y, float max_y, const int8_t *d_cur_state,
+                                                    const orbx_projection *d_map_points_left, const orbx_projection *d_map_points_right,
+                                                    const uint8_t *d_map_point_desc, const int32_t *d_np, int max_np,
+                                                    const int32_t *d_left_to_right, const int32_t *d_right_to_left, float th, float nnratio,
+                                                    void *d_assign, void *d_nmatches);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference
  * src/ORBmatcher1.cc:225-427 (decl include/ORBmatcher.h:62), F.Nleft == -1 / pKF->mpCamera2 == NULL; Tracking::TrackReferenceKeyFrame
  * and Relocalization.  Both FeatureVectors (pKF->mFeatVec, F.mFeatVec) as orbx_vocabulary_transform returns them: ascending node

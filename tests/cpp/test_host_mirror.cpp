@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/orbx_synth.h"
@@ -310,6 +311,71 @@ static int runComputeBoW()
     return 0;
 }
 
+// The operator() adaptor (orbx::extractInto) instantiated with stand-ins for the OpenCV types it touches: what a build with
+// -DORBX_WITH_OPENCV instantiates with cv::InputArray / cv::Mat / cv::OutputArray / cv::KeyPoint.  The stand-ins carry exactly the members
+// the adaptor uses, with cv::Mat's semantics (a header that shares its buffer, step in bytes, create() re-allocates).
+namespace cvshape {
+struct Mat {
+    uint8_t *data = nullptr;
+    int cols = 0, rows = 0, flags = 0;
+    size_t step = 0;
+    std::shared_ptr<std::vector<uint8_t>> buf;
+    int type() const { return flags; }
+};
+struct InputArray {
+    const Mat *m;
+    bool empty() const { return !m || !m->data || m->rows == 0 || m->cols == 0; }
+    Mat getMat() const { return *m; }
+};
+struct OutputArray {
+    Mat *m;
+    void release() { *m = Mat(); }
+    void create(int rows, int cols, int type)
+    {
+        m->buf = std::make_shared<std::vector<uint8_t>>((size_t)rows * cols);
+        m->data = m->buf->data(); m->rows = rows; m->cols = cols; m->step = (size_t)cols; m->flags = type;
+    }
+    Mat getMat() const { return *m; }
+};
+struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };  // cv::KeyPoint: Point2f pt; float size, angle, response; int octave, class_id
+}  // namespace cvshape
+
+static int runCvShapedAdaptor()
+{
+    const int w = 640, h = 480, pitch = 704, T8UC1 = 0 /* CV_8UC1 */, T8U = 0 /* CV_8U */;
+    std::vector<uint8_t> img((size_t)pitch * h, 0x5A);  // a view with row padding, as a cv::Mat ROI has
+    orbx_synth_frame_impl(77, w, h, img.data(), pitch);
+    cvshape::Mat image;
+    image.data = img.data(); image.cols = w; image.rows = h; image.step = pitch; image.flags = T8UC1;
+    orbx::ORBextractor extractor(1000, 1.2f, 8, 20, 7, 0, w, h);
+    std::vector<cvshape::KeyPoint> keypoints(3);
+    cvshape::Mat descriptors;
+    cvshape::OutputArray out{&descriptors};
+    std::vector<int> lap = {0, 1000};
+    const int mono = orbx::extractInto(extractor, cvshape::InputArray{&image}, keypoints, out, lap, T8UC1, T8U);
+    oracle_handle *ref = oracle_create(1000, 1.2f, 8, 20, 7, 0, 0);
+    std::vector<oracle_keypoint> rk(oracle_max_keypoints(ref) + 64);
+    std::vector<uint8_t> rd(rk.size() * 32);
+    int rn = 0;
+    const int rmono = oracle_extract(ref, img.data(), w, h, pitch, lap[0], lap[1], rk.data(), rd.data(), &rn);
+    oracle_destroy(ref);
+    ASSERT_EQ(mono, rmono);
+    ASSERT_EQ((int)keypoints.size(), rn);
+    ASSERT_EQ(descriptors.rows, rn);
+    ASSERT_EQ(descriptors.cols, 32);
+    ASSERT_TRUE(memcmp(keypoints.data(), rk.data(), (size_t)rn * 28) == 0);
+    ASSERT_TRUE(memcmp(descriptors.data, rd.data(), (size_t)rn * 32) == 0);
+    // empty image -> -1, keypoints / descriptors untouched; wrong type -> exception (the reference asserts)
+    cvshape::Mat none;
+    ASSERT_EQ(orbx::extractInto(extractor, cvshape::InputArray{&none}, keypoints, out, lap, T8UC1, T8U), -1);
+    ASSERT_EQ((int)keypoints.size(), rn);
+    image.flags = 16;
+    bool thrown = false;
+    try { orbx::extractInto(extractor, cvshape::InputArray{&image}, keypoints, out, lap, T8UC1, T8U); } catch (const std::runtime_error &) { thrown = true; }
+    ASSERT_TRUE(thrown);
+    return 0;
+}
+
 // frames dealt over several handles from one process; one handle per GPU where the box has several, two on GPU 0 otherwise
 static int runShardedBatch()
 {
@@ -364,6 +430,7 @@ int main()
     if (runSearchByProjection()) return 1;                           // SURVEY 8(f) rank 2, tracking searches
     if (runComputeBoW()) return 1;
     if (runShardedBatch()) return 1;                                 // SURVEY 8(e), one process
+    if (runCvShapedAdaptor()) return 1;                              // the operator() adaptor of the OpenCV build, on stand-in types
     printf("OK host mirror\n");
     return 0;
 }

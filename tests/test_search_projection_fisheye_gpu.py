@@ -161,3 +161,53 @@ def test_fisheye_known_answers(pkg):
                                                checkOrientation=kw.pop("check_orientation"), **kw)
         assert n == n_exp and np.array_equal(a, a_exp), (name, n, a)
     m.close()
+
+
+def test_fisheye_frames_batch_equals_single_calls(pkg):
+    """orbx_search_by_projection_fisheye_frames / _points_fisheye_frames: a batch of rig frames, device-resident on two extractors' outputs,
+    against the single-frame entry points (which the tests above hold against the oracle) - combined indices map i -> i, capL + j -> nl + j."""
+    P, w, h = 5, 640, 480
+    rng = np.random.default_rng(77)
+    left = np.stack([pkg.synth_frame(900 + p, w, h) for p in range(P)])
+    right = np.stack([np.roll(left[p], -(8 + p), axis=1) for p in range(P)])
+    exl = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=P); exr = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=P)
+    nl, _, kl, dl = exl.extract_batch(left, (0, 0)); nr, _, kr, dr = exr.extract_batch(right, (0, 0))
+    capL, capR = exl.capacity, exr.capacity
+    sf = exl.GetScaleFactors().copy()
+    # "last frame" of every frame: its own left keypoints moved by a small motion
+    pls, prs, descs, states, l2rs, r2ls = [], [], [], [], [], []
+    for p in range(P):
+        k1, d1 = kl[p][: nl[p]], dl[p][: nl[p]]
+        n_pts = len(k1) - 37 * p  # ragged point counts
+        pl, pr = _records(pkg, k1[:n_pts], rng, 2, -1, 8 + p)
+        if p == 3:
+            pl, pr = pl[:0], pr[:0]  # a frame without points
+        pls.append(pl); prs.append(pr); descs.append(d1[: len(pl)])
+        st = np.full(capL + capR, -1, np.int8)
+        st[: nl[p]] = rng.choice(np.int8([-1, -1, 0, 1]), nl[p]); st[capL: capL + nr[p]] = rng.choice(np.int8([-1, -1, 0, 1]), nr[p])
+        states.append(st)
+        a, b = _stereo_partners(rng, nl[p], nr[p])
+        l2r = np.full(capL, -1, np.int32); r2l = np.full(capR, -1, np.int32); l2r[: nl[p]] = a; r2l[: nr[p]] = b
+        l2rs.append(l2r); r2ls.append(r2l)
+    m = pkg.ORBmatcher(8192, 8192)
+    for mode in ("frames", "points"):
+        if mode == "frames":
+            nm, assign = m.SearchByProjectionFisheyeFrames(exl, exr, P, BOUNDS, np.stack(states), pls, prs, descs, 15.0)
+        else:
+            pls2 = [x.copy() for x in pls]; prs2 = [x.copy() for x in prs]
+            for x, y in zip(pls2, prs2):
+                x["angle"] = rng.choice(np.float32([0.9, 0.999]), len(x)); y["angle"] = x["angle"]
+            nm, assign = m.SearchByProjectionFisheyeFrames(exl, exr, P, BOUNDS, np.stack(states), pls2, prs2, descs, 3.0, left_to_right=np.stack(l2rs),
+                                                           right_to_left=np.stack(r2ls), map_points_nnratio=0.8)
+        for p in range(P):
+            kc = np.concatenate([kl[p][: nl[p]], kr[p][: nr[p]]]); dc = np.concatenate([dl[p][: nl[p]], dr[p][: nr[p]]])
+            st = np.concatenate([states[p][: nl[p]], states[p][capL: capL + nr[p]]])
+            if mode == "frames":
+                rn, ra = m.SearchByProjectionFisheye(kc, dc, int(nl[p]), st, BOUNDS, sf, pls[p], prs[p], descs[p], 15.0)
+            else:
+                rn, ra = m.SearchByProjectionPointsFisheye(kc, dc, int(nl[p]), st, BOUNDS, sf, pls2[p], prs2[p], descs[p], l2rs[p][: nl[p]],
+                                                           r2ls[p][: nr[p]], 3.0, 0.8)
+            got = np.concatenate([assign[p][: nl[p]], assign[p][capL: capL + nr[p]]])
+            assert nm[p] == rn and np.array_equal(got, ra), (mode, p, nm[p], rn)
+        assert nm[3] == 0 and nm.sum() > 100
+    m.close(); exl.close(); exr.close()

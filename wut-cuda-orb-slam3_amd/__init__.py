@@ -75,6 +75,8 @@ ABI_SYMBOLS = [
     "orbx_distinctive_descriptors",
     "orbx_search_by_projection_sim3",
     "orbx_search_by_projection_keyframe",
+    "orbx_search_by_projection_fisheye_frames",
+    "orbx_search_by_projection_points_fisheye_frames",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
     "orbx_vocabulary_create",
@@ -195,6 +197,11 @@ def load_library() -> ctypes.CDLL:
                                                    c_int, c_void_p, c_float, c_void_p]
     lib.orbx_search_by_projection_keyframe.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
                                                        c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]
+    lib.orbx_search_by_projection_fisheye_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                                             c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_search_by_projection_points_fisheye_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p,
+                                                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float,
+                                                                    c_void_p, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
@@ -653,6 +660,46 @@ class ORBmatcher:
         hk = np.empty((nframes, cap), KEYPOINT_DTYPE)
         _check(self._lib.orbx_matcher_download(self._h, c_void_p(kun.data_ptr()), hk.ctypes.data, hk.nbytes), "orbx_matcher_download")
         return self._download(nm), self._download(assign), hk
+
+    def SearchByProjectionFisheyeFrames(self, left: "ORBextractor", right: "ORBextractor", nframes: int, bounds, cur_state, proj_left, proj_right,
+                                        proj_desc, th: float, forward: bool = False, backward: bool = False, checkOrientation: bool = True,
+                                        left_to_right=None, right_to_left=None, map_points_nnratio=None):
+        """The Nleft != -1 (KB8 fisheye rig) branches of ORBmatcher::SearchByProjection for a batch of frames, device-resident: frame p =
+        frame p of both extractors' last batches.  cur_state [P, capL + capR] (combined indices: left i, right capL + j); proj_left[p] /
+        proj_right[p] / proj_desc[p]: the records of frame p.  map_points_nnratio: the map-point variant (then left_to_right [P, capL] /
+        right_to_left [P, capR] = mvLeftToRightMatch / mvRightToLeftMatch).  Returns (nmatches[P], assign[P, capL + capR])."""
+        import torch
+        dev = left.device
+        capC = left.capacity + right.capacity
+        max_np = max(1, max(len(p) for p in proj_left))
+        hl = np.zeros((nframes, max_np), PROJECTION_DTYPE); hr = np.zeros((nframes, max_np), PROJECTION_DTYPE)
+        hd = np.zeros((nframes, max_np, 32), np.uint8); hn = np.zeros(nframes, np.int32)
+        for p in range(nframes):
+            hn[p] = len(proj_left[p]); hl[p, : hn[p]] = proj_left[p]; hr[p, : hn[p]] = proj_right[p]
+            hd[p, : hn[p]] = np.asarray(proj_desc[p], np.uint8).reshape(-1, 32)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(f"cuda:{dev}")
+        d_l, d_r, d_d, d_n = up(hl.view(np.uint8)), up(hr.view(np.uint8)), up(hd), up(hn)
+        d_cs = up(np.ascontiguousarray(cur_state, np.int8).reshape(nframes, capC))
+        assign = self._dev_out((nframes, capC), torch.int32, dev, -1); nm = self._dev_out((nframes,), torch.int32, dev, 0)
+        keep = [d_l, d_r, d_d, d_n, d_cs, assign, nm]
+        if map_points_nnratio is None:
+            self._launch_fence(*keep)
+            _check(self._lib.orbx_search_by_projection_fisheye_frames(self._h, left._h, right._h, nframes, bounds[0], bounds[1], bounds[2], bounds[3],
+                                                                      c_void_p(d_cs.data_ptr()), c_void_p(d_l.data_ptr()), c_void_p(d_r.data_ptr()),
+                                                                      c_void_p(d_d.data_ptr()), c_void_p(d_n.data_ptr()), max_np, th, int(forward),
+                                                                      int(backward), int(checkOrientation), c_void_p(assign.data_ptr()),
+                                                                      c_void_p(nm.data_ptr())), "orbx_search_by_projection_fisheye_frames")
+        else:
+            d_lr = up(np.ascontiguousarray(left_to_right, np.int32).reshape(nframes, left.capacity))
+            d_rl = up(np.ascontiguousarray(right_to_left, np.int32).reshape(nframes, right.capacity))
+            self._launch_fence(*keep, d_lr, d_rl)
+            _check(self._lib.orbx_search_by_projection_points_fisheye_frames(self._h, left._h, right._h, nframes, bounds[0], bounds[1], bounds[2], bounds[3],
+                                                                             c_void_p(d_cs.data_ptr()), c_void_p(d_l.data_ptr()), c_void_p(d_r.data_ptr()),
+                                                                             c_void_p(d_d.data_ptr()), c_void_p(d_n.data_ptr()), max_np,
+                                                                             c_void_p(d_lr.data_ptr()), c_void_p(d_rl.data_ptr()), th,
+                                                                             float(map_points_nnratio), c_void_p(assign.data_ptr()),
+                                                                             c_void_p(nm.data_ptr())), "orbx_search_by_projection_points_fisheye_frames")
+        return self._download(nm), self._download(assign)
 
     def SearchForInitializationFrames(self, ex1: "ORBextractor", ex2: "ORBextractor", npairs: int, k4, dist, bounds, windowSize: int = 100,
                                       nnratio: float = 0.9, checkOrientation: bool = True, frame2_offset: int = 0, prev_matched=None,

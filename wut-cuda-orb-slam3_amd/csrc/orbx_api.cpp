@@ -2757,6 +2757,99 @@ static int searchByProjectionFramesImpl(const char *fn, int mode, float nnratio,
     return orderExtractorsAfter(m, ex, ex);
 }
 
+// The CurrentFrame.Nleft != -1 branches (two KB8 fisheye cameras) of both SearchByProjection functions for a BATCH of frames, device-resident:
+// frame p = (frame p of `left`'s last batch, frame p of `right`'s).  Keypoints and descriptors of a frame are gathered into one buffer
+// [capL left slots | capR right slots] (the kernels address the right keypoints at a fixed offset: "NLeft" = capL, unused slots never
+// enter a grid); combined indices - in d_cur_state, d_assign - are i for left keypoint i and capL + j for right keypoint j.
+static int searchByProjectionFisheyeFramesImpl(const char *fn, int mode, float nnratio, orbx_matcher *m, orbx_extractor *left, orbx_extractor *right,
+                                               int nframes, float min_x, float max_x, float min_y, float max_y, const int8_t *d_cur_state,
+                                               const orbx_projection *d_proj_left, const orbx_projection *d_proj_right, const uint8_t *d_proj_desc,
+                                               const int32_t *d_np, int max_np, const int32_t *d_left_to_right, const int32_t *d_right_to_left,
+                                               float th, int forward, int backward, int check_orientation, void *d_assign, void *d_nmatches)
+{
+    if (!m || !left || !right) return setError(ORBX_ERR_INVALID_ARG, "%s: null handle", fn);
+    if (left == right) return setError(ORBX_ERR_INVALID_ARG, "%s: left and right must be two extractors", fn);
+    if (left->prm.device != m->device || right->prm.device != m->device) return setError(ORBX_ERR_INVALID_ARG, "%s: matcher and extractors must live on the same device", fn);
+    if (left->prm.nlevels != right->prm.nlevels) return setError(ORBX_ERR_INVALID_ARG, "%s: the extractors differ in nlevels", fn);
+    if (nframes < 0 || nframes > left->lastFrames || nframes > right->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: %d frames, the extractors' last batches hold %d / %d", fn, nframes, left->lastFrames, right->lastFrames);
+    if (max_np < 0 || (max_np > 0 && (!d_proj_left || !d_proj_right || !d_proj_desc)) || !d_np || !d_cur_state || !d_assign || !d_nmatches || !(th >= 0.f) ||
+        (mode == 1 && (!d_left_to_right || !d_right_to_left)))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    int rc = checkGridBounds(min_x, max_x, min_y, max_y, fn);
+    if (rc != ORBX_OK) return rc;
+    const int capL = left->maxKeypoints, capR = right->maxKeypoints, capC = capL + capR, nlev = left->prm.nlevels;
+    if (capC >= 65536) return setError(ORBX_ERR_CAPACITY, "%s: at most 65535 keypoints per frame (left + right capacity)", fn);
+    if (nframes == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t F = (size_t)nframes, NP = (size_t)std::max(max_np, 1);
+    // scratch: combined keypoints / descriptors, two grids per frame, steps, candidate lists, resolve state
+    if ((rc = m->d_bKps.ensure(F * capC)) != ORBX_OK) return rc;
+    if ((rc = m->d_siWork.ensure(F * capC * 32 + 64)) != ORBX_OK) return rc;
+    const size_t gridInts = (size_t)ORBX_GRID_CELLS + 1;
+    if ((rc = m->d_grid.ensure(2 * F * gridInts + 4 * F * capC)) != ORBX_OK) return rc;
+    // work: count[2 NP], choice[2 NP], next[4 NP] per frame; head[capC], partner[capC] per frame; result[2] per frame
+    if ((rc = m->d_work.ensure(F * (8 * NP + 2 * (size_t)capC + 2) + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure(F * 2 * NP * ORBX_SBP_CAP)) != ORBX_OK) return rc;
+    if ((rc = m->d_proj.ensure(F * 2 * NP)) != ORBX_OK) return rc;
+    int *csL = m->d_grid.p, *csR = csL + F * gridInts, *itL = csR + F * gridInts, *itR = itL + F * capC, *coL = itR + F * capC, *coR = coL + F * capC;
+    int *count = m->d_work.p, *choice = count + F * 2 * NP, *next = choice + F * 2 * NP, *head = next + F * 4 * NP, *dPartner = head + F * capC,
+        *result = dPartner + F * capC;
+    hipStream_t st = m->stream;
+    if ((rc = orderAfterExtractors(m, left, right)) != ORBX_OK) return rc;
+    // gather: rows = frames, the left block then the right block of every frame
+    orbx_keypoint *kc = m->d_bKps.p;
+    uint8_t *dc = m->d_siWork.p;
+    HIP_TRY(hipMemcpy2DAsync(kc, (size_t)capC * sizeof(orbx_keypoint), left->d_kps.p, (size_t)capL * sizeof(orbx_keypoint), (size_t)capL * sizeof(orbx_keypoint), F, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(kc + capL, (size_t)capC * sizeof(orbx_keypoint), right->d_kps.p, (size_t)capR * sizeof(orbx_keypoint), (size_t)capR * sizeof(orbx_keypoint), F, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(dc, (size_t)capC * 32, left->d_desc.p, (size_t)capL * 32, (size_t)capL * 32, F, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(dc + (size_t)capL * 32, (size_t)capC * 32, right->d_desc.p, (size_t)capR * 32, (size_t)capR * 32, F, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p, left->scale.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(orbxLaunchGridBuild(st, kc, capL, min_x, max_x, min_y, max_y, csL, itL, coL, nframes, capC, left->d_n.p));
+    HIP_TRY(orbxLaunchGridBuild(st, kc + capL, capR, min_x, max_x, min_y, max_y, csR, itR, coR, nframes, capC, right->d_n.p));
+    HIP_TRY(orbxLaunchFisheyeSteps(st, d_proj_left, d_proj_right, d_np, max_np, nframes, mode, m->d_proj.p));
+    if (mode == 1) HIP_TRY(orbxLaunchFisheyePartner(st, d_left_to_right, d_right_to_left, left->d_n.p, right->d_n.p, capL, capR, nframes, dPartner));
+    OrbxSbpBatch b;
+    b.nframes = nframes; b.kcStride = capC; b.projStride = 2 * (long long)max_np; b.ncDev = right->d_n.p; b.npDev = d_np;
+    OrbxSbpFisheye f;
+    f.kc = kc; f.dc = dc; f.curState = (const signed char *)d_cur_state; f.nLeft = capL; f.nRight = capR;
+    f.cellStartL = csL; f.itemsL = itL; f.cellStartR = csR; f.itemsR = itR;
+    f.minX = min_x; f.maxX = max_x; f.minY = min_y; f.maxY = max_y; f.scale = m->d_scale.p;
+    f.steps = m->d_proj.p; f.dproj = d_proj_desc; f.np = max_np;
+    f.th = th; f.forward = forward != 0; f.backward = backward != 0; f.checkOri = check_orientation != 0; f.mode = mode; f.nnratio = nnratio;
+    f.partner = mode == 1 ? dPartner : nullptr;
+    f.cand = m->d_sbpCand.p; f.count = count; f.choice = choice; f.head = head; f.next = next; f.assign = (int *)d_assign; f.result = result;
+    f.batch = &b;
+    HIP_TRY(orbxLaunchSearchByProjectionFisheye(st, f));
+    HIP_TRY(orbxLaunchGatherResults(st, result, nframes, (int *)d_nmatches));
+    return orderExtractorsAfter(m, left, right);
+}
+
+extern "C" int orbx_search_by_projection_fisheye_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int nframes, float min_x,
+                                                        float max_x, float min_y, float max_y, const int8_t *d_cur_state,
+                                                        const orbx_projection *d_proj_left, const orbx_projection *d_proj_right,
+                                                        const uint8_t *d_proj_desc, const int32_t *d_np, int max_np, float th, int forward,
+                                                        int backward, int check_orientation, void *d_assign, void *d_nmatches)
+{
+    ORBX_API_ENTRY;
+    return searchByProjectionFisheyeFramesImpl("orbx_search_by_projection_fisheye_frames", 0, 0.f, m, left, right, nframes, min_x, max_x, min_y, max_y,
+                                               d_cur_state, d_proj_left, d_proj_right, d_proj_desc, d_np, max_np, nullptr, nullptr, th, forward, backward,
+                                               check_orientation, d_assign, d_nmatches);
+}
+
+extern "C" int orbx_search_by_projection_points_fisheye_frames(orbx_matcher *m, orbx_extractor *left, orbx_extractor *right, int nframes, float min_x,
+                                                               float max_x, float min_y, float max_y, const int8_t *d_cur_state,
+                                                               const orbx_projection *d_map_points_left, const orbx_projection *d_map_points_right,
+                                                               const uint8_t *d_map_point_desc, const int32_t *d_np, int max_np,
+                                                               const int32_t *d_left_to_right, const int32_t *d_right_to_left, float th,
+                                                               float nnratio, void *d_assign, void *d_nmatches)
+{
+    ORBX_API_ENTRY;
+    return searchByProjectionFisheyeFramesImpl("orbx_search_by_projection_points_fisheye_frames", 1, nnratio, m, left, right, nframes, min_x, max_x, min_y,
+                                               max_y, d_cur_state, d_map_points_left, d_map_points_right, d_map_point_desc, d_np, max_np, d_left_to_right,
+                                               d_right_to_left, th, 0, 0, 0, d_assign, d_nmatches);
+}
+
 extern "C" int orbx_search_by_projection_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
                                                 const float *knew4, float min_x, float max_x, float min_y, float max_y, float mbf,
                                                 const float *d_u_right, const int8_t *d_cur_state, const orbx_projection *d_proj,

@@ -253,7 +253,12 @@ struct OrbxSbpFisheye {
     float th; int forward, backward, checkOri, mode; float nnratio;
     const int *partner;
     uint32_t *cand; int *count, *choice, *head, *next, *assign, *result;
+    const OrbxSbpBatch *batch = nullptr;  // a batch of frames: kc / dc / curState / partner / head / assign advance by kcStride = capL + capR records per frame
+                                          // (nLeft = capL: right keypoints start at the left capacity), steps / dproj by projStride = 2 maxNp / maxNp
 };
+hipError_t orbxLaunchFisheyeSteps(hipStream_t st, const void *pl, const void *pr, const int *npDev, int maxNp, int nframes, int mode, void *steps);
+hipError_t orbxLaunchFisheyePartner(hipStream_t st, const int *l2r, const int *r2l, const int *nlDev, const int *nrDev, int capL, int capR, int nframes,
+                                    int *partner);
 hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFisheye &f);
 
 #endif

@@ -1814,20 +1814,25 @@ struct SbpArgs {
     const int *cellStartR, *itemsR;   // mGridRight over kc + nLeft
     const int *partner;               // [nc] mvLeftToRightMatch / mvRightToLeftMatch as combined indices, -1 none; NULL in mode 0
     int *head, *next;                 // [nc], [2 np] work of k_sbp_resolve_fe: writers of a keypoint as linked lists
+    int ncBase;                       // batch of fisheye frames: keypoints of frame p = ncBase (the left capacity) + ncDev[p] right ones
 };
 
 // frame p of a batch: every per-frame array advances by its stride, the counts come from the device arrays
 __device__ __forceinline__ void sbp_select_frame(SbpArgs &a, size_t p)
 {
-    if (a.ncDev) a.nc = min(a.nc, a.ncDev[p]);
-    if (a.npDev) a.np = min(a.np, a.npDev[p]);
+    if (a.ncDev) a.nc = min(a.nc, a.ncBase + a.ncDev[p]);
+    if (a.npDev) a.np = min(a.np, a.nLeft >= 0 ? 2 * a.npDev[p] : a.npDev[p]);  // (fisheye: two steps per point)
     a.kc += p * a.kcStride; a.dc += p * a.kcStride * 32;
     if (a.uRight) a.uRight += p * a.kcStride;
     if (a.curState) a.curState += p * a.kcStride;
     a.cellStart += p * (GRID_CELLS + 1); a.items += p * a.kcStride;
-    a.proj += p * a.projStride; a.dproj += p * a.projStride * 32;
+    a.proj += p * a.projStride; a.dproj += p * (a.nLeft >= 0 ? a.projStride / 2 : a.projStride) * 32;  // (fisheye: two steps, one descriptor per point)
     a.cand += p * a.projStride * SBP_CAP; a.count += p * a.projStride; a.choice += p * a.projStride;
-    a.owner += p * 2 * a.kcStride; a.assign += p * a.kcStride; a.result += p * 2;
+    if (a.owner) a.owner += p * 2 * a.kcStride;
+    a.assign += p * a.kcStride; a.result += p * 2;
+    if (a.cellStartR) { a.cellStartR += p * (GRID_CELLS + 1); a.itemsR += p * a.kcStride; }
+    if (a.partner) a.partner += p * a.kcStride;
+    if (a.head) { a.head += p * a.kcStride; a.next += p * 2 * a.projStride; }
 }
 
 __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
@@ -2024,6 +2029,7 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc)
 __global__ __launch_bounds__(1024) void k_sbp_resolve_fe(SbpArgs a)
 {
     const int TH_HIGH = 100, HISTO_LENGTH = 30;
+    sbp_select_frame(a, blockIdx.x);  // (a single call: strides 0, no device-side counts)
     const int tid = threadIdx.x, S = a.np, nc = a.nc;
     __shared__ int changed, hist[32], nAcc;
     for (int i = tid; i < nc; i += 1024) { a.head[i] = -1; a.assign[i] = -1; }
@@ -2117,10 +2123,54 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve_fe(SbpArgs a)
     if (tid == 0) a.result[0] = nAcc;
 }
 
+// ---- a batch of fisheye frames: small device-side preparations ----------------------------------------------------------------------
+// steps of point i of frame p: 2 i = its left record, 2 i + 1 = its right record, with the merges searchByProjectionFisheyeImpl does on
+// the host for a single call (mode 0: one keypoint of the last frame behind both records; mode 1: one map point)
+__global__ void k_fe_steps(const SbpProj *pl, const SbpProj *pr, const int *npDev, int maxNp, int mode, SbpProj *steps)
+{
+    const size_t p = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(maxNp, npDev[p])) return;
+    SbpProj L = pl[p * maxNp + i], R = pr[p * maxNp + i];
+    if (mode == 0) { R.octave = L.octave; R.angle = L.angle; R.flags = L.flags; R.invz = L.invz; }
+    else { if (R.octave == -1) R.flags &= ~1; R.flags = (R.flags & ~2) | (L.flags & 2); }
+    steps[(p * maxNp + i) * 2] = L; steps[(p * maxNp + i) * 2 + 1] = R;
+}
+// stereo partners in combined indices (left i -> i, right j -> capL + j) from mvLeftToRightMatch / mvRightToLeftMatch
+__global__ void k_fe_partner(const int *l2r, const int *r2l, const int *nlDev, const int *nrDev, int capL, int capR, int *partner)
+{
+    const size_t p = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, capC = capL + capR;
+    if (i >= capC) return;
+    int v = -1;
+    if (i < capL) { if (i < nlDev[p]) { const int r = l2r[p * capL + i]; if (r >= 0 && r < nrDev[p]) v = capL + r; } }
+    else { const int j = i - capL; if (j < nrDev[p]) { const int l = r2l[p * capR + j]; if (l >= 0 && l < nlDev[p]) v = l; } }
+    partner[p * capC + i] = v;
+}
+hipError_t orbxLaunchFisheyeSteps(hipStream_t st, const void *pl, const void *pr, const int *npDev, int maxNp, int nframes, int mode, void *steps)
+{
+    if (nframes <= 0 || maxNp <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fe_steps, dim3((maxNp + 255) / 256, nframes), dim3(256), 0, st, (const SbpProj *)pl, (const SbpProj *)pr, npDev, maxNp, mode, (SbpProj *)steps);
+    return hipGetLastError();
+}
+hipError_t orbxLaunchFisheyePartner(hipStream_t st, const int *l2r, const int *r2l, const int *nlDev, const int *nrDev, int capL, int capR, int nframes,
+                                    int *partner)
+{
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fe_partner, dim3((capL + capR + 255) / 256, nframes), dim3(256), 0, st, l2r, r2l, nlDev, nrDev, capL, capR, partner);
+    return hipGetLastError();
+}
+
 hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFisheye &f)
 {
     SbpArgs a;
-    a.kcStride = 0; a.projStride = 0; a.ncDev = nullptr; a.npDev = nullptr;
+    a.kcStride = 0; a.projStride = 0; a.ncDev = nullptr; a.npDev = nullptr; a.ncBase = 0;
+    int nframes = 1;
+    if (f.batch) {  // frames of a batch: keypoints [capL left slots | capR right slots] per frame, 2 maxNp steps per frame
+        nframes = f.batch->nframes; a.kcStride = f.batch->kcStride; a.projStride = f.batch->projStride;
+        a.ncDev = f.batch->ncDev; a.npDev = f.batch->npDev; a.ncBase = f.nLeft;
+        if (nframes <= 0) return hipSuccess;
+    }
     a.mode = f.mode; a.nnratio = f.nnratio;
     a.kc = (const MtKp *)f.kc; a.dc = f.dc; a.uRight = nullptr; a.curState = f.curState; a.nc = f.nLeft + f.nRight;
     a.cellStart = f.cellStartL; a.items = f.itemsL; a.cellStartR = f.cellStartR; a.itemsR = f.itemsR;
@@ -2130,10 +2180,10 @@ hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFish
     a.th = f.th; a.forward = f.forward; a.backward = f.backward; a.checkOri = f.checkOri;
     a.cand = f.cand; a.count = f.count; a.choice = f.choice; a.owner = nullptr; a.assign = f.assign; a.result = f.result;
     a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next;
-    hipError_t e = hipMemsetAsync(f.result, 0, 2 * sizeof(int), st);
+    hipError_t e = hipMemsetAsync(f.result, 0, 2 * sizeof(int) * (size_t)nframes, st);
     if (e != hipSuccess) return e;
-    if (f.np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(2 * f.np, 1), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_sbp_resolve_fe, dim3(1), dim3(1024), 0, st, a);
+    if (f.np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(2 * f.np, nframes), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_sbp_resolve_fe, dim3(nframes), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 
@@ -2144,6 +2194,7 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
                                         int *owner, int *assign, int *result, const OrbxSbpBatch *batch)
 {
     SbpArgs a;
+    a.ncBase = 0; a.cellStartR = nullptr; a.itemsR = nullptr; a.partner = nullptr; a.head = nullptr; a.next = nullptr;
     const int nframes = batch ? batch->nframes : 1;
     a.kcStride = batch ? batch->kcStride : 0; a.projStride = batch ? batch->projStride : 0;
     a.ncDev = batch ? batch->ncDev : nullptr; a.npDev = batch ? batch->npDev : nullptr;

@@ -573,29 +573,42 @@ private:
 }  // namespace orbx
 
 // ---- OpenCV adaptor (compiled only inside the reference's build, where OpenCV >= 4.4 exists) ----------------
-#if defined(ORBX_WITH_OPENCV) && __has_include(<opencv2/core.hpp>)
-#include <opencv2/core.hpp>
 namespace orbx {
-// Drop-in for `int ORB_SLAM3::ORBextractor::operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&,
-// cv::OutputArray, std::vector<int>&)` (reference include/ORBextractor.h:66-68).
-inline int extract(ORBextractor &ex, cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints,
-                   cv::OutputArray _descriptors, std::vector<int> &vLappingArea)
+// The body of the drop-in for `int ORB_SLAM3::ORBextractor::operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&,
+// cv::OutputArray, std::vector<int>&)` (reference include/ORBextractor.h:66-68, src/ORBextractor.cc:1227-1307), written against the few
+// members of cv::_InputArray / cv::Mat / cv::_OutputArray it uses - empty(), getMat(), Mat::type() / data / cols / rows / step, release(),
+// create(rows, cols, type) - so that it is compiled and run in this repository's tests with small stand-in types
+// (tests/cpp/test_host_mirror.cpp::runCvShapedAdaptor; the image has no OpenCV), and instantiated with the real ones below.
+// KeyPointT must have cv::KeyPoint's 28-byte layout; type8UC1 / type8U = CV_8UC1 / CV_8U.
+template <class InputArrayT, class OutputArrayT, class KeyPointT>
+inline int extractInto(ORBextractor &ex, const InputArrayT &_image, std::vector<KeyPointT> &_keypoints, OutputArrayT &_descriptors,
+                       std::vector<int> &vLappingArea, int type8UC1, int type8U)
 {
-    static_assert(sizeof(cv::KeyPoint) == sizeof(KeyPoint), "cv::KeyPoint layout");
-    if (_image.empty()) return -1;
-    cv::Mat image = _image.getMat();
-    CV_Assert(image.type() == CV_8UC1);
+    static_assert(sizeof(KeyPointT) == sizeof(KeyPoint), "cv::KeyPoint layout (28 bytes: pt, size, angle, response, octave, class_id)");
+    if (_image.empty()) return -1;                                                         // :1231-1232
+    auto image = _image.getMat();
+    if (image.type() != type8UC1) throw std::runtime_error("ORBextractor: image must be CV_8UC1");  // assert(image.type() == CV_8UC1), :1235
     std::vector<KeyPoint> kps;
     Descriptors d;
-    int mono = ex(Image(image.data, image.cols, image.rows, (ptrdiff_t)image.step), Image(), kps, d, vLappingArea);
+    const int mono = ex(Image(image.data, image.cols, image.rows, (ptrdiff_t)image.step), Image(), kps, d, vLappingArea);
     _keypoints.resize(kps.size());
     if (!kps.empty()) std::memcpy((void *)_keypoints.data(), kps.data(), kps.size() * sizeof(KeyPoint));
-    if (kps.empty()) _descriptors.release();
+    if (kps.empty()) _descriptors.release();                                               // :1248-1249
     else {
-        _descriptors.create((int)kps.size(), 32, CV_8U);
+        _descriptors.create((int)kps.size(), 32, type8U);                                  // :1251
         std::memcpy(_descriptors.getMat().data, d.data.data(), d.data.size());
     }
     return mono;
+}
+}  // namespace orbx
+
+#if defined(ORBX_WITH_OPENCV) && __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+namespace orbx {
+inline int extract(ORBextractor &ex, cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint> &_keypoints,
+                   cv::OutputArray _descriptors, std::vector<int> &vLappingArea)
+{
+    return extractInto(ex, _image, _keypoints, _descriptors, vLappingArea, CV_8UC1, CV_8U);
 }
 }  // namespace orbx
 #endif
