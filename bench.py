@@ -13,7 +13,8 @@ Frame::ComputeStereoMatches per pair; c4 = 512x512 mono, nFeatures=1500; c5 = 19
 extraction + brute-force kNN-2 Hamming cross-match (4000 x 4000 per pair).  Stereo steps run the two extractors and the
 device-resident batched matcher entry point; nothing crosses PCIe inside a step.
 
-Multi-GPU (--gpus N under torch.distributed.run): frames shard across ranks, one process per GPU, no data-path collective.
+Multi-GPU: `python bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run`, one process per GPU over RCCL;
+the parent never touches the GPU); under an external launcher (RANK set) it is a rank.  Frames shard across ranks, no data-path collective.
 --scaling weak (default): every rank runs its own batch per step.  --scaling strong: a fixed stream (c3: the 3,682 pairs of
 EuRoC MH01) is dealt frame f -> rank f mod N and every rank works through its share in batches.  With --gather the
 fixed-capacity result records are all-gathered over RCCL inside the timed region and placed by frame index on the device
@@ -42,6 +43,8 @@ import __graft_entry__ as graft  # noqa: E402
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PCIE_PEAK_GBS = 63.0        # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
+PRACTICAL_CYCLES_PER_VALU = 3.9  # measured issue cost of k_pyr_fast's own inner bodies run dense, in 2.4 GHz cycles (profiles/r03_inner_body_issue_rates.txt)
+MFMA_I8_16x16x64_CYCLES = 22.0   # measured back-to-back issue of v_mfma_i32_16x16x64_i8 on one SIMD (tools/experiments/mfma_i8_rate.hip; 16 by the data sheet)
 N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 CONFIGS = {
     # units = what one GPU processes per step; a stereo unit is a pair (2 frames)
@@ -433,10 +436,17 @@ def main() -> None:
             # 2.4-2.7 cycles for add/and/bitop3/shift, 4.1-4.5 for min/max/mul/alignbyte/SDWA forms, the peak is lower: `peak_mix`)
             ach = valu / (pyr_ms * 1e-3) / 1e9
             roof["hbm"] = dict(hbm, traffic=roof["traffic"])
+            # `peak_practical`: what the kernel's OWN inner bodies (ring test, pre-test, corner score) reach when they run alone in dense
+            # loops from LDS, 8 waves per SIMD: 3.8 - 4.45 cycles per vector instruction in 2.4 GHz terms (3.3 - 4.0 real cycles at the
+            # 2.0 - 2.1 GHz the chip holds under that load), tools/experiments/ring_rate.hip -> profiles/r03_inner_body_issue_rates.txt;
+            # weighted with the phases' instruction shares: 3.9
+            prac = PRACTICAL_CYCLES_PER_VALU
             roof.update({"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(N_SIMD * CLOCK_GHZ / 2.0, 1), "unit": "G wave-instr/s",
                          "frac": round(ach / (N_SIMD * CLOCK_GHZ / 2.0), 4), "peak_mix": round(N_SIMD * CLOCK_GHZ / cyc, 1),
-                         "frac_mix": round(ach / (N_SIMD * CLOCK_GHZ / cyc), 3), "valu_wave_instr_per_launch_set": int(valu),
-                         "cycles_per_instr_mix": cyc, "clock_ghz": CLOCK_GHZ, "valu_source": src,
+                         "frac_mix": round(ach / (N_SIMD * CLOCK_GHZ / cyc), 3), "peak_practical": round(N_SIMD * CLOCK_GHZ / prac, 1),
+                         "frac_practical": round(ach / (N_SIMD * CLOCK_GHZ / prac), 3),
+                         "practical_source": "profiles/r03_inner_body_issue_rates.txt (tools/experiments/ring_rate.hip)",
+                         "valu_wave_instr_per_launch_set": int(valu), "cycles_per_instr_mix": cyc, "clock_ghz": CLOCK_GHZ, "valu_source": src,
                          "frac_hbm": hbm["frac"]})
         except Exception as e:  # the HBM block above stands (it is measured live); say why the counter-based part is missing
             roof["counters_dropped"] = f"{type(e).__name__}: {e}"[:240]
@@ -477,10 +487,13 @@ def main() -> None:
             # k_knn2_scan_mfma: a 16 x 16 tile of (train row, query) pairs = 4 x v_mfma_i32_16x16x64_i8 of 16 cycles on one SIMD's
             # matrix core -> 256 pairs per 64 cycles.  (The vector-ALU scan it replaced: 8 v_xor + 8 v_bcnt + key, min, med3 = 65 issue
             # cycles per 64 pairs, ORBX_KNN_MFMA=0.)
-            peak = N_SIMD * 256 * CLOCK_GHZ * 1e9 / 64.0
+            # (peak: at the MEASURED issue interval of that instruction, 22 cycles - the data-sheet 16 cycles is not reachable in a bare loop)
+            peak = N_SIMD * 256 * CLOCK_GHZ * 1e9 / (4 * MFMA_I8_16x16x64_CYCLES)
+            peak16 = N_SIMD * 256 * CLOCK_GHZ * 1e9 / 64.0
             valu_peak = N_SIMD * 64 * CLOCK_GHZ * 1e9 / 65.0
             blk.update({"descriptor_pairs_per_s": round(dpairs / mt, 0), "mfma_peak_descriptor_pairs_per_s": round(peak, 0),
-                        "frac_of_mfma_peak": round(dpairs / mt / peak, 3),
+                        "frac_of_mfma_peak": round(dpairs / mt / peak, 3), "mfma_issue_cycles_measured": MFMA_I8_16x16x64_CYCLES,
+                        "frac_of_16_cycle_datasheet_peak": round(dpairs / mt / peak16, 3),
                         "valu_scan_issue_peak_descriptor_pairs_per_s": round(valu_peak, 0)})
         out["matcher"] = blk
     if not args.no_pcie and world == 1:  # (host legs on rank 0 at N = 1 only)

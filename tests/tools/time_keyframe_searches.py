@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""GPU entry point vs single-thread CPU oracle for the keyframe searches of round 3 (host arrays in and out, one call each):
+SearchForTriangulation, Fuse / SearchBySim3 window searches, SearchByProjection(KeyFrame, Sim3) rounds, ComputeDistinctiveDescriptors.
+Usage on the GPU box: python tests/tools/time_keyframe_searches.py > gpurun_out/keyframe_searches.txt"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft  # noqa: E402
+
+pkg, orc = graft.load_package(), graft.load_oracle()
+import test_fuse_sim3_gpu as tf  # noqa: E402
+import test_triangulation_search_gpu as tt  # noqa: E402
+from voc_synth import make_vocabulary  # noqa: E402
+
+
+def bench(fn, reps=20):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+m = pkg.ORBmatcher(8192, 8192)
+k1, d1, k2, d2, F, ep, rng = tt._pinhole_scene(pkg, 2000, seed=1)
+parent, leaf, desc, weight = make_vocabulary(10, 4, seed=3)
+voc = pkg.ORBVocabulary(10, 4, 0, 0, parent=parent, is_leaf=leaf, desc=desc, weight=weight)
+fv1, fv2 = voc.transform(d1, 2), voc.transform(d2, 2)
+a = pkg.keyframe_view(k1, d1, np.zeros(len(k1), np.uint8), fv1, tt.SF, tt.SIGMA2)
+b = pkg.keyframe_view(k2, d2, np.zeros(len(k2), np.uint8), fv2, tt.SF, tt.SIGMA2)
+g = pkg.triangulation_geometry(ep, F)
+print(f"SearchForTriangulation 2000 x 2250 features, {len(fv1['fv_node'])} nodes: GPU {bench(lambda: m.SearchForTriangulation(a, b, g)):.3f} ms, "
+      f"oracle 1 thread {bench(lambda: orc.search_for_triangulation(a, b, g), 5):.3f} ms")
+k, d, ur, pts, pd = tf._scene(pkg, orc, 2000, 1500, seed=5)
+print(f"Fuse window search 1500 points x 2000 keypoints: GPU {bench(lambda: m.Fuse(k, d, tf.BOUNDS, pts, pd, 8, u_right=ur, inv_level_sigma2=tf.INV_SIGMA2)):.3f} ms, "
+      f"oracle {bench(lambda: orc.search_keyframe_windows(k, d, tf.BOUNDS, pts, pd, u_right=ur, inv_level_sigma2=tf.INV_SIGMA2, chi2_test=True), 5):.3f} ms")
+matched = np.zeros(len(k), np.uint8)
+print(f"SearchByProjection(KeyFrame, Sim3) 1500 points x 2000 keypoints: GPU {bench(lambda: m.SearchByProjectionSim3(k, d, tf.BOUNDS, pts, pd, matched)):.3f} ms, "
+      f"oracle {bench(lambda: orc.search_by_projection_sim3(k, d, tf.BOUNDS, pts, pd, matched), 5):.3f} ms")
+counts = rng.integers(2, 15, 5000)
+start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+dd = rng.integers(0, 256, (int(start[-1]), 32), dtype=np.uint8)
+print(f"ComputeDistinctiveDescriptors 5000 map points, {int(start[-1])} observations: GPU {bench(lambda: m.ComputeDistinctiveDescriptors(dd, start)):.3f} ms, "
+      f"oracle {bench(lambda: orc.distinctive_descriptors(dd, start), 3):.3f} ms")
