@@ -311,6 +311,60 @@ static int runComputeBoW()
     return 0;
 }
 
+// Fuse (search part) and MapPoint::ComputeDistinctiveDescriptors through the C++ mirror against the oracle (round 3 widening)
+static int runKeyframeSearches()
+{
+    const int n = 1500, np = 900, nlev = 8;
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    std::vector<orbx::KeyPoint> keys(n);
+    orbx::Descriptors desc; desc.create(n);
+    for (int i = 0; i < n; ++i) {
+        keys[i].pt.x = 5.f + (float)(rnd() % 74000) / 100.f; keys[i].pt.y = 5.f + (float)(rnd() % 47000) / 100.f;
+        keys[i].octave = (int)(rnd() % nlev); keys[i].size = 31.f; keys[i].angle = 0.f; keys[i].response = 1.f; keys[i].class_id = -1;
+        for (int b = 0; b < 32; ++b) desc.data[(size_t)i * 32 + b] = (uint8_t)rnd();
+    }
+    std::vector<float> invSigma2(nlev), uRight(n);
+    float sc = 1.f;
+    for (int l = 0; l < nlev; ++l) { invSigma2[l] = 1.f / (sc * sc); sc *= 1.2f; }
+    for (int i = 0; i < n; ++i) uRight[i] = (rnd() & 1) ? keys[i].pt.x - 7.f : -1.f;
+    std::vector<orbx_window_point> pts(np);
+    orbx::Descriptors pd; pd.create(np);
+    for (int i = 0; i < np; ++i) {
+        const int src = (int)(rnd() % n);
+        pts[i].u = keys[src].pt.x + (float)((int)(rnd() % 400) - 200) / 100.f; pts[i].v = keys[src].pt.y + (float)((int)(rnd() % 400) - 200) / 100.f;
+        pts[i].ur = pts[i].u - 7.f; pts[i].level = keys[src].octave; pts[i].radius = 6.f * (1.f + 0.2f * (float)pts[i].level); pts[i].search = (rnd() % 10) != 0;
+        for (int b = 0; b < 32; ++b) pd.data[(size_t)i * 32 + b] = desc.data[(size_t)src * 32 + b] ^ (uint8_t)((rnd() % 5 == 0) ? (1u << (rnd() % 8)) : 0);
+    }
+    orbx::FrameView KF;
+    KF.mvKeysUn = &keys; KF.mDescriptors = &desc; KF.mnMinX = 0.f; KF.mnMaxX = 752.f; KF.mnMinY = 0.f; KF.mnMaxY = 480.f;
+    orbx::ORBmatcher matcher(0.6f, true, 4096, 0);
+    std::vector<int> fused;
+    const int nFused = matcher.Fuse(KF, uRight, invSigma2, pts, pd, true, fused);
+    std::vector<int32_t> bi(np), bd(np);
+    oracle_search_keyframe_windows((const oracle_keypoint *)keys.data(), desc.data.data(), uRight.data(), n, 0.f, 752.f, 0.f, 480.f, invSigma2.data(),
+                                   (const oracle_window_point *)pts.data(), pd.data.data(), np, 1, bi.data(), bd.data());
+    int expFused = 0;
+    for (int i = 0; i < np; ++i) {
+        const int e = bd[i] <= 50 ? bi[i] : -1;
+        ASSERT_EQ(fused[i], e);
+        expFused += e >= 0;
+    }
+    ASSERT_EQ(nFused, expFused);
+    ASSERT_TRUE(nFused > np / 4);
+    // distinctive descriptors: 200 map points with 1 .. 9 observations each
+    std::vector<int32_t> start(1, 0);
+    for (int p = 0; p < 200; ++p) start.push_back(start.back() + 1 + (int)(rnd() % 9));
+    orbx::Descriptors obs; obs.create(start.back());
+    for (size_t b = 0; b < obs.data.size(); ++b) obs.data[b] = (uint8_t)(rnd() % 4 ? 0x5A : rnd());
+    std::vector<int> best;
+    matcher.ComputeDistinctiveDescriptors(obs, start, best);
+    std::vector<int32_t> rb(200);
+    oracle_distinctive_descriptors(obs.data.data(), start.data(), 200, rb.data());
+    for (int p = 0; p < 200; ++p) ASSERT_EQ(best[p], rb[p]);
+    return 0;
+}
+
 // The operator() adaptor (orbx::extractInto) instantiated with stand-ins for the OpenCV types it touches: what a build with
 // -DORBX_WITH_OPENCV instantiates with cv::InputArray / cv::Mat / cv::OutputArray / cv::KeyPoint.  The stand-ins carry exactly the members
 // the adaptor uses, with cv::Mat's semantics (a header that shares its buffer, step in bytes, create() re-allocates).
@@ -430,6 +484,7 @@ int main()
     if (runSearchByProjection()) return 1;                           // SURVEY 8(f) rank 2, tracking searches
     if (runComputeBoW()) return 1;
     if (runShardedBatch()) return 1;                                 // SURVEY 8(e), one process
+    if (runKeyframeSearches()) return 1;                             // Fuse + ComputeDistinctiveDescriptors through the C++ mirror
     if (runCvShapedAdaptor()) return 1;                              // the operator() adaptor of the OpenCV build, on stand-in types
     printf("OK host mirror\n");
     return 0;

@@ -239,6 +239,29 @@ def test_host_batch_in_sub_batches(pkg, orc):
     ex.close()
 
 
+def test_small_batch_graph_cache_alternating_sources(pkg, orc):
+    """A single-frame handle replays a captured launch graph per (source buffer, image size, lapping area); a caller that alternates camera
+    buffers or lapping areas must hit the handle's small cache of graphs (4 entries) and get every frame's own result - also after more
+    distinct keys than the cache holds."""
+    import torch
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=1)
+    imgs = [pkg.synth_frame(6000 + i, 640, 480) for i in range(6)]
+    dev = [torch.from_numpy(im).cuda() for im in imgs]
+    ref = orc.Oracle(1000, 1.2, 8, 20, 7)
+    want = {}
+    for i, im in enumerate(imgs):
+        for lap in ((0, 1000), (100, 300)):
+            want[(i, lap)] = ref.extract(im, lap)
+    order = [(0, (0, 1000)), (1, (0, 1000)), (0, (0, 1000)), (1, (100, 300)), (0, (100, 300)), (1, (0, 1000)),   # 4 keys, alternating
+             (2, (0, 1000)), (3, (0, 1000)), (4, (0, 1000)), (5, (0, 1000)), (0, (0, 1000)), (2, (100, 300)), (1, (0, 1000))]  # more than 4
+    for i, lap in order * 2:
+        ex.extract_batch_device(dev[i].data_ptr(), 1, 640, 480, 640, 640 * 480, lap)
+        n, mono, kps, desc = ex.download_outputs(1)
+        rmono, rk, rd = want[(i, lap)]
+        assert mono[0] == rmono and n[0] == len(rk) and kps[0][: n[0]].tobytes() == rk.tobytes() and desc[0][: n[0]].tobytes() == rd.tobytes(), (i, lap)
+    ex.close()
+
+
 def _same_valid_rows(a, b):
     (n, mono, kps, desc), (n2, mono2, kps2, desc2) = a, b
     assert np.array_equal(n, n2) and np.array_equal(mono, mono2)

@@ -142,8 +142,12 @@ struct orbx_extractor {
 
     // small batches (a SLAM front end calls operator() one frame at a time): the launch sequence as a captured hipGraph
     struct GraphKey { const void *src; int nframes, w, h; long long stride, frameStride; int lap0, lap1, generation; };
-    hipGraphExec_t graphExec = nullptr;
-    GraphKey graphKey = {};
+    // a few captured sequences, least recently used replaced: a caller that alternates two or three source buffers (a camera ring) or
+    // lapping areas must not re-capture on every call (capture + instantiate run under the process-wide setup lock)
+    static const int kGraphSlots = 4;        // = the slots of the per-level argument blocks (pfArgsKey)
+    hipGraphExec_t graphExec[kGraphSlots] = {};
+    GraphKey graphKey[kGraphSlots] = {};
+    unsigned long long graphUse[kGraphSlots] = {}, graphClock = 0;
     int generation = 0;                      // bumped whenever the geometry or a device buffer changes
     hipStream_t qtStream[ORBX_MAX_LEVELS] = {};  // one branch per level for the quadtree instances of a small batch
     hipEvent_t evQt[ORBX_MAX_LEVELS] = {};
@@ -319,7 +323,8 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i)
         if (ex->evLevel[i]) (void)hipEventDestroy(ex->evLevel[i]);
     for (auto &e : ex->events) (void)hipEventDestroy(e);
-    if (ex->graphExec) (void)hipGraphExecDestroy(ex->graphExec);
+    for (int k = 0; k < orbx_extractor::kGraphSlots; ++k)
+        if (ex->graphExec[k]) (void)hipGraphExecDestroy(ex->graphExec[k]);
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i) {
         if (ex->qtStream[i]) { (void)hipStreamSynchronize(ex->qtStream[i]); (void)hipStreamDestroy(ex->qtStream[i]); }
         if (ex->evQt[i]) (void)hipEventDestroy(ex->evQt[i]);
@@ -1129,10 +1134,26 @@ static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w,
     int rcl = prepareLevelArgs(ex, src0, nf, stride, frame_stride);  // (before any capture: it may copy synchronously)
     if (rcl != ORBX_OK) return rcl;
     if (!useGraph) { HIP_TRY(issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1)); return ORBX_OK; }
-    const orbx_extractor::GraphKey key = {src0, nf, w, h, (long long)stride, (long long)frame_stride, lap0, lap1, ex->generation};
-    if (!ex->graphExec || memcmp(&key, &ex->graphKey, sizeof key) != 0) {
+    orbx_extractor::GraphKey key;
+    memset(&key, 0, sizeof key);  // (padding bytes: the keys are compared with memcmp)
+    key.src = src0; key.nframes = nf; key.w = w; key.h = h; key.stride = (long long)stride; key.frameStride = (long long)frame_stride;
+    key.lap0 = lap0; key.lap1 = lap1; key.generation = ex->generation;
+    int slot = -1;
+    for (int k = 0; k < orbx_extractor::kGraphSlots; ++k)
+        if (ex->graphExec[k] && memcmp(&key, &ex->graphKey[k], sizeof key) == 0) { slot = k; break; }
+    if (slot < 0) {
         ORBX_SETUP_LOCK;
-        if (ex->graphExec) { (void)hipGraphExecDestroy(ex->graphExec); ex->graphExec = nullptr; }
+        slot = 0;  // an empty slot, else the least recently used one
+        for (int k = 0; k < orbx_extractor::kGraphSlots; ++k) {
+            if (!ex->graphExec[k]) { slot = k; break; }
+            if (ex->graphUse[k] < ex->graphUse[slot]) slot = k;
+        }
+        if (ex->graphExec[slot]) {
+            // (a replaced sequence may still be running: its launch was the last use of the exec object)
+            HIP_TRY(hipStreamSynchronize(ex->stream));
+            (void)hipGraphExecDestroy(ex->graphExec[slot]);
+            ex->graphExec[slot] = nullptr;
+        }
         HIP_TRY(hipStreamBeginCapture(ex->stream, hipStreamCaptureModeRelaxed));
         const hipError_t ie = issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1);
         hipGraph_t graph = nullptr;
@@ -1141,13 +1162,13 @@ static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w,
             if (graph) (void)hipGraphDestroy(graph);
             return setError(ORBX_ERR_HIP, "capturing the launch sequence failed: %s", hipGetErrorString(ie != hipSuccess ? ie : ce));
         }
-        const hipError_t ge = hipGraphInstantiate(&ex->graphExec, graph, nullptr, nullptr, 0);
+        const hipError_t ge = hipGraphInstantiate(&ex->graphExec[slot], graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (ge != hipSuccess) { ex->graphExec = nullptr; return setError(ORBX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge)); }
-        memset(&ex->graphKey, 0, sizeof ex->graphKey);
-        ex->graphKey = key;
+        if (ge != hipSuccess) { ex->graphExec[slot] = nullptr; return setError(ORBX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ge)); }
+        memcpy(&ex->graphKey[slot], &key, sizeof key);
     }
-    HIP_TRY(hipGraphLaunch(ex->graphExec, ex->stream));
+    ex->graphUse[slot] = ++ex->graphClock;
+    HIP_TRY(hipGraphLaunch(ex->graphExec[slot], ex->stream));
     return ORBX_OK;
 }
 

@@ -433,6 +433,90 @@ public:
         return n;
     }
 
+    // The search part of `int Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th, const bool bRight)` (reference
+    // include/ORBmatcher.h:82, src/ORBmatcher2.cc:420-610; bChi2 = true) and of `Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)` (:612-770;
+    // bChi2 = false).  KF: the keyframe's keypoints / descriptors of the side being searched and its image bounds; vuRight = mvuRight (may
+    // be empty), vInvLevelSigma2 = mvInvLevelSigma2; vPoints[i] = map point i projected by the caller (orbx_window_point: search = 0 for a
+    // point that failed one of the tests in front of GetFeaturesInArea); vPointDescriptors = their MapPoint::GetDescriptor() rows.
+    // vnFusedIdx[i] = keypoint with bestDist <= TH_LOW or -1; Replace / AddObservation / AddMapPoint (:581-600) remain the caller's.
+    int Fuse(const FrameView &KF, const std::vector<float> &vuRight, const std::vector<float> &vInvLevelSigma2,
+             const std::vector<orbx_window_point> &vPoints, const Descriptors &vPointDescriptors, bool bChi2, std::vector<int> &vnFusedIdx)
+    {
+        const int n = (int)KF.mvKeysUn->size(), np = (int)vPoints.size();
+        if (vPointDescriptors.rows != np || (!vuRight.empty() && (int)vuRight.size() != n)) throw std::runtime_error("Fuse: inconsistent array sizes");
+        vnFusedIdx.assign((size_t)np, -1);
+        const int r = orbx_fuse(m_, (const orbx_keypoint *)KF.mvKeysUn->data(), KF.mDescriptors->data.data(), vuRight.empty() ? nullptr : vuRight.data(), n,
+                                KF.mnMinX, KF.mnMaxX, KF.mnMinY, KF.mnMaxY, vInvLevelSigma2.data(), (int)vInvLevelSigma2.size(), vPoints.data(),
+                                vPointDescriptors.data.data(), np, bChi2 ? 1 : 0, vnFusedIdx.data());
+        if (r < 0) check(r, "Fuse");
+        return r;
+    }
+
+    // int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint*> &vpMatches12, const Sim3f &S12, const float th) — reference
+    // include/ORBmatcher.h:76, src/ORBmatcher3.cc:37-254.  vPoints1in2[i1] / vPoints2in1[i2]: the map point of feature i1 of pKF1 (i2 of pKF2)
+    // transformed with S21 (S12) and projected, search = 0 where the reference `continue`s (:70-118, :158-186); vMapPointDesc1 / 2 their
+    // descriptors.  vnMatches12[i1] = i2 whose map point vpMatches12[i1] becomes, -1 = unchanged.
+    int SearchBySim3(const FrameView &KF1, const FrameView &KF2, const std::vector<orbx_window_point> &vPoints1in2, const Descriptors &vMapPointDesc1,
+                     const std::vector<orbx_window_point> &vPoints2in1, const Descriptors &vMapPointDesc2, int nLevels, std::vector<int> &vnMatches12)
+    {
+        const int n1 = (int)KF1.mvKeysUn->size(), n2 = (int)KF2.mvKeysUn->size();
+        if ((int)vPoints1in2.size() != n1 || (int)vPoints2in1.size() != n2 || vMapPointDesc1.rows != n1 || vMapPointDesc2.rows != n2)
+            throw std::runtime_error("SearchBySim3: one projected point and one descriptor per feature of each keyframe");
+        const float b1[4] = {KF1.mnMinX, KF1.mnMaxX, KF1.mnMinY, KF1.mnMaxY}, b2[4] = {KF2.mnMinX, KF2.mnMaxX, KF2.mnMinY, KF2.mnMaxY};
+        vnMatches12.assign((size_t)n1, -1);
+        const int r = orbx_search_by_sim3(m_, (const orbx_keypoint *)KF1.mvKeysUn->data(), KF1.mDescriptors->data.data(), n1, b1,
+                                          (const orbx_keypoint *)KF2.mvKeysUn->data(), KF2.mDescriptors->data.data(), n2, b2, vPoints1in2.data(),
+                                          vMapPointDesc1.data.data(), vPoints2in1.data(), vMapPointDesc2.data.data(), nLevels, vnMatches12.data());
+        if (r < 0) check(r, "SearchBySim3");
+        return r;
+    }
+
+    // int SearchByProjection(KeyFrame *pKF, Sim3f &Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th, float
+    // ratioHamming) — reference include/ORBmatcher.h:59-60, src/ORBmatcher1.cc:429-533 (and :535-648).  vbMatched[idx] = (vpMatched[idx] !=
+    // NULL) on entry; vnNewMatch[idx] = the point whose map point vpMatched[idx] becomes, -1 = unchanged.
+    int SearchByProjection(const FrameView &KF, const std::vector<orbx_window_point> &vPoints, const Descriptors &vPointDescriptors,
+                           const std::vector<uint8_t> &vbMatched, int nLevels, float ratioHamming, std::vector<int> &vnNewMatch)
+    {
+        const int n = (int)KF.mvKeysUn->size(), np = (int)vPoints.size();
+        if (vPointDescriptors.rows != np || (int)vbMatched.size() != n) throw std::runtime_error("SearchByProjection: inconsistent array sizes");
+        vnNewMatch.assign((size_t)n, -1);
+        const int r = orbx_search_by_projection_sim3(m_, (const orbx_keypoint *)KF.mvKeysUn->data(), KF.mDescriptors->data.data(), n, KF.mnMinX, KF.mnMaxX,
+                                                     KF.mnMinY, KF.mnMaxY, nLevels, vPoints.data(), vPointDescriptors.data.data(), np, vbMatched.data(),
+                                                     ratioHamming, vnNewMatch.data());
+        if (r < 0) check(r, "SearchByProjection");
+        return r;
+    }
+
+    // int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist) —
+    // reference include/ORBmatcher.h:57, src/ORBmatcher3.cc:469-590 (Relocalization).  vPoints[i] / vPointAngles[i]: the keyframe's map point i
+    // projected with the frame's pose, pKF->mvKeysUn[i].angle; vbHasMapPoint[i2] = (CurrentFrame.mvpMapPoints[i2] != NULL) on entry.
+    int SearchByProjection(const FrameView &CurrentFrame, const std::vector<orbx_window_point> &vPoints, const Descriptors &vPointDescriptors,
+                           const std::vector<float> &vPointAngles, const std::vector<uint8_t> &vbHasMapPoint, int nLevels, int ORBdist,
+                           std::vector<int> &vnNewMatch)
+    {
+        const int n = (int)CurrentFrame.mvKeysUn->size(), np = (int)vPoints.size();
+        if (vPointDescriptors.rows != np || (int)vPointAngles.size() != np || (int)vbHasMapPoint.size() != n)
+            throw std::runtime_error("SearchByProjection: inconsistent array sizes");
+        vnNewMatch.assign((size_t)n, -1);
+        const int r = orbx_search_by_projection_keyframe(m_, (const orbx_keypoint *)CurrentFrame.mvKeysUn->data(), CurrentFrame.mDescriptors->data.data(), n,
+                                                         CurrentFrame.mnMinX, CurrentFrame.mnMaxX, CurrentFrame.mnMinY, CurrentFrame.mnMaxY, nLevels,
+                                                         vPoints.data(), vPointDescriptors.data.data(), vPointAngles.data(), np, vbHasMapPoint.data(),
+                                                         ORBdist, mbCheckOrientation ? 1 : 0, vnNewMatch.data());
+        if (r < 0) check(r, "SearchByProjection");
+        return r;
+    }
+
+    // void MapPoint::ComputeDistinctiveDescriptors() — reference include/MapPoint.h, src/MapPoint.cc:329-403, for many map points at once:
+    // vObserved = the rows the reference collects into vDescriptors, point p owning rows [vStart[p], vStart[p + 1]); vnBest[p] = the row
+    // (relative) that becomes mDescriptor, -1 without observations.
+    void ComputeDistinctiveDescriptors(const Descriptors &vObserved, const std::vector<int32_t> &vStart, std::vector<int> &vnBest)
+    {
+        if (vStart.empty()) { vnBest.clear(); return; }
+        if (vStart.back() != vObserved.rows) throw std::runtime_error("ComputeDistinctiveDescriptors: vStart does not cover the descriptor rows");
+        vnBest.assign(vStart.size() - 1, -1);
+        check(orbx_distinctive_descriptors(m_, vObserved.data.data(), vStart.data(), (int)vStart.size() - 1, vnBest.data()), "ComputeDistinctiveDescriptors");
+    }
+
     // Frame::UndistortKeyPoints — reference src/Frame.cc:777-811: mvKeysUn from mvKeys.  K = toK() and mK as {fx, fy, cx, cy},
     // mDistCoef as the reference's 4 / 5 / 8 / 12 floats (copies when mDistCoef[0] == 0).
     void UndistortKeyPoints(const std::vector<KeyPoint> &mvKeys, const float (&K)[4], const std::vector<float> &mDistCoef, const float (&mK)[4],
