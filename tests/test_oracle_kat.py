@@ -495,3 +495,85 @@ def test_fisheye_search_by_projection_known_answers(orc):
             n, a = orc.search_by_projection_fisheye(kw.pop("kc"), kw.pop("dc"), kw.pop("n_left"), kw.pop("cur_state"), kat.BOUNDS, kat.SCALE,
                                                     kw.pop("proj_l"), kw.pop("proj_r"), kw.pop("proj_desc"), kw.pop("th"), **kw)
         assert n == n_exp and np.array_equal(a, a_exp), (name, n, a)
+
+
+def _fast9_16_from_the_definition(img, threshold):
+    """FAST-9/16 with non-maximum suppression written from its published definition (Rosten & Drummond; cv::FAST TYPE_9_16 docs), not from
+    OpenCV's code: a pixel p is a corner at threshold t iff 9 CONTIGUOUS pixels of the 16-pixel Bresenham circle of radius 3 are all
+    brighter than I(p) + t or all darker than I(p) - t; its score is the largest t for which that still holds (= the best arc's smallest
+    absolute difference, minus 1); a corner survives iff its score is STRICTLY greater than the scores of its 8 neighbours (non-corners
+    score 0).  Pure numpy loops - independent of oracle/orb_oracle.cpp's SWAR-free but OpenCV-shaped implementation."""
+    ring = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+    h, w = img.shape
+    I = img.astype(np.int32)
+    score = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = np.array([I[y, x] - I[y + dy, x + dx] for dx, dy in ring])  # > 0: ring pixel darker
+            best = 0
+            for s in range(16):
+                arc = d[[(s + k) % 16 for k in range(9)]]
+                best = max(best, arc.min(), (-arc).min())  # all darker by at least .., all brighter by at least ..
+            if best > threshold:
+                score[y, x] = best - 1
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s > 0:
+                nb = score[y - 1:y + 2, x - 1:x + 2].copy()
+                nb[1, 1] = -1
+                if s > nb.max():
+                    out.append((x, y, s))
+    return out
+
+
+@pytest.mark.parametrize("seed,threshold", [(1, 20), (2, 7), (3, 40), (4, 20), (5, 12)])
+def test_fast_against_its_definition(orc, seed, threshold):
+    """The oracle's cv::FAST restatement (fast_roi: one cell ROI, NMS on) against a brute-force implementation of the detector's definition:
+    same corners, same scores, same (raster) order - on noisy blobs, checkerboards and ramps, at the thresholds the extractor uses."""
+    rng = np.random.default_rng(seed)
+    h, w = 41, 47
+    img = rng.integers(60, 90, (h, w)).astype(np.int32)
+    for _ in range(10):  # bright / dark rectangles and a few single pixels
+        x0, y0 = int(rng.integers(0, w - 4)), int(rng.integers(0, h - 4))
+        img[y0:y0 + int(rng.integers(2, 12)), x0:x0 + int(rng.integers(2, 12))] = int(rng.integers(0, 256))
+    if seed == 4:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (((xx // 6 + yy // 6) % 2) * 120 + 40 + rng.integers(-5, 6, (h, w)))  # checkerboard: equal scores next to each other
+    if seed == 5:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.clip(xx * 5 + yy * 3 + rng.integers(-8, 9, (h, w)), 0, 255)         # ramps: both polarities pass the quick test
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    kp = orc.fast_roi(img, threshold)
+    got = list(zip((kp & 0xFFF).tolist(), ((kp >> 12) & 0xFFF).tolist(), (kp >> 24).tolist()))
+    want = _fast9_16_from_the_definition(img, threshold)
+    assert got == [(x, y, s) for x, y, s in want]
+    if seed in (1, 2):
+        assert len(got) >= 3
+
+
+def test_resize_and_blur_stay_within_one_level_of_their_real_valued_definitions(orc):
+    """cv::resize(INTER_LINEAR) and cv::GaussianBlur(7x7, sigma 2, REFLECT_101) are fixed-point implementations of real-valued operators;
+    whatever the fixed-point details (which only a real OpenCV can pin), the oracle's restatement must stay within one grey level of the
+    operator's definition: bilinear interpolation at source coordinate (d + 0.5) * src / dst - 0.5 with edge replication, and the
+    convolution with the normalised 7-tap Gaussian (4.5.1 taps / 256; the 4.5.0 taps sum to 257 / 256: + 0.8 % gain)."""
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:97, 0:131]
+    img = np.clip(100 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.integers(-20, 21, xx.shape), 0, 255).astype(np.uint8)
+    for dw, dh in ((109, 81), (131, 97), (66, 49)):
+        out = orc.resize_linear(img, dw, dh).astype(np.float64)
+        sx = np.clip((np.arange(dw) + 0.5) * (img.shape[1] / dw) - 0.5, 0, img.shape[1] - 1)
+        sy = np.clip((np.arange(dh) + 0.5) * (img.shape[0] / dh) - 0.5, 0, img.shape[0] - 1)
+        x0 = np.floor(sx).astype(int); x1 = np.minimum(x0 + 1, img.shape[1] - 1); fx = sx - x0
+        y0 = np.floor(sy).astype(int); y1 = np.minimum(y0 + 1, img.shape[0] - 1); fy = sy - y0
+        I = img.astype(np.float64)
+        want = ((I[np.ix_(y0, x0)] * (1 - fx) + I[np.ix_(y0, x1)] * fx) * (1 - fy)[:, None] + (I[np.ix_(y1, x0)] * (1 - fx) + I[np.ix_(y1, x1)] * fx) * fy[:, None])
+        assert np.abs(out - want).max() <= 1.0, (dw, dh, np.abs(out - want).max())
+    for variant, taps in ((1, [18, 34, 48, 56, 48, 34, 18]), (0, [18, 34, 49, 55, 49, 34, 18])):
+        out = orc.gaussian_blur7(img, variant).astype(np.float64)
+        k = np.array(taps, np.float64) / 256.0
+        pad = np.pad(img.astype(np.float64), 3, mode="reflect")  # numpy "reflect" = BORDER_REFLECT_101
+        tmp = sum(k[i] * pad[:, i:i + img.shape[1]] for i in range(7))
+        want = sum(k[i] * tmp[i:i + img.shape[0], :] for i in range(7))
+        assert np.abs(out - np.minimum(want, 255.0)).max() <= 1.0, (variant, np.abs(out - want).max())
