@@ -228,3 +228,21 @@ def test_global_resolve_kernel_in_subprocess(pkg):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+@pytest.mark.parametrize("top", ["0", "1", "2"])
+def test_resolve_list_heads_in_subprocess(pkg, top):
+    """k_sbp_candidates puts the 8 entries with the smallest (distance, list position) in front of every candidate list and a round of
+    k_sbp_resolve reads only those, walking the list itself when they do not decide (all of them taken; map-point variant: no second
+    best among them).  ORBX_SBP_TOPK (read once per process) shortens the head a round looks at to 0, 1 or 2 entries, so that the walk
+    behind an undecided head runs for most points: this file's parity tests once more under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ORBX_SBP_TOPK") or os.environ.get("ORBX_SBP_RESOLVE_GLOBAL"):
+        pytest.skip("already a forced run")
+    env = dict(os.environ, ORBX_SBP_TOPK=top)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not subprocess"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]

@@ -1786,6 +1786,10 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
 //                     chains are short in practice (a conflict needs two points that want the same keypoint).
 // =====================================================================================================
 #define SBP_CAP 512  // candidates kept per projected point (more -> the call reports a capacity error)
+#define SBP_TOPK 8   // the candidates with the smallest (distance, list position) of a point, sorted, in front of its list
+#define SBP_ROW (SBP_TOPK + SBP_CAP)  // entries per point: [SBP_TOPK sorted | the list in GetFeaturesInArea order]; == ORBX_SBP_ROW
+#define SBP_NONE 0xFFFFFFFFu
+static_assert(SBP_CAP == ORBX_SBP_CAP && SBP_ROW == ORBX_SBP_ROW, "candidate buffer layout");
 
 struct SbpProj { float u, v, invz, angle; int octave, flags; };
 
@@ -1799,7 +1803,7 @@ struct SbpArgs {
     int mode;        // 0: SearchByProjection(Frame, Frame); 1: SearchByProjection(Frame, vector<MapPoint*>) - then SbpProj holds
                      //    u, v = mTrackProjX / Y, invz = mTrackProjXR, angle = mTrackViewCos, octave = mnTrackScaleLevel
     float nnratio;
-    uint32_t *cand;  // [np][SBP_CAP] index | dist << 16 | octave << 25
+    uint32_t *cand;  // [np][SBP_ROW] index | dist << 16 | octave << 25
     int *count;      // [np] list length, -1: point not searched
     int *choice;     // [np] work
     int *owner;      // [2][nc] work
@@ -1815,6 +1819,7 @@ struct SbpArgs {
     const int *partner;               // [nc] mvLeftToRightMatch / mvRightToLeftMatch as combined indices, -1 none; NULL in mode 0
     int *head, *next;                 // [nc], [2 np] work of k_sbp_resolve_fe: writers of a keypoint as linked lists
     int ncBase;                       // batch of fisheye frames: keypoints of frame p = ncBase (the left capacity) + ncDev[p] right ones
+    int topUse;                       // k_sbp_resolve: entries of a list's sorted head a round looks at (ORBX_SBP_TOPK; tests: 0 - 2)
 };
 
 // frame p of a batch: every per-frame array advances by its stride, the counts come from the device arrays
@@ -1827,7 +1832,7 @@ __device__ __forceinline__ void sbp_select_frame(SbpArgs &a, size_t p)
     if (a.curState) a.curState += p * a.kcStride;
     a.cellStart += p * (GRID_CELLS + 1); a.items += p * a.kcStride;
     a.proj += p * a.projStride; a.dproj += p * (a.nLeft >= 0 ? a.projStride / 2 : a.projStride) * 32;  // (fisheye: two steps, one descriptor per point)
-    a.cand += p * a.projStride * SBP_CAP; a.count += p * a.projStride; a.choice += p * a.projStride;
+    a.cand += p * a.projStride * SBP_ROW; a.count += p * a.projStride; a.choice += p * a.projStride;
     if (a.owner) a.owner += p * 2 * a.kcStride;
     a.assign += p * a.kcStride; a.result += p * 2;
     if (a.cellStartR) { a.cellStartR += p * (GRID_CELLS + 1); a.itemsR += p * a.kcStride; }
@@ -1875,8 +1880,13 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.dproj + (size_t)(fe ? i >> 1 : i) * 32))[w];
     const float ur = a.mode == 0 ? __fsub_rn(x, __fmul_rn(a.mbf, P.invz)) : P.invz;  // mode 1: mTrackProjXR
     const int ny = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny;
-    uint32_t *out = a.cand + (size_t)i * SBP_CAP;
+    uint32_t *top = a.cand + (size_t)i * SBP_ROW, *out = top + SBP_TOPK;
     __shared__ int stage[1024];  // keypoints of up to 64 cells in the reference's order, then filtered with ballots
+    __shared__ uint32_t kept[SBP_CAP];  // the list once more, for the selection of its SBP_TOPK smallest entries
+    // A keypoint that held a map point with observations before the call is skipped by every point in every round (:338-340, src/
+    // ORBmatcher1.cc:96-98): it never enters the list.  (Not so on a fisheye frame, where a later step can hand such a keypoint to a
+    // point without observations: k_sbp_resolve_fe looks at the holder of the moment.)
+    const bool dropHeld = !fe && a.curState != nullptr;
     int nOut = 0;
     bool overflow = false;
     for (int cb = 0; cb < nCells; cb += 64) {  // cells in (ix outer, iy inner) order
@@ -1909,6 +1919,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
                     const float urc = a.uRight[i2];
                     if (urc > 0 && fabsf(__fsub_rn(ur, urc)) > r) keep = false;
                 }
+                if (keep && dropHeld && a.curState[i2] > 0) keep = false;
                 if (keep) {
                     const uint32_t *t = (const uint32_t *)(a.dc + (size_t)i2 * 32);
 #pragma unroll
@@ -1918,7 +1929,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
             const unsigned long long m = __ballot(keep);
             const int pos = nOut + __popcll(m & ((1ull << lane) - 1ull));
             if (keep) {
-                if (pos < SBP_CAP) out[pos] = (uint32_t)(i2 + base) | ((uint32_t)dist << 16) | ((uint32_t)oct << 25);
+                if (pos < SBP_CAP) out[pos] = kept[pos] = (uint32_t)(i2 + base) | ((uint32_t)dist << 16) | ((uint32_t)oct << 25);
                 else overflow = true;
             }
             nOut += __popcll(m);
@@ -1927,11 +1938,43 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     }
     if (__ballot(overflow) || nOut > SBP_CAP) { if (lane == 0) { *cnt = 0; atomicExch(&a.result[1], 1); } return; }
     if (lane == 0) *cnt = nOut;
+    // The resolve rounds take, per point, the first minimum of the list among the keypoints nobody blocks (and the second smallest
+    // distance): in the order (distance, list position) that is the first (and second) entry not blocked.  The SBP_TOPK smallest
+    // entries in that order go in front of the list; a round then reads them instead of walking the list.
+    __syncthreads();
+    if (nOut <= 64) {
+        // (the usual case) one entry per lane: its rank among the keys = number of smaller ones, counted with the keys of the other
+        // lanes broadcast one by one (v_readlane with a uniform index: no LDS round trips)
+        const uint32_t e = lane < nOut ? kept[lane] : 0u;
+        const uint32_t key = lane < nOut ? (((e >> 16) & 0x1FFu) << 9) | (uint32_t)lane : SBP_NONE;
+        int rank = 0;
+        for (int j = 0; j < nOut; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key ? 1 : 0;
+        if (lane < nOut && rank < SBP_TOPK) top[rank] = e;
+        if (lane >= nOut && lane < SBP_TOPK) top[lane] = SBP_NONE;
+        return;
+    }
+    uint32_t last = 0;
+    for (int k = 0; k < SBP_TOPK; ++k) {  // the k-th smallest key (distinct: the position is part of it)
+        uint32_t mn = SBP_NONE;
+        for (int j = lane; j < nOut; j += 64) {
+            const uint32_t v = (((kept[j] >> 16) & 0x1FFu) << 9) | (uint32_t)j;
+            if ((k == 0 || v > last) && v < mn) mn = v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        if (mn == SBP_NONE) {
+            if (lane >= k && lane < SBP_TOPK) top[lane] = SBP_NONE;
+            break;
+        }
+        if (lane == 0) top[k] = kept[mn & 511u];
+        last = mn;
+    }
 }
 
-// LDS: the owner arrays and the "holds a map point with observations" flags of the current frame's keypoints live in LDS (ldsNc entries
-// each; frames of up to SBP_LDS_NC keypoints) - a thread walks its candidate list with two dependent reads per entry, and from global
-// memory that was 95 us of a 156 us tracking step
+// LDS: the owner arrays of the current frame's keypoints live in LDS (ldsNc entries each; frames of up to SBP_LDS_NC keypoints).  A
+// round reads, per point, the SBP_TOPK sorted entries k_sbp_candidates put in front of its list - from registers for the first two
+// points of a thread (frames of up to 2048 points), loaded once - and walks the list itself only when those do not decide: walking the
+// lists in every round (a chain of global loads per point) made a single frame's resolve 80 - 220 us, 70 % of the call.
 #define SBP_LDS_NC 12288
 template <bool LDS>
 __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc)
@@ -1942,34 +1985,78 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc)
     const int tid = threadIdx.x;
     __shared__ int changed, hist[32], nAcc;
     int *own = LDS ? sbpL : a.owner, *ownNew = LDS ? sbpL + ldsNc : a.owner + a.nc;
-    signed char *heldL = (signed char *)(sbpL + 2 * ldsNc);
-    if (LDS)
-        for (int i = tid; i < a.nc; i += 1024) heldL[i] = a.curState ? (a.curState[i] > 0 ? 1 : 0) : 0;
     for (int i = tid; i < a.nc; i += 1024) { own[i] = INT_MAX; a.assign[i] = -1; }
     if (tid < 32) hist[tid] = 0;
     if (tid == 0) nAcc = 0;
+    // what a round needs of point i: list length, the "has observations" flag, the sorted head of the list
+    struct Head { int n, obs; uint32_t e[SBP_TOPK]; };
+    auto loadHead = [&](int i, Head &h) {
+        h.n = a.count[i]; h.obs = (a.proj[i].flags & 2) != 0;
+        if (h.n > 0) {
+            const uint4 *t = (const uint4 *)(a.cand + (size_t)i * SBP_ROW);
+            const uint4 t0 = t[0], t1 = t[1];
+            h.e[0] = t0.x; h.e[1] = t0.y; h.e[2] = t0.z; h.e[3] = t0.w; h.e[4] = t1.x; h.e[5] = t1.y; h.e[6] = t1.z; h.e[7] = t1.w;
+        }
+    };
+    // the choice of point i against the owners of the previous round
+    auto choose = [&](int i, const Head &h) {
+        if (h.n <= 0) return -1;
+        int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1, found = 0;
+        const int K = min(h.n, a.topUse);
+#pragma unroll
+        for (int k = 0; k < SBP_TOPK; ++k) {
+            if (k >= K) break;
+            const uint32_t e = h.e[k];
+            const int i2 = e & 0xFFFF;
+            if (found >= 2 || own[i2] < i) continue;  // taken by an earlier point with observations
+            if (found == 0) { best = (e >> 16) & 0x1FF; bestL = e >> 25; bestI = i2; }
+            else { best2 = (e >> 16) & 0x1FF; bestL2 = e >> 25; }
+            ++found;
+        }
+        const bool complete = h.n <= a.topUse;
+        // decided by the head: the best is known and (frame variant, or a best above TH_HIGH) nothing else matters, or the second is known too
+        const bool decided = found >= 2 || complete || (found == 1 && (a.mode == 0 || best > TH_HIGH));
+        if (!decided) {
+            best = 256; bestI = -1; best2 = 256; bestL = -1; bestL2 = -1;
+            const uint32_t *lst = a.cand + (size_t)i * SBP_ROW + SBP_TOPK;
+            for (int c = 0; c < h.n; ++c) {
+                const uint32_t e = lst[c];
+                const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
+                if (own[i2] < i) continue;
+                if (dist < best) { best2 = best; bestL2 = bestL; best = dist; bestL = lv; bestI = i2; }
+                else if (dist < best2) { best2 = dist; bestL2 = lv; }
+            }
+        }
+        int ch = best <= TH_HIGH ? bestI : -1;
+        // map-point variant: ratio to the second match, only if best and second are in the same scale level (:122-129)
+        if (a.mode == 1 && ch >= 0 && bestL == bestL2 && (float)best > __fmul_rn(a.nnratio, (float)best2)) ch = -1;
+        return ch;
+    };
+    Head h0, h1;
+    h0.n = -1; h1.n = -1; h0.obs = 0; h1.obs = 0;
+    if (tid < a.np) loadHead(tid, h0);
+    if (tid + 1024 < a.np) loadHead(tid + 1024, h1);
     __syncthreads();
     for (int round = 0; round <= a.np + 1; ++round) {
         for (int i = tid; i < a.nc; i += 1024) ownNew[i] = INT_MAX;
         if (tid == 0) changed = 0;
         __syncthreads();
-        for (int i = tid; i < a.np; i += 1024) {
-            const int n = a.count[i];
-            int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1;
-            const uint32_t *lst = a.cand + (size_t)i * SBP_CAP;
-            for (int c = 0; c < n; ++c) {
-                const uint32_t e = lst[c];
-                const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
-                const bool held = LDS ? heldL[i2] != 0 : (a.curState && a.curState[i2] > 0);
-                if (held || own[i2] < i) continue;  // mvpMapPoints[i2]->Observations() > 0: before the call / taken earlier
-                if (dist < best) { best2 = best; bestL2 = bestL; best = dist; bestL = lv; bestI = i2; }
-                else if (dist < best2) { best2 = dist; bestL2 = lv; }
-            }
-            int ch = best <= TH_HIGH ? bestI : -1;
-            // map-point variant: ratio to the second match, only if best and second are in the same scale level (:122-129)
-            if (a.mode == 1 && ch >= 0 && bestL == bestL2 && (float)best > __fmul_rn(a.nnratio, (float)best2)) ch = -1;
+        if (tid < a.np) {
+            const int ch = choose(tid, h0);
+            a.choice[tid] = ch;
+            if (ch >= 0 && h0.obs) atomicMin(&ownNew[ch], tid);
+        }
+        if (tid + 1024 < a.np) {
+            const int ch = choose(tid + 1024, h1);
+            a.choice[tid + 1024] = ch;
+            if (ch >= 0 && h1.obs) atomicMin(&ownNew[ch], tid + 1024);
+        }
+        for (int i = tid + 2048; i < a.np; i += 1024) {
+            Head h;
+            loadHead(i, h);
+            const int ch = choose(i, h);
             a.choice[i] = ch;
-            if (ch >= 0 && (a.proj[i].flags & 2)) atomicMin(&ownNew[ch], i);
+            if (ch >= 0 && h.obs) atomicMin(&ownNew[ch], i);
         }
         __syncthreads();
         for (int i = tid; i < a.nc; i += 1024)
@@ -2049,7 +2136,7 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve_fe(SbpArgs a)
                 if (side == 0 && a.mode == 0 && n <= 0) skipRight = true;  // the left part's `continue`s leave the right part out
                 if (n > 0 && !(side && skipRight)) {
                     int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1;
-                    const uint32_t *lst = a.cand + (size_t)s * SBP_CAP;
+                    const uint32_t *lst = a.cand + (size_t)s * SBP_ROW + SBP_TOPK;
                     for (int c = 0; c < n; ++c) {
                         const uint32_t e = lst[c];
                         const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
@@ -2179,7 +2266,7 @@ hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFish
     a.scale = f.scale; a.mbf = 0.f; a.proj = (const SbpProj *)f.steps; a.dproj = f.dproj; a.np = 2 * f.np;
     a.th = f.th; a.forward = f.forward; a.backward = f.backward; a.checkOri = f.checkOri;
     a.cand = f.cand; a.count = f.count; a.choice = f.choice; a.owner = nullptr; a.assign = f.assign; a.result = f.result;
-    a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next;
+    a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next; a.topUse = 0;
     hipError_t e = hipMemsetAsync(f.result, 0, 2 * sizeof(int) * (size_t)nframes, st);
     if (e != hipSuccess) return e;
     if (f.np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(2 * f.np, nframes), dim3(64), 0, st, a);
@@ -2208,20 +2295,22 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
     a.th = th; a.forward = forward; a.backward = backward; a.checkOri = checkOri;
     a.cand = cand; a.count = count; a.choice = choice; a.owner = owner; a.assign = assign; a.result = result;
     a.nLeft = -1; a.cellStartR = nullptr; a.itemsR = nullptr; a.partner = nullptr; a.head = nullptr; a.next = nullptr;
+    static const int topUse = [] { const char *e = getenv("ORBX_SBP_TOPK"); return e ? std::min(std::max(atoi(e), 0), SBP_TOPK) : SBP_TOPK; }();
+    a.topUse = topUse;
     hipError_t e = hipMemsetAsync(result, 0, (size_t)nframes * 2 * sizeof(int), st);
     if (e != hipSuccess) return e;
     if (np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(np, nframes), dim3(64), 0, st, a);
     static const bool forceGlobal = getenv("ORBX_SBP_RESOLVE_GLOBAL") != nullptr;  // tests: the variant for frames beyond SBP_LDS_NC keypoints
     if (a.nc <= SBP_LDS_NC && !forceGlobal) {
         const int ldsNc = (a.nc + 3) & ~3;
-        const size_t lds = (size_t)ldsNc * 9 + 16;
+        const size_t lds = (size_t)ldsNc * 8 + 16;
         static size_t attrBytes[64] = {};  // per device
         int devId = 0;
         (void)hipGetDevice(&devId);
         if (lds > attrBytes[devId & 63]) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_sbp_resolve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SBP_LDS_NC * 9 + 16));
+            const hipError_t e = hipFuncSetAttribute((const void *)k_sbp_resolve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SBP_LDS_NC * 8 + 16));
             if (e != hipSuccess) return e;
-            attrBytes[devId & 63] = (size_t)SBP_LDS_NC * 9 + 16;
+            attrBytes[devId & 63] = (size_t)SBP_LDS_NC * 8 + 16;
         }
         hipLaunchKernelGGL(k_sbp_resolve<true>, dim3(nframes), dim3(1024), lds, st, a, ldsNc);
     } else {
