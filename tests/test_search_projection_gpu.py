@@ -216,8 +216,8 @@ def test_search_by_projection_points_frames_batch(pkg, orc):
 
 
 def test_global_resolve_kernel_in_subprocess(pkg):
-    """k_sbp_resolve keeps the owner arrays of frames up to 12288 keypoints in LDS and works on global memory beyond;
-    ORBX_SBP_RESOLVE_GLOBAL (read once per process) forces the global variant: run this file's parity tests once more under it."""
+    """k_sbp_resolve keeps the owner arrays and the per-point state of frames up to 12288 keypoints in LDS; larger frames go through
+    k_sbp_resolve_walk (global memory).  ORBX_SBP_RESOLVE_GLOBAL (read once per process) forces it: this file's parity tests once more."""
     import os
     import subprocess
     import sys
@@ -230,18 +230,17 @@ def test_global_resolve_kernel_in_subprocess(pkg):
     assert out.returncode == 0, out.stdout[-3000:]
 
 
-@pytest.mark.parametrize("top", ["0", "1", "2"])
-def test_resolve_list_heads_in_subprocess(pkg, top):
-    """k_sbp_candidates puts the 8 entries with the smallest (distance, list position) in front of every candidate list and a round of
-    k_sbp_resolve reads only those, walking the list itself when they do not decide (all of them taken; map-point variant: no second
-    best among them).  ORBX_SBP_TOPK (read once per process) shortens the head a round looks at to 0, 1 or 2 entries, so that the walk
-    behind an undecided head runs for most points: this file's parity tests once more under it."""
+@pytest.mark.parametrize("entries", ["0", "4"])
+def test_resolve_list_entries_in_lds_in_subprocess(pkg, entries):
+    """k_sbp_resolve keeps the first 8 entries of a point's sorted candidate list in registers, the next (up to 24) in LDS, and walks on
+    in global memory behind them.  ORBX_SBP_LIST_LDS (read once per process) shortens the LDS part to 0 or 4 entries, so that the walk
+    crosses both borders for many points: this file's parity tests once more under it."""
     import os
     import subprocess
     import sys
-    if os.environ.get("ORBX_SBP_TOPK") or os.environ.get("ORBX_SBP_RESOLVE_GLOBAL"):
+    if os.environ.get("ORBX_SBP_LIST_LDS") or os.environ.get("ORBX_SBP_RESOLVE_GLOBAL"):
         pytest.skip("already a forced run")
-    env = dict(os.environ, ORBX_SBP_TOPK=top)
+    env = dict(os.environ, ORBX_SBP_LIST_LDS=entries)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not subprocess"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

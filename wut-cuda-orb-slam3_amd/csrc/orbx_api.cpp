@@ -1736,7 +1736,7 @@ struct orbx_matcher {
     DevBuf<int> d_grid, d_work;   // frame grid (cellStart + items + cellOf), SearchForInitialization state
     DevBuf<float> d_prev;
     DevBuf<signed char> d_bin;
-    DevBuf<uint32_t> d_sbpCand;   // SearchByProjection: candidate lists [maxQ][ORBX_SBP_ROW]
+    DevBuf<uint32_t> d_sbpCand;   // SearchByProjection: candidate lists [maxQ][ORBX_SBP_CAP]
     DevBuf<uint8_t> d_siWork;     // SearchForInitialization: octave-0 subset of F2 and the shortest candidates of every F1 keypoint
     DevBuf<orbx_projection> d_proj;
 };
@@ -2429,7 +2429,7 @@ static int searchByProjectionImpl(orbx_matcher *m, const orbx_keypoint *kc, cons
     // work: count[maxQ], choice[maxQ], owner[2 * maxT], assign[maxT], result[2], curState (maxT bytes, int-aligned)
     const size_t workInts = 2 * (size_t)m->maxQ + 3 * (size_t)m->maxT + 2 + ((size_t)m->maxT + 3) / 4 + 4;
     if ((rc = m->d_work.ensure(workInts)) != ORBX_OK) return rc;
-    if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_ROW)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_CAP)) != ORBX_OK) return rc;
     if ((rc = m->d_proj.ensure((size_t)m->maxQ)) != ORBX_OK) return rc;
     if ((rc = m->d_prev.ensure(2 * (size_t)std::max(m->maxQ, m->maxT))) != ORBX_OK) return rc;
     int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
@@ -2523,7 +2523,7 @@ static int searchByProjectionFisheyeImpl(const char *fn, orbx_matcher *m, const 
     // work: count[maxQ], choice[maxQ], next[2 maxQ], head[maxT], partner[maxT], assign[maxT], result[2], curState (maxT bytes)
     const size_t workInts = 4 * (size_t)m->maxQ + 3 * (size_t)m->maxT + 2 + ((size_t)m->maxT + 3) / 4 + 4;
     if ((rc = m->d_work.ensure(workInts)) != ORBX_OK) return rc;
-    if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_ROW)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_CAP)) != ORBX_OK) return rc;
     if ((rc = m->d_proj.ensure((size_t)m->maxQ)) != ORBX_OK) return rc;
     int *csL = m->d_grid.p, *itL = csL + ORBX_GRID_CELLS + 1, *coL = itL + m->maxT;
     int *csR = m->d_grid.p + gridInts, *itR = csR + ORBX_GRID_CELLS + 1, *coR = itR + m->maxT;
@@ -2758,7 +2758,7 @@ static int searchByProjectionFramesImpl(const char *fn, int mode, float nnratio,
     if ((rc = m->d_grid.ensure(F * ((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)cap))) != ORBX_OK) return rc;
     const size_t workInts = F * (2 * (size_t)std::max(max_np, 1) + 2 * (size_t)cap + 2);
     if ((rc = m->d_work.ensure(workInts)) != ORBX_OK) return rc;
-    if ((rc = m->d_sbpCand.ensure(F * (size_t)std::max(max_np, 1) * ORBX_SBP_ROW)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure(F * (size_t)std::max(max_np, 1) * ORBX_SBP_CAP)) != ORBX_OK) return rc;
     int *cs = m->d_grid.p, *it = cs + F * (ORBX_GRID_CELLS + 1), *co = it + F * cap;
     int *count = m->d_work.p, *choice = count + F * std::max(max_np, 1), *owner = choice + F * std::max(max_np, 1), *result = owner + F * 2 * cap;
     if ((rc = orderAfterExtractors(m, ex, ex)) != ORBX_OK) return rc;
@@ -2811,7 +2811,7 @@ static int searchByProjectionFisheyeFramesImpl(const char *fn, int mode, float n
     if ((rc = m->d_grid.ensure(2 * F * gridInts + 4 * F * capC)) != ORBX_OK) return rc;
     // work: count[2 NP], choice[2 NP], next[4 NP] per frame; head[capC], partner[capC] per frame; result[2] per frame
     if ((rc = m->d_work.ensure(F * (8 * NP + 2 * (size_t)capC + 2) + 64)) != ORBX_OK) return rc;
-    if ((rc = m->d_sbpCand.ensure(F * 2 * NP * ORBX_SBP_ROW)) != ORBX_OK) return rc;
+    if ((rc = m->d_sbpCand.ensure(F * 2 * NP * ORBX_SBP_CAP)) != ORBX_OK) return rc;
     if ((rc = m->d_proj.ensure(F * 2 * NP)) != ORBX_OK) return rc;
     int *csL = m->d_grid.p, *csR = csL + F * gridInts, *itL = csR + F * gridInts, *itR = itL + F * capC, *coL = itR + F * capC, *coR = coL + F * capC;
     int *count = m->d_work.p, *choice = count + F * 2 * NP, *next = choice + F * 2 * NP, *head = next + F * 4 * NP, *dPartner = head + F * capC,

@@ -243,7 +243,6 @@ hipError_t orbxLaunchGatherResults(hipStream_t st, const int *result, int n, int
 // a batch of frames through the SearchByProjection kernels: per-frame strides (records) and device-side counts
 struct OrbxSbpBatch { int nframes; long long kcStride, projStride; const int *ncDev, *npDev; };
 #define ORBX_SBP_CAP 512  // == SBP_CAP in orbx_match.hip
-#define ORBX_SBP_ROW 520  // == SBP_ROW: entries per point of the candidate buffer (the sorted head of a list + the list)
 // the CurrentFrame.Nleft != -1 (fisheye rig) branches: kc / dc = left then right keypoints, one grid per side, steps[2 np] = the left and
 // right record of every point interleaved, dproj[np]; partner[nLeft + nRight] (mode 1) or NULL
 struct OrbxSbpFisheye {

@@ -1786,10 +1786,7 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
 //                     chains are short in practice (a conflict needs two points that want the same keypoint).
 // =====================================================================================================
 #define SBP_CAP 512  // candidates kept per projected point (more -> the call reports a capacity error)
-#define SBP_TOPK 8   // the candidates with the smallest (distance, list position) of a point, sorted, in front of its list
-#define SBP_ROW (SBP_TOPK + SBP_CAP)  // entries per point: [SBP_TOPK sorted | the list in GetFeaturesInArea order]; == ORBX_SBP_ROW
-#define SBP_NONE 0xFFFFFFFFu
-static_assert(SBP_CAP == ORBX_SBP_CAP && SBP_ROW == ORBX_SBP_ROW, "candidate buffer layout");
+static_assert(SBP_CAP == ORBX_SBP_CAP, "candidate buffer layout");
 
 struct SbpProj { float u, v, invz, angle; int octave, flags; };
 
@@ -1803,7 +1800,7 @@ struct SbpArgs {
     int mode;        // 0: SearchByProjection(Frame, Frame); 1: SearchByProjection(Frame, vector<MapPoint*>) - then SbpProj holds
                      //    u, v = mTrackProjX / Y, invz = mTrackProjXR, angle = mTrackViewCos, octave = mnTrackScaleLevel
     float nnratio;
-    uint32_t *cand;  // [np][SBP_ROW] index | dist << 16 | octave << 25
+    uint32_t *cand;  // [np][SBP_CAP] index | dist << 16 | octave << 25, sorted by (dist, position in GetFeaturesInArea order)
     int *count;      // [np] list length, -1: point not searched
     int *choice;     // [np] work
     int *owner;      // [2][nc] work
@@ -1819,7 +1816,6 @@ struct SbpArgs {
     const int *partner;               // [nc] mvLeftToRightMatch / mvRightToLeftMatch as combined indices, -1 none; NULL in mode 0
     int *head, *next;                 // [nc], [2 np] work of k_sbp_resolve_fe: writers of a keypoint as linked lists
     int ncBase;                       // batch of fisheye frames: keypoints of frame p = ncBase (the left capacity) + ncDev[p] right ones
-    int topUse;                       // k_sbp_resolve: entries of a list's sorted head a round looks at (ORBX_SBP_TOPK; tests: 0 - 2)
 };
 
 // frame p of a batch: every per-frame array advances by its stride, the counts come from the device arrays
@@ -1832,7 +1828,7 @@ __device__ __forceinline__ void sbp_select_frame(SbpArgs &a, size_t p)
     if (a.curState) a.curState += p * a.kcStride;
     a.cellStart += p * (GRID_CELLS + 1); a.items += p * a.kcStride;
     a.proj += p * a.projStride; a.dproj += p * (a.nLeft >= 0 ? a.projStride / 2 : a.projStride) * 32;  // (fisheye: two steps, one descriptor per point)
-    a.cand += p * a.projStride * SBP_ROW; a.count += p * a.projStride; a.choice += p * a.projStride;
+    a.cand += p * a.projStride * SBP_CAP; a.count += p * a.projStride; a.choice += p * a.projStride;
     if (a.owner) a.owner += p * 2 * a.kcStride;
     a.assign += p * a.kcStride; a.result += p * 2;
     if (a.cellStartR) { a.cellStartR += p * (GRID_CELLS + 1); a.itemsR += p * a.kcStride; }
@@ -1880,9 +1876,9 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.dproj + (size_t)(fe ? i >> 1 : i) * 32))[w];
     const float ur = a.mode == 0 ? __fsub_rn(x, __fmul_rn(a.mbf, P.invz)) : P.invz;  // mode 1: mTrackProjXR
     const int ny = cy1 - cy0 + 1, nCells = (cx1 - cx0 + 1) * ny;
-    uint32_t *top = a.cand + (size_t)i * SBP_ROW, *out = top + SBP_TOPK;
+    uint32_t *out = a.cand + (size_t)i * SBP_CAP;
     __shared__ int stage[1024];  // keypoints of up to 64 cells in the reference's order, then filtered with ballots
-    __shared__ uint32_t kept[SBP_CAP];  // the list once more, for the selection of its SBP_TOPK smallest entries
+    __shared__ uint32_t kept[SBP_CAP];  // the list in the reference's order; it leaves sorted
     // A keypoint that held a map point with observations before the call is skipped by every point in every round (:338-340, src/
     // ORBmatcher1.cc:96-98): it never enters the list.  (Not so on a fisheye frame, where a later step can hand such a keypoint to a
     // point without observations: k_sbp_resolve_fe looks at the holder of the moment.)
@@ -1929,7 +1925,7 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
             const unsigned long long m = __ballot(keep);
             const int pos = nOut + __popcll(m & ((1ull << lane) - 1ull));
             if (keep) {
-                if (pos < SBP_CAP) out[pos] = kept[pos] = (uint32_t)(i2 + base) | ((uint32_t)dist << 16) | ((uint32_t)oct << 25);
+                if (pos < SBP_CAP) kept[pos] = (uint32_t)(i2 + base) | ((uint32_t)dist << 16) | ((uint32_t)oct << 25);
                 else overflow = true;
             }
             nOut += __popcll(m);
@@ -1939,149 +1935,105 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
     if (__ballot(overflow) || nOut > SBP_CAP) { if (lane == 0) { *cnt = 0; atomicExch(&a.result[1], 1); } return; }
     if (lane == 0) *cnt = nOut;
     // The resolve rounds take, per point, the first minimum of the list among the keypoints nobody blocks (and the second smallest
-    // distance): in the order (distance, list position) that is the first (and second) entry not blocked.  The SBP_TOPK smallest
-    // entries in that order go in front of the list; a round then reads them instead of walking the list.
+    // distance): in the order (distance, list position) that is the first (and second) entry not blocked - the sequential rule
+    // `dist < best .. else dist < best2` over any order of the candidates gives exactly those two.  So the list leaves SORTED by
+    // (distance, position): a round looks at its head and walks on only while entries are blocked.  Rank of an entry = number of
+    // smaller keys (distinct: the position is part of the key).
     __syncthreads();
     if (nOut <= 64) {
-        // (the usual case) one entry per lane: its rank among the keys = number of smaller ones, counted with the keys of the other
-        // lanes broadcast one by one (v_readlane with a uniform index: no LDS round trips)
+        // (the usual case) one entry per lane, the keys of the other lanes broadcast one by one (v_readlane with a uniform index)
         const uint32_t e = lane < nOut ? kept[lane] : 0u;
-        const uint32_t key = lane < nOut ? (((e >> 16) & 0x1FFu) << 9) | (uint32_t)lane : SBP_NONE;
+        const uint32_t key = lane < nOut ? (((e >> 16) & 0x1FFu) << 9) | (uint32_t)lane : 0xFFFFFFFFu;
         int rank = 0;
         for (int j = 0; j < nOut; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)key, j) < key ? 1 : 0;
-        if (lane < nOut && rank < SBP_TOPK) top[rank] = e;
-        if (lane >= nOut && lane < SBP_TOPK) top[lane] = SBP_NONE;
-        return;
-    }
-    uint32_t last = 0;
-    for (int k = 0; k < SBP_TOPK; ++k) {  // the k-th smallest key (distinct: the position is part of it)
-        uint32_t mn = SBP_NONE;
-        for (int j = lane; j < nOut; j += 64) {
-            const uint32_t v = (((kept[j] >> 16) & 0x1FFu) << 9) | (uint32_t)j;
-            if ((k == 0 || v > last) && v < mn) mn = v;
+        if (lane < nOut) out[rank] = e;
+    } else {
+        for (int u = lane; u < nOut; u += 64) {
+            const uint32_t e = kept[u];
+            const uint32_t key = (((e >> 16) & 0x1FFu) << 9) | (uint32_t)u;
+            int rank = 0;
+            for (int j = 0; j < nOut; ++j) rank += ((((kept[j] >> 16) & 0x1FFu) << 9) | (uint32_t)j) < key ? 1 : 0;
+            out[rank] = e;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-        if (mn == SBP_NONE) {
-            if (lane >= k && lane < SBP_TOPK) top[lane] = SBP_NONE;
-            break;
-        }
-        if (lane == 0) top[k] = kept[mn & 511u];
-        last = mn;
     }
+    // (entries behind the list are never read: a round clamps its head to the list length)
 }
 
-// LDS: the owner arrays of the current frame's keypoints live in LDS (ldsNc entries each; frames of up to SBP_LDS_NC keypoints).  A
-// round reads, per point, the SBP_TOPK sorted entries k_sbp_candidates put in front of its list - from registers for the first two
-// points of a thread (frames of up to 2048 points), loaded once - and walks the list itself only when those do not decide: walking the
-// lists in every round (a chain of global loads per point) made a single frame's resolve 80 - 220 us, 70 % of the call.
+// ---- the resolve rounds -------------------------------------------------------------------------------------------------------------
+// One workgroup per frame.  A point's choice in a round is a function of the owners (of the round before) of the list entries it LOOKS
+// AT: it walks its sorted list and stops at the first entry that settles the outcome - the first one nobody earlier holds (frame
+// variant), the second such one (map-point variant: best and second best), or, whatever is blocked, the first entry that cannot
+// change the outcome any more: before a best is found, one beyond TH_HIGH (every later best would be rejected, :343 / src/
+// ORBmatcher1.cc:131); behind the best of the map-point variant, one so far away that the ratio test (:122-129) passes against it and
+// all later ones.  Points without a real match (lists of random descriptors whose keypoints their real partners hold) end there
+// instead of walking everything in every round.  What a round touches is in registers and LDS: the first 8 entries of the lists of a
+// thread's first two points (frames of up to 2048 points) are loaded once, the next (up to 24) entries of every list and both owner
+// arrays live in LDS; two barriers per round.  A single frame's resolve took 80 - 220 us with every point walking its list (in
+// GetFeaturesInArea order: always to the end) from global memory in every round; it is 1024 threads of ONE CU, so a round costs its
+// dependent instruction chain.  Measured alternatives (tools/experiments/sbp_timing.py): a compacted work list of the points one of whose
+// looked-at keypoints changed its owner evaluates 12 x fewer points and is slower (five barriers and a scan of all points per round).
+// Owner arrays hold point << 1 (SBP_FREE = nobody).
 #define SBP_LDS_NC 12288
-template <bool LDS>
-__global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc)
-{
-    const int TH_HIGH = 100, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
-    extern __shared__ int sbpL[];
-    sbp_select_frame(a, blockIdx.x);
-    const int tid = threadIdx.x;
-    __shared__ int changed, hist[32], nAcc;
-    int *own = LDS ? sbpL : a.owner, *ownNew = LDS ? sbpL + ldsNc : a.owner + a.nc;
-    for (int i = tid; i < a.nc; i += 1024) { own[i] = INT_MAX; a.assign[i] = -1; }
-    if (tid < 32) hist[tid] = 0;
-    if (tid == 0) nAcc = 0;
-    // what a round needs of point i: list length, the "has observations" flag, the sorted head of the list
-    struct Head { int n, obs; uint32_t e[SBP_TOPK]; };
-    auto loadHead = [&](int i, Head &h) {
-        h.n = a.count[i]; h.obs = (a.proj[i].flags & 2) != 0;
-        if (h.n > 0) {
-            const uint4 *t = (const uint4 *)(a.cand + (size_t)i * SBP_ROW);
-            const uint4 t0 = t[0], t1 = t[1];
-            h.e[0] = t0.x; h.e[1] = t0.y; h.e[2] = t0.z; h.e[3] = t0.w; h.e[4] = t1.x; h.e[5] = t1.y; h.e[6] = t1.z; h.e[7] = t1.w;
-        }
-    };
-    // the choice of point i against the owners of the previous round
-    auto choose = [&](int i, const Head &h) {
-        if (h.n <= 0) return -1;
-        int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1, found = 0;
-        const int K = min(h.n, a.topUse);
-#pragma unroll
-        for (int k = 0; k < SBP_TOPK; ++k) {
-            if (k >= K) break;
-            const uint32_t e = h.e[k];
-            const int i2 = e & 0xFFFF;
-            if (found >= 2 || own[i2] < i) continue;  // taken by an earlier point with observations
-            if (found == 0) { best = (e >> 16) & 0x1FF; bestL = e >> 25; bestI = i2; }
-            else { best2 = (e >> 16) & 0x1FF; bestL2 = e >> 25; }
-            ++found;
-        }
-        const bool complete = h.n <= a.topUse;
-        // decided by the head: the best is known and (frame variant, or a best above TH_HIGH) nothing else matters, or the second is known too
-        const bool decided = found >= 2 || complete || (found == 1 && (a.mode == 0 || best > TH_HIGH));
-        if (!decided) {
-            best = 256; bestI = -1; best2 = 256; bestL = -1; bestL2 = -1;
-            const uint32_t *lst = a.cand + (size_t)i * SBP_ROW + SBP_TOPK;
-            for (int c = 0; c < h.n; ++c) {
-                const uint32_t e = lst[c];
-                const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
-                if (own[i2] < i) continue;
-                if (dist < best) { best2 = best; bestL2 = bestL; best = dist; bestL = lv; bestI = i2; }
-                else if (dist < best2) { best2 = dist; bestL2 = lv; }
-            }
-        }
+#define SBP_FREE 0x7FFFFFFE
+#define SBP_HEAD 8   // entries at the head of a point's sorted list that the rounds keep in registers
+#ifdef SBP_TIMING
+// debug build (-DSBP_TIMING): s_memtime stamps of thread 0 of the last launch (start, setup done, rounds done, end) and the number of
+// rounds; read back with orbx_debug_sbp_timing (tools/experiments/sbp_timing.py)
+__device__ unsigned long long g_sbpTiming[8];
+extern "C" int orbx_debug_sbp_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sbpTiming), sizeof(g_sbpTiming)); }
+#define SBP_STAMP(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sbpTiming[i] = (v); } while (0)
+#else
+#define SBP_STAMP(i, v) do { } while (0)
+#endif
+
+// One step of a point's walk: entry e (sorted position), the owner entry of its keypoint.  Returns false when the walk is over.
+struct SbpWalk {
+    int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1, found = 0;
+    bool stop = false;
+    __device__ __forceinline__ bool done(int mode) const { return found >= 2 || stop || (found == 1 && mode == 0); }
+    __device__ __forceinline__ void visit(uint32_t e, int owner, int i, int mode, float nnratio)
+    {
+        const int TH_HIGH = 100;
+        const int d = (e >> 16) & 0x1FF;
+        if (found == 0 && d > TH_HIGH) { stop = true; return; }
+        if (found == 1 && (mode == 0 || (nnratio >= 0.f && !((float)best > __fmul_rn(nnratio, (float)d))))) { stop = true; return; }
+        if ((owner >> 1) < i) return;  // taken by an earlier point with observations
+        if (found == 0) { best = d; bestL = e >> 25; bestI = e & 0xFFFF; }
+        else { best2 = d; bestL2 = e >> 25; }
+        ++found;
+    }
+    __device__ __forceinline__ int choice(int mode, float nnratio) const
+    {
+        const int TH_HIGH = 100;
         int ch = best <= TH_HIGH ? bestI : -1;
         // map-point variant: ratio to the second match, only if best and second are in the same scale level (:122-129)
-        if (a.mode == 1 && ch >= 0 && bestL == bestL2 && (float)best > __fmul_rn(a.nnratio, (float)best2)) ch = -1;
+        if (mode == 1 && ch >= 0 && bestL == bestL2 && (float)best > __fmul_rn(nnratio, (float)best2)) ch = -1;
         return ch;
-    };
-    Head h0, h1;
-    h0.n = -1; h1.n = -1; h0.obs = 0; h1.obs = 0;
-    if (tid < a.np) loadHead(tid, h0);
-    if (tid + 1024 < a.np) loadHead(tid + 1024, h1);
-    __syncthreads();
-    for (int round = 0; round <= a.np + 1; ++round) {
-        for (int i = tid; i < a.nc; i += 1024) ownNew[i] = INT_MAX;
-        if (tid == 0) changed = 0;
-        __syncthreads();
-        if (tid < a.np) {
-            const int ch = choose(tid, h0);
-            a.choice[tid] = ch;
-            if (ch >= 0 && h0.obs) atomicMin(&ownNew[ch], tid);
-        }
-        if (tid + 1024 < a.np) {
-            const int ch = choose(tid + 1024, h1);
-            a.choice[tid + 1024] = ch;
-            if (ch >= 0 && h1.obs) atomicMin(&ownNew[ch], tid + 1024);
-        }
-        for (int i = tid + 2048; i < a.np; i += 1024) {
-            Head h;
-            loadHead(i, h);
-            const int ch = choose(i, h);
-            a.choice[i] = ch;
-            if (ch >= 0 && h.obs) atomicMin(&ownNew[ch], i);
-        }
-        __syncthreads();
-        for (int i = tid; i < a.nc; i += 1024)
-            if (ownNew[i] != own[i]) changed = 1;
-        __syncthreads();
-        const int ch = changed;
-        int *t = own; own = ownNew; ownNew = t;
-        __syncthreads();
-        if (!ch) break;
     }
-    // CurrentFrame.mvpMapPoints[i2] = the map point of the LAST accepted taker (later ones overwrite); nmatches counts every taker
+};
+
+// votes of the accepted points (rotation histogram), CurrentFrame.mvpMapPoints[i2] = the LAST accepted taker, nmatches
+template <class GetChoice, class SetChoice>
+__device__ __forceinline__ void sbp_finish(const SbpArgs &a, int *hist, int *nAcc, GetChoice getChoice, SetChoice setChoice)
+{
+    const int HISTO_LENGTH = 30, tid = threadIdx.x;
     for (int i = tid; i < a.np; i += 1024) {
-        const int ch = a.count[i] >= 0 ? a.choice[i] : -1;
+        const int ch = getChoice(i);
+        int c = -1;
         if (ch >= 0) {
             atomicMax(&a.assign[ch], i);
-            atomicAdd(&nAcc, 1);
+            atomicAdd(nAcc, 1);
+            c = ch;
             if (a.checkOri) {
                 float rot = __fsub_rn(a.proj[i].angle, a.kc[ch].angle);
                 if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                 int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
                 if (bin == HISTO_LENGTH) bin = 0;
                 atomicAdd(&hist[bin], 1);
-                a.choice[i] = ch | (bin << 16);
+                c = ch | (bin << 16);
             }
-        } else a.choice[i] = -1;
+        }
+        setChoice(i, c);
     }
     __syncthreads();
     if (a.checkOri) {
@@ -2096,14 +2048,164 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc)
         else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
         __syncthreads();
         for (int i = tid; i < a.np; i += 1024) {
-            const int c = a.choice[i];
+            const int c = getChoice(i);
             if (c < 0) continue;
             const int bin = c >> 16, ch = c & 0xFFFF;
-            if (bin != ind1 && bin != ind2 && bin != ind3) { a.assign[ch] = -2; atomicSub(&nAcc, 1); }
+            if (bin != ind1 && bin != ind2 && bin != ind3) { a.assign[ch] = -2; atomicSub(nAcc, 1); }
         }
     }
     __syncthreads();
-    if (tid == 0) a.result[0] = nAcc;
+    if (tid == 0) a.result[0] = *nAcc;
+}
+
+__global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc, int extLen)
+{
+    extern __shared__ int sbpL[];
+    sbp_select_frame(a, blockIdx.x);
+    const int tid = threadIdx.x;
+    SBP_STAMP(0, __builtin_amdgcn_s_memtime());
+    __shared__ int changedF[2], hist[32], nAcc;
+    int *const own = sbpL;                                  // [2][ldsNc] (offsets cur / nxt: swapped POINTERS would turn every read into a flat load)
+    uint32_t *const ext = (uint32_t *)(sbpL + 2 * ldsNc);   // [np][extLen] entries SBP_HEAD .. SBP_HEAD + extLen - 1 of every list
+    int cur = 0, nxt = ldsNc;
+    for (int i = tid; i < a.nc; i += 1024) { own[cur + i] = SBP_FREE; own[nxt + i] = SBP_FREE; a.assign[i] = -1; }
+    if (tid < 32) hist[tid] = 0;
+    if (tid < 2) changedF[tid] = 0;
+    if (tid == 0) nAcc = 0;
+    // what a round needs of point i: list length, the "has observations" flag, the head of the list
+    struct Head { int n, obs; uint32_t e[SBP_HEAD]; };
+    auto loadHead = [&](int i, Head &h) {
+        h.n = a.count[i]; h.obs = (a.proj[i].flags & 2) != 0;
+#pragma unroll
+        for (int k = 0; k < SBP_HEAD; ++k) h.e[k] = 0;
+        if (h.n > 0) {
+            const uint4 *t = (const uint4 *)(a.cand + (size_t)i * SBP_CAP);
+            const uint4 t0 = t[0], t1 = t[1];  // (entries behind the list: whatever an earlier call left - masked by k < n below)
+            h.e[0] = t0.x; h.e[1] = t0.y; h.e[2] = t0.z; h.e[3] = t0.w; h.e[4] = t1.x; h.e[5] = t1.y; h.e[6] = t1.z; h.e[7] = t1.w;
+        }
+    };
+    if (extLen > 0)
+        for (int i = tid; i < a.np; i += 1024) {
+            const int n = a.count[i];
+            const uint4 *src = (const uint4 *)(a.cand + (size_t)i * SBP_CAP + SBP_HEAD);
+            uint4 *dst = (uint4 *)(ext + (size_t)i * extLen);
+            for (int c = 0; c < extLen / 4 && SBP_HEAD + 4 * c < n; ++c) dst[c] = src[c];
+        }
+    const int ncm1 = max(a.nc - 1, 0);
+    // the choice of point i against the owners of the round before
+    auto choose = [&](int i, const Head &h) {
+        if (h.n <= 0) return -1;
+        // (opaque copies of the head: everything derived from an entry - index, distance, level - is loop-invariant, and hoisted out of
+        // the rounds for two heads it took 80 registers: spilled to scratch at the 128 a 1024-thread workgroup leaves)
+        uint32_t he[SBP_HEAD];
+#pragma unroll
+        for (int k = 0; k < SBP_HEAD; ++k) { he[k] = h.e[k]; asm volatile("" : "+v"(he[k])); }
+        int ow[SBP_HEAD];
+#pragma unroll
+        for (int k = 0; k < SBP_HEAD; ++k) ow[k] = own[cur + min((int)(he[k] & 0xFFFF), ncm1)];  // eight independent reads
+        SbpWalk wk;
+#pragma unroll
+        for (int k = 0; k < SBP_HEAD; ++k)
+            if (k < h.n && !wk.done(a.mode)) wk.visit(he[k], ow[k], i, a.mode, a.nnratio);
+        // not settled by the head: on through the sorted list, four entries per step - in LDS as far as it is there
+        if (!wk.done(a.mode) && h.n > SBP_HEAD) {
+            const uint32_t *lst = a.cand + (size_t)i * SBP_CAP;
+            const uint32_t *extI = ext + (size_t)i * extLen - SBP_HEAD;
+            for (int c0 = SBP_HEAD; c0 < h.n && !wk.done(a.mode); c0 += 4) {
+                const uint4 q = c0 + 4 <= SBP_HEAD + extLen ? *(const uint4 *)(extI + c0) : *(const uint4 *)(lst + c0);
+                const uint32_t e4[4] = {q.x, q.y, q.z, q.w};
+                int o4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o4[k] = own[cur + min((int)(e4[k] & 0xFFFF), ncm1)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c0 + k < h.n && !wk.done(a.mode)) wk.visit(e4[k], o4[k], i, a.mode, a.nnratio);
+            }
+        }
+        return wk.choice(a.mode, a.nnratio);
+    };
+    // the first two points of a thread live in registers: heads and choices; further ones (frames of more than 2048 points) go through memory
+    Head h0, h1;
+    h0.n = -1; h1.n = -1; h0.obs = 0; h1.obs = 0;
+    if (tid < a.np) loadHead(tid, h0);
+    if (tid + 1024 < a.np) loadHead(tid + 1024, h1);
+    int ch0 = -1, ch1 = -1;
+    __syncthreads();
+    SBP_STAMP(1, __builtin_amdgcn_s_memtime());
+    // Two barriers per round: choices + atomicMin into the (all free) next array | compare with the current array, which is cleared in
+    // the same pass and becomes the next round's next array
+    for (int round = 0; round <= a.np + 1; ++round) {
+        SBP_STAMP(4, (unsigned long long)round + 1);
+        if (tid < a.np) {
+            ch0 = choose(tid, h0);
+            if (ch0 >= 0 && h0.obs) atomicMin(&own[nxt + ch0], tid << 1);
+        }
+        if (tid + 1024 < a.np) {
+            ch1 = choose(tid + 1024, h1);
+            if (ch1 >= 0 && h1.obs) atomicMin(&own[nxt + ch1], (tid + 1024) << 1);
+        }
+        for (int i = tid + 2048; i < a.np; i += 1024) {
+            Head h;
+            loadHead(i, h);
+            const int ch = choose(i, h);
+            a.choice[i] = ch;
+            if (ch >= 0 && h.obs) atomicMin(&own[nxt + ch], i << 1);
+        }
+        __syncthreads();
+        bool diff = false;
+        for (int i = tid; i < a.nc; i += 1024) { diff |= own[nxt + i] != own[cur + i]; own[cur + i] = SBP_FREE; }
+        if (diff) changedF[round & 1] = 1;
+        if (tid == 0) changedF[(round + 1) & 1] = 0;
+        __syncthreads();
+        const int chg = changedF[round & 1];
+        const int t = cur; cur = nxt; nxt = t;
+        if (!chg) break;
+    }
+    SBP_STAMP(2, __builtin_amdgcn_s_memtime());
+    sbp_finish(a, hist, &nAcc,
+               [&](int i) { return i < 1024 ? ch0 : i < 2048 ? ch1 : a.choice[i]; },
+               [&](int i, int c) { if (i < 1024) ch0 = c; else if (i < 2048) ch1 = c; else a.choice[i] = c; });
+    SBP_STAMP(3, __builtin_amdgcn_s_memtime());
+}
+
+// The same rounds without the LDS state, for frames of more than SBP_LDS_NC keypoints: owners in global memory, every point walks its
+// sorted list in every round.
+__global__ __launch_bounds__(1024) void k_sbp_resolve_walk(SbpArgs a)
+{
+    sbp_select_frame(a, blockIdx.x);
+    const int tid = threadIdx.x;
+    __shared__ int changedF[2], hist[32], nAcc;
+    int *const own = a.owner;
+    int cur = 0, nxt = a.nc;
+    for (int i = tid; i < a.nc; i += 1024) { own[cur + i] = SBP_FREE; own[nxt + i] = SBP_FREE; a.assign[i] = -1; }
+    if (tid < 32) hist[tid] = 0;
+    if (tid < 2) changedF[tid] = 0;
+    if (tid == 0) nAcc = 0;
+    __syncthreads();
+    for (int round = 0; round <= a.np + 1; ++round) {
+        for (int i = tid; i < a.np; i += 1024) {
+            const int n = a.count[i];
+            SbpWalk wk;
+            const uint32_t *glist = a.cand + (size_t)i * SBP_CAP;
+            for (int c = 0; c < n && !wk.done(a.mode); ++c) {
+                const uint32_t e = glist[c];
+                wk.visit(e, own[cur + (e & 0xFFFF)], i, a.mode, a.nnratio);
+            }
+            const int ch = n > 0 ? wk.choice(a.mode, a.nnratio) : -1;
+            a.choice[i] = ch;
+            if (ch >= 0 && (a.proj[i].flags & 2)) atomicMin(&own[nxt + ch], i << 1);
+        }
+        __syncthreads();
+        bool diff = false;
+        for (int k = tid; k < a.nc; k += 1024) { diff |= own[nxt + k] != own[cur + k]; own[cur + k] = SBP_FREE; }
+        if (diff) changedF[round & 1] = 1;
+        if (tid == 0) changedF[(round + 1) & 1] = 0;
+        __syncthreads();
+        const int chg = changedF[round & 1];
+        const int t = cur; cur = nxt; nxt = t;
+        if (!chg) break;
+    }
+    sbp_finish(a, hist, &nAcc, [&](int i) { return a.choice[i]; }, [&](int i, int c) { a.choice[i] = c; });
 }
 
 // The Nleft != -1 branches of both SearchByProjection functions (src/ORBmatcher3.cc:300-436, src/ORBmatcher1.cc:45-215).  The reference
@@ -2136,7 +2238,7 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve_fe(SbpArgs a)
                 if (side == 0 && a.mode == 0 && n <= 0) skipRight = true;  // the left part's `continue`s leave the right part out
                 if (n > 0 && !(side && skipRight)) {
                     int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1;
-                    const uint32_t *lst = a.cand + (size_t)s * SBP_ROW + SBP_TOPK;
+                    const uint32_t *lst = a.cand + (size_t)s * SBP_CAP;
                     for (int c = 0; c < n; ++c) {
                         const uint32_t e = lst[c];
                         const int i2 = e & 0xFFFF, dist = (e >> 16) & 0x1FF, lv = e >> 25;
@@ -2266,7 +2368,7 @@ hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFish
     a.scale = f.scale; a.mbf = 0.f; a.proj = (const SbpProj *)f.steps; a.dproj = f.dproj; a.np = 2 * f.np;
     a.th = f.th; a.forward = f.forward; a.backward = f.backward; a.checkOri = f.checkOri;
     a.cand = f.cand; a.count = f.count; a.choice = f.choice; a.owner = nullptr; a.assign = f.assign; a.result = f.result;
-    a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next; a.topUse = 0;
+    a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next;
     hipError_t e = hipMemsetAsync(f.result, 0, 2 * sizeof(int) * (size_t)nframes, st);
     if (e != hipSuccess) return e;
     if (f.np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(2 * f.np, nframes), dim3(64), 0, st, a);
@@ -2295,26 +2397,30 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
     a.th = th; a.forward = forward; a.backward = backward; a.checkOri = checkOri;
     a.cand = cand; a.count = count; a.choice = choice; a.owner = owner; a.assign = assign; a.result = result;
     a.nLeft = -1; a.cellStartR = nullptr; a.itemsR = nullptr; a.partner = nullptr; a.head = nullptr; a.next = nullptr;
-    static const int topUse = [] { const char *e = getenv("ORBX_SBP_TOPK"); return e ? std::min(std::max(atoi(e), 0), SBP_TOPK) : SBP_TOPK; }();
-    a.topUse = topUse;
     hipError_t e = hipMemsetAsync(result, 0, (size_t)nframes * 2 * sizeof(int), st);
     if (e != hipSuccess) return e;
     if (np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(np, nframes), dim3(64), 0, st, a);
-    static const bool forceGlobal = getenv("ORBX_SBP_RESOLVE_GLOBAL") != nullptr;  // tests: the variant for frames beyond SBP_LDS_NC keypoints
+    static const bool forceGlobal = getenv("ORBX_SBP_RESOLVE_GLOBAL") != nullptr;  // tests: the variant for frames that do not fit the LDS
+    // LDS: the two owner arrays, then as many entries of every point's list behind its head as fit (at most 24, in fours; more frames
+    // than CUs: half the LDS each, so that two workgroups share a CU)
+    const int ldsNc = (a.nc + 3) & ~3;
+    const size_t budget = 160 * 1024 - 1024, owners = (size_t)ldsNc * 8, share = nframes > 256 ? budget / 2 - 512 : budget;
     if (a.nc <= SBP_LDS_NC && !forceGlobal) {
-        const int ldsNc = (a.nc + 3) & ~3;
-        const size_t lds = (size_t)ldsNc * 8 + 16;
+        int extLen = np > 0 && share > owners ? (int)std::min<size_t>(24, (share - owners) / ((size_t)np * 4)) & ~3 : 0;
+        static const int extEnv = [] { const char *e = getenv("ORBX_SBP_LIST_LDS"); return e ? atoi(e) : -1; }();  // tests: fewer (0: no) list entries in LDS
+        if (extEnv >= 0) extLen = std::min(extLen, extEnv & ~3);
+        const size_t lds = owners + (size_t)np * extLen * 4 + 16;
         static size_t attrBytes[64] = {};  // per device
         int devId = 0;
         (void)hipGetDevice(&devId);
         if (lds > attrBytes[devId & 63]) {
-            const hipError_t e = hipFuncSetAttribute((const void *)k_sbp_resolve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SBP_LDS_NC * 8 + 16));
-            if (e != hipSuccess) return e;
-            attrBytes[devId & 63] = (size_t)SBP_LDS_NC * 8 + 16;
+            const hipError_t e2 = hipFuncSetAttribute((const void *)k_sbp_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+            if (e2 != hipSuccess) return e2;
+            attrBytes[devId & 63] = budget;
         }
-        hipLaunchKernelGGL(k_sbp_resolve<true>, dim3(nframes), dim3(1024), lds, st, a, ldsNc);
+        hipLaunchKernelGGL(k_sbp_resolve, dim3(nframes), dim3(1024), lds, st, a, ldsNc, extLen);
     } else {
-        hipLaunchKernelGGL(k_sbp_resolve<false>, dim3(nframes), dim3(1024), 0, st, a, 0);
+        hipLaunchKernelGGL(k_sbp_resolve_walk, dim3(nframes), dim3(1024), 0, st, a);
     }
     return hipGetLastError();
 }
