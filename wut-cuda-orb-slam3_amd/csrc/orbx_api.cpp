@@ -1739,6 +1739,108 @@ struct orbx_matcher {
     DevBuf<uint32_t> d_sbpCand;   // SearchByProjection: candidate lists [maxQ][ORBX_SBP_CAP]
     DevBuf<uint8_t> d_siWork;     // SearchForInitialization: octave-0 subset of F2 and the shortest candidates of every F1 keypoint
     DevBuf<orbx_projection> d_proj;
+    // single calls with host pointers: all inputs of a call cross the link in ONE transfer (HostPack), the results in one more
+    DevBuf<uint8_t> d_arena, d_arenaOut;
+    uint8_t *h_arena = nullptr, *h_out = nullptr;   // page-locked staging
+    size_t h_arenaBytes = 0, h_outBytes = 0;
+};
+
+// The inputs of a single call with host pointers (keypoints, descriptors, flags, projections ...: two to ten arrays of a few KB each)
+// are packed into the matcher's page-locked staging and cross the link as ONE copy into an arena of the same layout; a piece either
+// stays there (dev()) or one small launch moves the pieces on to the buffers the kernels read (add(.., ddst)).  The results go the
+// same way back (HostFetch).  A hipMemcpyAsync from or to pageable memory costs 20 - 30 us of host time and ~7 us on the device
+// whatever its size (tools/experiments/single_call_trace.sh): seven of them were a third of a single-frame orbx_search_by_projection.
+// Only for calls that synchronise the stream before they return: the staging is reused by the next call.
+static int growPinned(uint8_t *&p, size_t &have, size_t need, size_t keep)
+{
+    if (have >= need) return ORBX_OK;
+    ORBX_SETUP_LOCK;
+    uint8_t *q = nullptr;
+    const size_t want = std::max(need + need / 2, (size_t)1 << 20);
+    HIP_TRY(hipHostMalloc((void **)&q, want, hipHostMallocDefault));
+    if (p) { if (keep) memcpy(q, p, keep); (void)hipHostFree(p); }
+    p = q; have = want;
+    return ORBX_OK;
+}
+static const size_t kDirectBytes = (size_t)256 << 10;
+struct HostPack {
+    orbx_matcher *m;
+    OrbxCopyPieces sc;       // pieces that go on to a buffer of their own (src = offset into the arena until send())
+    size_t bytes = 0;
+    int err = ORBX_OK;
+    explicit HostPack(orbx_matcher *mm) : m(mm) { sc.n = 0; }
+    // packs `nbytes` from `src`; returns the offset of the piece in the arena.  ddst != NULL: the piece is copied on to ddst by send()
+    size_t add(const void *src, size_t nbytes, void *ddst = nullptr)
+    {
+        const size_t off = (bytes + 255) & ~(size_t)255;
+        if (err != ORBX_OK || nbytes == 0) return off;
+        if (ddst && nbytes > kDirectBytes) {  // a large piece gains nothing from the detour: straight to its buffer, in stream order
+            if (hipMemcpyAsync(ddst, src, nbytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) err = setError(ORBX_ERR_HIP, "hipMemcpyAsync (host to device) failed");
+            return off;
+        }
+        if ((err = growPinned(m->h_arena, m->h_arenaBytes, off + nbytes, bytes)) != ORBX_OK) return off;
+        memcpy(m->h_arena + off, src, nbytes);
+        bytes = off + nbytes;
+        if (ddst) {
+            if (sc.n >= ORBX_COPY_PIECES || nbytes > 0xFFFFFFFFull) { err = setError(ORBX_ERR_INVALID_ARG, "internal: too many / too large pieces in a packed transfer"); return off; }
+            sc.dst[sc.n] = ddst; sc.src[sc.n] = (const void *)off; sc.bytes[sc.n] = (unsigned)nbytes; ++sc.n;
+        }
+        return off;
+    }
+    int send()
+    {
+        if (err != ORBX_OK) return err;
+        if (bytes == 0) return ORBX_OK;
+        int rc = m->d_arena.ensure(bytes);
+        if (rc != ORBX_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(m->d_arena.p, m->h_arena, bytes, hipMemcpyHostToDevice, m->stream));
+        for (int i = 0; i < sc.n; ++i) sc.src[i] = m->d_arena.p + (size_t)sc.src[i];
+        HIP_TRY(orbxLaunchCopyPieces(m->stream, sc));
+        return ORBX_OK;
+    }
+    template <class T> T *dev(size_t off) const { return (T *)(m->d_arena.p + off); }
+};
+// The results of such a call: the pieces are gathered into one device buffer by one launch, cross the link as one copy into page-locked
+// staging and are handed to the caller's arrays after the stream has been synchronised (finish()).
+struct HostFetch {
+    orbx_matcher *m;
+    OrbxCopyPieces gt;       // dst = offset into the gather buffer until finish()
+    void *host[ORBX_COPY_PIECES];
+    size_t bytes = 0;
+    int err = ORBX_OK;
+    explicit HostFetch(orbx_matcher *mm) : m(mm) { gt.n = 0; }
+    void add(void *hdst, const void *dsrc, size_t nbytes)
+    {
+        if (err != ORBX_OK || nbytes == 0) return;
+        if (nbytes > kDirectBytes) {  // (see HostPack::add)
+            if (hipMemcpyAsync(hdst, dsrc, nbytes, hipMemcpyDeviceToHost, m->stream) != hipSuccess) err = setError(ORBX_ERR_HIP, "hipMemcpyAsync (device to host) failed");
+            return;
+        }
+        if (gt.n >= ORBX_COPY_PIECES || nbytes > 0xFFFFFFFFull) { err = setError(ORBX_ERR_INVALID_ARG, "internal: too many / too large pieces in a packed transfer"); return; }
+        const size_t off = (bytes + 255) & ~(size_t)255;
+        gt.dst[gt.n] = (void *)off; gt.src[gt.n] = dsrc; gt.bytes[gt.n] = (unsigned)nbytes; host[gt.n] = hdst; ++gt.n;
+        bytes = off + nbytes;
+    }
+    // gathers, copies, synchronises the stream, delivers
+    int finish()
+    {
+        if (err != ORBX_OK) return err;
+        if (bytes == 0) { HIP_TRY(hipStreamSynchronize(m->stream)); return ORBX_OK; }
+        int rc = m->d_arenaOut.ensure(bytes);
+        if (rc != ORBX_OK) return rc;
+        if ((rc = growPinned(m->h_out, m->h_outBytes, bytes, 0)) != ORBX_OK) return rc;
+        size_t offs[ORBX_COPY_PIECES];
+        for (int i = 0; i < gt.n; ++i) { offs[i] = (size_t)gt.dst[i]; gt.dst[i] = m->d_arenaOut.p + offs[i]; }
+        if (gt.n == 1) {
+            HIP_TRY(hipMemcpyAsync(m->h_out + offs[0], gt.src[0], gt.bytes[0], hipMemcpyDeviceToHost, m->stream));
+        } else {
+            HIP_TRY(orbxLaunchCopyPieces(m->stream, gt));
+            HIP_TRY(hipMemcpyAsync(m->h_out, m->d_arenaOut.p, bytes, hipMemcpyDeviceToHost, m->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        for (int i = 0; i < gt.n; ++i) memcpy(host[i], m->h_out + offs[i], gt.bytes[i]);
+        return ORBX_OK;
+    }
 };
 
 extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orbx_matcher **out)
@@ -1780,6 +1882,9 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (m->evWait) (void)hipEventDestroy(m->evWait);
     m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
     m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release(); m->d_sbpCand.release(); m->d_proj.release();
+    m->d_arena.release(); m->d_arenaOut.release();
+    if (m->h_arena) (void)hipHostFree(m->h_arena);
+    if (m->h_out) (void)hipHostFree(m->h_out);
     delete m;
 }
 
@@ -1792,12 +1897,14 @@ extern "C" int orbx_matcher_sync(orbx_matcher *m)
     return ORBX_OK;
 }
 
-static int uploadQT(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt)
+// query / train descriptors of a call into d_q / d_t (pieces of the call's packed transfer: in.send() moves them)
+static int uploadQT(HostPack &in, const uint8_t *q, int nq, const uint8_t *t, int nt)
 {
+    orbx_matcher *m = in.m;
     if (nq > m->maxQ || nt > m->maxT) return setError(ORBX_ERR_CAPACITY, "matcher capacity (%d x %d) exceeded by %d x %d", m->maxQ, m->maxT, nq, nt);
-    if (nq > 0) HIP_TRY(hipMemcpyAsync(m->d_q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
-    if (nt > 0) HIP_TRY(hipMemcpyAsync(m->d_t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, m->stream));
-    return ORBX_OK;
+    if (nq > 0) in.add(q, (size_t)nq * 32, m->d_q.p);
+    if (nt > 0) in.add(t, (size_t)nt * 32, m->d_t.p);
+    return in.err;
 }
 
 extern "C" int orbx_hamming_matrix(orbx_matcher *m, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *dist)
@@ -1806,13 +1913,14 @@ extern "C" int orbx_hamming_matrix(orbx_matcher *m, const uint8_t *q, int nq, co
     if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || !dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_hamming_matrix: bad argument");
     if (nq == 0 || nt == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
-    int rc = uploadQT(m, q, nq, t, nt);
-    if (rc != ORBX_OK) return rc;
+    HostPack in(m);
+    int rc = uploadQT(in, q, nq, t, nt);
+    if (rc != ORBX_OK || (rc = in.send()) != ORBX_OK) return rc;
     if ((rc = m->d_mat.ensure((size_t)nq * nt)) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchHammingMatrix(m->stream, m->d_q.p, nq, m->d_t.p, nt, m->d_mat.p));
-    HIP_TRY(hipMemcpyAsync(dist, m->d_mat.p, (size_t)nq * nt * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return ORBX_OK;
+    HostFetch out(m);
+    out.add(dist, m->d_mat.p, (size_t)nq * nt * sizeof(int));
+    return out.finish();
 }
 
 // kNN-2 of `npairs` independent (query, train) sets in one launch: split count, scratch for the per-split partial results
@@ -1861,13 +1969,14 @@ extern "C" int orbx_match_knn2(orbx_matcher *m, const uint8_t *q, int nq, const 
     if (!m || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || !idx || !dist) return setError(ORBX_ERR_INVALID_ARG, "orbx_match_knn2: bad argument");
     if (nq == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
-    int rc = uploadQT(m, q, nq, t, nt);
-    if (rc != ORBX_OK) return rc;
+    HostPack in(m);
+    int rc = uploadQT(in, q, nq, t, nt);
+    if (rc != ORBX_OK || (rc = in.send()) != ORBX_OK) return rc;
     if ((rc = knn2Launch(m, 1, m->d_q.p, 0, nullptr, nullptr, nq, m->d_t.p, 0, nullptr, nullptr, nt, m->d_idx.p, m->d_dist.p)) != ORBX_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(idx, m->d_idx.p, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(dist, m->d_dist.p, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return ORBX_OK;
+    HostFetch out(m);
+    out.add(idx, m->d_idx.p, (size_t)nq * 2 * sizeof(int));
+    out.add(dist, m->d_dist.p, (size_t)nq * 2 * sizeof(int));
+    return out.finish();
 }
 
 extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int nl, const orbx_keypoint *kr,
@@ -1882,21 +1991,23 @@ extern "C" int orbx_match_stereo_rows(orbx_matcher *m, const orbx_keypoint *kl, 
     for (int i = 0; i < nr; ++i)
         if (kr[i].octave < 0 || kr[i].octave >= nlevels) return setError(ORBX_ERR_INVALID_ARG, "right keypoint %d has octave %d outside [0,%d)", i, kr[i].octave, nlevels);
     HIP_TRY(hipSetDevice(m->device));
-    int rc = uploadQT(m, dl, nl, dr, nr);
+    HostPack in(m);
+    int rc = uploadQT(in, dl, nl, dr, nr);
     if (rc != ORBX_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    in.add(kl, (size_t)nl * sizeof(orbx_keypoint), m->d_kl.p);
+    in.add(kr, (size_t)nr * sizeof(orbx_keypoint), m->d_kr.p);
+    in.add(scale_factors, (size_t)nlevels * sizeof(float), m->d_scale.p);
     float maxScale = 1.f;
     for (int i = 0; i < nlevels; ++i) maxScale = std::max(maxScale, scale_factors[i]);
     const int itemStride = orbxStereoBandItems(nr, maxScale);
     if ((rc = m->d_rowStart.ensure((size_t)n_rows + 1)) != ORBX_OK || (rc = m->d_rowItems.ensure((size_t)std::max(itemStride, 1))) != ORBX_OK) return rc;
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, n_rows, m->d_scale.p, min_d, max_d,
                                  m->d_idx.p, m->d_dist.p, nullptr, m->d_rowStart.p, m->d_rowItems.p, itemStride));
-    HIP_TRY(hipMemcpyAsync(best_idx, m->d_idx.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(best_dist, m->d_dist.p, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return ORBX_OK;
+    HostFetch out(m);
+    out.add(best_idx, m->d_idx.p, (size_t)nl * sizeof(int));
+    out.add(best_dist, m->d_dist.p, (size_t)nl * sizeof(int));
+    return out.finish();
 }
 
 #define ORBX_GRID_CELLS (64 * 48)
@@ -1944,7 +2055,8 @@ static int searchByBowImpl(orbx_matcher *m, const int32_t *kf_fv_node, const int
     for (int i = 0; i < nOut; ++i) matches[i] = -1;
     if (kf_nfv == 0 || f_nfv == 0 || kf_n == 0 || f_n == 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, kf_desc, kf_n, f_desc, f_n)) != ORBX_OK) return rc;
+    HostPack in(m);
+    if ((rc = uploadQT(in, kf_desc, kf_n, f_desc, f_n)) != ORBX_OK) return rc;
     const size_t Q = (size_t)m->maxQ, T = (size_t)m->maxT, X = std::max(Q, T);
     if ((rc = m->d_work.ensure(3 * Q + 3 * T + 2 * X + 2 + 64)) != ORBX_OK) return rc;
     if ((rc = m->d_bin.ensure(Q + T)) != ORBX_OK) return rc;
@@ -1953,22 +2065,24 @@ static int searchByBowImpl(orbx_matcher *m, const int32_t *kf_fv_node, const int
     int maxNodeF = 1;
     for (int j = 0; j < f_nfv; ++j) maxNodeF = std::max(maxNodeF, f_fv_start[j + 1] - f_fv_start[j]);
     hipStream_t st = m->stream;
-    HIP_TRY(hipMemcpyAsync(kfNode, kf_fv_node, (size_t)kf_nfv * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(kfStart, kf_fv_start, ((size_t)kf_nfv + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    if (kf_fv_start[kf_nfv] > 0) HIP_TRY(hipMemcpyAsync(kfFeat, kf_fv_feature, (size_t)kf_fv_start[kf_nfv] * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(fNode, f_fv_node, (size_t)f_nfv * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(fStart, f_fv_start, ((size_t)f_nfv + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    if (f_fv_start[f_nfv] > 0) HIP_TRY(hipMemcpyAsync(fFeat, f_fv_feature, (size_t)f_fv_start[f_nfv] * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kf_keys, (size_t)kf_n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(m->d_kr.p, f_keys, (size_t)f_n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(m->d_bin.p, kf_valid, (size_t)kf_n, hipMemcpyHostToDevice, st));
-    if (mode == 1) HIP_TRY(hipMemcpyAsync(m->d_bin.p + Q, f_valid, (size_t)f_n, hipMemcpyHostToDevice, st));
+    in.add(kf_fv_node, (size_t)kf_nfv * sizeof(int), kfNode);
+    in.add(kf_fv_start, ((size_t)kf_nfv + 1) * sizeof(int), kfStart);
+    if (kf_fv_start[kf_nfv] > 0) in.add(kf_fv_feature, (size_t)kf_fv_start[kf_nfv] * sizeof(int), kfFeat);
+    in.add(f_fv_node, (size_t)f_nfv * sizeof(int), fNode);
+    in.add(f_fv_start, ((size_t)f_nfv + 1) * sizeof(int), fStart);
+    if (f_fv_start[f_nfv] > 0) in.add(f_fv_feature, (size_t)f_fv_start[f_nfv] * sizeof(int), fFeat);
+    in.add(kf_keys, (size_t)kf_n * sizeof(orbx_keypoint), m->d_kl.p);
+    in.add(f_keys, (size_t)f_n * sizeof(orbx_keypoint), m->d_kr.p);
+    in.add(kf_valid, (size_t)kf_n, m->d_bin.p);
+    if (mode == 1) in.add(f_valid, (size_t)f_n, m->d_bin.p + Q);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchSearchByBoW(st, kfNode, kfStart, kfFeat, kf_nfv, m->d_kl.p, m->d_q.p, m->d_bin.p, fNode, fStart, fFeat, f_nfv, m->d_kr.p,
                                   m->d_t.p, f_n, maxNodeF, nnratio, check_orientation != 0, mode, m->d_bin.p + Q, nOut, dMatches, binOf, result));
     int nmatches = 0;
-    HIP_TRY(hipMemcpyAsync(matches, dMatches, (size_t)nOut * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&nmatches, result, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HostFetch out(m);
+    out.add(matches, dMatches, (size_t)nOut * sizeof(int));
+    out.add(&nmatches, result, sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     return nmatches;
 }
 
@@ -2023,7 +2137,8 @@ extern "C" int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyfram
     for (int i = 0; i < n1; ++i) matches12[i] = -1;
     if (kf1->nfv == 0 || kf2->nfv == 0 || n1 == 0 || n2 == 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, kf1->desc, n1, kf2->desc, n2)) != ORBX_OK) return rc;
+    HostPack in(m);
+    if ((rc = uploadQT(in, kf1->desc, n1, kf2->desc, n2)) != ORBX_OK) return rc;
     const size_t Q = (size_t)m->maxQ, T = (size_t)m->maxT;
     if ((rc = m->d_work.ensure(3 * Q + 3 * T + 2 * Q + 2 + 64)) != ORBX_OK) return rc;
     if ((rc = m->d_bin.ensure(Q + T)) != ORBX_OK) return rc;
@@ -2032,7 +2147,7 @@ extern "C" int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyfram
         *dMatches = feat2 + T, *binOf = dMatches + Q, *result = binOf + Q;
     float *uR1 = m->d_prev.p, *uR2 = uR1 + Q, *scale2 = uR2 + T, *sigma1 = scale2 + ORBX_MAX_LEVELS, *sigma2 = sigma1 + ORBX_MAX_LEVELS;
     hipStream_t st = m->stream;
-    auto up = [&](void *dst, const void *src, size_t bytes) { return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) : hipSuccess; };
+    auto up = [&](void *dst, const void *src, size_t bytes) { in.add(src, bytes, dst); return hipSuccess; };  // (pieces of one packed transfer)
     HIP_TRY(up(node1, kf1->fv_node, (size_t)kf1->nfv * 4)); HIP_TRY(up(start1, kf1->fv_start, ((size_t)kf1->nfv + 1) * 4));
     HIP_TRY(up(feat1, kf1->fv_feature, (size_t)kf1->fv_start[kf1->nfv] * 4));
     HIP_TRY(up(node2, kf2->fv_node, (size_t)kf2->nfv * 4)); HIP_TRY(up(start2, kf2->fv_start, ((size_t)kf2->nfv + 1) * 4));
@@ -2055,11 +2170,13 @@ extern "C" int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyfram
     memcpy(h.camL, g->cam_left, sizeof h.camL); memcpy(h.camR, g->cam_right, sizeof h.camR); h.precision = g->precision;
     memcpy(h.R, g->R, sizeof h.R); memcpy(h.t, g->t, sizeof h.t);
     h.matches = dMatches; h.binOf = binOf; h.result = result;
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchSearchForTriangulation(st, h));
     int nmatches = 0;
-    HIP_TRY(hipMemcpyAsync(matches12, dMatches, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&nmatches, result, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HostFetch out(m);
+    out.add(matches12, dMatches, (size_t)n1 * sizeof(int));
+    out.add(&nmatches, result, sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     if (pairs) {  // vMatchedPairs (:405-413): (idx1, idx2) in increasing idx1
         int k = 0;
         for (int i = 0; i < n1; ++i)
@@ -2086,7 +2203,8 @@ static int keyframeWindowsImpl(const char *fn, orbx_matcher *m, const orbx_keypo
     for (int i = 0; i < np; ++i) { best_idx[i] = -1; best_dist[i] = INT32_MAX; }
     if (n == 0 || np == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, point_desc, np, desc, n)) != ORBX_OK) return rc;
+    HostPack in(m);
+    if ((rc = uploadQT(in, point_desc, np, desc, n)) != ORBX_OK) return rc;
     if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
     if ((rc = m->d_work.ensure(2 * (size_t)m->maxQ + 6 * (size_t)m->maxQ + 64)) != ORBX_OK) return rc;
     if ((rc = m->d_prev.ensure((size_t)m->maxT + ORBX_MAX_LEVELS)) != ORBX_OK) return rc;
@@ -2095,16 +2213,18 @@ static int keyframeWindowsImpl(const char *fn, orbx_matcher *m, const orbx_keypo
     orbx_window_point *dPts = (orbx_window_point *)(dDist + m->maxQ);
     float *dUR = u_right ? m->d_prev.p : nullptr, *dSig = m->d_prev.p + m->maxT;
     hipStream_t st = m->stream;
-    HIP_TRY(hipMemcpyAsync(m->d_kr.p, keys, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dPts, points, (size_t)np * sizeof(orbx_window_point), hipMemcpyHostToDevice, st));
-    if (u_right) HIP_TRY(hipMemcpyAsync(dUR, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
-    if (inv_level_sigma2) HIP_TRY(hipMemcpyAsync(dSig, inv_level_sigma2, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, st));
+    in.add(keys, (size_t)n * sizeof(orbx_keypoint), m->d_kr.p);
+    in.add(points, (size_t)np * sizeof(orbx_window_point), dPts);
+    if (u_right) in.add(u_right, (size_t)n * sizeof(float), dUR);
+    if (inv_level_sigma2) in.add(inv_level_sigma2, (size_t)nlevels * sizeof(float), dSig);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchGridBuild(st, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
     HIP_TRY(orbxLaunchKeyframeWindowSearch(st, m->d_kr.p, m->d_t.p, dUR, dSig, cs, it, min_x, max_x, min_y, max_y, dPts, m->d_q.p, np, chi2_test != 0,
                                            dIdx, dDist));
-    HIP_TRY(hipMemcpyAsync(best_idx, dIdx, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(best_dist, dDist, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HostFetch out(m);
+    out.add(best_idx, dIdx, (size_t)np * sizeof(int));
+    out.add(best_dist, dDist, (size_t)np * sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     return ORBX_OK;
 }
 
@@ -2181,7 +2301,8 @@ static int projectionRoundsImpl(const char *fn, orbx_matcher *m, const orbx_keyp
     }
     if (n == 0 || np == 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, point_desc, np, desc, n)) != ORBX_OK) return rc;
+    HostPack in(m);
+    if ((rc = uploadQT(in, point_desc, np, desc, n)) != ORBX_OK) return rc;
     if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
     if ((rc = m->d_work.ensure(8 * (size_t)m->maxQ + (size_t)m->maxT + 64)) != ORBX_OK) return rc;
     if ((rc = m->d_bin.ensure((size_t)m->maxQ + (size_t)m->maxT)) != ORBX_OK) return rc;
@@ -2193,18 +2314,22 @@ static int projectionRoundsImpl(const char *fn, orbx_matcher *m, const orbx_keyp
     hipStream_t st = m->stream;
     std::vector<signed char> blocked((size_t)n, 0);
     if (matched) for (int i = 0; i < n; ++i) blocked[i] = matched[i] ? 1 : 0;
-    HIP_TRY(hipMemcpyAsync(m->d_kr.p, keys, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dPts, points, (size_t)np * sizeof(orbx_window_point), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dBlocked, blocked.data(), (size_t)n, hipMemcpyHostToDevice, st));
+    in.add(keys, (size_t)n * sizeof(orbx_keypoint), m->d_kr.p);
+    in.add(points, (size_t)np * sizeof(orbx_window_point), dPts);
+    in.add(blocked.data(), (size_t)n, dBlocked);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchGridBuild(st, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
     std::vector<int32_t> idx((size_t)np), dist((size_t)np), choice((size_t)np, -2), owner((size_t)n, -1);
     for (int round = 0; round <= np; ++round) {
-        HIP_TRY(hipMemcpyAsync(dOwner, owner.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+        HostPack own(m);  // (the staging is free again: every round ends with a synchronised stream)
+        own.add(owner.data(), (size_t)n * sizeof(int), dOwner);
+        if ((rc = own.send()) != ORBX_OK) return rc;
         HIP_TRY(orbxLaunchKeyframeWindowSearch(st, m->d_kr.p, m->d_t.p, nullptr, nullptr, cs, it, min_x, max_x, min_y, max_y, dPts, m->d_q.p, np, 0, dIdx,
                                                dDist, dBlocked, dOwner, level_hi));
-        HIP_TRY(hipMemcpyAsync(idx.data(), dIdx, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(dist.data(), dDist, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HostFetch out(m);
+        out.add(idx.data(), dIdx, (size_t)np * sizeof(int));
+        out.add(dist.data(), dDist, (size_t)np * sizeof(int));
+        if ((rc = out.finish()) != ORBX_OK) return rc;
         bool changed = false;
         std::fill(owner.begin(), owner.end(), -1);
         for (int i = 0; i < np; ++i) {  // accepted choices of this round; the earliest taker owns a keypoint
@@ -2280,16 +2405,19 @@ extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc
     const size_t total = (size_t)start[npoints];
     if (total > 0 && !desc) return setError(ORBX_ERR_INVALID_ARG, "orbx_distinctive_descriptors: null descriptors");
     HIP_TRY(hipSetDevice(m->device));
+    HostPack in(m);
     int rc;
     if ((rc = m->d_siWork.ensure(total * 32 + 64)) != ORBX_OK) return rc;
     if ((rc = m->d_mat.ensure(2 * (size_t)npoints + 2)) != ORBX_OK) return rc;
     int *dStart = m->d_mat.p, *dBest = dStart + npoints + 1;
     hipStream_t st = m->stream;
-    if (total) HIP_TRY(hipMemcpyAsync(m->d_siWork.p, desc, total * 32, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dStart, start, ((size_t)npoints + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    if (total) in.add(desc, total * 32, m->d_siWork.p);
+    in.add(start, ((size_t)npoints + 1) * sizeof(int), dStart);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchDistinctive(st, m->d_siWork.p, dStart, npoints, dBest));
-    HIP_TRY(hipMemcpyAsync(best, dBest, (size_t)npoints * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HostFetch out(m);
+    out.add(best, dBest, (size_t)npoints * sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     return ORBX_OK;
 }
 
@@ -2315,10 +2443,13 @@ extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_keypoint *kp
     }
     if (n > m->maxT) return setError(ORBX_ERR_CAPACITY, "%d keypoints exceed the matcher capacity %d", n, m->maxT);
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipMemcpyAsync(m->d_kr.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HostPack in(m);
+    in.add(kps, (size_t)n * sizeof(orbx_keypoint), m->d_kr.p);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchUndistort(m->stream, m->d_kr.p, m->d_kl.p, n, k4, dist, ndist, knew4));
-    HIP_TRY(hipMemcpyAsync(out, m->d_kl.p, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HostFetch res(m);
+    res.add(out, m->d_kl.p, (size_t)n * sizeof(orbx_keypoint));
+    if ((rc = res.finish()) != ORBX_OK) return rc;
     return ORBX_OK;
 }
 
@@ -2353,12 +2484,19 @@ extern "C" int orbx_assign_features_to_grid(orbx_matcher *m, const orbx_keypoint
     HIP_TRY(hipSetDevice(m->device));
     if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
     int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
-    if (n > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    HostPack in(m);
+    in.add(kps, (size_t)n * sizeof(orbx_keypoint), m->d_kr.p);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
-    HIP_TRY(hipMemcpyAsync(cell_start, cs, (ORBX_GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    // every keypoint is in at most one cell: the first n entries of `items` hold all of them (total <= n)
+    std::vector<int32_t> all((size_t)n);
+    HostFetch out(m);
+    out.add(cell_start, cs, (ORBX_GRID_CELLS + 1) * sizeof(int));
+    out.add(all.data(), it, (size_t)n * sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     const int total = cell_start[ORBX_GRID_CELLS];
-    if (total > 0) HIP_TRY(hipMemcpy(items, it, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+    if (total > n) return setError(ORBX_ERR_HIP, "orbx_assign_features_to_grid: internal: %d items for %d keypoints", total, n);
+    if (total > 0) memcpy(items, all.data(), (size_t)total * sizeof(int));
     return total;
 }
 
@@ -2376,7 +2514,8 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     if (rc != ORBX_OK) return rc;
     if (n1 == 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, d1, n1, d2, n2)) != ORBX_OK) return rc;
+    HostPack in(m);
+    if ((rc = uploadQT(in, d1, n1, d2, n2)) != ORBX_OK) return rc;
     if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
     if ((rc = m->d_work.ensure((size_t)m->maxQ + 2 * (size_t)m->maxT + 4)) != ORBX_OK) return rc;
     if ((rc = m->d_prev.ensure(2 * (size_t)m->maxQ)) != ORBX_OK) return rc;
@@ -2390,17 +2529,19 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     if (forceGeneric) level0of2 = -1;
     int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
     int *m12 = m->d_work.p, *m21 = m12 + m->maxQ, *md = m21 + m->maxT, *nm = md + m->maxT;
-    HIP_TRY(hipMemcpyAsync(m->d_kl.p, k1, (size_t)n1 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    if (n2 > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, k2, (size_t)n2 * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(m->d_prev.p, prev_matched, 2 * (size_t)n1 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    in.add(k1, (size_t)n1 * sizeof(orbx_keypoint), m->d_kl.p);
+    if (n2 > 0) in.add(k2, (size_t)n2 * sizeof(orbx_keypoint), m->d_kr.p);
+    in.add(prev_matched, 2 * (size_t)n1 * sizeof(float), m->d_prev.p);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     if (!(orbxSearchInitInLds(level0of1, n2, level0of2) && n1 < 65536)) HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n2, min_x, max_x, min_y, max_y, cs, it, co));
     HIP_TRY(orbxLaunchSearchInit(m->stream, m->d_kl.p, m->d_q.p, n1, m->d_kr.p, m->d_t.p, n2, cs, it, min_x, max_x, min_y, max_y,
                                  m->d_prev.p, m12, m21, md, m->d_bin.p, nm, window_size, nnratio, check_orientation, level0of2, m->d_siWork.p, level0of1));
     int nmatches = 0;
-    HIP_TRY(hipMemcpyAsync(matches12, m12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(prev_matched, m->d_prev.p, 2 * (size_t)n1 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(&nmatches, nm, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HostFetch out(m);
+    out.add(matches12, m12, (size_t)n1 * sizeof(int));
+    out.add(prev_matched, m->d_prev.p, 2 * (size_t)n1 * sizeof(float));
+    out.add(&nmatches, nm, sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     return nmatches;
 }
 
@@ -2424,31 +2565,30 @@ static int searchByProjectionImpl(orbx_matcher *m, const orbx_keypoint *kc, cons
     if (nc == 0) return 0;
     static_assert(sizeof(orbx_projection) == 24, "orbx_projection layout");
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, proj_desc, np, dc, nc)) != ORBX_OK) return rc;
     if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
-    // work: count[maxQ], choice[maxQ], owner[2 * maxT], assign[maxT], result[2], curState (maxT bytes, int-aligned)
-    const size_t workInts = 2 * (size_t)m->maxQ + 3 * (size_t)m->maxT + 2 + ((size_t)m->maxT + 3) / 4 + 4;
+    // work: count[maxQ], choice[maxQ], owner[2 * maxT], result[2] + assign[maxT] (one piece: they leave together)
+    const size_t workInts = 2 * (size_t)m->maxQ + 3 * (size_t)m->maxT + 2 + 4;
     if ((rc = m->d_work.ensure(workInts)) != ORBX_OK) return rc;
     if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_CAP)) != ORBX_OK) return rc;
-    if ((rc = m->d_proj.ensure((size_t)m->maxQ)) != ORBX_OK) return rc;
-    if ((rc = m->d_prev.ensure(2 * (size_t)std::max(m->maxQ, m->maxT))) != ORBX_OK) return rc;
     int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
-    int *count = m->d_work.p, *choice = count + m->maxQ, *owner = choice + m->maxQ, *dAssign = owner + 2 * m->maxT, *result = dAssign + m->maxT;
-    signed char *dState = (signed char *)(result + 2);
-    float *dURight = u_right ? m->d_prev.p : nullptr;
-    HIP_TRY(hipMemcpyAsync(m->d_kr.p, kc, (size_t)nc * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(dState, cur_state, (size_t)nc, hipMemcpyHostToDevice, m->stream));
-    if (u_right) HIP_TRY(hipMemcpyAsync(dURight, u_right, (size_t)nc * sizeof(float), hipMemcpyHostToDevice, m->stream));
-    if (np > 0) HIP_TRY(hipMemcpyAsync(m->d_proj.p, proj, (size_t)np * sizeof(orbx_projection), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, nc, min_x, max_x, min_y, max_y, cs, it, co));
-    HIP_TRY(orbxLaunchSearchByProjection(m->stream, m->d_kr.p, m->d_t.p, dURight, dState, nc, cs, it, min_x, max_x, min_y, max_y,
-                                         m->d_scale.p, mbf, m->d_proj.p, m->d_q.p, np, th, forward != 0, backward != 0,
-                                         check_orientation != 0, mode, nnratio, m->d_sbpCand.p, count, choice, owner, dAssign, result));
+    int *count = m->d_work.p, *choice = count + m->maxQ, *owner = choice + m->maxQ, *result = owner + 2 * m->maxT, *dAssign = result + 2;
+    HostPack in(m);
+    const size_t oKc = in.add(kc, (size_t)nc * sizeof(orbx_keypoint)), oDc = in.add(dc, (size_t)nc * 32), oState = in.add(cur_state, (size_t)nc);
+    const size_t oUr = u_right ? in.add(u_right, (size_t)nc * sizeof(float)) : 0;
+    const size_t oProj = in.add(proj, (size_t)np * sizeof(orbx_projection)), oPd = in.add(proj_desc, (size_t)np * 32);
+    const size_t oScale = in.add(scale_factors, (size_t)nlevels * sizeof(float));
+    if ((rc = in.send()) != ORBX_OK) return rc;
+    const orbx_keypoint *dKc = in.dev<orbx_keypoint>(oKc);
+    HIP_TRY(orbxLaunchGridBuild(m->stream, dKc, nc, min_x, max_x, min_y, max_y, cs, it, co));
+    HIP_TRY(orbxLaunchSearchByProjection(m->stream, dKc, in.dev<uint8_t>(oDc), u_right ? in.dev<float>(oUr) : nullptr, in.dev<signed char>(oState), nc,
+                                         cs, it, min_x, max_x, min_y, max_y, in.dev<float>(oScale), mbf, in.dev<orbx_projection>(oProj),
+                                         in.dev<uint8_t>(oPd), np, th, forward != 0, backward != 0, check_orientation != 0, mode, nnratio,
+                                         m->d_sbpCand.p, count, choice, owner, dAssign, result));
     int res[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(assign, dAssign, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(res, result, sizeof res, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HostFetch out(m);
+    out.add(res, result, sizeof res);
+    out.add(assign, dAssign, (size_t)nc * sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     if (res[1]) return setError(ORBX_ERR_CAPACITY, "orbx_search_by_projection: a search window holds more than %d candidates", ORBX_SBP_CAP);
     return res[0];
 }
@@ -2517,7 +2657,8 @@ static int searchByProjectionFisheyeImpl(const char *fn, orbx_matcher *m, const 
     }
     if (nc == 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, proj_desc, np, dc, nc)) != ORBX_OK) return rc;
+    HostPack in(m);
+    if ((rc = uploadQT(in, proj_desc, np, dc, nc)) != ORBX_OK) return rc;
     const size_t gridInts = (size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT;  // cellStart, items, cellOf of one grid
     if ((rc = m->d_grid.ensure(2 * gridInts)) != ORBX_OK) return rc;
     // work: count[maxQ], choice[maxQ], next[2 maxQ], head[maxT], partner[maxT], assign[maxT], result[2], curState (maxT bytes)
@@ -2530,11 +2671,12 @@ static int searchByProjectionFisheyeImpl(const char *fn, orbx_matcher *m, const 
     int *count = m->d_work.p, *choice = count + m->maxQ, *next = choice + m->maxQ, *head = next + 2 * (size_t)m->maxQ, *dPartner = head + m->maxT,
         *dAssign = dPartner + m->maxT, *result = dAssign + m->maxT;
     signed char *dState = (signed char *)(result + 2);
-    HIP_TRY(hipMemcpyAsync(m->d_kr.p, kc, (size_t)nc * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(dState, cur_state, (size_t)nc, hipMemcpyHostToDevice, m->stream));
-    if (np > 0) HIP_TRY(hipMemcpyAsync(m->d_proj.p, steps.data(), steps.size() * sizeof(orbx_projection), hipMemcpyHostToDevice, m->stream));
-    if (mode == 1) HIP_TRY(hipMemcpyAsync(dPartner, partner.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(m->d_scale.p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    in.add(kc, (size_t)nc * sizeof(orbx_keypoint), m->d_kr.p);
+    in.add(cur_state, (size_t)nc, dState);
+    if (np > 0) in.add(steps.data(), steps.size() * sizeof(orbx_projection), m->d_proj.p);
+    if (mode == 1) in.add(partner.data(), (size_t)nc * sizeof(int), dPartner);
+    in.add(scale_factors, (size_t)nlevels * sizeof(float), m->d_scale.p);
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p, n_left, min_x, max_x, min_y, max_y, csL, itL, coL));
     HIP_TRY(orbxLaunchGridBuild(m->stream, m->d_kr.p + n_left, n_right, min_x, max_x, min_y, max_y, csR, itR, coR));
     OrbxSbpFisheye f;
@@ -2547,9 +2689,10 @@ static int searchByProjectionFisheyeImpl(const char *fn, orbx_matcher *m, const 
     f.cand = m->d_sbpCand.p; f.count = count; f.choice = choice; f.head = head; f.next = next; f.assign = dAssign; f.result = result;
     HIP_TRY(orbxLaunchSearchByProjectionFisheye(m->stream, f));
     int res[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(assign, dAssign, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(res, result, sizeof res, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));  // (also keeps `steps` / `partner` alive until the uploads have been consumed)
+    HostFetch out(m);
+    out.add(assign, dAssign, (size_t)nc * sizeof(int));
+    out.add(res, result, sizeof res);
+    if ((rc = out.finish()) != ORBX_OK) return rc;  // (also keeps `steps` / `partner` alive until the uploads have been consumed)
     if (res[1]) return setError(ORBX_ERR_CAPACITY, "%s: a search window holds more than %d candidates", fn, ORBX_SBP_CAP);
     return res[0];
 }
@@ -2600,20 +2743,22 @@ extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left
     for (int i = 0; i < nr; ++i)
         if (kr[i].octave < 0 || kr[i].octave >= nlev) return setError(ORBX_ERR_INVALID_ARG, "right keypoint %d has octave %d", i, kr[i].octave);
     HIP_TRY(hipSetDevice(m->device));
+    HostPack in(m);
     // the pyramids must be complete before the matcher stream reads them
     HIP_TRY(hipStreamSynchronize(left->stream));
     HIP_TRY(hipStreamSynchronize(right->stream));
-    int rc = uploadQT(m, dl, nl, dr, nr);
+    int rc = uploadQT(in, dl, nl, dr, nr);
     if (rc != ORBX_OK) return rc;
     if ((rc = m->d_uRight.ensure(m->maxQ)) != ORBX_OK || (rc = m->d_depth.ensure(m->maxQ)) != ORBX_OK || (rc = m->d_sad.ensure(m->maxQ)) != ORBX_OK)
         return rc;
-    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(m->d_scale.p, left->scale.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    in.add(kl, (size_t)nl * sizeof(orbx_keypoint), m->d_kl.p);
+    if (nr > 0) in.add(kr, (size_t)nr * sizeof(orbx_keypoint), m->d_kr.p);
+    in.add(left->scale.data(), (size_t)nlev * sizeof(float), m->d_scale.p);
     const float minZ = mb, minD = 0.f, maxD = mbf / minZ;
     const int nRows = left->geom[0].h;  // mvImagePyramid[0].rows (:848)
     const int itemStride = orbxStereoBandItems(nr, left->scale.back());
     if ((rc = m->d_rowStart.ensure((size_t)nRows + 1)) != ORBX_OK || (rc = m->d_rowItems.ensure((size_t)std::max(itemStride, 1))) != ORBX_OK) return rc;
+    if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchStereoRows(m->stream, m->d_kl.p, m->d_q.p, nl, m->d_kr.p, m->d_t.p, nr, nRows, m->d_scale.p, minD, maxD,
                                  m->d_idx.p, m->d_dist.p, nullptr, m->d_rowStart.p, m->d_rowItems.p, itemStride));
     OrbxStereoLevels lv;
@@ -2630,9 +2775,10 @@ extern "C" int orbx_compute_stereo_matches(orbx_matcher *m, orbx_extractor *left
     }
     HIP_TRY(orbxLaunchStereoRefine(m->stream, &lv, m->d_kl.p, nl, m->d_kr.p, m->d_idx.p, m->d_dist.p, mbf, minD, maxD, m->d_uRight.p,
                                    m->d_depth.p, m->d_sad.p, nullptr));
-    HIP_TRY(hipMemcpyAsync(u_right, m->d_uRight.p, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(depth, m->d_depth.p, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HostFetch out(m);
+    out.add(u_right, m->d_uRight.p, (size_t)nl * sizeof(float));
+    out.add(depth, m->d_depth.p, (size_t)nl * sizeof(float));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     return ORBX_OK;
 }
 
@@ -2979,13 +3125,15 @@ extern "C" int orbx_compute_stereo_fisheye_matches(orbx_matcher *m, const orbx_k
     for (int i = 0; i < nr; ++i) right_to_left[i] = -1;
     if (nl - mono_left <= 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
-    if ((rc = uploadQT(m, dl, nl, dr, nr)) != ORBX_OK) return rc;
+    HostPack in(m);
+    if ((rc = uploadQT(in, dl, nl, dr, nr)) != ORBX_OK) return rc;
     if ((rc = m->d_uRight.ensure(m->maxQ)) != ORBX_OK || (rc = m->d_depth.ensure((size_t)m->maxQ * 3)) != ORBX_OK || (rc = m->d_sad.ensure(m->maxQ)) != ORBX_OK ||
         (rc = m->d_bIdx.ensure((size_t)std::max(m->maxT, 16) + 16)) != ORBX_OK)
         return rc;
-    HIP_TRY(hipMemcpyAsync(m->d_kl.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
-    if (nr > 0) HIP_TRY(hipMemcpyAsync(m->d_kr.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, m->stream));
+    in.add(kl, (size_t)nl * sizeof(orbx_keypoint), m->d_kl.p);
+    if (nr > 0) in.add(kr, (size_t)nr * sizeof(orbx_keypoint), m->d_kr.p);
     const int nq = nl - mono_left, nt = nr - mono_right;
+    if ((rc = in.send()) != ORBX_OK) return rc;
     if ((rc = knn2Launch(m, 1, m->d_q.p + (size_t)mono_left * 32, 0, nullptr, nullptr, nq, m->d_t.p + (size_t)mono_right * 32, 0, nullptr, nullptr, nt,
                          m->d_idx.p, m->d_dist.p)) != ORBX_OK)
         return rc;
@@ -2996,12 +3144,13 @@ extern "C" int orbx_compute_stereo_fisheye_matches(orbx_matcher *m, const orbx_k
     a.nMatches = m->d_bIdx.p + std::max(m->maxT, 16);
     HIP_TRY(orbxLaunchFisheyeTriangulate(m->stream, &a, 1));
     int nMatches = 0;
-    HIP_TRY(hipMemcpyAsync(left_to_right, a.leftToRight, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    if (nr > 0) HIP_TRY(hipMemcpyAsync(right_to_left, a.rightToLeft, (size_t)nr * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(depth, a.depth, (size_t)nl * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(p3d, a.p3d, (size_t)nl * 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(&nMatches, a.nMatches, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HostFetch out(m);
+    out.add(left_to_right, a.leftToRight, (size_t)nl * sizeof(int));
+    if (nr > 0) out.add(right_to_left, a.rightToLeft, (size_t)nr * sizeof(int));
+    out.add(depth, a.depth, (size_t)nl * sizeof(float));
+    out.add(p3d, a.p3d, (size_t)nl * 3 * sizeof(float));
+    out.add(&nMatches, a.nMatches, sizeof(int));
+    if ((rc = out.finish()) != ORBX_OK) return rc;
     return nMatches;
 }
 

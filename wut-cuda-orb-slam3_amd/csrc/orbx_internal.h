@@ -240,6 +240,10 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
                                         int backward, int checkOri, int mode, float nnratio, uint32_t *cand, int *count, int *choice,
                                         int *owner, int *assign, int *result, const struct OrbxSbpBatch *batch = nullptr);
 hipError_t orbxLaunchGatherResults(hipStream_t st, const int *result, int n, int *out);
+// up to ORBX_COPY_PIECES device-to-device copies in one launch (the pieces of a packed host transfer to / from their buffers)
+#define ORBX_COPY_PIECES 24
+struct OrbxCopyPieces { void *dst[ORBX_COPY_PIECES]; const void *src[ORBX_COPY_PIECES]; unsigned bytes[ORBX_COPY_PIECES]; int n; };
+hipError_t orbxLaunchCopyPieces(hipStream_t st, const OrbxCopyPieces &p);
 // a batch of frames through the SearchByProjection kernels: per-frame strides (records) and device-side counts
 struct OrbxSbpBatch { int nframes; long long kcStride, projStride; const int *ncDev, *npDev; };
 #define ORBX_SBP_CAP 512  // == SBP_CAP in orbx_match.hip

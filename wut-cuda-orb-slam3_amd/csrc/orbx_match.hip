@@ -2426,6 +2426,29 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
 }
 
 
+// the pieces of a packed host transfer: blockIdx.y = piece, 16-byte vectors where both ends are aligned
+__global__ __launch_bounds__(256) void k_copy_pieces(OrbxCopyPieces p)
+{
+    const int pc = blockIdx.y;
+    uint8_t *dst = (uint8_t *)p.dst[pc];
+    const uint8_t *src = (const uint8_t *)p.src[pc];
+    const size_t bytes = p.bytes[pc];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        const size_t nv = bytes >> 4;
+        for (size_t i = t; i < nv; i += nt) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+        for (size_t i = (nv << 4) + t; i < bytes; i += nt) dst[i] = src[i];
+    } else {
+        for (size_t i = t; i < bytes; i += nt) dst[i] = src[i];
+    }
+}
+hipError_t orbxLaunchCopyPieces(hipStream_t st, const OrbxCopyPieces &p)
+{
+    if (p.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_pieces, dim3(16, p.n), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 // nmatches of a batch: result[2 p] (count) / result[2 p + 1] (candidate-list overflow) -> out[p] = count or -1
 __global__ void k_sbp_gather(const int *result, int n, int *out)
 {
