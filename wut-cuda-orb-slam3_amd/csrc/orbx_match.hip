@@ -941,8 +941,22 @@ __device__ __forceinline__ int mt_excl_scan(int v, int &total)
 // One wave per frame: cell = ix * GRID_ROWS + iy of every keypoint (PosInGrid: std::round, half away from zero; -1 outside),
 // counts, exclusive prefix (cellStart[GRID_CELLS + 1]) and the items of every cell in push_back order (increasing index).
 // blockIdx.x = frame of a batch: keypoints / items / cellOf advance by kpStride records, cellStart by GRID_CELLS + 1, n = nDev[frame]
-__global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBounds b, int *cellStart, int *items, int *cellOf, long long kpStride,
-                                                   const int *nDev)
+// Ordering point of a SINGLE-WAVE workgroup whose lanes talk through LDS: the wave's LDS operations execute in order, so it is enough
+// to wait for them and to keep the compiler from moving LDS accesses across.  __syncthreads() also waits for the wave's global
+// STORES (s_waitcnt vmcnt(0)) - a write acknowledgement (~1 us) per step of a loop that stores one result per step.
+__device__ __forceinline__ void mt_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define GB_LDS_N 8192
+#define GB_NT 256  // four waves for the parallel parts (cells of the keypoints, prefix over the 3072 cells); the ordered placement is wave 0's
+static_assert(GRID_CELLS % GB_NT == 0, "k_grid_build: cells per thread");
+__global__ __launch_bounds__(GB_NT) void k_grid_build(const MtKp *k, int n, GridBounds b, int *cellStart, int *items, int *cellOf, long long kpStride,
+                                                      const int *nDev)
 {
     {
         const size_t p = blockIdx.x;
@@ -951,47 +965,65 @@ __global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBou
     }
     __shared__ int cnt[GRID_CELLS];
     __shared__ int occ[GRID_CELLS];  // keypoints of the current 64 per cell
-    const int lane = threadIdx.x;
-    for (int c = lane; c < GRID_CELLS; c += 64) { cnt[c] = 0; occ[c] = 0; }
+    // cells of the first GB_LDS_N keypoints (0xFFFF: outside the grid) for the placement loop
+    __shared__ uint16_t cellL[GB_LDS_N];
+    __shared__ int waveTot[GB_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < GRID_CELLS; c += GB_NT) { cnt[c] = 0; occ[c] = 0; }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 256) {  // (one wave: four independent loads per step instead of a memory latency per 64 keypoints)
+    for (int i0 = 0; i0 < n; i0 += 4 * GB_NT) {  // four independent loads per thread and step
         float vx[4], vy[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = min(i0 + 64 * u + lane, n - 1); vx[u] = k[i].x; vy[u] = k[i].y; }
+        for (int u = 0; u < 4; ++u) { const int i = min(i0 + GB_NT * u + tid, n - 1); vx[u] = k[i].x; vy[u] = k[i].y; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 64 * u + lane;
+            const int i = i0 + GB_NT * u + tid;
             if (i < n) {
                 const int px = (int)roundf(__fmul_rn(__fsub_rn(vx[u], b.minX), b.invW));
                 const int py = (int)roundf(__fmul_rn(__fsub_rn(vy[u], b.minY), b.invH));
                 const int c = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
                 cellOf[i] = c;
+                if (i < GB_LDS_N) cellL[i] = (uint16_t)c;
                 if (c >= 0) atomicAdd(&cnt[c], 1);
             }
         }
     }
     __syncthreads();
-    int base = 0;
-    for (int cb = 0; cb < GRID_CELLS; cb += 64) {
+    {   // exclusive prefix over the cells: a run of consecutive cells per thread, wave scan over the runs, wave totals through LDS
+        constexpr int CPT = GRID_CELLS / GB_NT;
+        int v[CPT], sum = 0;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { v[j] = cnt[tid * CPT + j]; sum += v[j]; }
         int total;
-        const int v = cnt[cb + lane];
-        const int o = base + mt_excl_scan(v, total);
-        cellStart[cb + lane] = o;
-        cnt[cb + lane] = o;  // becomes the write cursor of the cell
-        base += total;
+        int o = mt_excl_scan(sum, total);
+        if (lane == 0) waveTot[wave] = total;
+        __syncthreads();
+        int all = 0;
+        for (int w = 0; w < GB_NT / 64; ++w) { const int t = waveTot[w]; if (w < wave) o += t; all += t; }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            cellStart[tid * CPT + j] = o;
+            cnt[tid * CPT + j] = o;  // becomes the write cursor of the cell
+            o += v[j];
+        }
+        if (tid == 0) cellStart[GRID_CELLS] = all;
     }
-    if (lane == 0) cellStart[GRID_CELLS] = base;
     __syncthreads();
+    if (wave != 0) return;
     // stable placement: 64 keypoints per step in index order.  A keypoint that is alone in its cell among these 64 (nearly all of them)
     // goes straight to the cell's cursor; lanes that share a cell are ranked by lane, one cell per round.
     for (int ib = 0; ib < n; ib += 64) {
         const int i = ib + lane;
-        const int c = i < n ? cellOf[i] : -1;
+        int c = -1;
+        if (i < n) {
+            if (i < GB_LDS_N) { const int cl = cellL[i]; c = cl == 0xFFFF ? -1 : cl; }
+            else c = cellOf[i];
+        }
         if (c >= 0) atomicAdd(&occ[c], 1);
-        __syncthreads();
+        mt_wave_sync();
         const bool alone = c >= 0 && occ[c] == 1;
         if (alone) { items[cnt[c]] = i; cnt[c] += 1; }
-        __syncthreads();
+        mt_wave_sync();
         if (c >= 0) occ[c] = 0;
         unsigned long long todo = __ballot(c >= 0 && !alone);
         while (todo) {
@@ -999,9 +1031,9 @@ __global__ __launch_bounds__(64) void k_grid_build(const MtKp *k, int n, GridBou
             const int cl = __shfl(c, leader);
             const unsigned long long same = __ballot(c == cl);
             if (c == cl) items[cnt[cl] + __popcll(same & ((1ull << lane) - 1ull))] = i;
-            __syncthreads();
+            mt_wave_sync();
             if (lane == leader) cnt[cl] += __popcll(same);
-            __syncthreads();
+            mt_wave_sync();
             todo &= ~same;
         }
     }
@@ -1656,7 +1688,7 @@ hipError_t orbxLaunchGridBuild(hipStream_t st, const void *k, int n, float minX,
     b.minX = minX; b.minY = minY;
     b.invW = (float)GRID_COLS / (maxX - minX); b.invH = (float)GRID_ROWS / (maxY - minY);
     if (nframes <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_grid_build, dim3(nframes), dim3(64), 0, st, (const MtKp *)k, n, b, cellStart, items, cellOf, kpStride, nDev);
+    hipLaunchKernelGGL(k_grid_build, dim3(nframes), dim3(GB_NT), 0, st, (const MtKp *)k, n, b, cellStart, items, cellOf, kpStride, nDev);
     return hipGetLastError();
 }
 
