@@ -2170,6 +2170,7 @@ extern "C" int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyfram
     memcpy(h.camL, g->cam_left, sizeof h.camL); memcpy(h.camR, g->cam_right, sizeof h.camR); h.precision = g->precision;
     memcpy(h.R, g->R, sizeof h.R); memcpy(h.t, g->t, sizeof h.t);
     h.matches = dMatches; h.binOf = binOf; h.result = result;
+    for (int j = 0; j < kf1->nfv; ++j) h.maxPerNode1 = std::max(h.maxPerNode1, kf1->fv_start[j + 1] - kf1->fv_start[j]);
     if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchSearchForTriangulation(st, h));
     int nmatches = 0;

@@ -173,6 +173,7 @@ struct OrbxSftHost {
     float ep[2], F[9]; int model, rig, onlyStereo, coarse, checkOri;
     float camL[8], camR[8], precision, R[4][9], t[4][3];
     int *matches, *binOf, *result;
+    int maxPerNode1;  // most features of pKF1 under one node (the launch's second dimension)
 };
 hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h);
 hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
