@@ -47,3 +47,9 @@ start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
 dd = rng.integers(0, 256, (int(start[-1]), 32), dtype=np.uint8)
 print(f"ComputeDistinctiveDescriptors 5000 map points, {int(start[-1])} observations: GPU {bench(lambda: m.ComputeDistinctiveDescriptors(dd, start)):.3f} ms, "
       f"oracle {bench(lambda: orc.distinctive_descriptors(dd, start), 3):.3f} ms")
+valid = np.ones(len(k1), np.uint8)
+for lv in (2, 3):  # levelsup 2: ~100 nodes (ORB-SLAM3 uses 4 of 6 levels: ~100 nodes for 1000-2000 features); 3: ~10 nodes
+    f1, f2 = voc.transform(d1, lv), voc.transform(d2, lv)
+    print(f"SearchByBoW(KeyFrame, Frame) {len(k1)} x {len(k2)} features, {len(f1['fv_node'])} nodes: GPU "
+          f"{bench(lambda: m.SearchByBoW(f1, k1, d1, valid, f2, k2, d2, 0.7, True)):.3f} ms, "
+          f"oracle {bench(lambda: orc.search_by_bow(f1, k1, d1, valid, f2, k2, d2, 0.7, True), 5):.3f} ms")

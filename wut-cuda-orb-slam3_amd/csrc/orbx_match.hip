@@ -567,6 +567,7 @@ struct StereoBatch {
 // the band [floor(y - r), ceil(y + r)] of every right keypoint into LDS row counters, scans them, and fills the lists with LDS cursors.
 // The lists are unordered - the search below does not depend on the visiting order (see there).
 __device__ __forceinline__ int mt_excl_scan(int v, int &total);
+__device__ __forceinline__ unsigned mt_wave_min_u32(unsigned v);
 
 __global__ __launch_bounds__(256) void k_stereo_buckets(const MtKp *kr, int nr, int nRows, const float *scale, int *rowStart, int *rowItems,
                                                         int itemStride, StereoBatch sb)
@@ -1300,8 +1301,7 @@ __global__ __launch_bounds__(64) void k_si_topk(SearchInitArgs a, uint32_t *topA
             const uint32_t v = keys[j];
             if ((k == 0 || v > last) && v < mn) mn = v;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        mn = mt_wave_min_u32(mn);
         if (lane == 0) top[k] = mn;
         last = mn;
         if (mn == SI_KEY_NONE) {
@@ -2775,80 +2775,126 @@ struct SbowArgs {
     int *result;   // [0] nmatches, [1 .. 30] rotation histogram
 };
 
-__device__ __forceinline__ unsigned sbow_wave_min(unsigned v)
+// minimum over the wave (all 64 lanes active, result wave-uniform) without the LDS crossbar: four DPP steps leave each row's minimum
+// in its lanes, the four rows are merged as scalars - a ds_bpermute round trip per step (__shfl_xor) made two minima cost ~1000 cycles
+// of a dependent loop
+__device__ __forceinline__ unsigned mt_wave_min_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
+    int x = (int)v;
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));  // row_mirror
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane(x, 0), r1 = (unsigned)__builtin_amdgcn_readlane(x, 16),
+                   r2 = (unsigned)__builtin_amdgcn_readlane(x, 32), r3 = (unsigned)__builtin_amdgcn_readlane(x, 48);
+    return min(min(r0, r1), min(r2, r3));
 }
 
+// The walk over a node's keyframe features is sequential (a frame feature taken by one is gone for the next), so nothing inside it may
+// wait for memory: the node's frame features (index, angle, taken flag) are staged in LDS and the descriptors of its first 256 in
+// registers; the keyframe features are loaded 64 at a time, a lane each (index, validity, angle, descriptor), and handed to the walk
+// with v_readlane.  (One dependent global round trip per keyframe feature - its index, then its flag and descriptor, then on a match
+// the frame feature's index and both angles - made a node of 200 features take 0.9 ms.)
+#define SBOW_LDS_F 2048   // frame features of a node whose index / angle live in LDS (beyond: global reads)
+#define SBOW_REG_F 4      // chunks of 64 frame features whose descriptors live in registers
 __global__ __launch_bounds__(64) void k_sbow_match(SbowArgs a)
 {
     const int TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
     extern __shared__ uint8_t taken[];        // per frame feature of this node: already holds a map point
+    __shared__ int fReal[SBOW_LDS_F];
+    __shared__ float fAng[SBOW_LDS_F];
     const int j = blockIdx.x, lane = threadIdx.x;
     const int node = a.kfNode[j];
     int lo = 0, hi = a.fNfv;  // the merge of the two maps only ever pairs equal node ids
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fNode[mid] < node) lo = mid + 1; else hi = mid; }
     if (lo >= a.fNfv || a.fNode[lo] != node) return;
     const int fs = a.fStart[lo], nFn = a.fStart[lo + 1] - fs;
-    for (int i = lane; i < nFn; i += 64) taken[i] = a.mode == 1 && !a.fValid[a.fFeat[fs + i]] ? 1 : 0;  // (mode 1: !pMP2 || isBad())
-    uint32_t d0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int realF0 = -1;
-    if (lane < nFn) {
-        realF0 = a.fFeat[fs + lane];
+    uint32_t dF[SBOW_REG_F][8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) d0[w] = ((const uint32_t *)(a.fDesc + (size_t)realF0 * 32))[w];
+    for (int c = 0; c < SBOW_REG_F; ++c) {
+        const int iF = 64 * c + lane;
+        int r = -1;
+        if (iF < nFn) r = a.fFeat[fs + iF];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dF[c][w] = r >= 0 ? ((const uint32_t *)(a.fDesc + (size_t)r * 32))[w] : 0u;
+        if (r >= 0) { fReal[iF] = r; fAng[iF] = a.fKeys[r].angle; taken[iF] = a.mode == 1 && !a.fValid[r] ? 1 : 0; }  // (mode 1: !pMP2 || isBad())
     }
-    __syncthreads();
+    for (int iF = 64 * SBOW_REG_F + lane; iF < nFn; iF += 64) {
+        const int r = a.fFeat[fs + iF];
+        if (iF < SBOW_LDS_F) { fReal[iF] = r; fAng[iF] = a.fKeys[r].angle; }
+        taken[iF] = a.mode == 1 && !a.fValid[r] ? 1 : 0;
+    }
+    mt_wave_sync();
     const unsigned NONE = (256u << 16) | 0xFFFFu;
     const float factor = 1.0f / HISTO_LENGTH;
-    for (int iKF = a.kfStart[j]; iKF < a.kfStart[j + 1]; ++iKF) {
-        const int realIdxKF = a.kfFeat[iKF];
-        if (!a.kfValid[realIdxKF]) continue;  // !pMP || pMP->isBad()
-        uint32_t q[8];
+    const int kEnd = a.kfStart[j + 1];
+    for (int kb = a.kfStart[j]; kb < kEnd; kb += 64) {
+        // this lane's keyframe feature of the block
+        int myIdx = -1, myValid = 0;
+        float myAng = 0.f;
+        uint32_t myQ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (kb + lane < kEnd) {
+            myIdx = a.kfFeat[kb + lane];
+            myValid = a.kfValid[myIdx] ? 1 : 0;  // pMP && !pMP->isBad()
+            myAng = a.kfKeys[myIdx].angle;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.kfDesc + (size_t)realIdxKF * 32))[w];
-        unsigned k1 = NONE, k2 = NONE;  // this lane's smallest and second smallest key
-        if (lane < nFn && !taken[lane]) {
-            int dist = 0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ d0[w]);
-            k1 = ((unsigned)dist << 16) | (unsigned)lane;
+            for (int w = 0; w < 8; ++w) myQ[w] = ((const uint32_t *)(a.kfDesc + (size_t)myIdx * 32))[w];
         }
-        for (int c0 = 64; c0 < nFn; c0 += 64) {
-            const int iF = c0 + lane;
-            if (iF < nFn && !taken[iF]) {
-                const uint32_t *t = (const uint32_t *)(a.fDesc + (size_t)a.fFeat[fs + iF] * 32);
-                int dist = 0;
+        const int cnt = min(64, kEnd - kb);
+        for (int t = 0; t < cnt; ++t) {
+            if (!__builtin_amdgcn_readlane(myValid, t)) continue;  // wave-uniform
+            uint32_t q[8];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ t[w]);
-                const unsigned key = ((unsigned)dist << 16) | (unsigned)iF;
-                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-            }
-        }
-        const unsigned best = sbow_wave_min(k1);
-        const unsigned second = sbow_wave_min(k1 == best ? k2 : k1);  // (keys are unique: the position is part of them)
-        const int bestDist1 = (int)(best >> 16), bestDist2 = (int)(second >> 16);
-        const bool near = a.mode == 0 ? bestDist1 <= TH_LOW : bestDist1 < TH_LOW;  // (:352 `<=`, ORBmatcher2.cc:127 `<`)
-        if (near && (float)bestDist1 < __fmul_rn(a.nnratio, (float)bestDist2)) {
-            const int pos = (int)(best & 0xFFFFu);
-            if (lane == 0) {
-                const int bestIdxF = a.fFeat[fs + pos];
-                taken[pos] = 1;
-                const int slot = a.mode == 0 ? bestIdxF : realIdxKF;  // vpMapPointMatches[bestIdxF] / vpMatches12[idx1]
-                a.matches[slot] = a.mode == 0 ? realIdxKF : bestIdxF;
-                if (a.checkOri) {
-                    float rot = __fsub_rn(a.kfKeys[realIdxKF].angle, a.fKeys[bestIdxF].angle);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    int bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == HISTO_LENGTH) bin = 0;
-                    a.binOf[slot] = bin;
-                    atomicAdd(&a.result[1 + bin], 1);
+            for (int w = 0; w < 8; ++w) q[w] = (uint32_t)__builtin_amdgcn_readlane((int)myQ[w], t);
+            unsigned k1 = NONE, k2 = NONE;  // this lane's smallest and second smallest key
+#pragma unroll
+            for (int c = 0; c < SBOW_REG_F; ++c) {
+                const int iF = 64 * c + lane;
+                if (64 * c < nFn && iF < nFn && !taken[iF]) {
+                    int dist = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ dF[c][w]);
+                    const unsigned key = ((unsigned)dist << 16) | (unsigned)iF;
+                    if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
                 }
-                atomicAdd(&a.result[0], 1);
             }
-            __syncthreads();  // (one wave) the next keyframe feature must see taken[pos]
+            for (int c0 = 64 * SBOW_REG_F; c0 < nFn; c0 += 64) {
+                const int iF = c0 + lane;
+                if (iF < nFn && !taken[iF]) {
+                    const int r = iF < SBOW_LDS_F ? fReal[iF] : a.fFeat[fs + iF];
+                    const uint32_t *tt = (const uint32_t *)(a.fDesc + (size_t)r * 32);
+                    int dist = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ tt[w]);
+                    const unsigned key = ((unsigned)dist << 16) | (unsigned)iF;
+                    if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                }
+            }
+            const unsigned best = mt_wave_min_u32(k1);
+            const unsigned second = mt_wave_min_u32(k1 == best ? k2 : k1);  // (keys are unique: the position is part of them)
+            const int bestDist1 = (int)(best >> 16), bestDist2 = (int)(second >> 16);
+            const bool near = a.mode == 0 ? bestDist1 <= TH_LOW : bestDist1 < TH_LOW;  // (:352 `<=`, ORBmatcher2.cc:127 `<`)
+            if (near && (float)bestDist1 < __fmul_rn(a.nnratio, (float)bestDist2)) {
+                const int pos = (int)(best & 0xFFFFu);
+                const int realIdxKF = __builtin_amdgcn_readlane(myIdx, t);
+                const float ang1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myAng), t));
+                if (lane == 0) {
+                    const int bestIdxF = pos < SBOW_LDS_F ? fReal[pos] : a.fFeat[fs + pos];
+                    taken[pos] = 1;
+                    const int slot = a.mode == 0 ? bestIdxF : realIdxKF;  // vpMapPointMatches[bestIdxF] / vpMatches12[idx1]
+                    a.matches[slot] = a.mode == 0 ? realIdxKF : bestIdxF;
+                    if (a.checkOri) {
+                        float rot = __fsub_rn(ang1, pos < SBOW_LDS_F ? fAng[pos] : a.fKeys[bestIdxF].angle);
+                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                        int bin = (int)roundf(__fmul_rn(rot, factor));
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        a.binOf[slot] = bin;
+                        atomicAdd(&a.result[1 + bin], 1);
+                    }
+                    atomicAdd(&a.result[0], 1);
+                }
+                mt_wave_sync();  // (one wave) the next keyframe feature must see taken[pos]
+            }
         }
     }
 }
@@ -2991,7 +3037,7 @@ __global__ __launch_bounds__(64) void k_sft_match(SftArgs a)
             }
             if (ok) key = min(key, ((unsigned)dist << 16) | (unsigned)(0xFFFF - p2));
         }
-        const unsigned best = sbow_wave_min(key);
+        const unsigned best = mt_wave_min_u32(key);
         if (best != NONE && lane == 0) {
             const int bestIdx2 = a.feat2[s2 + (0xFFFF - (int)(best & 0xFFFFu))];
             a.matches[idx1] = bestIdx2;
@@ -3192,7 +3238,7 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint8_t *desc, const i
         }
         key = min(key, ((unsigned)lo << 16) | (unsigned)min(i, 0xFFFF));
     }
-    key = sbow_wave_min(key);
+    key = mt_wave_min_u32(key);
     if (lane == 0) best[p] = (int)(key & 0xFFFFu);
 }
 
