@@ -204,3 +204,19 @@ def test_knn2_other_scans_in_subprocess(pkg, variant):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+def test_knn2_large_sets_take_the_direct_transfers(pkg, orc):
+    """A call's host arrays cross the link packed into one transfer - except pieces above 256 KB, which go straight to their buffers:
+    12000 x 9000 descriptors (384 KB and 288 KB of input, 96 KB per result array) against the oracle, then a small call on the same
+    matcher (its staging has been used by neither of the large inputs)."""
+    rng = np.random.default_rng(991)
+    q, t = _desc(rng, 12000), _desc(rng, 9000, dup=0.1)
+    m = pkg.ORBmatcher(16384, 16384)
+    idx, dist = m.knnMatch(q, t)
+    ridx, rdist = orc.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    idx, dist = m.knnMatch(q[:300], t[:700])
+    ridx, rdist = orc.knn2(q[:300], t[:700])
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    m.close()

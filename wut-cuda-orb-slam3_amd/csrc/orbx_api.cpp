@@ -109,6 +109,7 @@ struct orbx_extractor {
     hipEvent_t evCopy[8] = {};
     hipStream_t streamOut = nullptr;        // host-pointer API: D2H of sub-batch i's results under the kernels / H2D of the following ones
     hipEvent_t evBack[8] = {}, evOut[8] = {}, evIn = nullptr;
+    hipEvent_t evCopy0[8] = {};             // ORBX_HOST_TIMELINE: start of sub-batch i's input copy
     uint8_t *h_stage = nullptr; size_t h_stageBytes = 0;  // page-locked staging of a whole batch's results (counts, keypoints, descriptors)
     hipEvent_t evLevel[ORBX_MAX_LEVELS] = {};    // level l of the pyramid is complete (recorded after pyr_fast(l-1))
 
@@ -190,6 +191,12 @@ static inline long long blurFrameBytes(const OrbxLevelGeom &g) { return (long lo
 
 static int computeGeometry(orbx_extractor *ex, int w, int h);
 static int ensureBuffers(orbx_extractor *ex);
+
+static bool hostTimeline()
+{
+    static const bool v = [] { const char *e = getenv("ORBX_HOST_TIMELINE"); return e && atoi(e) != 0; }();
+    return v;
+}
 
 extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
 {
@@ -278,14 +285,18 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
         if (e == hipSuccess) e = mode ? hipStreamCreateWithPriority(&ex->stream3, hipStreamNonBlocking, prLo) : hipStreamCreateWithFlags(&ex->stream3, hipStreamNonBlocking);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evJoin, hipEventDisableTiming);
+    // ORBX_HOST_TIMELINE=1 (debug): the events of the host-pointer pipeline keep time stamps and every orbx_extract_batch call prints
+    // when each sub-batch's copy in, kernels and copy out started / ended (stderr; tools/time_host_batch.py --timeline)
+    const unsigned pipeFlags = hostTimeline() ? hipEventDefault : hipEventDisableTiming;
     for (int i = 0; i < 8 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&ex->evFront[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBlur[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evCopy[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBack[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evOut[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evCopy[i], pipeFlags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evCopy0[i], pipeFlags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBack[i], pipeFlags);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evOut[i], pipeFlags);
     }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evIn, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evIn, pipeFlags);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->streamCopy, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->streamOut, hipStreamNonBlocking);
     for (int i = 0; i < ORBX_MAX_LEVELS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ex->evLevel[i], hipEventDisableTiming);
@@ -315,6 +326,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
         if (ex->evFront[i]) (void)hipEventDestroy(ex->evFront[i]);
         if (ex->evBlur[i]) (void)hipEventDestroy(ex->evBlur[i]);
         if (ex->evCopy[i]) (void)hipEventDestroy(ex->evCopy[i]);
+        if (ex->evCopy0[i]) (void)hipEventDestroy(ex->evCopy0[i]);
         if (ex->evBack[i]) (void)hipEventDestroy(ex->evBack[i]);
         if (ex->evOut[i]) (void)hipEventDestroy(ex->evOut[i]);
     }
@@ -1266,6 +1278,7 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
                         ORBX_API_ENTRY;
                         int rcf = hipSetDevice(ex->prm.device) == hipSuccess ? ORBX_OK : setError(ORBX_ERR_HIP, "hipSetDevice failed in the copy thread");
                         for (int k = 0; k < nsub; ++k) {
+                            if (rcf == ORBX_OK && hostTimeline()) (void)hipEventRecord(ex->evCopy0[k], ex->streamCopy);
                             if (rcf == ORBX_OK) rcf = stageHostFrames(ex, dIn, stride, frame_stride, host, pipe->f0[k], pipe->nf[k], nframes, w, h, ex->streamCopy);
                             if (rcf == ORBX_OK && hipEventRecord(ex->evCopy[k], ex->streamCopy) != hipSuccess) rcf = setError(ORBX_ERR_HIP, "hipEventRecord failed in the copy thread");
                             std::lock_guard<std::mutex> lk(pipe->mu);
@@ -1281,6 +1294,7 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
                 pipe->cv.wait(lk, [&] { return pipe->staged > sb; });
                 if (pipe->feederRc != ORBX_OK) { g_lastError = pipe->feederErr; return pipe->feederRc; }
             } else {
+                if (hostTimeline()) (void)hipEventRecord(ex->evCopy0[sb], ex->streamCopy);
                 const int rcs = stageHostFrames(ex, dIn, stride, frame_stride, host, f0, nf, nframes, w, h, ex->streamCopy);
                 if (rcs != ORBX_OK) return rcs;
                 HIP_TRY(hipEventRecord(ex->evCopy[sb], ex->streamCopy));
@@ -1551,6 +1565,13 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
     rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
     if (rc == ORBX_OK) rc = pipeDrain(ex, &hf, true, pipe.nsub);
     if (rc != ORBX_OK) (void)hipStreamSynchronize(ex->streamOut);  // nothing of this call may still be writing into the caller's arrays
+    if (rc == ORBX_OK && hostTimeline()) {
+        auto at = [&](hipEvent_t e) { float ms = -1.f; (void)hipEventElapsedTime(&ms, ex->evIn, e); return ms; };
+        fprintf(stderr, "[orbx] host batch of %d frames in %d sub-batches (ms since the call's first event):\n", nframes, pipe.nsub);
+        for (int k = 0; k < pipe.nsub; ++k)
+            fprintf(stderr, "[orbx]   sub-batch %d (%4d frames): copy in %6.3f - %6.3f | kernels done %6.3f | results out %6.3f\n", k, pipe.nf[k],
+                    at(ex->evCopy0[k]), at(ex->evCopy[k]), at(ex->evBack[k]), at(ex->evOut[k]));
+    }
     return rc;  // (~HostPipe joins the copy thread)
 }
 
