@@ -145,7 +145,8 @@ struct orbx_extractor {
     struct GraphKey { const void *src; int nframes, w, h; long long stride, frameStride; int lap0, lap1, generation; };
     // a few captured sequences, least recently used replaced: a caller that alternates two or three source buffers (a camera ring) or
     // lapping areas must not re-capture on every call (capture + instantiate run under the process-wide setup lock)
-    static const int kGraphSlots = 4;        // = the slots of the per-level argument blocks (pfArgsKey)
+    static const int kGraphSlots = 4;        // graph slot k owns the per-level argument block k (pfArgsKey[k]): a captured sequence has
+                                             // the block's address baked in, so the block may only change with the graph of its slot
     hipGraphExec_t graphExec[kGraphSlots] = {};
     GraphKey graphKey[kGraphSlots] = {};
     unsigned long long graphUse[kGraphSlots] = {}, graphClock = 0;
@@ -157,7 +158,7 @@ struct orbx_extractor {
     // per-level argument blocks of k_pyr_fast<.., ML> (small batches: FAST of all levels in one launch), a few source buffers cached
     struct LevelArgsKey { const void *src; int nframes; long long stride, frameStride; int generation, iniTh, minTh; };
     DevBuf<uint8_t> d_pfArgs;
-    LevelArgsKey pfArgsKey[4] = {};
+    LevelArgsKey pfArgsKey[2 * kGraphSlots] = {};  // [0, kGraphSlots): the graphs' blocks; the rest: calls without a graph, round robin
     int pfArgsNext = 0;
     const void *curLevelArgs = nullptr;      // the slot the next issueSmallBatch uses
 
@@ -970,23 +971,25 @@ static int smallBatchPrepare(orbx_extractor *ex)
 // outside a stream capture.
 static const bool kSmallSplit = [] { const char *e = getenv("ORBX_SMALL_SPLIT"); return e ? atoi(e) != 0 : true; }();
 
-static int prepareLevelArgs(orbx_extractor *ex, const uint8_t *src0, int nf, ptrdiff_t stride, ptrdiff_t frame_stride)
+// graphSlot >= 0: the block of that graph slot (rewritten when it holds another call signature - the caller replaces the graph with it);
+// -1: a call without a graph looks its signature up among the other blocks, round robin on a miss
+static int prepareLevelArgs(orbx_extractor *ex, const uint8_t *src0, int nf, ptrdiff_t stride, ptrdiff_t frame_stride, int graphSlot)
 {
     ex->curLevelArgs = nullptr;
     if (!kSmallSplit) return ORBX_OK;
-    const int nl = ex->prm.nlevels;
+    const int nl = ex->prm.nlevels, G = orbx_extractor::kGraphSlots;
     const size_t blk = orbxPyrFastArgsBytes(), slotBytes = blk * ORBX_MAX_LEVELS;
-    int rc = ex->d_pfArgs.ensure(4 * slotBytes);
+    int rc = ex->d_pfArgs.ensure(2 * G * slotBytes);
     if (rc != ORBX_OK) return rc;
     orbx_extractor::LevelArgsKey key;
     memset(&key, 0, sizeof key);
     key.src = src0; key.nframes = nf; key.stride = stride; key.frameStride = frame_stride; key.generation = ex->generation;
     key.iniTh = ex->prm.ini_th_fast; key.minTh = ex->prm.min_th_fast;
-    for (int k = 0; k < 4; ++k)
+    for (int k = graphSlot >= 0 ? graphSlot : G; k < (graphSlot >= 0 ? graphSlot + 1 : 2 * G); ++k)
         if (memcmp(&key, &ex->pfArgsKey[k], sizeof key) == 0) { ex->curLevelArgs = ex->d_pfArgs.p + k * slotBytes; return ORBX_OK; }
     ORBX_SETUP_LOCK;
-    const int slot = ex->pfArgsNext;
-    ex->pfArgsNext = (slot + 1) & 3;
+    int slot = graphSlot;
+    if (slot < 0) { slot = G + ex->pfArgsNext; ex->pfArgsNext = (ex->pfArgsNext + 1) % G; }
     std::vector<uint8_t> host(slotBytes, 0);
     for (int l = 0; l < nl; ++l) {
         const OrbxLevelGeom &g = ex->geom[l];
@@ -1143,9 +1146,12 @@ static hipError_t issueSmallBatch(orbx_extractor *ex, const uint8_t *src0, int n
 static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1,
                          bool useGraph)
 {
-    int rcl = prepareLevelArgs(ex, src0, nf, stride, frame_stride);  // (before any capture: it may copy synchronously)
-    if (rcl != ORBX_OK) return rcl;
-    if (!useGraph) { HIP_TRY(issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1)); return ORBX_OK; }
+    if (!useGraph) {
+        const int rcl = prepareLevelArgs(ex, src0, nf, stride, frame_stride, -1);
+        if (rcl != ORBX_OK) return rcl;
+        HIP_TRY(issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1));
+        return ORBX_OK;
+    }
     orbx_extractor::GraphKey key;
     memset(&key, 0, sizeof key);  // (padding bytes: the keys are compared with memcmp)
     key.src = src0; key.nframes = nf; key.w = w; key.h = h; key.stride = (long long)stride; key.frameStride = (long long)frame_stride;
@@ -1153,7 +1159,8 @@ static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w,
     int slot = -1;
     for (int k = 0; k < orbx_extractor::kGraphSlots; ++k)
         if (ex->graphExec[k] && memcmp(&key, &ex->graphKey[k], sizeof key) == 0) { slot = k; break; }
-    if (slot < 0) {
+    const bool hit = slot >= 0;
+    if (!hit) {
         ORBX_SETUP_LOCK;
         slot = 0;  // an empty slot, else the least recently used one
         for (int k = 0; k < orbx_extractor::kGraphSlots; ++k) {
@@ -1166,6 +1173,16 @@ static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w,
             (void)hipGraphExecDestroy(ex->graphExec[slot]);
             ex->graphExec[slot] = nullptr;
         }
+    }
+    // the per-level argument block of THIS slot (a hit finds it unchanged; before any capture: a rewrite copies synchronously).  The
+    // blocks used to be a cache of their own with a replacement order of its own: a graph that stayed cached while its block was
+    // handed to another source then read that source's frame (six buffers visited in turn: wrong keypoints for the third one).
+    {
+        const int rcl = prepareLevelArgs(ex, src0, nf, stride, frame_stride, slot);
+        if (rcl != ORBX_OK) return rcl;
+    }
+    if (!hit) {
+        ORBX_SETUP_LOCK;
         HIP_TRY(hipStreamBeginCapture(ex->stream, hipStreamCaptureModeRelaxed));
         const hipError_t ie = issueSmallBatch(ex, src0, nf, stride, frame_stride, lap0, lap1);
         hipGraph_t graph = nullptr;
