@@ -245,3 +245,33 @@ def test_resolve_list_entries_in_lds_in_subprocess(pkg, entries):
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+def test_search_by_projection_large_frame(pkg, orc):
+    """12000 keypoints and 12000 projections on a fresh matcher: the call's packed input (1.5 MB) outgrows the page-locked staging
+    while it is being filled (the pieces packed so far move with it), the owner arrays take 94 KB of the resolve kernel's LDS and no
+    list entries fit behind them; then the same matcher takes a small frame again."""
+    rng = np.random.default_rng(4242)
+    n = 12000
+    k2 = np.zeros(n, pkg.KEYPOINT_DTYPE)
+    k2["x"] = rng.uniform(20, 1220, n).astype(np.float32); k2["y"] = rng.uniform(20, 350, n).astype(np.float32)
+    k2["octave"] = rng.integers(0, 8, n); k2["angle"] = rng.uniform(0, 360, n).astype(np.float32); k2["size"] = 31
+    d2 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    src = rng.permutation(n)
+    pr = np.zeros(n, pkg.PROJECTION_DTYPE)
+    pr["u"] = k2["x"][src] + rng.normal(0, 2, n).astype(np.float32); pr["v"] = k2["y"][src] + rng.normal(0, 2, n).astype(np.float32)
+    pr["invz"] = 0.1; pr["angle"] = k2["angle"][src]; pr["octave"] = k2["octave"][src]
+    pr["flags"] = 1 | ((rng.random(n) < 0.7).astype(np.int32) << 1)
+    d1 = d2[src].copy()
+    d1[:, :3] ^= rng.integers(0, 256, (n, 3), dtype=np.uint8)  # ~12 bits away from the true partner
+    state = rng.choice(np.int8([-1, -1, -1, 0, 1]), n)
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    m = pkg.ORBmatcher(16384, 16384)
+    nm, assign = m.SearchByProjection(k2, d2, state, bounds, sf, pr, d1, 15)
+    rn, rassign = orc.search_by_projection(k2, d2, state, bounds, sf, pr, d1, 15)
+    assert nm == rn and np.array_equal(assign, rassign) and nm > 4000
+    nm, assign = m.SearchByProjection(k2[:900], d2[:900], state[:900], bounds, sf, pr[:700], d1[:700], 15)
+    rn, rassign = orc.search_by_projection(k2[:900], d2[:900], state[:900], bounds, sf, pr[:700], d1[:700], 15)
+    assert nm == rn and np.array_equal(assign, rassign)
+    m.close()
