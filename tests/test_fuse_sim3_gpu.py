@@ -204,3 +204,42 @@ def test_projection_keyframe_matches_oracle(pkg, orc, n, np_, dense, dist, check
     ref = orc.search_by_projection_keyframe(k, d, BOUNDS, pts, pd, pa, has, dist, check)
     assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[0] == int((got[1] >= 0).sum()) and got[0] > 30
     m.close()
+
+
+@pytest.mark.gpu
+def test_projection_rounds_on_the_host_in_subprocess(pkg):
+    """Both projection searches run their rounds inside one launch (sorted candidate lists + k_sbp_resolve); a window with more than 512
+    candidates falls back to rounds of the window search with a round trip each.  ORBX_PROJECTION_HOST_ROUNDS (read once per process)
+    forces that fallback: the two parity tests above once more under it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ORBX_PROJECTION_HOST_ROUNDS"):
+        pytest.skip("already the forced run")
+    env = dict(os.environ, ORBX_PROJECTION_HOST_ROUNDS="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "projection and matches_oracle"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_projection_sim3_window_beyond_the_list_capacity(pkg, orc):
+    """600 keypoints inside one window (more than a candidate list holds): the call falls back to the rounds of the window search by
+    itself and still equals the oracle."""
+    rng = np.random.default_rng(77)
+    n = 900
+    k = np.zeros(n, pkg.KEYPOINT_DTYPE)
+    k["x"] = 300 + rng.uniform(-12, 12, n).astype(np.float32); k["y"] = 200 + rng.uniform(-12, 12, n).astype(np.float32)
+    k["x"][600:] = rng.uniform(20, 620, n - 600).astype(np.float32); k["y"][600:] = rng.uniform(20, 460, n - 600).astype(np.float32)
+    k["octave"] = 1; k["size"] = 31
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pts = _points(orc, [(300, 200, 0, 20, 1, 1)] * 40 + [(float(k["x"][i]), float(k["y"][i]), 0, 6, 1, 1) for i in range(600, 700)])
+    src = np.concatenate([rng.integers(0, 600, 40), np.arange(600, 700)])
+    pd = d[src].copy(); pd[:, 0] ^= rng.integers(0, 8, len(src), dtype=np.uint8)
+    matched = np.zeros(n, np.uint8)
+    m = pkg.ORBmatcher(8192, 8192)
+    got = m.SearchByProjectionSim3(k, d, BOUNDS, pts, pd, matched, 1.0, LEVELS)
+    ref = orc.search_by_projection_sim3(k, d, BOUNDS, pts, pd, matched, 1.0)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[0] > 100
+    m.close()

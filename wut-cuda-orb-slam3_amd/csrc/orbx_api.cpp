@@ -2340,6 +2340,44 @@ static int projectionRoundsImpl(const char *fn, orbx_matcher *m, const orbx_keyp
     }
     if (n == 0 || np == 0) return 0;
     HIP_TRY(hipSetDevice(m->device));
+    // The rounds on the device (k_sbp_candidates in its keyframe mode + k_sbp_resolve: sorted candidate lists, the fixed point of "an
+    // earlier accepted point took it" inside one launch, rotation histogram) - unless a window holds more candidates than a list takes:
+    // then the rounds of the window search below (a launch and a round trip per round, no limit).
+    static const bool hostRounds = getenv("ORBX_PROJECTION_HOST_ROUNDS") != nullptr;  // tests: the fallback
+    if (n < 65536 && !hostRounds) {
+        if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;
+        if ((rc = m->d_work.ensure(2 * (size_t)m->maxQ + 3 * (size_t)m->maxT + 2 + 4)) != ORBX_OK) return rc;
+        if ((rc = m->d_sbpCand.ensure((size_t)m->maxQ * ORBX_SBP_CAP)) != ORBX_OK) return rc;
+        int *cs = m->d_grid.p, *it = cs + ORBX_GRID_CELLS + 1, *co = it + m->maxT;
+        int *count = m->d_work.p, *choice = count + m->maxQ, *owner = choice + m->maxQ, *result = owner + 2 * m->maxT, *dAssign = result + 2;
+        std::vector<orbx_projection> pr((size_t)np);
+        for (int i = 0; i < np; ++i) {
+            pr[i].u = points[i].u; pr[i].v = points[i].v; pr[i].invz = points[i].radius; pr[i].angle = point_angle ? point_angle[i] : 0.f;
+            pr[i].octave = points[i].level; pr[i].flags = points[i].search ? 3 : 0;
+        }
+        std::vector<int8_t> blocked((size_t)n, 0);
+        if (matched) for (int i = 0; i < n; ++i) blocked[i] = matched[i] ? 1 : 0;
+        HostPack in(m);
+        const size_t oK = in.add(keys, (size_t)n * sizeof(orbx_keypoint)), oD = in.add(desc, (size_t)n * 32), oB = in.add(blocked.data(), (size_t)n);
+        const size_t oP = in.add(pr.data(), (size_t)np * sizeof(orbx_projection)), oPd = in.add(point_desc, (size_t)np * 32);
+        if ((rc = in.send()) != ORBX_OK) return rc;
+        const orbx_keypoint *dK = in.dev<orbx_keypoint>(oK);
+        HIP_TRY(orbxLaunchGridBuild(m->stream, dK, n, min_x, max_x, min_y, max_y, cs, it, co));
+        HIP_TRY(orbxLaunchSearchByProjection(m->stream, dK, in.dev<uint8_t>(oD), nullptr, in.dev<signed char>(oB), n, cs, it, min_x, max_x, min_y, max_y,
+                                             nullptr, 0.f, in.dev<orbx_projection>(oP), in.dev<uint8_t>(oPd), np, 0.f, 0, 0,
+                                             check_orientation && point_angle ? 1 : 0, 2, 0.f, m->d_sbpCand.p, count, choice, owner, dAssign, result,
+                                             nullptr, level_hi, bound));
+        int res[2] = {0, 0};
+        HostFetch out(m);
+        out.add(res, result, sizeof res);
+        out.add(new_match, dAssign, (size_t)n * sizeof(int));
+        if ((rc = out.finish()) != ORBX_OK) return rc;
+        if (!res[1]) {
+            for (int i = 0; i < n; ++i) if (new_match[i] < 0) new_match[i] = -1;  // (-2: removed by the rotation check)
+            return res[0];
+        }
+        for (int i = 0; i < n; ++i) new_match[i] = -1;  // a list overflowed: the rounds below
+    }
     HostPack in(m);
     if ((rc = uploadQT(in, point_desc, np, desc, n)) != ORBX_OK) return rc;
     if ((rc = m->d_grid.ensure((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)m->maxT)) != ORBX_OK) return rc;

@@ -239,7 +239,8 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
                                         const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
                                         int backward, int checkOri, int mode, float nnratio, uint32_t *cand, int *count, int *choice,
-                                        int *owner, int *assign, int *result, const struct OrbxSbpBatch *batch = nullptr);
+                                        int *owner, int *assign, int *result, const struct OrbxSbpBatch *batch = nullptr, int levelHi = 0,
+                                        float bound = 100.f);  // mode 2 (keyframe-side searches): proj.invz = window radius, levels level - 1 .. level + levelHi
 hipError_t orbxLaunchGatherResults(hipStream_t st, const int *result, int n, int *out);
 // up to ORBX_COPY_PIECES device-to-device copies in one launch (the pieces of a packed host transfer to / from their buffers)
 #define ORBX_COPY_PIECES 24

@@ -1832,6 +1832,11 @@ struct SbpArgs {
     int mode;        // 0: SearchByProjection(Frame, Frame); 1: SearchByProjection(Frame, vector<MapPoint*>) - then SbpProj holds
                      //    u, v = mTrackProjX / Y, invz = mTrackProjXR, angle = mTrackViewCos, octave = mnTrackScaleLevel
     float nnratio;
+    // mode 2: the keyframe-side projection searches (SearchByProjection(KeyFrame, Sim3, ..), SearchByProjection(Frame, KeyFrame, ..)): SbpProj
+    // holds u, v, invz = the window radius, angle = the point's keypoint angle, octave = nPredictedLevel, flags; keypoint levels
+    // nPredictedLevel - 1 .. nPredictedLevel + levelHi; every accepted point keeps its keypoint from the later ones
+    int levelHi;
+    float bound;     // a best distance is accepted iff (float)dist <= bound (TH_HIGH = 100 for the frame searches)
     uint32_t *cand;  // [np][SBP_CAP] index | dist << 16 | octave << 25, sorted by (dist, position in GetFeaturesInArea order)
     int *count;      // [np] list length, -1: point not searched
     int *choice;     // [np] work
@@ -1890,6 +1895,9 @@ __global__ __launch_bounds__(64) void k_sbp_candidates(SbpArgs a)
         if (a.forward) { minLevel = lastOct; maxLevel = -1; }
         else if (a.backward) { minLevel = 0; maxLevel = lastOct; }
         else { minLevel = lastOct - 1; maxLevel = lastOct + 1; }
+    } else if (a.mode == 2) {
+        r = P.invz;
+        minLevel = lastOct - 1; maxLevel = lastOct + a.levelHi;
     } else {
         float rv = (double)P.angle > 0.998 ? 2.5f : 4.0f;  // ORBmatcher::RadiusByViewingCos (src/ORBmatcher1.cc:217-223), a double compare
         if (a.th != 1.0f && side == 0) rv = __fmul_rn(rv, a.th);  // (the right search of a fisheye frame takes no th factor, :147)
@@ -2022,22 +2030,21 @@ extern "C" int orbx_debug_sbp_timing(unsigned long long *out) { return (int)hipM
 struct SbpWalk {
     int best = 256, bestI = -1, best2 = 256, bestL = -1, bestL2 = -1, found = 0;
     bool stop = false;
-    __device__ __forceinline__ bool done(int mode) const { return found >= 2 || stop || (found == 1 && mode == 0); }
-    __device__ __forceinline__ void visit(uint32_t e, int owner, int i, int mode, float nnratio)
+    // (mode 1: the map-point variant with its second best; 0 and 2: the first free entry decides)
+    __device__ __forceinline__ bool done(int mode) const { return found >= 2 || stop || (found == 1 && mode != 1); }
+    __device__ __forceinline__ void visit(uint32_t e, int owner, int i, int mode, float nnratio, float bound)
     {
-        const int TH_HIGH = 100;
         const int d = (e >> 16) & 0x1FF;
-        if (found == 0 && d > TH_HIGH) { stop = true; return; }
-        if (found == 1 && (mode == 0 || (nnratio >= 0.f && !((float)best > __fmul_rn(nnratio, (float)d))))) { stop = true; return; }
+        if (found == 0 && !((float)d <= bound)) { stop = true; return; }
+        if (found == 1 && (mode != 1 || (nnratio >= 0.f && !((float)best > __fmul_rn(nnratio, (float)d))))) { stop = true; return; }
         if ((owner >> 1) < i) return;  // taken by an earlier point with observations
         if (found == 0) { best = d; bestL = e >> 25; bestI = e & 0xFFFF; }
         else { best2 = d; bestL2 = e >> 25; }
         ++found;
     }
-    __device__ __forceinline__ int choice(int mode, float nnratio) const
+    __device__ __forceinline__ int choice(int mode, float nnratio, float bound) const
     {
-        const int TH_HIGH = 100;
-        int ch = best <= TH_HIGH ? bestI : -1;
+        int ch = (float)best <= bound ? bestI : -1;
         // map-point variant: ratio to the second match, only if best and second are in the same scale level (:122-129)
         if (mode == 1 && ch >= 0 && bestL == bestL2 && (float)best > __fmul_rn(nnratio, (float)best2)) ch = -1;
         return ch;
@@ -2138,7 +2145,7 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc, int 
         SbpWalk wk;
 #pragma unroll
         for (int k = 0; k < SBP_HEAD; ++k)
-            if (k < h.n && !wk.done(a.mode)) wk.visit(he[k], ow[k], i, a.mode, a.nnratio);
+            if (k < h.n && !wk.done(a.mode)) wk.visit(he[k], ow[k], i, a.mode, a.nnratio, a.bound);
         // not settled by the head: on through the sorted list, four entries per step - in LDS as far as it is there
         if (!wk.done(a.mode) && h.n > SBP_HEAD) {
             const uint32_t *lst = a.cand + (size_t)i * SBP_CAP;
@@ -2151,10 +2158,10 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(SbpArgs a, int ldsNc, int 
                 for (int k = 0; k < 4; ++k) o4[k] = own[cur + min((int)(e4[k] & 0xFFFF), ncm1)];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (c0 + k < h.n && !wk.done(a.mode)) wk.visit(e4[k], o4[k], i, a.mode, a.nnratio);
+                    if (c0 + k < h.n && !wk.done(a.mode)) wk.visit(e4[k], o4[k], i, a.mode, a.nnratio, a.bound);
             }
         }
-        return wk.choice(a.mode, a.nnratio);
+        return wk.choice(a.mode, a.nnratio, a.bound);
     };
     // the first two points of a thread live in registers: heads and choices; further ones (frames of more than 2048 points) go through memory
     Head h0, h1;
@@ -2221,9 +2228,9 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve_walk(SbpArgs a)
             const uint32_t *glist = a.cand + (size_t)i * SBP_CAP;
             for (int c = 0; c < n && !wk.done(a.mode); ++c) {
                 const uint32_t e = glist[c];
-                wk.visit(e, own[cur + (e & 0xFFFF)], i, a.mode, a.nnratio);
+                wk.visit(e, own[cur + (e & 0xFFFF)], i, a.mode, a.nnratio, a.bound);
             }
-            const int ch = n > 0 ? wk.choice(a.mode, a.nnratio) : -1;
+            const int ch = n > 0 ? wk.choice(a.mode, a.nnratio, a.bound) : -1;
             a.choice[i] = ch;
             if (ch >= 0 && (a.proj[i].flags & 2)) atomicMin(&own[nxt + ch], i << 1);
         }
@@ -2400,7 +2407,7 @@ hipError_t orbxLaunchSearchByProjectionFisheye(hipStream_t st, const OrbxSbpFish
     a.scale = f.scale; a.mbf = 0.f; a.proj = (const SbpProj *)f.steps; a.dproj = f.dproj; a.np = 2 * f.np;
     a.th = f.th; a.forward = f.forward; a.backward = f.backward; a.checkOri = f.checkOri;
     a.cand = f.cand; a.count = f.count; a.choice = f.choice; a.owner = nullptr; a.assign = f.assign; a.result = f.result;
-    a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next;
+    a.nLeft = f.nLeft; a.partner = f.partner; a.head = f.head; a.next = f.next; a.levelHi = 0; a.bound = 100.f;
     hipError_t e = hipMemsetAsync(f.result, 0, 2 * sizeof(int) * (size_t)nframes, st);
     if (e != hipSuccess) return e;
     if (f.np > 0) hipLaunchKernelGGL(k_sbp_candidates, dim3(2 * f.np, nframes), dim3(64), 0, st, a);
@@ -2412,9 +2419,10 @@ hipError_t orbxLaunchSearchByProjection(hipStream_t st, const void *kc, const ui
                                         int nc, const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY,
                                         const float *scale, float mbf, const void *proj, const uint8_t *dproj, int np, float th, int forward,
                                         int backward, int checkOri, int mode, float nnratio, uint32_t *cand, int *count, int *choice,
-                                        int *owner, int *assign, int *result, const OrbxSbpBatch *batch)
+                                        int *owner, int *assign, int *result, const OrbxSbpBatch *batch, int levelHi, float bound)
 {
     SbpArgs a;
+    a.levelHi = levelHi; a.bound = bound;
     a.ncBase = 0; a.cellStartR = nullptr; a.itemsR = nullptr; a.partner = nullptr; a.head = nullptr; a.next = nullptr;
     const int nframes = batch ? batch->nframes : 1;
     a.kcStride = batch ? batch->kcStride : 0; a.projStride = batch ? batch->projStride : 0;
