@@ -1,6 +1,6 @@
 #!/bin/bash
 # HIP API / kernel / copy breakdown of the single-call (host-pointer) searches: where the time of a call goes
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 T=${1:-tests/tools/time_search_projection.py}
 mkdir -p $R/gpurun_out/sct

@@ -1059,6 +1059,7 @@ struct SearchInitArgs {
     // all per pair (cap1 = stride of the t-indexed arrays).  topUse: entries of a list the walk looks at.
     const uint32_t *top; const float *topAng; const uint16_t *list1G, *origG; const int *nL1G, *n0G; int topUse, cap1;
     int ldsN1;                     // k_search_init_lds: octave-0 keypoints of F1 its LDS arrays are sized for (n1 when unknown)
+    int blockWalk;                 // k_search_init_lds: 1 = eight keypoints per step of the walk where they do not depend on each other (ORBX_SI_BLOCK)
 };
 
 __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
@@ -1317,8 +1318,18 @@ __global__ __launch_bounds__(64) void k_si_topk(SearchInitArgs a, uint32_t *topA
 // and vnMatches21 of that subset in LDS: a global round trip per dependent step made the generic kernel above take ~21 us per
 // keypoint of F1.  Used when F2 has at most SI_CAP2 octave-0 keypoints and both frames have fewer than 65536 keypoints.
 
+#ifdef SI_TIMING
+// debug build (-DSI_TIMING): s_memtime stamps of the last launch's workgroup 0 (start, subsets, grid counted, grid placed, descriptors in
+// LDS, walk done, end) and the blocks the walk took eight keypoints at a time / step by step; read back with orbx_debug_si_timing
+__device__ unsigned long long g_siTiming[16];
+extern "C" int orbx_debug_si_timing(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_siTiming), sizeof(g_siTiming)); }
+#define SI_STAMP(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_siTiming[i] = (v); } while (0)
+#else
+#define SI_STAMP(i, v) do { } while (0)
+#endif
 __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
 {
+    SI_STAMP(0, __builtin_amdgcn_s_memtime());
     const int TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
     extern __shared__ __attribute__((aligned(16))) uint8_t si_lds[];
     uint32_t *desc = (uint32_t *)si_lds;                    // [SI_CAP2][8]
@@ -1391,6 +1402,7 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         }
     }
     for (int t = lane; t < nL1; t += 64) { m12L[t] = 0xFFFF; binL[t] = -1; }
+    SI_STAMP(1, __builtin_amdgcn_s_memtime());
     int *occ = cnt + GRID_CELLS;                            // [GRID_CELLS] setup only: keypoints of the current 64 per cell
     for (int c = lane; c < 2 * GRID_CELLS; c += 64) cnt[c] = 0;
     __syncthreads();
@@ -1428,15 +1440,16 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
         if (lane == 0) cs0[GRID_CELLS] = (uint16_t)base;
     }
     __syncthreads();
+    SI_STAMP(2, __builtin_amdgcn_s_memtime());
     for (int ib = 0; ib < n0; ib += 64) {  // stable placement, 64 keypoints per step in index order
         const int c = ib + lane;
         const int cl = c < n0 ? (int)cellOf[c] : 0xFFFF;
         // keypoints that are alone in their cell among these 64 (nearly all of them) go straight to the cell's cursor
         if (cl != 0xFFFF) atomicAdd(&occ[cl], 1);
-        __syncthreads();
+        mt_wave_sync();
         const bool alone = cl != 0xFFFF && occ[cl] == 1;
         if (alone) { items0[cnt[cl]] = (uint16_t)c; cnt[cl] += 1; }
-        __syncthreads();
+        mt_wave_sync();
         if (cl != 0xFFFF) occ[cl] = 0;
         unsigned long long todo = __ballot(cl != 0xFFFF && !alone);
         while (todo) {
@@ -1444,13 +1457,14 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
             const int cll = __shfl(cl, leader);
             const unsigned long long same = __ballot(cl == cll);
             if (cl == cll) items0[cnt[cll] + __popcll(same & lt)] = (uint16_t)c;
-            __syncthreads();
+            mt_wave_sync();
             if (lane == leader) cnt[cll] += __popcll(same);
-            __syncthreads();
+            mt_wave_sync();
             todo &= ~same;
         }
     }
-    __syncthreads();
+    mt_wave_sync();
+    SI_STAMP(3, __builtin_amdgcn_s_memtime());
     for (int i0 = 0; i0 < n0 * 2; i0 += 512) {  // descriptors, 16 bytes per lane and load, eight loads in flight (over cnt[])
         uint4 v[8];
 #pragma unroll
@@ -1469,26 +1483,20 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     }
     __syncthreads();
 
+    SI_STAMP(4, __builtin_amdgcn_s_memtime());
+#ifdef SI_TIMING
+    unsigned long long nFast = 0, nSlow = 0;
+#endif
     // ---- the sequential walk over the octave-0 keypoints of F1 ---------------------------------------------------
     const float factor = 1.0f / HISTO_LENGTH;
     const float r = (float)a.window;
-    // an accepted match: vnMatches21's previous owner loses it (:725-729), the rotation histogram gets its vote (:736-746)
-    // Everything the walk writes stays in LDS (matches by position t, written out behind the walk): a global store per accepted match
-    // would have to be acknowledged before the next block's prefetch can be waited for.
-    auto accept = [&](int t, int bD, int bC, float ang1) {
-        if (lane == 0) {
-            const int old = m21[bC];
-            const float ang2 = kang[bC];  // (both reads in one LDS round trip; the histogram itself is counted behind the walk)
-            if (old >= 0) m12L[old] = 0xFFFF;
-            m12L[t] = (uint16_t)bC; m21[bC] = t; mdist[bC] = (uint16_t)bD;
-            if (a.checkOri) {
-                float rot = __fsub_rn(ang1, ang2);
-                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                int bin = (int)roundf(__fmul_rn(rot, factor));
-                if (bin == HISTO_LENGTH) bin = 0;
-                binL[t] = (signed char)bin;
-            }
-        }
+    // an accepted match: vnMatches21's previous owner loses it (:725-729), the rotation histogram gets its vote (:736-746).
+    // The walk only RECORDS it - three LDS stores, nothing read: who lost a keypoint (the holder is the last taker: m21) and the
+    // histogram bins (the partner's angle) are worked out behind the walk, for all keypoints at once.  Read inside the walk they were an
+    // LDS round trip in every accepted step of a chain that has nothing else to wait for.  (Everything the walk writes stays in LDS; a
+    // global store per accepted match would have to be acknowledged before the next block's prefetch can be waited for.)
+    auto accept = [&](int t, int bD, int bC, float) {
+        if (lane == 0) { m12L[t] = (uint16_t)bC; m21[bC] = t; mdist[bC] = (uint16_t)bD; }
         // One wave: its LDS accesses execute in order, so the next step sees lane 0's writes without a barrier
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1578,6 +1586,75 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
             const int td = (int)(bkeys >> 23), tc = (int)(bkeys & (SI_CAP2 - 1));
             // vMatchedDistance of the block's 64 candidates in one LDS read; what the block's own matches change is patched in registers
             int md = (int)mdist[tc];
+            if (a.blockWalk) {
+                // All eight keypoints of the block at once, every group of eight lanes deciding for its keypoint.  What a keypoint sees of
+                // the EARLIER ones of its block is only this: a match they accept lowers vMatchedDistance of its partner, which kills
+                // the candidate entries of that partner at the same or a larger distance (`vMatchedDistance[i2] <= dist`, :700).
+                // Keypoints adjacent in index are neighbours in the image and share candidates, so that happens in most blocks - the
+                // block is therefore iterated to ITS fixed point: decide all eight, strike the entries the accepted matches of earlier
+                // groups kill, decide again while anything changed (group g is final after g + 1 passes; two or three in practice,
+                // against eight dependent steps).  Only a keypoint whose short list does not decide sends the block to the single steps.
+                const bool live0 = bkeys != SI_KEY_NONE && !(md <= td);
+                const int gl = lane & ~7;
+                bool live = live0, acc = false, fail = false;
+                int bD = 0, bC = 0;
+                bool pAcc = false;
+                int pD = -1, pC = -1;  // the decisions of the pass before
+                for (int pass = 0; pass < 9; ++pass) {
+                    const unsigned long long liveAll = __ballot(live);
+                    const unsigned f = (unsigned)(liveAll >> gl) & 0xFFu, f2 = f & (f - 1u);
+                    const uint32_t lastKey = (uint32_t)__shfl((int)bkeys, gl + topUse - 1);
+                    const uint32_t key0 = (uint32_t)__shfl((int)bkeys, f ? gl + __ffs((int)f) - 1 : gl);
+                    const uint32_t key1 = (uint32_t)__shfl((int)bkeys, f2 ? gl + __ffs((int)f2) - 1 : gl);
+                    const bool complete = lastKey == SI_KEY_NONE;
+                    const int lastD = (int)(lastKey >> 23);
+                    bD = (int)(key0 >> 23); bC = (int)(key0 & (SI_CAP2 - 1));
+                    int decided = 0, second = INT_MAX;  // as below: 1 no match, 2 test (best, second), 0 the full scan
+                    if (f == 0u) decided = complete ? 1 : 0;
+                    else if (bD > TH_LOW) decided = 1;
+                    else if (f2) { second = (int)(key1 >> 23); decided = 2; }
+                    else if (complete) decided = 2;
+                    else if (a.nnratio > 0.0f && (float)bD < __fmul_rn((float)lastD, a.nnratio)) { second = lastD; decided = 2; }
+                    acc = decided == 2 && (float)bD < __fmul_rn((float)second, a.nnratio);
+                    if (__ballot(decided == 0) != 0ull) { fail = true; break; }
+                    // (the same accepted matches as in the pass before strike the same entries: done)
+                    if (pass > 0 && __ballot(acc != pAcc || (acc && (bC != pC || bD != pD))) == 0ull) break;
+                    pAcc = acc; pC = bC; pD = bD;
+                    bool nl = live0;  // the entries left alive by the matches the earlier groups accept in this pass
+                    for (int sI = 0; sI < 7; ++sI) {
+                        if (!__builtin_amdgcn_readlane((int)acc, 8 * sI)) continue;  // (wave-uniform)
+                        const int cS = __builtin_amdgcn_readlane(bC, 8 * sI), dS = __builtin_amdgcn_readlane(bD, 8 * sI);
+                        if (grp > sI && tc == cS && td >= dS) nl = false;
+                    }
+                    if (__ballot(nl != live) == 0ull) break;
+                    live = nl;
+                    if (pass == 8) fail = true;  // (cannot happen: group g is final after g + 1 passes)
+                }
+                if (!fail) {
+                    // every accepted match is recorded; the partner's holder and distance are those of the LAST keypoint of the block that
+                    // takes it (what the single steps would leave behind)
+                    bool last = acc;
+                    for (int sI = 1; sI < 8; ++sI) {
+                        if (!__builtin_amdgcn_readlane((int)acc, 8 * sI)) continue;
+                        const int cS = __builtin_amdgcn_readlane(bC, 8 * sI);
+                        if (grp < sI && bC == cS) last = false;
+                    }
+                    if (sub == 0 && acc) {
+                        const int t = tb + grp;
+                        m12L[t] = (uint16_t)bC;
+                        if (last) { m21[bC] = t; mdist[bC] = (uint16_t)bD; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#ifdef SI_TIMING
+                    ++nFast;
+#endif
+                    continue;
+                }
+#ifdef SI_TIMING
+                ++nSlow;
+#endif
+            }
             for (int sI = 0; sI < 8 && tb + sI < nL1; ++sI) {
                 const bool liveK = grp == sI && bkeys != SI_KEY_NONE && !(md <= td);
                 const unsigned mlive = (unsigned)((__ballot(liveK) >> (8 * sI)) & 0xFFull);
@@ -1634,7 +1711,25 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
             fullScan(t, x, y, q, ang1);
         }
     }
+    SI_STAMP(5, __builtin_amdgcn_s_memtime());
+#ifdef SI_TIMING
+    SI_STAMP(7, nFast); SI_STAMP(8, nSlow);
+#endif
     __threadfence_block();
+    __syncthreads();
+    // what the walk left out: the bin of every recorded match (also of one that was stolen later), and the stolen ones
+    for (int t = lane; t < nL1; t += 64) {
+        const int c2 = m12L[t];
+        if (c2 == 0xFFFF) continue;
+        if (a.checkOri) {
+            float rot = __fsub_rn(a.k1[list1[t]].angle, kang[c2]);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == HISTO_LENGTH) bin = 0;
+            binL[t] = (signed char)bin;
+        }
+        if (m21[c2] != t) m12L[t] = 0xFFFF;  // a later keypoint of F1 took the partner
+    }
     __syncthreads();
     if (a.checkOri) {
         // rotHist sizes (:742-746): every match that was recorded votes, also one that was stolen later
@@ -1671,6 +1766,7 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     for (int o = 32; o > 0; o >>= 1) cntM += __shfl_xor(cntM, o);
     // nmatches as the reference counts it (++ per accepted match, -- per stolen or rotation-filtered one) = entries still >= 0
     if (lane == 0) *a.nmatches = cntM;
+    SI_STAMP(6, __builtin_amdgcn_s_memtime());
 }
 
 // true when orbxLaunchSearchInit takes the LDS-resident kernel (which builds its own grid: no orbxLaunchGridBuild needed)
@@ -1734,6 +1830,8 @@ static int searchInitTopUse()
 static void searchInitPrepass(hipStream_t st, SearchInitArgs &a, int npairs, int cap1, void *work)
 {
     a.top = nullptr; a.topAng = nullptr; a.list1G = nullptr; a.origG = nullptr; a.nL1G = nullptr; a.n0G = nullptr; a.topUse = 0; a.cap1 = cap1;
+    static const int blockWalk = [] { const char *e = getenv("ORBX_SI_BLOCK"); return e ? atoi(e) != 0 : 1; }();  // tests: 0 = step by step
+    a.blockWalk = blockWalk;
     const int use = searchInitTopUse();
     if (!work || use <= 0 || cap1 <= 0) return;
     const size_t P = (size_t)npairs, C = (size_t)cap1;
@@ -1783,6 +1881,7 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     SearchInitArgs a;
     a.stride1 = 0; a.stride2 = 0; a.n1Dev = nullptr; a.n2Dev = nullptr; a.initPrev = 0;
     a.top = nullptr; a.topAng = nullptr; a.list1G = nullptr; a.origG = nullptr; a.nL1G = nullptr; a.n0G = nullptr; a.topUse = 0; a.cap1 = n1;
+    a.blockWalk = 0;
     a.k1 = (const MtKp *)k1; a.d1 = d1; a.n1 = n1; a.k2 = (const MtKp *)k2; a.d2 = d2; a.n2 = n2;
     a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY;
