@@ -484,6 +484,7 @@ def test_blur_fallback_kernels(pkg, env):
                                       ({"ORBX_QT_STREAMS": "2", "ORBX_QT_PER_LEVEL": "3"}, ["640", "480", "1000", "24"]),
                                       ({"ORBX_QT_STREAMS": "3", "ORBX_QT_PER_LEVEL": "2"}, ["752", "480", "1200", "5"]),
                                       ({}, ["512", "512", "1500", "648"]),
+                                      ({"ORBX_PF_LANE_ALLOC": "0"}, ["640", "480", "1000", "24"]),
                                       ({"ORBX_FRONT_PARTS": "3", "ORBX_FRONT_STAGGER": "1"}, ["640", "480", "1000", "300"])])
 def test_launch_schedules(pkg, env, args):
     """The launch sequence has measured alternatives behind environment switches (quadtree per level / per group of levels, blur

@@ -94,6 +94,17 @@ __device__ __forceinline__ unsigned wave_queue_alloc(unsigned *counter, unsigned
     return __builtin_amdgcn_readfirstlane(base);
 }
 
+// `n` queue slots for THIS lane from an LDS counter: the hardware's own same-address atomic (the active lanes' additions are serialised
+// by the LDS, a few cycles each).  Written as atomicAdd() the compiler "optimises" it into a wave reduction over v_readlane; the
+// ballot / v_mbcnt prefix counts of wave_queue_alloc cost ~12 vector instructions per queue and wave.  For queues whose order is free.
+__device__ __forceinline__ unsigned lane_queue_alloc(unsigned *counter, unsigned n)
+{
+    unsigned r;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)counter;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(n) : "memory");
+    return r;
+}
+
 // FAST corner score (cornerScore<16>: largest threshold for which the pixel is still a corner = max over the
 // 16 arcs of 9 of the minimum one-sided difference, minus 1).  `c` points at the centre pixel inside an LDS tile
 // with row pitch `tp`.  Only called for pixels that passed the ring test (sparse), so byte reads are fine here.
@@ -250,6 +261,7 @@ struct PyrFastArgs {
     int iniTh, minTh;
     int nframes;
     const OrbxPfTile *tiles;  // [g.nTiles] host-built tile records of this level
+    int laneAlloc;  // 1: queue slots by per-lane LDS atomics (ORBX_PF_LANE_ALLOC), 0: ballot prefix counts
     int phases;  // debug/ablation mask (ORBX_PF_PHASES): 1 resize, 2 ring test+score, 4 NMS, 8 count+emit;
                  // bits 4..7 = stop point for instruction-count profiles (tools/pmc_phases.sh): return after 1 tile load,
                  // 2 LDS setup, 3 resize, 4 pre-test, 5 ring test, 6 score, 7 NMS (round 0)
@@ -548,6 +560,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         uint16_t *gq = (uint16_t *)(lds + a.g.oGq), *cq = (uint16_t *)(lds + a.g.oCq);
         uint8_t *colInfo = lds + a.g.oColInfo;
         const int phases = DBG ? a.phases : 15;
+        const bool laneAlloc = a.laneAlloc != 0;
         const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
         const int cInt0 = t.cInt0, cInt1 = t.cInt1, nCells = t.nCells, THi = t.THi, rowOff = t.rowOff;
         const int s0 = t.s0, NS = t.NS;  // strips cover LDS columns [8s + 4, 8s + 12)
@@ -584,6 +597,15 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                 const bool g0 = f0 != 0, g1 = f1 != 0;
                 // queue slots: one LDS atomic per wave and ballot prefix counts (a per-lane atomicAdd on one address is expanded by
                 // the compiler into a readlane loop over the active lanes: ~9 scalar instructions per passing strip)
+                if (laneAlloc) {
+                    if (g0 | g1) {
+                        unsigned pos = lane_queue_alloc(&gqCountR[round], (unsigned)g0 + (unsigned)g1);
+                        const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
+                        if (g0) gq[pos++] = (uint16_t)e;
+                        if (g1) gq[pos] = (uint16_t)(e | 1u);
+                    }
+                    return;
+                }
                 const unsigned long long bg0 = __ballot(g0), bg1 = __ballot(g1);
                 if (bg0 | bg1) {
                     unsigned pos = wave_queue_alloc(&gqCountR[round], (unsigned)(__popcll(bg0) + __popcll(bg1))) + mbcnt64(bg0) + mbcnt64(bg1);
@@ -643,6 +665,19 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                     m &= keep << plo;
                 }
                 const unsigned nc = __popc(m);  // 0..4
+                if (laneAlloc) {
+                    if (nc) {
+                        unsigned pos = lane_queue_alloc(&cqCountR[round], nc);
+                        while (m) {
+                            const int k = __ffs(m) - 1;
+                            m &= m - 1;
+                            if (pos < PF_QCAP) cq[pos] = (uint16_t)((r << 9) | (c4 + k - cInt0));
+                            else pf_score_one(tile, score, tp, sp, rowOff, r, c4 + k, thEff);  // queue overflow: score in place
+                            ++pos;
+                        }
+                    }
+                    continue;
+                }
                 const unsigned long long n1 = __ballot((nc & 1u) != 0), n2 = __ballot((nc & 2u) != 0), n4 = __ballot((nc & 4u) != 0);
                 if (n1 | n2 | n4) {
                     const unsigned total = (unsigned)(__popcll(n1) + 2 * __popcll(n2) + 4 * __popcll(n4));
@@ -1320,6 +1355,8 @@ static void fillPyrFastArgs(PyrFastArgs &a, int nframes, const OrbxLevelGeom &g,
     a.iniTh = iniTh; a.minTh = minTh;
     a.nframes = nframes;
     a.phases = 15;
+    static const int laneAlloc = [] { const char *e = getenv("ORBX_PF_LANE_ALLOC"); return e ? atoi(e) : 1; }();  // (0: A/B and tests)
+    a.laneAlloc = laneAlloc;
 }
 
 size_t orbxPyrFastArgsBytes() { return sizeof(PyrFastArgs); }
