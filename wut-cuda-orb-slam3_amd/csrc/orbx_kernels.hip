@@ -560,7 +560,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         uint16_t *gq = (uint16_t *)(lds + a.g.oGq), *cq = (uint16_t *)(lds + a.g.oCq);
         uint8_t *colInfo = lds + a.g.oColInfo;
         const int phases = DBG ? a.phases : 15;
-        const bool laneAlloc = a.laneAlloc != 0;
+        // (the prefix-count allocation lives in the debug instance only: both paths in the production kernel cost it four spilled
+        // registers - 16 bytes of scratch per lane, +0.3 GB of HBM writes per launch set)
+        const bool laneAlloc = !DBG || a.laneAlloc != 0;
         const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
         const int cInt0 = t.cInt0, cInt1 = t.cInt1, nCells = t.nCells, THi = t.THi, rowOff = t.rowOff;
         const int s0 = t.s0, NS = t.NS;  // strips cover LDS columns [8s + 4, 8s + 12)
@@ -1444,7 +1446,7 @@ hipError_t orbxLaunchPyrFast(hipStream_t st, int nframes, const OrbxLevelGeom &g
         else hipLaunchKernelGGL(k_pyr_fast_cw<true>, grid, dim3(PF_NT), g.cwLdsBytes + ldsPad, st, a);
         return hipGetLastError();
     }
-    if (a.phases == 15) hipLaunchKernelGGL(k_pyr_fast<false>, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
+    if (a.phases == 15 && a.laneAlloc) hipLaunchKernelGGL(k_pyr_fast<false>, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
     else hipLaunchKernelGGL(k_pyr_fast<true>, grid, dim3(PF_NT), g.ldsBytes + ldsPad, st, a);
     return hipGetLastError();
 }
