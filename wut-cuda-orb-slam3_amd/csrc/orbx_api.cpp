@@ -1758,6 +1758,21 @@ extern "C" void orbx_synth_frame(uint64_t frame_index, int w, int h, uint8_t *ou
 // ---------------------------------------------------------------------------------------------------------
 // matcher
 // ---------------------------------------------------------------------------------------------------------
+// staging of the packed host transfers (HostPack / HostFetch below) of a handle: page-locked memory both ways, a device arena both ways
+struct HostXfer {
+    hipStream_t stream = nullptr;
+    DevBuf<uint8_t> d_arena, d_arenaOut;
+    uint8_t *h_arena = nullptr, *h_out = nullptr;
+    size_t h_arenaBytes = 0, h_outBytes = 0;
+    void release()
+    {
+        d_arena.release(); d_arenaOut.release();
+        if (h_arena) (void)hipHostFree(h_arena);
+        if (h_out) (void)hipHostFree(h_out);
+        h_arena = h_out = nullptr; h_arenaBytes = h_outBytes = 0;
+    }
+};
+
 struct orbx_matcher {
     int device = 0, maxQ = 0, maxT = 0;
     hipStream_t stream = nullptr;
@@ -1778,9 +1793,7 @@ struct orbx_matcher {
     DevBuf<uint8_t> d_siWork;     // SearchForInitialization: octave-0 subset of F2 and the shortest candidates of every F1 keypoint
     DevBuf<orbx_projection> d_proj;
     // single calls with host pointers: all inputs of a call cross the link in ONE transfer (HostPack), the results in one more
-    DevBuf<uint8_t> d_arena, d_arenaOut;
-    uint8_t *h_arena = nullptr, *h_out = nullptr;   // page-locked staging
-    size_t h_arenaBytes = 0, h_outBytes = 0;
+    HostXfer xf;
 };
 
 // The inputs of a single call with host pointers (keypoints, descriptors, flags, projections ...: two to ten arrays of a few KB each)
@@ -1802,23 +1815,26 @@ static int growPinned(uint8_t *&p, size_t &have, size_t need, size_t keep)
 }
 static const size_t kDirectBytes = (size_t)256 << 10;
 struct HostPack {
-    orbx_matcher *m;
+    orbx_matcher *m;         // (NULL for another handle's transfers)
+    HostXfer *x;
     OrbxCopyPieces sc;       // pieces that go on to a buffer of their own (src = offset into the arena until send())
     size_t bytes = 0;
-    int err = ORBX_OK;
-    explicit HostPack(orbx_matcher *mm) : m(mm) { sc.n = 0; }
+    int err = ORBX_OK, npieces = 0;
+    explicit HostPack(orbx_matcher *mm) : m(mm), x(&mm->xf) { sc.n = 0; }
+    explicit HostPack(HostXfer *xx) : m(nullptr), x(xx) { sc.n = 0; }
     // packs `nbytes` from `src`; returns the offset of the piece in the arena.  ddst != NULL: the piece is copied on to ddst by send()
     size_t add(const void *src, size_t nbytes, void *ddst = nullptr)
     {
         const size_t off = (bytes + 255) & ~(size_t)255;
         if (err != ORBX_OK || nbytes == 0) return off;
         if (ddst && nbytes > kDirectBytes) {  // a large piece gains nothing from the detour: straight to its buffer, in stream order
-            if (hipMemcpyAsync(ddst, src, nbytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) err = setError(ORBX_ERR_HIP, "hipMemcpyAsync (host to device) failed");
+            if (hipMemcpyAsync(ddst, src, nbytes, hipMemcpyHostToDevice, x->stream) != hipSuccess) err = setError(ORBX_ERR_HIP, "hipMemcpyAsync (host to device) failed");
             return off;
         }
-        if ((err = growPinned(m->h_arena, m->h_arenaBytes, off + nbytes, bytes)) != ORBX_OK) return off;
-        memcpy(m->h_arena + off, src, nbytes);
+        if ((err = growPinned(x->h_arena, x->h_arenaBytes, off + nbytes, bytes)) != ORBX_OK) return off;
+        memcpy(x->h_arena + off, src, nbytes);
         bytes = off + nbytes;
+        ++npieces;
         if (ddst) {
             if (sc.n >= ORBX_COPY_PIECES || nbytes > 0xFFFFFFFFull) { err = setError(ORBX_ERR_INVALID_ARG, "internal: too many / too large pieces in a packed transfer"); return off; }
             sc.dst[sc.n] = ddst; sc.src[sc.n] = (const void *)off; sc.bytes[sc.n] = (unsigned)nbytes; ++sc.n;
@@ -1829,29 +1845,34 @@ struct HostPack {
     {
         if (err != ORBX_OK) return err;
         if (bytes == 0) return ORBX_OK;
-        int rc = m->d_arena.ensure(bytes);
+        if (sc.n == 1 && npieces == 1) {  // one piece with a buffer of its own: straight from the staging
+            HIP_TRY(hipMemcpyAsync(sc.dst[0], x->h_arena + (size_t)sc.src[0], sc.bytes[0], hipMemcpyHostToDevice, x->stream));
+            return ORBX_OK;
+        }
+        int rc = x->d_arena.ensure(bytes);
         if (rc != ORBX_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(m->d_arena.p, m->h_arena, bytes, hipMemcpyHostToDevice, m->stream));
-        for (int i = 0; i < sc.n; ++i) sc.src[i] = m->d_arena.p + (size_t)sc.src[i];
-        HIP_TRY(orbxLaunchCopyPieces(m->stream, sc));
+        HIP_TRY(hipMemcpyAsync(x->d_arena.p, x->h_arena, bytes, hipMemcpyHostToDevice, x->stream));
+        for (int i = 0; i < sc.n; ++i) sc.src[i] = x->d_arena.p + (size_t)sc.src[i];
+        HIP_TRY(orbxLaunchCopyPieces(x->stream, sc));
         return ORBX_OK;
     }
-    template <class T> T *dev(size_t off) const { return (T *)(m->d_arena.p + off); }
+    template <class T> T *dev(size_t off) const { return (T *)(x->d_arena.p + off); }
 };
 // The results of such a call: the pieces are gathered into one device buffer by one launch, cross the link as one copy into page-locked
 // staging and are handed to the caller's arrays after the stream has been synchronised (finish()).
 struct HostFetch {
-    orbx_matcher *m;
+    HostXfer *x;
     OrbxCopyPieces gt;       // dst = offset into the gather buffer until finish()
     void *host[ORBX_COPY_PIECES];
     size_t bytes = 0;
     int err = ORBX_OK;
-    explicit HostFetch(orbx_matcher *mm) : m(mm) { gt.n = 0; }
+    explicit HostFetch(orbx_matcher *mm) : x(&mm->xf) { gt.n = 0; }
+    explicit HostFetch(HostXfer *xx) : x(xx) { gt.n = 0; }
     void add(void *hdst, const void *dsrc, size_t nbytes)
     {
         if (err != ORBX_OK || nbytes == 0) return;
         if (nbytes > kDirectBytes) {  // (see HostPack::add)
-            if (hipMemcpyAsync(hdst, dsrc, nbytes, hipMemcpyDeviceToHost, m->stream) != hipSuccess) err = setError(ORBX_ERR_HIP, "hipMemcpyAsync (device to host) failed");
+            if (hipMemcpyAsync(hdst, dsrc, nbytes, hipMemcpyDeviceToHost, x->stream) != hipSuccess) err = setError(ORBX_ERR_HIP, "hipMemcpyAsync (device to host) failed");
             return;
         }
         if (gt.n >= ORBX_COPY_PIECES || nbytes > 0xFFFFFFFFull) { err = setError(ORBX_ERR_INVALID_ARG, "internal: too many / too large pieces in a packed transfer"); return; }
@@ -1863,20 +1884,20 @@ struct HostFetch {
     int finish()
     {
         if (err != ORBX_OK) return err;
-        if (bytes == 0) { HIP_TRY(hipStreamSynchronize(m->stream)); return ORBX_OK; }
-        int rc = m->d_arenaOut.ensure(bytes);
+        if (bytes == 0) { HIP_TRY(hipStreamSynchronize(x->stream)); return ORBX_OK; }
+        int rc = x->d_arenaOut.ensure(bytes);
         if (rc != ORBX_OK) return rc;
-        if ((rc = growPinned(m->h_out, m->h_outBytes, bytes, 0)) != ORBX_OK) return rc;
+        if ((rc = growPinned(x->h_out, x->h_outBytes, bytes, 0)) != ORBX_OK) return rc;
         size_t offs[ORBX_COPY_PIECES];
-        for (int i = 0; i < gt.n; ++i) { offs[i] = (size_t)gt.dst[i]; gt.dst[i] = m->d_arenaOut.p + offs[i]; }
+        for (int i = 0; i < gt.n; ++i) { offs[i] = (size_t)gt.dst[i]; gt.dst[i] = x->d_arenaOut.p + offs[i]; }
         if (gt.n == 1) {
-            HIP_TRY(hipMemcpyAsync(m->h_out + offs[0], gt.src[0], gt.bytes[0], hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipMemcpyAsync(x->h_out + offs[0], gt.src[0], gt.bytes[0], hipMemcpyDeviceToHost, x->stream));
         } else {
-            HIP_TRY(orbxLaunchCopyPieces(m->stream, gt));
-            HIP_TRY(hipMemcpyAsync(m->h_out, m->d_arenaOut.p, bytes, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(orbxLaunchCopyPieces(x->stream, gt));
+            HIP_TRY(hipMemcpyAsync(x->h_out, x->d_arenaOut.p, bytes, hipMemcpyDeviceToHost, x->stream));
         }
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        for (int i = 0; i < gt.n; ++i) memcpy(host[i], m->h_out + offs[i], gt.bytes[i]);
+        HIP_TRY(hipStreamSynchronize(x->stream));
+        for (int i = 0; i < gt.n; ++i) memcpy(host[i], x->h_out + offs[i], gt.bytes[i]);
         return ORBX_OK;
     }
 };
@@ -1897,6 +1918,7 @@ extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orb
     m->device = device; m->maxQ = max_query; m->maxT = max_train;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; return setError(ORBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    m->xf.stream = m->stream;
     int rc;
     if ((rc = m->d_q.ensure((size_t)max_query * 32)) != ORBX_OK || (rc = m->d_t.ensure((size_t)max_train * 32)) != ORBX_OK ||
         (rc = m->d_idx.ensure((size_t)max_query * 2)) != ORBX_OK || (rc = m->d_dist.ensure((size_t)max_query * 2)) != ORBX_OK ||
@@ -1920,9 +1942,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (m->evWait) (void)hipEventDestroy(m->evWait);
     m->d_kl.release(); m->d_kr.release(); m->d_scale.release(); m->d_uRight.release(); m->d_depth.release(); m->d_sad.release();
     m->d_grid.release(); m->d_work.release(); m->d_prev.release(); m->d_bin.release(); m->d_sbpCand.release(); m->d_proj.release();
-    m->d_arena.release(); m->d_arenaOut.release();
-    if (m->h_arena) (void)hipHostFree(m->h_arena);
-    if (m->h_out) (void)hipHostFree(m->h_out);
+    m->xf.release();
     delete m;
 }
 
@@ -3287,6 +3307,7 @@ struct orbx_vocabulary {
     DevBuf<int> d_work;  // featWord, featNode, bowWord, fvNode, fvStart, fvFeature, counts
     DevBuf<int> d_batchInt;       // the same per frame of a batch (orbx_vocabulary_transform_batch)
     DevBuf<double> d_batchDbl;
+    HostXfer xf;                  // packed transfers of the single-frame transform
 };
 
 extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
@@ -3299,6 +3320,7 @@ extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
     v->d_childStart.release(); v->d_childNode.release(); v->d_wordOfNode.release(); v->d_childDesc.release(); v->d_feat.release();
     v->d_weight.release(); v->d_featWeight.release(); v->d_bowValue.release(); v->d_work.release();
     v->d_batchInt.release(); v->d_batchDbl.release();
+    v->xf.release();
     delete v;
 }
 
@@ -3412,23 +3434,39 @@ static int vocabularyTransformImpl(orbx_vocabulary *v, const uint8_t *desc, bool
     const size_t F = ORBX_BOW_MAX_FEATURES;
     int *featWord = v->d_work.p, *featNode = featWord + F, *bowWord = featNode + F, *fvNode = bowWord + F, *fvStart = fvNode + F,
         *fvFeature = fvStart + F + 1, *counts = fvFeature + F;
-    if (!deviceDesc) HIP_TRY(hipMemcpyAsync(v->d_feat.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    v->xf.stream = v->stream;
+    if (!deviceDesc) {
+        HostPack in(&v->xf);
+        in.add(desc, (size_t)n * 32, v->d_feat.p);
+        const int rcs = in.send();
+        if (rcs != ORBX_OK) return rcs;
+    }
     HIP_TRY(orbxLaunchBowTransform(v->stream, v->d_childStart.p, v->d_childNode.p, v->d_childDesc.p, v->d_wordOfNode.p, v->d_weight.p, v->L,
                                    v->scoring, v->weighting, deviceDesc ? (const void *)desc : (const void *)v->d_feat.p, n, levelsup, featWord,
                                    featNode, v->d_featWeight.p, bowWord, v->d_bowValue.p, fvNode, fvStart, fvFeature, counts));
+    // One transfer back: the counts and every array at its largest possible size (n entries; 36 n bytes) - the counts are only known on
+    // the host, and asking for them first meant three round trips per frame.
     int cnt[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(cnt, counts, sizeof cnt, hipMemcpyDeviceToHost, v->stream));
-    if (feat_word) HIP_TRY(hipMemcpyAsync(feat_word, featWord, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, v->stream));
-    if (feat_node) HIP_TRY(hipMemcpyAsync(feat_node, featNode, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, v->stream));
-    HIP_TRY(hipStreamSynchronize(v->stream));
-    if (cnt[0] > 0) {
-        HIP_TRY(hipMemcpyAsync(bow_word, bowWord, (size_t)cnt[0] * sizeof(int), hipMemcpyDeviceToHost, v->stream));
-        HIP_TRY(hipMemcpyAsync(bow_value, v->d_bowValue.p, (size_t)cnt[0] * sizeof(double), hipMemcpyDeviceToHost, v->stream));
+    std::vector<int32_t> tBowWord((size_t)n), tFvNode((size_t)n), tFvStart((size_t)n + 1), tFvFeature((size_t)n);
+    std::vector<double> tBowValue((size_t)n);
+    HostFetch out(&v->xf);
+    out.add(cnt, counts, sizeof cnt);
+    if (feat_word) out.add(feat_word, featWord, (size_t)n * sizeof(int));
+    if (feat_node) out.add(feat_node, featNode, (size_t)n * sizeof(int));
+    out.add(tBowWord.data(), bowWord, (size_t)n * sizeof(int));
+    out.add(tBowValue.data(), v->d_bowValue.p, (size_t)n * sizeof(double));
+    out.add(tFvNode.data(), fvNode, (size_t)n * sizeof(int));
+    out.add(tFvStart.data(), fvStart, ((size_t)n + 1) * sizeof(int));
+    out.add(tFvFeature.data(), fvFeature, (size_t)n * sizeof(int));
+    {
+        const int rcf = out.finish();
+        if (rcf != ORBX_OK) return rcf;
     }
-    if (cnt[1] > 0) HIP_TRY(hipMemcpyAsync(fv_node, fvNode, (size_t)cnt[1] * sizeof(int), hipMemcpyDeviceToHost, v->stream));
-    HIP_TRY(hipMemcpyAsync(fv_start, fvStart, ((size_t)cnt[1] + 1) * sizeof(int), hipMemcpyDeviceToHost, v->stream));
-    HIP_TRY(hipStreamSynchronize(v->stream));
-    if (fv_start[cnt[1]] > 0) HIP_TRY(hipMemcpy(fv_feature, fvFeature, (size_t)fv_start[cnt[1]] * sizeof(int), hipMemcpyDeviceToHost));
+    if (cnt[0] < 0 || cnt[0] > n || cnt[1] < 0 || cnt[1] > n) return setError(ORBX_ERR_HIP, "orbx_vocabulary_transform: internal: counts %d / %d for %d features", cnt[0], cnt[1], n);
+    if (cnt[0] > 0) { memcpy(bow_word, tBowWord.data(), (size_t)cnt[0] * sizeof(int)); memcpy(bow_value, tBowValue.data(), (size_t)cnt[0] * sizeof(double)); }
+    if (cnt[1] > 0) memcpy(fv_node, tFvNode.data(), (size_t)cnt[1] * sizeof(int));
+    memcpy(fv_start, tFvStart.data(), ((size_t)cnt[1] + 1) * sizeof(int));
+    if (fv_start[cnt[1]] > 0) memcpy(fv_feature, tFvFeature.data(), (size_t)std::min(fv_start[cnt[1]], n) * sizeof(int));
     *n_bow = cnt[0]; *n_fv = cnt[1];
     return cnt[0];
 }
