@@ -3843,7 +3843,11 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
     const float ar = __fmul_rn(angle, factorPI);
     float myA, myB;
     if (tb.trigMode == 1) { myA = orbx_glibc_sincosf(ar, 1); myB = orbx_glibc_sincosf(ar, 0); }   // cosf / sinf (float overloads)
-    else { myA = (float)cos((double)ar); myB = (float)sin((double)ar); }                // ::cos(double), narrowed
+    else {  // ::cos(double) / ::sin(double), narrowed - one argument reduction for both (the same values as two calls, 100 instructions less)
+        double sd, cd;
+        sincos((double)ar, &sd, &cd);
+        myA = (float)cd; myB = (float)sd;
+    }
     if (lane < cnt) kps[(size_t)f * cap + myPos].angle = angle;
 
     OD_STAMP(3);
