@@ -144,6 +144,11 @@ int orbx_extract_batch_sharded(orbx_extractor *const *handles, int nhandles, int
  * re-allocated per call, src/ORBextractor.cc:1251,1257,1315.) */
 void *orbx_host_alloc(size_t bytes);
 void orbx_host_free(void *p);
+/* The same for buffers the caller already owns (the cv::Mat data of a camera ring, a std::vector of frames): page-locks the range
+ * [p, p + bytes) in place so that orbx_extract_batch takes its asynchronous route from it; orbx_host_unregister before the memory is
+ * freed.  Registering costs milliseconds per 100 MB: once per buffer, not per call.  Returns ORBX_OK or a negative orbx_status. */
+int orbx_host_register(void *p, size_t bytes);
+int orbx_host_unregister(void *p);
 
 /* Device-resident batch: d_imgs is a device pointer (frames already in HBM); results stay in HBM in the
  * handle's own output buffers, retrievable with orbx_device_outputs().  Launches asynchronously on the

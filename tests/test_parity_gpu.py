@@ -291,6 +291,26 @@ def test_host_batch_page_locked_and_reused_arrays(pkg):
     ex.close()
 
 
+def test_host_batch_from_registered_caller_memory(pkg):
+    """orbx_host_register page-locks a buffer the caller already owns (a numpy array here, cv::Mat data in the reference): the batch call
+    then takes its asynchronous route from it - same bytes out as from the pageable array, before and after unregistering; a null
+    range is an error, not a crash."""
+    B = 160
+    imgs = np.stack([pkg.synth_frame(500 + i, 640, 480) for i in range(B)])
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    ref = [a.copy() for a in ex.extract_batch(imgs, (0, 0))]
+    lib = pkg.load_library()
+    with pkg.host_registered(imgs) as locked:
+        got = ex.extract_batch(locked, (0, 0))
+        for a, b in zip(got, ref):
+            assert a.tobytes() == b.tobytes()
+    got = ex.extract_batch(imgs, (0, 0))
+    for a, b in zip(got, ref):
+        assert a.tobytes() == b.tobytes()
+    assert lib.orbx_host_register(None, 16) != 0 and lib.orbx_host_register(imgs.ctypes.data, 0) != 0 and lib.orbx_host_unregister(None) == 0
+    ex.close()
+
+
 def test_sharded_host_batch_two_handles(pkg):
     """orbx_extract_batch_sharded: frames dealt over two handles (here on one device; one per GPU on a node) in blocks of 1 and of 8
     frames, more frames than the handles hold at once, a ragged tail - every frame's result at its index, equal to one handle's."""

@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_get_scale_factors", "orbx_get_inverse_scale_factors", "orbx_get_scale_sigma_squares",
     "orbx_get_inverse_scale_sigma_squares", "orbx_get_features_per_level", "orbx_get_umax", "orbx_max_keypoints",
-    "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_sharded", "orbx_host_alloc", "orbx_host_free", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
+    "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_sharded", "orbx_host_alloc", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
@@ -129,6 +129,10 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_host_alloc.restype = c_void_p
     lib.orbx_host_free.argtypes = [c_void_p]
     lib.orbx_host_free.restype = None
+    lib.orbx_host_register.argtypes = [c_void_p, c_size_t]
+    lib.orbx_host_register.restype = c_int
+    lib.orbx_host_unregister.argtypes = [c_void_p]
+    lib.orbx_host_unregister.restype = c_int
     lib.orbx_extract_batch_device.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int]
     lib.orbx_sync.argtypes = [c_void_p]
     lib.orbx_device_outputs.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]
@@ -309,6 +313,26 @@ def host_array(shape, dtype) -> np.ndarray:
     nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
     blk = _HostBlock(nbytes)
     return np.frombuffer(blk.buf, dtype=np.uint8, count=nbytes).view(dt).reshape(shape)
+
+
+class host_registered:
+    """Context manager around orbx_host_register / orbx_host_unregister: page-locks an existing (C-contiguous) numpy array in place for
+    the duration of the block, so that orbx_extract_batch reads frames from it asynchronously - what a caller does once for the buffers
+    of a camera ring it already owns."""
+
+    def __init__(self, array: np.ndarray):
+        if not array.flags["C_CONTIGUOUS"]:
+            raise ValueError("host_registered needs a C-contiguous array")
+        self.array = array
+        self._lib = load_library()
+
+    def __enter__(self):
+        _check(self._lib.orbx_host_register(self.array.ctypes.data, self.array.nbytes), "orbx_host_register")
+        return self.array
+
+    def __exit__(self, *exc):
+        _check(self._lib.orbx_host_unregister(self.array.ctypes.data), "orbx_host_unregister")
+        return False
 
 
 def extract_batch_sharded(extractors, images: np.ndarray, vLappingArea=(0, 0), block: int = 1, out=None):

@@ -1660,6 +1660,22 @@ extern "C" void orbx_host_free(void *p)
     ORBX_API_ENTRY;
     if (p) (void)hipHostFree(p);
 }
+extern "C" int orbx_host_register(void *p, size_t bytes)
+{
+    ORBX_API_ENTRY;
+    if (!p || bytes == 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_host_register: null pointer or empty range");
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return setError(ORBX_ERR_HIP, "orbx_host_register(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    return ORBX_OK;
+}
+extern "C" int orbx_host_unregister(void *p)
+{
+    ORBX_API_ENTRY;
+    if (!p) return ORBX_OK;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return setError(ORBX_ERR_HIP, "orbx_host_unregister: %s", hipGetErrorString(e)); }
+    return ORBX_OK;
+}
 
 extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
                             orbx_keypoint *kps, uint8_t *desc, int capacity, int *n_out)
