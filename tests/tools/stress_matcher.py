@@ -42,7 +42,7 @@ for c in range(cases):
 os.environ.pop("ORBX_KNN_SPLIT", None)
 for c in range(max(cases // 6, 4)):
     w, h = int(rng.integers(320, 1000)), int(rng.integers(240, 700))
-    h = min(h, int(1.9 * w))  # (W / H < 0.5 leaves DistributeOctTree without a root node, src/ORBextractor.cc:589: orbx_create rejects it)
+    h = min(h, int(1.4 * w))  # (W / H < 0.5 on any level - the 16-px borders count - leaves DistributeOctTree without a root node, src/ORBextractor.cc:589: orbx_create rejects it)
     nf = int(rng.integers(300, 2500))
     shift = int(rng.integers(2, 60))
     left = pkg.synth_frame(int(rng.integers(0, 10000)), w, h)
