@@ -155,6 +155,7 @@ struct orbx_extractor {
     hipEvent_t evQt[ORBX_MAX_LEVELS] = {};
     hipEvent_t evPart[4] = {}, evStag[4] = {};   // front parts of a large batch (ORBX_FRONT_PARTS): end of a part's chain / of its level 0
     uint8_t *h_out = nullptr; size_t h_outBytes = 0;  // pinned staging for the single-frame download
+    DevBuf<uint8_t> d_outPack;                        // ... and the device side of it: counts, keypoints, descriptors packed by one launch
     // per-level argument blocks of k_pyr_fast<.., ML> (small batches: FAST of all levels in one launch), a few source buffers cached
     struct LevelArgsKey { const void *src; int nframes; long long stride, frameStride; int generation, iniTh, minTh; };
     DevBuf<uint8_t> d_pfArgs;
@@ -345,7 +346,7 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
         if (i < 4 && ex->evStag[i]) (void)hipEventDestroy(ex->evStag[i]);
     }
     if (ex->h_out) (void)hipHostFree(ex->h_out);
-    ex->d_in.release(); ex->d_inPacked.release();
+    ex->d_in.release(); ex->d_inPacked.release(); ex->d_outPack.release();
     for (auto &b : ex->d_raw) b.release();
     for (auto &b : ex->d_blur) b.release();
     ex->d_qtNodes.release(); ex->d_pfArgs.release();
@@ -1533,12 +1534,25 @@ static int downloadSmall(orbx_extractor *ex, const HostFrames *host, int nframes
         ex->h_outBytes = need;
     }
     int32_t *hn = (int32_t *)ex->h_out, *hm = hn + nframes;
-    orbx_keypoint *hk = (orbx_keypoint *)(ex->h_out + ((2 * bN + 15) & ~(size_t)15));
+    const size_t oK = (2 * bN + 15) & ~(size_t)15;
+    orbx_keypoint *hk = (orbx_keypoint *)(ex->h_out + oK);
     uint8_t *hd = (uint8_t *)(hk + (size_t)nframes * cap);
-    HIP_TRY(hipMemcpyAsync(hn, ex->d_n.p, bN, hipMemcpyDeviceToHost, ex->stream));
-    HIP_TRY(hipMemcpyAsync(hm, ex->d_mono.p, bN, hipMemcpyDeviceToHost, ex->stream));
-    if (kps) HIP_TRY(hipMemcpyAsync(hk, ex->d_kps.p, bK, hipMemcpyDeviceToHost, ex->stream));
-    if (desc) HIP_TRY(hipMemcpyAsync(hd, ex->d_desc.p, bD, hipMemcpyDeviceToHost, ex->stream));
+    // the four result arrays packed by one launch and fetched by ONE copy (a copy costs ~6 us on the device and as much again on the
+    // host whatever its size: four of them were a tenth of a single-frame call)
+    {
+        int rcp = ex->d_outPack.ensure(need);
+        if (rcp != ORBX_OK) return rcp;
+        OrbxCopyPieces pc;
+        pc.n = 0;
+        auto piece = [&](size_t off, const void *src, size_t bytes) { pc.dst[pc.n] = ex->d_outPack.p + off; pc.src[pc.n] = src; pc.bytes[pc.n] = (unsigned)bytes; ++pc.n; };
+        piece(0, ex->d_n.p, bN);
+        piece(bN, ex->d_mono.p, bN);
+        if (kps) piece(oK, ex->d_kps.p, bK);
+        if (desc) piece(oK + bK, ex->d_desc.p, bD);
+        HIP_TRY(orbxLaunchCopyPieces(ex->stream, pc));
+        const size_t total = desc ? oK + bK + bD : (kps ? oK + bK : 2 * bN);
+        HIP_TRY(hipMemcpyAsync(ex->h_out, ex->d_outPack.p, total, hipMemcpyDeviceToHost, ex->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ex->stream));
     for (int f = 0; f < nframes; ++f)
         if (hn[f] > capacity) return setError(ORBX_ERR_CAPACITY, "frame %d has %d keypoints, output capacity is %d", f, hn[f], capacity);
