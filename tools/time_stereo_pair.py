@@ -18,14 +18,14 @@ m = pkg.ORBmatcher(8192, 8192)
 mb, mbf = 0.54, 386.1448  # KITTI03.yaml: Camera.bf / fx
 
 
+from concurrent.futures import ThreadPoolExecutor
+pool = ThreadPoolExecutor(2)  # two persistent workers, like the reference's two std::threads per frame without Python's thread start-up cost
+
+
 def frame_threads():
-    out = [None, None]
-    def run(i, ex, img):
-        out[i] = ex(img, None, (0, 0))
-    t = [threading.Thread(target=run, args=(0, exl, left)), threading.Thread(target=run, args=(1, exr, right))]
-    for x in t: x.start()
-    for x in t: x.join()
-    return out
+    fl = pool.submit(exl, left, None, (0, 0))
+    fr = pool.submit(exr, right, None, (0, 0))
+    return [fl.result(), fr.result()]
 
 
 def frame_serial():
