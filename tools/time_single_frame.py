@@ -19,6 +19,15 @@ for _ in range(N):
     ex.extract_batch(frames) if B > 1 else ex(frames[0], None, (0, 0))
 t1 = time.perf_counter()
 print("host-pointer call, batch %d: %.3f ms per call (%.3f ms per frame)" % (B, 1e3 * (t1 - t0) / N, 1e3 * (t1 - t0) / N / B))
+if B == 1:  # the caller's frame buffer page-locked in place (orbx_host_register): what a camera ring would do once
+    with pkg.host_registered(frames) as reg:
+        for _ in range(5):
+            ex(reg[0], None, (0, 0))
+        t0 = time.perf_counter()
+        for _ in range(N):
+            ex(reg[0], None, (0, 0))
+        t1 = time.perf_counter()
+    print("host-pointer call from a registered (page-locked) frame buffer: %.3f ms per call" % (1e3 * (t1 - t0) / N))
 d = torch.from_numpy(frames).cuda()
 for _ in range(5):
     ex.extract_batch_device(d.data_ptr(), B, 640, 480, 640, 640 * 480); ex.sync()
