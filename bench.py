@@ -3,10 +3,12 @@
 
 Default (`--config c2`, BASELINE.json configs[1], the configuration the metric is quoted on): one "step" = one pass of
 ORBextractor::operator() (pyramid -> FAST/NMS -> quadtree -> IC-angle -> blur -> rBRIEF -> pack) over ONE batch of 1024
-synthetic 640x480 mono frames, nFeatures=1000, 8 levels, scale 1.2, per GPU.  `value` = frames/s with the inputs resident
-in HBM before the timed region and the results left in HBM; the PCIe-inclusive rate of the host-pointer API
-(orbx_extract_batch: H2D of the frames and D2H of keypoints + descriptors inside the call) is printed next to
-it as `pcie_inclusive_frames_per_s` - never as `value`.
+synthetic 640x480 mono frames, nFeatures=1000, 8 levels, scale 1.2, per GPU - over `--batches-per-step` (4) DISTINCT batches per step,
+so the timed region covers 80 batches / >= 0.25 s at the default 20 steps.  `value` = frames/s with the inputs resident in HBM before
+the timed region and the results left in HBM (`value_definition` in the line says so).  SURVEY §8(d)'s metric - the PCIe-inclusive
+rate of the host-pointer API orbx_extract_batch, H2D of the frames and D2H of keypoints + descriptors inside the call, page-locked
+caller buffers - is the top-level `metric_8d_frames_per_s` (with `pcie_inclusive_*` per kind of caller memory), measured on EVERY rank
+at every N (each rank its own host buffers, barrier on both sides, aggregate = all ranks' frames / slowest rank's wall time) - never `value`.
 
 Other workloads (`--config`): c3 = 752x480 stereo pairs, nFeatures=1200, extraction of both images +
 Frame::ComputeStereoMatches per pair; c4 = 512x512 mono, nFeatures=1500; c5 = 1920x1080 stereo pairs, nFeatures=4000,
@@ -16,10 +18,11 @@ device-resident batched matcher entry point; nothing crosses PCIe inside a step.
 Multi-GPU: `python bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run`, one process per GPU over RCCL;
 the parent never touches the GPU); under an external launcher (RANK set) it is a rank.  Frames shard across ranks, no data-path collective.
 --scaling weak (default): every rank runs its own batch per step.  --scaling strong: a fixed stream (c3: the 3,682 pairs of
-EuRoC MH01) is dealt frame f -> rank f mod N and every rank works through its share in batches.  With --gather the
-fixed-capacity result records are all-gathered over RCCL inside the timed region and placed by frame index on the device
-(wut-cuda-orb-slam3_amd/sharding.py, the code path tests/test_sharding_gloo.py covers); off by default because the path
-itself has no exchange step.
+EuRoC MH01) is dealt frame f -> rank f mod N and every rank works through its share in batches.  At N > 1 the fixed-capacity
+result records of every batch are all-gathered over RCCL INSIDE the timed region and placed by frame index on the device (north_star's
+"trivial gather"; wut-cuda-orb-slam3_amd/sharding.py, the code path tests/test_sharding_gloo.py covers) and `gather_ms` reports the
+collective's share per step; --no-gather leaves it out, --gather forces it at N = 1 (world-1 all-gather = a copy).  A rehearsal on
+fewer devices than ranks (gloo rendezvous) has no RCCL: `gather_ms` is null there.
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,7 +47,6 @@ import __graft_entry__ as graft  # noqa: E402
 NLEVELS, SCALE, INI_TH, MIN_TH = 8, 1.2, 20, 7
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PCIE_PEAK_GBS = 63.0        # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec)
-PRACTICAL_CYCLES_PER_VALU = 3.9  # measured issue cost of k_pyr_fast's own inner bodies run dense, in 2.4 GHz cycles (profiles/r03_inner_body_issue_rates.txt)
 MFMA_I8_16x16x64_CYCLES = 22.0   # measured back-to-back issue of v_mfma_i32_16x16x64_i8 on one SIMD (tools/experiments/mfma_i8_rate.hip; 16 by the data sheet)
 N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 CONFIGS = {
@@ -230,7 +232,9 @@ def main() -> None:
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="workload (default c2 = the metric's configuration)")
     ap.add_argument("--batch", type=int, default=0, help="units (frames / stereo pairs) per GPU per step (default: the config's)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--gather", action="store_true", help="all-gather the result records over RCCL inside the timed region")
+    ap.add_argument("--batches-per-step", type=int, default=4, help="distinct batches one step passes over (weak scaling)")
+    ap.add_argument("--gather", action="store_true", help="all-gather the result records over RCCL inside the timed region (default at N > 1)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1 without the result gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=5.0, help="seconds of all-thread CPU work per oracle build in the baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=0, help="units in the CPU-baseline sample (default: by config)")
@@ -275,6 +279,8 @@ def main() -> None:
             if args.gather:
                 raise SystemExit("--gather needs the nccl (RCCL) backend")
             dist.init_process_group(backend)
+    # the result gather is part of the multi-GPU job (north_star): on by default at N > 1 over RCCL
+    do_gather = (args.gather or (world > 1 and backend == "nccl")) and not args.no_gather
 
     pkg = graft.load_package()
     import importlib
@@ -288,8 +294,9 @@ def main() -> None:
     # weak: units rank * B .. rank * B + B - 1, the same batch every step.  strong: global stream of cfg["stream"] units dealt
     # f -> rank f mod world; the rank works through its share in sub-batches of B, `steps` passes over the whole stream.
     if args.scaling == "weak":
-        my_units = np.arange(rank * B, rank * B + B)
-        global_units = world * B
+        per_rank = B * max(args.batches_per_step, 1)
+        my_units = np.arange(rank * per_rank, rank * per_rank + per_rank)
+        global_units = world * per_rank
     else:
         global_units = cfg["stream"]
         my_units = sharding.frames_of_rank(global_units, world, rank)
@@ -300,11 +307,15 @@ def main() -> None:
         ids = my_units[c0: c0 + B]
         left = np.empty((len(ids), H, W), np.uint8)
         right = np.empty_like(left) if stereo else None
-        for j, u in enumerate(ids):
-            l1, r1 = make_frames(pkg, cfg, int(u), 1)
+
+        def fill(j):
+            l1, r1 = make_frames(pkg, cfg, int(ids[j]), 1)
             left[j] = l1[0]
             if stereo:
                 right[j] = r1[0]
+
+        with concurrent.futures.ThreadPoolExecutor(min(os.cpu_count() or 1, 8)) as tp:  # (the generator is C code behind ctypes: no GIL)
+            list(tp.map(fill, range(len(ids))))
         if host_first is None:
             host_first = (left, right)
         # units of this chunk over all ranks: weak = every rank its own B; strong = the global range [world * c0, world * (c0 + B))
@@ -338,15 +349,21 @@ def main() -> None:
     # result gather (north_star's "trivial gather"): zero-copy views of the left extractor's HBM outputs, RCCL all-gather,
     # device-side placement by frame index; ordered against the library's stream without a host synchronisation
     gather_state = None
-    if args.gather:
+    if do_gather:
         ext = torch.cuda.ExternalStream(exl.stream(), device=dev)
-        gather_state = {"ext": ext}
+        gather_state = {"ext": ext, "events": [], "timed": False}
 
     def gather(n, gtotal):
         cur = torch.cuda.current_stream()
         cur.wait_stream(gather_state["ext"])            # results of this rank are complete
+        if gather_state["timed"]:                       # the collective + placement alone, on the stream it runs on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
         local = sharding.device_output_tensors(exl, n, dev)
         rec = sharding.gather_frame_records(local, gtotal)  # slot = frame index within the chunk's global range
+        if gather_state["timed"]:
+            e1.record(cur)
+            gather_state["events"].append((e0, e1))
         gather_state["ext"].wait_stream(cur)            # the next batch overwrites the buffers only after the gather has read them
         return rec
 
@@ -372,21 +389,83 @@ def main() -> None:
         step()
     fence()
     exl.stage_times()  # reset the event ring
+    if gather_state is not None:
+        gather_state["timed"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     stage_ms, nb = exl.stage_times()
+    gather_ms = None
+    if gather_state is not None:
+        gather_state["timed"] = False
+        gather_ms = sum(a.elapsed_time(b) for a, b in gather_state["events"]) / max(args.steps, 1)
 
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def all_reduce(x, op):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return float(t.item())
+
+    dt = all_reduce(dt, "max")
+    if gather_ms is not None:
+        gather_ms = all_reduce(gather_ms, "max")
 
     n_last = chunks[-1][2]
     n, mono, _, _ = exl.download_outputs(n_last)
     total_kps = int(n.sum())
+
+    # ---- every rank: SURVEY 8(d)'s metric - orbx_extract_batch with host frames in (H2D) and keypoints + descriptors out (D2H) inside
+    # the call.  Three callers: everything pageable; frames page-locked; frames AND result arrays page-locked (orbx_host_alloc).  Result
+    # arrays are the caller's and reused between calls, as the reference's caller reuses its containers.  At N > 1 every rank runs the
+    # leg on its own buffers at the same time (barrier on both sides): the ranks share the host's DRAM and root complexes, which is the
+    # scaling question of this metric.  Aggregate = all ranks' frames / the slowest rank's wall time.
+    pcie = None
+    if not args.no_pcie:
+        hl, hr = host_first
+        np_units = min(len(hl), chunks[0][2])
+        hl, hr = hl[:np_units], (hr[:np_units] if stereo else None)
+
+        def locked(a):
+            p = pkg.host_array(a.shape, a.dtype)
+            p[...] = a
+            return p
+
+        pl, pr = locked(hl), (locked(hr) if stereo else None)
+        outs = {False: (exl.output_arrays(np_units), exr.output_arrays(np_units) if stereo else None),
+                True: (exl.output_arrays(np_units, page_locked=True), exr.output_arrays(np_units, page_locked=True) if stereo else None)}
+
+        def host_call(a, b, lockedOut):
+            # a stereo pair's two extractors on two host threads, as the reference runs them (src/Frame.cc:124-127): the copies of one
+            # handle's sub-batches fill the link while the other one's kernels run (ctypes releases the GIL inside the call)
+            # - with page-locked frames.  Two callers with PAGEABLE frames contend inside the runtime (it pins the pages of a copy behind
+            # the call): measured 15 % slower than one call after the other, so those run in turn.
+            t = None
+            if stereo and a is pl:
+                t = threading.Thread(target=lambda: exr.extract_batch(b, cfg["lap"], out=outs[lockedOut][1]))
+                t.start()
+            exl.extract_batch(a, cfg["lap"], out=outs[lockedOut][0])
+            if t:
+                t.join()
+            elif stereo:
+                exr.extract_batch(b, cfg["lap"], out=outs[lockedOut][1])
+
+        pcie = {}
+        reps = 5
+        for tag, (a, b, lo) in (("pageable", (hl, hr, False)), ("pinned_input", (pl, pr, False)), ("page_locked", (pl, pr, True))):
+            host_call(a, b, lo)
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                host_call(a, b, lo)
+            wall = time.perf_counter() - t1
+            if world > 1:
+                dist.barrier()
+            pcie[tag] = {"rank_frames_per_s": reps * np_units * fpu / wall,
+                         "frames_per_s": all_reduce(reps * np_units * fpu, "sum") / all_reduce(wall, "max")}
 
     if rank != 0:
         if world > 1:
@@ -397,7 +476,7 @@ def main() -> None:
     # ---- rank 0: roofline of the dominant kernel, matcher block, PCIe-inclusive rate, CPU baseline ---------------------------------
     d_left0, d_right0, n0, _ = chunks[0]
     # pyramid + FAST launch set alone on the GPU (stereo configs run two handles side by side in the timed loop)
-    if stereo or len(chunks) > 1:
+    if stereo or any(c[2] != n0 for c in chunks):
         for _ in range(2):
             exl.extract_batch_device(d_left0.data_ptr(), n0, W, H, W, W * H, cfg["lap"])
         exl.sync()
@@ -436,19 +515,13 @@ def main() -> None:
             # 2 cycles per instruction (the best case; at the measured cost of this instruction mix, profiles/r01_valu_microbench.txt:
             # 2.4-2.7 cycles for add/and/bitop3/shift, 4.1-4.5 for min/max/mul/alignbyte/SDWA forms, the peak is lower: `peak_mix`)
             ach = valu / (pyr_ms * 1e-3) / 1e9
-            roof["hbm"] = dict(hbm, traffic=roof["traffic"])
-            # `peak_practical`: what the kernel's OWN inner bodies (ring test, pre-test, corner score) reach when they run alone in dense
-            # loops from LDS, 8 waves per SIMD: 3.8 - 4.45 cycles per vector instruction in 2.4 GHz terms (3.3 - 4.0 real cycles at the
-            # 2.0 - 2.1 GHz the chip holds under that load), tools/experiments/ring_rate.hip -> profiles/r03_inner_body_issue_rates.txt;
-            # weighted with the phases' instruction shares: 3.9
-            prac = PRACTICAL_CYCLES_PER_VALU
-            roof.update({"bound": "valu_issue", "achieved": round(ach, 1), "peak": round(N_SIMD * CLOCK_GHZ / 2.0, 1), "unit": "G wave-instr/s",
-                         "frac": round(ach / (N_SIMD * CLOCK_GHZ / 2.0), 4), "peak_mix": round(N_SIMD * CLOCK_GHZ / cyc, 1),
-                         "frac_mix": round(ach / (N_SIMD * CLOCK_GHZ / cyc), 3), "peak_practical": round(N_SIMD * CLOCK_GHZ / prac, 1),
-                         "frac_practical": round(ach / (N_SIMD * CLOCK_GHZ / prac), 3),
-                         "practical_source": "profiles/r03_inner_body_issue_rates.txt (tools/experiments/ring_rate.hip)",
-                         "valu_wave_instr_per_launch_set": int(valu), "cycles_per_instr_mix": cyc, "clock_ghz": CLOCK_GHZ, "valu_source": src,
-                         "frac_hbm": hbm["frac"]})
+            # `roofline` stays the HBM roofline SURVEY 8(d) / the bench contract define (achieved = algorithmic bytes / launch-set time,
+            # peak 8 TB/s); the vector-issue view of the same launch set rides along as `valu_issue`, against the 2-cycle issue peak
+            # (1024 SIMD-32 x 2.4 GHz / 2) and against the peak of this instruction mix by class (`cycles_per_instr_mix`)
+            roof["valu_issue"] = {"achieved": round(ach, 1), "peak": round(N_SIMD * CLOCK_GHZ / 2.0, 1), "unit": "G wave-instr/s",
+                                  "frac": round(ach / (N_SIMD * CLOCK_GHZ / 2.0), 4), "peak_mix": round(N_SIMD * CLOCK_GHZ / cyc, 1),
+                                  "frac_mix": round(ach / (N_SIMD * CLOCK_GHZ / cyc), 3), "valu_wave_instr_per_launch_set": int(valu),
+                                  "cycles_per_instr_mix": cyc, "clock_ghz": CLOCK_GHZ, "valu_source": src}
         except Exception as e:  # the HBM block above stands (it is measured live); say why the counter-based part is missing
             roof["counters_dropped"] = f"{type(e).__name__}: {e}"[:240]
 
@@ -460,7 +533,13 @@ def main() -> None:
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / frames_total * 1e3, 6),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "value_definition": "frames/s of the whole job with the frames resident in HBM when the timed region starts and the results left in HBM"
+                            + (", result gather over RCCL inside the timed region" if gather_state is not None else "")
+                            + "; SURVEY 8(d)'s PCIe-inclusive rate is metric_8d_frames_per_s",
+        "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+        **({"gather_note": "rehearsal (gloo rendezvous, ranks share devices): no RCCL gather"} if rehearsal else {}),
         "config": {"workload": cfg["name"].format(u=B), "config_id": args.config, "units_per_gpu_per_step": int(len(my_units)),
+                   "batches_per_step": len(chunks), "distinct_frames_per_gpu": int(len(my_units)) * fpu,
                    "frames_per_unit": fpu, "keypoints_per_frame": round(total_kps / n_last, 1),
                    "parallelism": f"frame-sharded x{world}" + (f", stream of {global_units} units dealt f mod {world}" if args.scaling == "strong" else ""),
                    "gather": bool(gather_state is not None),
@@ -497,60 +576,30 @@ def main() -> None:
                         "frac_of_16_cycle_datasheet_peak": round(dpairs / mt / peak16, 3),
                         "valu_scan_issue_peak_descriptor_pairs_per_s": round(valu_peak, 0)})
         out["matcher"] = blk
-    if not args.no_pcie and world == 1:  # (host legs on rank 0 at N = 1 only)
-        # SURVEY 8(d)'s metric: orbx_extract_batch with host frames in (H2D) and keypoints + descriptors out (D2H) inside the call.  Three
-        # callers: everything pageable; frames page-locked; frames AND result arrays page-locked (orbx_host_alloc).  Result arrays are the
-        # caller's and reused between calls, as the reference's caller reuses its containers.
-        hl, hr = host_first
-        np_units = min(len(hl), n0)
-        hl, hr = hl[:np_units], (hr[:np_units] if stereo else None)
-
-        def locked(a):
-            p = pkg.host_array(a.shape, a.dtype)
-            p[...] = a
-            return p
-
-        pl, pr = locked(hl), (locked(hr) if stereo else None)
-        outs = {False: (exl.output_arrays(np_units), exr.output_arrays(np_units) if stereo else None),
-                True: (exl.output_arrays(np_units, page_locked=True), exr.output_arrays(np_units, page_locked=True) if stereo else None)}
-
-        def host_call(a, b, lockedOut):
-            # a stereo pair's two extractors on two host threads, as the reference runs them (src/Frame.cc:124-127): the copies of one
-            # handle's sub-batches fill the link while the other one's kernels run (ctypes releases the GIL inside the call)
-            # - with page-locked frames.  Two callers with PAGEABLE frames contend inside the runtime (it pins the pages of a copy behind
-            # the call): measured 15 % slower than one call after the other, so those run in turn.
-            t = None
-            if stereo and a is pl:
-                t = threading.Thread(target=lambda: exr.extract_batch(b, cfg["lap"], out=outs[lockedOut][1]))
-                t.start()
-            exl.extract_batch(a, cfg["lap"], out=outs[lockedOut][0])
-            if t:
-                t.join()
-            elif stereo:
-                exr.extract_batch(b, cfg["lap"], out=outs[lockedOut][1])
-
-        res = {}
-        reps = 5
-        for tag, (a, b, lo) in (("pageable", (hl, hr, False)), ("pinned_input", (pl, pr, False)), ("page_locked", (pl, pr, True))):
-            host_call(a, b, lo)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                host_call(a, b, lo)
-            res[tag] = reps * np_units * fpu / (time.perf_counter() - t1)
+    if pcie is not None:
+        res = {tag: v["frames_per_s"] for tag, v in pcie.items()}
+        out["metric_8d_frames_per_s"] = round(res["page_locked"], 1)
+        out["metric_8d_definition"] = ("SURVEY 8(d): orbx_extract_batch, host frames in (H2D) and keypoints + descriptors out (D2H) inside the call, page-locked "
+                                       "caller buffers; all ranks at the same time, all ranks' frames / slowest rank's wall time")
         out["pcie_inclusive_frames_per_s"] = round(res["pageable"], 1)
         out["pcie_inclusive_pinned_input_frames_per_s"] = round(res["pinned_input"], 1)
         out["pcie_inclusive_page_locked_frames_per_s"] = round(res["page_locked"], 1)
         bytes_in = W * H
-        bytes_out = float(total_kps) / n_last * 60.0 + 8.0  # keypoints (28 B) + descriptors (32 B) per feature, two counts per frame
+        kpf = float(total_kps) / n_last
+        payload_out = kpf * 60.0 + 8.0     # keypoints (28 B) + descriptors (32 B) per feature, two counts per frame
+        direct_out = cap * 60.0 + 8.0      # page-locked result arrays laid out like the handle's: full-capacity rows cross the link
         link = {}
         for tag in res:
-            gbs = res[tag] * bytes_in / 1e9
-            link[tag] = {"frames_per_s": round(res[tag], 1), "achieved": round(gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s H2D",
-                         "frac": round(gbs / PCIE_PEAK_GBS, 3), "d2h_gbs": round(res[tag] * bytes_out / 1e9, 2)}
-        out["pcie_roofline"] = {"bound": "pcie_h2d", "peak_note": "PCIe Gen5 x16, 63 GB/s per direction (MI355X_MICROARCH.md); frames cross H2D "
-                                "while results cross D2H (full duplex), so the input direction is the bound", **link}
+            gbs = res[tag] * bytes_in / 1e9 / world   # per GPU link
+            link[tag] = {"frames_per_s": round(res[tag], 1), "achieved": round(gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s H2D per GPU link",
+                         "frac": round(gbs / PCIE_PEAK_GBS, 3), "d2h_payload_gbs": round(res[tag] * payload_out / 1e9 / world, 2),
+                         "d2h_link_gbs": round(res[tag] * (direct_out if tag == "page_locked" else payload_out) / 1e9 / world, 2)}
+        out["pcie_roofline"] = {"bound": "pcie_h2d", "peak_note": "PCIe Gen5 x16, 63 GB/s per direction and GPU (MI355X_MICROARCH.md); frames cross H2D "
+                                "while results cross D2H (full duplex), so the input direction is the bound; d2h_link_gbs = bytes that really crossed "
+                                "(full-capacity rows in the page-locked direct mode), d2h_payload_gbs = the n[f] rows the caller uses", **link}
         out["pcie_inclusive_note"] = ("orbx_extract_batch: host frames in (H2D), keypoints + descriptors out (D2H), per call; extraction only"
-                                      + (" (both images of a pair; page-locked frames: one host thread per extractor, pageable frames: one call after the other)" if stereo else ""))
+                                      + (" (both images of a pair; page-locked frames: one host thread per extractor, pageable frames: one call after the other)" if stereo else "")
+                                      + (f"; {world} ranks at the same time, each on its own host buffers" if world > 1 else ""))
     if not args.no_cpu_baseline and world == 1:
         hl, hr = host_first
         ns = args.cpu_sample or {"c2": 1024, "c3": 128, "c4": 1024, "c5": 16}[args.config]

@@ -140,8 +140,11 @@ int orbx_extract_batch_sharded(orbx_extractor *const *handles, int nhandles, int
 
 /* Page-locked host memory for frames and result arrays.  orbx_extract_batch works from any host memory; frames in page-locked memory
  * cross the link asynchronously without a helper thread, and result arrays in page-locked memory (with capacity == orbx_max_keypoints)
- * are written by the device directly.  (The reference has no counterpart: its cv::Mat / std::vector buffers are pageable and
- * re-allocated per call, src/ORBextractor.cc:1251,1257,1315.) */
+ * are written by the device directly.  In that direct mode the device copies FULL-CAPACITY rows: the rows of frame f beyond n_out[f]
+ * are overwritten with unspecified bytes (with pageable or differently laid-out result arrays exactly n_out[f] rows per frame are
+ * written and the rest is left alone).  The whole range a call reads / writes must be page-locked for the asynchronous routes to be
+ * taken: a range registered only in part falls back to the staged routes.  (The reference has no counterpart: its cv::Mat /
+ * std::vector buffers are pageable and re-allocated per call, src/ORBextractor.cc:1251,1257,1315.) */
 void *orbx_host_alloc(size_t bytes);
 void orbx_host_free(void *p);
 /* The same for buffers the caller already owns (the cv::Mat data of a camera ring, a std::vector of frames): page-locks the range

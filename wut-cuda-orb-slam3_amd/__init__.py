@@ -571,7 +571,11 @@ class ORBmatcher:
 
     def _launch_fence(self, *inputs) -> None:
         import torch
-        torch.cuda.synchronize()
+        # every device the tensors live on (torch.cuda.synchronize() alone waits for torch's CURRENT device only: with the matcher on
+        # another GPU the fills / uploads above could land after its kernels)
+        devs = {t.device for t in inputs if t is not None and getattr(t, "is_cuda", False)}
+        for d in devs or {None}:
+            torch.cuda.synchronize(d)
         if not hasattr(self, "_inflight"):
             self._inflight = []
         self._inflight.extend(t for t in inputs if t is not None)

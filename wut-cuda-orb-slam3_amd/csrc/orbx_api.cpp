@@ -821,6 +821,22 @@ static bool isPageLocked(const void *p)
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // plain malloc'ed memory: "invalid value"
     return a.type == hipMemoryTypeHost;
 }
+// the whole range [p, p + bytes): orbx_host_register accepts any sub-range of a buffer, so the first byte alone does not say that the
+// tail is page-locked too (a pageable tail would turn the asynchronous copies into blocking ones)
+static bool isPageLockedRange(const void *p, size_t bytes)
+{
+    if (!isPageLocked(p)) return false;
+    return bytes <= 1 || isPageLocked((const uint8_t *)p + bytes - 1);
+}
+// after an error in the middle of a batch: nothing of the failed call may still run (or copy out of / into the caller's arrays) when the
+// next call on this handle starts
+static void drainHandle(orbx_extractor *ex)
+{
+    for (hipStream_t st : {ex->stream, ex->stream2, ex->stream3, ex->streamCopy, ex->streamOut})
+        if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : ex->qtStream)
+        if (st) (void)hipStreamSynchronize(st);
+}
 
 // H2D of frames [f0, f0 + nf) of a host batch into the pitched device buffer.  A host-to-device copy whose two pitches differ is a 2-D
 // copy, which the runtime executes row by row: 3.0 ms for ONE 1242 x 375 frame (KITTI) against 0.03 ms for a 1024-wide one whose pitch
@@ -1590,12 +1606,15 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
     HostPipe pipe;
     pipe.kps = kps; pipe.desc = desc; pipe.capacity = capacity; pipe.nOut = n_out; pipe.monoOut = mono_out;
     static const int feederEnv = [] { const char *e = getenv("ORBX_HOST_FEEDER"); return e ? atoi(e) : -1; }();  // A/B: 0 no helper thread, 1 always
-    pipe.feeder = feederEnv >= 0 ? feederEnv != 0 : !isPageLocked(hf.imgs);
-    pipe.direct = capacity == ex->maxKeypoints && hf.run >= nframes && (!kps || isPageLocked(kps)) && (!desc || isPageLocked(desc));
+    // (first to last byte this handle reads: its last frame sits at host index hostIndex(nframes - 1))
+    const size_t imgBytes = hf.hostIndex(nframes - 1) * (size_t)hf.frameStride + (size_t)(h - 1) * (size_t)hf.stride + (size_t)w;
+    pipe.feeder = feederEnv >= 0 ? feederEnv != 0 : !(hf.frameStride > 0 && isPageLockedRange(hf.imgs, imgBytes));
+    pipe.direct = capacity == ex->maxKeypoints && hf.run >= nframes && (!kps || isPageLockedRange(kps, (size_t)nframes * capacity * sizeof(orbx_keypoint))) &&
+                  (!desc || isPageLockedRange(desc, (size_t)nframes * capacity * 32));
     hf.pipe = &pipe;
     rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
     if (rc == ORBX_OK) rc = pipeDrain(ex, &hf, true, pipe.nsub);
-    if (rc != ORBX_OK) (void)hipStreamSynchronize(ex->streamOut);  // nothing of this call may still be writing into the caller's arrays
+    if (rc != ORBX_OK) drainHandle(ex);  // nothing of this call may still be running, or copying out of / into the caller's arrays
     if (rc == ORBX_OK && hostTimeline()) {
         auto at = [&](hipEvent_t e) { float ms = -1.f; (void)hipEventElapsedTime(&ms, ex->evIn, e); return ms; };
         fprintf(stderr, "[orbx] host batch of %d frames in %d sub-batches (ms since the call's first event):\n", nframes, pipe.nsub);
@@ -2444,13 +2463,18 @@ static int projectionRoundsImpl(const char *fn, orbx_matcher *m, const orbx_keyp
     in.add(keys, (size_t)n * sizeof(orbx_keypoint), m->d_kr.p);
     in.add(points, (size_t)np * sizeof(orbx_window_point), dPts);
     in.add(blocked.data(), (size_t)n, dBlocked);
+    std::vector<int32_t> idx((size_t)np), dist((size_t)np), choice((size_t)np, -2), owner((size_t)n, -1);
+    // round 0's owner array rides with the inputs: the staging still belongs to `in`'s asynchronous copy until the first
+    // synchronisation (HostFetch::finish at the end of round 0) - a second HostPack before that would overwrite it under the copy
+    in.add(owner.data(), (size_t)n * sizeof(int), dOwner);
     if ((rc = in.send()) != ORBX_OK) return rc;
     HIP_TRY(orbxLaunchGridBuild(st, m->d_kr.p, n, min_x, max_x, min_y, max_y, cs, it, co));
-    std::vector<int32_t> idx((size_t)np), dist((size_t)np), choice((size_t)np, -2), owner((size_t)n, -1);
     for (int round = 0; round <= np; ++round) {
-        HostPack own(m);  // (the staging is free again: every round ends with a synchronised stream)
-        own.add(owner.data(), (size_t)n * sizeof(int), dOwner);
-        if ((rc = own.send()) != ORBX_OK) return rc;
+        if (round > 0) {
+            HostPack own(m);  // (the staging is free again: every round ends with a synchronised stream)
+            own.add(owner.data(), (size_t)n * sizeof(int), dOwner);
+            if ((rc = own.send()) != ORBX_OK) return rc;
+        }
         HIP_TRY(orbxLaunchKeyframeWindowSearch(st, m->d_kr.p, m->d_t.p, nullptr, nullptr, cs, it, min_x, max_x, min_y, max_y, dPts, m->d_q.p, np, 0, dIdx,
                                                dDist, dBlocked, dOwner, level_hi));
         HostFetch out(m);

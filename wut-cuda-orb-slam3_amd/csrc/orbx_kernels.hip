@@ -157,12 +157,56 @@ __device__ __forceinline__ int fast_corner_score(const uint8_t *c, int tp)
 #define SW_H 0x80808080u
 #define SW_L 0x7F7F7F7Fu
 
+// 3-input bitwise function by truth table (v_bitop3_b32): result bit = tt[(a << 2) | (b << 1) | c], i.e. a = 0xF0, b = 0xCC, c = 0xAA.
+#define BITOP3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+// per byte, bit 7: [x < y] (unsigned) from x, y and a word t whose bit 7 says [low 7 bits of x >= low 7 bits of y]:
+// (~x & y) | (~(x ^ y) & ~t) - ONE v_bitop3.  Written as that C expression the compiler does not keep it one instruction where x or y is
+// itself an expression: it expands LO = tS ^ ((V ^ ~T4) & SW_H) and HI into their terms and re-associates, and every compare then
+// costs two or three v_bitop3 plus a (half-rate) v_and_or - 9 instead of 6 vector instructions per ring position (round 4; ISA of round 3's
+// kernel).  PF_SWAR_IMPL=0 keeps the round-3 formulation for tools/experiments/ring_rate.hip.
+#define SW_LT(x, y, t) BITOP3((x), (y), (t), 0x4D)
+#define SW_AND3(a, b, c) BITOP3((a), (b), (c), 0x80)
+#define SW_OR3(a, b, c) BITOP3((a), (b), (c), 0xFE)
+#ifndef PF_SWAR_IMPL
+#define PF_SWAR_IMPL 1
+#endif
+// a value the optimiser cannot look into (no instruction)
+__device__ __forceinline__ uint32_t sw_opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
+
+// The per-group constants of the two compares of a ring byte P against the centre byte v:
+//   dark   P < LO = v - th :  td = (P & 0x7F) + Kd,  Kd = 0x80 - (LO & 0x7F):  bit 7 of td = [Pl >= LOl];  D = SW_LT(P, LO, td)
+//   bright P > HI = v + th :  tb = HIh - (P & 0x7F), HIh = HI | 0x80:          bit 7 of tb = [HIl >= Pl];  B = SW_LT(HI, P, tb)
+// LO / HI wrap modulo 256; pixels with v - th < 0 (v + th > 255) cannot have dark (bright) ring pixels: noDark / noBright.
+struct SwarCentre {
+    uint32_t LO, HI, Kd, HIh, noDark, noBright;
+};
+__device__ __forceinline__ SwarCentre swar_centre(uint32_t V, uint32_t T4, uint32_t C4)
+{
+    SwarCentre c;
+    const uint32_t Vl = V & SW_L;
+    const uint32_t tS = (V | SW_H) - (T4 & SW_L);
+    const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
+    c.noDark = SW_LT(V, T4, tS);
+    const uint32_t HI = (Vl + (T4 & SW_L)) ^ ((V ^ T4) & SW_H);
+    const uint32_t tC = (C4 | SW_H) - Vl;
+    c.noBright = SW_LT(C4, V, tC);
+    c.LO = sw_opaque(LO);
+    c.HI = sw_opaque(HI);
+    c.Kd = sw_opaque(SW_H - (c.LO & SW_L));
+    c.HIh = sw_opaque(c.HI | SW_H);
+    return c;
+}
+
 // The group's pixels are bytes 4..7 of a 16-byte LDS window starting at `wp` (row y-3; 4-byte aligned).  Each ring dword
 // pair is fetched from LDS on demand instead of holding a 7 x 16-byte window in registers: ~50 VGPRs instead of ~75,
 // so the kernel reaches 8 waves/SIMD without scratch spills.
 __device__ __forceinline__ uint32_t fast_group_flags_lds(const uint8_t *wp, int tp, uint32_t T4, uint32_t C4)
 {
     const uint32_t V = *(const uint32_t *)(wp + 3 * tp + 4);
+#if PF_SWAR_IMPL
+    const SwarCentre c = swar_centre(V, T4, C4);
+    const uint32_t LO = c.LO, HI = c.HI, Kd = c.Kd, HIh = c.HIh, ltVT = c.noDark, ltCV = c.noBright;
+#else
     const uint32_t Vl = V & SW_L;
     const uint32_t tS = (V | SW_H) - (T4 & SW_L);
     const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
@@ -172,7 +216,13 @@ __device__ __forceinline__ uint32_t fast_group_flags_lds(const uint8_t *wp, int 
     const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);
     const uint32_t Kd = SW_H - (LO & SW_L);
     const uint32_t HIh = HI | SW_H;
+#endif
     uint32_t D[16], B[16];
+#if PF_SWAR_IMPL
+#define RING_CMP(k) D[k] = SW_LT(P, LO, td); B[k] = SW_LT(HI, P, tb);
+#else
+#define RING_CMP(k) D[k] = (~P & LO) | (~(P ^ LO) & ~td); B[k] = (~HI & P) | (~(HI ^ P) & ~tb);
+#endif
 #define RING(k, dx, dy)                                                                            \
     {                                                                                              \
         constexpr int o = 4 + (dx);                                                                \
@@ -181,12 +231,37 @@ __device__ __forceinline__ uint32_t fast_group_flags_lds(const uint8_t *wp, int 
         const uint32_t Pl = P & SW_L;                                                              \
         const uint32_t td = Pl + Kd;                                                               \
         const uint32_t tb = HIh - Pl;                                                              \
-        D[k] = (~P & LO) | (~(P ^ LO) & ~td);                                                      \
-        B[k] = (~HI & P) | (~(HI ^ P) & ~tb);                                                      \
+        RING_CMP(k)                                                                                \
     }
     RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
     RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2) RING(15, -1, 3)
 #undef RING
+#undef RING_CMP
+#if PF_SWAR_IMPL
+    // ">= 9 contiguous of 16": runs of three, runs of nine out of three runs of three, then the OR over the 16 arcs - all 3-input
+    uint32_t d3[16], b3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        d3[k] = SW_AND3(D[k], D[(k + 1) & 15], D[(k + 2) & 15]);
+        b3[k] = SW_AND3(B[k], B[(k + 1) & 15], B[(k + 2) & 15]);
+    }
+    uint32_t d9[16], b9[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        d9[k] = SW_AND3(d3[k], d3[(k + 3) & 15], d3[(k + 6) & 15]);
+        b9[k] = SW_AND3(b3[k], b3[(k + 3) & 15], b3[(k + 6) & 15]);
+    }
+    uint32_t rd = SW_OR3(d9[0], d9[1], d9[2]), rb = SW_OR3(b9[0], b9[1], b9[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) {
+        rd = SW_OR3(rd, d9[k], d9[k + 1]);
+        rb = SW_OR3(rb, b9[k], b9[k + 1]);
+    }
+    // (rd | d9[15]) & ~noDark  |  (rb | b9[15]) & ~noBright
+    rd = BITOP3(rd, d9[15], ltVT, 0x54);  // (a | b) & ~c
+    rb = BITOP3(rb, b9[15], ltCV, 0x54);
+    return (rd | rb) & SW_H;
+#else
     uint32_t d3[16], b3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -200,17 +275,20 @@ __device__ __forceinline__ uint32_t fast_group_flags_lds(const uint8_t *wp, int 
         rb |= b3[k] & b3[(k + 3) & 15] & b3[(k + 6) & 15];
     }
     return ((rd & ~ltVT) | (rb & ~ltCV)) & SW_H;
+#endif
 }
 
 // Cheap necessary condition for the ring test of one 4-pixel group: a contiguous arc of 9 ring pixels contains two
 // adjacent compass points, i.e. (k0 | k8) & (k4 | k12) must hold for one polarity (the first two of OpenCV's
 // opposite-pair checks).  Needs only the rows y-3, y, y+3 of the strip window (w0, w3, w6).  On the benchmark
 // frames 11-22 % of the groups pass at iniThFAST; only those go through the full 16-position test.
-template <int GRP>
-__device__ __forceinline__ uint32_t fast_group_pretest(const uint32_t (&w0)[4], const uint32_t (&w3)[4], const uint32_t (&w6)[4],
-                                                       uint32_t T4, uint32_t C4)
+// V = the group's centre dword, Vlft / Vrgt its neighbours in the row, Pdn / Pup the dwords three rows below / above.
+__device__ __forceinline__ uint32_t fast_group_pretest_v(uint32_t V, uint32_t Vlft, uint32_t Vrgt, uint32_t Pdn, uint32_t Pup, uint32_t T4, uint32_t C4)
 {
-    const uint32_t V = w3[1 + GRP];
+#if PF_SWAR_IMPL
+    const SwarCentre c = swar_centre(V, T4, C4);
+    const uint32_t LO = c.LO, HI = c.HI, Kd = c.Kd, HIh = c.HIh, ltVT = c.noDark, ltCV = c.noBright;
+#else
     const uint32_t Vl = V & SW_L;
     const uint32_t tS = (V | SW_H) - (T4 & SW_L);
     const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
@@ -220,20 +298,38 @@ __device__ __forceinline__ uint32_t fast_group_pretest(const uint32_t (&w0)[4], 
     const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);
     const uint32_t Kd = SW_H - (LO & SW_L);
     const uint32_t HIh = HI | SW_H;
+#endif
     uint32_t D[4], B[4];
-    const uint32_t P[4] = {w6[1 + GRP], __builtin_amdgcn_alignbyte(w3[2 + GRP], w3[1 + GRP], 3), w0[1 + GRP],
-                           __builtin_amdgcn_alignbyte(w3[1 + GRP], w3[GRP], 1)};  // k = 0, 4, 8, 12
+    const uint32_t P[4] = {Pdn, __builtin_amdgcn_alignbyte(Vrgt, V, 3), Pup, __builtin_amdgcn_alignbyte(V, Vlft, 1)};  // k = 0, 4, 8, 12
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t Pl = P[j] & SW_L;
         const uint32_t td = Pl + Kd;
         const uint32_t tb = HIh - Pl;
+#if PF_SWAR_IMPL
+        D[j] = SW_LT(P[j], LO, td);
+        B[j] = SW_LT(HI, P[j], tb);
+#else
         D[j] = (~P[j] & LO) | (~(P[j] ^ LO) & ~td);
         B[j] = (~HI & P[j]) | (~(HI ^ P[j]) & ~tb);
+#endif
     }
+#if PF_SWAR_IMPL
+    // ((D0 | D2) & (D1 | D3) & ~noDark) | ((B0 | B2) & (B1 | B3) & ~noBright)
+    const uint32_t dv = BITOP3(D[0], D[2], ltVT, 0x54), bv = BITOP3(B[0], B[2], ltCV, 0x54);  // (a | b) & ~c
+    const uint32_t d = BITOP3(D[1], D[3], dv, 0xA8), b = BITOP3(B[1], B[3], bv, 0xA8);        // (a | b) & c
+    return (d | b) & SW_H;
+#else
     const uint32_t d = (D[0] | D[2]) & (D[1] | D[3]);
     const uint32_t b = (B[0] | B[2]) & (B[1] | B[3]);
     return ((d & ~ltVT) | (b & ~ltCV)) & SW_H;
+#endif
+}
+template <int GRP>
+__device__ __forceinline__ uint32_t fast_group_pretest(const uint32_t (&w0)[4], const uint32_t (&w3)[4], const uint32_t (&w6)[4],
+                                                       uint32_t T4, uint32_t C4)
+{
+    return fast_group_pretest_v(w3[1 + GRP], w3[GRP], w3[2 + GRP], w6[1 + GRP], w0[1 + GRP], T4, C4);
 }
 
 // exclusive prefix sum over the wave (all 64 lanes active): Kogge-Stone inside the rows of 16 lanes with DPP row shifts, then the
@@ -806,33 +902,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
 // =====================================================================================================
 #define PFC_GQ 128  // entries of a wave's ring of pre-test survivors (row << 9 | LDS column / 4)
 
-// pre-test of ONE 4-pixel group (see fast_group_pretest): centre dword V with its left / right neighbours in the row, the dwords three
-// rows below (ring position 0) and above (8)
-__device__ __forceinline__ uint32_t fast_group_pretest1(uint32_t V, uint32_t Vl_, uint32_t Vr_, uint32_t Pdn, uint32_t Pup, uint32_t T4, uint32_t C4)
-{
-    const uint32_t Vl = V & SW_L;
-    const uint32_t tS = (V | SW_H) - (T4 & SW_L);
-    const uint32_t LO = tS ^ ((V ^ ~T4) & SW_H);
-    const uint32_t ltVT = (~V & T4) | (~(V ^ T4) & ~tS);
-    const uint32_t HI = (Vl + (T4 & SW_L)) ^ ((V ^ T4) & SW_H);
-    const uint32_t tC = (C4 | SW_H) - Vl;
-    const uint32_t ltCV = (~C4 & V) | (~(C4 ^ V) & ~tC);
-    const uint32_t Kd = SW_H - (LO & SW_L);
-    const uint32_t HIh = HI | SW_H;
-    uint32_t D[4], B[4];
-    const uint32_t P[4] = {Pdn, __builtin_amdgcn_alignbyte(Vr_, V, 3), Pup, __builtin_amdgcn_alignbyte(V, Vl_, 1)};  // k = 0, 4, 8, 12
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t Pl = P[j] & SW_L;
-        const uint32_t td = Pl + Kd;
-        const uint32_t tb = HIh - Pl;
-        D[j] = (~P[j] & LO) | (~(P[j] ^ LO) & ~td);
-        B[j] = (~HI & P[j]) | (~(HI ^ P[j]) & ~tb);
-    }
-    const uint32_t d = (D[0] | D[2]) & (D[1] | D[3]);
-    const uint32_t b = (B[0] | B[2]) & (B[1] | B[3]);
-    return ((d & ~ltVT) | (b & ~ltCV)) & SW_H;
-}
+// pre-test of ONE 4-pixel group: fast_group_pretest_v (centre dword V with its left / right neighbours in the row, the dwords three
+// rows below (ring position 0) and above (8))
+#define fast_group_pretest1 fast_group_pretest_v
 
 // strict 3x3 maximum inside the cell's columns [cc0, cc1) (cv::FAST's nonmax suppression on the cell's ROI): score row r + 1 of the
 // score tile is tile row r; rows 0 and THi + 1 stay zero
