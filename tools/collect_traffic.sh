@@ -9,8 +9,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/traffic
 rm -rf gpurun_out/traffic/FETCH_SIZE gpurun_out/traffic/WRITE_SIZE gpurun_out/traffic/SQ
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/traffic/$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie "$@" > gpurun_out/traffic/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/traffic/$c -- python3 bench.py --batches-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pcie "$@" > gpurun_out/traffic/$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/traffic/SQ -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie "$@" > gpurun_out/traffic/SQ.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/traffic/SQ -- python3 bench.py --batches-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pcie "$@" > gpurun_out/traffic/SQ.log 2>&1
 python3 tools/summarize_traffic.py gpurun_out/traffic
 cat gpurun_out/traffic/pyr_fast_counters.json

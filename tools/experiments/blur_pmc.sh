@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() { # name, counters
   rm -rf gpurun_out/bpmc_$1
-  rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/bpmc_$1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > gpurun_out/bpmc_$1.log 2>&1
+  rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/bpmc_$1 -- python3 bench.py --batches-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > gpurun_out/bpmc_$1.log 2>&1
   rc=$?
   f=$(find gpurun_out/bpmc_$1 -name "*counter_collection.csv" 2>/dev/null | sort | sed -n 1p)
   if [ $rc -ne 0 ] || [ -z "$f" ]; then echo "pass $1 ($2): rocprofv3 exit $rc, no counter file - see gpurun_out/bpmc_$1.log"; return 1; fi

@@ -97,23 +97,171 @@ def ring_like(reads, wait, nbanked=True):
     return out
 
 
+body("alt_and_bitop3", [(f"v_and_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}" if i % 2 else
+                         f"v_bitop3_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{srcs_distinct(acc(i))[1]} bitop3:0x96") for i in range(NB)],
+     note="4-byte and 8-byte encodings alternating")
+body("alt_and_alignbyte", [(f"v_and_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}" if i % 2 else
+                            f"v_alignbyte_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, 1") for i in range(NB)], note="VOP2 and the slow VOP3 class alternating")
+body("and3_e32_x3", [f"v_and_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}" for i in range(3 * NB)], note="96 instructions per loop body (loop overhead / fetch of a longer body)")
+# LDS-only streams: 16 reads, one wait.  v7 = 4 * lane (dword-aligned, consecutive lanes = consecutive dwords); v6 = 8 * lane; v5 = 16 * lane
+def lds_body(ins):
+    out = []
+    for k in range(16):
+        d = 40 + (k % 2) * 4
+        out.append(ins.format(k=k, k1=k + 1, o4=4 * k, o8=8 * k, o8p4=8 * k + 4, o16=16 * k, d=d, d1=d + 1, d2=d + 2, d3=d + 3))
+    return out + ["s_waitcnt lgkmcnt(0)"]
+body("lds_read_b32", lds_body("ds_read_b32 v{d}, v7 offset:{o4}"), nvalu=16, note="LDS only: 16 x ds_read_b32 (lane stride 4 B), one wait")
+body("lds_read2_b32", lds_body("ds_read2_b32 v[{d}:{d}+1], v7 offset0:{k} offset1:{k}+1".replace("{d}+1", "{d1}").replace("{k}+1", "{k1}")), nvalu=16, note="LDS only: ds_read2_b32 of two adjacent dwords")
+body("lds_read_b64_al8", lds_body("ds_read_b64 v[{d}:{d1}], v6 offset:{o8}"), nvalu=16, note="LDS only: ds_read_b64, 8-byte aligned (lane stride 8 B)")
+body("lds_read_b64_al4", lds_body("ds_read_b64 v[{d}:{d1}], v6 offset:{o8p4}"), nvalu=16, note="LDS only: ds_read_b64 at addresses = 4 mod 8")
+body("lds_read_b64_s4", lds_body("ds_read_b64 v[{d}:{d1}], v7 offset:{o4}"), nvalu=16, note="LDS only: ds_read_b64, lane stride 4 B (overlapping, as the ring test's pairs)")
+body("lds_read_b128_al16", lds_body("ds_read_b128 v[{d}:{d3}], v5 offset:{o16}"), nvalu=16, note="LDS only: ds_read_b128, 16-byte aligned")
+body("lds_read_b96_s4", lds_body("ds_read_b96 v[{d}:{d2}], v7 offset:{o4}"), nvalu=16, note="LDS only: ds_read_b96, lane stride 4 B (3 dwords of a row window)")
+body("lds_read_b128_s4", lds_body("ds_read_b128 v[{d}:{d3}], v7 offset:{o4}"), nvalu=16, note="LDS only: ds_read_b128, lane stride 4 B, dword-aligned only")
+# ---- mixing rules: runs of k full-rate instructions (F = v_and_b32_e32 / v_bitop3) followed by ONE instruction of another class, 96 per body
+def F(i):
+    return f"v_and_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}" if i % 2 else \
+           f"v_bitop3_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{srcs_distinct(acc(i))[1]} bitop3:0x96"
+SLOW = {
+    "alignbyte": lambda i: f"v_alignbyte_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, 1",
+    "sgprsrc": lambda i: f"v_and_b32_e32 v{acc(i)}, s21, v{acc(i)}",
+    "min": lambda i: f"v_min_i32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "mul24": lambda i: f"v_mul_u32_u24_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "or3": lambda i: f"v_or3_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{srcs_distinct(acc(i))[1]}",
+    "cvt": lambda i: f"v_cvt_f32_u32_e32 v{acc(i)}, v{acc(i)}",
+    "lit": lambda i: f"v_and_b32_e32 v{acc(i)}, 0x7f7f7f7f, v{acc(i)}",
+    "cndmask": lambda i: f"v_cndmask_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}, vcc",
+    "cmp": lambda i: f"v_cmp_lt_u32_e32 vcc, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "readlane": lambda i: f"v_readfirstlane_b32 s22, v{acc(i)}",
+    "dpp": lambda i: f"v_add_u32_dpp v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]} row_shr:1 row_mask:0xf bank_mask:0xf",
+    "mbcnt": lambda i: f"v_mbcnt_lo_u32_b32 v{acc(i)}, -1, v{acc(i)}",
+    "lshl_add": lambda i: f"v_lshl_add_u32 v{acc(i)}, v{acc(i)}, 1, v{srcs_distinct(acc(i))[1]}",
+    "mad_u64": lambda i: f"v_mad_u64_u32 v[44:45], s[22:23], v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v[44:45]",
+}
+for sname, fn in SLOW.items():
+    body(f"pure_{sname}", [fn(i) for i in range(96)], note=f"96 x {sname}")
+    for k in (1, 3, 7):
+        lines = []
+        for i in range(96):
+            lines.append(fn(i) if i % (k + 1) == k else F(i))
+        body(f"F{k}_{sname}", lines, note=f"runs of {k} full-rate instructions + one {sname}")
+# ---- how long does the slow rate last after one slow-class instruction?  runs of k full-rate instructions + 1 v_alignbyte, k up to 255
+for k in (15, 31, 63, 127, 255):
+    n = max(256, k + 1)
+    body(f"F{k}_alignbyte", [SLOW["alignbyte"](i) if i % (k + 1) == k else F(i) for i in range(n)], note=f"runs of {k} full-rate instructions + one v_alignbyte")
+# clustered: the same 1 : 7 ratio as F7_alignbyte, but the slow instructions together
+for g in (4, 16, 32):
+    body(f"S{g}_F{7 * g}", [SLOW["alignbyte"](i) for i in range(g)] + [F(i) for i in range(7 * g)], note=f"{g} x v_alignbyte together, then {7 * g} full-rate instructions")
+# ---- class of further opcodes, by their effect on the neighbours: F7_<op> ~ 2.2 -> full rate, ~ 4 -> slow class
+CLASSIFY = {
+    "xor": lambda i: f"v_xor_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "or": lambda i: f"v_or_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "sub": lambda i: f"v_sub_u32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "subrev": lambda i: f"v_subrev_u32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "lshl": lambda i: f"v_lshlrev_b32_e32 v{acc(i)}, 3, v{acc(i)}",
+    "lshl_v": lambda i: f"v_lshlrev_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "ashr": lambda i: f"v_ashrrev_i32_e32 v{acc(i)}, 3, v{acc(i)}",
+    "mov": lambda i: f"v_mov_b32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}",
+    "not": lambda i: f"v_not_b32_e32 v{acc(i)}, v{acc(i)}",
+    "add_f32": lambda i: f"v_add_f32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "mul_f32": lambda i: f"v_mul_f32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "fmac_f32": lambda i: f"v_fmac_f32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{srcs_distinct(acc(i))[1]}",
+    "fma_f32": lambda i: f"v_fma_f32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{srcs_distinct(acc(i))[1]}",
+    "max_f32": lambda i: f"v_max_f32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "cndmask_s": lambda i: f"v_cndmask_b32_e64 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}, s[24:25]",
+    "bfe": lambda i: f"v_bfe_u32 v{acc(i)}, v{acc(i)}, 3, 8",
+    "and_or": lambda i: f"v_and_or_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{srcs_distinct(acc(i))[1]}",
+    "lshl_or": lambda i: f"v_lshl_or_b32 v{acc(i)}, v{acc(i)}, 3, v{srcs_distinct(acc(i))[0]}",
+    "add_co": lambda i: f"v_add_co_u32_e32 v{acc(i)}, vcc, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "mul_lo": lambda i: f"v_mul_lo_u32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}",
+    "sdwa": lambda i: f"v_add_u32_sdwa v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD",
+    "bcnt": lambda i: f"v_bcnt_u32_b32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "max_u32": lambda i: f"v_max_u32_e32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+    "pk_add_u16": lambda i: f"v_pk_add_u16 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}",
+    "bitop3_lit": lambda i: f"v_bitop3_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, s21 bitop3:0x96",
+    "alignbit": lambda i: f"v_alignbit_b32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, 8",
+    "and_inl": lambda i: f"v_and_b32_e32 v{acc(i)}, 63, v{acc(i)}",
+    "bfi": lambda i: f"v_bfi_b32 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{srcs_distinct(acc(i))[1]}, v{acc(i)}",
+    "add_lshl": lambda i: f"v_add_lshl_u32 v{acc(i)}, v{acc(i)}, v{srcs_distinct(acc(i))[0]}, 2",
+    "sub_i32_e64": lambda i: f"v_sub_u32_e64 v{acc(i)}, v{srcs_distinct(acc(i))[0]}, v{acc(i)}",
+}
+for cname, fn in CLASSIFY.items():
+    body(f"pure_{cname}", [fn(i) for i in range(96)], note=f"96 x {cname}")
+    body(f"F7_{cname}", [fn(i) if i % 8 == 7 else F(i) for i in range(96)], note=f"runs of 7 full-rate instructions + one {cname}")
+# ---- what ends the slow rate?  one v_alignbyte, ONE candidate instruction, then 126 full-rate instructions (and the loop's s_sub / s_cmp / s_cbranch)
+RESET = {
+    "nothing": [],
+    "s_nop0": ["s_nop 0"],
+    "s_nop7": ["s_nop 7"],
+    "waitcnt_lgkm": ["s_waitcnt lgkmcnt(0)"],
+    "waitcnt_vm": ["s_waitcnt vmcnt(0)"],
+    "s_add": ["s_add_u32 s22, s22, 1"],
+    "s_mov": ["s_mov_b32 s22, 5"],
+    "s_cmp": ["s_cmp_lg_u32 s22, 0"],
+    "s_branch_next": ["s_branch .Lnext_{name}_{u}", ".Lnext_{name}_{u}:"],
+    "s_cbranch_nottaken": ["s_cmp_eq_u32 s20, 0", "s_cbranch_scc1 .Lloop_{name}"],
+    "s_cbranch_taken_next": ["s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 .Lnext_{name}_{u}", ".Lnext_{name}_{u}:"],
+    "ds_read_wait": ["ds_read_b32 v40, v7", "s_waitcnt lgkmcnt(0)"],
+    "ds_read_nowait": ["ds_read_b32 v40, v7"],
+    "s_barrier": ["s_barrier"],
+    "s_sleep": ["s_sleep 1"],
+    "s_setprio": ["s_setprio 0"],
+    "v_nop": ["v_nop"],
+    "v_mov": ["v_mov_b32_e32 v41, v24"],
+    "s_setreg": ["s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 4), 0"],
+    "s_waitcnt_depctr": ["s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)"],
+    "two_F_then_nop": None,
+}
+for rname, cand in RESET.items():
+    lines = []
+    for rep in range(2):   # two such sequences per loop body (256 vector instructions)
+        lines.append(SLOW["alignbyte"](0))
+        if cand is None:
+            lines += [F(1), F(2), "s_nop 0"]
+            lines += [F(i) for i in range(3, 128)]
+        else:
+            lines += [c.replace("{u}", str(rep)) for c in cand]
+            lines += [F(i) for i in range(1, 128)]
+    body(f"R_{rname}", ["@@" + l for l in lines], nvalu=len([l for l in lines if l.startswith("v_")]), note=f"v_alignbyte, then [{rname}], then 127 full-rate instructions (x 2 per loop body)")
+# ---- the same mixes with the s_nop 0 that tools/sq_slowmode.py inserts behind every slow-class instruction: per wave the slow rate should
+# then hold for the slow instruction alone - unless the slow rate is a state of the SIMD that the OTHER waves' instructions keep alive
+ALLCLS = dict(SLOW); ALLCLS.update(CLASSIFY)
+for sname in ("alignbyte", "min", "cmp", "lshl", "mul24", "cvt", "mul_lo", "lshl_add"):
+    fn = ALLCLS[sname]
+    for k in (1, 3, 7, 15):
+        lines = []
+        for i in range(96):
+            if i % (k + 1) == k:
+                lines += [fn(i), "s_nop 0"]
+            else:
+                lines.append(F(i))
+        body(f"N{k}_{sname}", lines, note=f"runs of {k} full-rate instructions + one {sname} + s_nop 0")
+body("pure_F", [F(i) for i in range(96)], note="96 x full-rate (v_and_b32_e32 / v_bitop3 alternating)")
+body("F7_salu", sum([[F(8 * j + t) for t in range(7)] + ["s_add_u32 s22, s22, 1"] for j in range(12)], []), note="7 full-rate + one s_add_u32 (84 vector instructions)")
+body("F7_nop", sum([[F(8 * j + t) for t in range(7)] + ["s_nop 0"] for j in range(12)], []), note="7 full-rate + s_nop 0")
+body("F7_waitcnt", sum([[F(8 * j + t) for t in range(7)] + ["s_waitcnt lgkmcnt(0)"] for j in range(12)], []), note="7 full-rate + s_waitcnt lgkmcnt(0) with nothing outstanding")
+body("F7_ldsread", sum([[F(8 * j + t) for t in range(7)] + [f"ds_read_b32 v{40 + j % 4}, v7 offset:{16 * j}"] for j in range(12)] + [["s_waitcnt lgkmcnt(0)"]], []),
+     note="7 full-rate + one ds_read_b32, one wait per body (84 vector instructions, 12 reads)")
+body("F7_ldsread_wait", sum([[F(8 * j + t) for t in range(7)] + [f"ds_read_b32 v{40 + j % 4}, v7 offset:{16 * j}", "s_waitcnt lgkmcnt(0)"] for j in range(12)], []),
+     note="7 full-rate + ds_read_b32 + s_waitcnt lgkmcnt(0)")
 body("ring_mix_nolds", ring_like("none", False), note="the ring test's instruction mix, operands in registers")
 body("ring_mix_lds_wait0", ring_like("ondemand", True), note="+ ds_read2_b32 per position, s_waitcnt lgkmcnt(0) right behind it (as compiled)")
 body("ring_mix_lds_ahead", ring_like("ahead", True), note="+ ds_read2_b32 per position issued one position ahead, counted wait")
 body("ring_mix_sgprconst", [l.replace("0x7f7f7f7f", "s21") for l in ring_like("none", False)], note="ring mix, the and-mask in an SGPR (4-byte encoding)")
 
-ALLREGS = ", ".join(f'"v{i}"' for i in range(7, 48))
+ALLREGS = ", ".join(f'"v{i}"' for i in range(5, 48))
 
 
 def kernel(name, lines, nvalu):
+    lines = [l[2:].replace("{name}", name) if l.startswith("@@") else l for l in lines]
     asm = "\n".join(f'        "{l}\\n"' for l in lines)
     init = "\n".join(f'        "v_add_u32_e32 v{i}, {hex((i * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF)}, %[tid]\\n"' for i in range(8, 48))
     fold = "\n".join(f'        "v_xor_b32_e32 v8, v{i}, v8\\n"' for i in range(9, 44))
     return f'''
-__global__ __launch_bounds__(256) void k_{name}(unsigned long long *out, int iters)
+__global__ __launch_bounds__(512) void k_{name}(unsigned long long *out, int iters)
 {{
     extern __shared__ unsigned char lds[];
-    for (unsigned i = threadIdx.x; i < 1024; i += 256) ((volatile unsigned *)lds)[i] = i * 2654435761u;
+    for (unsigned i = threadIdx.x; i < 2048; i += blockDim.x) ((volatile unsigned *)lds)[i] = i * 2654435761u;
     __syncthreads();
     unsigned long long t0, t1, r0, r1;
     unsigned accv;
@@ -121,7 +269,11 @@ __global__ __launch_bounds__(256) void k_{name}(unsigned long long *out, int ite
     asm volatile(
 {init}
         "v_mov_b32_e32 v7, %[la]\\n"
+        "v_lshlrev_b32_e32 v6, 1, v7\\n"
+        "v_lshlrev_b32_e32 v5, 2, v7\\n"
         "s_mov_b32 s21, 0x7f7f7f7f\\n"
+        "s_mov_b32 s24, 0x0f0f3355\\n"
+        "s_mov_b32 s25, 0x00ff5533\\n"
         "s_mov_b32 s20, %[iters]\\n"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\\n"
         "s_barrier\\n"
@@ -141,9 +293,9 @@ __global__ __launch_bounds__(256) void k_{name}(unsigned long long *out, int ite
         "v_mov_b32_e32 %[accv], v8\\n"
         : [t0] "=&s"(t0), [r0] "=&s"(r0), [t1] "=&s"(t1), [r1] "=&s"(r1), [accv] "=&v"(accv)
         : [tid] "v"(tid), [la] "v"(la), [iters] "s"(iters)
-        : {ALLREGS}, "s20", "s21", "scc", "vcc", "memory");
-    const unsigned w = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if ((threadIdx.x & 63) == 0) {{ out[2 * w] = t1 - t0; out[2 * w + 1] = r1 - r0; }}
+        : {ALLREGS}, "s20", "s21", "s22", "s23", "s24", "s25", "scc", "vcc", "memory");
+    const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0) {{ out[4 * w] = t1 - t0; out[4 * w + 1] = r1 - r0; out[4 * w + 2] = r0; out[4 * w + 3] = r1; }}
     if (accv == 0x12345u && iters < 0) out[0] = accv;
 }}
 '''
@@ -170,27 +322,46 @@ int main(int argc, char **argv)
     if (hipGetDeviceProperties(&prop, 0) == hipSuccess) cus = prop.multiProcessorCount;
     unsigned long long *d;
     const int maxWaves = cus * 32;
-    if (hipMalloc(&d, (size_t)maxWaves * 16) != hipSuccess) return 1;
-    std::vector<unsigned long long> h((size_t)maxWaves * 2);
-    printf("%-22s %3s %10s %8s %8s %9s  %s\n", "probe", "W", "cyc/instr", "min", "max", "clock GHz", "note  (W = waves per SIMD; cycles = shader cycles per vector instruction per SIMD)");
+    if (hipMalloc(&d, (size_t)maxWaves * 32) != hipSuccess) return 1;
+    std::vector<unsigned long long> h((size_t)maxWaves * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("CUs %d.  W = waves per SIMD, T = threads per workgroup.  in-kernel: s_memtime ticks of one wave / (its instructions x W), median [min max] over the waves;\n"
+           "wall: hipEvent time of the launch x in-kernel clock / (instructions per SIMD); start spread = (latest - earliest wave start) / wave duration.\n", cus);
+    printf("%-22s %2s %4s %9s %7s %7s %9s %7s %7s  %s\n", "probe", "W", "T", "in-kernel", "min", "max", "wall", "clk GHz", "spread", "note");
     for (auto &p : probes) {
         if (only && !strstr(p.name, only)) continue;
-        for (int W : {8, 4, 2, 1}) {
-            if (W != 8 && !(strstr(p.name, "and_e32") || strstr(p.name, "bitop3_distinct") || strstr(p.name, "ring_mix") || strstr(p.name, "dep_chain") || strstr(p.name, "alignbyte_distinct"))) continue;
-            const size_t ldsBytes = W == 8 ? 16 * 1024 : W == 4 ? 36 * 1024 : W == 2 ? 72 * 1024 : 150 * 1024;  // W workgroups fit a CU's 160 KB
+        for (int cfg = 0; cfg < 6; ++cfg) {
+            const int W = cfg == 0 ? 8 : cfg == 1 ? 8 : cfg == 2 ? 4 : cfg == 3 ? 2 : cfg == 4 ? 1 : 16, T = cfg == 1 ? 512 : 256;
+            if (cfg == 5) continue;
+            const bool sweep = strstr(p.name, "and_e32") || strstr(p.name, "bitop3_distinct") || strstr(p.name, "ring_mix") || strstr(p.name, "alignbyte_distinct") || strstr(p.name, "lds_read");
+            const bool mixing = !strncmp(p.name, "pure_", 5) || !strncmp(p.name, "R_", 2) || (p.name[0] == 'N' && p.name[1] >= '0' && p.name[1] <= '9') || (p.name[0] == 'F' && p.name[1] >= '0' && p.name[1] <= '9');
+            if (mixing) { if (cfg != 1 && cfg != 3) continue; }   // the kernel's shape (8 waves per SIMD, 512-thread workgroups) and 2 waves per SIMD
+            else if (cfg >= 1 && !sweep) continue;
+            const int wavesPerBlock = T / 64, blocksPerCu = W * 4 / wavesPerBlock;
+            const size_t ldsBytes = (size_t)(152 * 1024 / blocksPerCu) & ~(size_t)1023;   // exactly blocksPerCu workgroups fit a CU's 160 KB
             hipFuncSetAttribute((const void *)p.k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-            const int blocks = cus * W, iters = 24000 / W;
-            hipLaunchKernelGGL(p.k, dim3(blocks), dim3(256), ldsBytes, 0, d, iters);   // warm-up
-            hipLaunchKernelGGL(p.k, dim3(blocks), dim3(256), ldsBytes, 0, d, iters);
+            const int blocks = cus * blocksPerCu, iters = 24000 / W;
+            hipLaunchKernelGGL(p.k, dim3(blocks), dim3(T), ldsBytes, 0, d, iters);   // warm-up
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(p.k, dim3(blocks), dim3(T), ldsBytes, 0, d, iters);
+            hipEventRecord(e1);
             if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", p.name); return 1; }
-            hipMemcpy(h.data(), d, (size_t)blocks * 4 * 16, hipMemcpyDeviceToHost);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            const int nw = blocks * wavesPerBlock;
+            hipMemcpy(h.data(), d, (size_t)nw * 32, hipMemcpyDeviceToHost);
             std::vector<double> c, clk;
-            for (int w = 0; w < blocks * 4; ++w) {
-                c.push_back((double)h[2 * w] / ((double)iters * p.nvalu * W));
-                if (h[2 * w + 1]) clk.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 0.1);
+            unsigned long long r0min = ~0ull, r0max = 0, durSum = 0;
+            for (int w = 0; w < nw; ++w) {
+                c.push_back((double)h[4 * w] / ((double)iters * p.nvalu * W));
+                if (h[4 * w + 1]) clk.push_back((double)h[4 * w] / (double)h[4 * w + 1] * 0.1);
+                r0min = std::min(r0min, h[4 * w + 2]); r0max = std::max(r0max, h[4 * w + 2]); durSum += h[4 * w + 1];
             }
             std::sort(c.begin(), c.end()); std::sort(clk.begin(), clk.end());
-            printf("%-22s %3d %10.3f %8.3f %8.3f %9.2f  %s\n", p.name, W, c[c.size() / 2], c.front(), c.back(), clk.empty() ? 0.0 : clk[clk.size() / 2], p.note);
+            const double ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+            const double wall = ms * 1e-3 * ghz * 1e9 / ((double)iters * p.nvalu * W);
+            printf("%-22s %2d %4d %9.3f %7.3f %7.3f %9.3f %7.2f %7.2f  %s\n", p.name, W, T, c[c.size() / 2], c.front(), c.back(), wall, ghz,
+                   (double)(r0max - r0min) / ((double)durSum / nw), p.note);
             fflush(stdout);
         }
     }

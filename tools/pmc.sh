@@ -2,7 +2,7 @@
 # PMC counter passes for the bench (own runs, --kernel-trace only, as the pool requires)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() { # name, counters
-  rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc_$1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > gpurun_out/pmc_$1.log 2>&1
+  rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc_$1 -- python3 bench.py --batches-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > gpurun_out/pmc_$1.log 2>&1
   f=$(find gpurun_out/pmc_$1 -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv,sys,collections

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {
-rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc3_$1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > gpurun_out/pmc3_$1.log 2>&1
+rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc3_$1 -- python3 bench.py --batches-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > gpurun_out/pmc3_$1.log 2>&1
 f=$(find gpurun_out/pmc3_$1 -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections

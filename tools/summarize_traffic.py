@@ -1,5 +1,5 @@
 """Summarises the rocprofv3 PMC passes of tools/collect_traffic.sh per kernel and per batch of the bench command
-(bench.py --steps 2 --warmup 1 = 3 batches).  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in units of 1024 B.
+(bench.py --batches-per-step 1 --steps 2 --warmup 1 = 3 batches).  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in units of 1024 B.
 Writes <dir>/summary.json (every kernel) and <dir>/pyr_fast_counters.json (the flat record of the north-star kernel that
 bench.py reads from profiles/pyr_fast_counters_latest.json)."""
 import collections
@@ -60,6 +60,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import bench  # noqa: E402  (no torch import at module level)
 pf["kernel_source_sha256"] = bench.kernel_source_sha256()
 pf["commit"] = os.environ.get("ORBX_COMMIT", "")  # .git does not travel to the GPU box: tools/profile_round.sh is given the commit
-pf["bench"] = "bench.py --config c2 --steps 2 --warmup 1 (3 batches of 1024 frames)"
+pf["bench"] = "bench.py --config c2 --batches-per-step 1 --steps 2 --warmup 1 (3 batches of 1024 frames)"
 json.dump(pf, open(os.path.join(root, "pyr_fast_counters.json"), "w"), indent=1)
 print(json.dumps(pf, indent=1))
