@@ -379,6 +379,63 @@ int orbx_search_by_projection_points_fisheye_frames(orbx_matcher *m, orbx_extrac
                                                     const int32_t *d_left_to_right, const int32_t *d_right_to_left, float th, float nnratio,
                                                     void *d_assign, void *d_nmatches);
 
+/* ---- The projection head of the two tracking searches (round 4): "project-then-match" with the PROJECT half on the device ----------
+ * The record-taking entry points above stay; these compute the orbx_projection records from world points and a pose, in the reference's
+ * own float arithmetic - every +, -, *, / in float and un-fused, in the order Eigen / Sophus evaluate it (3-term sums as x0 + (x1 + x2):
+ * Eigen's unrolled redux of a 3-vector; the reference builds with -O3 and no -march, so nothing is contracted), sqrt correctly rounded,
+ * 1.0 / z in double narrowed once.  PARITY: bit-equal to the CPU oracle (oracle_project_*); the Eigen evaluation order itself is
+ * restated from Eigen's sources, not checked against a build of the reference (Eigen / Sophus are not in this image): "unpinned". */
+
+/* GeometricCamera::project(const Eigen::Vector3f &): type 0 = Pinhole (src/CameraModels/Pinhole.cpp:43-49: fx * x / z + cx),
+ * type 1 = KannalaBrandt8 (src/CameraModels/KannalaBrandt8.cpp:67-84); p = mvParameters: fx fy cx cy [k0 k1 k2 k3]. */
+typedef struct {
+    int32_t type;
+    float p[8];
+} orbx_camera;
+
+/* What the two loops read of one MapPoint (and, for the motion-model search, of the last frame's keypoint that observes it). */
+typedef struct {
+    float pos[3];      /* pMP->GetWorldPos() */
+    float normal[3];   /* pMP->GetNormal()                                                   (in-frustum mode only) */
+    float min_distance, max_distance; /* mfMinDistance, mfMaxDistance: GetMinDistanceInvariance() = 0.8f * min, GetMax.. = 1.2f * max
+                                         (src/MapPoint.cc; in-frustum mode only) */
+    float angle;       /* LastFrame.mvKeysUn[i].angle                                        (motion-model mode only) */
+    int32_t octave;    /* LastFrame.mvKeys[i].octave                                         (motion-model mode only) */
+    int32_t flags;     /* orbx_projection.flags before the geometric tests: bit 0 the point takes part (exists, !isBad(), not an outlier /
+                          not already matched in this frame), bit 1 Observations() > 0 */
+} orbx_world_point;
+
+/* Mode 0, the head of ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, ..) - reference
+ * src/ORBmatcher3.cc:281-296: x3Dc = Tcw * x3Dw with Tcw a Sophus::SE3f (unit quaternion q = x, y, z, w and translation t;
+ * Thirdparty/Sophus/sophus/so3.hpp:358-367: uv = q.vec x p, uv += uv, p + w * uv + q.vec x uv; se3.hpp: + t), invzc = 1.0 / x3Dc(2),
+ * uv = mpCamera->project(x3Dc).  proj_out[i] = {uv(0), uv(1), invzc, angle, octave, flags} - the tests on invzc and the image bounds
+ * stay in the search (orbx_search_by_projection), as in the reference's loop. */
+int orbx_project_last_frame_points(orbx_matcher *m, const float q_xyzw[4], const float t[3], const orbx_camera *cam,
+                                   const orbx_world_point *points, int np, orbx_projection *proj_out);
+
+/* Mode 1, Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit) - reference src/Frame.cc:542-600 (Nleft == -1), as
+ * Tracking::SearchLocalPoints runs it over the local map (src/Tracking4.cc:700-737) - plus the far-point test at the head of
+ * ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &, ..) (src/ORBmatcher1.cc:57-58).  Rcw (row-major 3 x 3), tcw, Ow =
+ * Frame::mRcw, mtcw, mOw; bounds = mnMinX, mnMaxX, mnMinY, mnMaxY; log_scale_factor / nlevels = mfLogScaleFactor / mnScaleLevels
+ * (MapPoint::PredictScale, src/MapPoint.cc:531-546: ceil(log(mfMaxDistance / dist) / mfLogScaleFactor) in double, clamped).
+ * proj_out[i] = {mTrackProjX, mTrackProjY, mTrackProjXR = uv(0) - mbf * invz, mTrackViewCos, mnTrackScaleLevel, flags} with flags bit 0 =
+ * the input bit && mbTrackInView && !(far_points && mTrackDepth > th_far_points) - exactly the record orbx_search_by_projection_points
+ * takes.  (log() is the device's double-precision log: it can differ from the host libm's in the last bit, which changes the level only
+ * when the quotient lies within 1e-16 of an integer.) */
+int orbx_project_in_frustum(orbx_matcher *m, const float Rcw[9], const float tcw[3], const float Ow[3], const orbx_camera *cam,
+                            const float bounds[4], float mbf, float viewing_cos_limit, float log_scale_factor, int nlevels,
+                            int far_points, float th_far_points, const orbx_world_point *points, int np, orbx_projection *proj_out);
+
+/* Both modes for a BATCH of frames, device-resident: d_pose [nframes][16] floats per frame - mode 0: q x y z w, t x y z; mode 1: Rcw[9],
+ * tcw[3], Ow[3] -, d_points [nframes][max_np], d_np [nframes]; d_proj_out [nframes][max_np] is what
+ * orbx_search_by_projection_frames / orbx_search_by_projection_points_frames take as d_proj / d_map_points (same stream: no
+ * synchronisation in between).  The scalar parameters after `cam` are read in mode 1 only.  One launch, asynchronous on the matcher's
+ * stream. */
+int orbx_project_points_frames(orbx_matcher *m, int mode, int nframes, const float *d_pose, const orbx_camera *cam, const float bounds[4],
+                               float mbf, float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points,
+                               float th_far_points, const orbx_world_point *d_points, const int32_t *d_np, int max_np,
+                               orbx_projection *d_proj_out);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference
  * src/ORBmatcher1.cc:225-427 (decl include/ORBmatcher.h:62), F.Nleft == -1 / pKF->mpCamera2 == NULL; Tracking::TrackReferenceKeyFrame
  * and Relocalization.  Both FeatureVectors (pKF->mFeatVec, F.mFeatVec) as orbx_vocabulary_transform returns them: ascending node

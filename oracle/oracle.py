@@ -67,6 +67,11 @@ def lib() -> ctypes.CDLL:
                                               c_void_p, c_int]
         L.oracle_search_for_initialization.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
                                                        c_float, c_void_p, c_void_p, c_int, c_float, c_int]
+        L.oracle_project_last_frame_points.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]
+        L.oracle_project_last_frame_points.restype = None
+        L.oracle_project_in_frustum.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int,
+                                                c_float, c_void_p, c_int, c_void_p]
+        L.oracle_project_in_frustum.restype = None
         L.oracle_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p,
                                                   c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
         L.oracle_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
@@ -298,6 +303,34 @@ def search_for_initialization(k1, d1, k2, d2, prev_matched, bounds, window_size=
 
 
 PROJECTION_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("invz", "<f4"), ("angle", "<f4"), ("octave", "<i4"), ("flags", "<i4")])
+
+
+WORLD_POINT_DTYPE = np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("angle", "<f4"),
+                              ("octave", "<i4"), ("flags", "<i4")])  # oracle_world_point == orbx_world_point (44 bytes)
+
+
+def project_last_frame_points(q_xyzw, t, cam_type, cam, points):
+    """x3Dc = Tcw * x3Dw; invzc; uv = mpCamera->project(x3Dc) (reference src/ORBmatcher3.cc:283-293) -> PROJECTION_DTYPE records."""
+    q = np.ascontiguousarray(q_xyzw, np.float32); tt = np.ascontiguousarray(t, np.float32)
+    c = np.zeros(8, np.float32); c[:len(cam)] = cam
+    pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+    out = np.zeros(len(pts), PROJECTION_DTYPE)
+    lib().oracle_project_last_frame_points(q.ctypes.data, tt.ctypes.data, int(cam_type), c.ctypes.data, pts.ctypes.data, len(pts), out.ctypes.data)
+    return out
+
+
+def project_in_frustum(Rcw, tcw, Ow, cam_type, cam, bounds, mbf, viewing_cos_limit, log_scale_factor, nlevels, points, far_points=False,
+                       th_far_points=0.0):
+    """Frame::isInFrustum over `points` (reference src/Frame.cc:542-600) -> PROJECTION_DTYPE records as SearchByProjection(F, vpMapPoints) reads them."""
+    R = np.ascontiguousarray(Rcw, np.float32).reshape(9); tt = np.ascontiguousarray(tcw, np.float32); ow = np.ascontiguousarray(Ow, np.float32)
+    c = np.zeros(8, np.float32); c[:len(cam)] = cam
+    b = np.ascontiguousarray(bounds, np.float32)
+    pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+    out = np.zeros(len(pts), PROJECTION_DTYPE)
+    lib().oracle_project_in_frustum(R.ctypes.data, tt.ctypes.data, ow.ctypes.data, int(cam_type), c.ctypes.data, b.ctypes.data, float(mbf),
+                                    float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)), float(th_far_points),
+                                    pts.ctypes.data, len(pts), out.ctypes.data)
+    return out
 
 
 def search_by_projection(kc, dc, cur_state, bounds, scale_factors, proj, proj_desc, th, u_right=None, mbf=0.0, forward=False,

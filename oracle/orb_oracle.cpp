@@ -1756,6 +1756,93 @@ static void kb8Project(const float *P, const float v[3], float uv[2])
 
 static inline float dot3f(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
+// =====================================================================================================================================
+// Projection head of the two tracking searches: reference src/ORBmatcher3.cc:281-296 (motion model: Sophus::SE3f * point, invzc, project)
+// and src/Frame.cc:542-600 (Frame::isInFrustum, Nleft == -1) with MapPoint::PredictScale (src/MapPoint.cc:531-546).
+// PARITY UNPINNED for the evaluation order: Eigen / Sophus are not in this image.  Restated from their sources:
+//   * Eigen evaluates a fixed-size 3 x 3 times 3 x 1 product coefficient by coefficient (product_type_selector<Small, 1, Small> =
+//     CoeffBasedProductMode), each coefficient as (row.transpose().cwiseProduct(col)).sum(), and sum() / dot() / squaredNorm() of three
+//     terms through the unrolled redux redux_novec_unroller<Func, Eval, 0, 3> = func(x0, func(x1, x2)): x0 + (x1 + x2);
+//   * cross() of two 3-vectors: (a1 b2 - a2 b1, a2 b0 - a0 b2, a0 b1 - a1 b0);
+//   * Sophus SO3 * p: uv = q.vec().cross(p); uv += uv; return p + q.w() * uv + q.vec().cross(uv); SE3 * p adds the translation;
+//   * all of it in float, un-fused (the reference is built with -O3 and no -march: no FMA contraction); `1.0 / x3Dc(2)` in double,
+//     narrowed by the assignment to `const float invzc`; norm() = std::sqrt(float) correctly rounded.
+// (KannalaBrandt8::TriangulateMatches above sums its 3-term products left to right - written in round 2 before this derivation; both are
+// "unpinned" until the reference can be built.)
+// =====================================================================================================================================
+static inline float sum3e(float x0, float x1, float x2) { return x0 + (x1 + x2); }
+static inline void cross3e(const float *a, const float *b, float *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void cameraProject(int type, const float *P, const float v[3], float uv[2])
+{
+    if (type == 0) {  // Pinhole::project(const Eigen::Vector3f &), src/CameraModels/Pinhole.cpp:43-49
+        uv[0] = P[0] * v[0] / v[2] + P[2];
+        uv[1] = P[1] * v[1] / v[2] + P[3];
+    } else kb8Project(P, v, uv);
+}
+
+extern "C" void oracle_project_last_frame_points(const float *q, const float *t, int cam_type, const float *cam, const oracle_world_point *pts, int np,
+                                                 oracle_projection *out)
+{
+    for (int i = 0; i < np; ++i) {
+        const float *p = pts[i].pos;
+        float uv[3], c2[3], x[3];
+        cross3e(q, p, uv);                                  // so3.hpp:364
+        for (int k = 0; k < 3; ++k) uv[k] = uv[k] + uv[k];  // :365
+        cross3e(q, uv, c2);
+        for (int k = 0; k < 3; ++k) x[k] = ((p[k] + q[3] * uv[k]) + c2[k]) + t[k];  // :366, se3.hpp (so3() * p + translation())
+        oracle_projection o;
+        o.invz = (float)(1.0 / (double)x[2]);               // src/ORBmatcher3.cc:288
+        float w[2];
+        cameraProject(cam_type, cam, x, w);                 // :293
+        o.u = w[0]; o.v = w[1];
+        o.angle = pts[i].angle; o.octave = pts[i].octave; o.flags = pts[i].flags;
+        out[i] = o;
+    }
+}
+
+extern "C" void oracle_project_in_frustum(const float *R, const float *t, const float *Ow, int cam_type, const float *cam, const float *bounds,
+                                          float mbf, float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points,
+                                          float th_far_points, const oracle_world_point *pts, int np, oracle_projection *out)
+{
+    for (int i = 0; i < np; ++i) {
+        const float *P = pts[i].pos;
+        float Pc[3];
+        for (int k = 0; k < 3; ++k) Pc[k] = sum3e(R[3 * k] * P[0], R[3 * k + 1] * P[1], R[3 * k + 2] * P[2]) + t[k];  // src/Frame.cc:553
+        const float Pc_dist = sqrtf(sum3e(Pc[0] * Pc[0], Pc[1] * Pc[1], Pc[2] * Pc[2]));                              // :554
+        const float PcZ = Pc[2];
+        const float invz = 1.0f / PcZ;                                                                                // :558
+        bool in = !(PcZ < 0.0f);                                                                                      // :559-560
+        float uv[2];
+        cameraProject(cam_type, cam, Pc, uv);                                                                         // :562
+        if (uv[0] < bounds[0] || uv[0] > bounds[1]) in = false;                                                       // :564-567
+        if (uv[1] < bounds[2] || uv[1] > bounds[3]) in = false;
+        const float maxDistance = 1.2f * pts[i].max_distance, minDistance = 0.8f * pts[i].min_distance;              // src/MapPoint.cc
+        const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};                                                // :575
+        const float dist = sqrtf(sum3e(PO[0] * PO[0], PO[1] * PO[1], PO[2] * PO[2]));                                 // :576
+        if (dist < minDistance || dist > maxDistance) in = false;                                                     // :578-579
+        const float *Pn = pts[i].normal;
+        const float viewCos = sum3e(PO[0] * Pn[0], PO[1] * Pn[1], PO[2] * Pn[2]) / dist;                               // :584
+        if (viewCos < viewing_cos_limit) in = false;                                                                  // :586-587
+        // MapPoint::PredictScale(dist, this): ratio = mfMaxDistance / currentDist; ceil(log(ratio) / mfLogScaleFactor), clamped
+        const float ratio = pts[i].max_distance / dist;
+        const double lv = ceil(log((double)ratio) / (double)log_scale_factor);
+        int nScale = lv >= (double)nlevels ? nlevels - 1 : lv < 0.0 ? 0 : (int)lv;
+        if (!(lv == lv)) nScale = 0;
+        if (far_points && Pc_dist > th_far_points) in = false;                                                        // src/ORBmatcher1.cc:57-58
+        oracle_projection o;
+        o.u = uv[0]; o.v = uv[1];
+        o.invz = uv[0] - mbf * invz;                                                                                  // mTrackProjXR, :594
+        o.angle = viewCos; o.octave = nScale;
+        o.flags = (pts[i].flags & ~1) | (((pts[i].flags & 1) && in) ? 1 : 0);
+        out[i] = o;
+    }
+}
+
 // right singular vector of the smallest singular value of the 4 x 4 matrix A (row-major), see the header comment
 static void smallestRightSingularVector4(const float A[16], float v[4])
 {

@@ -124,6 +124,23 @@ int oracle_search_by_projection(const oracle_keypoint *kc, const uint8_t *dc, co
                                 const oracle_projection *proj, const uint8_t *dproj, int np, float th, int forward, int backward,
                                 int check_orientation, int32_t *assign);
 
+/* ---- projection head of the two tracking searches (the PROJECT half of "project-then-match") ---------------------------------------
+ * What the loops read of one MapPoint: same layout as orbx_world_point. */
+typedef struct {
+    float pos[3], normal[3], min_distance, max_distance, angle;
+    int32_t octave, flags;
+} oracle_world_point;
+/* x3Dc = Tcw * x3Dw; invzc = 1.0 / x3Dc(2); uv = mpCamera->project(x3Dc) - reference src/ORBmatcher3.cc:283-293 with Tcw a Sophus::SE3f
+ * (Thirdparty/Sophus/sophus/so3.hpp:358-367, se3.hpp) and the camera of src/CameraModels/{Pinhole.cpp:43-49, KannalaBrandt8.cpp:67-84}
+ * (cam_type 0 / 1, cam = mvParameters).  out[i] = {uv(0), uv(1), invzc, angle, octave, flags}. */
+void oracle_project_last_frame_points(const float *q_xyzw, const float *t, int cam_type, const float *cam, const oracle_world_point *pts, int np,
+                                      oracle_projection *out);
+/* Frame::isInFrustum (src/Frame.cc:542-600, Nleft == -1) + MapPoint::PredictScale (src/MapPoint.cc:531-546) + the far-point test of
+ * src/ORBmatcher1.cc:57-58; out[i] = {mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos, mnTrackScaleLevel, flags}. */
+void oracle_project_in_frustum(const float *Rcw, const float *tcw, const float *Ow, int cam_type, const float *cam, const float *bounds, float mbf,
+                               float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points, float th_far_points,
+                               const oracle_world_point *pts, int np, oracle_projection *out);
+
 /* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th, ..) (src/ORBmatcher1.cc:45-215), F.Nleft == -1, points
  * with mbTrackInView: a record holds u = mTrackProjX, v = mTrackProjY, invz = mTrackProjXR, angle = mTrackViewCos,
  * octave = mnTrackScaleLevel, flags as above.  Returns nmatches. */

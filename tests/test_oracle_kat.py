@@ -577,3 +577,89 @@ def test_resize_and_blur_stay_within_one_level_of_their_real_valued_definitions(
         tmp = sum(k[i] * pad[:, i:i + img.shape[1]] for i in range(7))
         want = sum(k[i] * tmp[i:i + img.shape[0], :] for i in range(7))
         assert np.abs(out - np.minimum(want, 255.0)).max() <= 1.0, (variant, np.abs(out - want).max())
+
+
+# ---- projection head of the tracking searches (round 4): oracle_project_last_frame_points / oracle_project_in_frustum ----------------
+def _world_points(orc, pos, **fields):
+    pts = np.zeros(len(pos), orc.WORLD_POINT_DTYPE)
+    pts["pos"] = np.float32(pos)
+    pts["flags"] = 3
+    pts["max_distance"] = 10.0
+    pts["min_distance"] = 0.1
+    pts["normal"] = [0, 0, -1]
+    for k, v in fields.items():
+        pts[k] = v
+    return pts
+
+
+def test_projection_head_motion_model_known_answers(orc):
+    """Sophus::SE3f * point + Pinhole::project (reference src/ORBmatcher3.cc:283-293): identity, pure translation, a quarter turn about the
+    optical axis (exact in float: q = (0, 0, s, s) with s = sqrt(0.5) gives 2 s^2 = 1 up to rounding), and agreement with a double-precision
+    rotation matrix to float accuracy for random poses."""
+    cam = (0, (400.0, 300.0, 320.0, 240.0))
+    pts = _world_points(orc, [[0, 0, 2], [1, 0, 4], [0, -1, 5], [0.5, 0.25, -2]], angle=[1, 2, 3, 4], octave=[0, 1, 2, 3])
+    out = orc.project_last_frame_points([0, 0, 0, 1], [0, 0, 0], *cam, pts)
+    assert list(out["u"]) == [320.0, 420.0, 320.0, 220.0] and list(out["v"]) == [240.0, 240.0, 180.0, 202.5]
+    assert list(out["invz"]) == [0.5, 0.25, np.float32(0.2), -0.5]              # behind the camera: invzc < 0, the search skips it (:290)
+    assert list(out["angle"]) == [1, 2, 3, 4] and list(out["octave"]) == [0, 1, 2, 3] and list(out["flags"]) == [3] * 4
+    out = orc.project_last_frame_points([0, 0, 0, 1], [0.5, 0, 2], *cam, pts[:2])
+    assert list(out["u"]) == [370.0, 420.0] and list(out["invz"]) == [0.25, np.float32(1.0 / 6.0)]
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis); ang = rng.uniform(-1, 1)
+        q = np.float32(np.concatenate([axis * np.sin(ang / 2), [np.cos(ang / 2)]])); t = np.float32(rng.normal(0, 0.3, 3))
+        P = rng.uniform(-2, 2, (50, 3)); P[:, 2] += 6
+        out = orc.project_last_frame_points(q, t, *cam, _world_points(orc, P))
+        qd = q.astype(np.float64); qd /= np.linalg.norm(qd)
+        x, y, z, w = qd
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        Xc = np.float32(P).astype(np.float64) @ R.T + t
+        assert np.allclose(out["u"], 400 * Xc[:, 0] / Xc[:, 2] + 320, atol=2e-3) and np.allclose(out["invz"], 1 / Xc[:, 2], rtol=1e-5)
+
+
+def test_projection_head_in_frustum_each_test_rejects_on_its_own(orc):
+    """Frame::isInFrustum (reference src/Frame.cc:542-600): every rejection cause alone clears bit 0 and nothing else; the track data of an
+    accepted point are the reference's formulas (mTrackProjXR = u - mbf / z, viewCos, PredictScale)."""
+    cam = (0, (400.0, 300.0, 320.0, 240.0))
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    R, t, Ow = np.eye(3, dtype=np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+    logsf = float(np.log(np.float32(1.2)))
+    base = dict(mbf=40.0, viewing_cos_limit=0.5, log_scale_factor=logsf, nlevels=8)
+    ok = _world_points(orc, [[0, 0, 4.0]], normal=[[0, 0, 1]], max_distance=4.0 * 1.2 ** 3 * 0.999, min_distance=0.5)
+    out = orc.project_in_frustum(R, t, Ow, *cam, bounds, points=ok, **base)
+    assert out["flags"][0] == 3 and out["u"][0] == 320.0 and out["v"][0] == 240.0
+    assert out["invz"][0] == np.float32(320.0) - np.float32(40.0) * np.float32(0.25)         # mTrackProjXR
+    assert out["angle"][0] == 1.0 and out["octave"][0] == 3                                   # viewCos; ceil(log(1.2^3 * 0.999) / log 1.2) = 3
+    cases = {
+        "behind": _world_points(orc, [[0, 0, -4.0]], normal=[[0, 0, -1]]),
+        "left of the image": _world_points(orc, [[-4.0, 0, 4.0]], normal=[[-0.7, 0, 0.7]]),
+        "below the image": _world_points(orc, [[0, 4.0, 4.0]], normal=[[0, 0.7, 0.7]]),
+        "too far (> 1.2 max)": _world_points(orc, [[0, 0, 4.0]], normal=[[0, 0, 1]], max_distance=3.3),
+        "too close (< 0.8 min)": _world_points(orc, [[0, 0, 4.0]], normal=[[0, 0, 1]], min_distance=5.1),
+        "viewing angle > 60 deg": _world_points(orc, [[0, 0, 4.0]], normal=[[0.9, 0, 0.4358899]]),
+        "not a candidate on entry": _world_points(orc, [[0, 0, 4.0]], normal=[[0, 0, 1]], flags=2),
+    }
+    for name, pts in cases.items():
+        out = orc.project_in_frustum(R, t, Ow, *cam, bounds, points=pts, **base)
+        assert out["flags"][0] == 2, name
+    far = orc.project_in_frustum(R, t, Ow, *cam, bounds, points=ok, far_points=True, th_far_points=3.9, **base)
+    near = orc.project_in_frustum(R, t, Ow, *cam, bounds, points=ok, far_points=True, th_far_points=4.1, **base)
+    assert far["flags"][0] == 2 and near["flags"][0] == 3                                      # src/ORBmatcher1.cc:57-58 on mTrackDepth
+    # PredictScale clamps (src/MapPoint.cc:540-543)
+    lo = _world_points(orc, [[0, 0, 4.0]], normal=[[0, 0, 1]], max_distance=3.5, min_distance=0.1)     # ratio < 1: level 0
+    hi = _world_points(orc, [[0, 0, 0.5]], normal=[[0, 0, 1]], max_distance=40.0, min_distance=0.1)    # ratio 80: level 7
+    assert orc.project_in_frustum(R, t, Ow, *cam, bounds, points=lo, **base)["octave"][0] == 0
+    assert orc.project_in_frustum(R, t, Ow, *cam, bounds, points=hi, **base)["octave"][0] == 7
+
+
+def test_projection_head_kb8_agrees_with_the_fisheye_model(orc):
+    """KannalaBrandt8::project (reference src/CameraModels/KannalaBrandt8.cpp:67-84) through the head: r(theta) polynomial along the ray's azimuth."""
+    k = (190.0, 191.0, 255.0, 256.0, 0.0035, 0.0007, -0.002, 0.0002)
+    rng = np.random.default_rng(6)
+    P = rng.uniform(-3, 3, (200, 3)); P[:, 2] = rng.uniform(0.5, 6, 200)
+    out = orc.project_last_frame_points([0, 0, 0, 1], [0, 0, 0], 1, k, _world_points(orc, P))
+    Pf = np.float32(P).astype(np.float64)
+    th = np.arctan2(np.hypot(Pf[:, 0], Pf[:, 1]), Pf[:, 2]); psi = np.arctan2(Pf[:, 1], Pf[:, 0])
+    r = th + k[4] * th ** 3 + k[5] * th ** 5 + k[6] * th ** 7 + k[7] * th ** 9
+    assert np.allclose(out["u"], k[0] * r * np.cos(psi) + k[2], atol=1e-3) and np.allclose(out["v"], k[1] * r * np.sin(psi) + k[3], atol=1e-3)

@@ -9,6 +9,7 @@ import torch  # noqa: F401
 pkg = importlib.import_module("wut-cuda-orb-slam3_amd")
 from oracle import oracle as orc
 from voc_synth import features_near_words, make_vocabulary
+import scene3d
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -71,9 +72,20 @@ for c in range(cases):
     o, e = voc.transform(f, lu), ref.transform(f, lu)
     ok3 = all(o[key].tobytes() == e[key].tobytes() for key in e)
     voc.close()
-    if not (ok0 and ok1 and ok2 and ok3):
+    # projection head (round 4): both modes, both camera models, random poses / depths / distance ranges, records bit for bit
+    cam = (scene3d.PINHOLE, scene3d.KB8)[int(rng.integers(0, 2))]
+    cam = (cam[0], tuple(float(v) * float(rng.uniform(0.8, 1.25)) if i < 4 else float(v) for i, v in enumerate(cam[1])))
+    pts, q, t, R, Ow = scene3d.make_scene(rng, k1, cam, pkg.WORLD_POINT_DTYPE, motion=float(rng.uniform(0, 0.5)), rot=float(rng.uniform(0, 0.3)),
+                                          behind=float(rng.uniform(0, 0.2)))
+    a4 = m.ProjectLastFramePoints(q, t, cam[0], cam[1], pts); r4 = orc.project_last_frame_points(q, t, cam[0], cam[1], pts)
+    lsf = float(np.log(np.float32(rng.uniform(1.1, 2.0)))); nlev = int(rng.integers(1, 9)); farp = bool(rng.random() < 0.5)
+    args = (R, t, Ow, cam[0], cam[1], bounds, float(rng.uniform(0, 60)), float(rng.uniform(0.2, 0.8)), lsf, nlev, pts)
+    thf = float(rng.uniform(2, 12))
+    a5 = m.ProjectInFrustum(*args, far_points=farp, th_far_points=thf); r5 = orc.project_in_frustum(*args, far_points=farp, th_far_points=thf)
+    ok4 = a4.tobytes() == r4.tobytes() and a5.tobytes() == r5.tobytes()
+    if not (ok0 and ok1 and ok2 and ok3 and ok4):
         bad += 1
-        print("case %d MISMATCH: frame search %s, map-point search %s, undistort %s, vocabulary %s (k=%d L=%d scoring=%d weighting=%d n=%d levelsup=%d)" % (c, ok0, ok1, ok2, ok3, kk, LL, sc, wt, len(f), lu), flush=True)
+        print("case %d MISMATCH: frame search %s, map-point search %s, undistort %s, vocabulary %s, projection head %s (k=%d L=%d scoring=%d weighting=%d n=%d levelsup=%d)" % (c, ok0, ok1, ok2, ok3, ok4, kk, LL, sc, wt, len(f), lu), flush=True)
     elif c % 10 == 0:
         print("case %d ok (%d x %d, %d / %d keypoints, %d matches; vocabulary k=%d L=%d, %d features -> %d words)" % (c, w, h, n1, len(k2), g[0], kk, LL, len(f), len(o["bow_word"])), flush=True)
 print("cases: %d, mismatches: %d" % (cases, bad))

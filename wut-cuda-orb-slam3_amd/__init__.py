@@ -54,6 +54,22 @@ class _Params(ctypes.Structure):
 
 
 # every symbol include/orbx.h declares (checked by tests/test_abi.py)
+WORLD_POINT_DTYPE = np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("angle", "<f4"),
+                              ("octave", "<i4"), ("flags", "<i4")])  # orbx_world_point (44 bytes)
+
+
+class _Camera(ctypes.Structure):  # orbx_camera
+    _fields_ = [("type", c_int), ("p", c_float * 8)]
+
+
+def _camera(cam_type: int, params) -> "_Camera":
+    c = _Camera()
+    c.type = int(cam_type)
+    for i, v in enumerate(list(params)[:8]):
+        c.p[i] = float(v)
+    return c
+
+
 ABI_SYMBOLS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_get_scale_factors", "orbx_get_inverse_scale_factors", "orbx_get_scale_sigma_squares",
@@ -79,6 +95,9 @@ ABI_SYMBOLS = [
     "orbx_search_by_projection_points_fisheye_frames",
     "orbx_undistort_keypoints",
     "orbx_compute_image_bounds",
+    "orbx_project_last_frame_points",
+    "orbx_project_in_frustum",
+    "orbx_project_points_frames",
     "orbx_vocabulary_create",
     "orbx_vocabulary_load_text",
     "orbx_vocabulary_destroy",
@@ -208,6 +227,11 @@ def load_library() -> ctypes.CDLL:
                                                                     c_void_p, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_project_last_frame_points.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_int, c_void_p]
+    lib.orbx_project_in_frustum.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_float, c_float, c_float, c_int,
+                                            c_int, c_float, c_void_p, c_int, c_void_p]
+    lib.orbx_project_points_frames.argtypes = [c_void_p, c_int, c_int, c_void_p, POINTER(_Camera), c_void_p, c_float, c_float, c_float, c_int, c_int,
+                                               c_float, c_void_p, c_void_p, c_int, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
     lib.orbx_vocabulary_load_text.argtypes = [c_int, ctypes.c_char_p, ctypes.POINTER(c_void_p)]
     lib.orbx_vocabulary_destroy.argtypes = [c_void_p]
@@ -649,20 +673,79 @@ class ORBmatcher:
                "orbx_compute_stereo_fisheye_matches_frames")
         return self._download(nm), self._download(l2r), self._download(r2l), self._download(depth), self._download(p3d)
 
+    # ---- projection head of the tracking searches (include/orbx.h "The projection head") ------------------------------------------
+    def ProjectLastFramePoints(self, q_xyzw, t, cam_type: int, cam, points) -> np.ndarray:
+        """x3Dc = Tcw * x3Dw, invzc, mpCamera->project(x3Dc) for the last frame's map points (reference src/ORBmatcher3.cc:283-293):
+        Tcw as the Sophus::SE3f's unit quaternion (x, y, z, w) and translation; points: WORLD_POINT_DTYPE.  Returns PROJECTION_DTYPE records."""
+        q = np.ascontiguousarray(q_xyzw, np.float32); tt = np.ascontiguousarray(t, np.float32)
+        pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+        out = np.zeros(len(pts), PROJECTION_DTYPE)
+        c = _camera(cam_type, cam)
+        _check(self._lib.orbx_project_last_frame_points(self._h, q.ctypes.data, tt.ctypes.data, ctypes.byref(c), pts.ctypes.data, len(pts),
+                                                        out.ctypes.data), "orbx_project_last_frame_points")
+        return out
+
+    def ProjectInFrustum(self, Rcw, tcw, Ow, cam_type: int, cam, bounds, mbf: float, viewing_cos_limit: float, log_scale_factor: float, nlevels: int,
+                         points, far_points: bool = False, th_far_points: float = 0.0) -> np.ndarray:
+        """Frame::isInFrustum over the local map points (reference src/Frame.cc:542-600) -> the records SearchByProjectionPoints takes."""
+        R = np.ascontiguousarray(Rcw, np.float32).reshape(9); tt = np.ascontiguousarray(tcw, np.float32); ow = np.ascontiguousarray(Ow, np.float32)
+        b = np.ascontiguousarray(bounds, np.float32)
+        pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+        out = np.zeros(len(pts), PROJECTION_DTYPE)
+        c = _camera(cam_type, cam)
+        _check(self._lib.orbx_project_in_frustum(self._h, R.ctypes.data, tt.ctypes.data, ow.ctypes.data, ctypes.byref(c), b.ctypes.data, float(mbf),
+                                                 float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)),
+                                                 float(th_far_points), pts.ctypes.data, len(pts), out.ctypes.data), "orbx_project_in_frustum")
+        return out
+
+    def ProjectPointsFrames(self, mode: int, poses, cam_type: int, cam, points, device: int, bounds=None, mbf: float = 0.0,
+                            viewing_cos_limit: float = 0.5, log_scale_factor: float = 0.0, nlevels: int = 0, far_points: bool = False,
+                            th_far_points: float = 0.0):
+        """The projection head for a batch of frames, device-resident: poses [P, 16] (mode 0: q xyzw, t; mode 1: Rcw[9], tcw, Ow), points = list
+        of P arrays of WORLD_POINT_DTYPE.  Returns (d_proj [P, max_np, 24] uint8 torch tensor on the device, d_np [P] int32 tensor, max_np):
+        pass d_proj / d_np as `proj=` / `proj_counts=` of SearchByProjectionFrames - nothing of the projections crosses the link."""
+        import torch
+        P = len(points)
+        max_np = max(1, max(len(p) for p in points))
+        hw = np.zeros((P, max_np), WORLD_POINT_DTYPE); hn = np.zeros(P, np.int32)
+        for f in range(P):
+            hn[f] = len(points[f]); hw[f, : hn[f]] = points[f]
+        hpose = np.zeros((P, 16), np.float32); hpose[:, : np.asarray(poses).shape[1]] = np.asarray(poses, np.float32)
+        dv = f"cuda:{device}"
+        d_w = torch.from_numpy(hw.view(np.uint8).reshape(P, -1)).to(dv); d_n = torch.from_numpy(hn).to(dv); d_pose = torch.from_numpy(hpose).to(dv)
+        d_out = self._dev_out((P, max_np, PROJECTION_DTYPE.itemsize), torch.uint8, device, 0)
+        b = np.ascontiguousarray(bounds if bounds is not None else (0, 0, 0, 0), np.float32)
+        c = _camera(cam_type, cam)
+        self._launch_fence(d_w, d_n, d_pose, d_out)
+        _check(self._lib.orbx_project_points_frames(self._h, int(mode), P, c_void_p(d_pose.data_ptr()), ctypes.byref(c), b.ctypes.data, float(mbf),
+                                                    float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)),
+                                                    float(th_far_points), c_void_p(d_w.data_ptr()), c_void_p(d_n.data_ptr()), max_np,
+                                                    c_void_p(d_out.data_ptr())), "orbx_project_points_frames")
+        return d_out, d_n, max_np
+
     def SearchByProjectionFrames(self, ex: "ORBextractor", nframes: int, k4, dist, bounds, mbf: float, proj, proj_desc, th: float,
                                  forward: bool = False, backward: bool = False, checkOrientation: bool = True, u_right=None, cur_state=None,
-                                 download: bool = True, map_points_nnratio=None):
+                                 download: bool = True, map_points_nnratio=None, proj_counts=None):
         """Batched, device-resident tracking matcher: UndistortKeyPoints -> AssignFeaturesToGrid -> SearchByProjection(Frame, Frame) for the
         first `nframes` frames of the extractor's last batch.  proj[p] / proj_desc[p]: the projections of frame p (lists of arrays of
-        PROJECTION_DTYPE / [n, 32] uint8).  Returns (nmatches[P], assign[P, cap], kps_un[P, cap])."""
+        PROJECTION_DTYPE / [n, 32] uint8) - or, with proj_counts, the device tensors ProjectPointsFrames returned (d_proj, d_np): the
+        projection head's records are consumed where they are.  Returns (nmatches[P], assign[P, cap], kps_un[P, cap])."""
         import torch
         dev = ex.device
         cap = ex.capacity
-        max_np = max(1, max(len(p) for p in proj))
-        hp = np.zeros((nframes, max_np), PROJECTION_DTYPE); hd = np.zeros((nframes, max_np, 32), np.uint8); hn = np.zeros(nframes, np.int32)
-        for p in range(nframes):
-            hn[p] = len(proj[p]); hp[p, : hn[p]] = proj[p]; hd[p, : hn[p]] = np.asarray(proj_desc[p], np.uint8).reshape(-1, 32)
-        d_p = torch.from_numpy(hp.view(np.uint8)).to(f"cuda:{dev}"); d_d = torch.from_numpy(hd).to(f"cuda:{dev}"); d_n = torch.from_numpy(hn).to(f"cuda:{dev}")
+        if proj_counts is not None:
+            d_p, d_n = proj, proj_counts
+            max_np = int(d_p.shape[1])
+            hd = np.zeros((nframes, max_np, 32), np.uint8)
+            for p in range(nframes):
+                dd = np.asarray(proj_desc[p], np.uint8).reshape(-1, 32); hd[p, : len(dd)] = dd
+        else:
+            max_np = max(1, max(len(p) for p in proj))
+            hp = np.zeros((nframes, max_np), PROJECTION_DTYPE); hd = np.zeros((nframes, max_np, 32), np.uint8); hn = np.zeros(nframes, np.int32)
+            for p in range(nframes):
+                hn[p] = len(proj[p]); hp[p, : hn[p]] = proj[p]; hd[p, : hn[p]] = np.asarray(proj_desc[p], np.uint8).reshape(-1, 32)
+            d_p = torch.from_numpy(hp.view(np.uint8)).to(f"cuda:{dev}"); d_n = torch.from_numpy(hn).to(f"cuda:{dev}")
+        d_d = torch.from_numpy(hd).to(f"cuda:{dev}")
         d_ur = torch.from_numpy(np.ascontiguousarray(u_right, np.float32)).to(f"cuda:{dev}") if u_right is not None else None
         d_cs = torch.from_numpy(np.ascontiguousarray(cur_state, np.int8)).to(f"cuda:{dev}") if cur_state is not None else None
         kun = self._dev_out((nframes, cap * 28), torch.uint8, dev, 0)

@@ -2604,6 +2604,89 @@ extern "C" int orbx_undistort_keypoints(orbx_matcher *m, const orbx_keypoint *kp
     return ORBX_OK;
 }
 
+// ---- projection head of the tracking searches (include/orbx.h "The projection head"; k_project_points) ------------------------------
+static int projectArgs(OrbxProjectArgs &a, const char *fn, int mode, const orbx_camera *cam, const float *bounds, float mbf, float viewCosLimit,
+                       float logScaleFactor, int nlevels, int farPoints, float thFar)
+{
+    if (mode != 0 && mode != 1) return setError(ORBX_ERR_INVALID_ARG, "%s: mode must be 0 (motion model) or 1 (in frustum)", fn);
+    if (!cam || (cam->type != 0 && cam->type != 1)) return setError(ORBX_ERR_INVALID_ARG, "%s: camera type must be 0 (Pinhole) or 1 (KannalaBrandt8)", fn);
+    memset(&a, 0, sizeof a);
+    a.mode = mode; a.camType = cam->type;
+    memcpy(a.cam, cam->p, sizeof a.cam);
+    if (mode == 1) {
+        if (!bounds || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(logScaleFactor > 0.f))
+            return setError(ORBX_ERR_INVALID_ARG, "%s: in-frustum mode needs bounds, 0 < nlevels <= %d and log_scale_factor > 0", fn, ORBX_MAX_LEVELS);
+        a.minX = bounds[0]; a.maxX = bounds[1]; a.minY = bounds[2]; a.maxY = bounds[3];
+        a.mbf = mbf; a.viewCosLimit = viewCosLimit; a.logScaleFactor = logScaleFactor; a.nlevels = nlevels; a.farPoints = farPoints; a.thFar = thFar;
+    }
+    return ORBX_OK;
+}
+
+static int projectHost(const char *fn, orbx_matcher *m, OrbxProjectArgs &a, const float *pose16, const orbx_world_point *points, int np,
+                       orbx_projection *out)
+{
+    if (!m || np < 0 || (np > 0 && (!points || !out))) return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    if (np == 0) return ORBX_OK;
+    if (np > m->maxQ) return setError(ORBX_ERR_CAPACITY, "%s: %d points exceed the matcher capacity %d", fn, np, m->maxQ);
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = m->d_proj.ensure((size_t)m->maxQ);
+    if (rc != ORBX_OK) return rc;
+    HostPack in(m);
+    const size_t oP = in.add(pose16, 16 * sizeof(float)), oW = in.add(points, (size_t)np * sizeof(orbx_world_point));
+    if ((rc = in.send()) != ORBX_OK) return rc;
+    a.nframes = 1; a.maxNp = np; a.np = np; a.npDev = nullptr;
+    a.pose = in.dev<float>(oP); a.points = in.dev<uint8_t>(oW); a.out = m->d_proj.p;
+    HIP_TRY(orbxLaunchProjectPoints(m->stream, &a));
+    HostFetch res(m);
+    res.add(out, m->d_proj.p, (size_t)np * sizeof(orbx_projection));
+    return res.finish();
+}
+
+extern "C" int orbx_project_last_frame_points(orbx_matcher *m, const float *q_xyzw, const float *t, const orbx_camera *cam,
+                                              const orbx_world_point *points, int np, orbx_projection *proj_out)
+{
+    ORBX_API_ENTRY;
+    if (!q_xyzw || !t) return setError(ORBX_ERR_INVALID_ARG, "orbx_project_last_frame_points: null pose");
+    OrbxProjectArgs a;
+    int rc = projectArgs(a, "orbx_project_last_frame_points", 0, cam, nullptr, 0.f, 0.f, 0.f, 0, 0, 0.f);
+    if (rc != ORBX_OK) return rc;
+    float pose[16] = {q_xyzw[0], q_xyzw[1], q_xyzw[2], q_xyzw[3], t[0], t[1], t[2]};
+    return projectHost("orbx_project_last_frame_points", m, a, pose, points, np, proj_out);
+}
+
+extern "C" int orbx_project_in_frustum(orbx_matcher *m, const float *Rcw, const float *tcw, const float *Ow, const orbx_camera *cam,
+                                       const float *bounds, float mbf, float viewing_cos_limit, float log_scale_factor, int nlevels,
+                                       int far_points, float th_far_points, const orbx_world_point *points, int np, orbx_projection *proj_out)
+{
+    ORBX_API_ENTRY;
+    if (!Rcw || !tcw || !Ow) return setError(ORBX_ERR_INVALID_ARG, "orbx_project_in_frustum: null pose");
+    OrbxProjectArgs a;
+    int rc = projectArgs(a, "orbx_project_in_frustum", 1, cam, bounds, mbf, viewing_cos_limit, log_scale_factor, nlevels, far_points, th_far_points);
+    if (rc != ORBX_OK) return rc;
+    float pose[16] = {0};
+    memcpy(pose, Rcw, 9 * sizeof(float)); memcpy(pose + 9, tcw, 3 * sizeof(float)); memcpy(pose + 12, Ow, 3 * sizeof(float));
+    return projectHost("orbx_project_in_frustum", m, a, pose, points, np, proj_out);
+}
+
+extern "C" int orbx_project_points_frames(orbx_matcher *m, int mode, int nframes, const float *d_pose, const orbx_camera *cam, const float *bounds,
+                                          float mbf, float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points,
+                                          float th_far_points, const orbx_world_point *d_points, const int32_t *d_np, int max_np,
+                                          orbx_projection *d_proj_out)
+{
+    ORBX_API_ENTRY;
+    if (!m || nframes < 0 || max_np < 0 || (nframes > 0 && max_np > 0 && (!d_pose || !d_points || !d_np || !d_proj_out)))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_project_points_frames: bad argument");
+    OrbxProjectArgs a;
+    int rc = projectArgs(a, "orbx_project_points_frames", mode, cam, bounds, mbf, viewing_cos_limit, log_scale_factor, nlevels, far_points, th_far_points);
+    if (rc != ORBX_OK) return rc;
+    if (nframes == 0 || max_np == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    a.nframes = nframes; a.maxNp = max_np; a.np = max_np; a.npDev = d_np;
+    a.pose = d_pose; a.points = d_points; a.out = d_proj_out;
+    HIP_TRY(orbxLaunchProjectPoints(m->stream, &a));
+    return ORBX_OK;
+}
+
 // Frame::ComputeImageBounds — reference src/Frame.cc:813-845: the four image corners through the same kernel.
 extern "C" int orbx_compute_image_bounds(orbx_matcher *m, int cols, int rows, const float *k4, const float *dist, int ndist,
                                          const float *knew4, float *bounds)

@@ -262,6 +262,17 @@ struct OrbxSbpFisheye {
     const OrbxSbpBatch *batch = nullptr;  // a batch of frames: kc / dc / curState / partner / head / assign advance by kcStride = capL + capR records per frame
                                           // (nLeft = capL: right keypoints start at the left capacity), steps / dproj by projStride = 2 maxNp / maxNp
 };
+// projection head of the tracking searches (orbx_project_points_frames): scalar parameters of the in-frustum mode
+struct OrbxProjectArgs {
+    int mode, nframes, maxNp;          // mode 0 motion model (Sophus SE3f * point), 1 Frame::isInFrustum
+    const float *pose;                 // [nframes][16] device (or the one pose of a single call, also device)
+    int camType; float cam[8];
+    float minX, maxX, minY, maxY, mbf, viewCosLimit, logScaleFactor, thFar;
+    int nlevels, farPoints;
+    const void *points; const int *npDev; int np;  // npDev NULL: np points in every frame
+    void *out;
+};
+hipError_t orbxLaunchProjectPoints(hipStream_t st, const OrbxProjectArgs *a);
 hipError_t orbxLaunchFisheyeSteps(hipStream_t st, const void *pl, const void *pr, const int *npDev, int maxNp, int nframes, int mode, void *steps);
 hipError_t orbxLaunchFisheyePartner(hipStream_t st, const int *l2r, const int *r2l, const int *nlDev, const int *nrDev, int capL, int capR, int nframes,
                                     int *partner);

@@ -2721,6 +2721,96 @@ __device__ void fe_project(const float *P, const float v[3], float uv[2])
     uv[1] = (float)__dadd_rn(__dmul_rn((double)__fmul_rn(P[1], r), sin((double)psi)), (double)P[3]);
 }
 
+// =====================================================================================================================================
+// Projection head of the two tracking searches (round 4; include/orbx.h "The projection head"): orbx_projection records from world points
+// and a pose, one thread per point.  Every operation in float, un-fused, in the order Eigen / Sophus evaluate it:
+//   * a 3-term sum (matrix row times vector, dot, squaredNorm) is Eigen's unrolled redux x0 + (x1 + x2) (Eigen/src/Core/Redux.h,
+//     redux_novec_unroller: func(run<Start, Length / 2>, run<Start + Length / 2, Length - Length / 2>));
+//   * cross(a, b) = (a1 b2 - a2 b1, a2 b0 - a0 b2, a0 b1 - a1 b0) (Eigen/src/Geometry/OrthoMethods.h);
+//   * Sophus SO3 * p = p + w * uv + q.vec x uv with uv = 2 (q.vec x p) (Thirdparty/Sophus/sophus/so3.hpp:358-367), SE3: + translation.
+// =====================================================================================================================================
+struct ProjPointIn { float pos[3], normal[3], minD, maxD, angle; int octave, flags; };   // orbx_world_point
+static_assert(sizeof(ProjPointIn) == 44, "orbx_world_point layout");
+__device__ __forceinline__ float pp_sum3(float x0, float x1, float x2) { return __fadd_rn(x0, __fadd_rn(x1, x2)); }
+__device__ __forceinline__ void pp_cross(const float *a, const float *b, float *c)
+{
+    c[0] = __fsub_rn(__fmul_rn(a[1], b[2]), __fmul_rn(a[2], b[1]));
+    c[1] = __fsub_rn(__fmul_rn(a[2], b[0]), __fmul_rn(a[0], b[2]));
+    c[2] = __fsub_rn(__fmul_rn(a[0], b[1]), __fmul_rn(a[1], b[0]));
+}
+__device__ void fe_project(const float *P, const float v[3], float uv[2]);
+__device__ __forceinline__ void pp_camera_project(int type, const float *P, const float v[3], float uv[2])
+{
+    if (type == 0) {  // Pinhole::project(Eigen::Vector3f), src/CameraModels/Pinhole.cpp:43-49
+        uv[0] = __fadd_rn(__fdiv_rn(__fmul_rn(P[0], v[0]), v[2]), P[2]);
+        uv[1] = __fadd_rn(__fdiv_rn(__fmul_rn(P[1], v[1]), v[2]), P[3]);
+    } else fe_project(P, v, uv);  // KannalaBrandt8::project, src/CameraModels/KannalaBrandt8.cpp:67-84
+}
+
+__global__ __launch_bounds__(256) void k_project_points(OrbxProjectArgs a)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int np = a.npDev ? min(a.npDev[f], a.maxNp) : a.np;
+    if (i >= np) return;
+    const ProjPointIn pt = ((const ProjPointIn *)a.points)[(size_t)f * a.maxNp + i];
+    const float *T = a.pose + (size_t)f * 16;
+    SbpProj o;
+    o.angle = pt.angle; o.octave = pt.octave; o.flags = pt.flags;
+    const float *p = pt.pos;
+    if (a.mode == 0) {
+        // x3Dc = Tcw * x3Dw (src/ORBmatcher3.cc:283-284)
+        const float *q = T, *t = T + 4;  // q = x y z w
+        float uv[3], c2[3], x[3];
+        pp_cross(q, p, uv);
+        for (int k = 0; k < 3; ++k) uv[k] = __fadd_rn(uv[k], uv[k]);
+        pp_cross(q, uv, c2);
+        for (int k = 0; k < 3; ++k) x[k] = __fadd_rn(__fadd_rn(__fadd_rn(p[k], __fmul_rn(q[3], uv[k])), c2[k]), t[k]);
+        o.invz = (float)__ddiv_rn(1.0, (double)x[2]);   // const float invzc = 1.0 / x3Dc(2) (:288)
+        float w[2];
+        pp_camera_project(a.camType, a.cam, x, w);       // (:293)
+        o.u = w[0]; o.v = w[1];
+    } else {
+        // Frame::isInFrustum, src/Frame.cc:549-599
+        const float *R = T, *t = T + 9, *Ow = T + 12;
+        float Pc[3];
+        for (int k = 0; k < 3; ++k)
+            Pc[k] = __fadd_rn(pp_sum3(__fmul_rn(R[3 * k], p[0]), __fmul_rn(R[3 * k + 1], p[1]), __fmul_rn(R[3 * k + 2], p[2])), t[k]);
+        const float PcDist = fe_sqrtf(pp_sum3(__fmul_rn(Pc[0], Pc[0]), __fmul_rn(Pc[1], Pc[1]), __fmul_rn(Pc[2], Pc[2])));
+        const float invz = __fdiv_rn(1.0f, Pc[2]);
+        bool in = !(Pc[2] < 0.0f);
+        float w[2];
+        pp_camera_project(a.camType, a.cam, Pc, w);
+        if (w[0] < a.minX || w[0] > a.maxX) in = false;
+        if (w[1] < a.minY || w[1] > a.maxY) in = false;
+        const float maxDistance = __fmul_rn(1.2f, pt.maxD), minDistance = __fmul_rn(0.8f, pt.minD);
+        const float PO[3] = {__fsub_rn(p[0], Ow[0]), __fsub_rn(p[1], Ow[1]), __fsub_rn(p[2], Ow[2])};
+        const float dist = fe_sqrtf(pp_sum3(__fmul_rn(PO[0], PO[0]), __fmul_rn(PO[1], PO[1]), __fmul_rn(PO[2], PO[2])));
+        if (dist < minDistance || dist > maxDistance) in = false;
+        const float viewCos = __fdiv_rn(pp_sum3(__fmul_rn(PO[0], pt.normal[0]), __fmul_rn(PO[1], pt.normal[1]), __fmul_rn(PO[2], pt.normal[2])), dist);
+        if (viewCos < a.viewCosLimit) in = false;
+        // MapPoint::PredictScale (src/MapPoint.cc:531-546)
+        const float ratio = __fdiv_rn(pt.maxD, dist);
+        const double lv = ceil(__ddiv_rn(log((double)ratio), (double)a.logScaleFactor));
+        int nScale = lv >= (double)a.nlevels ? a.nlevels - 1 : lv < 0.0 ? 0 : (int)lv;   // (int conversion first, then the clamps: same result inside int range;
+                                                                                          //  a NaN / huge quotient is undefined in the reference)
+        if (!(lv == lv)) nScale = 0;
+        if (a.farPoints && PcDist > a.thFar) in = false;   // src/ORBmatcher1.cc:57-58 (mTrackDepth = Pc_dist)
+        o.u = w[0]; o.v = w[1];
+        o.invz = __fsub_rn(w[0], __fmul_rn(a.mbf, invz));   // mTrackProjXR
+        o.angle = viewCos; o.octave = nScale;
+        o.flags = (pt.flags & ~1) | ((pt.flags & 1) && in ? 1 : 0);
+    }
+    ((SbpProj *)a.out)[(size_t)f * a.maxNp + i] = o;
+}
+
+hipError_t orbxLaunchProjectPoints(hipStream_t st, const OrbxProjectArgs *a)
+{
+    const int n = a->npDev ? a->maxNp : a->np;
+    if (a->nframes <= 0 || n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_project_points, dim3((n + 255) / 256, a->nframes), dim3(256), 0, st, *a);
+    return hipGetLastError();
+}
+
 __device__ void fe_null_vector4(const float A[16], float v[4])
 {
     double U[4][4], V[4][4];
