@@ -7,8 +7,12 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/$tag
 mkdir -p $o
 if [ -z "$SKIP_TESTS" ]; then   # (SKIP_TESTS=1: the GPU tests ran in a call of their own)
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $o/pytest_gpu.log 2>&1; echo "pytest exit=$?" >> $o/pytest_gpu.log
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $o/pytest_gpu.log 2>&1; prc=$?; echo "pytest exit=$prc" >> $o/pytest_gpu.log
 tail -3 $o/pytest_gpu.log
+if [ $prc -ne 0 ]; then echo "!!!! profile_round: the GPU tests FAILED - no evidence is collected from a failing build !!!!"; exit 1; fi
+fi
+if [ -n "$WITH_STRESS" ]; then   # (WITH_STRESS=1: the randomised sweeps too; a failing sweep stops the round)
+bash tools/stress_round.sh $tag || { echo "!!!! profile_round: a stress sweep FAILED !!!!"; exit 1; }
 fi
 bash tools/collect_traffic.sh > $o/traffic.log 2>&1
 cp gpurun_out/traffic/summary.json $o/hbm_traffic_pmc.json

@@ -72,6 +72,7 @@ struct Knn2Args {
     int nSplit, splitRows;
     uint32_t *part;                       // [pair][split][nq][2] partial keys (nSplit > 1)
     int *idx, *dist;                      // [pair][nq][2]
+    int sharedBound;                      // k_knn2_scan_mfma: the insert bound shared by the four lane groups of a query (ORBX_KNN_SHARED_BOUND)
 };
 
 __device__ __forceinline__ void kn_insert(uint32_t &k0, uint32_t &k1, uint32_t key)
@@ -281,6 +282,17 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
                         if (TAIL && jr + r >= j1) key = KN_NONE;
                         kn_insert(k0[qt], k1[qt], key);
                     }
+                    // (Round 4, measured and dropped: the bound shared by the four lane groups of a query - the smallest of their second
+                    // keys, exact because each group's pair alone holds two keys below its own second key.  It cuts the insert events of an
+                    // unsplit 4000-row scan from 85 % to ~40 % of the tile x query-tile steps, but the two ds_bpermute round trips per event
+                    // cost more than the events saved: 2.01 against 1.87 ms per 512 pairs, 0.61 against 0.52 ms for c5's 128 split pairs.)
+                    if (a.sharedBound) {   // A/B (ORBX_KNN_SHARED_BOUND=1): the query-wide bound through v_permlane32/16_swap (no LDS round trip)
+                        int t = (int)(k1[qt] >> 22);
+                        auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false);
+                        t = min((int)s32[0], (int)s32[1]);
+                        auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false);
+                        thr[qt] = min((int)s16[0], (int)s16[1]);
+                    } else
                     thr[qt] = (int)(k1[qt] >> 22);
                 }
             }
@@ -542,6 +554,8 @@ hipError_t orbxLaunchKnn2Batch(hipStream_t st, int npairs, const uint8_t *q, lon
     // quarter of the vector instructions per descriptor pair and a 23 % lower matrix floor (34 cycles per 32768 products against 22 per
     // 16384, tools/experiments/mfma_i8_rate.hip), but 202 VGPRs = two waves per SIMD: 2.06 against 1.80 ms per 512 pairs of 4000 x 4000
     static const int mfma = [] { const char *e = getenv("ORBX_KNN_MFMA"); return e ? atoi(e) : 1; }();
+    static const int sharedBound = [] { const char *e = getenv("ORBX_KNN_SHARED_BOUND"); return e ? atoi(e) : 0; }();
+    a.sharedBound = sharedBound;
     if (mfma == 2) hipLaunchKernelGGL(k_knn2_scan_mfma32, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
     else if (mfma) hipLaunchKernelGGL(k_knn2_scan_mfma, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_knn2_scan, dim3((nq + 63) / 64, a.nSplit, npairs), dim3(64), 0, st, a);
