@@ -80,6 +80,14 @@ __device__ __forceinline__ int max3i(int a, int b, int c)
     return r;
 }
 
+// (a * b) >> 32 for a, b < 2^24 (v_mul_hi_u32_u24: half rate; a full v_mul_lo_u32 / v_mul_hi_u32 issues at ~8 cycles on gfx950)
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Number of set bits of a wave mask below this lane.
 __device__ __forceinline__ unsigned mbcnt64(unsigned long long m)
 {
@@ -568,7 +576,8 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                                                                                       // cv::resize clamps sx to w - 1 its weight is 0
             auto yEntry = [&](int sy, int w2) {  // LDS byte offsets of the two source rows
                 const int sy0 = min(max(sy, 0), hm1) - ly0, sy1 = min(max(sy + 1, 0), hm1) - ly0;
-                return make_int2((sy0 * tp) | ((sy1 * tp) << 16), w2);
+                // .y = the first row's weight b0 << 8, ready for v_mul_hi_u32_u24 (phase 1); b1 = 2048 - b0 (cv::resize: the two sum to 2048)
+                return make_int2((sy0 * tp) | ((sy1 * tp) << 16), (w2 & 0xFFFF) << 8);
             };
             const int i0 = otid();
             if (i0 < ndx) xt[i0] = xEntry(xo_, xw_);
@@ -608,23 +617,27 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                     ok[j] = dx >= dx0 && dx < dx1;
                     const int2 e = xt[min(max(dx, dx0), dx1 - 1) - dx0];
                     ca[j] = e.x;
-                    wa[j] = (short)(e.y & 0xFFFF);
-                    wb[j] = e.y >> 16;
+                    wa[j] = (e.y & 0xFFFF) << 4;   // weights are in [0, 2048]; << 4: the horizontal sum comes out as h << 4 (< 2^24)
+                    wb[j] = (e.y >> 16) << 4;
                 }
                 const bool full = ok[0] && ok[3];
 #pragma nounroll
                 for (int dy = dy0 + rc; dy < dy1; dy += RC) {
                     const int2 ye = yt[dy - dy0];
-                    const int b0 = ye.y & 0xFFFF, b1 = (unsigned)ye.y >> 16;  // weights are in [0, 2048]
+                    const uint32_t b0s = (uint32_t)ye.y, b1s = (2048u << 8) - b0s;  // vertical weights << 8 (the two sum to 2048)
                     const uint8_t *r0 = tile + (ye.x & 0xFFFF);
                     const uint8_t *r1 = tile + ((unsigned)ye.x >> 16);
                     uint32_t packed = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int h0 = r0[ca[j]] * wa[j] + r0[ca[j] + 1] * wb[j];
-                        const int h1 = r1[ca[j]] * wa[j] + r1[ca[j] + 1] * wb[j];
+                        // cv::resize: ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2 >> 2 with h = S[sx] * a0 + S[sx + 1] * a1.
+                        // Every factor is below 2^24, so the 24-bit multipliers do: h << 4 directly from the pre-shifted weights
+                        // (v_mul_u32_u24 + v_mad_u32_u24), and (b * (h >> 4)) >> 16 = ((b << 8) * ((h >> 4) << 8)) >> 32 = ONE v_mul_hi_u32_u24
+                        // on (h << 4) & ~0xFF.  v_mul_lo_u32, which the compiler emits for the plain expression, issues at ~8 cycles.
+                        const uint32_t h0 = __umul24(r0[ca[j]], (uint32_t)wa[j]) + __umul24(r0[ca[j] + 1], (uint32_t)wb[j]);
+                        const uint32_t h1 = __umul24(r1[ca[j]], (uint32_t)wa[j]) + __umul24(r1[ca[j] + 1], (uint32_t)wb[j]);
                         // <= 255: the weights of each axis sum to 2048
-                        const uint32_t v = (uint32_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+                        const uint32_t v = (mul_hi_u24(h0 & 0xFFFFFF00u, b0s) + mul_hi_u24(h1 & 0xFFFFFF00u, b1s) + 2u) >> 2;
                         packed |= v << (8 * j);
                     }
                     uint8_t *drow = dstF + (size_t)dy * dstPitch + q * 4;
