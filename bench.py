@@ -71,8 +71,10 @@ def kernel_source_sha256():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "wut-cuda-orb-slam3_amd", "csrc")
-    for name in ("orbx_kernels.hip", "orbx_internal.h"):
-        h.update(open(os.path.join(d, name), "rb").read())
+    # (the Makefile and tools/sq_slowmode.py too: the device assembly passes through the s_nop pass before it is assembled)
+    for name in (os.path.join(d, "orbx_kernels.hip"), os.path.join(d, "orbx_internal.h"), os.path.join(d, "Makefile"),
+                 os.path.join(ROOT, "tools", "sq_slowmode.py")):
+        h.update(open(name, "rb").read())
     return h.hexdigest()
 
 

@@ -540,6 +540,23 @@ int orbx_fuse(orbx_matcher *m, const orbx_keypoint *keys, const uint8_t *desc, c
               float min_y, float max_y, const float *inv_level_sigma2, int nlevels, const orbx_window_point *points,
               const uint8_t *point_desc, int np, int chi2_test, int32_t *fused_idx);
 
+/* The same two searches over a BATCH of keyframes, device-resident (round 4): keyframe p = frame p of `ex`'s last batch - its keypoints
+ * through Frame::UndistortKeyPoints (k4 / dist / knew4 as in orbx_undistort_keypoints; mvKeysUn is what KeyFrame::GetFeaturesInArea reads),
+ * its descriptors where the extractor left them, its 64 x 48 grid built on the device - the shape of LocalMapping::SearchInNeighbors
+ * (src/LocalMapping.cc:772-803: the new keyframe's map points fused into its 10 - 30 neighbours, and theirs into it) and of the loop
+ * closer's Fuse calls.  d_points [nframes][max_np] / d_point_desc [nframes][max_np][32] / d_np [nframes]: the map points projected into
+ * keyframe p (orbx_window_point, as for the single-keyframe calls); d_u_right [nframes][cap] = mvuRight or NULL; inv_level_sigma2 =
+ * the extractor's own table (mvInvLevelSigma2).  Outputs, device: d_best_idx / d_best_dist [nframes][max_np] (orbx_search_keyframe_windows)
+ * resp. d_fused_idx [nframes][max_np] + d_nfused [nframes] (orbx_fuse).  cap = orbx_max_keypoints(ex).  Three launches for the whole batch,
+ * asynchronous on the matcher's stream. */
+int orbx_search_keyframe_windows_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
+                                        const float *knew4, float min_x, float max_x, float min_y, float max_y, const float *d_u_right,
+                                        const orbx_window_point *d_points, const uint8_t *d_point_desc, const int32_t *d_np, int max_np,
+                                        int chi2_test, void *d_best_idx, void *d_best_dist);
+int orbx_fuse_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist, const float *knew4,
+                     float min_x, float max_x, float min_y, float max_y, const float *d_u_right, const orbx_window_point *d_points,
+                     const uint8_t *d_point_desc, const int32_t *d_np, int max_np, int chi2_test, void *d_fused_idx, void *d_nfused);
+
 /* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const Sim3f &S12, const float th) —
  * reference src/ORBmatcher3.cc:37-254 (loop closing): the map points of pKF1 projected into pKF2 (points_1in2, one per feature of pKF1,
  * search = 0 for a feature without a usable map point, an already matched one (:70-82) or a failed visibility test) search pKF2's

@@ -243,3 +243,53 @@ def test_projection_sim3_window_beyond_the_list_capacity(pkg, orc):
     ref = orc.search_by_projection_sim3(k, d, BOUNDS, pts, pd, matched, 1.0)
     assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and got[0] > 100
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("distorted", [False, True])
+def test_fuse_and_window_search_over_a_batch_of_keyframes(pkg, orc, distorted):
+    """orbx_fuse_frames / orbx_search_keyframe_windows_frames: K keyframes = the frames of an extractor batch, map points projected into each of
+    them, everything device-resident; per keyframe the result equals the single-keyframe oracle on that frame's (undistorted) keypoints -
+    LocalMapping::SearchInNeighbors' shape (reference src/LocalMapping.cc:772-803 around src/ORBmatcher2.cc:420-610)."""
+    import torch
+    K = 5
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=K)
+    imgs = np.stack([pkg.synth_frame(50 + f, 640, 480) for f in range(K)])
+    d_imgs = torch.from_numpy(imgs).to("cuda:0")
+    ex.extract_batch_device(d_imgs.data_ptr(), K, 640, 480, 640, 640 * 480, (0, 0)); ex.sync()
+    n, _, kk, dd = ex.download_outputs(K)
+    inv_sigma2 = ex.GetInverseScaleSigmaSquares().copy()
+    sf = ex.GetScaleFactors().copy()
+    k4 = np.float32([458.654, 457.296, 367.215, 248.375])
+    dist = np.float32([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]) if distorted else np.zeros(0, np.float32)
+    m = pkg.ORBmatcher(8192, 8192)
+    bounds = m.ComputeImageBounds(640, 480, k4, dist) if distorted else (0.0, 640.0, 0.0, 480.0)
+    rng = np.random.default_rng(9)
+    pts_all, pd_all, ur_all, kun_all = [], [], np.full((K, ex.capacity), -1, np.float32), []
+    for f in range(K):
+        nc = int(n[f])
+        kun = orc.undistort_keypoints(kk[f, :nc], k4, dist) if distorted else kk[f, :nc]
+        kun_all.append(kun)
+        np_ = int(rng.integers(1, 1500)) if f else 0         # keyframe 0: no points at all
+        src = rng.integers(0, nc, np_)
+        pts = np.zeros(np_, orc.WINDOW_POINT_DTYPE)
+        pts["u"] = kun["x"][src] + rng.normal(0, 2.0, np_); pts["v"] = kun["y"][src] + rng.normal(0, 2.0, np_)
+        pts["level"] = np.clip(kun["octave"][src] + rng.integers(0, 2, np_), 0, 7)
+        pts["radius"] = (rng.choice([3.0, 4.0, 7.5], np_) * sf[pts["level"]]).astype(np.float32)
+        pts["ur"] = pts["u"] - rng.uniform(1, 30, np_)
+        pts["search"] = rng.random(np_) < 0.9
+        pd = np.stack([_flip(dd[f, s], rng.integers(0, 256, int(rng.integers(0, 70)))) for s in src]) if np_ else np.zeros((0, 32), np.uint8)
+        ur_all[f, :nc] = np.where(rng.random(nc) < 0.5, kun["x"] - rng.uniform(1, 30, nc), -1)
+        pts_all.append(pts); pd_all.append(pd)
+    for chi2, ur in ((False, None), (True, None), (True, ur_all)):
+        bi, bd = m.FuseFrames(ex, K, k4, dist, bounds, pts_all, pd_all, chi2_test=chi2, u_right=ur, fuse=False)
+        fi, nf = m.FuseFrames(ex, K, k4, dist, bounds, pts_all, pd_all, chi2_test=chi2, u_right=ur, fuse=True)
+        for f in range(K):
+            nc, np_ = int(n[f]), len(pts_all[f])
+            ref = orc.search_keyframe_windows(kun_all[f], dd[f, :nc], bounds, pts_all[f], pd_all[f], u_right=None if ur is None else ur[f, :nc],
+                                              inv_level_sigma2=inv_sigma2, chi2_test=chi2)
+            assert np.array_equal(bi[f, :np_], ref[0]) and np.array_equal(bd[f, :np_], ref[1]), (chi2, f)
+            exp = np.where(ref[1] <= 50, ref[0], -1)
+            assert np.array_equal(fi[f, :np_], exp) and nf[f] == int((exp >= 0).sum()), (chi2, f)
+        assert nf[0] == 0 and nf[1:].sum() > 100
+    m.close(); ex.close()

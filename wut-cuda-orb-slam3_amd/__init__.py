@@ -98,6 +98,8 @@ ABI_SYMBOLS = [
     "orbx_project_last_frame_points",
     "orbx_project_in_frustum",
     "orbx_project_points_frames",
+    "orbx_search_keyframe_windows_frames",
+    "orbx_fuse_frames",
     "orbx_vocabulary_create",
     "orbx_vocabulary_load_text",
     "orbx_vocabulary_destroy",
@@ -227,6 +229,9 @@ def load_library() -> ctypes.CDLL:
                                                                     c_void_p, c_void_p]
     lib.orbx_undistort_keypoints.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_compute_image_bounds.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    for _name in ("orbx_search_keyframe_windows_frames", "orbx_fuse_frames"):
+        getattr(lib, _name).argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_project_last_frame_points.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_int, c_void_p]
     lib.orbx_project_in_frustum.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_float, c_float, c_float, c_int,
                                             c_int, c_float, c_void_p, c_int, c_void_p]
@@ -672,6 +677,33 @@ class ORBmatcher:
                                                                     c_void_p(depth.data_ptr()), c_void_p(p3d.data_ptr()), c_void_p(nm.data_ptr())),
                "orbx_compute_stereo_fisheye_matches_frames")
         return self._download(nm), self._download(l2r), self._download(r2l), self._download(depth), self._download(p3d)
+
+    def FuseFrames(self, ex: "ORBextractor", nframes: int, k4, dist, bounds, points, point_desc, chi2_test: bool = True, u_right=None,
+                   fuse: bool = True):
+        """ORBmatcher::Fuse's search (fuse=True: fused_idx + nFused) or the plain KeyFrame window search (fuse=False: best_idx + best_dist) for the
+        first `nframes` frames of the extractor's last batch taken as keyframes, device-resident (orbx_fuse_frames /
+        orbx_search_keyframe_windows_frames).  points[p] / point_desc[p]: WINDOW_POINT_DTYPE records / [n, 32] uint8 of keyframe p.
+        Returns (fused_idx [P, max_np], nfused [P]) resp. (best_idx, best_dist)."""
+        import torch
+        dev = ex.device
+        cap = ex.capacity
+        max_np = max(1, max(len(p) for p in points))
+        hp = np.zeros((nframes, max_np), WINDOW_POINT_DTYPE); hd = np.zeros((nframes, max_np, 32), np.uint8); hn = np.zeros(nframes, np.int32)
+        for p in range(nframes):
+            hn[p] = len(points[p]); hp[p, : hn[p]] = points[p]; hd[p, : hn[p]] = np.asarray(point_desc[p], np.uint8).reshape(-1, 32)
+        dv = f"cuda:{dev}"
+        d_p = torch.from_numpy(hp.view(np.uint8).reshape(nframes, -1)).to(dv); d_d = torch.from_numpy(hd).to(dv); d_n = torch.from_numpy(hn).to(dv)
+        d_ur = torch.from_numpy(np.ascontiguousarray(u_right, np.float32)).to(dv) if u_right is not None else None
+        o1 = self._dev_out((nframes, max_np), torch.int32, dev, -1)
+        o2 = self._dev_out((nframes,) if fuse else (nframes, max_np), torch.int32, dev, 0 if fuse else np.iinfo(np.int32).max)
+        k4 = np.ascontiguousarray(k4, np.float32); dist = np.ascontiguousarray(dist, np.float32).ravel()
+        self._launch_fence(d_p, d_d, d_n, d_ur, o1, o2)
+        fn = self._lib.orbx_fuse_frames if fuse else self._lib.orbx_search_keyframe_windows_frames
+        _check(fn(self._h, ex._h, nframes, k4.ctypes.data, dist.ctypes.data if len(dist) else None, len(dist), None, bounds[0], bounds[1], bounds[2],
+                  bounds[3], c_void_p(d_ur.data_ptr()) if d_ur is not None else None, c_void_p(d_p.data_ptr()), c_void_p(d_d.data_ptr()),
+                  c_void_p(d_n.data_ptr()), max_np, int(bool(chi2_test)), c_void_p(o1.data_ptr()), c_void_p(o2.data_ptr())),
+               "orbx_fuse_frames" if fuse else "orbx_search_keyframe_windows_frames")
+        return self._download(o1), self._download(o2)
 
     # ---- projection head of the tracking searches (include/orbx.h "The projection head") ------------------------------------------
     def ProjectLastFramePoints(self, q_xyzw, t, cam_type: int, cam, points) -> np.ndarray:

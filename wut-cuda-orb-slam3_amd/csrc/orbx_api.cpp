@@ -1972,7 +1972,7 @@ extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orb
     if ((rc = m->d_q.ensure((size_t)max_query * 32)) != ORBX_OK || (rc = m->d_t.ensure((size_t)max_train * 32)) != ORBX_OK ||
         (rc = m->d_idx.ensure((size_t)max_query * 2)) != ORBX_OK || (rc = m->d_dist.ensure((size_t)max_query * 2)) != ORBX_OK ||
         (rc = m->d_kl.ensure(max_query)) != ORBX_OK || (rc = m->d_kr.ensure(max_train)) != ORBX_OK ||
-        (rc = m->d_scale.ensure(ORBX_MAX_LEVELS)) != ORBX_OK) {
+        (rc = m->d_scale.ensure(2 * ORBX_MAX_LEVELS)) != ORBX_OK) {
         orbx_matcher_destroy(m);
         return rc;
     }
@@ -3156,6 +3156,70 @@ static int searchByProjectionFramesImpl(const char *fn, int mode, float nnratio,
     // nmatches[p] = result[2 p]; a window with more than SBP_CAP candidates is reported as -1 for that frame
     HIP_TRY(orbxLaunchGatherResults(m->stream, result, nframes, (int *)d_nmatches));
     return orderExtractorsAfter(m, ex, ex);
+}
+
+// KeyFrame::GetFeaturesInArea window searches (Fuse, SearchBySim3's halves) for a BATCH of keyframes = the frames of an extractor's last
+// batch: undistort -> grid -> one launch of the window search over (point, keyframe).  fuse: bestDist <= TH_LOW decides on the device.
+static int keyframeWindowsFramesImpl(const char *fn, bool fuse, orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist,
+                                     int ndist, const float *knew4, float min_x, float max_x, float min_y, float max_y, const float *d_u_right,
+                                     const orbx_window_point *d_points, const uint8_t *d_point_desc, const int32_t *d_np, int max_np, int chi2_test,
+                                     void *d_out_idx, void *d_out2)
+{
+    if (!m || !ex) return setError(ORBX_ERR_INVALID_ARG, "%s: null handle", fn);
+    if (ex->prm.device != m->device) return setError(ORBX_ERR_INVALID_ARG, "%s: matcher and extractor must live on the same device", fn);
+    if (nframes < 0 || nframes > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "%s: %d keyframes, the extractor's last batch holds %d", fn, nframes, ex->lastFrames);
+    if (max_np < 0 || (max_np > 0 && (!d_points || !d_point_desc)) || !d_np || !d_out_idx || !d_out2)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    int rc = checkCamera(k4, dist, ndist, knew4 ? knew4 : k4, fn);
+    if (rc != ORBX_OK) return rc;
+    if ((rc = checkGridBounds(min_x, max_x, min_y, max_y, fn)) != ORBX_OK) return rc;
+    const int cap = ex->maxKeypoints, nlev = ex->prm.nlevels;
+    if (nframes == 0 || max_np == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t F = (size_t)nframes;
+    if ((rc = m->d_bKps.ensure(F * cap)) != ORBX_OK) return rc;
+    if ((rc = m->d_grid.ensure(F * ((size_t)ORBX_GRID_CELLS + 1 + 2 * (size_t)cap))) != ORBX_OK) return rc;
+    if (fuse && (rc = m->d_work.ensure(F * (size_t)max_np + 64)) != ORBX_OK) return rc;
+    int *cs = m->d_grid.p, *it = cs + F * (ORBX_GRID_CELLS + 1), *co = it + F * cap;
+    orbx_keypoint *kun = m->d_bKps.p;
+    if ((rc = orderAfterExtractors(m, ex, ex)) != ORBX_OK) return rc;
+    // mvInvLevelSigma2 behind the scale table (d_scale holds 2 * ORBX_MAX_LEVELS floats)
+    HIP_TRY(hipMemcpyAsync(m->d_scale.p + ORBX_MAX_LEVELS, ex->invSigma2.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (ndist == 0 || dist[0] == 0.0)
+        HIP_TRY(hipMemcpyAsync(kun, ex->d_kps.p, F * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToDevice, m->stream));
+    else
+        HIP_TRY(orbxLaunchUndistort(m->stream, ex->d_kps.p, kun, cap, k4, dist, ndist, knew4 ? knew4 : k4, nframes, cap, cap, ex->d_n.p));
+    HIP_TRY(orbxLaunchGridBuild(m->stream, kun, cap, min_x, max_x, min_y, max_y, cs, it, co, nframes, cap, ex->d_n.p));
+    OrbxKfwFrames b;
+    b.nframes = nframes; b.maxNp = max_np; b.chi2 = chi2_test != 0; b.fuseTh = fuse ? 50 : -1;   // TH_LOW (src/ORBmatcher1.cc:38)
+    b.keys = kun; b.desc = ex->d_desc.p; b.uRight = d_u_right; b.invSigma2 = m->d_scale.p + ORBX_MAX_LEVELS;
+    b.cellStart = cs; b.items = it; b.keyStride = cap; b.gridStride = ORBX_GRID_CELLS + 1; b.itemStride = cap;
+    b.minX = min_x; b.maxX = max_x; b.minY = min_y; b.maxY = max_y;
+    b.pts = d_points; b.ptDesc = d_point_desc; b.npDev = d_np;
+    b.bestIdx = (int *)d_out_idx;
+    b.bestDist = fuse ? m->d_work.p : (int *)d_out2;
+    b.nFused = fuse ? (int *)d_out2 : nullptr;
+    HIP_TRY(orbxLaunchKeyframeWindowSearchFrames(m->stream, &b));
+    return orderExtractorsAfter(m, ex, ex);
+}
+
+extern "C" int orbx_search_keyframe_windows_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist,
+                                                   const float *knew4, float min_x, float max_x, float min_y, float max_y, const float *d_u_right,
+                                                   const orbx_window_point *d_points, const uint8_t *d_point_desc, const int32_t *d_np,
+                                                   int max_np, int chi2_test, void *d_best_idx, void *d_best_dist)
+{
+    ORBX_API_ENTRY;
+    return keyframeWindowsFramesImpl("orbx_search_keyframe_windows_frames", false, m, ex, nframes, k4, dist, ndist, knew4, min_x, max_x, min_y, max_y,
+                                     d_u_right, d_points, d_point_desc, d_np, max_np, chi2_test, d_best_idx, d_best_dist);
+}
+
+extern "C" int orbx_fuse_frames(orbx_matcher *m, orbx_extractor *ex, int nframes, const float *k4, const float *dist, int ndist, const float *knew4,
+                                float min_x, float max_x, float min_y, float max_y, const float *d_u_right, const orbx_window_point *d_points,
+                                const uint8_t *d_point_desc, const int32_t *d_np, int max_np, int chi2_test, void *d_fused_idx, void *d_nfused)
+{
+    ORBX_API_ENTRY;
+    return keyframeWindowsFramesImpl("orbx_fuse_frames", true, m, ex, nframes, k4, dist, ndist, knew4, min_x, max_x, min_y, max_y, d_u_right, d_points,
+                                     d_point_desc, d_np, max_np, chi2_test, d_fused_idx, d_nfused);
 }
 
 // The CurrentFrame.Nleft != -1 branches (two KB8 fisheye cameras) of both SearchByProjection functions for a BATCH of frames, device-resident:

@@ -262,6 +262,16 @@ struct OrbxSbpFisheye {
     const OrbxSbpBatch *batch = nullptr;  // a batch of frames: kc / dc / curState / partner / head / assign advance by kcStride = capL + capR records per frame
                                           // (nLeft = capL: right keypoints start at the left capacity), steps / dproj by projStride = 2 maxNp / maxNp
 };
+// KeyFrame window search / Fuse for a batch of keyframes (orbx_search_keyframe_windows_frames, orbx_fuse_frames)
+struct OrbxKfwFrames {
+    int nframes, maxNp, chi2, fuseTh;
+    const void *keys; const uint8_t *desc; const float *uRight; const float *invSigma2;
+    const int *cellStart, *items; long long keyStride, gridStride, itemStride;
+    float minX, maxX, minY, maxY;
+    const void *pts; const uint8_t *ptDesc; const int *npDev;
+    int *bestIdx, *bestDist, *nFused;
+};
+hipError_t orbxLaunchKeyframeWindowSearchFrames(hipStream_t st, const OrbxKfwFrames *b);
 // projection head of the tracking searches (orbx_project_points_frames): scalar parameters of the in-frustum mode
 struct OrbxProjectArgs {
     int mode, nframes, maxNp;          // mode 0 motion model (Sophus SE3f * point), 1 Frame::isInFrustum

@@ -529,7 +529,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
             uint8_t *colInfo = lds + a.g.oColInfo;
             const int wCell = a.g.wCell, TWi = t.TWi;
             const float invWC = __builtin_amdgcn_rcpf((float)wCell);
-#pragma nounroll
+            // (at most two turns; unrolled / interleaved by eight the loop spilled two registers of the tile vectors that are in flight -
+            // and a spill store of a load's destination waits for the load)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int x = otid(); x < TWi; x += PF_NT) {
                 int cell = (int)(((float)x + 0.5f) * invWC), cx = x - cell * wCell;
                 int cw = min(wCell, TWi - cell * wCell);
@@ -675,7 +677,8 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
         const int cInt0 = t.cInt0, cInt1 = t.cInt1, nCells = t.nCells, THi = t.THi, rowOff = t.rowOff;
         const int s0 = t.s0, NS = t.NS;  // strips cover LDS columns [8s + 4, 8s + 12)
-        const float invNS = __builtin_amdgcn_rcpf((float)NS);
+        // (1 / NS is formed where it is used, from a copy of NS the optimiser cannot see through: hoisted out of the round loop it stayed
+        // live - and spilled - through both rounds)
         const int nItems = NS * THi;
         for (int round = 0; round < 2; ++round) {
             const int th = round == 0 ? iniTh : minTh;
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
             if (round == 1) {
                 // lane c looks at cell c (a scalar loop over the cells is unrolled by the compiler into a chain of wave-uniform
                 // conditions that all stay live - and spilled - through the rounds)
-                eMask = (unsigned)__ballot(lane < nCells && cnt[lane & (PF_MAX_GROUP_CELLS - 1)] == 0);
+                eMask = (unsigned)__ballot(lane < nCells && cnt[otid() & (PF_MAX_GROUP_CELLS - 1)] == 0);
                 if (minTh >= iniTh || !eMask) break;  // uniform
             }
             const uint32_t T4 = (uint32_t)th * 0x01010101u, C4 = (uint32_t)(255 - th) * 0x01010101u;
@@ -730,6 +733,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                 // dS strips (+ one row when the strip index wraps).  Dividing every item by NS through a float reciprocal cost two
                 // v_cvt, four v_mul_lo_u32 (~8 issue cycles each on gfx950) and a dozen adds per strip - a fifth of the pre-test's issue time.
                 int it = otid();
+                int nsO = NS;
+                asm volatile("" : "+s"(nsO));
+                const float invNS = __builtin_amdgcn_rcpf((float)nsO);
                 int r = (int)(((float)it + 0.5f) * invNS), sI = it - r * NS;
                 const int dR = (int)(((float)PF_NT + 0.5f) * invNS), dS = PF_NT - dR * NS;   // wave-uniform
                 const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * (s0 + sI);
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + a.g.candBase + (size_t)tileId * a.g.slotCap;
         // keypoints of the cells before cell c: a wave scan over the per-cell counts (lane = cell)
         int tot;
-        const int cellBase = wave_excl_scan(lane < nCells ? cnt[lane & (PF_MAX_GROUP_CELLS - 1)] : 0, tot);
+        const int cellBase = wave_excl_scan(lane < nCells ? cnt[otid() & (PF_MAX_GROUP_CELLS - 1)] : 0, tot);
         if (tid == 0) a.tileCount[(size_t)f * a.tilesPerFrame + a.g.tileBase + tileId] = tot;
         for (int c = wave; c < nCells; c += PF_NW) {
             const uint32_t *cbits = bits + (size_t)c * cellWords;

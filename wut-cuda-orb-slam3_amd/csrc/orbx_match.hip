@@ -3308,11 +3308,25 @@ struct KfwArgs {
     // in the current round of the fixed-point iteration (a point skips the keypoints an EARLIER point took) - NULL for Fuse / SearchBySim3
     const signed char *blocked; const int *owner;
     int levelHi;  // keypoint levels nPredictedLevel - 1 .. nPredictedLevel + levelHi (0; 1 for SearchByProjection(Frame, KeyFrame, ..))
+    // a BATCH of keyframes (orbx_search_keyframe_windows_frames / orbx_fuse_frames): blockIdx.y = keyframe; record strides between
+    // consecutive keyframes, the per-keyframe point counts on the device, and - Fuse - the acceptance bound and the per-keyframe counter
+    long long keyStride, gridStride, itemStride, ptStride;   // keypoints / descriptors (x 32) / u_right; cellStart; items; points / descriptors (x 32) / outputs
+    const int *npDev;
+    int fuseTh;            // >= 0: bestIdx[i] = -1 unless bestDist <= fuseTh (TH_LOW), nFused[keyframe] counts the rest
+    int *nFused;
 };
 
 __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
+    if (a.npDev) {   // keyframe blockIdx.y of a batch
+        const size_t f = blockIdx.y;
+        a.np = min(a.np, a.npDev[f]);
+        a.keys += f * a.keyStride; a.desc += f * a.keyStride * 32; if (a.uRight) a.uRight += f * a.keyStride;
+        a.cellStart += f * a.gridStride; a.items += f * a.itemStride;
+        a.pts += f * a.ptStride; a.ptDesc += f * a.ptStride * 32; a.bestIdx += f * a.ptStride; a.bestDist += f * a.ptStride;
+        if (a.nFused) a.nFused += f;
+    }
     if (i >= a.np) return;
     const KfwPoint P = a.pts[i];
     int outIdx = -1, outDist = INT_MAX;
@@ -3396,7 +3410,13 @@ __global__ __launch_bounds__(64) void k_kf_window_search(KfwArgs a)
             }
         }
     }
-    if (lane == 0) { a.bestIdx[i] = outIdx; a.bestDist[i] = outDist; }
+    if (lane == 0) {
+        if (a.fuseTh >= 0) {   // Fuse: bestDist <= TH_LOW (src/ORBmatcher2.cc:581, :716)
+            if (outIdx >= 0 && outDist <= a.fuseTh) atomicAdd(a.nFused, 1);
+            else outIdx = -1;
+        }
+        a.bestIdx[i] = outIdx; a.bestDist[i] = outDist;
+    }
 }
 
 hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
@@ -3410,7 +3430,24 @@ hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, cons
     a.keys = (const MtKp *)keys; a.desc = desc; a.uRight = uRight; a.invSigma2 = invSigma2; a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY; a.b.invW = (float)GRID_COLS / (maxX - minX); a.b.invH = (float)GRID_ROWS / (maxY - minY);
     a.pts = (const KfwPoint *)pts; a.ptDesc = ptDesc; a.np = np; a.chi2 = chi2; a.bestIdx = bestIdx; a.bestDist = bestDist;
+    a.keyStride = a.gridStride = a.itemStride = a.ptStride = 0; a.npDev = nullptr; a.fuseTh = -1; a.nFused = nullptr;
     hipLaunchKernelGGL(k_kf_window_search, dim3(np), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+// the same search for a batch of keyframes (blockIdx.y): see KfwArgs
+hipError_t orbxLaunchKeyframeWindowSearchFrames(hipStream_t st, const OrbxKfwFrames *b)
+{
+    if (b->nframes <= 0 || b->maxNp <= 0) return hipSuccess;
+    KfwArgs a;
+    a.blocked = nullptr; a.owner = nullptr; a.levelHi = 0;
+    a.keys = (const MtKp *)b->keys; a.desc = b->desc; a.uRight = b->uRight; a.invSigma2 = b->invSigma2; a.cellStart = b->cellStart; a.items = b->items;
+    a.b.minX = b->minX; a.b.minY = b->minY; a.b.invW = (float)GRID_COLS / (b->maxX - b->minX); a.b.invH = (float)GRID_ROWS / (b->maxY - b->minY);
+    a.pts = (const KfwPoint *)b->pts; a.ptDesc = b->ptDesc; a.np = b->maxNp; a.chi2 = b->chi2; a.bestIdx = b->bestIdx; a.bestDist = b->bestDist;
+    a.keyStride = b->keyStride; a.gridStride = b->gridStride; a.itemStride = b->itemStride; a.ptStride = b->maxNp; a.npDev = b->npDev;
+    a.fuseTh = b->fuseTh; a.nFused = b->nFused;
+    if (b->nFused) { const hipError_t e = hipMemsetAsync(b->nFused, 0, (size_t)b->nframes * sizeof(int), st); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(k_kf_window_search, dim3(b->maxNp, b->nframes), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
