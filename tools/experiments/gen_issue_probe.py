@@ -236,6 +236,24 @@ for sname in ("alignbyte", "min", "cmp", "lshl", "mul24", "cvt", "mul_lo", "lshl
             else:
                 lines.append(F(i))
         body(f"N{k}_{sname}", lines, note=f"runs of {k} full-rate instructions + one {sname} + s_nop 0")
+# ---- scalar instructions beside the vector stream: k_pyr_fast issues one scalar instruction per 2.7 vector instructions
+def with_salu(k, salu):
+    out = []
+    i = 0
+    while i < 96:
+        out += [F(i + t) for t in range(k)]
+        out += salu
+        i += k
+    return out
+body("V1_sadd", with_salu(1, ["s_add_u32 s22, s22, 1"]), note="1 full-rate vector instruction : 1 s_add_u32")
+body("V2_sadd", with_salu(2, ["s_add_u32 s22, s22, 1"]), note="2 : 1 s_add_u32")
+body("V3_sadd", with_salu(3, ["s_add_u32 s22, s22, 1"]), note="3 : 1 s_add_u32")
+body("V3_sadd2", with_salu(3, ["s_add_u32 s22, s22, 1", "s_and_b32 s23, s22, 7"]), note="3 : 2 scalar ALU")
+body("V3_exec", with_salu(3, ["s_and_saveexec_b64 s[24:25], vcc", "s_or_b64 exec, exec, s[24:25]"]), note="3 : s_and_saveexec_b64 + s_or_b64 exec (vcc = all lanes)")
+body("V3_branch", with_salu(3, ["s_cbranch_execz .Lloop_{name}"]), note="3 : 1 s_cbranch_execz, never taken")
+body("V6_exec_branch", with_salu(6, ["s_and_saveexec_b64 s[24:25], vcc", "s_cbranch_execz .Lloop_{name}", "s_or_b64 exec, exec, s[24:25]"]),
+     note="6 : saveexec + branch (not taken) + restore: a divergent if")
+body("V3_waitcnt", with_salu(3, ["s_waitcnt lgkmcnt(0)"]), note="3 : 1 s_waitcnt with nothing outstanding")
 body("pure_F", [F(i) for i in range(96)], note="96 x full-rate (v_and_b32_e32 / v_bitop3 alternating)")
 body("F7_salu", sum([[F(8 * j + t) for t in range(7)] + ["s_add_u32 s22, s22, 1"] for j in range(12)], []), note="7 full-rate + one s_add_u32 (84 vector instructions)")
 body("F7_nop", sum([[F(8 * j + t) for t in range(7)] + ["s_nop 0"] for j in range(12)], []), note="7 full-rate + s_nop 0")
@@ -253,7 +271,7 @@ ALLREGS = ", ".join(f'"v{i}"' for i in range(5, 48))
 
 
 def kernel(name, lines, nvalu):
-    lines = [l[2:].replace("{name}", name) if l.startswith("@@") else l for l in lines]
+    lines = [l[2:].replace("{name}", name) if l.startswith("@@") else l.replace("{name}", name) for l in lines]
     asm = "\n".join(f'        "{l}\\n"' for l in lines)
     init = "\n".join(f'        "v_add_u32_e32 v{i}, {hex((i * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF)}, %[tid]\\n"' for i in range(8, 48))
     fold = "\n".join(f'        "v_xor_b32_e32 v8, v{i}, v8\\n"' for i in range(9, 44))
@@ -272,6 +290,7 @@ __global__ __launch_bounds__(512) void k_{name}(unsigned long long *out, int ite
         "v_lshlrev_b32_e32 v6, 1, v7\\n"
         "v_lshlrev_b32_e32 v5, 2, v7\\n"
         "s_mov_b32 s21, 0x7f7f7f7f\\n"
+        "s_mov_b64 vcc, -1\\n"
         "s_mov_b32 s24, 0x0f0f3355\\n"
         "s_mov_b32 s25, 0x00ff5533\\n"
         "s_mov_b32 s20, %[iters]\\n"
@@ -335,7 +354,7 @@ int main(int argc, char **argv)
             const int W = cfg == 0 ? 8 : cfg == 1 ? 8 : cfg == 2 ? 4 : cfg == 3 ? 2 : cfg == 4 ? 1 : 16, T = cfg == 1 ? 512 : 256;
             if (cfg == 5) continue;
             const bool sweep = strstr(p.name, "and_e32") || strstr(p.name, "bitop3_distinct") || strstr(p.name, "ring_mix") || strstr(p.name, "alignbyte_distinct") || strstr(p.name, "lds_read");
-            const bool mixing = !strncmp(p.name, "pure_", 5) || !strncmp(p.name, "R_", 2) || (p.name[0] == 'N' && p.name[1] >= '0' && p.name[1] <= '9') || (p.name[0] == 'F' && p.name[1] >= '0' && p.name[1] <= '9');
+            const bool mixing = !strncmp(p.name, "pure_", 5) || !strncmp(p.name, "R_", 2) || (p.name[0] == 'V' && p.name[1] >= '0' && p.name[1] <= '9') || (p.name[0] == 'N' && p.name[1] >= '0' && p.name[1] <= '9') || (p.name[0] == 'F' && p.name[1] >= '0' && p.name[1] <= '9');
             if (mixing) { if (cfg != 1 && cfg != 3) continue; }   // the kernel's shape (8 waves per SIMD, 512-thread workgroups) and 2 waves per SIMD
             else if (cfg >= 1 && !sweep) continue;
             const int wavesPerBlock = T / 64, blocksPerCu = W * 4 / wavesPerBlock;
