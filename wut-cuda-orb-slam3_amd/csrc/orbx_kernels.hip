@@ -43,6 +43,29 @@ __device__ __forceinline__ bool xcd_decode(int nframes, int units, int &frame, i
     return frame < nframes;
 }
 static inline unsigned xcd_grid(int nframes, int units) { return (unsigned)((nframes + 7) / 8) * 8u * (unsigned)units; }
+// The same decode with the division by `per` = 8 * units as a multiply-high by a host-computed reciprocal (xcd_magic): the generic 32-bit
+// division is ~25 dependent scalar / vector instructions (v_rcp_iflag_f32 and two correction steps) in front of a workgroup's first load.
+// For per not a power of two: m = floor(2^(32 + l) / per) + 1, l = floor(log2 per): floor(b / per) = mulhi(b, m) >> l for every b < 2^31.
+struct XcdMagic { unsigned m; int l; unsigned per; };
+static inline XcdMagic xcd_magic(int units)
+{
+    XcdMagic x;
+    x.per = 8u * (unsigned)units;
+    int l = 0;
+    while ((2u << l) <= x.per) ++l;   // floor(log2 per)
+    x.l = l;
+    x.m = (x.per & (x.per - 1)) == 0 ? 0u : (unsigned)((((unsigned long long)1 << (32 + l)) / x.per) + 1ull);   // 0: power of two, shift only
+    return x;
+}
+__device__ __forceinline__ bool xcd_decode_magic(int nframes, unsigned m, int l, unsigned per, int &frame, int &unit)
+{
+    const unsigned b = blockIdx.x;
+    const unsigned chunk = m ? __umulhi(b, m) >> l : b >> l;
+    const unsigned rem = b - chunk * per;
+    frame = (int)(chunk * 8u + (rem & 7u));
+    unit = (int)(rem >> 3);
+    return frame < nframes;
+}
 
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {
@@ -366,6 +389,7 @@ struct PyrFastArgs {
     int nframes;
     const OrbxPfTile *tiles;  // [g.nTiles] host-built tile records of this level
     int laneAlloc;  // 1: queue slots by per-lane LDS atomics (ORBX_PF_LANE_ALLOC), 0: ballot prefix counts
+    unsigned xcdM; int xcdL; unsigned xcdPer;  // xcd_magic(g.nTiles): the workgroup -> (frame, tile) decode without a division
     int phases;  // debug/ablation mask (ORBX_PF_PHASES): 1 resize, 2 ring test+score, 4 NMS, 8 count+emit;
                  // bits 4..7 = stop point for instruction-count profiles (tools/pmc_phases.sh): return after 1 tile load,
                  // 2 LDS setup, 3 resize, 4 pre-test, 5 ring test, 6 score, 7 NMS (round 0)
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
     PF_STAMP(0);
     if constexpr (!ML) {
         KArgs &a = K();
-        if (!xcd_decode(a.nframes, a.g.nTiles, f, tileId)) return;
+        if (!xcd_decode_magic(a.nframes, a.xcdM, a.xcdL, a.xcdPer, f, tileId)) return;
     }
     auto T = [&]() -> TileK & { TileK *p = (TileK *)(unsigned long long)K().tiles + tileId; asm volatile("" : "+s"(p)); return *p; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1459,6 +1483,8 @@ static void fillPyrFastArgs(PyrFastArgs &a, int nframes, const OrbxLevelGeom &g,
     a.phases = 15;
     static const int laneAlloc = [] { const char *e = getenv("ORBX_PF_LANE_ALLOC"); return e ? atoi(e) : 1; }();  // (0: A/B and tests)
     a.laneAlloc = laneAlloc;
+    const XcdMagic xm = xcd_magic(g.nTiles);
+    a.xcdM = xm.m; a.xcdL = xm.l; a.xcdPer = xm.per;
 }
 
 size_t orbxPyrFastArgsBytes() { return sizeof(PyrFastArgs); }
