@@ -1783,6 +1783,228 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     SI_STAMP(6, __builtin_amdgcn_s_memtime());
 }
 
+// ---- SearchForInitialization of ONE pair as fixed-point rounds over ALL octave-0 keypoints of F1 (round 4) ------------------------------
+// The walk of k_search_init_lds is a chain of ~136 dependent steps on one wave (0.2 of the 0.38 ms a single call takes).  What keypoint t
+// sees of the earlier ones is only vMatchedDistance: the distance of the LAST earlier keypoint that matched a candidate - and since a
+// keypoint can only take a partner at a distance BELOW its vMatchedDistance (`vMatchedDistance[i2] <= dist` skips, :700), that is the
+// minimum over the earlier acceptors of that partner.  So every keypoint decides at once against the decisions of the round before -
+//   md(c, t) = min { dist(t') : t' < t accepted partner c }   (per-partner lists of acceptors, rebuilt every round),
+//   first / second entry of t's short list (k_si_topk: ascending distance, ties in visiting order) with md(c, t) > dist,
+// and the rounds repeat until no decision changes: the decision of t depends on decisions of t' < t only, so after k rounds the first k
+// keypoints are final - the fixed point IS the sequential result; in practice the chains are a handful of keypoints long.  A keypoint
+// whose 8-entry list does not decide (fewer than two live entries of an incomplete list and the ratio test could still fail) scans all
+// of F2's octave-0 keypoints for that round, a wave per such keypoint (same keys as k_si_topk, so the same order).  No grid, no
+// descriptor copy: the setup of the single-wave kernel (0.15 ms) goes with the walk.  One workgroup of 1024 threads, up to 2048 keypoints.
+#define SIR_NT 1024
+#define SIR_KPT 2
+#define SIR_CAP1 (SIR_NT * SIR_KPT)
+__global__ __launch_bounds__(SIR_NT) void k_search_init_rounds(SearchInitArgs a)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
+    __shared__ int head[SI_CAP2];          // per F2 subset keypoint: first acceptor of its list (keypoint position t), -1 none
+    __shared__ int lastAcc[SI_CAP2];       // the last (largest t) acceptor: the keypoint that holds the partner in the end (vnMatches21)
+    __shared__ int nxt[SIR_CAP1];
+    __shared__ uint16_t decC[SIR_CAP1];    // decision of t: partner (subset index), 0xFFFF none
+    __shared__ uint8_t decD[SIR_CAP1];     // its distance (<= TH_LOW)
+    __shared__ uint16_t scanC[SIR_CAP1];   // result of t's scan of all of F2 in this round
+    __shared__ uint8_t scanD[SIR_CAP1];
+    __shared__ signed char binL[SIR_CAP1];
+    __shared__ uint16_t undecided[SIR_CAP1];
+    __shared__ int hist[32];
+    __shared__ int nUndecided, changed, cntM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nL1 = a.nL1G[0], n0 = a.n0G[0];
+    for (int i = tid; i < a.n1; i += SIR_NT) a.m12[i] = -1;
+    if (a.initPrev)
+        for (int i = tid; i < a.n1; i += SIR_NT) { a.prev[2 * i] = a.k1[i].x; a.prev[2 * i + 1] = a.k1[i].y; }
+    if (n0 > SI_CAP2 || nL1 > SIR_CAP1) {  // (the host checks before it takes this kernel; a capacity error like the single-wave kernel's)
+        if (tid == 0) *a.nmatches = -1;
+        return;
+    }
+    // this thread's keypoints t = tid + s * SIR_NT and their short lists
+    uint32_t keys[SIR_KPT][SI_TOPK];
+#pragma unroll
+    for (int s = 0; s < SIR_KPT; ++s) {
+        const int t = tid + s * SIR_NT;
+#pragma unroll
+        for (int e = 0; e < SI_TOPK; ++e) keys[s][e] = t < nL1 ? a.top[(size_t)t * SI_TOPK + e] : SI_KEY_NONE;
+        decC[t] = 0xFFFF; decD[t] = 0; binL[t] = -1;
+    }
+    if (tid < 32) hist[tid] = 0;
+    if (tid == 0) { changed = 0; cntM = 0; }
+    const float r = (float)a.window;
+    const int topUse = min(max(a.topUse, 1), SI_TOPK);
+    // vMatchedDistance of partner c as keypoint t sees it under the decisions of the last round
+    auto seen = [&](int c, int t) {
+        int md = 0x7FFFFFFF;
+        for (int j = head[c]; j >= 0; j = nxt[j])
+            if (j < t) md = min(md, (int)decD[j]);
+        return md;
+    };
+    for (int round = 0; round <= nL1; ++round) {
+        for (int c = tid; c < n0; c += SIR_NT) head[c] = -1;
+        if (tid == 0) nUndecided = 0;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SIR_KPT; ++s) {
+            const int t = tid + s * SIR_NT;
+            if (t < nL1 && decC[t] != 0xFFFF) nxt[t] = atomicExch(&head[decC[t]], t);
+        }
+        __syncthreads();
+        int newC[SIR_KPT], newD[SIR_KPT];
+#pragma unroll
+        for (int s = 0; s < SIR_KPT; ++s) {
+            const int t = tid + s * SIR_NT;
+            newC[s] = 0xFFFF; newD[s] = 0;
+            if (t >= nL1) continue;
+            // first and second entry of the list that are not skipped (reference :690-712)
+            int bD = 0, bC = -1, second = 0x7FFFFFFF, nLive = 0;
+            uint32_t lastKey = SI_KEY_NONE;
+#pragma unroll
+            for (int e = 0; e < SI_TOPK; ++e) {
+                const uint32_t key = keys[s][e];
+                if (e == topUse - 1) lastKey = key;        // (ORBX_SI_TOPK < 8, tests: the list ends here - most keypoints then take the scan)
+                if (e >= topUse || key == SI_KEY_NONE || nLive >= 2) continue;
+                const int c = (int)(key & (SI_CAP2 - 1)), d = (int)(key >> 23);
+                if (seen(c, t) <= d) continue;
+                if (nLive == 0) { bD = d; bC = c; } else second = d;
+                ++nLive;
+            }
+            const bool complete = lastKey == SI_KEY_NONE;
+            const int lastD = (int)(lastKey >> 23);
+            int decided = 0;  // 1 no match, 2 test (best, second), 0 the scan of all of F2
+            if (nLive == 0) decided = complete ? 1 : 0;
+            else if (bD > TH_LOW) decided = 1;
+            else if (nLive >= 2) decided = 2;
+            else if (complete) decided = 2;
+            else if (a.nnratio > 0.0f && (float)bD < __fmul_rn((float)lastD, a.nnratio)) { second = lastD; decided = 2; }
+            if (decided == 2 && (float)bD < __fmul_rn((float)second, a.nnratio)) { newC[s] = bC; newD[s] = bD; }
+            if (decided == 0) { undecided[atomicAdd(&nUndecided, 1)] = (uint16_t)t; newC[s] = 0x10000; }
+        }
+        __syncthreads();
+        // the undecided keypoints: every octave-0 keypoint of F2 in the window, a wave per keypoint (keys as in k_si_topk)
+        const int nU = nUndecided;
+        for (int u = wave; u < nU; u += SIR_NT / 64) {
+            const int t = undecided[u];
+            const int i1 = a.list1G[t];
+            const float x = a.prev[2 * i1], y = a.prev[2 * i1 + 1];   // (vbPrevMatched is only updated behind the rounds)
+            const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+            const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+            const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+            const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+            uint32_t best = SI_KEY_NONE;
+            int sec = 0x7FFFFFFF;
+            if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
+                uint32_t q[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
+                for (int c2 = lane; c2 < n0; c2 += 64) {
+                    const int i2 = a.origG[c2];
+                    const float kx = a.k2[i2].x, ky = a.k2[i2].y;
+                    const int px = (int)roundf(__fmul_rn(__fsub_rn(kx, a.b.minX), a.b.invW));  // Frame::PosInGrid
+                    const int py = (int)roundf(__fmul_rn(__fsub_rn(ky, a.b.minY), a.b.invH));
+                    if (!(px >= cx0 && px <= cx1 && py >= cy0 && py <= cy1 && fabsf(__fsub_rn(kx, x)) < r && fabsf(__fsub_rn(ky, y)) < r)) continue;
+                    const uint32_t *tt = (const uint32_t *)(a.d2 + (size_t)i2 * 32);
+                    int dist = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ tt[w]);
+                    if (seen(c2, t) <= dist) continue;
+                    const uint32_t key = ((uint32_t)dist << 23) | ((uint32_t)px << 17) | ((uint32_t)py << 11) | (uint32_t)c2;
+                    if (key < best) { if (best != SI_KEY_NONE) sec = min(sec, (int)(best >> 23)); best = key; }
+                    else sec = min(sec, dist);
+                }
+            }
+            const uint32_t gBest = mt_wave_min_u32(best);
+            // second smallest distance over the wave: the lane that holds the best contributes its own second, the others their best
+            int gSec = best == SI_KEY_NONE ? 0x7FFFFFFF : (best == gBest ? sec : (int)(best >> 23));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gSec = min(gSec, __shfl_xor(gSec, o));
+            if (lane == 0) {
+                int c = 0xFFFF, d = 0;
+                if (gBest != SI_KEY_NONE) {
+                    const int bD = (int)(gBest >> 23);
+                    if (bD <= TH_LOW && (float)bD < __fmul_rn((float)gSec, a.nnratio)) { c = (int)(gBest & (SI_CAP2 - 1)); d = bD; }
+                }
+                scanC[t] = (uint16_t)c; scanD[t] = (uint8_t)d;
+            }
+        }
+        __syncthreads();   // every list walk of this round is done: the decisions may change
+        bool ch = false;
+#pragma unroll
+        for (int s = 0; s < SIR_KPT; ++s) {
+            const int t = tid + s * SIR_NT;
+            if (t >= nL1) continue;
+            if (newC[s] == 0x10000) { newC[s] = scanC[t]; newD[s] = scanD[t]; }
+            if (decC[t] != (uint16_t)newC[s] || decD[t] != (uint8_t)newD[s]) ch = true;
+            decC[t] = (uint16_t)newC[s]; decD[t] = (uint8_t)newD[s];
+        }
+        if (ch) changed = 1;
+        __syncthreads();
+        const int any = changed;
+        __syncthreads();
+        if (!any) break;
+        if (tid == 0) changed = 0;   // (read again only behind the next round's barriers)
+    }
+    // ---- behind the rounds: who holds a partner in the end, rotation histogram, write-out (as k_search_init_lds) ------------------------
+    for (int c = tid; c < n0; c += SIR_NT) lastAcc[c] = -1;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SIR_KPT; ++s) {
+        const int t = tid + s * SIR_NT;
+        if (t < nL1 && decC[t] != 0xFFFF) atomicMax(&lastAcc[decC[t]], t);
+    }
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    bool kept[SIR_KPT];
+#pragma unroll
+    for (int s = 0; s < SIR_KPT; ++s) {
+        const int t = tid + s * SIR_NT;
+        kept[s] = false;
+        if (t >= nL1 || decC[t] == 0xFFFF) continue;
+        const int c2 = decC[t];
+        if (a.checkOri) {   // every recorded match votes (:736-746), also one that a later keypoint took over
+            float rot = __fsub_rn(a.topAng[t], a.k2[a.origG[c2]].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == HISTO_LENGTH) bin = 0;
+            binL[t] = (signed char)bin;
+            atomicAdd(&hist[bin], 1);
+        }
+        kept[s] = lastAcc[c2] == t;   // (:725-729: a later keypoint of F1 that takes the partner clears the earlier match)
+    }
+    __syncthreads();
+    if (a.checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) {  // ORBmatcher::ComputeThreeMaxima (every thread, uniform)
+            const int sz = hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+#pragma unroll
+        for (int s = 0; s < SIR_KPT; ++s) {
+            const int t = tid + s * SIR_NT;
+            if (t < nL1 && kept[s]) { const int b = binL[t]; if (b != ind1 && b != ind2 && b != ind3) kept[s] = false; }
+        }
+    }
+    int mine = 0;
+#pragma unroll
+    for (int s = 0; s < SIR_KPT; ++s) {
+        const int t = tid + s * SIR_NT;
+        if (t < nL1 && kept[s]) {
+            const int i1 = a.list1G[t], i2 = a.origG[decC[t]];
+            a.m12[i1] = i2; a.prev[2 * i1] = a.k2[i2].x; a.prev[2 * i1 + 1] = a.k2[i2].y;   // (:759-762)
+            ++mine;
+        }
+    }
+    // nmatches as the reference counts it (++ per accepted match, -- per stolen or rotation-filtered one) = entries still >= 0
+    if (mine) atomicAdd(&cntM, mine);
+    __syncthreads();
+    if (tid == 0) *a.nmatches = cntM;
+}
+
 // true when orbxLaunchSearchInit takes the LDS-resident kernel (which builds its own grid: no orbxLaunchGridBuild needed)
 bool orbxSearchInitInLds(int n1, int n2, int level0of2);
 
@@ -1907,7 +2129,13 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     const int l1 = level0of1 >= 0 ? std::min(level0of1, n1) : n1;
     a.ldsN1 = l1;
     const size_t lds = searchInitLdsBytes(l1);
-    if (orbxSearchInitInLds(l1, n2, level0of2) && n1 < 65536) {
+    // ORBX_SI_ROUNDS=0: the single-wave walk (k_search_init_lds) instead of the fixed-point rounds over all keypoints (A/B, tests)
+    static const int rounds = [] { const char *e = getenv("ORBX_SI_ROUNDS"); return e ? atoi(e) : 1; }();
+    if (rounds && work && searchInitTopUse() >= 1 && level0of2 >= 0 && level0of2 <= SI_CAP2 && level0of1 >= 0 && l1 <= SIR_CAP1 && n1 < 65536 &&
+        n2 < 65536) {
+        searchInitPrepass(st, a, 1, n1, work);
+        hipLaunchKernelGGL(k_search_init_rounds, dim3(1), dim3(SIR_NT), 0, st, a);
+    } else if (orbxSearchInitInLds(l1, n2, level0of2) && n1 < 65536) {
         const hipError_t e = searchInitLdsAttr(lds);
         if (e != hipSuccess) return e;
         searchInitPrepass(st, a, 1, n1, work);
