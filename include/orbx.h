@@ -735,6 +735,20 @@ int orbx_vocabulary_transform_frame(orbx_vocabulary *v, orbx_extractor *ex, int 
 int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extractor *ex, int nframes, int levelsup, int32_t *bow_word, double *bow_value,
                                     int32_t *n_bow, int32_t *fv_node, int32_t *fv_start, int32_t *fv_feature, int32_t *n_fv);
 
+/* The same search for ONE keyframe against a list of neighbours, device-resident (round 4): LocalMapping::CreateNewMapPoints' matcher call
+ * (reference src/LocalMapping.cc:466, inside the loop over vpNeighKFs).  Keyframes = frames of `ex`'s last batch (single camera, NLeft == -1);
+ * their mvKeysUn come from Frame::UndistortKeyPoints on the device (k4 / dist / knew4 as in orbx_undistort_keypoints), their descriptors lie
+ * where the extractor left them, and their FeatureVectors are the DEVICE results of the last orbx_vocabulary_transform_batch(voc, ex, ..)
+ * call - which must have covered these frames.  ref_frame = pKF1, neighbours[k] = pKF2 of pair k, geometry[k] (host) its two-view geometry
+ * as for the single call; d_has_map_point [nframes][cap] bytes (GetMapPoint(i) != NULL), d_u_right [nframes][cap] or NULL, cap =
+ * orbx_max_keypoints(ex).  Outputs, device: d_matches12 [nneigh][cap] (entries >= the keyframe's keypoint count stay -1), d_nmatches
+ * [nneigh].  Two launches per neighbour, asynchronous on the matcher's stream; nothing of the keyframes crosses the link. */
+int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabulary *voc, orbx_extractor *ex, int ref_frame, const int32_t *neighbours,
+                                         int nneigh, const float *k4, const float *dist, int ndist, const float *knew4,
+                                         const orbx_triangulation_geometry *geometry, const uint8_t *d_has_map_point, const float *d_u_right,
+                                         int only_stereo, int coarse, int check_orientation, void *d_matches12, void *d_nmatches);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,3 +180,69 @@ def test_kannala_brandt_pairs_match_oracle(pkg, orc, as_rig):
         assert got[0] == ref[0] and np.array_equal(got[2], ref[2]) and np.array_equal(got[1], ref[1])
     assert got[0] > 20
     voc.close(); m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo", [False, True])
+def test_search_for_triangulation_over_the_neighbours_of_a_keyframe(pkg, orc, stereo):
+    """orbx_search_for_triangulation_frames: one keyframe against K neighbours with keypoints, descriptors and FeatureVectors where the
+    extractor and the vocabulary left them on the device (LocalMapping::CreateNewMapPoints, reference src/LocalMapping.cc:466) - per
+    neighbour the same matches as the single-pair oracle on host copies.  Keyframes: shifted views of one synthetic frame (so that the views
+    share words), a small vocabulary around the reference view's descriptors, pinhole epipolar geometry of a pure x / y translation."""
+    import torch
+    from golden_scenarios import vocabulary
+    P = 5
+    shifts = [(0, 0), (9, -6), (-7, 4), (14, 3), (3, 11)]
+    base = pkg.synth_frame(77, 640, 480)
+    rng = np.random.default_rng(21)
+    imgs = np.stack([np.clip(np.roll(np.roll(base, dy, 0), dx, 1).astype(np.int16) + rng.integers(-3, 4, base.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+                     for dx, dy in shifts])
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=P)
+    d_imgs = torch.from_numpy(imgs).to("cuda:0")
+    ex.extract_batch_device(d_imgs.data_ptr(), P, 640, 480, 640, 640 * 480, (0, 0)); ex.sync()
+    n, _, kk, dd = ex.download_outputs(P)
+    parent, leaf, vdesc, vweight = vocabulary(dd[0, : n[0]])
+    voc = pkg.ORBVocabulary(8, 3, 0, 0, parent=parent, is_leaf=leaf, desc=vdesc, weight=vweight)
+    fvs = voc.transform_batch(ex, P, levelsup=2)
+    sf = ex.GetScaleFactors().copy(); sigma2 = ex.GetScaleSigmaSquares().copy()
+    cap = ex.capacity
+    has = np.zeros((P, cap), np.uint8); ur = np.full((P, cap), -1, np.float32)
+    for f in range(P):
+        has[f, : n[f]] = rng.random(n[f]) < 0.3
+        if stereo:
+            ur[f, : n[f]] = np.where(rng.random(n[f]) < 0.6, kk[f, : n[f]]["x"] - rng.uniform(1, 30, n[f]), -1)
+    k4 = np.float32([458.654, 457.296, 367.215, 248.375])
+    K = np.array([[k4[0], 0, k4[2]], [0, k4[1], k4[3]], [0, 0, 1]], np.float64)
+    neighbours, geoms = [], []
+    for f in range(1, P):
+        dx, dy = shifts[f]
+        # views related by a translation parallel to the image plane: t12 ~ (dx, dy, 0); F12 = K^-T [t]x K^-1; the epipole lies at infinity:
+        # far outside the image, as for a sideways motion
+        t = np.array([dx, dy, 0.0]) / np.hypot(dx, dy)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Kinv = np.linalg.inv(K)
+        F12 = (Kinv.T @ tx @ Kinv).astype(np.float32)
+        geoms.append(pkg.triangulation_geometry((1e6 * t[0], 1e6 * t[1]), F12))
+        neighbours.append(f)
+    m = pkg.ORBmatcher(8192, 8192)
+    for only_stereo, coarse in ((False, False), (False, True)) + (((True, False),) if stereo else ()):
+        nm, m12 = m.SearchForTriangulationFrames(voc, ex, 0, neighbours, k4, np.zeros(0, np.float32), geoms, has, u_right=ur if stereo else None,
+                                                 bOnlyStereo=only_stereo, bCoarse=coarse)
+        total = 0
+        for k, f in enumerate(neighbours):
+            a = pkg.keyframe_view(kk[0, : n[0]], dd[0, : n[0]], has[0, : n[0]], fvs[0], sf, sigma2, u_right=ur[0, : n[0]] if stereo else None)
+            b = pkg.keyframe_view(kk[f, : n[f]], dd[f, : n[f]], has[f, : n[f]], fvs[f], sf, sigma2, u_right=ur[f, : n[f]] if stereo else None)
+            rn, _, rm = orc.search_for_triangulation(a, b, geoms[k], only_stereo, coarse, True)
+            assert nm[k] == rn and np.array_equal(m12[k, : n[0]], rm), (only_stereo, coarse, f)
+            assert (m12[k, n[0]:] == -1).all()
+            total += rn
+        if not only_stereo:
+            assert total > 40
+    # a neighbour list that repeats a keyframe and includes the reference itself; and the guard against a stale transform
+    nm, m12 = m.SearchForTriangulationFrames(voc, ex, 2, [2, 1, 1], k4, np.zeros(0, np.float32), [geoms[0]] * 3, has)
+    assert nm[1] == nm[2] and np.array_equal(m12[1], m12[2])
+    ex2 = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=P)
+    ex2.extract_batch_device(d_imgs.data_ptr(), P, 640, 480, 640, 640 * 480, (0, 0)); ex2.sync()
+    with pytest.raises(pkg.OrbxError, match="transform_batch"):
+        m.SearchForTriangulationFrames(voc, ex2, 0, [1], k4, np.zeros(0, np.float32), geoms[:1], has)
+    m.close(); voc.close(); ex.close(); ex2.close()

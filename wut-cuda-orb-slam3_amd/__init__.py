@@ -100,6 +100,7 @@ ABI_SYMBOLS = [
     "orbx_project_points_frames",
     "orbx_search_keyframe_windows_frames",
     "orbx_fuse_frames",
+    "orbx_search_for_triangulation_frames",
     "orbx_vocabulary_create",
     "orbx_vocabulary_load_text",
     "orbx_vocabulary_destroy",
@@ -232,6 +233,8 @@ def load_library() -> ctypes.CDLL:
     for _name in ("orbx_search_keyframe_windows_frames", "orbx_fuse_frames"):
         getattr(lib, _name).argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_search_for_triangulation_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                         c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_project_last_frame_points.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_int, c_void_p]
     lib.orbx_project_in_frustum.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_float, c_float, c_float, c_int,
                                             c_int, c_float, c_void_p, c_int, c_void_p]
@@ -1033,6 +1036,32 @@ class ORBmatcher:
         if n < 0:
             _check(n, "orbx_search_for_triangulation")
         return n, pairs[:n].copy(), matches
+
+    def SearchForTriangulationFrames(self, voc: "ORBVocabulary", ex: "ORBextractor", ref_frame: int, neighbours, k4, dist, geometries,
+                                     has_map_point, u_right=None, bOnlyStereo: bool = False, bCoarse: bool = False,
+                                     checkOrientation: bool = True):
+        """ORBmatcher::SearchForTriangulation of keyframe `ref_frame` against each of `neighbours` (frames of the extractor's last batch),
+        device-resident: the FeatureVectors are the device results of the last voc.transform_batch(ex, ..) (orbx_search_for_triangulation_frames).
+        geometries: one triangulation_geometry(..) per neighbour; has_map_point [P, cap] uint8; u_right [P, cap] or None.
+        Returns (nmatches [K], matches12 [K, cap])."""
+        import torch
+        dev = ex.device
+        cap = ex.capacity
+        nb = np.ascontiguousarray(neighbours, np.int32)
+        K = len(nb)
+        garr = (TriangulationGeometryC * max(K, 1))(*geometries)
+        dv = f"cuda:{dev}"
+        d_h = torch.from_numpy(np.ascontiguousarray(has_map_point, np.uint8)).to(dv)
+        d_ur = torch.from_numpy(np.ascontiguousarray(u_right, np.float32)).to(dv) if u_right is not None else None
+        m12 = self._dev_out((max(K, 1), cap), torch.int32, dev, -1); nm = self._dev_out((max(K, 1),), torch.int32, dev, 0)
+        k4 = np.ascontiguousarray(k4, np.float32); dist = np.ascontiguousarray(dist, np.float32).ravel()
+        self._launch_fence(d_h, d_ur, m12, nm)
+        _check(self._lib.orbx_search_for_triangulation_frames(self._h, voc._h, ex._h, int(ref_frame), nb.ctypes.data, K, k4.ctypes.data,
+                                                              dist.ctypes.data if len(dist) else None, len(dist), None, ctypes.byref(garr),
+                                                              c_void_p(d_h.data_ptr()), c_void_p(d_ur.data_ptr()) if d_ur is not None else None,
+                                                              int(bool(bOnlyStereo)), int(bool(bCoarse)), int(bool(checkOrientation)),
+                                                              c_void_p(m12.data_ptr()), c_void_p(nm.data_ptr())), "orbx_search_for_triangulation_frames")
+        return self._download(nm)[:K], self._download(m12)[:K]
 
     @staticmethod
     def _camera(k4, dist, knew4):

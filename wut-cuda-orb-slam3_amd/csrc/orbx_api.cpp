@@ -3508,6 +3508,10 @@ struct orbx_vocabulary {
     DevBuf<int> d_work;  // featWord, featNode, bowWord, fvNode, fvStart, fvFeature, counts
     DevBuf<int> d_batchInt;       // the same per frame of a batch (orbx_vocabulary_transform_batch)
     DevBuf<double> d_batchDbl;
+    // the last batch transform's FeatureVectors stay on the device for the keyframe-side batch searches (orbx_search_for_triangulation_frames)
+    const orbx_extractor *batchEx = nullptr; int batchFrames = 0, batchCap = 0;
+    const int *batchFvNode = nullptr, *batchFvStart = nullptr, *batchFvFeature = nullptr;
+    std::vector<int> batchNFv;
     HostXfer xf;                  // packed transfers of the single-frame transform
 };
 
@@ -3736,5 +3740,79 @@ extern "C" int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extracto
     HIP_TRY(hipMemcpyAsync(fv_start, fvStart, (F + nframes) * sizeof(int), hipMemcpyDeviceToHost, v->stream));
     HIP_TRY(hipStreamSynchronize(v->stream));
     for (int f = 0; f < nframes; ++f) { n_bow[f] = cnt[2 * (size_t)f]; n_fv[f] = cnt[2 * (size_t)f + 1]; }
+    v->batchEx = ex; v->batchFrames = nframes; v->batchCap = cap;
+    v->batchFvNode = fvNode; v->batchFvStart = fvStart; v->batchFvFeature = fvFeature;
+    v->batchNFv.assign(n_fv, n_fv + nframes);
     return ORBX_OK;
+}
+
+// int ORBmatcher::SearchForTriangulation(pKF1, pKF2, ..) for ONE keyframe against a list of neighbours, everything where the extractor and the
+// vocabulary left it on the device (LocalMapping::CreateNewMapPoints, reference src/LocalMapping.cc:466 inside the loop over vpNeighKFs):
+// keyframes = frames of `ex`'s last batch, FeatureVectors = the device results of the last orbx_vocabulary_transform_batch(voc, ex, ..).
+// One k_sft_match + finish per neighbour, all asynchronous on the matcher's stream.
+extern "C" int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabulary *voc, orbx_extractor *ex, int ref_frame, const int32_t *neighbours,
+                                                    int nneigh, const float *k4, const float *dist, int ndist, const float *knew4,
+                                                    const orbx_triangulation_geometry *geometry, const uint8_t *d_has_map_point,
+                                                    const float *d_u_right, int only_stereo, int coarse, int check_orientation,
+                                                    void *d_matches12, void *d_nmatches)
+{
+    ORBX_API_ENTRY;
+    const char *fn = "orbx_search_for_triangulation_frames";
+    if (!m || !voc || !ex || nneigh < 0 || (nneigh > 0 && (!neighbours || !geometry || !d_has_map_point || !d_matches12 || !d_nmatches)))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: null argument", fn);
+    if (ex->prm.device != m->device || voc->device != m->device) return setError(ORBX_ERR_INVALID_ARG, "%s: matcher, vocabulary and extractor must live on the same device", fn);
+    if (voc->batchEx != ex || voc->batchFrames <= 0 || voc->batchCap != ex->maxKeypoints)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: call orbx_vocabulary_transform_batch(voc, ex, ..) on this batch first (its FeatureVectors are read on the device)", fn);
+    const int F = voc->batchFrames, cap = ex->maxKeypoints, nlev = ex->prm.nlevels;
+    if (F > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "%s: the extractor's batch changed since the transform", fn);
+    if (ref_frame < 0 || ref_frame >= F) return setError(ORBX_ERR_INVALID_ARG, "%s: reference keyframe %d of %d", fn, ref_frame, F);
+    for (int k = 0; k < nneigh; ++k) {
+        if (neighbours[k] < 0 || neighbours[k] >= F) return setError(ORBX_ERR_INVALID_ARG, "%s: neighbour %d is keyframe %d of %d", fn, k, neighbours[k], F);
+        if (geometry[k].model != 0 && geometry[k].model != 1) return setError(ORBX_ERR_INVALID_ARG, "%s: model must be 0 (pinhole) or 1 (KannalaBrandt8)", fn);
+        if (geometry[k].rig) return setError(ORBX_ERR_INVALID_ARG, "%s: single-camera keyframes only (NLeft == -1)", fn);
+    }
+    int rc = checkCamera(k4, dist, ndist, knew4 ? knew4 : k4, fn);
+    if (rc != ORBX_OK) return rc;
+    if (nneigh == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t FF = (size_t)F, K = (size_t)nneigh;
+    if ((rc = m->d_bKps.ensure(FF * cap)) != ORBX_OK) return rc;
+    if ((rc = m->d_work.ensure(K * (size_t)cap + 32 * K + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_prev.ensure(3 * ORBX_MAX_LEVELS)) != ORBX_OK) return rc;
+    orbx_keypoint *kun = m->d_bKps.p;
+    int *binOf = m->d_work.p, *result = binOf + K * cap;
+    float *scale = m->d_prev.p, *sigma = scale + ORBX_MAX_LEVELS;
+    hipStream_t st = m->stream;
+    if ((rc = orderAfterExtractors(m, ex, ex)) != ORBX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(voc->stream));   // (the transform returned synchronised; a later one on the same vocabulary would have changed batchEx)
+    HIP_TRY(hipMemcpyAsync(scale, ex->scale.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sigma, ex->sigma2.data(), (size_t)nlev * sizeof(float), hipMemcpyHostToDevice, st));
+    if (ndist == 0 || dist[0] == 0.0)
+        HIP_TRY(hipMemcpyAsync(kun, ex->d_kps.p, FF * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToDevice, st));
+    else
+        HIP_TRY(orbxLaunchUndistort(st, ex->d_kps.p, kun, cap, k4, dist, ndist, knew4 ? knew4 : k4, F, cap, cap, ex->d_n.p));
+    for (int k = 0; k < nneigh; ++k) {
+        const int f1 = ref_frame, f2 = neighbours[k];
+        const orbx_triangulation_geometry *g = geometry + k;
+        OrbxSftHost h;
+        memset(&h, 0, sizeof h);
+        h.node1 = voc->batchFvNode + (size_t)f1 * cap; h.start1 = voc->batchFvStart + (size_t)f1 * (cap + 1); h.feat1 = voc->batchFvFeature + (size_t)f1 * cap;
+        h.nfv1 = voc->batchNFv[f1];
+        h.node2 = voc->batchFvNode + (size_t)f2 * cap; h.start2 = voc->batchFvStart + (size_t)f2 * (cap + 1); h.feat2 = voc->batchFvFeature + (size_t)f2 * cap;
+        h.nfv2 = voc->batchNFv[f2];
+        h.keys1 = kun + (size_t)f1 * cap; h.desc1 = ex->d_desc.p + (size_t)f1 * cap * 32; h.hasMp1 = (const signed char *)d_has_map_point + (size_t)f1 * cap;
+        h.keys2 = kun + (size_t)f2 * cap; h.desc2 = ex->d_desc.p + (size_t)f2 * cap * 32; h.hasMp2 = (const signed char *)d_has_map_point + (size_t)f2 * cap;
+        h.uRight1 = d_u_right ? d_u_right + (size_t)f1 * cap : nullptr; h.uRight2 = d_u_right ? d_u_right + (size_t)f2 * cap : nullptr;
+        h.nLeft1 = -1; h.nLeft2 = -1; h.n1 = cap;
+        h.scale2 = scale; h.sigma1 = sigma; h.sigma2 = sigma;
+        memcpy(h.ep, g->ep, sizeof h.ep); memcpy(h.F, g->F12, sizeof h.F);
+        h.model = g->model; h.rig = 0; h.onlyStereo = only_stereo != 0; h.coarse = coarse != 0; h.checkOri = check_orientation != 0;
+        memcpy(h.camL, g->cam_left, sizeof h.camL); memcpy(h.camR, g->cam_right, sizeof h.camR); h.precision = g->precision;
+        memcpy(h.R, g->R, sizeof h.R); memcpy(h.t, g->t, sizeof h.t);
+        h.matches = (int *)d_matches12 + (size_t)k * cap; h.binOf = binOf + (size_t)k * cap; h.result = result + 32 * (size_t)k;
+        h.maxPerNode1 = 8;   // (the per-node feature counts are on the device: a fixed second grid dimension, the kernel strides over a node's features)
+        HIP_TRY(orbxLaunchSearchForTriangulation(st, h));
+    }
+    HIP_TRY(hipMemcpy2DAsync(d_nmatches, sizeof(int), result, 32 * sizeof(int), sizeof(int), K, hipMemcpyDeviceToDevice, st));
+    return orderExtractorsAfter(m, ex, ex);
 }
