@@ -138,6 +138,11 @@ int orbx_extract_batch_sharded(orbx_extractor *const *handles, int nhandles, int
                                ptrdiff_t stride, ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc,
                                int capacity, int32_t *n_out, int32_t *mono_out);
 
+/* The ORBX_* environment switches the library reads (A / B measurements and tests; none is needed - DESIGN.md appendix).  orbx_create /
+ * orbx_matcher_create refuse an ORBX_* variable that is not one of them (ORBX_ERR_INVALID_ARG): a mistyped switch must not silently run the
+ * default.  Writes up to `capacity` names, returns their number. */
+int orbx_known_switches(const char **names, int capacity);
+
 /* Page-locked host memory for frames and result arrays.  orbx_extract_batch works from any host memory; frames in page-locked memory
  * cross the link asynchronously without a helper thread, and result arrays in page-locked memory (with capacity == orbx_max_keypoints)
  * are written by the device directly.  In that direct mode the device copies FULL-CAPACITY rows: the rows of frame f beyond n_out[f]

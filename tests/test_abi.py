@@ -83,3 +83,40 @@ def test_inline_hamming_in_header_compiles_and_matches(tmp_path, orc):
     a = np.array([(i * 7 + 1) & 255 for i in range(32)], np.uint8)
     b = np.array([(255 - i * 3) & 255 for i in range(32)], np.uint8)
     assert got == orc.hamming256(a, b)
+
+
+def test_known_switch_list_matches_the_sources(pkg):
+    """Every getenv("ORBX_..") of the native sources is in the library's list of known switches (orbx_known_switches) and nothing else is -
+    apart from the three names of the Python side / tooling; an unknown ORBX_* variable makes orbx_create fail (checked on the GPU box:
+    tests/test_parity_gpu.py), so the list must not rot."""
+    import ctypes, glob, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    used = set()
+    for f in glob.glob(os.path.join(root, "wut-cuda-orb-slam3_amd", "csrc", "*.*")):
+        if f.endswith((".cpp", ".hip", ".h")):
+            used |= set(re.findall(r'getenv\("(ORBX_[A-Z0-9_]+)"\)', open(f).read()))
+    lib = pkg.load_library()
+    arr = (ctypes.c_char_p * 256)()
+    lib.orbx_known_switches.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+    n = lib.orbx_known_switches(arr, 256)
+    known = {arr[i].decode() for i in range(n)}
+    assert known - {"ORBX_LIB", "ORBX_BENCH_BACKEND", "ORBX_COMMIT"} == used, (sorted(known - used), sorted(used - known))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    missing = [k for k in sorted(used) if k not in design]
+    assert not missing, f"switches not described in DESIGN.md's appendix: {missing}"
+
+
+def test_unknown_switch_is_refused():
+    """ORBX_PF_KERNAL=2 (a typo) must not silently run the default: orbx_create fails with the switch's name - before it looks for a device,
+    so this runs on the CPU box too (where, without the typo, the same call fails with 'no HIP device')."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import __graft_entry__ as g\npkg = g.load_package()\n"
+            "try:\n    pkg.ORBextractor(1000, 1.2, 8, 20, 7)\n    print('CREATED')\nexcept pkg.OrbxError as e:\n    print('ERR', e)\n")
+    for env_extra, expect in (({"ORBX_PF_KERNAL": "2"}, "unknown environment switch ORBX_PF_KERNAL"), ({"ORBX_PF_KERNEL": "1"}, None)):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120).stdout
+        if expect:
+            assert expect in out, out[-500:]
+        else:
+            assert "unknown environment switch" not in out, out[-500:]

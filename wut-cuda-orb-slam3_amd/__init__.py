@@ -101,6 +101,7 @@ ABI_SYMBOLS = [
     "orbx_search_keyframe_windows_frames",
     "orbx_fuse_frames",
     "orbx_search_for_triangulation_frames",
+    "orbx_known_switches",
     "orbx_vocabulary_create",
     "orbx_vocabulary_load_text",
     "orbx_vocabulary_destroy",

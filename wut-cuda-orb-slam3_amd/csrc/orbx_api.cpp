@@ -200,12 +200,47 @@ static bool hostTimeline()
     return v;
 }
 
+// The ORBX_* environment switches exist for A / B measurements and so that the tests can force every kernel variant; none
+// is needed to run the library.  A name that no source reads is refused at the first create call: a mistyped switch that silently runs the
+// default would make an A / B measurement - or a test of a variant - meaningless.  (tests/test_abi.py keeps this list equal to the
+// getenv() calls of the sources; ORBX_LIB / ORBX_BENCH_BACKEND / ORBX_COMMIT belong to the Python side and the tooling.)
+static const char *const kKnownSwitches[] = {
+    "ORBX_BLUR_KERNEL", "ORBX_BLUR_SEG", "ORBX_BLUR_WAVES", "ORBX_CHAIN_TILE", "ORBX_DEBUG", "ORBX_EARLY_BLUR", "ORBX_FRONT_PARTS", "ORBX_FRONT_STAGGER",
+    "ORBX_GRAPH", "ORBX_HOST_FEEDER", "ORBX_HOST_SUBBATCHES", "ORBX_HOST_TIMELINE", "ORBX_KNN_MFMA", "ORBX_KNN_SHARED_BOUND", "ORBX_KNN_SPLIT", "ORBX_NO_BLUR",
+    "ORBX_PF_CLCAP", "ORBX_PF_KERNEL", "ORBX_PF_LANE_ALLOC", "ORBX_PF_LDS_FIT", "ORBX_PF_LDS_PAD", "ORBX_PF_PHASES", "ORBX_PROJECTION_HOST_ROUNDS", "ORBX_QT_KCH",
+    "ORBX_QT_KERNEL", "ORBX_QT_LDS_KEYS", "ORBX_QT_MAX_KEYS", "ORBX_QT_MAX_KEYS2", "ORBX_QT_MW", "ORBX_QT_MW_LDS_KEYS", "ORBX_QT_PER_LEVEL", "ORBX_QT_POOL_SLACK",
+    "ORBX_QT_STOP", "ORBX_QT_STREAMS", "ORBX_SBP_LIST_LDS", "ORBX_SBP_RESOLVE_GLOBAL", "ORBX_SEARCH_INIT_GENERIC", "ORBX_SI_BLOCK", "ORBX_SI_ROUNDS", "ORBX_SI_TOPK",
+    "ORBX_SMALL_BLUR_LEVELS", "ORBX_SMALL_PYR_CHAIN", "ORBX_SMALL_QT_BRANCHES", "ORBX_SMALL_SPLIT", "ORBX_STREAM_PRIO", "ORBX_SUBBATCHES", "ORBX_TILE_W",
+    "ORBX_LIB", "ORBX_BENCH_BACKEND", "ORBX_COMMIT",
+};
+extern char **environ;
+static int checkEnvironmentSwitches(const char *fn)
+{
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "ORBX_", 5) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+        bool known = false;
+        for (const char *k : kKnownSwitches)
+            if (strlen(k) == len && strncmp(k, *e, len) == 0) { known = true; break; }
+        if (!known) return setError(ORBX_ERR_INVALID_ARG, "%s: unknown environment switch %.*s (see DESIGN.md, appendix \"environment switches\")", fn, (int)len, *e);
+    }
+    return ORBX_OK;
+}
+extern "C" int orbx_known_switches(const char **names, int capacity)
+{
+    const int n = (int)(sizeof kKnownSwitches / sizeof kKnownSwitches[0]);
+    for (int i = 0; i < n && i < capacity; ++i) names[i] = kKnownSwitches[i];
+    return n;
+}
+
 extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
 {
     ORBX_API_ENTRY;
     ORBX_SETUP_LOCK;
     if (!p || !out) return setError(ORBX_ERR_INVALID_ARG, "orbx_create: null argument");
     *out = nullptr;
+    { const int rcEnv = checkEnvironmentSwitches("orbx_create"); if (rcEnv != ORBX_OK) return rcEnv; }
     if (p->nfeatures <= 0 || p->nlevels <= 0 || p->nlevels > ORBX_MAX_LEVELS || !(p->scale_factor > 1.0f))
         return setError(ORBX_ERR_INVALID_ARG, "orbx_create: nfeatures>0, 1<=nlevels<=%d, scale_factor>1 required", ORBX_MAX_LEVELS);
     if (p->trig_mode != ORBX_TRIG_DOUBLE && p->trig_mode != ORBX_TRIG_FLOAT) return setError(ORBX_ERR_INVALID_ARG, "orbx_create: trig_mode must be 0 or 1");
@@ -1957,6 +1992,7 @@ extern "C" int orbx_matcher_create(int device, int max_query, int max_train, orb
     ORBX_SETUP_LOCK;
     if (!out || max_query <= 0 || max_train <= 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_matcher_create: bad argument");
     *out = nullptr;
+    { const int rcEnv = checkEnvironmentSwitches("orbx_matcher_create"); if (rcEnv != ORBX_OK) return rcEnv; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return setError(ORBX_ERR_NO_DEVICE, "orbx_matcher_create: no HIP device available (this library has no CPU fallback)");
