@@ -2,6 +2,7 @@
 // Reads like the reference's own tests (test/src/OpenCLTest.cpp: build an extractor, run one stage, check the
 // result) — but asserts numeric equality instead of "the kernel started".  Needs a GPU; built and run by
 // tests/test_host_mirror_gpu.py.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -194,6 +195,42 @@ static int runSearchByProjection()
         oracle_compute_image_bounds(w, h, K, mDistCoef.data(), 4, K, rb);
         ASSERT_TRUE(B.mnMinX == rb[0] && B.mnMaxX == rb[1] && B.mnMinY == rb[2] && B.mnMaxY == rb[3]);
         ASSERT_TRUE(B.mnMinX < 0.f && B.mnMaxX > (float)w);
+    }
+
+    // round 4: the loop head on the device - Tracking::TrackWithMotionModel's x3Dc = Tcw * x3Dw; invzc; project (src/ORBmatcher3.cc:281-296) and
+    // Frame::isInFrustum over the local map (src/Frame.cc:542-600): records bit-equal to the oracle's, then straight into the searches
+    {
+        const orbx_camera cam = {0, {458.654f, 457.296f, 367.215f, 248.375f, 0, 0, 0, 0}};
+        std::vector<orbx_world_point> wp((size_t)np);
+        for (int i = 0; i < np; ++i) {
+            const float z = 2.f + (float)(i % 11);
+            wp[i].pos[0] = (keysLast[i].pt.x - cam.p[2]) / cam.p[0] * z; wp[i].pos[1] = (keysLast[i].pt.y - cam.p[3]) / cam.p[1] * z; wp[i].pos[2] = i % 37 ? z : -z;
+            wp[i].normal[0] = 0.f; wp[i].normal[1] = (float)(i % 3) * 0.3f; wp[i].normal[2] = 1.f - (float)(i % 3) * 0.1f;
+            wp[i].min_distance = 0.5f; wp[i].max_distance = z * 1.2f * 1.2f * (i % 4 ? 1.f : 0.5f);
+            wp[i].angle = keysLast[i].angle; wp[i].octave = keysLast[i].octave; wp[i].flags = (i % 7 ? 1 : 0) | (i % 4 ? 2 : 0);
+        }
+        const float q[4] = {0.001f, -0.002f, 0.0015f, 0.99999f}, t[3] = {0.02f, 0.01f, -0.015f};
+        std::vector<orbx_projection> vProj, refProj((size_t)np);
+        matcher.ProjectLastFramePoints(q, t, cam, wp, vProj);
+        oracle_project_last_frame_points(q, t, cam.type, cam.p, (const oracle_world_point *)wp.data(), np, (oracle_projection *)refProj.data());
+        ASSERT_TRUE(memcmp(vProj.data(), refProj.data(), (size_t)np * sizeof(orbx_projection)) == 0);
+        const int n3 = matcher.SearchByProjection(CurrentFrame, noRight, state, mvScaleFactors, 0.f, vProj, descLast, assigned, 15, false, false);
+        const int r3 = oracle_search_by_projection((const oracle_keypoint *)keysCur.data(), descCur.data.data(), nullptr, state.data(), nc, 0.f, (float)w,
+                                                   0.f, (float)h, mvScaleFactors.data(), (int)mvScaleFactors.size(), 0.f,
+                                                   (const oracle_projection *)refProj.data(), descLast.data.data(), np, 15, 0, 0, 1, ref.data());
+        ASSERT_EQ(n3, r3);
+        for (int i = 0; i < nc; ++i) ASSERT_EQ(assigned[i], ref[i]);
+        const float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Ow[3] = {-t[0], -t[1], -t[2]};
+        const float logsf = logf(1.2f);
+        std::vector<orbx_projection> vMP;
+        matcher.IsInFrustum(CurrentFrame, R, t, Ow, cam, 40.f, 0.5f, logsf, 8, wp, vMP, true, 9.5f);
+        const float bounds[4] = {0.f, (float)w, 0.f, (float)h};
+        oracle_project_in_frustum(R, t, Ow, cam.type, cam.p, bounds, 40.f, 0.5f, logsf, 8, 1, 9.5f, (const oracle_world_point *)wp.data(), np,
+                                  (oracle_projection *)refProj.data());
+        ASSERT_TRUE(memcmp(vMP.data(), refProj.data(), (size_t)np * sizeof(orbx_projection)) == 0);
+        int inView = 0;
+        for (int i = 0; i < np; ++i) inView += vMP[i].flags & 1;
+        ASSERT_TRUE(inView > 50 && inView < np);
     }
 
     // local map: the same points as Frame::isInFrustum would leave them (mTrackViewCos, mnTrackScaleLevel, mTrackProjXR)

@@ -535,6 +535,29 @@ public:
         F.mnMinX = b[0]; F.mnMaxX = b[1]; F.mnMinY = b[2]; F.mnMaxY = b[3];
     }
 
+    // The loop head of SearchByProjection(CurrentFrame, LastFrame, ..) — reference src/ORBmatcher3.cc:281-296 — for all map points of the last
+    // frame at once: x3Dc = Tcw * x3Dw (Tcw = CurrentFrame.GetPose() as unit quaternion x, y, z, w and translation), invzc, mpCamera->project.
+    // vProj[i] is the record SearchByProjection(CurrentFrame, .., vProj, ..) above takes.
+    void ProjectLastFramePoints(const float (&qxyzw)[4], const float (&t)[3], const orbx_camera &mpCamera, const std::vector<orbx_world_point> &vPoints,
+                                std::vector<orbx_projection> &vProj)
+    {
+        vProj.resize(vPoints.size());
+        check(orbx_project_last_frame_points(m_, qxyzw, t, &mpCamera, vPoints.data(), (int)vPoints.size(), vProj.data()), "ProjectLastFramePoints");
+    }
+
+    // Frame::isInFrustum(pMP, 0.5) for the whole local map — reference src/Frame.cc:542-600 (Tracking::SearchLocalPoints, src/Tracking4.cc:700-737)
+    // - plus the far-point test of src/ORBmatcher1.cc:57-58: vMapPoints[i] = {mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos,
+    // mnTrackScaleLevel, flags}, what SearchByProjection(F, .., vMapPoints, ..) above takes.  F supplies the image bounds.
+    void IsInFrustum(const FrameView &F, const float (&mRcw)[9], const float (&mtcw)[3], const float (&mOw)[3], const orbx_camera &mpCamera, float mbf,
+                     float viewingCosLimit, float mfLogScaleFactor, int mnScaleLevels, const std::vector<orbx_world_point> &vPoints,
+                     std::vector<orbx_projection> &vMapPoints, bool bFarPoints = false, float thFarPoints = 0.f)
+    {
+        vMapPoints.resize(vPoints.size());
+        const float bounds[4] = {F.mnMinX, F.mnMaxX, F.mnMinY, F.mnMaxY};
+        check(orbx_project_in_frustum(m_, mRcw, mtcw, mOw, &mpCamera, bounds, mbf, viewingCosLimit, mfLogScaleFactor, mnScaleLevels, bFarPoints ? 1 : 0,
+                                      thFarPoints, vPoints.data(), (int)vPoints.size(), vMapPoints.data()), "IsInFrustum");
+    }
+
     // Frame::AssignFeaturesToGrid — reference src/Frame.cc:387-418: mGrid[ix][iy] = items[cellStart[ix * 48 + iy] .. cellStart[.. + 1])
     void AssignFeaturesToGrid(const FrameView &F, std::vector<int32_t> &cellStart, std::vector<int32_t> &items)
     {
