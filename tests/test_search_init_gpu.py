@@ -91,7 +91,7 @@ def test_search_for_initialization_edge_cases(pkg, orc, two_frames):
 
 
 @pytest.mark.parametrize("var,val", [("ORBX_SEARCH_INIT_GENERIC", "1"), ("ORBX_SI_TOPK", "0"), ("ORBX_SI_TOPK", "1"), ("ORBX_SI_TOPK", "2"),
-                                     ("ORBX_SI_BLOCK", "0"), ("ORBX_SI_ROUNDS", "0")])
+                                     ("ORBX_SI_BLOCK", "0"), ("ORBX_SI_ROUNDS", "0"), ("ORBX_SI_ROUNDS_CAP", "300")])
 def test_other_kernels_in_subprocess(pkg, var, val):
     """orbx_search_for_initialization takes an LDS-resident kernel when the octave-0 subset of F2 fits (<= 2048 keypoints) and a
     generic one otherwise; ORBX_SEARCH_INIT_GENERIC (read once per process) forces the generic kernel.  The LDS-resident walk decides
@@ -100,11 +100,13 @@ def test_other_kernels_in_subprocess(pkg, var, val):
     the block-wise walk - eight keypoints per step where they do not depend on each other - meets undecided keypoints in nearly every
     block and falls back to single steps); ORBX_SI_BLOCK=0 walks step by step throughout.  Round 4: a single pair runs as fixed-point rounds
     over all keypoints (k_search_init_rounds; with ORBX_SI_TOPK = 1 / 2 most of its keypoints take the per-round scan of all of F2);
-    ORBX_SI_ROUNDS=0 takes the single-wave walk for single pairs again.  Run this file's parity tests once more under each."""
+    ORBX_SI_ROUNDS=0 takes the single-wave walk again; batches of pairs take the rounds too, a workgroup per pair, and
+    ORBX_SI_ROUNDS_CAP=300 leaves the pairs with more than 300 octave-0 keypoints in F1 to the walk kernel launched behind the rounds
+    (the path of a pair beyond the rounds' 2048).  Run this file's parity tests once more under each."""
     import os
     import subprocess
     import sys
-    if os.environ.get("ORBX_SEARCH_INIT_GENERIC") or os.environ.get("ORBX_SI_TOPK") or os.environ.get("ORBX_SI_BLOCK") or os.environ.get("ORBX_SI_ROUNDS"):
+    if os.environ.get("ORBX_SEARCH_INIT_GENERIC") or os.environ.get("ORBX_SI_TOPK") or os.environ.get("ORBX_SI_BLOCK") or os.environ.get("ORBX_SI_ROUNDS") or os.environ.get("ORBX_SI_ROUNDS_CAP"):
         pytest.skip("already a forced run")
     env = dict(os.environ)
     env[var] = val

@@ -1,4 +1,5 @@
-"""Randomised parity sweep of SearchForInitialization / AssignFeaturesToGrid against the oracle (development tool).
+"""Randomised parity sweep of SearchForInitialization (single pairs, and every third case a batch of device-resident pairs) /
+AssignFeaturesToGrid against the oracle (development tool).
 Usage: python tests/tools/stress_search_init.py [n] [seed]"""
 import os
 import sys
@@ -29,6 +30,26 @@ for case in range(n_cases):
     _, k1, d1 = ex(img1, None, (0, 0)); k1, d1 = k1.copy(), d1.copy()
     _, k2, d2 = ex(img2, None, (0, 0)); k2, d2 = k2.copy(), d2.copy()
     ex.close()
+    batch_ok = True
+    if case % 3 == 0:  # the batched form: pairs (frame p, frame p + 1) of one extractor batch, vbPrevMatched = F1's positions
+        exb = pkg.ORBextractor(nf, 1.2, nlev, 20, 7, max_width=w, max_height=h, max_batch=3)
+        img3 = np.roll(img2, int(rng.integers(-10, 11)), 1)
+        nb, _, kb, db = exb.extract_batch(np.stack([img1, img2, img3]), (0, 0))
+        bw = int(rng.choice([10, 30, 100]))
+        bnds = (float(rng.uniform(-20, 5)), float(w + rng.uniform(-5, 20)), float(rng.uniform(-20, 5)), float(h + rng.uniform(-5, 20)))
+        try:
+            bn, bm12, bprev = m.SearchForInitializationFrames(exb, exb, 2, np.float32([400, 400, w / 2, h / 2]), np.float32([]), bnds, bw, 0.9, True,
+                                                              frame2_offset=1)
+            for p in range(2):
+                ka, da, kc, dc = kb[p, : nb[p]], db[p, : nb[p]], kb[p + 1, : nb[p + 1]], db[p + 1, : nb[p + 1]]
+                if bn[p] == -1 and int((kc["octave"] == 0).sum()) > 2048:
+                    continue  # more octave-0 keypoints in F2 than the batched kernels hold: the documented capacity report
+                rn, rm12, rpv = orc.search_for_initialization(ka, da, kc, dc, np.stack([ka["x"], ka["y"]], 1), bnds, bw, 0.9, True)
+                batch_ok = batch_ok and bn[p] == rn and np.array_equal(bm12[p, : nb[p]], rm12) and \
+                    np.array_equal(bprev[p, : nb[p]].view(np.uint32), rpv.view(np.uint32))
+        except pkg.OrbxError as e:  # more octave-0 keypoints in F2 than the batched kernels hold: a reported capacity error, not a mismatch
+            print(f"case {case}: batch refused ({e})", flush=True)
+        exb.close()
     if rng.random() < 0.3:  # duplicated descriptors: ties
         d2[rng.integers(0, len(d2), len(d2) // 3)] = d2[rng.integers(0, len(d2), len(d2) // 3)]
     bounds = (float(rng.uniform(-20, 5)), float(w + rng.uniform(-5, 20)), float(rng.uniform(-20, 5)), float(h + rng.uniform(-5, 20)))
@@ -41,7 +62,7 @@ for case in range(n_cases):
     cs, it = m.AssignFeaturesToGrid(k2, bounds)
     rcs, rit = orc.assign_grid(k2, bounds)
     ok = n == rn and np.array_equal(m12, rm12) and np.array_equal(pv.view(np.uint32), rpv.view(np.uint32)) and np.array_equal(cs, rcs) \
-        and np.array_equal(it, rit)
+        and np.array_equal(it, rit) and batch_ok
     print(f"case {case}: {w}x{h} nf={nf} levels={nlev} n1={len(k1)} n2={len(k2)} window={window} ratio={ratio} check={check} matches={rn} "
           f"{'ok' if ok else 'MISMATCH'}", flush=True)
     bad += not ok

@@ -209,7 +209,7 @@ static const char *const kKnownSwitches[] = {
     "ORBX_GRAPH", "ORBX_HOST_FEEDER", "ORBX_HOST_SUBBATCHES", "ORBX_HOST_TIMELINE", "ORBX_KNN_MFMA", "ORBX_KNN_SHARED_BOUND", "ORBX_KNN_SPLIT", "ORBX_NO_BLUR",
     "ORBX_PF_CLCAP", "ORBX_PF_KERNEL", "ORBX_PF_LANE_ALLOC", "ORBX_PF_LDS_FIT", "ORBX_PF_LDS_PAD", "ORBX_PF_PHASES", "ORBX_PROJECTION_HOST_ROUNDS", "ORBX_QT_KCH",
     "ORBX_QT_KERNEL", "ORBX_QT_LDS_KEYS", "ORBX_QT_MAX_KEYS", "ORBX_QT_MAX_KEYS2", "ORBX_QT_MW", "ORBX_QT_MW_LDS_KEYS", "ORBX_QT_PER_LEVEL", "ORBX_QT_POOL_SLACK",
-    "ORBX_QT_STOP", "ORBX_QT_STREAMS", "ORBX_SBP_LIST_LDS", "ORBX_SBP_RESOLVE_GLOBAL", "ORBX_SEARCH_INIT_GENERIC", "ORBX_SI_BLOCK", "ORBX_SI_ROUNDS", "ORBX_SI_TOPK",
+    "ORBX_QT_STOP", "ORBX_QT_STREAMS", "ORBX_SBP_LIST_LDS", "ORBX_SBP_RESOLVE_GLOBAL", "ORBX_SEARCH_INIT_GENERIC", "ORBX_SI_BLOCK", "ORBX_SI_ROUNDS", "ORBX_SI_ROUNDS_CAP", "ORBX_SI_TOPK",
     "ORBX_SMALL_BLUR_LEVELS", "ORBX_SMALL_PYR_CHAIN", "ORBX_SMALL_QT_BRANCHES", "ORBX_SMALL_SPLIT", "ORBX_STREAM_PRIO", "ORBX_SUBBATCHES", "ORBX_TILE_W",
     "ORBX_LIB", "ORBX_BENCH_BACKEND", "ORBX_COMMIT",
 };

@@ -1054,6 +1054,10 @@ __global__ __launch_bounds__(GB_NT) void k_grid_build(const MtKp *k, int n, Grid
     }
 }
 
+// the octave-0 subset of F2 sorted by grid cell (k_si_sort): positions, key low bits, descriptor halves, cell starts - per pair
+#define SI_CELLS_PAD (GRID_CELLS + 64)   // cell starts per pair (GRID_CELLS + 1 used)
+struct SiSorted { float2 *xy; uint32_t *code; uint4 *dlo, *dhi; uint16_t *cellStart; };
+
 struct SearchInitArgs {
     const MtKp *k1; const uint8_t *d1; int n1;
     const MtKp *k2; const uint8_t *d2; int n2;
@@ -1074,6 +1078,10 @@ struct SearchInitArgs {
     const uint32_t *top; const float *topAng; const uint16_t *list1G, *origG; const int *nL1G, *n0G; int topUse, cap1;
     int ldsN1;                     // k_search_init_lds: octave-0 keypoints of F1 its LDS arrays are sized for (n1 when unknown)
     int blockWalk;                 // k_search_init_lds: 1 = eight keypoints per step of the walk where they do not depend on each other (ORBX_SI_BLOCK)
+    SiSorted sorted;               // k_search_init_rounds: the sorted subset of F2 (pre-pass), for the scans behind undecided lists
+    int roundsCap;                 // k_search_init_rounds: octave-0 keypoints of F1 it takes (SIR_CAP1; ORBX_SI_ROUNDS_CAP lowers it for the tests)
+    int *walkPair;                 // batch: [npairs] written by k_search_init_rounds - 1 = this pair is beyond its capacity and is left to
+                                   // k_search_init_lds, which then skips the others (nullptr: every pair takes the walk)
 };
 
 __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
@@ -1215,116 +1223,229 @@ __global__ __launch_bounds__(64) void k_search_init(SearchInitArgs a)
 #define SI_TOPK 8
 #define SI_KEY_NONE 0xFFFFFFFFu
 
-// octave-0 subsets of both frames in index order, one wave per pair and frame: orig[c2] = index in F2 (n0 of them), list1[t] = index in F1 (nL1)
-__global__ __launch_bounds__(64) void k_si_subset(SearchInitArgs a, uint16_t *orig, int *n0Out, uint16_t *list1, int *nL1Out)
+// octave-0 subsets of both frames in index order, one workgroup per pair and frame: orig[c2] = index in F2 (n0 of them), list1[t] = index
+// in F1 (nL1).  Chunks of 64 keypoints, a wave each: the ballot of a chunk and its count go to LDS, a prefix over the chunk counts gives
+// every chunk its place in the list.  (One wave per frame walked its 5000 keypoints in 20 dependent steps: 26 - 37 us.)
+#define SUB_NT 1024
+#define SUB_CHUNKS 1024   // 65536 keypoints
+__global__ __launch_bounds__(SUB_NT) void k_si_subset(SearchInitArgs a, uint16_t *orig, int *n0Out, uint16_t *list1, int *nL1Out)
 {
+    __shared__ unsigned long long mask[SUB_CHUNKS];
+    __shared__ int base[SUB_CHUNKS];
+    __shared__ int waveSum[SUB_NT / 64];
     const size_t p = blockIdx.x;
     if (a.n1Dev) {
         a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
         a.k1 += p * a.stride1; a.k2 += p * a.stride2;
     }
     orig += p * (size_t)SI_CAP2; list1 += p * (size_t)a.cap1;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int n0 = 0, nL1 = 0;
-    if (blockIdx.y == 0) a.n1 = 0; else a.n2 = 0;  // blockIdx.y: 0 the subset of F2, 1 the list of F1
-    for (int ib = 0; ib < a.n2; ib += 256) {  // four independent loads per step
-        bool z[4];
+    const bool second = blockIdx.y == 0;   // blockIdx.y: 0 the subset of F2 (octave == 0), 1 the list of F1 (!(octave > 0))
+    const MtKp *k = second ? a.k2 : a.k1;
+    const int n = second ? a.n2 : a.n1, nChunks = (n + 63) >> 6;
+    for (int c0 = wave; c0 < nChunks; c0 += 4 * (SUB_NT / 64)) {  // four independent loads per step
+        int oct[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = ib + 64 * u + lane; z[u] = i < a.n2 && a.k2[min(i, a.n2 - 1)].octave == 0; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned long long m = __ballot(z[u]);
-            const int pos = n0 + __popcll(m & lt);
-            if (z[u] && pos < SI_CAP2) orig[pos] = (uint16_t)(ib + 64 * u + lane);
-            n0 += __popcll(m);
-        }
-    }
-    for (int ib = 0; ib < a.n1; ib += 256) {
-        bool z[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = ib + 64 * u + lane; z[u] = i < a.n1 && !(a.k1[min(i, a.n1 - 1)].octave > 0); }
+        for (int u = 0; u < 4; ++u) oct[u] = k[min((c0 + u * (SUB_NT / 64)) * 64 + lane, n - 1)].octave;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const unsigned long long m = __ballot(z[u]);
-            if (z[u]) list1[nL1 + __popcll(m & lt)] = (uint16_t)(ib + 64 * u + lane);
-            nL1 += __popcll(m);
-        }
-    }
-    if (lane == 0) { if (blockIdx.y == 0) n0Out[p] = n0; else nL1Out[p] = nL1; }
-}
-
-// one wave per octave-0 keypoint of F1 (blockIdx.x = its position t in list1) and pair (blockIdx.y)
-__global__ __launch_bounds__(64) void k_si_topk(SearchInitArgs a, uint32_t *topAll, float *angAll)
-{
-    __shared__ uint32_t keys[SI_CAP2];
-    const int lane = threadIdx.x;
-    const size_t p = blockIdx.y;
-    const int t = blockIdx.x;
-    if (t >= a.nL1G[p]) return;
-    const int n0 = a.n0G[p];
-    if (n0 > SI_CAP2) return;  // (the walk reports the capacity error and never reads the lists)
-    if (a.n1Dev) {
-        a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32; a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32;
-        a.prev += p * a.stride1 * 2;
-    }
-    const uint16_t *orig = a.origG + p * (size_t)SI_CAP2;
-    const int i1 = a.list1G[p * (size_t)a.cap1 + t];
-    uint32_t *top = topAll + (p * (size_t)a.cap1 + t) * SI_TOPK;
-    if (lane == 0) angAll[p * (size_t)a.cap1 + t] = a.k1[i1].angle;
-    const float x = a.initPrev ? a.k1[i1].x : a.prev[2 * i1], y = a.initPrev ? a.k1[i1].y : a.prev[2 * i1 + 1];
-    const float r = (float)a.window;
-    // Frame::GetFeaturesInArea(x, y, r, 0, 0): the cell range, and "no candidates" where the reference returns early
-    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
-    const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
-    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
-    const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
-    int cnt = 0;
-    if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
-        uint32_t q[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int c0 = 0; c0 < n0; c0 += 64) {
-            const int c2 = c0 + lane;
-            bool in = false;
-            uint32_t key = 0;
-            if (c2 < n0) {
-                const int i2 = orig[c2];
-                const float kx = a.k2[i2].x, ky = a.k2[i2].y;
-                const int px = (int)roundf(__fmul_rn(__fsub_rn(kx, a.b.minX), a.b.invW));  // Frame::PosInGrid
-                const int py = (int)roundf(__fmul_rn(__fsub_rn(ky, a.b.minY), a.b.invH));
-                in = px >= cx0 && px <= cx1 && py >= cy0 && py <= cy1 && fabsf(__fsub_rn(kx, x)) < r && fabsf(__fsub_rn(ky, y)) < r;
-                if (in) {
-                    const uint32_t *tt = (const uint32_t *)(a.d2 + (size_t)i2 * 32);
-                    int dist = 0;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ tt[w]);
-                    key = ((uint32_t)dist << 23) | ((uint32_t)px << 17) | ((uint32_t)py << 11) | (uint32_t)c2;
-                }
-            }
-            const unsigned long long m = __ballot(in);
-            if (in) keys[cnt + __popcll(m & lt)] = key;
-            cnt += __popcll(m);
+            const int c = c0 + u * (SUB_NT / 64), i = c * 64 + lane;
+            const unsigned long long m = __ballot(i < n && (second ? oct[u] == 0 : !(oct[u] > 0)));
+            if (lane == 0 && c < nChunks) mask[c] = m;
         }
     }
     __syncthreads();
-    uint32_t last = 0;
-    for (int k = 0; k < SI_TOPK; ++k) {  // the k-th smallest key (keys are distinct: the subset index is part of them)
-        uint32_t mn = SI_KEY_NONE;
-        for (int j = lane; j < cnt; j += 64) {
-            const uint32_t v = keys[j];
-            if ((k == 0 || v > last) && v < mn) mn = v;
-        }
-        mn = mt_wave_min_u32(mn);
-        if (lane == 0) top[k] = mn;
-        last = mn;
-        if (mn == SI_KEY_NONE) {
-            if (lane > k && lane < SI_TOPK) top[lane] = SI_KEY_NONE;
-            break;
+    {
+        const int v = tid < nChunks ? __popcll(mask[tid]) : 0;
+        int total;
+        int off = mt_excl_scan(v, total);
+        if (lane == 0) waveSum[wave] = total;
+        __syncthreads();
+        int all = 0;
+        for (int w = 0; w < SUB_NT / 64; ++w) { if (w < wave) off += waveSum[w]; all += waveSum[w]; }
+        base[tid] = off;
+        if (tid == 0) { if (second) n0Out[p] = all; else nL1Out[p] = all; }
+    }
+    __syncthreads();
+    for (int c = wave; c < nChunks; c += SUB_NT / 64) {
+        const unsigned long long m = mask[c];
+        if ((m >> lane) & 1ull) {
+            const int pos = base[c] + __popcll(m & lt);
+            if (second) { if (pos < SI_CAP2) orig[pos] = (uint16_t)(c * 64 + lane); }
+            else list1[pos] = (uint16_t)(c * 64 + lane);
         }
     }
 }
+
+// ---- the candidate pre-pass (k_si_topk) --------------------------------------------------------------------------------------------------
+// k_si_sort: the octave-0 subset of F2 of a pair sorted by Frame::PosInGrid cell (column-major, the order GetFeaturesInArea visits the cells
+// in; any order inside a cell - the keys carry the subset index), one workgroup per pair: positions, key low bits (cell column << 17 | cell
+// row << 11 | subset index), descriptors (two 16-byte halves) and the cell starts.  k_si_topk then only visits the keypoints in the window's
+// cells (~11 % of F2 for a window of 100 px in 752 x 480) instead of testing every keypoint of F2 against every keypoint of F1, with
+// coalesced loads that depend on nothing (through orig[] -> k2[] -> d2[], a wave per keypoint of F1, it walked a chain of three L2 latencies
+// per 64 candidates: 28 us per keypoint, 0.97 of the 1.2 ms a batch of 256 pairs took).
+#define SIS_NT 1024
+__global__ __launch_bounds__(SIS_NT) void k_si_sort(SearchInitArgs a, SiSorted o)
+{
+    __shared__ int cnt[GRID_CELLS];
+    __shared__ int waveSum[SIS_NT / 64];
+    const size_t p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = a.n0G[p];
+    if (n0 > SI_CAP2) return;   // (capacity error: the searches report it and never read the lists)
+    if (a.n1Dev) { a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32; }
+    const uint16_t *orig = a.origG + p * (size_t)SI_CAP2;
+    o.xy += p * (size_t)SI_CAP2; o.code += p * (size_t)SI_CAP2; o.dlo += p * (size_t)SI_CAP2; o.dhi += p * (size_t)SI_CAP2;
+    o.cellStart += p * (size_t)SI_CELLS_PAD;
+    for (int c = tid; c < GRID_CELLS; c += SIS_NT) cnt[c] = 0;
+    __syncthreads();
+    constexpr int KPT = SI_CAP2 / SIS_NT;
+    int cell[KPT], rank[KPT], i2s[KPT];
+    float kxs[KPT], kys[KPT];
+#pragma unroll
+    for (int s = 0; s < KPT; ++s) {
+        const int c2 = tid + s * SIS_NT;
+        cell[s] = -1; rank[s] = 0; i2s[s] = 0; kxs[s] = kys[s] = 0.0f;
+        if (c2 < n0) {
+            const int i2 = orig[c2];
+            const float kx = a.k2[i2].x, ky = a.k2[i2].y;
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(kx, a.b.minX), a.b.invW));  // Frame::PosInGrid (false outside the grid: never a candidate)
+            const int py = (int)roundf(__fmul_rn(__fsub_rn(ky, a.b.minY), a.b.invH));
+            i2s[s] = i2; kxs[s] = kx; kys[s] = ky;
+            if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) { cell[s] = px * GRID_ROWS + py; rank[s] = atomicAdd(&cnt[cell[s]], 1); }
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the cells: three per thread, wave scan, wave totals through LDS
+        constexpr int CPT = GRID_CELLS / SIS_NT;
+        int v[CPT], sum = 0;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { v[j] = cnt[tid * CPT + j]; sum += v[j]; }
+        int total;
+        int off = mt_excl_scan(sum, total);
+        if (lane == 0) waveSum[wave] = total;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) off += waveSum[w];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { cnt[tid * CPT + j] = off; o.cellStart[tid * CPT + j] = (uint16_t)off; off += v[j]; }
+        if (tid == SIS_NT - 1) o.cellStart[GRID_CELLS] = (uint16_t)off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KPT; ++s) {
+        if (cell[s] < 0) continue;
+        const int c2 = tid + s * SIS_NT, idx = cnt[cell[s]] + rank[s];
+        const int px = cell[s] / GRID_ROWS, py = cell[s] - px * GRID_ROWS;
+        o.xy[idx] = make_float2(kxs[s], kys[s]);
+        o.code[idx] = ((uint32_t)px << 17) | ((uint32_t)py << 11) | (uint32_t)c2;
+        const uint4 *d = (const uint4 *)(a.d2 + (size_t)i2s[s] * 32);
+        o.dlo[idx] = d[0]; o.dhi[idx] = d[1];
+    }
+}
+static_assert(GRID_CELLS % SIS_NT == 0 && SI_CAP2 % SIS_NT == 0, "k_si_sort: cells / keypoints per thread");
+
+// k_si_topk: the SI_TOPK smallest candidate keys of every octave-0 keypoint of F1.  A workgroup holds the sorted subset of F2 of its pair
+// in LDS and takes SIT_NT / SIT_LPQ keypoints of F1 per turn: SIT_LPQ neighbouring lanes share a keypoint (lane j of them takes every
+// SIT_LPQ-th cell column of the window), every lane keeps the eight smallest keys it saw in registers (a sorted insert: min / max
+// pairs), and the lanes of a keypoint merge their lists with eight rounds of "minimum of the heads, its owner pops".
+// blockIdx.x: the workgroup's share of the pair's keypoints (turns blockIdx.x, + gridDim.x, ...), blockIdx.y: the pair.
+#define SIT_NT 1024
+// minimum over the LPQ lanes that share a keypoint (DPP: inside a quad / a row of 16 lanes)
+template <int LPQ>
+__device__ __forceinline__ uint32_t sit_group_min(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));  // quad_perm [1, 0, 3, 2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));  // quad_perm [2, 3, 0, 1]
+    if constexpr (LPQ == 16) {
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+        v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror
+    }
+    return v;
+}
+template <int SIT_LPQ>   // 4: batches of pairs; 16: a few pairs (four times the workgroups, a quarter of the candidates per lane)
+__global__ __launch_bounds__(SIT_NT) void k_si_topk(SearchInitArgs a, uint32_t *topAll, float *angAll, SiSorted o)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sit_lds[];
+    uint4 *dlo = (uint4 *)sit_lds;                          // [SI_CAP2]
+    uint4 *dhi = dlo + SI_CAP2;                             // [SI_CAP2]
+    float2 *xy = (float2 *)(dhi + SI_CAP2);                 // [SI_CAP2]
+    uint32_t *code = (uint32_t *)(xy + SI_CAP2);            // [SI_CAP2]
+    uint16_t *cellStart = (uint16_t *)(code + SI_CAP2);     // [SI_CELLS_PAD]
+    static_assert(SIT_LPQ == 4 || SIT_LPQ == 16, "sit_group_min");
+    constexpr int SIT_QPW = SIT_NT / SIT_LPQ;
+    const int tid = threadIdx.x;
+    const size_t p = blockIdx.y;
+    const int nL1 = a.nL1G[p];
+    if ((int)(blockIdx.x * SIT_QPW) >= nL1) return;   // (uniform)
+    const int n0 = a.n0G[p];
+    if (n0 > SI_CAP2) return;  // (the searches report the capacity error and never read the lists)
+    if (a.n1Dev) {
+        a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32;
+        a.prev += p * a.stride1 * 2;
+    }
+    o.xy += p * (size_t)SI_CAP2; o.code += p * (size_t)SI_CAP2; o.dlo += p * (size_t)SI_CAP2; o.dhi += p * (size_t)SI_CAP2;
+    o.cellStart += p * (size_t)SI_CELLS_PAD;
+    for (int c = tid; c < GRID_CELLS + 1; c += SIT_NT) cellStart[c] = o.cellStart[c];
+    for (int c = tid; c < n0; c += SIT_NT) { dlo[c] = o.dlo[c]; dhi[c] = o.dhi[c]; xy[c] = o.xy[c]; code[c] = o.code[c]; }
+    __syncthreads();
+    const float r = (float)a.window;
+    const int sub = tid & (SIT_LPQ - 1);
+    for (int t = blockIdx.x * SIT_QPW + tid / SIT_LPQ; t < nL1; t += gridDim.x * SIT_QPW) {
+        const int i1 = a.list1G[p * (size_t)a.cap1 + t];
+        const float x = a.initPrev ? a.k1[i1].x : a.prev[2 * i1], y = a.initPrev ? a.k1[i1].y : a.prev[2 * i1 + 1];
+        if (sub == 0) angAll[p * (size_t)a.cap1 + t] = a.k1[i1].angle;
+        // Frame::GetFeaturesInArea(x, y, r, 0, 0): the cell range, and "no candidates" where the reference returns early
+        const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+        const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
+        const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+        const int cy1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
+        uint32_t l[SI_TOPK];
+#pragma unroll
+        for (int k = 0; k < SI_TOPK; ++k) l[k] = SI_KEY_NONE;
+        if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
+            const uint4 q0 = ((const uint4 *)(a.d1 + (size_t)i1 * 32))[0], q1 = ((const uint4 *)(a.d1 + (size_t)i1 * 32))[1];
+            int cx = cx0 + sub, idx = 0, end = 0;
+            while (true) {
+                while (idx >= end && cx <= cx1) {  // next cell column of this lane: the cells (cx, cy0 .. cy1) are neighbours in the sorted order
+                    idx = cellStart[cx * GRID_ROWS + cy0]; end = cellStart[cx * GRID_ROWS + cy1 + 1];
+                    cx += SIT_LPQ;
+                }
+                if (idx >= end) break;
+                const float2 k2 = xy[idx];
+                if (fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r) {
+                    const uint4 d0 = dlo[idx], d1 = dhi[idx];
+                    const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                                     __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+                    uint32_t key = ((uint32_t)dist << 23) | code[idx];
+                    if (key < l[SI_TOPK - 1]) {
+#pragma unroll
+                        for (int k = 0; k < SI_TOPK; ++k) { const uint32_t lo = min(l[k], key); key = max(l[k], key); l[k] = lo; }
+                    }
+                }
+                ++idx;
+            }
+        }
+        // merge the lists of the SIT_LPQ lanes (keys are distinct: the subset index is part of them)
+        uint32_t *top = topAll + (p * (size_t)a.cap1 + t) * SI_TOPK;
+        uint32_t mine = 0, mine2 = 0;   // lane `sub` keeps entry sub (and, four lanes per keypoint, entry sub + 4) and stores it
+#pragma unroll
+        for (int k = 0; k < SI_TOPK; ++k) {
+            const uint32_t mn = sit_group_min<SIT_LPQ>(l[0]);
+            if (l[0] == mn && mn != SI_KEY_NONE) {
+#pragma unroll
+                for (int j = 0; j + 1 < SI_TOPK; ++j) l[j] = l[j + 1];
+                l[SI_TOPK - 1] = SI_KEY_NONE;
+            }
+            if (k == sub) mine = mn;
+            if (SIT_LPQ == 4 && k == sub + 4) mine2 = mn;
+        }
+        if (sub < SI_TOPK) top[sub] = mine;
+        if (SIT_LPQ == 4) top[sub + 4] = mine2;
+    }
+}
+static_assert(SI_TOPK == 8, "k_si_topk: list entries per lane");
+static const size_t kSitLdsBytes = (size_t)SI_CAP2 * (16 + 16 + 8 + 4) + SI_CELLS_PAD * 2;
 
 // The same search with everything the candidate loop touches in LDS.  Only octave-0 keypoints take part (F1: `level1 > 0` is
 // skipped; F2: GetFeaturesInArea(.., level1, level1)), so the kernel compacts both sides to their octave-0 subsets, rebuilds
@@ -1364,6 +1485,7 @@ __global__ __launch_bounds__(64) void k_search_init_lds(SearchInitArgs a)
     __shared__ int hist[32];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    if (a.walkPair && !a.walkPair[blockIdx.x]) return;  // (uniform) k_search_init_rounds did this pair
     if (a.n1Dev) {  // pair p of a batch
         const size_t p = blockIdx.x;
         a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
@@ -1813,14 +1935,26 @@ __global__ __launch_bounds__(SIR_NT) void k_search_init_rounds(SearchInitArgs a)
     __shared__ int hist[32];
     __shared__ int nUndecided, changed, cntM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.n1Dev) {  // pair p of a batch (as k_search_init_lds)
+        const size_t p = blockIdx.x;
+        a.n1 = min(a.n1, a.n1Dev[p]); a.n2 = min(a.n2, a.n2Dev[p]);
+        a.k1 += p * a.stride1; a.d1 += p * a.stride1 * 32; a.k2 += p * a.stride2; a.d2 += p * a.stride2 * 32;
+        a.prev += p * a.stride1 * 2; a.m12 += p * a.stride1; a.nmatches += p;
+        a.top += p * (size_t)a.cap1 * SI_TOPK; a.topAng += p * (size_t)a.cap1; a.list1G += p * (size_t)a.cap1;
+        a.origG += p * (size_t)SI_CAP2; a.nL1G += p; a.n0G += p;
+        a.sorted.xy += p * (size_t)SI_CAP2; a.sorted.code += p * (size_t)SI_CAP2; a.sorted.dlo += p * (size_t)SI_CAP2;
+        a.sorted.dhi += p * (size_t)SI_CAP2; a.sorted.cellStart += p * (size_t)SI_CELLS_PAD;
+    }
     const int nL1 = a.nL1G[0], n0 = a.n0G[0];
+    if (n0 > SI_CAP2 || nL1 > a.roundsCap) {
+        // a single call: the host checks before it takes this kernel; a batch (counts on the device): the pair is left to the walk
+        if (tid == 0) { if (a.walkPair) a.walkPair[blockIdx.x] = 1; else *a.nmatches = -1; }
+        return;
+    }
+    if (tid == 0 && a.walkPair) a.walkPair[blockIdx.x] = 0;
     for (int i = tid; i < a.n1; i += SIR_NT) a.m12[i] = -1;
     if (a.initPrev)
         for (int i = tid; i < a.n1; i += SIR_NT) { a.prev[2 * i] = a.k1[i].x; a.prev[2 * i + 1] = a.k1[i].y; }
-    if (n0 > SI_CAP2 || nL1 > SIR_CAP1) {  // (the host checks before it takes this kernel; a capacity error like the single-wave kernel's)
-        if (tid == 0) *a.nmatches = -1;
-        return;
-    }
     // this thread's keypoints t = tid + s * SIR_NT and their short lists
     uint32_t keys[SIR_KPT][SI_TOPK];
 #pragma unroll
@@ -1887,7 +2021,8 @@ __global__ __launch_bounds__(SIR_NT) void k_search_init_rounds(SearchInitArgs a)
         for (int u = wave; u < nU; u += SIR_NT / 64) {
             const int t = undecided[u];
             const int i1 = a.list1G[t];
-            const float x = a.prev[2 * i1], y = a.prev[2 * i1 + 1];   // (vbPrevMatched is only updated behind the rounds)
+            // (vbPrevMatched is only updated behind the rounds; initPrev: it is F1's keypoint positions, written by this workgroup above)
+            const float x = a.initPrev ? a.k1[i1].x : a.prev[2 * i1], y = a.initPrev ? a.k1[i1].y : a.prev[2 * i1 + 1];
             const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
             const int cx1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.b.minX), r), a.b.invW)));
             const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.b.minY), r), a.b.invH)));
@@ -1895,23 +2030,22 @@ __global__ __launch_bounds__(SIR_NT) void k_search_init_rounds(SearchInitArgs a)
             uint32_t best = SI_KEY_NONE;
             int sec = 0x7FFFFFFF;
             if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
-                uint32_t q[8];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) q[w] = ((const uint32_t *)(a.d1 + (size_t)i1 * 32))[w];
-                for (int c2 = lane; c2 < n0; c2 += 64) {
-                    const int i2 = a.origG[c2];
-                    const float kx = a.k2[i2].x, ky = a.k2[i2].y;
-                    const int px = (int)roundf(__fmul_rn(__fsub_rn(kx, a.b.minX), a.b.invW));  // Frame::PosInGrid
-                    const int py = (int)roundf(__fmul_rn(__fsub_rn(ky, a.b.minY), a.b.invH));
-                    if (!(px >= cx0 && px <= cx1 && py >= cy0 && py <= cy1 && fabsf(__fsub_rn(kx, x)) < r && fabsf(__fsub_rn(ky, y)) < r)) continue;
-                    const uint32_t *tt = (const uint32_t *)(a.d2 + (size_t)i2 * 32);
-                    int dist = 0;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ tt[w]);
-                    if (seen(c2, t) <= dist) continue;
-                    const uint32_t key = ((uint32_t)dist << 23) | ((uint32_t)px << 17) | ((uint32_t)py << 11) | (uint32_t)c2;
-                    if (key < best) { if (best != SI_KEY_NONE) sec = min(sec, (int)(best >> 23)); best = key; }
-                    else sec = min(sec, dist);
+                // the window's cells in the sorted subset, a cell column per lane (as k_si_topk; the keys are the same, so is the order)
+                const uint4 q0 = ((const uint4 *)(a.d1 + (size_t)i1 * 32))[0], q1 = ((const uint4 *)(a.d1 + (size_t)i1 * 32))[1];
+                for (int cx = cx0 + lane; cx <= cx1; cx += 64) {
+                    const int end = a.sorted.cellStart[cx * GRID_ROWS + cy1 + 1];
+                    for (int idx = a.sorted.cellStart[cx * GRID_ROWS + cy0]; idx < end; ++idx) {
+                        const float2 k2 = a.sorted.xy[idx];
+                        if (!(fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r)) continue;
+                        const uint4 d0 = a.sorted.dlo[idx], d1 = a.sorted.dhi[idx];
+                        const int dist = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) +
+                                         __popc(q1.x ^ d1.x) + __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+                        const uint32_t code = a.sorted.code[idx];
+                        if (seen((int)(code & (SI_CAP2 - 1)), t) <= dist) continue;
+                        const uint32_t key = ((uint32_t)dist << 23) | code;
+                        if (key < best) { if (best != SI_KEY_NONE) sec = min(sec, (int)(best >> 23)); best = key; }
+                        else sec = min(sec, dist);
+                    }
                 }
             }
             const uint32_t gBest = mt_wave_min_u32(best);
@@ -2051,7 +2185,8 @@ static size_t siAlign(size_t b) { return (b + 255) & ~(size_t)255; }
 size_t orbxSearchInitWorkBytes(int npairs, int cap1)
 {
     const size_t P = (size_t)std::max(npairs, 1), C = (size_t)std::max(cap1, 1);
-    return siAlign(P * SI_CAP2 * 2) + siAlign(P * C * 2) + 2 * siAlign(P * 4) + siAlign(P * C * SI_TOPK * 4) + siAlign(P * C * 4);
+    return siAlign(P * SI_CAP2 * 2) + siAlign(P * C * 2) + 3 * siAlign(P * 4) + siAlign(P * C * SI_TOPK * 4) + siAlign(P * C * 4) +
+           siAlign(P * SI_CAP2 * 8) + siAlign(P * SI_CAP2 * 4) + 2 * siAlign(P * SI_CAP2 * 16) + siAlign(P * SI_CELLS_PAD * 2);
 }
 
 // ORBX_SI_TOPK: entries of the precomputed candidate lists the walk looks at (0: none - every keypoint takes the full scan; the tests
@@ -2062,10 +2197,24 @@ static int searchInitTopUse()
     return v;
 }
 
+// ORBX_SI_ROUNDS=0: the single-wave walk (k_search_init_lds) instead of the fixed-point rounds over all keypoints (A/B, tests)
+static int searchInitRounds()
+{
+    static const int v = [] { const char *e = getenv("ORBX_SI_ROUNDS"); return e ? atoi(e) : 1; }();
+    return v;
+}
+// ORBX_SI_ROUNDS_CAP: octave-0 keypoints of F1 up to which a pair takes the rounds (tests: a small value sends pairs of a batch to the walk)
+static int searchInitRoundsCap()
+{
+    static const int v = [] { const char *e = getenv("ORBX_SI_ROUNDS_CAP"); return e ? std::min(std::max(atoi(e), 0), SIR_CAP1) : SIR_CAP1; }();
+    return v;
+}
+
 // the pre-pass of `npairs` pairs described by `a` into `work`; fills the pre-pass fields of `a`
 static void searchInitPrepass(hipStream_t st, SearchInitArgs &a, int npairs, int cap1, void *work)
 {
     a.top = nullptr; a.topAng = nullptr; a.list1G = nullptr; a.origG = nullptr; a.nL1G = nullptr; a.n0G = nullptr; a.topUse = 0; a.cap1 = cap1;
+    a.walkPair = nullptr; a.roundsCap = searchInitRoundsCap();
     static const int blockWalk = [] { const char *e = getenv("ORBX_SI_BLOCK"); return e ? atoi(e) != 0 : 1; }();  // tests: 0 = step by step
     a.blockWalk = blockWalk;
     const int use = searchInitTopUse();
@@ -2077,10 +2226,38 @@ static void searchInitPrepass(hipStream_t st, SearchInitArgs &a, int npairs, int
     int *n0 = (int *)w; w += siAlign(P * 4);
     int *nL1 = (int *)w; w += siAlign(P * 4);
     uint32_t *top = (uint32_t *)w; w += siAlign(P * C * SI_TOPK * 4);
-    float *ang = (float *)w;
-    hipLaunchKernelGGL(k_si_subset, dim3(npairs, 2), dim3(64), 0, st, a, orig, n0, list1, nL1);
+    float *ang = (float *)w; w += siAlign(P * C * 4);
+    a.walkPair = (int *)w; w += siAlign(P * 4);  // (the batch launcher clears the pointer again when it does not run the rounds kernel)
+    SiSorted so;
+    so.xy = (float2 *)w; w += siAlign(P * SI_CAP2 * 8);
+    so.code = (uint32_t *)w; w += siAlign(P * SI_CAP2 * 4);
+    so.dlo = (uint4 *)w; w += siAlign(P * SI_CAP2 * 16);
+    so.dhi = (uint4 *)w; w += siAlign(P * SI_CAP2 * 16);
+    so.cellStart = (uint16_t *)w;
+    a.sorted = so;
+    hipLaunchKernelGGL(k_si_subset, dim3(npairs, 2), dim3(SUB_NT), 0, st, a, orig, n0, list1, nL1);
     a.list1G = list1; a.origG = orig; a.nL1G = nL1; a.n0G = n0;
-    hipLaunchKernelGGL(k_si_topk, dim3(cap1, npairs), dim3(64), 0, st, a, top, ang);
+    hipLaunchKernelGGL(k_si_sort, dim3(npairs), dim3(SIS_NT), 0, st, a, so);
+    // workgroups per pair: enough turns of SIT_NT / LPQ keypoints for cap1 of them, but no more workgroups than keep the device busy - every
+    // one of them stages the pair's sorted subset (up to 96 KB) first
+    const int lpq = npairs <= 8 ? 16 : 4;
+    const int turns = (cap1 * lpq + SIT_NT - 1) / SIT_NT;
+    const int perPair = std::max(1, std::min(turns, (1024 + npairs - 1) / npairs));
+    {
+        static bool attrSet[64] = {};  // per device: more than the default 64 KB of dynamic LDS
+        int devId = 0;
+        (void)hipGetDevice(&devId);
+        if (!attrSet[devId & 63]) {
+            if (hipFuncSetAttribute((const void *)k_si_topk<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSitLdsBytes) != hipSuccess ||
+                hipFuncSetAttribute((const void *)k_si_topk<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSitLdsBytes) != hipSuccess) {
+                a.top = nullptr;   // (no lists: the searches scan; cannot happen on gfx950's 160 KB)
+                return;
+            }
+            attrSet[devId & 63] = true;
+        }
+    }
+    if (lpq == 16) hipLaunchKernelGGL(k_si_topk<16>, dim3(perPair, npairs), dim3(SIT_NT), kSitLdsBytes, st, a, top, ang, so);
+    else hipLaunchKernelGGL(k_si_topk<4>, dim3(perPair, npairs), dim3(SIT_NT), kSitLdsBytes, st, a, top, ang, so);
     a.top = top; a.topAng = ang; a.topUse = use;
 }
 
@@ -2105,6 +2282,10 @@ hipError_t orbxLaunchSearchInitBatch(hipStream_t st, int npairs, const void *k1,
     if (e != hipSuccess) return e;
     a.ldsN1 = cap1;
     searchInitPrepass(st, a, npairs, cap1, work);
+    // the fixed-point rounds, a workgroup per pair; a pair beyond their capacity (more than SIR_CAP1 octave-0 keypoints in F1: known on the
+    // device only) marks itself in walkPair and the walk kernel behind takes it - its workgroups for the other pairs leave at once
+    if (searchInitRounds() && a.top) hipLaunchKernelGGL(k_search_init_rounds, dim3(npairs), dim3(SIR_NT), 0, st, a);
+    else a.walkPair = nullptr;
     hipLaunchKernelGGL(k_search_init_lds, dim3(npairs), dim3(64), lds, st, a);
     return hipGetLastError();
 }
@@ -2117,7 +2298,7 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     SearchInitArgs a;
     a.stride1 = 0; a.stride2 = 0; a.n1Dev = nullptr; a.n2Dev = nullptr; a.initPrev = 0;
     a.top = nullptr; a.topAng = nullptr; a.list1G = nullptr; a.origG = nullptr; a.nL1G = nullptr; a.n0G = nullptr; a.topUse = 0; a.cap1 = n1;
-    a.blockWalk = 0;
+    a.blockWalk = 0; a.walkPair = nullptr; a.roundsCap = searchInitRoundsCap();
     a.k1 = (const MtKp *)k1; a.d1 = d1; a.n1 = n1; a.k2 = (const MtKp *)k2; a.d2 = d2; a.n2 = n2;
     a.cellStart = cellStart; a.items = items;
     a.b.minX = minX; a.b.minY = minY;
@@ -2129,16 +2310,17 @@ hipError_t orbxLaunchSearchInit(hipStream_t st, const void *k1, const uint8_t *d
     const int l1 = level0of1 >= 0 ? std::min(level0of1, n1) : n1;
     a.ldsN1 = l1;
     const size_t lds = searchInitLdsBytes(l1);
-    // ORBX_SI_ROUNDS=0: the single-wave walk (k_search_init_lds) instead of the fixed-point rounds over all keypoints (A/B, tests)
-    static const int rounds = [] { const char *e = getenv("ORBX_SI_ROUNDS"); return e ? atoi(e) : 1; }();
-    if (rounds && work && searchInitTopUse() >= 1 && level0of2 >= 0 && level0of2 <= SI_CAP2 && level0of1 >= 0 && l1 <= SIR_CAP1 && n1 < 65536 &&
+    const int rounds = searchInitRounds();
+    if (rounds && work && searchInitTopUse() >= 1 && level0of2 >= 0 && level0of2 <= SI_CAP2 && level0of1 >= 0 && l1 <= searchInitRoundsCap() && n1 < 65536 &&
         n2 < 65536) {
         searchInitPrepass(st, a, 1, n1, work);
+        a.walkPair = nullptr;
         hipLaunchKernelGGL(k_search_init_rounds, dim3(1), dim3(SIR_NT), 0, st, a);
     } else if (orbxSearchInitInLds(l1, n2, level0of2) && n1 < 65536) {
         const hipError_t e = searchInitLdsAttr(lds);
         if (e != hipSuccess) return e;
         searchInitPrepass(st, a, 1, n1, work);
+        a.walkPair = nullptr;
         hipLaunchKernelGGL(k_search_init_lds, dim3(1), dim3(64), lds, st, a);
     } else {
         hipLaunchKernelGGL(k_search_init, dim3(1), dim3(64), 0, st, a);
