@@ -442,6 +442,15 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         g.h = cvRoundF((float)h * ex->invScale[l]);
         g.pitch = (int)roundUp(g.w, 64);
         g.frameStride = (long long)roundUp((size_t)g.pitch * g.h, 256);
+        // columns a tile stages beyond its last interior column when another column group follows: the 3 of the FAST ring, or what the
+        // resize phase reads there - it produces up to 3 destination columns beyond the group's own (boundaries at multiples of 4, see
+        // the column ownership below): ceil(3 * scale) source columns further, + 1 for the right tap
+        int rightHalo = 3;
+        if (l + 1 < nl) {
+            const int w1 = cvRoundF((float)w * ex->invScale[l + 1]);
+            rightHalo = std::max(3, (int)std::ceil(3.0 * g.w / std::max(w1, 1)) + 1);
+        }
+        g.rightHalo = rightHalo;
         const int minB = ORBX_BORDER, maxBX = g.w - ORBX_EDGE + 3, maxBY = g.h - ORBX_EDGE + 3;
         const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
         const int nCols = (int)(width / 35.f), nRows = (int)(height / 35.f);
@@ -474,7 +483,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         if (ldsFit && tileWEnv <= 0 && ex->prm.max_batch > ORBX_GRAPH_MAX_FRAMES) {
             auto estimate = [&](int cells) {  // the LDS layout below for `cells` cells per group (resize tables at their nominal size)
                 const int tw = cells * g.wCell, ng = (g.ncx + cells - 1) / cells;
-                const size_t maxCols = ng == 1 ? (size_t)g.w : (size_t)tw + 3 + ORBX_FAST_MARGIN;   // edge groups hold the image margin
+                const size_t maxCols = ng == 1 ? (size_t)g.w : (size_t)tw + rightHalo + ORBX_FAST_MARGIN;   // edge groups hold the image margin
                 const size_t rows = g.ncy == 1 ? (size_t)g.h : (size_t)g.hCell + 3 + ORBX_FAST_MARGIN;
                 const size_t tp = roundUp(maxCols + 32, 16), sp = roundUp((size_t)tw, 16);
                 const size_t dx = roundUp((size_t)((tw + ORBX_FAST_MARGIN) / ex->prm.scale_factor) + 4, 2);
@@ -512,7 +521,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         for (int gi = 0; gi < g.nGroups; ++gi) {
             int c0 = gi * g.groupCells, c1 = std::min(c0 + g.groupCells, g.ncx);
             int tx0 = ORBX_FAST_MARGIN + c0 * g.wCell, tx1 = std::min(ORBX_FAST_MARGIN + c1 * g.wCell, g.w - ORBX_FAST_MARGIN);
-            int lx0 = gi == 0 ? 0 : tx0 - 3, lx1 = gi == g.nGroups - 1 ? g.w : tx1 + 3;
+            int lx0 = gi == 0 ? 0 : tx0 - 3, lx1 = gi == g.nGroups - 1 ? g.w : tx1 + rightHalo;
             maxCols = std::max(maxCols, lx1 - (lx0 & ~15));
         }
         g.tileRows = maxRows;
@@ -575,6 +584,21 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
             }
             colBeg[s.nGroups] = dx;
             if (dx != d.w) return setError(ORBX_ERR_INVALID_ARG, "internal: resize column ownership is not monotone (level %d)", l);
+            // The resize phase of k_pyr_fast writes 4 destination pixels per lane with one 32-bit store: the boundaries between the column
+            // groups move up to the next multiple of 4, so that no 4-pixel group straddles two tiles (a lane with a partial group stored
+            // byte by byte under four exec masks - ~17 scalar instructions per turn of EVERY lane's loop).  The left tile then produces up
+            // to 3 more destination columns, whose right taps lie up to 5 source columns beyond its last interior column: the tiles of
+            // such groups stage OrbxLevelGeom::rightHalo (5 at scale 1.2) instead of 3 columns there.  (The last group ends at the image edge: its last
+            // store may run into the row's padding, pitch = roundUp(w, 64).)
+            for (int gi = 1; gi < s.nGroups; ++gi) {
+                colBeg[gi] = std::min((colBeg[gi] + 3) & ~3, d.w);
+                const int c1 = std::min(gi * s.groupCells, s.ncx);
+                const int tx1 = std::min(ORBX_FAST_MARGIN + c1 * s.wCell, s.w - ORBX_FAST_MARGIN);
+                if (colBeg[gi] > colBeg[gi - 1] && std::min(xofs[colBeg[gi] - 1] + 1, s.w - 1) >= tx1 + s.rightHalo)
+                    return setError(ORBX_ERR_INVALID_ARG, "internal: resize column group %d of level %d reads beyond its staged columns", gi - 1, l);
+            }
+            for (int gi = 0; gi < s.nGroups; ++gi)
+                if (colBeg[gi + 1] < colBeg[gi]) return setError(ORBX_ERR_INVALID_ARG, "internal: resize column ownership is not monotone (level %d)", l);
         }
         for (int c = 0; c < s.ncy; ++c) geom[l].rsMaxDy = std::max(geom[l].rsMaxDy, rowBeg[c + 1] - rowBeg[c]);
         for (int gi = 0; gi < s.nGroups; ++gi) geom[l].rsMaxDx = std::max(geom[l].rsMaxDx, colBeg[gi + 1] - colBeg[gi]);
@@ -639,7 +663,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                 // rows / columns staged in LDS: interior + 3-px ring halo; edge tiles extend to the image border so that the tile also
                 // owns the source pixels of the next pyramid level there
                 const int ly0 = crow == 0 ? 0 : ty0 - 3, ly1 = crow == g.ncy - 1 ? g.h : ty1 + 3;
-                const int lx0 = grp == 0 ? 0 : tx0 - 3, lx1 = grp == g.nGroups - 1 ? g.w : tx1 + 3;
+                const int lx0 = grp == 0 ? 0 : tx0 - 3, lx1 = grp == g.nGroups - 1 ? g.w : tx1 + g.rightHalo;
                 t.ty0 = ty0; t.THi = ty1 - ty0; t.ly0 = ly0; t.nRowsL = ly1 - ly0; t.rowOff = ty0 - ly0;
                 t.ax0 = lx0 & ~15; t.lx1 = lx1; t.nV = (lx1 - t.ax0 + 15) >> 4; t.nVec = t.nRowsL * t.nV;
                 t.colOf0 = 16 - t.ax0;  // PF_XO: LDS column 16 holds image column ax0

@@ -37,6 +37,7 @@ struct OrbxLevelGeom {
     int tileRows;          // max rows held in LDS
     int wpc;               // 32-bit words per cell row in the NMS bitmaps
     int rsMaxDx, rsMaxDy;  // max destination columns / rows of the next level produced by one tile
+    int rightHalo;         // columns staged beyond a tile's last interior column when another column group follows (3 = FAST ring; resize: more)
     int gqCap;             // capacity of the pre-test group queue (2 groups per strip, all strips of the tile)
     int ldsBytes;
     // byte offsets of the LDS sub-buffers (the pixel tile starts at 0): score tile, NMS bitmaps (directly behind the score tile: one

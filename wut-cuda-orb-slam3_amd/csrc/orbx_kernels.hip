@@ -444,6 +444,9 @@ extern "C" int orbx_debug_pf_timing(unsigned long long *out) { return (int)hipMe
 #endif
 // DBG: the ablation mask / stop points of PyrFastArgs::phases (ORBX_PF_PHASES) are compiled in.  They are seven more wave-uniform
 // conditions that stay live through the FAST rounds (14 SGPRs, all spilled), so the production instance is built without them.
+#ifndef PF_RESIZE_PACK_SDWA
+#define PF_RESIZE_PACK_SDWA 1
+#endif
 // ML (multi-level): FAST / NMS / ordered candidates of ALL levels of a (small) batch in one launch - the pyramid exists already
 // (k_resize_level chain), the per-level argument blocks (the same PyrFastArgs the per-level launches take, with dst = NULL) lie in a
 // device array and are read like the kernarg segment, through the constant address space (DESIGN 6 "One frame at a time").  The
@@ -624,6 +627,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         if (a.dst && (!DBG || (a.phases & 1))) {
             TileK &t = T();
             const int2 *xt = (const int2 *)(lds + a.g.oXt), *yt = (const int2 *)(lds + a.g.oYt);
+            const uint32_t tileLds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)tile;  // LDS address of the tile
             uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
             const int dstPitch = a.dstPitch;
             const int dx0 = t.dx0, dx1 = t.dx1, dy0 = t.dy0, dy1 = t.dy1;
@@ -635,44 +639,61 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
             const int tt = otid();
             const int rc = nq >= PF_NT ? 0 : (int)(((float)tt + 0.5f) * __builtin_amdgcn_rcpf((float)nq));
             for (int q = q0 + (tt - rc * nq); q < q1 && rc < RC; q += PF_NT) {
+                // Every 4-pixel group is whole: the host puts the boundaries between column groups at multiples of 4 (dx0 = 4 q0; the tile
+                // stages the extra source columns, OrbxLevelGeom::rightHalo) and the last group of a row may run into the row's padding
+                // (dx >= dx1 there: the entry of the last column again).  A lane with a partial group stored byte by byte under four exec
+                // masks, ~17 scalar instructions in every turn of every lane's loop.
                 int ca[4], wa[4], wb[4];
-                bool ok[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int dx = q * 4 + j;
-                    ok[j] = dx >= dx0 && dx < dx1;
-                    const int2 e = xt[min(max(dx, dx0), dx1 - 1) - dx0];
+                    const int2 e = xt[min(q * 4 + j, dx1 - 1) - dx0];
                     ca[j] = e.x;
                     wa[j] = (e.y & 0xFFFF) << 4;   // weights are in [0, 2048]; << 4: the horizontal sum comes out as h << 4 (< 2^24)
                     wb[j] = (e.y >> 16) << 4;
                 }
-                const bool full = ok[0] && ok[3];
 #pragma nounroll
                 for (int dy = dy0 + rc; dy < dy1; dy += RC) {
                     const int2 ye = yt[dy - dy0];
                     const uint32_t b0s = (uint32_t)ye.y, b1s = (2048u << 8) - b0s;  // vertical weights << 8 (the two sum to 2048)
-                    const uint8_t *r0 = tile + (ye.x & 0xFFFF);
-                    const uint8_t *r1 = tile + ((unsigned)ye.x >> 16);
+                    // The 16 taps (2 rows x 4 pixels x 2 neighbouring bytes at an arbitrary address) as hand-written ds_read_u8 pairs with
+                    // offset:0 / offset:1.  Left to the compiler, its load-store vectoriser merges a pair into ONE ds_read_u16 - which the
+                    // LDS executes several times slower when the address is odd (the stage went from 1.66 to 3.56 ms when it started to).
+                    const uint32_t r0 = tileLds + (ye.x & 0xFFFF), r1 = tileLds + ((unsigned)ye.x >> 16);
+                    uint32_t t0[4], t1[4], u0[4], u1[4];   // row 0 left / right tap, row 1 left / right tap
+                    asm volatile("ds_read_u8 %0, %16\n\tds_read_u8 %4, %16 offset:1\n\tds_read_u8 %8, %20\n\tds_read_u8 %12, %20 offset:1\n\t"
+                                 "ds_read_u8 %1, %17\n\tds_read_u8 %5, %17 offset:1\n\tds_read_u8 %9, %21\n\tds_read_u8 %13, %21 offset:1\n\t"
+                                 "ds_read_u8 %2, %18\n\tds_read_u8 %6, %18 offset:1\n\tds_read_u8 %10, %22\n\tds_read_u8 %14, %22 offset:1\n\t"
+                                 "ds_read_u8 %3, %19\n\tds_read_u8 %7, %19 offset:1\n\tds_read_u8 %11, %23\n\tds_read_u8 %15, %23 offset:1\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(t0[0]), "=&v"(t0[1]), "=&v"(t0[2]), "=&v"(t0[3]), "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]),
+                                   "=&v"(u0[0]), "=&v"(u0[1]), "=&v"(u0[2]), "=&v"(u0[3]), "=&v"(u1[0]), "=&v"(u1[1]), "=&v"(u1[2]), "=&v"(u1[3])
+                                 : "v"(r0 + ca[0]), "v"(r0 + ca[1]), "v"(r0 + ca[2]), "v"(r0 + ca[3]), "v"(r1 + ca[0]), "v"(r1 + ca[1]),
+                                   "v"(r1 + ca[2]), "v"(r1 + ca[3])
+                                 : "memory");
                     uint32_t packed = 0;
+                    const uint32_t two = sw_opaque(2u);  // (SDWA takes no inline constant)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // cv::resize: ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2 >> 2 with h = S[sx] * a0 + S[sx + 1] * a1.
                         // Every factor is below 2^24, so the 24-bit multipliers do: h << 4 directly from the pre-shifted weights
                         // (v_mul_u32_u24 + v_mad_u32_u24), and (b * (h >> 4)) >> 16 = ((b << 8) * ((h >> 4) << 8)) >> 32 = ONE v_mul_hi_u32_u24
                         // on (h << 4) & ~0xFF.  v_mul_lo_u32, which the compiler emits for the plain expression, issues at ~8 cycles.
-                        const uint32_t h0 = __umul24(r0[ca[j]], (uint32_t)wa[j]) + __umul24(r0[ca[j] + 1], (uint32_t)wb[j]);
-                        const uint32_t h1 = __umul24(r1[ca[j]], (uint32_t)wa[j]) + __umul24(r1[ca[j] + 1], (uint32_t)wb[j]);
-                        // <= 255: the weights of each axis sum to 2048
-                        const uint32_t v = (mul_hi_u24(h0 & 0xFFFFFF00u, b0s) + mul_hi_u24(h1 & 0xFFFFFF00u, b1s) + 2u) >> 2;
-                        packed |= v << (8 * j);
+                        const uint32_t h0 = __umul24(t0[j], (uint32_t)wa[j]) + __umul24(t1[j], (uint32_t)wb[j]);
+                        const uint32_t h1 = __umul24(u0[j], (uint32_t)wa[j]) + __umul24(u1[j], (uint32_t)wb[j]);
+                        // <= 255 after the shift: the weights of each axis sum to 2048
+                        const uint32_t s2 = mul_hi_u24(h0 & 0xFFFFFF00u, b0s) + mul_hi_u24(h1 & 0xFFFFFF00u, b1s) + 2u;  // <= 1022
+#if PF_RESIZE_PACK_SDWA
+                        // byte j of `packed` = s2 >> 2, written in place by the shift itself (SDWA destination select, the other bytes
+                        // preserved): one instruction per pixel instead of shift + shift-add + mask + or
+                        if (j == 0) packed = s2 >> 2;
+                        else if (j == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(two), "v"(s2));
+                        else if (j == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(two), "v"(s2));
+                        else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(two), "v"(s2));
+#else
+                        packed |= (s2 >> 2) << (8 * j);
+#endif
                     }
-                    uint8_t *drow = dstF + (size_t)dy * dstPitch + q * 4;
-                    if (full) *(uint32_t *)drow = packed;
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (ok[j]) drow[j] = (uint8_t)(packed >> (8 * j));
-                    }
+                    *(uint32_t *)(dstF + (uint32_t)(dy * dstPitch + q * 4)) = packed;
                 }
             }
         }
