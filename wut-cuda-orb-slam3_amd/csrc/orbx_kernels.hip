@@ -444,6 +444,9 @@ extern "C" int orbx_debug_pf_timing(unsigned long long *out) { return (int)hipMe
 #endif
 // DBG: the ablation mask / stop points of PyrFastArgs::phases (ORBX_PF_PHASES) are compiled in.  They are seven more wave-uniform
 // conditions that stay live through the FAST rounds (14 SGPRs, all spilled), so the production instance is built without them.
+#ifndef PF_DUMMY_SALU
+#define PF_DUMMY_SALU 0
+#endif
 #ifndef PF_RESIZE_PACK_SDWA
 #define PF_RESIZE_PACK_SDWA 1
 #endif
@@ -601,12 +604,14 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         if (doResize) {
             int2 *xt = (int2 *)(lds + a.g.oXt), *yt = (int2 *)(lds + a.g.oYt);
             const int colOf0 = t.colOf0, hm1 = a.g.h - 1;
+            const uint32_t tileLdsA = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)tile;  // LDS address of the tile (< 64 K)
             auto xEntry = [&](int sx, int w2) { return make_int2(sx + colOf0, w2); };  // the right tap is always the next LDS column: where
                                                                                       // cv::resize clamps sx to w - 1 its weight is 0
-            auto yEntry = [&](int sy, int w2) {  // LDS byte offsets of the two source rows
+            auto yEntry = [&](int sy, int w2) {
                 const int sy0 = min(max(sy, 0), hm1) - ly0, sy1 = min(max(sy + 1, 0), hm1) - ly0;
-                // .y = the first row's weight b0 << 8, ready for v_mul_hi_u32_u24 (phase 1); b1 = 2048 - b0 (cv::resize: the two sum to 2048)
-                return make_int2((sy0 * tp) | ((sy1 * tp) << 16), (w2 & 0xFFFF) << 8);
+                // .x = the LDS addresses of the two rows (16 bits each), .y = the first row's weight b0 << 8, ready for v_mul_hi_u32_u24
+                // (phase 1); b1 = 2048 - b0 (cv::resize: the two sum to 2048)
+                return make_int2((int)((tileLdsA + sy0 * tp) | ((tileLdsA + sy1 * tp) << 16)), (w2 & 0xFFFF) << 8);
             };
             const int i0 = otid();
             if (i0 < ndx) xt[i0] = xEntry(xo_, xw_);
@@ -627,7 +632,6 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         if (a.dst && (!DBG || (a.phases & 1))) {
             TileK &t = T();
             const int2 *xt = (const int2 *)(lds + a.g.oXt), *yt = (const int2 *)(lds + a.g.oYt);
-            const uint32_t tileLds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)tile;  // LDS address of the tile
             uint8_t *dstF = a.dst + (size_t)f * a.dstFrameStride;
             const int dstPitch = a.dstPitch;
             const int dx0 = t.dx0, dx1 = t.dx1, dy0 = t.dy0, dy1 = t.dy1;
@@ -651,6 +655,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                     wa[j] = (e.y & 0xFFFF) << 4;   // weights are in [0, 2048]; << 4: the horizontal sum comes out as h << 4 (< 2^24)
                     wb[j] = (e.y >> 16) << 4;
                 }
+                const uint32_t two = sw_opaque(2u);  // (SDWA takes no inline constant)
 #pragma nounroll
                 for (int dy = dy0 + rc; dy < dy1; dy += RC) {
                     const int2 ye = yt[dy - dy0];
@@ -658,7 +663,9 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                     // The 16 taps (2 rows x 4 pixels x 2 neighbouring bytes at an arbitrary address) as hand-written ds_read_u8 pairs with
                     // offset:0 / offset:1.  Left to the compiler, its load-store vectoriser merges a pair into ONE ds_read_u16 - which the
                     // LDS executes several times slower when the address is odd (the stage went from 1.66 to 3.56 ms when it started to).
-                    const uint32_t r0 = tileLds + (ye.x & 0xFFFF), r1 = tileLds + ((unsigned)ye.x >> 16);
+                    // LDS addresses of the two source rows (opaque: folded into the eight address additions as SDWA word selects they
+                    // make every one of them a slow-class instruction)
+                    const uint32_t r0 = sw_opaque((uint32_t)ye.x & 0xFFFFu), r1 = sw_opaque((uint32_t)ye.x >> 16);
                     uint32_t t0[4], t1[4], u0[4], u1[4];   // row 0 left / right tap, row 1 left / right tap
                     asm volatile("ds_read_u8 %0, %16\n\tds_read_u8 %4, %16 offset:1\n\tds_read_u8 %8, %20\n\tds_read_u8 %12, %20 offset:1\n\t"
                                  "ds_read_u8 %1, %17\n\tds_read_u8 %5, %17 offset:1\n\tds_read_u8 %9, %21\n\tds_read_u8 %13, %21 offset:1\n\t"
@@ -671,7 +678,6 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
                                    "v"(r1 + ca[2]), "v"(r1 + ca[3])
                                  : "memory");
                     uint32_t packed = 0;
-                    const uint32_t two = sw_opaque(2u);  // (SDWA takes no inline constant)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // cv::resize: ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2 >> 2 with h = S[sx] * a0 + S[sx + 1] * a1.
@@ -701,6 +707,12 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
 
     PF_STAMP(3);
     if (DBG && (K().phases >> 4) == 3) return;
+#if PF_DUMMY_SALU
+    {   // calibration (tools/experiments): what N more scalar ALU instructions per wave cost the kernel
+        unsigned dummy = 0;
+        asm volatile(".rept %1\n\ts_add_u32 %0, %0, 1\n\t.endr" : "+s"(dummy) : "n"(PF_DUMMY_SALU));
+    }
+#endif
     // ---- phase 2: FAST-9/16 + cell-local NMS, in the reference's two rounds -----------------------------------------------
     // round 0: threshold iniThFAST everywhere; round 1: threshold minThFAST, only in cells that produced no keypoint
     // in round 0 (tileCalcKeypoints :908-925).  Each round: (A) 4-point pre-test on 8-pixel strips -> LDS queue of
