@@ -666,15 +666,28 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                 const int lx0 = grp == 0 ? 0 : tx0 - 3, lx1 = grp == g.nGroups - 1 ? g.w : tx1 + g.rightHalo;
                 t.ty0 = ty0; t.THi = ty1 - ty0; t.ly0 = ly0; t.nRowsL = ly1 - ly0; t.rowOff = ty0 - ly0;
                 t.ax0 = lx0 & ~15; t.lx1 = lx1; t.nV = (lx1 - t.ax0 + 15) >> 4; t.nVec = t.nRowsL * t.nV;
+                auto magic20 = [](int n, int range) {  // ceil(2^20 / n) if it divides every i <= range exactly, else 0
+                    if (n <= 0) return 0;
+                    const unsigned m = ((1u << 20) + (unsigned)n - 1) / (unsigned)n;
+                    for (int i = 0; i <= range; ++i)
+                        if ((int)(((unsigned)i * m) >> 20) != i / n) return 0;
+                    return (int)m;
+                };
+
                 t.colOf0 = 16 - t.ax0;  // PF_XO: LDS column 16 holds image column ax0
                 t.cInt0 = tx0 + t.colOf0; t.cInt1 = tx1 + t.colOf0;
                 t.nCells = c1 - c0; t.TWi = tx1 - tx0;
                 t.s0 = (t.cInt0 - 4) >> 3; t.NS = ((t.cInt1 - 1 - 4) >> 3) - t.s0 + 1;
+                t.nVMagic = magic20(t.nV, 1023);
+                if (!t.nVMagic) return setError(ORBX_ERR_INVALID_ARG, "internal: level %d: no 20-bit reciprocal for %d vectors per tile row", l, t.nV);
                 t.RC = 1;
                 if (rowBeg) {
                     t.dy0 = rowBeg[crow]; t.dy1 = rowBeg[crow + 1]; t.dx0 = colBeg[grp]; t.dx1 = colBeg[grp + 1];
                     t.q0 = t.dx0 >> 2; t.nq = ((t.dx1 + 3) >> 2) - t.q0;
                     t.RC = t.nq > 0 ? std::max(1, orbxPyrFastThreads() / t.nq) : 1;  // resize row classes: 512 lanes over (row class, 4-pixel group)
+                    t.nqMagic = t.nq > 0 && t.nq < orbxPyrFastThreads() ? magic20(t.nq, 511) : 0;
+                    if (t.nq > 0 && t.nq < orbxPyrFastThreads() && !t.nqMagic)
+                        return setError(ORBX_ERR_INVALID_ARG, "internal: level %d: no 20-bit reciprocal for %d pixel groups per row", l, t.nq);
                 }
             }
         const int *ri = (const int *)recs.data();

@@ -66,7 +66,10 @@ struct OrbxPfTile {
     int s0, NS;            // first 8-pixel strip, number of strips (strip s covers LDS columns [8 s + 4, 8 s + 12))
     int dx0, dx1;          // destination columns of the next level owned by this group
     int q0, nq, RC;        // resize: first 4-pixel group of a destination row, groups, row classes (512 / nq)
-    int pad[9];
+    // 20-bit reciprocals, ceil(2^20 / n): i / n = (i * magic) >> 20, checked by the host for the range the kernel uses them on
+    int nVMagic;           // nV, i < 1024 (the first two staging passes)
+    int nqMagic;           // nq, i < 512 (a thread's row class in the resize phase); 0 when nq >= 512
+    int pad[7];
 };
 static_assert(sizeof(OrbxPfTile) == 128, "OrbxPfTile is read with aligned scalar loads");
 

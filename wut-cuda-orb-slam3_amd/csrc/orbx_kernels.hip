@@ -526,16 +526,20 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
         uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;  // (two named registers sets: an array here ends up in scratch)
         int tvOff0 = -1, tvOff1 = -1;
         if (a.srcAlign == 16) {
+            // vector it = r * nV + c of the tile: r by a 20-bit reciprocal (the tile record's; exact below 1024), every product on the 24-bit
+            // multiplier, and a 32-bit offset from the frame's uniform base (a frame is < 2 GB): converted through float with 32-bit
+            // multiplies and a 64-bit address per lane this was ~60 issue cycles per load, in front of the kernel's first memory access
             const int it0 = otid(), it1 = it0 + PF_NT;
+            const uint32_t nVM = (uint32_t)t.nVMagic, rowBase = (uint32_t)(ly0 * a.srcPitch + ax0);
             if (it0 < nVec) {
-                const int r = (int)(((float)it0 + 0.5f) * invNV), c = it0 - r * nV;
-                tv0 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
-                tvOff0 = r * tp + PF_XO + c * 16;
+                const uint32_t r = __umul24((uint32_t)it0, nVM) >> 20, c = (uint32_t)it0 - __umul24(r, (uint32_t)nV);
+                tv0 = *(const uint4 *)(srcF + (rowBase + __umul24(r, (uint32_t)a.srcPitch) + c * 16));
+                tvOff0 = (int)(__umul24(r, (uint32_t)tp) + PF_XO + c * 16);
             }
             if (it1 < nVec) {
-                const int r = (int)(((float)it1 + 0.5f) * invNV), c = it1 - r * nV;
-                tv1 = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
-                tvOff1 = r * tp + PF_XO + c * 16;
+                const uint32_t r = __umul24((uint32_t)it1, nVM) >> 20, c = (uint32_t)it1 - __umul24(r, (uint32_t)nV);
+                tv1 = *(const uint4 *)(srcF + (rowBase + __umul24(r, (uint32_t)a.srcPitch) + c * 16));
+                tvOff1 = (int)(__umul24(r, (uint32_t)tp) + PF_XO + c * 16);
             }
         }
         int xo_ = 0, xw_ = 0, yo_ = 0, yw_ = 0;  // first table entries of this thread
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<M
             // row a wave-per-row mapping left 20 - 30 % of the lanes idle; here RC = 512 / nq row classes use all but 512 mod nq lanes.
             // (Rows wider than 2048 pixels fall back to several groups per lane.)
             const int tt = otid();
-            const int rc = nq >= PF_NT ? 0 : (int)(((float)tt + 0.5f) * __builtin_amdgcn_rcpf((float)nq));
+            const int rc = nq >= PF_NT ? 0 : (int)(__umul24((uint32_t)tt, (uint32_t)t.nqMagic) >> 20);  // tt / nq (the tile record's reciprocal)
             for (int q = q0 + (tt - rc * nq); q < q1 && rc < RC; q += PF_NT) {
                 // Every 4-pixel group is whole: the host puts the boundaries between column groups at multiples of 4 (dx0 = 4 q0; the tile
                 // stages the extra source columns, OrbxLevelGeom::rightHalo) and the last group of a row may run into the row's padding
