@@ -469,17 +469,22 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         // target interior width of a tile: wide tiles for throughput (fewer halo re-reads, less fixed cost per pixel); handles for small
         // batches take narrow ones - a single frame is latency-bound, its launches should be many short workgroups
         static const int tileWEnv = [] { const char *e = getenv("ORBX_TILE_W"); return e ? atoi(e) : 0; }();
-        const int tileW = tileWEnv > 0 ? tileWEnv : (ex->prm.max_batch <= ORBX_GRAPH_MAX_FRAMES ? 108 : 288);
+        // (round 4: 360 instead of 288 - with the kernel's loops shorter, what a WAVE does once weighs more (~300 scalar instructions of
+        // geometry per wave, 10 % of the kernel), and wider tiles mean fewer waves per pixel: c2 1.59 -> 1.55 ms, c4 1.38 -> 1.33, c3 - 1 %,
+        // c5 unchanged; three workgroups of <= 53 KB per CU instead of four of <= 40 KB - tools/experiments/pf_tile_cfg_r4.sh)
+        const int tileW = tileWEnv > 0 ? tileWEnv : (ex->prm.max_batch <= ORBX_GRAPH_MAX_FRAMES ? 108 : 360);
         // cells are 35 .. 69 px high (height / nRows): beyond the usual 35 .. 40 rows keep the tile area - and with it the LDS
         // footprint - about constant
         const int tileWl = std::max(g.wCell, tileW * 40 / std::max(g.hCell, 40));
         int gmax = std::max(1, tileWl / g.wCell);
         g.nGroups = (g.ncx + gmax - 1) / gmax;
         g.groupCells = (g.ncx + g.nGroups - 1) / g.nGroups;
-        // four workgroups per CU need <= 40 KB of LDS each (160 KB; a fifth of the levels of the bench workloads sat just above that and
-        // ran three per CU): give up to two cells of tile width for it - an estimate of the layout below with the resize tables at their
-        // nominal size; narrower than that the fixed cost per tile weighs more than the fourth workgroup
-        static const bool ldsFit = [] { const char *e = getenv("ORBX_PF_LDS_FIT"); return e ? atoi(e) != 0 : true; }();
+        // three workgroups per CU need <= 53 KB of LDS each (160 KB; rounds 2 - 3: four of <= 40 KB): give up to two cells of tile width
+        // for it - an estimate of the layout below with the resize tables at their nominal size; narrower than that the fixed cost per
+        // tile weighs more than the next workgroup
+        // ORBX_PF_LDS_FIT: 0 no fit; 1 (default) three workgroups per CU; > 1024: that many bytes per workgroup (40448 = four per CU, the
+        // fit of rounds 2 - 3)
+        static const int ldsFit = [] { const char *e = getenv("ORBX_PF_LDS_FIT"); return e ? atoi(e) : 1; }();
         if (ldsFit && tileWEnv <= 0 && ex->prm.max_batch > ORBX_GRAPH_MAX_FRAMES) {
             auto estimate = [&](int cells) {  // the LDS layout below for `cells` cells per group (resize tables at their nominal size)
                 const int tw = cells * g.wCell, ng = (g.ncx + cells - 1) / cells;
@@ -492,7 +497,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                 return rows * tp + (g.hCell + 2) * sp + roundUp((size_t)cells * g.hCell * ((g.wCell + 31) / 32) * 4, 16) +
                        roundUp(std::max((dx + dy) * 8, (size_t)2048), 16) + gq * 2 + roundUp((size_t)tw, 16);
             };
-            const size_t limit = 40960 - 512;  // (static LDS of the kernel, allocation granularity)
+            const size_t limit = ldsFit > 1024 ? (size_t)ldsFit : 160 * 1024 / 3 - 1024;  // (static LDS of the kernel, allocation granularity)
             const int wide = g.groupCells;
             for (int drop = 0; drop <= 2 && wide - drop >= 4; ++drop) {
                 const int ng = (g.ncx + wide - drop - 1) / (wide - drop), balanced = (g.ncx + ng - 1) / ng;
