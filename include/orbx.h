@@ -740,6 +740,20 @@ int orbx_vocabulary_transform_frame(orbx_vocabulary *v, orbx_extractor *ex, int 
 int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extractor *ex, int nframes, int levelsup, int32_t *bow_word, double *bow_value,
                                     int32_t *n_bow, int32_t *fv_node, int32_t *fv_start, int32_t *fv_feature, int32_t *n_fv);
 
+/* ORBmatcher::SearchByBoW for a batch of pairs, device-resident (round 4): Tracking::Relocalization's loop over the candidate keyframes
+ * (reference src/Tracking5.cc:83, SearchByBoW(pKF, mCurrentFrame, vvpMapPointMatches[i]): keyframe_pair = 0, semantics of orbx_search_by_bow)
+ * and LoopClosing's loop over the covisible keyframes of a candidate (src/LoopClosing1.cc:662, SearchByBoW(mpCurrentKF, vpCovKFi[j], ..):
+ * keyframe_pair = 1, semantics of orbx_search_by_bow_keyframes).  Both sides of pair k are frames of `ex`'s last batch - kf_frames[k] the
+ * keyframe (first keyframe), f_frames[k] the frame (second keyframe) - with the keypoints and descriptors where the extractor left them and
+ * the FeatureVectors of the last orbx_vocabulary_transform_batch(voc, ex, ..) call, which must have covered them.  d_valid [nframes][cap]
+ * bytes on the device: the map point of keypoint i of frame f exists and is not bad (read for the keyframe side; for both sides when
+ * keyframe_pair = 1); cap = orbx_max_keypoints(ex) <= 65535.  Outputs, device: d_matches [npairs][cap] int32 - keyframe_pair = 0: by
+ * frame feature, the keyframe feature whose map point it takes; 1: by feature of the first keyframe, the feature of the second - entries
+ * beyond the frame's keypoint count stay -1; d_nmatches [npairs].  Two launches for all pairs, asynchronous on the matcher's stream. */
+int orbx_search_by_bow_frames(orbx_matcher *m, orbx_vocabulary *voc, orbx_extractor *ex, const int32_t *kf_frames, const int32_t *f_frames,
+                              int npairs, int keyframe_pair, const uint8_t *d_valid, float nnratio, int check_orientation, void *d_matches,
+                              void *d_nmatches);
+
 /* The same search for ONE keyframe against a list of neighbours, device-resident (round 4): LocalMapping::CreateNewMapPoints' matcher call
  * (reference src/LocalMapping.cc:466, inside the loop over vpNeighKFs).  Keyframes = frames of `ex`'s last batch (single camera, NLeft == -1);
  * their mvKeysUn come from Frame::UndistortKeyPoints on the device (k4 / dist / knew4 as in orbx_undistort_keypoints), their descriptors lie

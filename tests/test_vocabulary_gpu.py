@@ -235,3 +235,60 @@ def test_transform_batch_from_extractor_outputs(pkg):
             assert out[f][key].tobytes() == ref[key].tobytes(), (f, key)
     assert len(out[3]["bow_word"]) == 0 and len(out[0]["bow_word"]) > 50
     voc.close(); ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levelsup", [2, 3])
+def test_search_by_bow_over_candidate_keyframes(pkg, orc, levelsup):
+    """orbx_search_by_bow_frames: the loops of Tracking::Relocalization (SearchByBoW(pKF, mCurrentFrame, ..) per candidate keyframe, reference
+    src/Tracking5.cc:83) and of LoopClosing (SearchByBoW(mpCurrentKF, vpCovKFi[j], ..), src/LoopClosing1.cc:662) as ONE batch of pairs of frames
+    of an extractor batch, with keypoints, descriptors and FeatureVectors where the extractor and the vocabulary left them on the device -
+    per pair the same matches as the single-call oracle on host copies."""
+    import torch
+    from golden_scenarios import vocabulary
+    P = 6
+    shifts = [(0, 0), (9, -6), (-7, 4), (14, 3), (3, 11), (-12, -8)]
+    base = pkg.synth_frame(78, 640, 480)
+    rng = np.random.default_rng(5)
+    imgs = np.stack([np.clip(np.roll(np.roll(base, dy, 0), dx, 1).astype(np.int16) + rng.integers(-3, 4, base.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+                     for dx, dy in shifts])
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=P)
+    d_imgs = torch.from_numpy(imgs).to("cuda:0")
+    ex.extract_batch_device(d_imgs.data_ptr(), P, 640, 480, 640, 640 * 480, (0, 0)); ex.sync()
+    n, _, kk, dd = ex.download_outputs(P)
+    parent, leaf, vdesc, vweight = vocabulary(dd[0, : n[0]])
+    voc = pkg.ORBVocabulary(8, 3, 0, 0, parent=parent, is_leaf=leaf, desc=vdesc, weight=vweight)
+    fvs = voc.transform_batch(ex, P, levelsup=levelsup)
+    cap = ex.capacity
+    valid = np.zeros((P, cap), np.uint8)
+    for f in range(P):
+        valid[f, : n[f]] = rng.random(n[f]) < 0.7
+    m = pkg.ORBmatcher(8192, 8192)
+    # Relocalization: candidate keyframes 1 .. P - 1 against the current frame 0 (+ a repeated candidate, + the frame against itself)
+    kfs = [1, 2, 3, 4, 5, 3, 0]; fs = [0] * len(kfs)
+    nm, mt = m.SearchByBoWFrames(voc, ex, kfs, fs, valid, 0.75, True)
+    total = 0
+    for k, (a, b) in enumerate(zip(kfs, fs)):
+        rn, rm = orc.search_by_bow(fvs[a], kk[a, : n[a]], dd[a, : n[a]], valid[a, : n[a]], fvs[b], kk[b, : n[b]], dd[b, : n[b]], 0.75, True)
+        assert nm[k] == rn and np.array_equal(mt[k, : n[b]], rm), (k, a, b)
+        assert (mt[k, n[b]:] == -1).all()
+        total += rn
+    assert total > 200 and np.array_equal(mt[2], mt[5])
+    # LoopClosing: the current keyframe 0 against covisible keyframes, both sides masked by their map points; no orientation check, ratio 0.8
+    kf1 = [0, 0, 0, 2]; kf2 = [1, 4, 5, 3]
+    nm, mt = m.SearchByBoWFrames(voc, ex, kf1, kf2, valid, 0.8, False, keyframe_pair=True)
+    for k, (a, b) in enumerate(zip(kf1, kf2)):
+        rn, rm = orc.search_by_bow_keyframes(fvs[a], kk[a, : n[a]], dd[a, : n[a]], valid[a, : n[a]], fvs[b], kk[b, : n[b]], dd[b, : n[b]],
+                                             valid[b, : n[b]], 0.8, False)
+        assert nm[k] == rn and np.array_equal(mt[k, : n[a]], rm), (k, a, b)
+    assert nm.sum() > 100
+    # nothing to do; a frame index beyond the batch; a transform of another extractor
+    nm, mt = m.SearchByBoWFrames(voc, ex, [], [], valid)
+    assert len(nm) == 0
+    with pytest.raises(pkg.OrbxError, match="frames"):
+        m.SearchByBoWFrames(voc, ex, [P], [0], valid)
+    ex2 = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=P)
+    ex2.extract_batch_device(d_imgs.data_ptr(), P, 640, 480, 640, 640 * 480, (0, 0)); ex2.sync()
+    with pytest.raises(pkg.OrbxError, match="transform_batch"):
+        m.SearchByBoWFrames(voc, ex2, [1], [0], valid)
+    m.close(); voc.close(); ex.close(); ex2.close()

@@ -53,3 +53,27 @@ for lv in (2, 3):  # levelsup 2: ~100 nodes (ORB-SLAM3 uses 4 of 6 levels: ~100 
     print(f"SearchByBoW(KeyFrame, Frame) {len(k1)} x {len(k2)} features, {len(f1['fv_node'])} nodes: GPU "
           f"{bench(lambda: m.SearchByBoW(f1, k1, d1, valid, f2, k2, d2, 0.7, True)):.3f} ms, "
           f"oracle {bench(lambda: orc.search_by_bow(f1, k1, d1, valid, f2, k2, d2, 0.7, True), 5):.3f} ms")
+
+# the candidate loop of Tracking::Relocalization as ONE batch of device-resident pairs (orbx_search_by_bow_frames) against a loop of single calls
+import torch  # noqa: E402
+from golden_scenarios import vocabulary  # noqa: E402
+P = 21
+base = pkg.synth_frame(78, 752, 480)
+imgs = np.stack([np.clip(np.roll(np.roll(base, int(rng.integers(-12, 13)), 0), int(rng.integers(-16, 17)), 1).astype(np.int16) +
+                         rng.integers(-3, 4, base.shape, dtype=np.int16), 0, 255).astype(np.uint8) for _ in range(P)])
+ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=P)
+d_imgs = torch.from_numpy(imgs).to("cuda:0")
+ex.extract_batch_device(d_imgs.data_ptr(), P, 752, 480, 752, 752 * 480, (0, 0)); ex.sync()
+n, _, kk, dd2 = ex.download_outputs(P)
+pr, lf, vd, vw = vocabulary(dd2[0, : n[0]])
+voc2 = pkg.ORBVocabulary(8, 3, 0, 0, parent=pr, is_leaf=lf, desc=vd, weight=vw)
+fvs = voc2.transform_batch(ex, P, levelsup=2)
+val = np.ones((P, ex.capacity), np.uint8)
+kfs = list(range(1, P)); fs = [0] * (P - 1)
+t_batch = bench(lambda: m.SearchByBoWFrames(voc2, ex, kfs, fs, val, 0.75, True))
+t_loop = bench(lambda: [m.SearchByBoW(fvs[a_], kk[a_, : n[a_]], dd2[a_, : n[a_]], val[a_, : n[a_]], fvs[0], kk[0, : n[0]], dd2[0, : n[0]], 0.75, True)
+                        for a_ in kfs], 5)
+t_orc = bench(lambda: [orc.search_by_bow(fvs[a_], kk[a_, : n[a_]], dd2[a_, : n[a_]], val[a_, : n[a_]], fvs[0], kk[0, : n[0]], dd2[0, : n[0]], 0.75, True)
+                       for a_ in kfs], 3)
+print(f"SearchByBoW, {P - 1} candidate keyframes against one frame ({int(n.mean())} features, {len(fvs[0]['fv_node'])} nodes): one device-resident batch "
+      f"{t_batch:.3f} ms (valid flags up, matches down), {P - 1} single calls with host arrays {t_loop:.3f} ms, oracle 1 thread {t_orc:.3f} ms")

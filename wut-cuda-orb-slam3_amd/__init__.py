@@ -101,6 +101,7 @@ ABI_SYMBOLS = [
     "orbx_search_keyframe_windows_frames",
     "orbx_fuse_frames",
     "orbx_search_for_triangulation_frames",
+    "orbx_search_by_bow_frames",
     "orbx_known_switches",
     "orbx_vocabulary_create",
     "orbx_vocabulary_load_text",
@@ -234,6 +235,8 @@ def load_library() -> ctypes.CDLL:
     for _name in ("orbx_search_keyframe_windows_frames", "orbx_fuse_frames"):
         getattr(lib, _name).argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.orbx_search_by_bow_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p]
+    lib.orbx_search_by_bow_frames.restype = c_int
     lib.orbx_search_for_triangulation_frames.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                          c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.orbx_project_last_frame_points.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_int, c_void_p]
@@ -1063,6 +1066,25 @@ class ORBmatcher:
                                                               int(bool(bOnlyStereo)), int(bool(bCoarse)), int(bool(checkOrientation)),
                                                               c_void_p(m12.data_ptr()), c_void_p(nm.data_ptr())), "orbx_search_for_triangulation_frames")
         return self._download(nm)[:K], self._download(m12)[:K]
+
+    def SearchByBoWFrames(self, voc: "ORBVocabulary", ex: "ORBextractor", kf_frames, f_frames, valid, nnratio: float = 0.75,
+                          checkOrientation: bool = True, keyframe_pair: bool = False):
+        """ORBmatcher::SearchByBoW for pairs of frames of the extractor's last batch, device-resident (orbx_search_by_bow_frames): pair k =
+        (keyframe kf_frames[k], frame f_frames[k]) as in Tracking::Relocalization, or (first, second keyframe) with keyframe_pair=True as in
+        LoopClosing; valid [P, cap] uint8 (the keypoint's map point exists and is not bad).  Returns (nmatches [K], matches [K, cap])."""
+        import torch
+        dev = ex.device
+        cap = ex.capacity
+        a = np.ascontiguousarray(kf_frames, np.int32); b = np.ascontiguousarray(f_frames, np.int32)
+        assert len(a) == len(b)
+        K = len(a)
+        d_v = torch.from_numpy(np.ascontiguousarray(valid, np.uint8)).to(f"cuda:{dev}")
+        mt = self._dev_out((max(K, 1), cap), torch.int32, dev, -1); nm = self._dev_out((max(K, 1),), torch.int32, dev, 0)
+        self._launch_fence(d_v, mt, nm)
+        _check(self._lib.orbx_search_by_bow_frames(self._h, voc._h, ex._h, a.ctypes.data, b.ctypes.data, K, int(bool(keyframe_pair)),
+                                                   c_void_p(d_v.data_ptr()), float(nnratio), int(bool(checkOrientation)), c_void_p(mt.data_ptr()),
+                                                   c_void_p(nm.data_ptr())), "orbx_search_by_bow_frames")
+        return self._download(nm)[:K], self._download(mt)[:K]
 
     @staticmethod
     def _camera(k4, dist, knew4):

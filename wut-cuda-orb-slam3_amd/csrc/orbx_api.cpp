@@ -3824,6 +3824,52 @@ extern "C" int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extracto
     return ORBX_OK;
 }
 
+// ORBmatcher::SearchByBoW for a batch of pairs of frames of `ex`'s last batch, everything where the extractor and the vocabulary left it on
+// the device: Tracking::Relocalization's loop over the candidate keyframes (reference src/Tracking5.cc:83: SearchByBoW(pKF, mCurrentFrame, ..),
+// keyframe_pair = 0) and LoopClosing's loop over the covisible keyframes of a candidate (src/LoopClosing1.cc:662: SearchByBoW(mpCurrentKF,
+// vpCovKFi[j], ..), keyframe_pair = 1).  Two launches for all pairs.
+extern "C" int orbx_search_by_bow_frames(orbx_matcher *m, orbx_vocabulary *voc, orbx_extractor *ex, const int32_t *kf_frames,
+                                         const int32_t *f_frames, int npairs, int keyframe_pair, const uint8_t *d_valid, float nnratio,
+                                         int check_orientation, void *d_matches, void *d_nmatches)
+{
+    ORBX_API_ENTRY;
+    const char *fn = "orbx_search_by_bow_frames";
+    if (!m || !voc || !ex || npairs < 0 || (npairs > 0 && (!kf_frames || !f_frames || !d_valid || !d_matches || !d_nmatches)))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: null argument", fn);
+    if (keyframe_pair != 0 && keyframe_pair != 1) return setError(ORBX_ERR_INVALID_ARG, "%s: keyframe_pair must be 0 or 1", fn);
+    if (ex->prm.device != m->device || voc->device != m->device) return setError(ORBX_ERR_INVALID_ARG, "%s: matcher, vocabulary and extractor must live on the same device", fn);
+    if (voc->batchEx != ex || voc->batchFrames <= 0 || voc->batchCap != ex->maxKeypoints)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: call orbx_vocabulary_transform_batch(voc, ex, ..) on this batch first (its FeatureVectors are read on the device)", fn);
+    const int F = voc->batchFrames, cap = ex->maxKeypoints;
+    if (F > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "%s: the extractor's batch changed since the transform", fn);
+    if (cap > 65535) return setError(ORBX_ERR_CAPACITY, "%s: %d keypoints per frame exceed 65535", fn, cap);
+    std::vector<int> table((size_t)npairs * 4);
+    int maxNfv = 0;
+    for (int k = 0; k < npairs; ++k) {
+        if (kf_frames[k] < 0 || kf_frames[k] >= F || f_frames[k] < 0 || f_frames[k] >= F)
+            return setError(ORBX_ERR_INVALID_ARG, "%s: pair %d is (%d, %d) of %d frames", fn, k, kf_frames[k], f_frames[k], F);
+        table[4 * k] = kf_frames[k]; table[4 * k + 1] = voc->batchNFv[kf_frames[k]];
+        table[4 * k + 2] = f_frames[k]; table[4 * k + 3] = voc->batchNFv[f_frames[k]];
+        if (table[4 * k + 3] > 0) maxNfv = std::max(maxNfv, table[4 * k + 1]);
+    }
+    if (npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t K = (size_t)npairs;
+    int rc;
+    if ((rc = m->d_work.ensure(K * (size_t)cap + 32 * K + 4 * K + 64)) != ORBX_OK) return rc;
+    int *binOf = m->d_work.p, *result = binOf + K * cap, *pairs = result + 32 * K;
+    hipStream_t st = m->stream;
+    if ((rc = orderAfterExtractors(m, ex, ex)) != ORBX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(voc->stream));   // (the transform returned synchronised; a later one on the same vocabulary would have changed batchEx)
+    HIP_TRY(hipMemcpyAsync(pairs, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // (the table is a local vector)
+    HIP_TRY(orbxLaunchSearchByBoWFrames(st, voc->batchFvNode, voc->batchFvStart, voc->batchFvFeature, ex->d_kps.p, ex->d_desc.p,
+                                        (const signed char *)d_valid, cap, pairs, npairs, maxNfv, nnratio, check_orientation != 0, keyframe_pair,
+                                        (int *)d_matches, binOf, result));
+    HIP_TRY(hipMemcpy2DAsync(d_nmatches, sizeof(int), result, 32 * sizeof(int), sizeof(int), K, hipMemcpyDeviceToDevice, st));
+    return orderExtractorsAfter(m, ex, ex);
+}
+
 // int ORBmatcher::SearchForTriangulation(pKF1, pKF2, ..) for ONE keyframe against a list of neighbours, everything where the extractor and the
 // vocabulary left it on the device (LocalMapping::CreateNewMapPoints, reference src/LocalMapping.cc:466 inside the loop over vpNeighKFs):
 // keyframes = frames of `ex`'s last batch, FeatureVectors = the device results of the last orbx_vocabulary_transform_batch(voc, ex, ..).

@@ -169,6 +169,9 @@ hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *k
                                  const uint8_t *kfDesc, const signed char *kfValid, const int *fNode, const int *fStart, const int *fFeat,
                                  int fNfv, const void *fKeys, const uint8_t *fDesc, int nF, int maxNodeF, float nnratio, int checkOri,
                                  int mode, const signed char *fValid, int nOut, int *matches, int *binOf, int *result);
+hipError_t orbxLaunchSearchByBoWFrames(hipStream_t st, const int *fvNode, const int *fvStart, const int *fvFeat, const void *keys,
+                                       const uint8_t *desc, const signed char *valid, int cap, const void *pairs, int npairs, int maxNfv,
+                                       float nnratio, int checkOri, int mode, int *matches, int *binOf, int *result);
 // ORBmatcher::SearchForTriangulation (orbx_match.hip): all pointers are device pointers
 struct OrbxSftHost {
     const int *node1, *start1, *feat1; int nfv1; const void *keys1; const uint8_t *desc1; const signed char *hasMp1; const float *uRight1; int nLeft1, n1;

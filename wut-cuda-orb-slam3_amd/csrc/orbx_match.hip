@@ -3418,13 +3418,13 @@ __device__ __forceinline__ unsigned mt_wave_min_u32(unsigned v)
 // the frame feature's index and both angles - made a node of 200 features take 0.9 ms.)
 #define SBOW_LDS_F 2048   // frame features of a node whose index / angle live in LDS (beyond: global reads)
 #define SBOW_REG_F 4      // chunks of 64 frame features whose descriptors live in registers
-__global__ __launch_bounds__(64) void k_sbow_match(SbowArgs a)
+__device__ __forceinline__ void sbow_match_body(const SbowArgs &a, const int j)
 {
     const int TH_LOW = 50, HISTO_LENGTH = 30;  // reference src/ORBmatcher1.cc:37-39
     extern __shared__ uint8_t taken[];        // per frame feature of this node: already holds a map point
     __shared__ int fReal[SBOW_LDS_F];
     __shared__ float fAng[SBOW_LDS_F];
-    const int j = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int node = a.kfNode[j];
     int lo = 0, hi = a.fNfv;  // the merge of the two maps only ever pairs equal node ids
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.fNode[mid] < node) lo = mid + 1; else hi = mid; }
@@ -3520,7 +3520,35 @@ __global__ __launch_bounds__(64) void k_sbow_match(SbowArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_sbow_finish(SbowArgs a)
+__global__ __launch_bounds__(64) void k_sbow_match(SbowArgs a) { sbow_match_body(a, blockIdx.x); }
+
+// A batch of (keyframe, frame) pairs whose keypoints, descriptors and FeatureVectors lie frame by frame in the extractor's / the vocabulary's
+// device arrays (orbx_search_by_bow_frames): blockIdx.y = pair, its two frame indices and FeatureVector sizes from a device table.
+struct SbowFramesArgs {
+    SbowArgs base;          // arrays of frame 0; matches / binOf / result of pair 0
+    const int4 *pairs;      // [npairs] keyframe-side frame, its FeatureVector nodes, frame-side frame, its nodes
+    long long cap;          // records per frame (keypoints, FeatureVector entries; fv_start: cap + 1)
+};
+__device__ __forceinline__ void sbow_select_pair(SbowArgs &a, const SbowFramesArgs &fa, int k)
+{
+    const int4 e = fa.pairs[k];
+    const size_t c = (size_t)fa.cap, f1 = (size_t)e.x, f2 = (size_t)e.z;
+    a.kfNode += f1 * c; a.kfStart += f1 * (c + 1); a.kfFeat += f1 * c; a.kfNfv = e.y;
+    a.kfKeys += f1 * c; a.kfDesc += f1 * c * 32; a.kfValid += f1 * c;
+    a.fNode += f2 * c; a.fStart += f2 * (c + 1); a.fFeat += f2 * c; a.fNfv = e.w;
+    a.fKeys += f2 * c; a.fDesc += f2 * c * 32;
+    if (a.fValid) a.fValid += f2 * c;
+    a.matches += (size_t)k * c; a.binOf += (size_t)k * c; a.result += 32 * (size_t)k;
+}
+__global__ __launch_bounds__(64) void k_sbow_match_frames(SbowFramesArgs fa)
+{
+    SbowArgs a = fa.base;
+    sbow_select_pair(a, fa, blockIdx.y);
+    if ((int)blockIdx.x >= a.kfNfv) return;
+    sbow_match_body(a, blockIdx.x);
+}
+
+__device__ __forceinline__ void sbow_finish_body(const SbowArgs &a)
 {
     const int HISTO_LENGTH = 30;
     if (!a.checkOri) return;
@@ -3544,6 +3572,13 @@ __global__ __launch_bounds__(256) void k_sbow_finish(SbowArgs a)
     __syncthreads();
     if (threadIdx.x == 0) a.result[0] -= removed;
 }
+__global__ __launch_bounds__(256) void k_sbow_finish(SbowArgs a) { sbow_finish_body(a); }
+__global__ __launch_bounds__(256) void k_sbow_finish_frames(SbowFramesArgs fa)
+{
+    SbowArgs a = fa.base;
+    sbow_select_pair(a, fa, blockIdx.x);
+    sbow_finish_body(a);
+}
 
 hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *kfStart, const int *kfFeat, int kfNfv, const void *kfKeys,
                                  const uint8_t *kfDesc, const signed char *kfValid, const int *fNode, const int *fStart, const int *fFeat,
@@ -3562,6 +3597,32 @@ hipError_t orbxLaunchSearchByBoW(hipStream_t st, const int *kfNode, const int *k
         const size_t lds = ((size_t)std::max(maxNodeF, 1) + 63) & ~(size_t)63;
         hipLaunchKernelGGL(k_sbow_match, dim3(kfNfv), dim3(64), lds, st, a);
         hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
+// `npairs` searches in two launches: frames of one extractor batch (cap records each) with the device FeatureVectors of the vocabulary's
+// last batch transform; pairs[k] = {keyframe-side frame, its FeatureVector nodes, frame-side frame, its nodes} on the device;
+// matches [npairs][cap], binOf [npairs][cap] work, result [npairs][32] ([0] = nmatches)
+hipError_t orbxLaunchSearchByBoWFrames(hipStream_t st, const int *fvNode, const int *fvStart, const int *fvFeat, const void *keys,
+                                       const uint8_t *desc, const signed char *valid, int cap, const void *pairs, int npairs, int maxNfv,
+                                       float nnratio, int checkOri, int mode, int *matches, int *binOf, int *result)
+{
+    if (npairs <= 0) return hipSuccess;
+    SbowFramesArgs fa;
+    SbowArgs &a = fa.base;
+    a.mode = mode; a.fValid = mode == 1 ? valid : nullptr; a.nOut = cap;
+    a.kfNode = fvNode; a.kfStart = fvStart; a.kfFeat = fvFeat; a.kfNfv = 0; a.kfKeys = (const MtKp *)keys; a.kfDesc = desc; a.kfValid = valid;
+    a.fNode = fvNode; a.fStart = fvStart; a.fFeat = fvFeat; a.fNfv = 0; a.fKeys = (const MtKp *)keys; a.fDesc = desc;
+    a.nF = cap; a.nnratio = nnratio; a.checkOri = checkOri; a.matches = matches; a.binOf = binOf; a.result = result;
+    fa.pairs = (const int4 *)pairs; fa.cap = cap;
+    hipError_t e = hipMemsetAsync(result, 0, (size_t)npairs * 32 * sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(matches, 0xFF, (size_t)npairs * cap * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    if (maxNfv > 0) {
+        const size_t lds = ((size_t)std::max(cap, 1) + 63) & ~(size_t)63;   // `taken`: a node holds at most every feature of the frame
+        hipLaunchKernelGGL(k_sbow_match_frames, dim3(maxNfv, npairs), dim3(64), lds, st, fa);
+        hipLaunchKernelGGL(k_sbow_finish_frames, dim3(npairs), dim3(256), 0, st, fa);
     }
     return hipGetLastError();
 }
