@@ -761,7 +761,7 @@ int orbx_search_by_bow_frames(orbx_matcher *m, orbx_vocabulary *voc, orbx_extrac
  * call - which must have covered these frames.  ref_frame = pKF1, neighbours[k] = pKF2 of pair k, geometry[k] (host) its two-view geometry
  * as for the single call; d_has_map_point [nframes][cap] bytes (GetMapPoint(i) != NULL), d_u_right [nframes][cap] or NULL, cap =
  * orbx_max_keypoints(ex).  Outputs, device: d_matches12 [nneigh][cap] (entries >= the keyframe's keypoint count stay -1), d_nmatches
- * [nneigh].  Two launches per neighbour, asynchronous on the matcher's stream; nothing of the keyframes crosses the link. */
+ * [nneigh].  Two launches for all neighbours on the matcher's stream; nothing of the keyframes crosses the link. */
 int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabulary *voc, orbx_extractor *ex, int ref_frame, const int32_t *neighbours,
                                          int nneigh, const float *k4, const float *dist, int ndist, const float *knew4,
                                          const orbx_triangulation_geometry *geometry, const uint8_t *d_has_map_point, const float *d_u_right,

@@ -77,3 +77,19 @@ t_orc = bench(lambda: [orc.search_by_bow(fvs[a_], kk[a_, : n[a_]], dd2[a_, : n[a
                        for a_ in kfs], 3)
 print(f"SearchByBoW, {P - 1} candidate keyframes against one frame ({int(n.mean())} features, {len(fvs[0]['fv_node'])} nodes): one device-resident batch "
       f"{t_batch:.3f} ms (valid flags up, matches down), {P - 1} single calls with host arrays {t_loop:.3f} ms, oracle 1 thread {t_orc:.3f} ms")
+
+# LocalMapping::CreateNewMapPoints: keyframe 0 against its 20 neighbours (orbx_search_for_triangulation_frames: two launches for all of them)
+has = np.zeros((P, ex.capacity), np.uint8)
+k4 = np.float32([458.654, 457.296, 367.215, 248.375])
+Kc = np.array([[k4[0], 0, k4[2]], [0, k4[1], k4[3]], [0, 0, 1]], np.float64)
+tdir = np.array([1.0, 0.3, 0.0]) / np.hypot(1.0, 0.3)
+tx = np.array([[0, -tdir[2], tdir[1]], [tdir[2], 0, -tdir[0]], [-tdir[1], tdir[0], 0]])
+F12 = (np.linalg.inv(Kc).T @ tx @ np.linalg.inv(Kc)).astype(np.float32)
+geoms = [pkg.triangulation_geometry((1e6 * tdir[0], 1e6 * tdir[1]), F12)] * (P - 1)
+sf2 = ex.GetScaleFactors().copy(); s22 = ex.GetScaleSigmaSquares().copy()
+t_batch = bench(lambda: m.SearchForTriangulationFrames(voc2, ex, 0, kfs, k4, np.zeros(0, np.float32), geoms, has))
+va = pkg.keyframe_view(kk[0, : n[0]], dd2[0, : n[0]], has[0, : n[0]], fvs[0], sf2, s22)
+views = [pkg.keyframe_view(kk[a_, : n[a_]], dd2[a_, : n[a_]], has[a_, : n[a_]], fvs[a_], sf2, s22) for a_ in kfs]
+t_loop = bench(lambda: [m.SearchForTriangulation(va, vb, geoms[0]) for vb in views], 5)
+print(f"SearchForTriangulation, one keyframe against {P - 1} neighbours ({int(n.mean())} features): one device-resident batch {t_batch:.3f} ms "
+      f"(flags up, matches down), {P - 1} single calls with host arrays {t_loop:.3f} ms")

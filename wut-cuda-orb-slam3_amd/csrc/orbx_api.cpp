@@ -3873,7 +3873,7 @@ extern "C" int orbx_search_by_bow_frames(orbx_matcher *m, orbx_vocabulary *voc, 
 // int ORBmatcher::SearchForTriangulation(pKF1, pKF2, ..) for ONE keyframe against a list of neighbours, everything where the extractor and the
 // vocabulary left it on the device (LocalMapping::CreateNewMapPoints, reference src/LocalMapping.cc:466 inside the loop over vpNeighKFs):
 // keyframes = frames of `ex`'s last batch, FeatureVectors = the device results of the last orbx_vocabulary_transform_batch(voc, ex, ..).
-// One k_sft_match + finish per neighbour, all asynchronous on the matcher's stream.
+// Two launches for all neighbours (k_sft_match_batch: grid z = neighbour, its argument block - pointers + two-view geometry - from a table).
 extern "C" int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabulary *voc, orbx_extractor *ex, int ref_frame, const int32_t *neighbours,
                                                     int nneigh, const float *k4, const float *dist, int ndist, const float *knew4,
                                                     const orbx_triangulation_geometry *geometry, const uint8_t *d_has_map_point,
@@ -3901,7 +3901,7 @@ extern "C" int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabu
     HIP_TRY(hipSetDevice(m->device));
     const size_t FF = (size_t)F, K = (size_t)nneigh;
     if ((rc = m->d_bKps.ensure(FF * cap)) != ORBX_OK) return rc;
-    if ((rc = m->d_work.ensure(K * (size_t)cap + 32 * K + 64)) != ORBX_OK) return rc;
+    if ((rc = m->d_work.ensure(K * (size_t)cap + 32 * K + K * ((orbxSftArgsBytes() + 3) / 4) + 64 + 8)) != ORBX_OK) return rc;
     if ((rc = m->d_prev.ensure(3 * ORBX_MAX_LEVELS)) != ORBX_OK) return rc;
     orbx_keypoint *kun = m->d_bKps.p;
     int *binOf = m->d_work.p, *result = binOf + K * cap;
@@ -3915,10 +3915,11 @@ extern "C" int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabu
         HIP_TRY(hipMemcpyAsync(kun, ex->d_kps.p, FF * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToDevice, st));
     else
         HIP_TRY(orbxLaunchUndistort(st, ex->d_kps.p, kun, cap, k4, dist, ndist, knew4 ? knew4 : k4, F, cap, cap, ex->d_n.p));
+    std::vector<OrbxSftHost> hs((size_t)nneigh);
     for (int k = 0; k < nneigh; ++k) {
         const int f1 = ref_frame, f2 = neighbours[k];
         const orbx_triangulation_geometry *g = geometry + k;
-        OrbxSftHost h;
+        OrbxSftHost &h = hs[(size_t)k];
         memset(&h, 0, sizeof h);
         h.node1 = voc->batchFvNode + (size_t)f1 * cap; h.start1 = voc->batchFvStart + (size_t)f1 * (cap + 1); h.feat1 = voc->batchFvFeature + (size_t)f1 * cap;
         h.nfv1 = voc->batchNFv[f1];
@@ -3935,7 +3936,13 @@ extern "C" int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabu
         memcpy(h.R, g->R, sizeof h.R); memcpy(h.t, g->t, sizeof h.t);
         h.matches = (int *)d_matches12 + (size_t)k * cap; h.binOf = binOf + (size_t)k * cap; h.result = result + 32 * (size_t)k;
         h.maxPerNode1 = 8;   // (the per-node feature counts are on the device: a fixed second grid dimension, the kernel strides over a node's features)
-        HIP_TRY(orbxLaunchSearchForTriangulation(st, h));
+    }
+    {   // all neighbours in two launches: the argument blocks (pointers into the device arrays + the pair's geometry) go up as one table
+        const size_t tb = orbxSftArgsBytes();
+        std::vector<uint8_t> table(K * tb);
+        uint8_t *dTable = (uint8_t *)(((uintptr_t)(result + 32 * K) + 15) & ~(uintptr_t)15);
+        HIP_TRY(orbxLaunchSearchForTriangulationBatch(st, hs.data(), nneigh, table.data(), dTable, cap));
+        HIP_TRY(hipStreamSynchronize(st));   // (the table is a local vector: its copy must be done before it goes)
     }
     HIP_TRY(hipMemcpy2DAsync(d_nmatches, sizeof(int), result, 32 * sizeof(int), sizeof(int), K, hipMemcpyDeviceToDevice, st));
     return orderExtractorsAfter(m, ex, ex);

@@ -183,6 +183,8 @@ struct OrbxSftHost {
     int maxPerNode1;  // most features of pKF1 under one node (the launch's second dimension)
 };
 hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h);
+size_t orbxSftArgsBytes();
+hipError_t orbxLaunchSearchForTriangulationBatch(hipStream_t st, const OrbxSftHost *h, int n, void *hostTable, void *dTable, int n1);
 hipError_t orbxLaunchKeyframeWindowSearch(hipStream_t st, const void *keys, const uint8_t *desc, const float *uRight, const float *invSigma2,
                                           const int *cellStart, const int *items, float minX, float maxX, float minY, float maxY, const void *pts,
                                           const uint8_t *ptDesc, int np, int chi2, int *bestIdx, int *bestDist, const signed char *blocked = nullptr,

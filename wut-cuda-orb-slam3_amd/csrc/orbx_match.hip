@@ -3650,7 +3650,7 @@ struct SftArgs {
     int *matches, *binOf, *result;
 };
 
-__global__ __launch_bounds__(64) void k_sft_match(SftArgs a)
+__device__ __forceinline__ void sft_match_body(const SftArgs &a)
 {
     const int TH_LOW = 50, HISTO_LENGTH = 30;
     const int j = blockIdx.x, lane = threadIdx.x;
@@ -3735,6 +3735,21 @@ __global__ __launch_bounds__(64) void k_sft_match(SftArgs a)
         }
     }
 }
+__global__ __launch_bounds__(64) void k_sft_match(SftArgs a) { sft_match_body(a); }
+// a batch of pairs (orbx_search_for_triangulation_frames): blockIdx.z = pair, its argument block from a device table
+__global__ __launch_bounds__(64) void k_sft_match_batch(const SftArgs *tab)
+{
+    const SftArgs a = tab[blockIdx.z];
+    if ((int)blockIdx.x >= a.nfv1 || a.nfv2 <= 0) return;
+    sft_match_body(a);
+}
+__global__ __launch_bounds__(256) void k_sft_finish_batch(const SftArgs *tab, int nOut)
+{
+    const SftArgs &t = tab[blockIdx.x];
+    SbowArgs f;
+    f.checkOri = t.checkOri; f.nOut = nOut; f.matches = t.matches; f.binOf = t.binOf; f.result = t.result;
+    sbow_finish_body(f);
+}
 
 hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h)
 {
@@ -3759,6 +3774,46 @@ hipError_t orbxLaunchSearchForTriangulation(hipStream_t st, const OrbxSftHost &h
         memset(&f, 0, sizeof f);
         f.checkOri = h.checkOri; f.nOut = h.n1; f.matches = h.matches; f.binOf = h.binOf; f.result = h.result;
         hipLaunchKernelGGL(k_sbow_finish, dim3(1), dim3(256), 0, st, f);
+    }
+    return hipGetLastError();
+}
+
+static void fillSftArgs(SftArgs &a, const OrbxSftHost &h)
+{
+    memset(&a, 0, sizeof a);
+    a.node1 = h.node1; a.start1 = h.start1; a.feat1 = h.feat1; a.nfv1 = h.nfv1;
+    a.keys1 = (const MtKp *)h.keys1; a.desc1 = h.desc1; a.hasMp1 = h.hasMp1; a.uRight1 = h.uRight1; a.nLeft1 = h.nLeft1;
+    a.node2 = h.node2; a.start2 = h.start2; a.feat2 = h.feat2; a.nfv2 = h.nfv2;
+    a.keys2 = (const MtKp *)h.keys2; a.desc2 = h.desc2; a.hasMp2 = h.hasMp2; a.uRight2 = h.uRight2; a.nLeft2 = h.nLeft2;
+    a.scale2 = h.scale2; a.sigma1 = h.sigma1; a.sigma2 = h.sigma2;
+    memcpy(a.ep, h.ep, sizeof a.ep); memcpy(a.F, h.F, sizeof a.F);
+    a.model = h.model; a.rig = h.rig; a.onlyStereo = h.onlyStereo; a.coarse = h.coarse; a.checkOri = h.checkOri;
+    memcpy(a.camL, h.camL, sizeof a.camL); memcpy(a.camR, h.camR, sizeof a.camR); a.precision = h.precision;
+    memcpy(a.R, h.R, sizeof a.R); memcpy(a.t, h.t, sizeof a.t);
+    a.matches = h.matches; a.binOf = h.binOf; a.result = h.result;
+}
+
+size_t orbxSftArgsBytes() { return sizeof(SftArgs); }
+
+// `n` pairs in two launches.  h[k].matches / result must be rows k of ONE [n][n1] / [n][32] array each (cleared here with one memset
+// each); hostTable: n * orbxSftArgsBytes() bytes of host memory the caller keeps alive until the copy to dTable is done (it synchronises)
+hipError_t orbxLaunchSearchForTriangulationBatch(hipStream_t st, const OrbxSftHost *h, int n, void *hostTable, void *dTable, int n1)
+{
+    if (n <= 0) return hipSuccess;
+    SftArgs *tab = (SftArgs *)hostTable;
+    int maxNfv1 = 0, maxPer = 1;
+    for (int k = 0; k < n; ++k) {
+        fillSftArgs(tab[k], h[k]);
+        if (h[k].nfv2 > 0) maxNfv1 = std::max(maxNfv1, h[k].nfv1);
+        maxPer = std::max(maxPer, h[k].maxPerNode1);
+    }
+    hipError_t e = hipMemcpyAsync(dTable, tab, (size_t)n * sizeof(SftArgs), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(h[0].result, 0, (size_t)n * 32 * sizeof(int), st);
+    if (e == hipSuccess && n1 > 0) e = hipMemsetAsync(h[0].matches, 0xFF, (size_t)n * n1 * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    if (maxNfv1 > 0) {
+        hipLaunchKernelGGL(k_sft_match_batch, dim3(maxNfv1, std::min(maxPer, 1024), n), dim3(64), 0, st, (const SftArgs *)dTable);
+        hipLaunchKernelGGL(k_sft_finish_batch, dim3(n), dim3(256), 0, st, (const SftArgs *)dTable, n1);
     }
     return hipGetLastError();
 }
