@@ -3976,11 +3976,15 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
 #pragma unroll
         for (int q = 0; q < OD_KPB; ++q) {
             const int k = min(k0 + q, cnt - 1);
-            const gptr_t c = (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myRaw >> 32), k) << 32) |
-                                      (unsigned)__builtin_amdgcn_readlane((int)myRaw, k));
             const int rp = __builtin_amdgcn_readlane(myRp, k);
+            // the patch's first dword (row -15, column -15) as a wave-uniform base, the lane's dwords at NON-NEGATIVE 32-bit offsets from it:
+            // a scalar base + a 32-bit vector offset is one addressing mode of the load (per lane 64-bit sums were five quarter-rate
+            // v_lshl_add_u64 and a v_mul_lo_u32 per keypoint)
+            const gptr_t c = (gptr_t)((((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myRaw >> 32), k) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane((int)myRaw, k)) - (unsigned long long)(15 * rp + 15));
+            const uint32_t off0 = __umul24((uint32_t)pr, (uint32_t)rp) + 4u * (uint32_t)pj;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) P[q][it] = *(gdw_t)(c + vv[it] * rp + 4 * pj - 15);
+            for (int it = 0; it < 4; ++it) P[q][it] = *(gdw_t)(c + (off0 + (uint32_t)(8 * it) * (uint32_t)rp));
         }
 #pragma unroll
         for (int q = 0; q < OD_KPB; ++q) {
@@ -4043,7 +4047,7 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         for (int i = 0; i < 3; ++i) {
             const int idx = lane + 64 * i, r = idx >> 2, tc = idx & 3;  // patch row r = 8 * tile row + row in tile, tile column tc
             if (tc < ntx && (r >> 3) < nty)
-                dst[i] = *(const __attribute__((address_space(1))) u32x4 *)(src + (r >> 3) * bp + tc * 128 + (r & 7) * 16);
+                dst[i] = *(const __attribute__((address_space(1))) u32x4 *)(src + (__umul24((uint32_t)(r >> 3), (uint32_t)bp) + (uint32_t)(tc * 128 + (r & 7) * 16)));
         }
     };
 #pragma unroll
@@ -4068,15 +4072,21 @@ __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, Orbx
         if (k + OD_PF < cnt) issue(k + OD_PF, nxt[k % OD_PF]);
         __syncthreads_lds_wave();
         const uint8_t *bc = patch + (yl - (((yl - 18) >> 3) << 3)) * OD_PPITCH + (xl - (((xl - 18) >> 4) << 4));
+        // cvRound(x) = round to nearest even = what adding 1.5 * 2^23 does to a float below 2^22: the sum's bit pattern is 0x4B400000 + round(x)
+        // (two's complement in the mantissa, either sign) - one full-rate v_add_f32 where v_rndne_f32 + v_cvt_i32_f32 are two slow-class
+        // instructions, 16 times per keypoint.  The LDS address (iy << 6) + ix + bc then is (Y << 6) + X + bc - 65 * 0x4B400000 modulo 2^32.
+        const float RM = 12582912.0f;
+        const uint32_t bcm = (uint32_t)(size_t)(__attribute__((address_space(3))) const uint8_t *)bc - 65u * 0x4B400000u;
         int t0[4], t1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)));
-            const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
-            const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
-            const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
-            t0[r] = bc[iy0 * OD_PPITCH + ix0];
-            t1[r] = bc[iy1 * OD_PPITCH + ix1];
+            const uint32_t Y0 = (uint32_t)__float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)), RM));
+            const uint32_t X0 = (uint32_t)__float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)), RM));
+            const uint32_t Y1 = (uint32_t)__float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)), RM));
+            const uint32_t X1 = (uint32_t)__float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)), RM));
+            static_assert(OD_PPITCH == 64, "sample address: row << 6");
+            t0[r] = *(const __attribute__((address_space(3))) uint8_t *)(size_t)((Y0 << 6) + X0 + bcm);
+            t1[r] = *(const __attribute__((address_space(3))) uint8_t *)(size_t)((Y1 << 6) + X1 + bcm);
         }
         unsigned long long word = 0;
 #pragma unroll
