@@ -444,6 +444,9 @@ extern "C" int orbx_debug_pf_timing(unsigned long long *out) { return (int)hipMe
 #endif
 // DBG: the ablation mask / stop points of PyrFastArgs::phases (ORBX_PF_PHASES) are compiled in.  They are seven more wave-uniform
 // conditions that stay live through the FAST rounds (14 SGPRs, all spilled), so the production instance is built without them.
+#ifndef PF_MIN_WAVES
+#define PF_MIN_WAVES 8      // waves per SIMD the register budget is for (8: 64 VGPRs; 6: 80 - measured slower, DESIGN 6 "Round 4")
+#endif
 #ifndef PF_DUMMY_SALU
 #define PF_DUMMY_SALU 0
 #endif
@@ -464,7 +467,7 @@ template <bool ML> struct PyrFastKernArg { typedef PyrFastArgs type; };
 template <> struct PyrFastKernArg<true> { typedef PyrFastLevelsArgs type; };
 
 template <bool DBG, bool ML = false>
-__global__ __launch_bounds__(PF_NT, 8) void k_pyr_fast(typename PyrFastKernArg<ML>::type)
+__global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFastKernArg<ML>::type)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // Scalars are kept PER PHASE.  The kernel has four phases (stage, resize, FAST rounds, emission) and ~60 wave-uniform values
