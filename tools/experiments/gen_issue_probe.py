@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gen_issue_probe.py - writes tools/experiments/issue_probe.hip: one-variable-at-a-time probes of gfx950 vector-instruction ISSUE.
+"""gen_issue_probe.py - writes issue_probe.hip (into --out-dir, default a temp directory; never into the tree): one-variable-at-a-time probes of gfx950 vector-instruction ISSUE.
 
 Question ("what's weak" 2): k_pyr_fast's inner bodies issue at ~3.3 real cycles per vector instruction where their
 instruction classes price out at <= 2.6.  Every kernel below is ONE hand-allocated asm loop (explicit VGPR numbers, so the register
@@ -387,8 +387,22 @@ int main(int argc, char **argv)
     return 0;
 }
 ''')
-    with open(os.path.join(here, "issue_probe.hip"), "w") as f:
+    # the 52 k generated lines are NOT tracked: they are written where they are used (default: a fresh temp directory) and, with
+    # --build, compiled there; tools/experiments/run_issue_probe.sh does both and runs the probe.
+    import argparse, subprocess, tempfile
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out-dir", default=None, help="directory for issue_probe.hip (default: a new temp directory)")
+    ap.add_argument("--build", action="store_true", help="also compile it with hipcc for gfx950")
+    a = ap.parse_args()
+    out = a.out_dir or tempfile.mkdtemp(prefix="issue_probe_")
+    os.makedirs(out, exist_ok=True)
+    hip = os.path.join(out, "issue_probe.hip")
+    with open(hip, "w") as f:
         f.write("\n".join(src))
+    exe = os.path.join(out, "issue_probe")
+    if a.build:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", hip, "-o", exe])
+    print(exe if a.build else hip)
 
 
 if __name__ == "__main__":

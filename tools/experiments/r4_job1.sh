@@ -2,7 +2,7 @@
 # round 4, GPU job 1: issue probes, ring-rate bodies (round-3 formulation vs explicit v_bitop3), parity + bench of the new build
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/r4job1; mkdir -p $o
-timeout -k 10 120 ./tools/experiments/issue_probe > $o/issue_probe.txt 2>&1; echo "issue_probe exit=$?"
+bash tools/experiments/run_issue_probe.sh > $o/issue_probe.txt 2>&1; echo "issue_probe exit=$?"
 cat $o/issue_probe.txt
 for b in ring_rate_r3 ring_rate; do
   timeout -k 10 60 ./tools/experiments/$b > $o/$b.txt 2>&1; cat $o/$b.txt
