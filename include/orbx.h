@@ -388,8 +388,11 @@ int orbx_search_by_projection_points_fisheye_frames(orbx_matcher *m, orbx_extrac
  * The record-taking entry points above stay; these compute the orbx_projection records from world points and a pose, in the reference's
  * own float arithmetic - every +, -, *, / in float and un-fused, in the order Eigen / Sophus evaluate it (3-term sums as x0 + (x1 + x2):
  * Eigen's unrolled redux of a 3-vector; the reference builds with -O3 and no -march, so nothing is contracted), sqrt correctly rounded,
- * 1.0 / z in double narrowed once.  PARITY: bit-equal to the CPU oracle (oracle_project_*); the Eigen evaluation order itself is
- * restated from Eigen's sources, not checked against a build of the reference (Eigen / Sophus are not in this image): "unpinned". */
+ * 1.0 / z in double narrowed once.  libm calls of the reference - atan2f (KannalaBrandt8::project), logf (MapPoint::PredictScale) - are
+ * evaluated with include/orbx_libm.h, glibc 2.35's algorithms restated and PINNED exhaustively against the real libm
+ * (tests/tools/libm_pin.cpp, profiles/r05_libm_pin.txt).  PARITY: bit-equal to the CPU oracle (oracle_project_*), which calls the real libm;
+ * the Eigen evaluation order is restated from Eigen's sources, not checked against a build of the reference (Eigen / Sophus are not in
+ * this image): "unpinned" in that respect only. */
 
 /* GeometricCamera::project(const Eigen::Vector3f &): type 0 = Pinhole (src/CameraModels/Pinhole.cpp:43-49: fx * x / z + cx),
  * type 1 = KannalaBrandt8 (src/CameraModels/KannalaBrandt8.cpp:67-84); p = mvParameters: fx fy cx cy [k0 k1 k2 k3]. */
@@ -422,11 +425,12 @@ int orbx_project_last_frame_points(orbx_matcher *m, const float q_xyzw[4], const
  * Tracking::SearchLocalPoints runs it over the local map (src/Tracking4.cc:700-737) - plus the far-point test at the head of
  * ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &, ..) (src/ORBmatcher1.cc:57-58).  Rcw (row-major 3 x 3), tcw, Ow =
  * Frame::mRcw, mtcw, mOw; bounds = mnMinX, mnMaxX, mnMinY, mnMaxY; log_scale_factor / nlevels = mfLogScaleFactor / mnScaleLevels
- * (MapPoint::PredictScale, src/MapPoint.cc:531-546: ceil(log(mfMaxDistance / dist) / mfLogScaleFactor) in double, clamped).
+ * (MapPoint::PredictScale, src/MapPoint.cc:531-546: ceil(log(mfMaxDistance / dist) / mfLogScaleFactor) in FLOAT - `using namespace std`
+ * reaches MapPoint.cc (MapPoint.h:23 -> .. -> Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:36), so the call is std::log(float) = logf, the
+ * division float / float, std::ceil(float) - then the int conversion and the clamps; pass log_scale_factor = logf(mfScaleFactor)).
  * proj_out[i] = {mTrackProjX, mTrackProjY, mTrackProjXR = uv(0) - mbf * invz, mTrackViewCos, mnTrackScaleLevel, flags} with flags bit 0 =
  * the input bit && mbTrackInView && !(far_points && mTrackDepth > th_far_points) - exactly the record orbx_search_by_projection_points
- * takes.  (log() is the device's double-precision log: it can differ from the host libm's in the last bit, which changes the level only
- * when the quotient lies within 1e-16 of an integer.) */
+ * takes.  (logf is glibc's, restated in include/orbx_libm.h and equal to it on every positive float: the level is the reference's.) */
 int orbx_project_in_frustum(orbx_matcher *m, const float Rcw[9], const float tcw[3], const float Ow[3], const orbx_camera *cam,
                             const float bounds[4], float mbf, float viewing_cos_limit, float log_scale_factor, int nlevels,
                             int far_points, float th_far_points, const orbx_world_point *points, int np, orbx_projection *proj_out);
@@ -675,8 +679,12 @@ int orbx_compute_stereo_matches_frames(orbx_matcher *m, orbx_extractor *left, or
  *   level_sigma2  mvLevelSigma2 (orbx_get_scale_sigma_squares)
  * Outputs: left_to_right[nl] = mvLeftToRightMatch, right_to_left[nr] = mvRightToLeftMatch, depth[nl] = mvDepth (-1: none),
  * p3d[nl][3] = mvStereo3Dpoints (written where depth > 0).  Returns nMatches (>= 0) or a negative status.
- * Floating point: the reference evaluates this with Eigen and libm; the restatement (operation order, double-narrowed transcendental
- * calls, fixed Jacobi sweeps for the null vector) is documented in oracle/orb_oracle.cpp and its parity with Eigen is unpinned. */
+ * Floating point: the reference evaluates this with Eigen and libm.  What is the reference's own arithmetic here: every float operation in
+ * source order with Eigen's 3-term redux x0 + (x1 + x2), atan2f / tanf as glibc computes them (include/orbx_libm.h, pinned exhaustively).
+ * What is TOLERANCE-LEVEL, not bit-equal, against the reference: the null vector of the 4 x 4 system - Eigen::JacobiSVD<Matrix4f> (a float
+ * two-sided Jacobi sweep) is restated as a double-precision one-sided Jacobi iteration (oracle/orb_oracle.cpp), so depth[] and p3d[] agree
+ * with the reference's to a few float ulp times the conditioning of the triangulation, and the match decisions taken from them (positive
+ * depth, reprojection error against 5.991 sigma2) agree away from their thresholds.  Against the CPU oracle all outputs are bit-equal. */
 int orbx_compute_stereo_fisheye_matches(orbx_matcher *m, const orbx_keypoint *kl, const uint8_t *dl, int nl, int mono_left,
                                         const orbx_keypoint *kr, const uint8_t *dr, int nr, int mono_right, const float *cam1,
                                         const float *cam2, float precision, const float *R12, const float *t12,

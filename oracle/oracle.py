@@ -72,6 +72,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_project_in_frustum.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int,
                                                 c_float, c_void_p, c_int, c_void_p]
         L.oracle_project_in_frustum.restype = None
+        L.oracle_predict_scale.argtypes = [c_float, c_float, c_int]
+        L.oracle_predict_scale.restype = c_int
         L.oracle_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p,
                                                   c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_int, c_void_p]
         L.oracle_search_by_projection_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float,
@@ -331,6 +333,11 @@ def project_in_frustum(Rcw, tcw, Ow, cam_type, cam, bounds, mbf, viewing_cos_lim
                                     float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)), float(th_far_points),
                                     pts.ctypes.data, len(pts), out.ctypes.data)
     return out
+
+
+def predict_scale(ratio, log_scale_factor, nlevels):
+    """MapPoint::PredictScale's arithmetic on an already formed float ratio (reference src/MapPoint.cc:538-544)."""
+    return int(lib().oracle_predict_scale(float(np.float32(ratio)), float(np.float32(log_scale_factor)), int(nlevels)))
 
 
 def search_by_projection(kc, dc, cur_state, bounds, scale_factors, proj, proj_desc, th, u_right=None, mbf=0.0, forward=False,

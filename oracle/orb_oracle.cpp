@@ -1709,17 +1709,23 @@ int oracle_search_by_bow_keyframes(const int32_t *node1, const int32_t *start1, 
 // =====================================================================================================================================
 // KannalaBrandt8::TriangulateMatches + Frame::ComputeStereoFishEyeMatches — reference src/CameraModels/KannalaBrandt8.cpp:306-375 (with
 // unproject :116-143, project :67-93, Triangulate :393-406) and src/Frame.cc:1156-1196 (second half).
-// PARITY UNPINNED for the floating-point part: the reference evaluates this with Eigen (float, expression templates, JacobiSVD) and the
-// platform libm (tanf / atan2f / cos / sin), neither of which exists in this image, and the reference holds no vectors for it.  What is
-// restated here, operation by operation, and what the GPU kernel reproduces bit for bit:
-//   * every +, -, *, / of the reference in float, in source order, un-fused; 3-term dot products and matrix-vector rows summed left to right;
-//   * sqrtf correctly rounded; transcendental calls as the double libm function narrowed to float ((float)tan((double)x), atan2, cos, sin);
-//     `cos(psi)` / `sin(psi)` in project() are unqualified there too: taken as ::cos(double), the product kept in double and narrowed
-//     once when it is stored into the Eigen::Vector2f (:81-82);
+// The reference evaluates this with Eigen (float, expression templates, JacobiSVD) and the platform libm (tanf / atan2f / cos / sin); Eigen
+// is not in this image and the reference holds no vectors for it.  What is restated here, operation by operation, and what the GPU kernel
+// reproduces bit for bit:
+//   * every +, -, *, / of the reference in float, in source order, un-fused; 3-term dot products, squared norms and the rows of fixed-size
+//     3 x 3 products as Eigen's unrolled redux x0 + (x1 + x2) (derivation at the projection head below; round 5 - rounds 2-4 summed left
+//     to right);
+//   * sqrtf correctly rounded; `atan2f` (:69-70) and `std::tan(float)` = tanf (:139) are the REAL libm calls here (glibc 2.35) - the GPU
+//     evaluates include/orbx_libm.h, which is pinned to this libm exhaustively (tests/tools/libm_pin.cpp, profiles/r05_libm_pin.txt);
+//     `cos(psi)` / `sin(psi)` in project() are unqualified and no using-directive reaches KannalaBrandt8.cpp (its include chain has none;
+//     g2o's sits in block_solver.hpp, which it does not include): taken as ::cos(double), the product kept in double and narrowed once
+//     when it is stored into the Eigen::Vector2f (:81-82);
 //   * Eigen::JacobiSVD<Matrix4f>(A, ComputeFullV).matrixV().col(3) (:402-404) = the right singular vector of the smallest singular value.
 //     Restated as a one-sided (Hestenes) Jacobi iteration on the columns of A in DOUBLE: cyclic pairs (0,1) (0,2) (0,3) (1,2) (1,3) (2,3),
 //     exactly 12 sweeps, rotation skipped when |a_p . a_q| <= 1e-300; the column with the smallest norm (first one on ties) gives the
-//     vector, narrowed to float.  Its sign cancels in x3D = x3Dh.head(3) / x3Dh(3).
+//     vector, narrowed to float.  Its sign cancels in x3D = x3Dh.head(3) / x3Dh(3).  TOLERANCE-LEVEL against the reference: Eigen's float
+//     two-sided Jacobi sweep cannot be reproduced bit for bit without Eigen; depth / 3-D point agree with a float SVD to a few ulp of the
+//     conditioning, and every decision taken from them (z > 0, the reprojection gates) is the same away from its threshold.
 // =====================================================================================================================================
 static void kb8Unproject(const float *P, float precision, float px, float py, float r[3])
 {
@@ -1738,7 +1744,7 @@ static void kb8Unproject(const float *P, float precision, float px, float py, fl
             theta = theta - theta_fix;
             if (fabsf(theta_fix) < precision) break;
         }
-        scale = (float)tan((double)theta) / theta_d;
+        scale = tanf(theta) / theta_d;                                             // std::tan(float), :139
     }
     r[0] = pwx * scale; r[1] = pwy * scale; r[2] = 1.f;
 }
@@ -1746,15 +1752,16 @@ static void kb8Unproject(const float *P, float precision, float px, float py, fl
 static void kb8Project(const float *P, const float v[3], float uv[2])
 {
     const float x2_plus_y2 = v[0] * v[0] + v[1] * v[1];
-    const float theta = (float)atan2((double)sqrtf(x2_plus_y2), (double)v[2]);
-    const float psi = (float)atan2((double)v[1], (double)v[0]);
+    const float theta = atan2f(sqrtf(x2_plus_y2), v[2]);                           // :69
+    const float psi = atan2f(v[1], v[0]);                                          // :70
     const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
     const float r = theta + P[4] * theta3 + P[5] * theta5 + P[6] * theta7 + P[7] * theta9;
     uv[0] = (float)((double)(P[0] * r) * cos((double)psi) + (double)P[2]);
     uv[1] = (float)((double)(P[1] * r) * sin((double)psi) + (double)P[3]);
 }
 
-static inline float dot3f(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// Eigen's 3-term redux (dot, squaredNorm, a row of a fixed-size 3 x 3 product): x0 + (x1 + x2), see the projection head below
+static inline float dot3f(const float *a, const float *b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
 
 // =====================================================================================================================================
 // Projection head of the two tracking searches: reference src/ORBmatcher3.cc:281-296 (motion model: Sophus::SE3f * point, invzc, project)
@@ -1767,8 +1774,7 @@ static inline float dot3f(const float *a, const float *b) { return a[0] * b[0] +
 //   * Sophus SO3 * p: uv = q.vec().cross(p); uv += uv; return p + q.w() * uv + q.vec().cross(uv); SE3 * p adds the translation;
 //   * all of it in float, un-fused (the reference is built with -O3 and no -march: no FMA contraction); `1.0 / x3Dc(2)` in double,
 //     narrowed by the assignment to `const float invzc`; norm() = std::sqrt(float) correctly rounded.
-// (KannalaBrandt8::TriangulateMatches above sums its 3-term products left to right - written in round 2 before this derivation; both are
-// "unpinned" until the reference can be built.)
+// (KannalaBrandt8::TriangulateMatches above follows the same derivation since round 5.)
 // =====================================================================================================================================
 static inline float sum3e(float x0, float x1, float x2) { return x0 + (x1 + x2); }
 static inline void cross3e(const float *a, const float *b, float *c)
@@ -1783,6 +1789,17 @@ static void cameraProject(int type, const float *P, const float v[3], float uv[2
         uv[0] = P[0] * v[0] / v[2] + P[2];
         uv[1] = P[1] * v[1] / v[2] + P[3];
     } else kb8Project(P, v, uv);
+}
+
+// the float -> int conversion of an out-of-range or NaN value is undefined in C++; x86-64's cvttss2si returns INT_MIN for it, which the
+// first clamp turns into level 0 - restated so (dist == 0 gives ratio = inf; such a point fails the distance test anyway)
+extern "C" int oracle_predict_scale(float ratio, float log_scale_factor, int nlevels)
+{
+    const float lv = std::ceil(std::log(ratio) / log_scale_factor);
+    int nScale = (lv >= -2147483648.0f && lv < 2147483648.0f) ? (int)lv : INT32_MIN;
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nlevels) nScale = nlevels - 1;
+    return nScale;
 }
 
 extern "C" void oracle_project_last_frame_points(const float *q, const float *t, int cam_type, const float *cam, const oracle_world_point *pts, int np,
@@ -1828,11 +1845,11 @@ extern "C" void oracle_project_in_frustum(const float *R, const float *t, const 
         const float *Pn = pts[i].normal;
         const float viewCos = sum3e(PO[0] * Pn[0], PO[1] * Pn[1], PO[2] * Pn[2]) / dist;                               // :584
         if (viewCos < viewing_cos_limit) in = false;                                                                  // :586-587
-        // MapPoint::PredictScale(dist, this): ratio = mfMaxDistance / currentDist; ceil(log(ratio) / mfLogScaleFactor), clamped
+        // MapPoint::PredictScale(dist, pF), src/MapPoint.cc:531-546: `int nScale = ceil(log(ratio) / pF->mfLogScaleFactor)` with float ratio and
+        // float mfLogScaleFactor under `using namespace std` (TemplatedVocabulary.h:36 through MapPoint.h:23): std::log(float) = logf, a float
+        // division, std::ceil(float), then the conversion to int and the two clamps.
         const float ratio = pts[i].max_distance / dist;
-        const double lv = ceil(log((double)ratio) / (double)log_scale_factor);
-        int nScale = lv >= (double)nlevels ? nlevels - 1 : lv < 0.0 ? 0 : (int)lv;
-        if (!(lv == lv)) nScale = 0;
+        const int nScale = oracle_predict_scale(ratio, log_scale_factor, nlevels);
         if (far_points && Pc_dist > th_far_points) in = false;                                                        // src/ORBmatcher1.cc:57-58
         oracle_projection o;
         o.u = uv[0]; o.v = uv[1];

@@ -135,6 +135,10 @@ typedef struct {
  * (cam_type 0 / 1, cam = mvParameters).  out[i] = {uv(0), uv(1), invzc, angle, octave, flags}. */
 void oracle_project_last_frame_points(const float *q_xyzw, const float *t, int cam_type, const float *cam, const oracle_world_point *pts, int np,
                                       oracle_projection *out);
+/* MapPoint::PredictScale (src/MapPoint.cc:514-546; the Frame and the KeyFrame overload are the same arithmetic): ratio = mfMaxDistance /
+ * currentDist (float), nScale = ceil(log(ratio) / mfLogScaleFactor) in FLOAT - std::log(float) = the real logf, float division, std::ceil(float)
+ * - then the int conversion and the clamps to [0, nlevels - 1]. */
+int oracle_predict_scale(float ratio, float log_scale_factor, int nlevels);
 /* Frame::isInFrustum (src/Frame.cc:542-600, Nleft == -1) + MapPoint::PredictScale (src/MapPoint.cc:531-546) + the far-point test of
  * src/ORBmatcher1.cc:57-58; out[i] = {mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos, mnTrackScaleLevel, flags}. */
 void oracle_project_in_frustum(const float *Rcw, const float *tcw, const float *Ow, int cam_type, const float *cam, const float *bounds, float mbf,

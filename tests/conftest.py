@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
+os.environ.setdefault("ORBX_STRICT_ENV", "1")   # a mistyped ORBX_* switch in a test must fail, not silently run the default
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

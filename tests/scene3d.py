@@ -2,6 +2,30 @@
 keypoints are un-projected to random depths with the last pose = identity, and seen again from a current pose a small motion away."""
 import numpy as np
 
+import ctypes
+
+_libm = ctypes.CDLL("libm.so.6")
+_libm.logf.argtypes = [ctypes.c_float]; _libm.logf.restype = ctypes.c_float
+
+
+def libm_logf(x):
+    """The platform's logf - what `log(mfScaleFactor)` (src/Frame.cc:114) and MapPoint::PredictScale's `log(ratio)` resolve to under
+    `using namespace std`; numpy's float32 log is its own SIMD routine and may differ in the last bit."""
+    return np.float32(_libm.logf(float(np.float32(x))))
+
+
+def predict_scale_float(ratio, log_scale_factor, nlevels):
+    """MapPoint::PredictScale (src/MapPoint.cc:538-544) from its definition: logf, a float division, ceil, int, the two clamps."""
+    lv = np.ceil(np.float32(libm_logf(ratio) / np.float32(log_scale_factor)))
+    return int(min(max(int(lv), 0), nlevels - 1)) if np.isfinite(lv) else 0
+
+
+def predict_scale_double(ratio, log_scale_factor, nlevels):
+    """The wrong restatement of rounds 1-4 (log and the division in double) - kept to show that a test's inputs tell the two apart."""
+    lv = np.ceil(np.log(np.float64(np.float32(ratio))) / np.float64(np.float32(log_scale_factor)))
+    return int(min(max(int(lv), 0), nlevels - 1)) if np.isfinite(lv) else 0
+
+
 PINHOLE = (0, (458.654, 457.296, 367.215, 248.375))                                               # EuRoC cam0 (fx fy cx cy)
 KB8 = (1, (190.978477, 190.973307, 254.931706, 256.897442, 0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367))  # TUM-VI cam0
 

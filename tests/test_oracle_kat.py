@@ -3,6 +3,7 @@ tables, umax literal, sampling-pattern hash, Hamming identities, packing rule, O
 import hashlib
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -663,3 +664,40 @@ def test_projection_head_kb8_agrees_with_the_fisheye_model(orc):
     th = np.arctan2(np.hypot(Pf[:, 0], Pf[:, 1]), Pf[:, 2]); psi = np.arctan2(Pf[:, 1], Pf[:, 0])
     r = th + k[4] * th ** 3 + k[5] * th ** 5 + k[6] * th ** 7 + k[7] * th ** 9
     assert np.allclose(out["u"], k[0] * r * np.cos(psi) + k[2], atol=1e-3) and np.allclose(out["v"], k[1] * r * np.sin(psi) + k[3], atol=1e-3)
+
+
+def test_glibc_libm_restatements(tmp_path):
+    """include/orbx_libm.h (what the GPU evaluates for logf / atanf / atan2f / tanf: MapPoint::PredictScale src/MapPoint.cc:538,
+    KannalaBrandt8::project / unproject src/CameraModels/KannalaBrandt8.cpp:69-70,139) against the REAL libm of this host: every 509th float
+    for the one-argument functions, 5 x 4 M argument pairs for atan2f.  The exhaustive run (stride 1, 5 x 10^9 pairs: a minute on 8 cores)
+    is recorded in profiles/r05_libm_pin.txt."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "libm_pin"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "tools", "libm_pin.cpp"), "-o", str(exe), "-lm"])
+    r = subprocess.run([str(exe), "509", "4", "4"], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout and "OK:" in r.stdout, r.stdout
+
+
+def test_predict_scale_is_the_reference_float_arithmetic(orc):
+    """MapPoint::PredictScale (src/MapPoint.cc:531-546): `ceil(log(ratio) / mfLogScaleFactor)` is std::log(float) / float / std::ceil(float)
+    (using namespace std reaches MapPoint.cc through TemplatedVocabulary.h:36).  Inputs: ratio = fl(fl(d * 1.2^l) / d), a map point seen from
+    the distance of its reference observation - where the float and the double evaluation (rounds 1-4) disagree on a tenth of the cases."""
+    import scene3d
+    lsf = scene3d.libm_logf(np.float32(1.2))
+    assert float(lsf).hex() == "0x1.7565060000000p-3"               # the correctly rounded log(1.2f); numpy's float32 log returns ...08p-3
+    rng = np.random.default_rng(5)
+    differ = 0
+    for _ in range(4000):
+        d = np.float32(rng.uniform(0.5, 30.0)); l = int(rng.integers(0, 10))
+        ratio = np.float32(np.float32(d * np.float32(1.2) ** np.float32(l)) / d)
+        want = scene3d.predict_scale_float(ratio, lsf, 8)
+        assert orc.predict_scale(ratio, lsf, 8) == want, (d, l, ratio)
+        differ += want != scene3d.predict_scale_double(ratio, lsf, 8)
+    assert differ > 100                                            # the inputs tell the two evaluations apart
+    for _ in range(2000):                                          # generic ratios
+        ratio = np.float32(rng.uniform(0.2, 6.0))
+        assert orc.predict_scale(ratio, lsf, 8) == scene3d.predict_scale_float(ratio, lsf, 8)
+    # clamps and the degenerate ratios (dist = 0 -> inf, 0 / 0 -> NaN: int conversion as x86-64 does it, INT_MIN -> level 0)
+    assert orc.predict_scale(1e-3, lsf, 8) == 0 and orc.predict_scale(1e6, lsf, 8) == 7 and orc.predict_scale(1.0, lsf, 8) == 0
+    assert orc.predict_scale(float("inf"), lsf, 8) == 0 and orc.predict_scale(float("nan"), lsf, 8) == 0

@@ -9,7 +9,7 @@ import scene3d
 pytestmark = pytest.mark.gpu
 
 BOUNDS = (0.0, 640.0, 0.0, 480.0)
-LOGSF = float(np.log(np.float32(1.2)))   # Frame::mfLogScaleFactor = log(mfScaleFactor) (src/Frame.cc:114)
+LOGSF = float(scene3d.libm_logf(np.float32(1.2)))   # Frame::mfLogScaleFactor = log(mfScaleFactor) (src/Frame.cc:114): the platform's logf
 
 
 def _bits(a):
@@ -62,6 +62,38 @@ def test_in_frustum_head_matches_the_oracle(pkg, orc, cam):
         assert set(np.unique(got["octave"])) <= set(range(8)) and len(np.unique(got["octave"])) >= 3
         causes += had - kept
     assert causes > 100
+    m.close()
+
+
+def test_predict_scale_at_level_boundaries(pkg, orc):
+    """MapPoint::PredictScale (src/MapPoint.cc:531-546) in the reference's FLOAT arithmetic (logf / float divide / ceilf): map points seen from
+    the distance of their reference observation, mfMaxDistance = fl(dist * 1.2^l), so that log(ratio) / mfLogScaleFactor sits on an integer
+    up to rounding - the float and the double evaluation (rounds 1-4) give different levels on a tenth of these.  The device level equals
+    the oracle's AND a restatement from the definition over the platform's logf."""
+    cam = scene3d.PINHOLE
+    rng = np.random.default_rng(77)
+    n = 20000
+    pts = np.zeros(n, pkg.WORLD_POINT_DTYPE)
+    z = rng.uniform(1.0, 20.0, n)
+    pts["pos"] = np.stack([rng.uniform(-0.5, 0.5, n) * z, rng.uniform(-0.4, 0.4, n) * z, z], -1).astype(np.float32)
+    pts["normal"] = pts["pos"] / np.linalg.norm(pts["pos"], axis=1, keepdims=True)
+    pts["flags"] = 1
+    # dist exactly as the head forms it (Ow = 0): sqrtf(x0 + (x1 + x2)) of float squares
+    P = pts["pos"]
+    sq = (P * P).astype(np.float32)
+    dist = np.sqrt((sq[:, 0] + (sq[:, 1] + sq[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    lev = rng.integers(0, 10, n)
+    pts["max_distance"] = (dist * (np.float32(1.2) ** lev.astype(np.float32)).astype(np.float32)).astype(np.float32)
+    pts["min_distance"] = 0.0
+    m = pkg.ORBmatcher(32768, 64)
+    got = m.ProjectInFrustum(np.eye(3), [0, 0, 0], [0, 0, 0], cam[0], cam[1], (-1e9, 1e9, -1e9, 1e9), 0.0, 0.5, LOGSF, 8, pts)
+    ref = orc.project_in_frustum(np.eye(3), [0, 0, 0], [0, 0, 0], cam[0], cam[1], (-1e9, 1e9, -1e9, 1e9), 0.0, 0.5, LOGSF, 8, pts)
+    assert np.array_equal(_bits(got), _bits(ref))
+    ratio = (pts["max_distance"] / dist).astype(np.float32)
+    want = np.array([scene3d.predict_scale_float(r, LOGSF, 8) for r in ratio])
+    wrong = np.array([scene3d.predict_scale_double(r, LOGSF, 8) for r in ratio])
+    assert np.array_equal(got["octave"], want)
+    assert (want != wrong).sum() > 500           # these inputs tell the two evaluations apart
     m.close()
 
 

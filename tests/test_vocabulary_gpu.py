@@ -291,4 +291,15 @@ def test_search_by_bow_over_candidate_keyframes(pkg, orc, levelsup):
     ex2.extract_batch_device(d_imgs.data_ptr(), P, 640, 480, 640, 640 * 480, (0, 0)); ex2.sync()
     with pytest.raises(pkg.OrbxError, match="transform_batch"):
         m.SearchByBoWFrames(voc, ex2, [1], [0], valid)
+    # the SAME extractor runs another batch of the same size after the transform: the cached FeatureVectors no longer belong to its keypoints
+    # (round 4 accepted this silently and paired old feature indices with new descriptors) - refused until the batch is transformed again
+    d_imgs2 = torch.from_numpy(np.ascontiguousarray(imgs[::-1])).to("cuda:0")
+    ex.extract_batch_device(d_imgs2.data_ptr(), P, 640, 480, 640, 640 * 480, (0, 0)); ex.sync()
+    with pytest.raises(pkg.OrbxError, match="another batch"):
+        m.SearchByBoWFrames(voc, ex, [1], [0], valid)
+    fvs2 = voc.transform_batch(ex, P, levelsup=levelsup)
+    n2, _, kk2, dd2 = ex.download_outputs(P)
+    nm, mt = m.SearchByBoWFrames(voc, ex, [1], [0], valid, 0.75, True)
+    rn, rm = orc.search_by_bow(fvs2[1], kk2[1, : n2[1]], dd2[1, : n2[1]], valid[1, : n2[1]], fvs2[0], kk2[0, : n2[0]], dd2[0, : n2[0]], 0.75, True)
+    assert nm[0] == rn and np.array_equal(mt[0, : n2[0]], rm)
     m.close(); voc.close(); ex.close(); ex2.close()

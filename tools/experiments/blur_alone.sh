@@ -1,6 +1,7 @@
 #!/bin/bash
 # GaussianBlur and quadtree stage times of a workload (CFG, default c2) together, and each (nearly) alone: ORBX_QT_STOP=1 cuts the
 # quadtree short after its gather (timing only - the keypoints are wrong), ORBX_NO_BLUR=1 skips the blur launches.
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/blur
 for mode in both blur_alone qt_alone; do

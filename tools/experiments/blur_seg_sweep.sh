@@ -1,5 +1,6 @@
 #!/bin/bash
 # The blur's rows per workgroup (ORBX_BLUR_SEG = 4 / 8 blocks of 16 rows) and width (ORBX_BLUR_WAVES = 4 / 8 strips of 16 columns) over the workloads
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/blurseg
 for cfg in ${CFGS:-c2 c3 c4 c5}; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # k_pyr_fast chain cut into groups of frames on streams of their own (ORBX_FRONT_PARTS), staggered by one level or not (ORBX_FRONT_STAGGER)
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/fparts
 for cfg in "1 1" "2 1" "2 0" "3 1" "4 1"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # k_pyr_fast: queue slots of the pre-test by per-lane LDS atomics (ORBX_PF_LANE_ALLOC=1) against ballot prefix counts: parity + stage time
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in 0 1; do
   echo "ORBX_PF_LANE_ALLOC=$v"

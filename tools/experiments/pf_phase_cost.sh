@@ -1,6 +1,7 @@
 #!/bin/bash
 # k_pyr_fast, debug instance (phase mask compiled in): stage time with all phases (271 = 15 + an unused bit, so that the debug instance runs)
 # against the mask without count + emission (263), without NMS + emission (259), without the FAST rounds (257): what the tail phases cost
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for ph in 271 263 259 257 271; do
   echo -n "ORBX_PF_PHASES=$ph: "

@@ -1,6 +1,7 @@
 #!/bin/bash
 # k_pyr_fast: threads per workgroup x tile width x kernel organisation (1 phases / 2 a wave per cell).  Prints the pyramid+FAST stage time
 # of the c2 bench (ms per 1024 frames).  Usage on the GPU box: bash tools/experiments/pf_threads_sweep.sh
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() { python bench.py --batches-per-step 1 --steps 8 --warmup 2 --no-cpu-baseline --no-pcie 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['stages_ms']['pyramid+FAST'], d['ms_per_step'])"; }
 for lib in liborbx.so liborbx_256.so; do

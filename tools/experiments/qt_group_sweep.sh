@@ -1,5 +1,6 @@
 #!/bin/bash
 # levels per quadtree launch (ORBX_QT_PER_LEVEL: 0 = all levels in one launch, k >= 2 = k - 1 levels per launch) over the workloads
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/qtgrp
 for cfg in ${CFGS:-c2 c3 c4 c5}; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # k_quadtree<KCH> choice on a workload (CFG, default c4): default rule against ORBX_QT_KCH=8 / 32, and the level grouping ORBX_QT_PER_LEVEL
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/qtkch
 for v in "" "ORBX_QT_KCH=8" "ORBX_QT_KCH=32" "ORBX_QT_PER_LEVEL=2" "ORBX_QT_PER_LEVEL=4" "ORBX_QT_PER_LEVEL=0"; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Multi-wave quadtree instances (k_quadtree_mw) against one wave per instance: parity with the choice forced, then single-frame
 # latency and the c5 / c3 / c2 bench lines with ORBX_QT_MW = 0 / 1 / default.
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/qtmw
 ORBX_QT_MW=1 timeout -k 10 500 python -m pytest tests/test_parity_gpu.py tests/test_golden.py -x -q -m gpu > gpurun_out/qtmw/pytest_mw1.log 2>&1 || { tail -30 gpurun_out/qtmw/pytest_mw1.log; exit 1; }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Where a 1080p quadtree instance spends its time: the bench line of a workload (CFG=c5 by default) with the kernel cut short (ORBX_QT_STOP: 1 after the gather, 2 after
 # the roots, 3 without the sorted phase, 4 without the sort itself).  Timing only - the keypoints are wrong with a stop point.
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/qtstop
 for st in 0 1 2 3 4; do

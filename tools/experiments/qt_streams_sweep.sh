@@ -1,6 +1,7 @@
 #!/bin/bash
 # quadtree launch groups dealt over ORBX_QT_STREAMS extra streams (0: behind each other on the back stream), per grouping ORBX_QT_PER_LEVEL;
 # VALS = list of streams,per_level
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/qtstr
 for cfg in ${CFGS:-c2 c3 c4 c5}; do

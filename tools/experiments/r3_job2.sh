@@ -1,3 +1,4 @@
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3b
 timeout -k 10 600 python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "host_batch or sharded or small or single or graph or lapping" > gpurun_out/r3b/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/r3b/pytest.log

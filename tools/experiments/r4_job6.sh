@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, GPU job 6: A/B of the s_nop pass (tools/sq_slowmode.py) on the whole extraction step, then the GPU tests on the fixed build
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/r4job6; mkdir -p $o
 for v in nofix fix nofix fix; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, GPU job 8: per-phase counters of k_pyr_fast with the s_nop pass (compare with profiles/r04a_*, the same sources without it) + stage-time A/B
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/r4job8; mkdir -p $o
 for v in nofix fix nofix fix; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export ORBX_SUBBATCHES=1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d gpurun_out/pmc2 -- python3 bench.py --batches-per-step 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > gpurun_out/pmc2.log 2>&1

@@ -2,6 +2,7 @@
 # Dynamic instruction profile of k_pyr_fast by phase: the kernel returns at stop point k (bits 4..7 of ORBX_PF_PHASES), so
 # the differences between consecutive runs are the VALU / LDS / SALU instructions and the time each phase adds.
 # Usage on the GPU box: bash tools/pmc_phases.sh > gpurun_out/pmc_phases.txt
+export ORBX_STRICT_ENV=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for k in 1 2 3 4 5 6 7 0; do  # (stop points: see PyrFastArgs::phases)
 export ORBX_PF_PHASES=$((15 + 16 * k))

@@ -9,6 +9,7 @@
 #include "orbx_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -74,6 +75,7 @@ static inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
 static inline int cvCeilD(double v) { int i = (int)v; return i + (i < v); }
 static inline short satShort(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 static inline size_t roundUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static std::atomic<unsigned long long> gBatchSerial{0};   // see orbx_extractor::batchSerial
 
 template <class T> struct DevBuf {
     T *p = nullptr;
@@ -165,6 +167,7 @@ struct orbx_extractor {
 
     // level-0 source of the last batch (for orbx_get_pyramid_level)
     const uint8_t *lastSrc = nullptr; int lastSrcPitch = 0; long long lastSrcFrameStride = 0; int lastFrames = 0;
+    unsigned long long batchSerial = 0;   // unique over all handles of the process: names the batch whose outputs the device buffers hold (stale-consumer checks)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -201,9 +204,11 @@ static bool hostTimeline()
 }
 
 // The ORBX_* environment switches exist for A / B measurements and so that the tests can force every kernel variant; none
-// is needed to run the library.  A name that no source reads is refused at the first create call: a mistyped switch that silently runs the
-// default would make an A / B measurement - or a test of a variant - meaningless.  (tests/test_abi.py keeps this list equal to the
-// getenv() calls of the sources; ORBX_LIB / ORBX_BENCH_BACKEND / ORBX_COMMIT belong to the Python side and the tooling.)
+// is needed to run the library.  A name that no source reads is reported at the create calls: a mistyped switch that silently runs the
+// default would make an A / B measurement - or a test of a variant - meaningless.  In production an ORBX_* variable of some other tool
+// (ORBX_HOME ..) must not take the path down, so the default is ONE warning on stderr; with ORBX_STRICT_ENV=1 - set by the tests and the
+// A / B scripts - the create call fails instead.  (tests/test_abi.py keeps this list equal to the getenv() calls of the sources; ORBX_LIB /
+// ORBX_BENCH_BACKEND / ORBX_COMMIT belong to the Python side and the tooling.)
 static const char *const kKnownSwitches[] = {
     "ORBX_BLUR_KERNEL", "ORBX_BLUR_SEG", "ORBX_BLUR_WAVES", "ORBX_CHAIN_TILE", "ORBX_DEBUG", "ORBX_EARLY_BLUR", "ORBX_FRONT_PARTS", "ORBX_FRONT_STAGGER",
     "ORBX_GRAPH", "ORBX_HOST_FEEDER", "ORBX_HOST_SUBBATCHES", "ORBX_HOST_TIMELINE", "ORBX_KNN_MFMA", "ORBX_KNN_SHARED_BOUND", "ORBX_KNN_SPLIT", "ORBX_NO_BLUR",
@@ -211,7 +216,7 @@ static const char *const kKnownSwitches[] = {
     "ORBX_QT_KERNEL", "ORBX_QT_LDS_KEYS", "ORBX_QT_MAX_KEYS", "ORBX_QT_MAX_KEYS2", "ORBX_QT_MW", "ORBX_QT_MW_LDS_KEYS", "ORBX_QT_PER_LEVEL", "ORBX_QT_POOL_SLACK",
     "ORBX_QT_STOP", "ORBX_QT_STREAMS", "ORBX_SBP_LIST_LDS", "ORBX_SBP_RESOLVE_GLOBAL", "ORBX_SEARCH_INIT_GENERIC", "ORBX_SI_BLOCK", "ORBX_SI_ROUNDS", "ORBX_SI_ROUNDS_CAP", "ORBX_SI_TOPK",
     "ORBX_SMALL_BLUR_LEVELS", "ORBX_SMALL_PYR_CHAIN", "ORBX_SMALL_QT_BRANCHES", "ORBX_SMALL_SPLIT", "ORBX_STREAM_PRIO", "ORBX_SUBBATCHES", "ORBX_TILE_W",
-    "ORBX_LIB", "ORBX_BENCH_BACKEND", "ORBX_COMMIT",
+    "ORBX_STRICT_ENV", "ORBX_LIB", "ORBX_BENCH_BACKEND", "ORBX_COMMIT",
 };
 extern char **environ;
 static int checkEnvironmentSwitches(const char *fn)
@@ -223,7 +228,13 @@ static int checkEnvironmentSwitches(const char *fn)
         bool known = false;
         for (const char *k : kKnownSwitches)
             if (strlen(k) == len && strncmp(k, *e, len) == 0) { known = true; break; }
-        if (!known) return setError(ORBX_ERR_INVALID_ARG, "%s: unknown environment switch %.*s (see DESIGN.md, appendix \"environment switches\")", fn, (int)len, *e);
+        if (known) continue;
+        const char *strict = getenv("ORBX_STRICT_ENV");
+        if (strict && atoi(strict) != 0)
+            return setError(ORBX_ERR_INVALID_ARG, "%s: unknown environment switch %.*s (see DESIGN.md, appendix \"environment switches\")", fn, (int)len, *e);
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+            fprintf(stderr, "liborbx: warning: unknown environment switch %.*s is ignored (ORBX_STRICT_ENV=1 makes this an error; DESIGN.md, appendix \"environment switches\")\n", (int)len, *e);
     }
     return ORBX_OK;
 }
@@ -1322,6 +1333,7 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
     const int nl = ex->prm.nlevels;
     const uint8_t *src0 = (const uint8_t *)d_imgs;
     ex->lastSrc = src0; ex->lastSrcPitch = (int)stride; ex->lastSrcFrameStride = (long long)frame_stride; ex->lastFrames = nframes;
+    ex->batchSerial = ++gBatchSerial;
     hipStream_t sFront = ex->stream, sBlur = ex->stream2, sBack = ex->stream3;
     const OrbxTables tb = makeTables(ex);
     const int cap = ex->maxKeypoints;
@@ -3588,6 +3600,7 @@ struct orbx_vocabulary {
     DevBuf<double> d_batchDbl;
     // the last batch transform's FeatureVectors stay on the device for the keyframe-side batch searches (orbx_search_for_triangulation_frames)
     const orbx_extractor *batchEx = nullptr; int batchFrames = 0, batchCap = 0;
+    unsigned long long batchSerial = 0;   // orbx_extractor::batchSerial of the batch the cached FeatureVectors were computed from
     const int *batchFvNode = nullptr, *batchFvStart = nullptr, *batchFvFeature = nullptr;
     std::vector<int> batchNFv;
     HostXfer xf;                  // packed transfers of the single-frame transform
@@ -3818,7 +3831,7 @@ extern "C" int orbx_vocabulary_transform_batch(orbx_vocabulary *v, orbx_extracto
     HIP_TRY(hipMemcpyAsync(fv_start, fvStart, (F + nframes) * sizeof(int), hipMemcpyDeviceToHost, v->stream));
     HIP_TRY(hipStreamSynchronize(v->stream));
     for (int f = 0; f < nframes; ++f) { n_bow[f] = cnt[2 * (size_t)f]; n_fv[f] = cnt[2 * (size_t)f + 1]; }
-    v->batchEx = ex; v->batchFrames = nframes; v->batchCap = cap;
+    v->batchEx = ex; v->batchFrames = nframes; v->batchCap = cap; v->batchSerial = ex->batchSerial;
     v->batchFvNode = fvNode; v->batchFvStart = fvStart; v->batchFvFeature = fvFeature;
     v->batchNFv.assign(n_fv, n_fv + nframes);
     return ORBX_OK;
@@ -3841,7 +3854,8 @@ extern "C" int orbx_search_by_bow_frames(orbx_matcher *m, orbx_vocabulary *voc, 
     if (voc->batchEx != ex || voc->batchFrames <= 0 || voc->batchCap != ex->maxKeypoints)
         return setError(ORBX_ERR_INVALID_ARG, "%s: call orbx_vocabulary_transform_batch(voc, ex, ..) on this batch first (its FeatureVectors are read on the device)", fn);
     const int F = voc->batchFrames, cap = ex->maxKeypoints;
-    if (F > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "%s: the extractor's batch changed since the transform", fn);
+    if (voc->batchSerial != ex->batchSerial || F > ex->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: the extractor ran another batch since orbx_vocabulary_transform_batch - its keypoints no longer belong to the cached FeatureVectors; transform again", fn);
     if (cap > 65535) return setError(ORBX_ERR_CAPACITY, "%s: %d keypoints per frame exceed 65535", fn, cap);
     std::vector<int> table((size_t)npairs * 4);
     int maxNfv = 0;
@@ -3888,7 +3902,8 @@ extern "C" int orbx_search_for_triangulation_frames(orbx_matcher *m, orbx_vocabu
     if (voc->batchEx != ex || voc->batchFrames <= 0 || voc->batchCap != ex->maxKeypoints)
         return setError(ORBX_ERR_INVALID_ARG, "%s: call orbx_vocabulary_transform_batch(voc, ex, ..) on this batch first (its FeatureVectors are read on the device)", fn);
     const int F = voc->batchFrames, cap = ex->maxKeypoints, nlev = ex->prm.nlevels;
-    if (F > ex->lastFrames) return setError(ORBX_ERR_INVALID_ARG, "%s: the extractor's batch changed since the transform", fn);
+    if (voc->batchSerial != ex->batchSerial || F > ex->lastFrames)
+        return setError(ORBX_ERR_INVALID_ARG, "%s: the extractor ran another batch since orbx_vocabulary_transform_batch - its keypoints no longer belong to the cached FeatureVectors; transform again", fn);
     if (ref_frame < 0 || ref_frame >= F) return setError(ORBX_ERR_INVALID_ARG, "%s: reference keyframe %d of %d", fn, ref_frame, F);
     for (int k = 0; k < nneigh; ++k) {
         if (neighbours[k] < 0 || neighbours[k] >= F) return setError(ORBX_ERR_INVALID_ARG, "%s: neighbour %d is keyframe %d of %d", fn, k, neighbours[k], F);

@@ -11,6 +11,7 @@
 // (strict `<` insertion, lower train index first) is the lexicographic (distance, index) order, kept by packed keys inside a split
 // and by k_knn2_merge across splits.  k_hamming_matrix stages train descriptors through LDS tiles.
 #include "orbx_internal.h"
+#include "../../include/orbx_libm.h"
 #include <cstring>
 #include <limits.h>
 #include <algorithm>
@@ -3110,7 +3111,8 @@ struct FisheyeArgs {
 // correctly rounded float square root: __fsqrt_rn is 1 ulp off on gfx950 (measured: 0x1.a88fb8p+0 -> 0x1.49adf4p+0 instead of
 // 0x1.49adf6p+0); the double root narrowed once is exact (53 >= 2 * 24 + 2 bits)
 __device__ __forceinline__ float fe_sqrtf(float x) { return (float)__dsqrt_rn((double)x); }
-__device__ __forceinline__ float fe_dot3(const float *a, const float *b) { return __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2])); }
+// Eigen's unrolled 3-term redux: x0 + (x1 + x2) (see the projection head below)
+__device__ __forceinline__ float fe_dot3(const float *a, const float *b) { return __fadd_rn(__fmul_rn(a[0], b[0]), __fadd_rn(__fmul_rn(a[1], b[1]), __fmul_rn(a[2], b[2]))); }
 
 __device__ void fe_unproject(const float *P, float precision, float px, float py, float r[3])
 {
@@ -3129,7 +3131,7 @@ __device__ void fe_unproject(const float *P, float precision, float px, float py
             theta = __fsub_rn(theta, theta_fix);
             if (fabsf(theta_fix) < precision) break;
         }
-        scale = __fdiv_rn((float)tan((double)theta), theta_d);
+        scale = __fdiv_rn(orbx_glibc_tanf(theta), theta_d);   // std::tan(float) = glibc's tanf, restated (include/orbx_libm.h)
     }
     r[0] = __fmul_rn(pwx, scale); r[1] = __fmul_rn(pwy, scale); r[2] = 1.f;
 }
@@ -3137,8 +3139,8 @@ __device__ void fe_unproject(const float *P, float precision, float px, float py
 __device__ void fe_project(const float *P, const float v[3], float uv[2])
 {
     const float x2y2 = __fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1]));
-    const float theta = (float)atan2((double)fe_sqrtf(x2y2), (double)v[2]);
-    const float psi = (float)atan2((double)v[1], (double)v[0]);
+    const float theta = orbx_glibc_atan2f(fe_sqrtf(x2y2), v[2]);   // glibc's atan2f, restated (include/orbx_libm.h)
+    const float psi = orbx_glibc_atan2f(v[1], v[0]);
     const float t2 = __fmul_rn(theta, theta), t3 = __fmul_rn(theta, t2), t5 = __fmul_rn(t3, t2), t7 = __fmul_rn(t5, t2), t9 = __fmul_rn(t7, t2);
     const float r = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(theta, __fmul_rn(P[4], t3)), __fmul_rn(P[5], t5)), __fmul_rn(P[6], t7)), __fmul_rn(P[7], t9));
     uv[0] = (float)__dadd_rn(__dmul_rn((double)__fmul_rn(P[0], r), cos((double)psi)), (double)P[2]);
@@ -3212,12 +3214,14 @@ __global__ __launch_bounds__(256) void k_project_points(OrbxProjectArgs a)
         if (dist < minDistance || dist > maxDistance) in = false;
         const float viewCos = __fdiv_rn(pp_sum3(__fmul_rn(PO[0], pt.normal[0]), __fmul_rn(PO[1], pt.normal[1]), __fmul_rn(PO[2], pt.normal[2])), dist);
         if (viewCos < a.viewCosLimit) in = false;
-        // MapPoint::PredictScale (src/MapPoint.cc:531-546)
+        // MapPoint::PredictScale (src/MapPoint.cc:531-546): ceil(log(ratio) / mfLogScaleFactor) in FLOAT - std::log(float) is glibc's logf
+        // (include/orbx_libm.h, pinned), a float division, std::ceil(float); the int conversion of a NaN / out-of-range value gives INT_MIN
+        // on x86-64 (cvttss2si), which the first clamp turns into level 0
         const float ratio = __fdiv_rn(pt.maxD, dist);
-        const double lv = ceil(__ddiv_rn(log((double)ratio), (double)a.logScaleFactor));
-        int nScale = lv >= (double)a.nlevels ? a.nlevels - 1 : lv < 0.0 ? 0 : (int)lv;   // (int conversion first, then the clamps: same result inside int range;
-                                                                                          //  a NaN / huge quotient is undefined in the reference)
-        if (!(lv == lv)) nScale = 0;
+        const float lv = ceilf(__fdiv_rn(orbx_glibc_logf(ratio), a.logScaleFactor));
+        int nScale = (lv >= -2147483648.0f && lv < 2147483648.0f) ? (int)lv : INT_MIN;
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= a.nlevels) nScale = a.nlevels - 1;
         if (a.farPoints && PcDist > a.thFar) in = false;   // src/ORBmatcher1.cc:57-58 (mTrackDepth = Pc_dist)
         o.u = w[0]; o.v = w[1];
         o.invz = __fsub_rn(w[0], __fmul_rn(a.mbf, invz));   // mTrackProjXR
@@ -3621,6 +3625,14 @@ hipError_t orbxLaunchSearchByBoWFrames(hipStream_t st, const int *fvNode, const 
     if (e != hipSuccess) return e;
     if (maxNfv > 0) {
         const size_t lds = ((size_t)std::max(cap, 1) + 63) & ~(size_t)63;   // `taken`: a node holds at most every feature of the frame
+        if (lds > 32 * 1024) {   // beyond the default dynamic limit next to the kernel's 16 KB of static LDS (cap admits up to 65535)
+            static size_t raisedTo = 0;
+            if (lds > raisedTo) {
+                e = hipFuncSetAttribute((const void *)k_sbow_match_frames, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                raisedTo = lds;
+            }
+        }
         hipLaunchKernelGGL(k_sbow_match_frames, dim3(maxNfv, npairs), dim3(64), lds, st, fa);
         hipLaunchKernelGGL(k_sbow_finish_frames, dim3(npairs), dim3(256), 0, st, fa);
     }
