@@ -216,6 +216,32 @@ def test_batch_parity_and_composition_independence(pkg, orc):
     ex.close()
 
 
+@pytest.mark.parametrize("scale,nlevels,size", [(1.1, 6, (640, 480)), (1.33, 5, (752, 480)), (1.7, 4, (640, 480)), (2.0, 4, (800, 600)),
+                                                (2.4, 3, (800, 600)), (3.0, 3, (1024, 768)), (3.4, 2, (640, 480)), (1.2, 8, (1001, 701))])
+def test_batch_resize_over_scale_factors(pkg, orc, scale, nlevels, size):
+    """The FUSED pyramid step of the large-batch schedule (k_pyr_fast; single frames build their pyramid with another kernel) over scale
+    factors: since round 5 the horizontal pass of cv::resize reads 8-byte windows (two pixels' taps) and runs on v_perm_b32 /
+    v_dot2_u32_u16 for scale factors up to 3, and falls back to the byte reads beyond.  Every pyramid level byte for byte, then the
+    keypoints and descriptors of every frame."""
+    B = 20
+    w, h = size
+    imgs = np.stack([pkg.synth_frame(4000 + i, w, h) for i in range(B)])
+    ex = pkg.ORBextractor(800, scale, nlevels, 20, 7, max_width=w, max_height=h, max_batch=B)
+    ref = orc.Oracle(800, scale, nlevels, 20, 7)
+    n, mono, kps, desc = ex.extract_batch(imgs, (0, 0))
+    for f in (0, B - 1):
+        ref.extract(imgs[f], (0, 0))
+        for lvl in range(nlevels):
+            assert ex.level_size(lvl) == ref.level_size(lvl)
+            assert np.array_equal(ex.pyramid_level(f, lvl), ref.level(lvl)), f"scale {scale}: frame {f} level {lvl}"
+    rc, rmono, rk, rd = ref.extract_batch(imgs, (0, 0), threads=8, want_outputs=True)
+    assert np.array_equal(n, rc) and np.array_equal(mono, rmono)
+    for f in range(B):
+        assert kps[f][: n[f]].tobytes() == rk[f][: n[f]].tobytes(), f"scale {scale}: frame {f}"
+        assert desc[f][: n[f]].tobytes() == rd[f][: n[f]].tobytes(), f"scale {scale}: frame {f}"
+    ex.close()
+
+
 def test_host_batch_in_sub_batches(pkg, orc):
     """Host-pointer batches of >= 256 frames are staged and processed in sub-batches (copy of the next one under the kernels of
     this one): 300 frames (sub-batches of 152 + 148), all 300 against the oracle's counts, every 7th frame byte for byte, and

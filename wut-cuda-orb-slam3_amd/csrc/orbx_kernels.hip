@@ -453,6 +453,9 @@ extern "C" int orbx_debug_pf_timing(unsigned long long *out) { return (int)hipMe
 #ifndef PF_RESIZE_PACK_SDWA
 #define PF_RESIZE_PACK_SDWA 1
 #endif
+#ifndef PF_RESIZE_WINDOW
+#define PF_RESIZE_WINDOW 1   // round 5: dword windows + v_perm_b32 + v_dot2_u32_u16 for the horizontal pass of the resize (0: the byte reads of round 4)
+#endif
 // ML (multi-level): FAST / NMS / ordered candidates of ALL levels of a (small) batch in one launch - the pyramid exists already
 // (k_resize_level chain), the per-level argument blocks (the same PyrFastArgs the per-level launches take, with dst = NULL) lie in a
 // device array and are read like the kernarg segment, through the constant address space (DESIGN 6 "One frame at a time").  The
@@ -655,14 +658,58 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
                 // (dx >= dx1 there: the entry of the last column again).  A lane with a partial group stored byte by byte under four exec
                 // masks, ~17 scalar instructions in every turn of every lane's loop.
                 int ca[4], wa[4], wb[4];
+                uint32_t wp[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int2 e = xt[min(q * 4 + j, dx1 - 1) - dx0];
                     ca[j] = e.x;
                     wa[j] = (e.y & 0xFFFF) << 4;   // weights are in [0, 2048]; << 4: the horizontal sum comes out as h << 4 (< 2^24)
                     wb[j] = (e.y >> 16) << 4;
+                    wp[j] = (uint32_t)e.y << 4;    // both weights << 4 as a u16 pair (2048 << 4 = 0x8000 still fits): the operand of v_dot2_u32_u16
                 }
                 const uint32_t two = sw_opaque(2u);  // (SDWA takes no inline constant)
+#if PF_RESIZE_WINDOW
+                // Round 5: the taps of two neighbouring pixels lie in ONE 8-byte window that starts at the dword of the first pixel's left
+                // tap (sx advances by ceil(scale) <= 3 per pixel: scale factors up to 3; the wave falls back to byte reads otherwise).  Per
+                // source row two ds_read2_b32 instead of eight ds_read_u8 - the byte reads made this phase the kernel's largest consumer of
+                // LDS cycles (196 M of 530 M per launch set, half of them bank conflicts) -, and per (pixel, row) one v_perm_b32 that puts
+                // the two taps into the halves of a dword (selector per pixel, constant over the phase) and one v_dot2_u32_u16 against
+                // the weight pair: h << 4 = S[sx] * (a0 << 4) + S[sx + 1] * (a1 << 4), the same integer as before.
+                const int b01 = ca[0] & ~3, b23 = ca[2] & ~3;
+                const int o0 = ca[0] - b01, o1 = ca[1] - b01, o2 = ca[2] - b23, o3 = ca[3] - b23;
+                if (__ballot(o1 > 6 || o3 > 6 || o1 < o0 || o3 < o2) == 0) {
+                    // selector bytes: {0x0c = constant 0, o + 1, 0x0c, o} -> S[sx] | S[sx + 1] << 16 out of {hi dword, lo dword}
+                    const uint32_t sl0 = (uint32_t)o0 * 0x00010001u + 0x0c010c00u, sl1 = (uint32_t)o1 * 0x00010001u + 0x0c010c00u;
+                    const uint32_t sl2 = (uint32_t)o2 * 0x00010001u + 0x0c010c00u, sl3 = (uint32_t)o3 * 0x00010001u + 0x0c010c00u;
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    typedef uint32_t Dw2 __attribute__((ext_vector_type(2), aligned(4)));   // 4-byte aligned pair: ds_read2_b32
+                    auto hsum = [](uint32_t hi, uint32_t lo, uint32_t sel, uint32_t w) {
+                        return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(hi, lo, sel)), __builtin_bit_cast(us2, w), 0u, false);
+                    };
+#pragma nounroll
+                    for (int dy = dy0 + rc; dy < dy1; dy += RC) {
+                        const int2 ye = yt[dy - dy0];
+                        const uint32_t b0s = (uint32_t)ye.y, b1s = (2048u << 8) - b0s;  // vertical weights << 8 (the two sum to 2048)
+                        const uint32_t r0 = sw_opaque((uint32_t)ye.x & 0xFFFFu), r1 = sw_opaque((uint32_t)ye.x >> 16);
+                        typedef const __attribute__((address_space(3))) Dw2 *LdsDw2;
+                        const Dw2 A0 = *(LdsDw2)(uintptr_t)(r0 + (uint32_t)b01), C0 = *(LdsDw2)(uintptr_t)(r0 + (uint32_t)b23);
+                        const Dw2 A1 = *(LdsDw2)(uintptr_t)(r1 + (uint32_t)b01), C1 = *(LdsDw2)(uintptr_t)(r1 + (uint32_t)b23);
+                        const uint32_t h0[4] = {hsum(A0.y, A0.x, sl0, wp[0]), hsum(A0.y, A0.x, sl1, wp[1]), hsum(C0.y, C0.x, sl2, wp[2]), hsum(C0.y, C0.x, sl3, wp[3])};
+                        const uint32_t h1[4] = {hsum(A1.y, A1.x, sl0, wp[0]), hsum(A1.y, A1.x, sl1, wp[1]), hsum(C1.y, C1.x, sl2, wp[2]), hsum(C1.y, C1.x, sl3, wp[3])};
+                        uint32_t packed = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t s2 = mul_hi_u24(h0[j] & 0xFFFFFF00u, b0s) + mul_hi_u24(h1[j] & 0xFFFFFF00u, b1s) + 2u;  // <= 1022
+                            if (j == 0) packed = s2 >> 2;
+                            else if (j == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(two), "v"(s2));
+                            else if (j == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(two), "v"(s2));
+                            else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(two), "v"(s2));
+                        }
+                        *(uint32_t *)(dstF + (uint32_t)(dy * dstPitch + q * 4)) = packed;
+                    }
+                    continue;
+                }
+#endif
 #pragma nounroll
                 for (int dy = dy0 + rc; dy < dy1; dy += RC) {
                     const int2 ye = yt[dy - dy0];
