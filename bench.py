@@ -3,8 +3,8 @@
 
 Default (`--config c2`, BASELINE.json configs[1], the configuration the metric is quoted on): one "step" = one pass of
 ORBextractor::operator() (pyramid -> FAST/NMS -> quadtree -> IC-angle -> blur -> rBRIEF -> pack) over ONE batch of 1024
-synthetic 640x480 mono frames, nFeatures=1000, 8 levels, scale 1.2, per GPU - over `--batches-per-step` (5) DISTINCT batches per step,
-so the timed region covers 100 batches / 0.3 s at the default 20 steps (>= 0.25 s: at 3.0 ms per batch four per step had become 0.24 s).  `value` = frames/s with the inputs resident in HBM before
+synthetic 640x480 mono frames, nFeatures=1000, 8 levels, scale 1.2, per GPU - over `--batches-per-step` (c2: 18) DISTINCT batches per step
+(18,432 frames, 5.7 GB of the 288 GB of HBM), so the timed region covers 360 batches / 1.1 s at the default 20 steps.  `value` = frames/s with the inputs resident in HBM before
 the timed region and the results left in HBM (`value_definition` in the line says so).  SURVEY §8(d)'s metric - the PCIe-inclusive
 rate of the host-pointer API orbx_extract_batch, H2D of the frames and D2H of keypoints + descriptors inside the call, page-locked
 caller buffers - is the top-level `metric_8d_frames_per_s` (with `pcie_inclusive_*` per kind of caller memory), measured on EVERY rank
@@ -234,7 +234,8 @@ def main() -> None:
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="workload (default c2 = the metric's configuration)")
     ap.add_argument("--batch", type=int, default=0, help="units (frames / stereo pairs) per GPU per step (default: the config's)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--batches-per-step", type=int, default=5, help="distinct batches one step passes over (weak scaling)")
+    ap.add_argument("--batches-per-step", type=int, default=0,
+                    help="distinct batches one step passes over (weak scaling); default: c2 18 (timed region >= 1 s at 20 steps), other configs 5")
     ap.add_argument("--gather", action="store_true", help="all-gather the result records over RCCL inside the timed region (default at N > 1)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1 without the result gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,6 +248,8 @@ def main() -> None:
     if args.cpu_child:
         cpu_child(args.cpu_child, args.config, args.cpu_budget)
         return
+    if args.batches_per_step <= 0:
+        args.batches_per_step = 18 if args.config == "c2" else 5
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: this process never touches the GPU (no torch / HIP import so far); it starts the N ranks as
         # child processes under torch.distributed.run, forwards rank 0's JSON line and returns the launcher's exit code
@@ -454,14 +457,25 @@ def main() -> None:
             elif stereo:
                 exr.extract_batch(b, cfg["lap"], out=outs[lockedOut][1])
 
+        def fresh_arrays(ex):
+            # the reference's own calling pattern: `_descriptors.create(n, 32, CV_8U)` and `_keypoints = vector<KeyPoint>(n)` allocate NEW
+            # result arrays in every call (src/ORBextractor.cc:1251,1257) - untouched pages, first written inside the call
+            return (np.empty((np_units,), np.int32), np.empty((np_units,), np.int32), np.empty((np_units, ex.capacity), pkg.KEYPOINT_DTYPE),
+                    np.empty((np_units, ex.capacity, 32), np.uint8))
+
         pcie = {}
         reps = 5
-        for tag, (a, b, lo) in (("pageable", (hl, hr, False)), ("pinned_input", (pl, pr, False)), ("page_locked", (pl, pr, True))):
+        for tag, (a, b, lo) in (("pageable", (hl, hr, False)), ("pinned_input", (pl, pr, False)), ("page_locked", (pl, pr, True)),
+                                ("fresh_result_arrays", (pl, pr, "fresh"))):
+            if lo == "fresh":
+                outs["fresh"] = (fresh_arrays(exl), fresh_arrays(exr) if stereo else None)
             host_call(a, b, lo)
             if world > 1:
                 dist.barrier()
             t1 = time.perf_counter()
             for _ in range(reps):
+                if lo == "fresh":
+                    outs["fresh"] = (fresh_arrays(exl), fresh_arrays(exr) if stereo else None)   # (np.empty: a mapping, no page is touched here)
                 host_call(a, b, lo)
             wall = time.perf_counter() - t1
             if world > 1:
@@ -586,6 +600,7 @@ def main() -> None:
         out["pcie_inclusive_frames_per_s"] = round(res["pageable"], 1)
         out["pcie_inclusive_pinned_input_frames_per_s"] = round(res["pinned_input"], 1)
         out["pcie_inclusive_page_locked_frames_per_s"] = round(res["page_locked"], 1)
+        out["pcie_inclusive_fresh_result_arrays_frames_per_s"] = round(res["fresh_result_arrays"], 1)
         bytes_in = W * H
         kpf = float(total_kps) / n_last
         payload_out = kpf * 60.0 + 8.0     # keypoints (28 B) + descriptors (32 B) per feature, two counts per frame
@@ -598,7 +613,9 @@ def main() -> None:
                          "d2h_link_gbs": round(res[tag] * (direct_out if tag == "page_locked" else payload_out) / 1e9 / world, 2)}
         out["pcie_roofline"] = {"bound": "pcie_h2d", "peak_note": "PCIe Gen5 x16, 63 GB/s per direction and GPU (MI355X_MICROARCH.md); frames cross H2D "
                                 "while results cross D2H (full duplex), so the input direction is the bound; d2h_link_gbs = bytes that really crossed "
-                                "(full-capacity rows in the page-locked direct mode), d2h_payload_gbs = the n[f] rows the caller uses", **link}
+                                "(full-capacity rows in the page-locked direct mode), d2h_payload_gbs = the n[f] rows the caller uses; fresh_result_arrays = page-locked "
+                                "frames, but NEW pageable result arrays in every call, as the reference's caller allocates them (src/ORBextractor.cc:1251,1257): "
+                                "the first-touch page faults of the copy-out are inside the call", **link}
         out["pcie_inclusive_note"] = ("orbx_extract_batch: host frames in (H2D), keypoints + descriptors out (D2H), per call; extraction only"
                                       + (" (both images of a pair; page-locked frames: one host thread per extractor, pageable frames: one call after the other)" if stereo else "")
                                       + (f"; {world} ranks at the same time, each on its own host buffers" if world > 1 else ""))

@@ -49,13 +49,13 @@ def test_bench_line_carries_the_8d_metric_and_the_contract_keys():
     d = _run_bench(["--steps", "2", "--warmup", "1", "--batch", "64", "--batches-per-step", "3", "--no-cpu-baseline"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "value_definition", "metric_8d_frames_per_s", "pcie_inclusive_frames_per_s",
-              "pcie_inclusive_page_locked_frames_per_s", "pcie_roofline", "gather_ms"):
+              "pcie_inclusive_page_locked_frames_per_s", "pcie_inclusive_fresh_result_arrays_frames_per_s", "pcie_roofline", "gather_ms"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["gather_ms"] is None
     assert d["config"]["batches_per_step"] == 3 and d["config"]["units_per_gpu_per_step"] == 192
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s" and 0 < d["roofline"]["frac"] < 1
     assert d["metric_8d_frames_per_s"] == d["pcie_inclusive_page_locked_frames_per_s"] > 0
-    assert "d2h_link_gbs" in d["pcie_roofline"]["page_locked"]
+    assert "d2h_link_gbs" in d["pcie_roofline"]["page_locked"] and d["pcie_roofline"]["fresh_result_arrays"]["frames_per_s"] > 0
 
 
 @pytest.mark.gpu

@@ -60,7 +60,16 @@ pf["kernel"] = "k_pyr_fast"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402  (no torch import at module level)
 pf["kernel_source_sha256"] = bench.kernel_source_sha256()
-pf["commit"] = os.environ.get("ORBX_COMMIT", "")  # .git does not travel to the GPU box: tools/profile_round.sh is given the commit
+# .git does not travel to the GPU box: tools/stamp_commit.sh writes HEAD (+ "-dirty") into .git_commit before the gpurun call
+commit = os.environ.get("ORBX_COMMIT", "")
+if not commit:
+    try:
+        commit = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".git_commit")).read().strip()
+    except OSError:
+        commit = ""
+if not commit:
+    raise SystemExit("summarize_traffic.py: no commit to stamp - run tools/stamp_commit.sh before the gpurun call (or set ORBX_COMMIT)")
+pf["commit"] = commit
 pf["bench"] = "bench.py --config c2 --batches-per-step 1 --steps 2 --warmup 1 (3 batches of 1024 frames)"
 json.dump(pf, open(os.path.join(root, "pyr_fast_counters.json"), "w"), indent=1)
 print(json.dumps(pf, indent=1))
