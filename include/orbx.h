@@ -127,6 +127,20 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int
                        ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
                        int32_t *n_out, int32_t *mono_out);
 
+/* orbx_extract_batch in two halves, for callers that keep the link busy across calls.  submit queues every copy and launch of the batch
+ * and returns without waiting; wait blocks until the results are in the caller's arrays (n_out / mono_out included) and returns the
+ * call's status.  A host-pointer call ends in a tail nothing of the same call can cover (the last sub-batch's kernels and its results,
+ * ~0.9 of 6.7 ms for 1024 VGA frames): one thread that feeds TWO handles in turn - submit(A), submit(B), wait(A), submit(A), wait(B) ..
+ * - has B's frames cross the link under A's tail, as the reference's two extractor objects run side by side on two threads
+ * (src/Frame.cc:124-127, 1089-1092).  Requirements: the frames in page-locked memory (orbx_host_alloc / orbx_host_register; pageable
+ * frames need the calling thread: ORBX_ERR_INVALID_ARG); frames and result arrays stay valid and untouched until the wait returns; one
+ * batch pending per handle - until its wait every other extraction call on the handle is refused, and the handle's device outputs
+ * (orbx_device_outputs, the *_frames matcher calls) belong to the pending batch.  orbx_destroy drains a batch nobody waited for. */
+int orbx_extract_batch_submit(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
+                              ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
+                              int32_t *n_out, int32_t *mono_out);
+int orbx_extract_batch_wait(orbx_extractor *ex);
+
 /* The same batch dealt over several handles - normally one per GPU of the node (orbx_params.device) - from ONE host process: block b of
  * `block` consecutive frames goes to handles[b mod nhandles] (block = 1: frame f -> GPU f mod G, the partition of SURVEY 8(e); larger
  * blocks keep each handle's host copies long), every handle runs on a host thread of its own - the reference drives its left and right
@@ -445,6 +459,51 @@ int orbx_project_points_frames(orbx_matcher *m, int mode, int nframes, const flo
                                float th_far_points, const orbx_world_point *d_points, const int32_t *d_np, int max_np,
                                orbx_projection *d_proj_out);
 
+/* Mode 2 (round 5), Frame::isInFrustum for a FISHEYE RIG - the Nleft != -1 branch, reference src/Frame.cc:604-614: isInFrustumChecks(pMP,
+ * viewingCosLimit) for the left camera and isInFrustumChecks(pMP, viewingCosLimit, true) for the right one (:1198-1272).  Rcw / tcw / Ow =
+ * Frame::mRcw, mtcw, mOw; Rrl (row-major) / trl = mTrl.rotationMatrix() / mTrl.translation(), tlr = mTlr.translation(), Rwc = mRwc: the
+ * right camera's pose is formed from them per call as the reference does (:1204-1210: mR = Rrl * mRcw, mt = Rrl * mtcw + trl, twc = mRwc *
+ * tlr + mOw, fixed-size Eigen products coefficient by coefficient).  cam1 / cam2 = mvParameters of mpCamera / mpCamera2 (KannalaBrandt8,
+ * 8 floats).  proj_left_out[i] / proj_right_out[i] = {mTrackProjX(R), mTrackProjY(R), mTrackDepth(R), mTrackViewCos(R), mnTrackScaleLevel(R),
+ * flags} - what orbx_search_by_projection_points_fisheye(_frames) takes as map_points_left / map_points_right; flags bit 0 = the input bit &&
+ * mbTrackInView(R) && !(far_points && mTrackDepth > th_far_points): the far-point test of ORBmatcher::SearchByProjection
+ * (src/ORBmatcher1.cc:57-58) reads the LEFT camera's depth for both sides.  Stated deviation: the reference stores mTrackDepth only when the
+ * left check passes to its end, so for a point the left camera rejects it compares whatever an earlier frame left in the MapPoint; here the
+ * test uses the left camera's Pc_dist of this frame.  Arithmetic as in mode 1 (atan2f / logf: include/orbx_libm.h). */
+int orbx_project_in_frustum_fisheye(orbx_matcher *m, const float Rcw[9], const float tcw[3], const float Ow[3], const float Rrl[9],
+                                    const float trl[3], const float tlr[3], const float Rwc[9], const float cam1[8], const float cam2[8],
+                                    const float bounds[4], float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points,
+                                    float th_far_points, const orbx_world_point *points, int np, orbx_projection *proj_left_out,
+                                    orbx_projection *proj_right_out);
+/* The same for a batch of frames, device-resident: d_pose [nframes][40] floats per frame = Rcw[9] tcw[3] Ow[3] Rrl[9] trl[3] tlr[3] Rwc[9]
+ * and one float of padding; outputs [nframes][max_np] each.  One launch, asynchronous on the matcher's stream. */
+int orbx_project_in_frustum_fisheye_frames(orbx_matcher *m, int nframes, const float *d_pose, const float cam1[8], const float cam2[8],
+                                           const float bounds[4], float viewing_cos_limit, float log_scale_factor, int nlevels,
+                                           int far_points, float th_far_points, const orbx_world_point *d_points, const int32_t *d_np,
+                                           int max_np, orbx_projection *d_proj_left_out, orbx_projection *d_proj_right_out);
+
+/* Mode 3 (round 5), the projection head of the KEYFRAME-SIDE searches - what orbx_window_point (below) says the caller computes: ORBmatcher::
+ * Fuse (reference src/ORBmatcher2.cc:446-520; the Sim3 form :640-688), SearchByProjection(KeyFrame *, Sim3, ..) (src/ORBmatcher1.cc:451-494,
+ * :557-600) and SearchByProjection(Frame &, KeyFrame *, ..) (src/ORBmatcher3.cc:486-519).  Per map point: p3Dc = Tcw * p3Dw (q_xyzw / t: the
+ * Sophus::SE3f the function holds - for the Sim3 forms SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale())), [p3Dc(2) < 0: skip],
+ * invz = 1 / p3Dc(2), uv = pCamera->project(p3Dc), KeyFrame::IsInImage (x >= mnMinX && x < mnMaxX ..; src/KeyFrame.cc:750-753) or the
+ * Frame form (uv < mnMin || uv > mnMax rejects), ur = uv(0) - bf * invz, PO = p3Dw - Ow, dist = PO.norm(), [dist outside 0.8 mfMinDistance ..
+ * 1.2 mfMaxDistance: skip], [PO.dot(Pn) < 0.5 * dist: skip], nPredictedLevel = MapPoint::PredictScale(dist, pKF) (src/MapPoint.cc:514-529,
+ * float arithmetic as above), radius = th * mvScaleFactors[nPredictedLevel].  tests: bit 0 the positive-depth test, bit 1 the viewing-angle
+ * test (Fuse and the Sim3 search: 3), bit 2 Frame-style bounds (SearchByProjection(Frame, KeyFrame): 4).  points[i].flags bit 0 = the
+ * caller's own skips (NULL / isBad() / IsInKeyFrame / already found) passed; points_out[i].search = that && every test passed.  The
+ * records feed orbx_search_keyframe_windows / orbx_fuse / orbx_search_by_projection_sim3 / orbx_search_by_projection_keyframe and their
+ * _frames forms without leaving the device. */
+struct orbx_window_point_s;
+int orbx_project_window_points(orbx_matcher *m, const float q_xyzw[4], const float t[3], const float Ow[3], const orbx_camera *cam,
+                               const float bounds[4], float bf, float th, const float *scale_factors, float log_scale_factor, int nlevels,
+                               int tests, const orbx_world_point *points, int np, struct orbx_window_point_s *points_out);
+/* Batch form: d_pose [nframes][16] floats per frame = q x y z w, t x y z, Ow x y z (+ 6 of padding); d_points_out [nframes][max_np]. */
+int orbx_project_window_points_frames(orbx_matcher *m, int nframes, const float *d_pose, const orbx_camera *cam, const float bounds[4],
+                                      float bf, float th, const float *scale_factors, float log_scale_factor, int nlevels, int tests,
+                                      const orbx_world_point *d_points, const int32_t *d_np, int max_np,
+                                      struct orbx_window_point_s *d_points_out);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches) — reference
  * src/ORBmatcher1.cc:225-427 (decl include/ORBmatcher.h:62), F.Nleft == -1 / pKF->mpCamera2 == NULL; Tracking::TrackReferenceKeyFrame
  * and Relocalization.  Both FeatureVectors (pKF->mFeatVec, F.mFeatVec) as orbx_vocabulary_transform returns them: ascending node
@@ -518,8 +577,8 @@ int orbx_search_for_triangulation(orbx_matcher *m, const orbx_keyframe_view *kf1
 /* One map point projected into a keyframe, as ORBmatcher::Fuse / SearchBySim3 have it when they reach `GetFeaturesInArea`: the pose
  * algebra and the visibility tests in front (Tcw * p3Dw, project, IsInImage, the distance and viewing-angle tests, PredictScale -
  * src/ORBmatcher2.cc:469-520, 645-688, src/ORBmatcher3.cc:82-118) are the caller's Sophus / Eigen code; a point that failed one of them
- * is passed with search = 0. */
-typedef struct {
+ * is passed with search = 0.  Since round 5 orbx_project_window_points(_frames) computes these records on the device. */
+typedef struct orbx_window_point_s {
     float u, v;       /* uv(0), uv(1) */
     float ur;         /* uv(0) - bf * invz (Fuse with stereo keypoints, :489); unused otherwise */
     float radius;     /* th * mvScaleFactors[nPredictedLevel] */

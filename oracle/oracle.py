@@ -72,6 +72,11 @@ def lib() -> ctypes.CDLL:
         L.oracle_project_in_frustum.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int,
                                                 c_float, c_void_p, c_int, c_void_p]
         L.oracle_project_in_frustum.restype = None
+        L.oracle_project_in_frustum_fisheye.argtypes = [c_void_p] * 10 + [c_float, c_float, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]
+        L.oracle_project_in_frustum_fisheye.restype = None
+        L.oracle_project_window_points.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_float, c_int,
+                                                   c_int, c_void_p, c_int, c_void_p]
+        L.oracle_project_window_points.restype = None
         L.oracle_predict_scale.argtypes = [c_float, c_float, c_int]
         L.oracle_predict_scale.restype = c_int
         L.oracle_search_by_projection.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p,
@@ -332,6 +337,35 @@ def project_in_frustum(Rcw, tcw, Ow, cam_type, cam, bounds, mbf, viewing_cos_lim
     lib().oracle_project_in_frustum(R.ctypes.data, tt.ctypes.data, ow.ctypes.data, int(cam_type), c.ctypes.data, b.ctypes.data, float(mbf),
                                     float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)), float(th_far_points),
                                     pts.ctypes.data, len(pts), out.ctypes.data)
+    return out
+
+
+def project_in_frustum_fisheye(Rcw, tcw, Ow, Rrl, trl, tlr, Rwc, cam1, cam2, bounds, viewing_cos_limit, log_scale_factor, nlevels, points,
+                               far_points=False, th_far_points=0.0):
+    """Frame::isInFrustum of a fisheye rig (reference src/Frame.cc:604-614, 1198-1272) -> (left records, right records), PROJECTION_DTYPE."""
+    f32 = lambda a, n: np.ascontiguousarray(a, np.float32).reshape(n)
+    arrs = [f32(Rcw, 9), f32(tcw, 3), f32(Ow, 3), f32(Rrl, 9), f32(trl, 3), f32(tlr, 3), f32(Rwc, 9)]
+    c1 = np.zeros(8, np.float32); c1[:len(cam1)] = cam1
+    c2 = np.zeros(8, np.float32); c2[:len(cam2)] = cam2
+    b = np.ascontiguousarray(bounds, np.float32)
+    pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+    ol = np.zeros(len(pts), PROJECTION_DTYPE); orr = np.zeros(len(pts), PROJECTION_DTYPE)
+    lib().oracle_project_in_frustum_fisheye(*[a.ctypes.data for a in arrs], c1.ctypes.data, c2.ctypes.data, b.ctypes.data, float(viewing_cos_limit),
+                                            float(log_scale_factor), int(nlevels), int(bool(far_points)), float(th_far_points), pts.ctypes.data,
+                                            len(pts), ol.ctypes.data, orr.ctypes.data)
+    return ol, orr
+
+
+def project_window_points(q_xyzw, t, Ow, cam_type, cam, bounds, bf, th, scale_factors, log_scale_factor, tests, points):
+    """The projection head of Fuse / SearchByProjection(KeyFrame, Sim3) / SearchByProjection(Frame, KeyFrame) -> WINDOW_POINT_DTYPE records."""
+    q = np.ascontiguousarray(q_xyzw, np.float32); tt = np.ascontiguousarray(t, np.float32); ow = np.ascontiguousarray(Ow, np.float32)
+    c = np.zeros(8, np.float32); c[:len(cam)] = cam
+    b = np.ascontiguousarray(bounds, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+    out = np.zeros(len(pts), WINDOW_POINT_DTYPE)
+    lib().oracle_project_window_points(q.ctypes.data, tt.ctypes.data, ow.ctypes.data, int(cam_type), c.ctypes.data, b.ctypes.data, float(bf), float(th),
+                                       sf.ctypes.data, float(log_scale_factor), len(sf), int(tests), pts.ctypes.data, len(pts), out.ctypes.data)
     return out
 
 

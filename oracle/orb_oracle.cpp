@@ -1822,40 +1822,130 @@ extern "C" void oracle_project_last_frame_points(const float *q, const float *t,
     }
 }
 
+// one camera of Frame::isInFrustum / Frame::isInFrustumChecks (src/Frame.cc:549-599, 1198-1272): R, t = the world -> camera pose of THAT
+// camera, twc its centre.  The checks return early in the reference; computed to the end here, the values that are stored when all pass are
+// the same.  Returns mbTrackInView; uv, invz, viewCos, level, PcDist as the reference forms them.
+struct FrustumSide { bool in; float uv[2], invz, viewCos, PcDist; int level; };
+static FrustumSide frustumSide(const float *R, const float *t, const float *twc, int cam_type, const float *cam, const float *bounds,
+                               float viewing_cos_limit, float log_scale_factor, int nlevels, const oracle_world_point &pt)
+{
+    FrustumSide o;
+    const float *P = pt.pos;
+    float Pc[3];
+    for (int k = 0; k < 3; ++k) Pc[k] = sum3e(R[3 * k] * P[0], R[3 * k + 1] * P[1], R[3 * k + 2] * P[2]) + t[k];  // src/Frame.cc:553
+    o.PcDist = sqrtf(sum3e(Pc[0] * Pc[0], Pc[1] * Pc[1], Pc[2] * Pc[2]));                                         // :554
+    const float PcZ = Pc[2];
+    o.invz = 1.0f / PcZ;                                                                                          // :558
+    bool in = !(PcZ < 0.0f);                                                                                      // :559-560
+    cameraProject(cam_type, cam, Pc, o.uv);                                                                       // :562
+    if (o.uv[0] < bounds[0] || o.uv[0] > bounds[1]) in = false;                                                   // :564-567
+    if (o.uv[1] < bounds[2] || o.uv[1] > bounds[3]) in = false;
+    const float maxDistance = 1.2f * pt.max_distance, minDistance = 0.8f * pt.min_distance;                      // src/MapPoint.cc
+    const float PO[3] = {P[0] - twc[0], P[1] - twc[1], P[2] - twc[2]};                                            // :575
+    const float dist = sqrtf(sum3e(PO[0] * PO[0], PO[1] * PO[1], PO[2] * PO[2]));                                 // :576
+    if (dist < minDistance || dist > maxDistance) in = false;                                                     // :578-579
+    const float *Pn = pt.normal;
+    o.viewCos = sum3e(PO[0] * Pn[0], PO[1] * Pn[1], PO[2] * Pn[2]) / dist;                                        // :584
+    if (o.viewCos < viewing_cos_limit) in = false;                                                                // :586-587
+    // MapPoint::PredictScale(dist, pF), src/MapPoint.cc:531-546: `int nScale = ceil(log(ratio) / pF->mfLogScaleFactor)` with float ratio and
+    // float mfLogScaleFactor under `using namespace std` (TemplatedVocabulary.h:36 through MapPoint.h:23): std::log(float) = logf, a float
+    // division, std::ceil(float), then the conversion to int and the two clamps.
+    const float ratio = pt.max_distance / dist;
+    o.level = oracle_predict_scale(ratio, log_scale_factor, nlevels);
+    o.in = in;
+    return o;
+}
+
 extern "C" void oracle_project_in_frustum(const float *R, const float *t, const float *Ow, int cam_type, const float *cam, const float *bounds,
                                           float mbf, float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points,
                                           float th_far_points, const oracle_world_point *pts, int np, oracle_projection *out)
 {
     for (int i = 0; i < np; ++i) {
-        const float *P = pts[i].pos;
-        float Pc[3];
-        for (int k = 0; k < 3; ++k) Pc[k] = sum3e(R[3 * k] * P[0], R[3 * k + 1] * P[1], R[3 * k + 2] * P[2]) + t[k];  // src/Frame.cc:553
-        const float Pc_dist = sqrtf(sum3e(Pc[0] * Pc[0], Pc[1] * Pc[1], Pc[2] * Pc[2]));                              // :554
-        const float PcZ = Pc[2];
-        const float invz = 1.0f / PcZ;                                                                                // :558
-        bool in = !(PcZ < 0.0f);                                                                                      // :559-560
-        float uv[2];
-        cameraProject(cam_type, cam, Pc, uv);                                                                         // :562
-        if (uv[0] < bounds[0] || uv[0] > bounds[1]) in = false;                                                       // :564-567
-        if (uv[1] < bounds[2] || uv[1] > bounds[3]) in = false;
-        const float maxDistance = 1.2f * pts[i].max_distance, minDistance = 0.8f * pts[i].min_distance;              // src/MapPoint.cc
-        const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};                                                // :575
-        const float dist = sqrtf(sum3e(PO[0] * PO[0], PO[1] * PO[1], PO[2] * PO[2]));                                 // :576
-        if (dist < minDistance || dist > maxDistance) in = false;                                                     // :578-579
-        const float *Pn = pts[i].normal;
-        const float viewCos = sum3e(PO[0] * Pn[0], PO[1] * Pn[1], PO[2] * Pn[2]) / dist;                               // :584
-        if (viewCos < viewing_cos_limit) in = false;                                                                  // :586-587
-        // MapPoint::PredictScale(dist, pF), src/MapPoint.cc:531-546: `int nScale = ceil(log(ratio) / pF->mfLogScaleFactor)` with float ratio and
-        // float mfLogScaleFactor under `using namespace std` (TemplatedVocabulary.h:36 through MapPoint.h:23): std::log(float) = logf, a float
-        // division, std::ceil(float), then the conversion to int and the two clamps.
-        const float ratio = pts[i].max_distance / dist;
-        const int nScale = oracle_predict_scale(ratio, log_scale_factor, nlevels);
-        if (far_points && Pc_dist > th_far_points) in = false;                                                        // src/ORBmatcher1.cc:57-58
+        const FrustumSide sd = frustumSide(R, t, Ow, cam_type, cam, bounds, viewing_cos_limit, log_scale_factor, nlevels, pts[i]);
+        bool in = sd.in;
+        if (far_points && sd.PcDist > th_far_points) in = false;                                                  // src/ORBmatcher1.cc:57-58
         oracle_projection o;
-        o.u = uv[0]; o.v = uv[1];
-        o.invz = uv[0] - mbf * invz;                                                                                  // mTrackProjXR, :594
-        o.angle = viewCos; o.octave = nScale;
+        o.u = sd.uv[0]; o.v = sd.uv[1];
+        o.invz = sd.uv[0] - mbf * sd.invz;                                                                        // mTrackProjXR, :594
+        o.angle = sd.viewCos; o.octave = sd.level;
         o.flags = (pts[i].flags & ~1) | (((pts[i].flags & 1) && in) ? 1 : 0);
+        out[i] = o;
+    }
+}
+
+// Frame::isInFrustum for a fisheye rig (the Nleft != -1 branch, src/Frame.cc:604-614): isInFrustumChecks(pMP, limit) for the left camera and
+// isInFrustumChecks(pMP, limit, true) for the right one (:1198-1272).  The right camera's pose is formed per call in the reference (:1204-1210):
+//   mR = Rrl * mRcw;  mt = Rrl * mtcw + trl;  twc = mRwc * mTlr.translation() + mOw      (Rrl / trl = mTrl.rotationMatrix() / .translation())
+// fixed-size Eigen products, coefficient by coefficient with the 3-term redux x0 + (x1 + x2) (see the derivation above).
+// Records: {mTrackProjX, mTrackProjY, mTrackDepth, mTrackViewCos, mnTrackScaleLevel, flags} and the same with the R members; flags bit 0 =
+// the input bit && mbTrackInView(R) && !(far_points && mTrackDepth > th_far_points) - the far-point test of ORBmatcher::SearchByProjection
+// (src/ORBmatcher1.cc:57-58) reads the LEFT camera's mTrackDepth for both sides.  DEVIATION, stated: the reference stores mTrackDepth only when
+// the left check passes to its end, so for a point the left camera rejects it compares whatever an EARLIER frame left in the MapPoint; here
+// that test always uses the left camera's Pc_dist of this frame (which isInFrustumChecks computes before its first check).
+extern "C" void oracle_project_in_frustum_fisheye(const float *Rcw, const float *tcw, const float *Ow, const float *Rrl, const float *trl,
+                                                  const float *tlr, const float *Rwc, const float *cam1, const float *cam2, const float *bounds,
+                                                  float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points, float th_far_points,
+                                                  const oracle_world_point *pts, int np, oracle_projection *out_left, oracle_projection *out_right)
+{
+    float mR[9], mt[3], twc[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) mR[3 * i + j] = sum3e(Rrl[3 * i] * Rcw[j], Rrl[3 * i + 1] * Rcw[3 + j], Rrl[3 * i + 2] * Rcw[6 + j]);
+        mt[i] = sum3e(Rrl[3 * i] * tcw[0], Rrl[3 * i + 1] * tcw[1], Rrl[3 * i + 2] * tcw[2]) + trl[i];
+        twc[i] = sum3e(Rwc[3 * i] * tlr[0], Rwc[3 * i + 1] * tlr[1], Rwc[3 * i + 2] * tlr[2]) + Ow[i];
+    }
+    for (int i = 0; i < np; ++i) {
+        const FrustumSide l = frustumSide(Rcw, tcw, Ow, 1, cam1, bounds, viewing_cos_limit, log_scale_factor, nlevels, pts[i]);
+        const FrustumSide r = frustumSide(mR, mt, twc, 1, cam2, bounds, viewing_cos_limit, log_scale_factor, nlevels, pts[i]);
+        const bool live = (pts[i].flags & 1) && !(far_points && l.PcDist > th_far_points);
+        oracle_projection o;
+        o.u = l.uv[0]; o.v = l.uv[1]; o.invz = l.PcDist; o.angle = l.viewCos; o.octave = l.level;
+        o.flags = (pts[i].flags & ~1) | ((live && l.in) ? 1 : 0);
+        out_left[i] = o;
+        o.u = r.uv[0]; o.v = r.uv[1]; o.invz = r.PcDist; o.angle = r.viewCos; o.octave = r.level;
+        o.flags = (pts[i].flags & ~1) | ((live && r.in) ? 1 : 0);
+        out_right[i] = o;
+    }
+}
+
+// The projection head of the keyframe-side searches - ORBmatcher::Fuse (src/ORBmatcher2.cc:446-520 and :640-688), SearchByProjection(KeyFrame*,
+// Sim3, ..) (src/ORBmatcher1.cc:451-494, :557-600) and SearchByProjection(Frame&, KeyFrame*, ..) (src/ORBmatcher3.cc:486-519): per map point
+//   p3Dc = Tcw * p3Dw (Sophus::SE3f: quaternion form, as oracle_project_last_frame_points); [p3Dc(2) < 0 -> skip]; invz = 1 / p3Dc(2);
+//   uv = pCamera->project(p3Dc); IsInImage(uv) (KeyFrame: x >= mnMinX && x < mnMaxX .., include/KeyFrame.h; Frame: uv < min || uv > max rejects);
+//   ur = uv(0) - bf * invz; PO = p3Dw - Ow; dist = PO.norm(); [dist < 0.8 min || dist > 1.2 max -> skip]; [PO.dot(Pn) < 0.5 * dist -> skip:
+//   `0.5 * dist3D` is a double product, the float dot product is promoted for the comparison]; nPredictedLevel = PredictScale(dist, pKF);
+//   radius = th * mvScaleFactors[nPredictedLevel].
+// tests: bit 0 the positive-depth test (Fuse, Sim3), bit 1 the viewing-angle test (Fuse, Sim3), bit 2 Frame-style bounds (SearchByProjection(Frame,
+// KeyFrame)).  out[i] = {u, v, ur, radius, level, search}; search = the point's flags bit 0 (the caller's isBad / IsInKeyFrame / already-found
+// tests) && every test passed.
+extern "C" void oracle_project_window_points(const float *q, const float *t, const float *Ow, int cam_type, const float *cam, const float *bounds,
+                                             float bf, float th, const float *scale_factors, float log_scale_factor, int nlevels, int tests,
+                                             const oracle_world_point *pts, int np, void *out_)
+{
+    oracle_window_point *out = (oracle_window_point *)out_;
+    for (int i = 0; i < np; ++i) {
+        const float *p = pts[i].pos;
+        float uvx[3], c2[3], x[3];
+        cross3e(q, p, uvx);
+        for (int k = 0; k < 3; ++k) uvx[k] = uvx[k] + uvx[k];
+        cross3e(q, uvx, c2);
+        for (int k = 0; k < 3; ++k) x[k] = ((p[k] + q[3] * uvx[k]) + c2[k]) + t[k];
+        bool ok = (pts[i].flags & 1) != 0;
+        if ((tests & 1) && x[2] < 0.0f) ok = false;
+        const float invz = 1 / x[2];                      // `const float invz = 1/p3Dc(2)`: int 1 converted to float, a float division
+        float uv[2];
+        cameraProject(cam_type, cam, x, uv);
+        if (tests & 4) { if (uv[0] < bounds[0] || uv[0] > bounds[1] || uv[1] < bounds[2] || uv[1] > bounds[3]) ok = false; }
+        else if (!(uv[0] >= bounds[0] && uv[0] < bounds[1] && uv[1] >= bounds[2] && uv[1] < bounds[3])) ok = false;
+        const float ur = uv[0] - bf * invz;
+        const float maxDistance = 1.2f * pts[i].max_distance, minDistance = 0.8f * pts[i].min_distance;
+        const float PO[3] = {p[0] - Ow[0], p[1] - Ow[1], p[2] - Ow[2]};
+        const float dist = sqrtf(sum3e(PO[0] * PO[0], PO[1] * PO[1], PO[2] * PO[2]));
+        if (dist < minDistance || dist > maxDistance) ok = false;
+        const float *Pn = pts[i].normal;
+        if ((tests & 2) && (double)sum3e(PO[0] * Pn[0], PO[1] * Pn[1], PO[2] * Pn[2]) < 0.5 * (double)dist) ok = false;
+        const int level = oracle_predict_scale(pts[i].max_distance / dist, log_scale_factor, nlevels);
+        oracle_window_point o;
+        o.u = uv[0]; o.v = uv[1]; o.ur = ur; o.radius = th * scale_factors[level]; o.level = level; o.search = ok ? 1 : 0;
         out[i] = o;
     }
 }

@@ -145,6 +145,19 @@ void oracle_project_in_frustum(const float *Rcw, const float *tcw, const float *
                                float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points, float th_far_points,
                                const oracle_world_point *pts, int np, oracle_projection *out);
 
+/* Frame::isInFrustum for a fisheye rig (src/Frame.cc:604-614 + isInFrustumChecks :1198-1272): both cameras' records from the left pose and the
+ * rig's relative pose (Rrl / trl = mTrl.rotationMatrix() / .translation(), tlr = mTlr.translation(), Rwc = mRwc); see orb_oracle.cpp. */
+void oracle_project_in_frustum_fisheye(const float *Rcw, const float *tcw, const float *Ow, const float *Rrl, const float *trl, const float *tlr,
+                                       const float *Rwc, const float *cam1, const float *cam2, const float *bounds, float viewing_cos_limit,
+                                       float log_scale_factor, int nlevels, int far_points, float th_far_points, const oracle_world_point *pts,
+                                       int np, oracle_projection *out_left, oracle_projection *out_right);
+/* The projection head of ORBmatcher::Fuse / SearchByProjection(KeyFrame, Sim3) / SearchByProjection(Frame, KeyFrame) (src/ORBmatcher2.cc:446-520,
+ * src/ORBmatcher1.cc:451-494, src/ORBmatcher3.cc:486-519) -> the oracle_window_point records (declared below) of the window searches; tests: bit 0
+ * positive depth, bit 1 viewing angle, bit 2 Frame-style bounds. */
+void oracle_project_window_points(const float *q_xyzw, const float *t, const float *Ow, int cam_type, const float *cam, const float *bounds, float bf,
+                                  float th, const float *scale_factors, float log_scale_factor, int nlevels, int tests,
+                                  const oracle_world_point *pts, int np, void *out /* oracle_window_point[np] */);
+
 /* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th, ..) (src/ORBmatcher1.cc:45-215), F.Nleft == -1, points
  * with mbTrackInView: a record holds u = mTrackProjX, v = mTrackProjY, invz = mTrackProjXR, angle = mTrackViewCos,
  * octave = mnTrackScaleLevel, flags as above.  Returns nmatches. */

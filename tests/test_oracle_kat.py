@@ -701,3 +701,78 @@ def test_predict_scale_is_the_reference_float_arithmetic(orc):
     # clamps and the degenerate ratios (dist = 0 -> inf, 0 / 0 -> NaN: int conversion as x86-64 does it, INT_MIN -> level 0)
     assert orc.predict_scale(1e-3, lsf, 8) == 0 and orc.predict_scale(1e6, lsf, 8) == 7 and orc.predict_scale(1.0, lsf, 8) == 0
     assert orc.predict_scale(float("inf"), lsf, 8) == 0 and orc.predict_scale(float("nan"), lsf, 8) == 0
+
+
+def _wp(orc, rows):
+    pts = np.zeros(len(rows), orc.WORLD_POINT_DTYPE)
+    for i, (pos, normal, mn, mx, flags) in enumerate(rows):
+        pts[i]["pos"] = pos; pts[i]["normal"] = normal; pts[i]["min_distance"] = mn; pts[i]["max_distance"] = mx; pts[i]["flags"] = flags
+    return pts
+
+
+def test_window_point_head_known_answers(orc):
+    """The projection head of Fuse / SearchByProjection(KeyFrame, Sim3) / SearchByProjection(Frame, KeyFrame) (reference src/ORBmatcher2.cc:446-520,
+    src/ORBmatcher1.cc:451-494, src/ORBmatcher3.cc:486-519): identity pose, pinhole - every value by hand, every test rejecting on its own."""
+    import scene3d
+    cam = (400.0, 400.0, 320.0, 240.0)
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    lsf = scene3d.libm_logf(np.float32(1.2))
+    I = [0, 0, 0, 1]
+    Z = [0, 0, 0]
+    pts = _wp(orc, [((0, 0, 2), (0, 0, 1), 0.5, 4.0, 1),          # on the axis, in range: ratio 4 / 2 -> level ceil(log 2 / log 1.2) = 4
+                    ((0, 0, -2), (0, 0, -1), 0.5, 4.0, 1),        # behind the camera
+                    ((1.6, 0, 2), (0, 0, 1), 0.5, 4.0, 1),        # u = 320 + 400 * 0.8 = 640: KeyFrame::IsInImage (x < mnMaxX) rejects, the Frame form accepts
+                    ((0, 0, 2), (0, 0, 1), 3.0, 4.0, 1),          # dist 2 < 0.8 * 3
+                    ((0, 0, 2), (0, 0, 1), 0.5, 1.5, 1),          # dist 2 > 1.2 * 1.5
+                    ((0, 0, 2), (1, 0, 0), 0.5, 4.0, 1),          # viewing direction 90 degrees off the normal
+                    ((0, 0, 2), (0, 0, 1), 0.5, 4.0, 0)])         # the caller's own skip
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    w = orc.project_window_points(I, Z, Z, 0, cam, bounds, 40.0, 3.0, sf, lsf, 3, pts)
+    assert w["search"].tolist() == [1, 0, 0, 0, 0, 0, 0]
+    assert (w["u"][0], w["v"][0], w["ur"][0], w["level"][0]) == (320.0, 240.0, 300.0, 4) and w["radius"][0] == np.float32(3.0) * sf[4]
+    assert w["u"][2] == 640.0
+    wf = orc.project_window_points(I, Z, Z, 0, cam, bounds, 40.0, 3.0, sf, lsf, 4, pts)     # Frame form: inclusive bounds, no depth / angle test
+    assert wf["search"].tolist() == [1, 1, 1, 0, 0, 1, 0]
+    w1 = orc.project_window_points(I, Z, Z, 0, cam, bounds, 40.0, 3.0, sf, lsf, 1, pts)     # depth test only
+    assert w1["search"].tolist() == [1, 0, 0, 0, 0, 1, 0]
+    # a translated / rotated pose: Ow = -R^T t; a quarter turn about z maps (x, y, z) -> (-y, x, z)
+    q = [0.0, 0.0, np.sqrt(0.5), np.sqrt(0.5)]
+    p2 = _wp(orc, [((0.5, 0.25, 2.0), (0, 0, 1), 0.1, 50.0, 1)])
+    w2 = orc.project_window_points(q, [0.1, -0.2, 0.3], [0.2, 0.1, -0.3], 0, cam, bounds, 0.0, 1.0, sf, lsf, 3, p2)
+    xc = np.float32([-0.25 + 0.1, 0.5 - 0.2, 2.3])
+    assert abs(w2["u"][0] - (400 * xc[0] / xc[2] + 320)) < 1e-3 and abs(w2["v"][0] - (400 * xc[1] / xc[2] + 240)) < 1e-3 and w2["search"][0] == 1
+
+
+def test_fisheye_frustum_head_equals_the_single_camera_head_per_side(orc):
+    """Frame::isInFrustum of a fisheye rig (reference src/Frame.cc:604-614 + isInFrustumChecks :1198-1272): the left records are the single-camera
+    head's with the left pose, the right ones the single-camera head's with the pose the reference forms per call (mR = Rrl * mRcw, mt = Rrl *
+    mtcw + trl, twc = mRwc * tlr + mOw; 3-term sums x0 + (x1 + x2)), and the far-point test of SearchByProjection reads the LEFT depth for both."""
+    import scene3d
+    rng = np.random.default_rng(12)
+    lsf = scene3d.libm_logf(np.float32(1.2))
+    cam1 = scene3d.KB8[1]; cam2 = tuple(np.float32(cam1) * np.float32([1.01, 0.99, 1.0, 1.0, 1.1, 0.9, 1.0, 1.0]))
+    keys = np.zeros(3000, [("x", "<f4"), ("y", "<f4"), ("angle", "<f4"), ("octave", "<i4")])
+    keys["x"] = rng.uniform(20, 490, 3000); keys["y"] = rng.uniform(20, 490, 3000)
+    pts, q, t, R, Ow = scene3d.make_scene(rng, keys, scene3d.KB8, orc.WORLD_POINT_DTYPE, motion=0.2, rot=0.05, behind=0.05)
+    Rrl = scene3d.rotation_matrix(scene3d.quat_from_axis_angle([0.1, 1.0, 0.05], 0.4)); trl = np.float32([-0.101, 0.002, 0.001])   # (a wide-angle rig: the two fields of view differ)
+    tlr = (-(Rrl.astype(np.float64).T @ trl.astype(np.float64))).astype(np.float32)
+    Rwc = np.ascontiguousarray(R.T)
+    bounds = (0.0, 512.0, 0.0, 512.0)
+    s3 = lambda a, b, c: np.float32(a + np.float32(b + c))
+    mR = np.float32([[s3(Rrl[i, 0] * R[0, j], Rrl[i, 1] * R[1, j], Rrl[i, 2] * R[2, j]) for j in range(3)] for i in range(3)])
+    mt = np.float32([s3(Rrl[i, 0] * t[0], Rrl[i, 1] * t[1], Rrl[i, 2] * t[2]) + trl[i] for i in range(3)])
+    twc = np.float32([s3(Rwc[i, 0] * tlr[0], Rwc[i, 1] * tlr[1], Rwc[i, 2] * tlr[2]) + Ow[i] for i in range(3)])
+    for far in (False, True):
+        L, Rr = orc.project_in_frustum_fisheye(R, t, Ow, Rrl, trl, tlr, Rwc, cam1, cam2, bounds, 0.5, lsf, 8, pts, far_points=far, th_far_points=8.0)
+        l1 = orc.project_in_frustum(R, t, Ow, 1, cam1, bounds, 0.0, 0.5, lsf, 8, pts)
+        r1 = orc.project_in_frustum(mR, mt, twc, 1, cam2, bounds, 0.0, 0.5, lsf, 8, pts)
+        for got, ref in ((L, l1), (Rr, r1)):
+            for k in ("u", "v", "angle", "octave"):
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+        depthL = L["invz"]                                                   # mTrackDepth
+        live = (pts["flags"] & 1).astype(bool) & ~(far & (depthL > 8.0))
+        assert np.array_equal((L["flags"] & 1).astype(bool), live & (l1["flags"] & 1).astype(bool))
+        assert np.array_equal((Rr["flags"] & 1).astype(bool), live & (r1["flags"] & 1).astype(bool))
+        assert np.array_equal(L["flags"] & ~1, pts["flags"] & ~1)
+    assert 100 < (L["flags"] & 1).sum() < len(pts) and 100 < (Rr["flags"] & 1).sum() and ((L["flags"] ^ Rr["flags"]) & 1).sum() > 10
+    assert (depthL > 8.0).sum() > 50

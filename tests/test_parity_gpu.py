@@ -317,6 +317,51 @@ def test_host_batch_page_locked_and_reused_arrays(pkg):
     ex.close()
 
 
+def test_submit_wait_two_batches_in_flight(pkg):
+    """orbx_extract_batch_submit / _wait (round 5): one thread keeps TWO handles busy - submit A, submit B, wait A, submit A, wait B .. - so
+    that one call's input copies cross the link under the other's tail.  Every frame's result is its own, byte for byte what the
+    synchronous call gives: through staging (pageable result arrays) and written by the device (page-locked ones), for different batches
+    in flight at the same time, and for a small (graph-schedule) batch.  A second submit on a busy handle, any other extraction call on it,
+    pageable frames and a wait with nothing pending are refused."""
+    B, w, h = 160, 640, 480
+    batches = [np.stack([pkg.synth_frame(9000 + 1000 * k + i, w, h) for i in range(B)]) for k in range(3)]
+    a = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    b = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    refs = [[x.copy() for x in a.extract_batch(img, (0, 0))] for img in batches]
+    pims = []
+    for img in batches:
+        p_ = pkg.host_array(img.shape, np.uint8); p_[...] = img; pims.append(p_)
+    outs = [a.output_arrays(B, page_locked=True), b.output_arrays(B), a.output_arrays(B, page_locked=True)]
+    a.extract_batch_submit(pims[0], (0, 0), out=outs[0])
+    b.extract_batch_submit(pims[1], (0, 0), out=outs[1])
+    with pytest.raises(pkg.OrbxError, match="pending"):
+        a.extract_batch_submit(pims[2], (0, 0), out=outs[2])
+    with pytest.raises(pkg.OrbxError, match="pending"):
+        a.extract_batch(batches[2], (0, 0))
+    with pytest.raises(pkg.OrbxError, match="pending"):
+        a(batches[2][0], None, (0, 0))
+    _same_valid_rows(refs[0], a.extract_batch_wait())
+    a.extract_batch_submit(pims[2], (0, 0), out=outs[2])
+    _same_valid_rows(refs[1], b.extract_batch_wait())
+    _same_valid_rows(refs[2], a.extract_batch_wait())
+    for rounds in range(3):                     # steady state: the same arrays reused, results still each call's own
+        a.extract_batch_submit(pims[rounds % 3], (0, 0), out=outs[0])
+        b.extract_batch_submit(pims[(rounds + 1) % 3], (0, 0), out=outs[1])
+        _same_valid_rows(refs[rounds % 3], a.extract_batch_wait())
+        _same_valid_rows(refs[(rounds + 1) % 3], b.extract_batch_wait())
+    with pytest.raises(pkg.OrbxError, match="no submitted batch"):
+        a.extract_batch_wait()
+    with pytest.raises(pkg.OrbxError, match="page-locked"):
+        a.extract_batch_submit(batches[0], (0, 0), out=outs[0])          # pageable frames need the calling thread
+    _same_valid_rows(refs[0], a.extract_batch(batches[0], (0, 0)))        # the handle is usable after the refusals
+    small = pims[0][:5]
+    sref = [x.copy() for x in a.extract_batch(np.ascontiguousarray(small), (0, 0))]
+    a.extract_batch_submit(small, (0, 0), out=a.output_arrays(5))
+    _same_valid_rows(sref, a.extract_batch_wait())
+    b.extract_batch_submit(pims[1], (0, 0), out=outs[1])                  # a batch nobody waits for: close() drains it
+    b.close(); a.close()
+
+
 def test_host_batch_from_registered_caller_memory(pkg):
     """orbx_host_register page-locks a buffer the caller already owns (a numpy array here, cv::Mat data in the reference): the batch call
     then takes its asynchronous route from it - same bytes out as from the pageable array, before and after unregistering; a null

@@ -189,6 +189,119 @@ def test_in_frustum_then_match_on_the_device(pkg, orc):
     m.close(); ex.close(); exb.close()
 
 
+def _rig_pose(R, t, Ow, angle=0.4):
+    Rrl = scene3d.rotation_matrix(scene3d.quat_from_axis_angle([0.1, 1.0, 0.05], angle)); trl = np.float32([-0.101, 0.002, 0.001])
+    tlr = (-(Rrl.astype(np.float64).T @ trl.astype(np.float64))).astype(np.float32)
+    return Rrl, trl, tlr, np.ascontiguousarray(R.T)
+
+
+def test_fisheye_frustum_head_matches_the_oracle(pkg, orc):
+    """Mode 2: Frame::isInFrustum of a fisheye rig (reference src/Frame.cc:604-614, isInFrustumChecks :1198-1272) - both cameras' records bit for
+    bit, single call and a batch of frames on the device; the far-point test reads the left depth for both sides."""
+    cam1 = scene3d.KB8[1]; cam2 = tuple(np.float32(cam1) * np.float32([1.01, 0.99, 1.0, 1.0, 1.1, 0.9, 1.0, 1.0]))
+    k1, _ = _frames(pkg, 35, 512, 512)
+    bounds = (0.0, 512.0, 0.0, 512.0)
+    m = pkg.ORBmatcher(8192, 8192)
+    poses, pts_all, refs = [], [], []
+    for seed in range(5):
+        rng = np.random.default_rng(300 + seed)
+        pts, q, t, R, Ow = scene3d.make_scene(rng, k1, scene3d.KB8, pkg.WORLD_POINT_DTYPE, motion=0.1 * (seed + 1), rot=0.03 * (seed + 1), behind=0.05)
+        if seed == 4:
+            pts = pts[:0]                                    # a frame without points
+        Rrl, trl, tlr, Rwc = _rig_pose(R, t, Ow)
+        far = bool(seed & 1)
+        gl, gr = m.ProjectInFrustumFisheye(R, t, Ow, Rrl, trl, tlr, Rwc, cam1, cam2, bounds, 0.5, LOGSF, 8, pts, far_points=far, th_far_points=9.0)
+        rl, rr = orc.project_in_frustum_fisheye(R, t, Ow, Rrl, trl, tlr, Rwc, cam1, cam2, bounds, 0.5, LOGSF, 8, pts, far_points=far, th_far_points=9.0)
+        assert np.array_equal(_bits(gl), _bits(rl)) and np.array_equal(_bits(gr), _bits(rr)), f"seed {seed}"
+        if len(pts):
+            assert 0 < (gl["flags"] & 1).sum() < (pts["flags"] & 1).sum() and ((gl["flags"] ^ gr["flags"]) & 1).sum() > 5
+        poses.append(np.concatenate([R.reshape(9), t, Ow, Rrl.reshape(9), trl, tlr, Rwc.reshape(9)])); pts_all.append(pts)
+        refs.append(orc.project_in_frustum_fisheye(R, t, Ow, Rrl, trl, tlr, Rwc, cam1, cam2, bounds, 0.5, LOGSF, 8, pts))
+    d_l, d_r, d_n, max_np = m.ProjectInFrustumFisheyeFrames(np.stack(poses), cam1, cam2, bounds, 0.5, LOGSF, 8, pts_all, device=0)
+    m.sync()                                                 # (asynchronous on the matcher's stream)
+    gl = d_l.cpu().numpy().view(pkg.PROJECTION_DTYPE).reshape(len(pts_all), max_np)
+    gr = d_r.cpu().numpy().view(pkg.PROJECTION_DTYPE).reshape(len(pts_all), max_np)
+    for f, (rl, rr) in enumerate(refs):
+        assert np.array_equal(_bits(gl[f, : len(rl)]), _bits(rl)) and np.array_equal(_bits(gr[f, : len(rr)]), _bits(rr)), f"frame {f}"
+    m.close()
+
+
+@pytest.mark.parametrize("cam", [scene3d.PINHOLE, scene3d.KB8], ids=["pinhole", "kb8"])
+def test_window_point_head_matches_the_oracle(pkg, orc, cam):
+    """Mode 3: the head of Fuse / SearchByProjection(KeyFrame, Sim3) / SearchByProjection(Frame, KeyFrame) (reference src/ORBmatcher2.cc:446-520,
+    src/ORBmatcher1.cc:451-494, src/ORBmatcher3.cc:486-519) - orbx_window_point records bit for bit, every combination of the three test bits."""
+    w, h = (640, 480) if cam[0] == 0 else (512, 512)
+    k1, _ = _frames(pkg, 37, w, h)
+    bounds = (0.0, float(w), 0.0, float(h))
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    m = pkg.ORBmatcher(8192, 8192)
+    seen = 0
+    for seed in range(4):
+        rng = np.random.default_rng(400 + seed)
+        pts, q, t, R, Ow = scene3d.make_scene(rng, k1, cam, pkg.WORLD_POINT_DTYPE, motion=0.1 * (seed + 1), rot=0.03 * (seed + 1), behind=0.05)
+        d = np.linalg.norm(pts["pos"] - Ow, axis=1)
+        pts["max_distance"] = (d * np.float32(1.2) ** rng.integers(0, 9, len(pts)) * rng.uniform(0.9, 1.1, len(pts))).astype(np.float32)
+        pts["min_distance"] = (pts["max_distance"] / np.float32(1.2) ** 7).astype(np.float32)
+        for tests in range(8):
+            got = m.ProjectWindowPoints(q, t, Ow, cam[0], cam[1], bounds, 47.9, 3.0 + tests, sf, LOGSF, tests, pts)
+            ref = orc.project_window_points(q, t, Ow, cam[0], cam[1], bounds, 47.9, 3.0 + tests, sf, LOGSF, tests, pts)
+            assert np.array_equal(_bits(got), _bits(ref)), (seed, tests)
+            seen += int(got["search"].sum())
+        assert 0 < got["search"].sum() < (pts["flags"] & 1).sum() and len(np.unique(got["level"])) >= 4
+    assert seen > 1000
+    with pytest.raises(pkg.OrbxError):
+        m.ProjectWindowPoints(q, t, Ow, cam[0], cam[1], bounds, 0.0, 3.0, sf, LOGSF, 8, pts)        # unknown test bit
+    m.close()
+
+
+def test_window_point_head_then_fuse_on_the_device(pkg, orc):
+    """LocalMapping::SearchInNeighbors' shape with NOTHING of the projections crossing the link: the head writes the orbx_window_point records
+    of K keyframes on the device (poses, map points in), orbx_fuse_frames consumes them there; per keyframe the same fused indices as the
+    oracle's head + the oracle's window search (reference src/ORBmatcher2.cc:420-610 from :446 on)."""
+    import torch
+    cam = scene3d.PINHOLE
+    K = 4
+    ex = pkg.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=K)
+    imgs = np.stack([pkg.synth_frame(60 + f, 640, 480) for f in range(K)])
+    d_imgs = torch.from_numpy(imgs).to("cuda:0")
+    ex.extract_batch_device(d_imgs.data_ptr(), K, 640, 480, 640, 640 * 480, (0, 0)); ex.sync()
+    n, _, kk, dd = ex.download_outputs(K)
+    inv_sigma2 = ex.GetInverseScaleSigmaSquares().copy(); sf = ex.GetScaleFactors().copy()
+    k4 = np.float32(cam[1]); nod = np.zeros(0, np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    rng = np.random.default_rng(21)
+    m = pkg.ORBmatcher(8192, 8192)
+    poses, pts_all, pd_all, ref_w = [], [], [], []
+    for f in range(K):
+        nc = int(n[f])
+        keys = kk[f, :nc]
+        pts, q, t, R, Ow = scene3d.make_scene(rng, keys, cam, pkg.WORLD_POINT_DTYPE, motion=0.0, rot=0.0, behind=0.02)
+        # the keyframe's pose = identity + a small step: the points re-project next to the keypoints they were lifted from
+        t = rng.normal(0, 0.002, 3).astype(np.float32); Ow = (-t).astype(np.float32)
+        dist = np.linalg.norm(pts["pos"] - Ow, axis=1)
+        pts["max_distance"] = (dist * np.float32(1.2) ** keys["octave"] * rng.uniform(0.97, 1.03, nc)).astype(np.float32)
+        pts["min_distance"] = (pts["max_distance"] / np.float32(1.2) ** 7).astype(np.float32)
+        pts["normal"] = (pts["pos"] - Ow) / np.maximum(np.linalg.norm(pts["pos"] - Ow, axis=1, keepdims=True), 1e-6)
+        sel = rng.permutation(nc)[: int(rng.integers(200, 900))]
+        pts = pts[sel]
+        pd = np.stack([dd[f, s] ^ (rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 2, 32, dtype=np.uint8) * np.uint8(3)) for s in sel])
+        poses.append(np.concatenate([[0, 0, 0, 1], t, Ow])); pts_all.append(pts); pd_all.append(pd)
+        ref_w.append(orc.project_window_points([0, 0, 0, 1], t, Ow, cam[0], cam[1], bounds, 40.0, 3.0, sf, LOGSF, 3, pts))
+    dev_pts = m.ProjectWindowPointsFrames(np.stack(poses), cam[0], cam[1], bounds, 40.0, 3.0, sf, LOGSF, 3, pts_all, device=0)
+    fi, nf = m.FuseFrames(ex, K, k4, nod, bounds, dev_pts, pd_all, chi2_test=True, fuse=True)   # (downloads: the matcher's stream is drained)
+    got_w = dev_pts[0].cpu().numpy().view(pkg.WINDOW_POINT_DTYPE).reshape(K, dev_pts[2])
+    total = 0
+    for f in range(K):
+        nc, np_ = int(n[f]), len(pts_all[f])
+        assert np.array_equal(_bits(got_w[f, :np_]), _bits(ref_w[f]))
+        ref = orc.search_keyframe_windows(kk[f, :nc], dd[f, :nc], bounds, ref_w[f], pd_all[f], inv_level_sigma2=inv_sigma2, chi2_test=True)
+        exp = np.where(ref[1] <= 50, ref[0], -1)
+        assert np.array_equal(fi[f, :np_], exp) and nf[f] == int((exp >= 0).sum()), f
+        total += int(nf[f])
+    assert total > 100 * K
+    m.close(); ex.close()
+
+
 def test_projection_head_argument_errors(pkg):
     m = pkg.ORBmatcher(64, 64)
     pts = np.zeros(4, pkg.WORLD_POINT_DTYPE); pts["pos"][:, 2] = 1

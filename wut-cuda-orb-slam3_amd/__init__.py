@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "orbx_default_params", "orbx_create", "orbx_destroy", "orbx_last_error", "orbx_get_levels", "orbx_get_scale_factor",
     "orbx_get_scale_factors", "orbx_get_inverse_scale_factors", "orbx_get_scale_sigma_squares",
     "orbx_get_inverse_scale_sigma_squares", "orbx_get_features_per_level", "orbx_get_umax", "orbx_max_keypoints",
-    "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_sharded", "orbx_host_alloc", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
+    "orbx_extract", "orbx_extract_batch", "orbx_extract_batch_submit", "orbx_extract_batch_wait", "orbx_extract_batch_sharded", "orbx_host_alloc", "orbx_host_free", "orbx_host_register", "orbx_host_unregister", "orbx_extract_batch_device", "orbx_sync", "orbx_device_outputs",
     "orbx_download_outputs", "orbx_stream", "orbx_get_level_size", "orbx_get_pyramid_level", "orbx_debug_get_candidates",
     "orbx_debug_get_selected", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_hamming_matrix", "orbx_match_knn2",
     "orbx_match_knn2_device", "orbx_match_knn2_batch_device", "orbx_match_knn2_frames", "orbx_compute_stereo_matches_frames",
@@ -98,6 +98,10 @@ ABI_SYMBOLS = [
     "orbx_project_last_frame_points",
     "orbx_project_in_frustum",
     "orbx_project_points_frames",
+    "orbx_project_in_frustum_fisheye",
+    "orbx_project_in_frustum_fisheye_frames",
+    "orbx_project_window_points",
+    "orbx_project_window_points_frames",
     "orbx_search_keyframe_windows_frames",
     "orbx_fuse_frames",
     "orbx_search_for_triangulation_frames",
@@ -147,6 +151,8 @@ def load_library() -> ctypes.CDLL:
     lib.orbx_extract.argtypes = [c_void_p, c_void_p, c_int, c_int, c_ssize_t, c_int, c_int, c_void_p, c_void_p, c_int, POINTER(c_int)]
     lib.orbx_extract_batch.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int, c_void_p,
                                        c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_extract_batch_submit.argtypes = lib.orbx_extract_batch.argtypes
+    lib.orbx_extract_batch_wait.argtypes = [c_void_p]
     lib.orbx_extract_batch_sharded.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_int, c_int, c_ssize_t, c_ssize_t, c_int, c_int,
                                                c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.orbx_host_alloc.argtypes = [c_size_t]
@@ -244,6 +250,13 @@ def load_library() -> ctypes.CDLL:
                                             c_int, c_float, c_void_p, c_int, c_void_p]
     lib.orbx_project_points_frames.argtypes = [c_void_p, c_int, c_int, c_void_p, POINTER(_Camera), c_void_p, c_float, c_float, c_float, c_int, c_int,
                                                c_float, c_void_p, c_void_p, c_int, c_void_p]
+    lib.orbx_project_in_frustum_fisheye.argtypes = [c_void_p] * 11 + [c_float, c_float, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_project_in_frustum_fisheye_frames.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_float,
+                                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.orbx_project_window_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(_Camera), c_void_p, c_float, c_float, c_void_p, c_float,
+                                               c_int, c_int, c_void_p, c_int, c_void_p]
+    lib.orbx_project_window_points_frames.argtypes = [c_void_p, c_int, c_void_p, POINTER(_Camera), c_void_p, c_float, c_float, c_void_p, c_float, c_int,
+                                                      c_int, c_void_p, c_void_p, c_int, c_void_p]
     lib.orbx_vocabulary_create.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]
     lib.orbx_vocabulary_load_text.argtypes = [c_int, ctypes.c_char_p, ctypes.POINTER(c_void_p)]
     lib.orbx_vocabulary_destroy.argtypes = [c_void_p]
@@ -473,6 +486,25 @@ class ORBextractor:
                                             self.capacity, n.ctypes.data, mono.ctypes.data), "orbx_extract_batch")
         return n, mono, kps, desc
 
+    def extract_batch_submit(self, images: np.ndarray, vLappingArea=(0, 0), out=None):
+        """orbx_extract_batch_submit: queues the batch and returns at once; `images` (page-locked: host_array) and `out` must stay alive and
+        untouched until extract_batch_wait(), which returns the same (n, mono, kps, desc)."""
+        assert images.dtype == np.uint8 and images.flags.c_contiguous and images.ndim == 3
+        b, h, w = images.shape
+        n, mono, kps, desc = out if out is not None else self.output_arrays(b)
+        assert kps.shape == (b, self.capacity) and desc.shape == (b, self.capacity, 32) and len(n) == b and len(mono) == b
+        _check(self._lib.orbx_extract_batch_submit(self._h, images.ctypes.data, b, w, h, images.strides[1], images.strides[0],
+                                                   int(vLappingArea[0]), int(vLappingArea[1]), kps.ctypes.data, desc.ctypes.data,
+                                                   self.capacity, n.ctypes.data, mono.ctypes.data), "orbx_extract_batch_submit")
+        self._submitted = (images, (n, mono, kps, desc))
+
+    def extract_batch_wait(self):
+        """orbx_extract_batch_wait: blocks until the submitted batch's results are in the arrays given to extract_batch_submit."""
+        _check(self._lib.orbx_extract_batch_wait(self._h), "orbx_extract_batch_wait")
+        _, out = self._submitted
+        self._submitted = None
+        return out
+
     def output_arrays(self, b: int, page_locked: bool = False):
         """(n[b], mono[b], kps[b, cap], desc[b, cap, 32]) zero-filled host arrays; page_locked: in orbx_host_alloc memory, which the
         device writes directly (no staging copy)."""
@@ -690,16 +722,25 @@ class ORBmatcher:
         """ORBmatcher::Fuse's search (fuse=True: fused_idx + nFused) or the plain KeyFrame window search (fuse=False: best_idx + best_dist) for the
         first `nframes` frames of the extractor's last batch taken as keyframes, device-resident (orbx_fuse_frames /
         orbx_search_keyframe_windows_frames).  points[p] / point_desc[p]: WINDOW_POINT_DTYPE records / [n, 32] uint8 of keyframe p.
-        Returns (fused_idx [P, max_np], nfused [P]) resp. (best_idx, best_dist)."""
+        Returns (fused_idx [P, max_np], nfused [P]) resp. (best_idx, best_dist).  points may also be the (d_points, d_np, max_np) that
+        ProjectWindowPointsFrames returned: the records then never leave the device."""
         import torch
         dev = ex.device
         cap = ex.capacity
-        max_np = max(1, max(len(p) for p in points))
-        hp = np.zeros((nframes, max_np), WINDOW_POINT_DTYPE); hd = np.zeros((nframes, max_np, 32), np.uint8); hn = np.zeros(nframes, np.int32)
-        for p in range(nframes):
-            hn[p] = len(points[p]); hp[p, : hn[p]] = points[p]; hd[p, : hn[p]] = np.asarray(point_desc[p], np.uint8).reshape(-1, 32)
         dv = f"cuda:{dev}"
-        d_p = torch.from_numpy(hp.view(np.uint8).reshape(nframes, -1)).to(dv); d_d = torch.from_numpy(hd).to(dv); d_n = torch.from_numpy(hn).to(dv)
+        on_device = isinstance(points, tuple) and len(points) == 3 and hasattr(points[0], "data_ptr")
+        max_np = points[2] if on_device else max(1, max(len(p) for p in points))
+        hd = np.zeros((nframes, max_np, 32), np.uint8)
+        for p in range(nframes):
+            pd = np.asarray(point_desc[p], np.uint8).reshape(-1, 32); hd[p, : len(pd)] = pd
+        d_d = torch.from_numpy(hd).to(dv)
+        if on_device:
+            d_p, d_n = points[0], points[1]
+        else:
+            hp = np.zeros((nframes, max_np), WINDOW_POINT_DTYPE); hn = np.zeros(nframes, np.int32)
+            for p in range(nframes):
+                hn[p] = len(points[p]); hp[p, : hn[p]] = points[p]
+            d_p = torch.from_numpy(hp.view(np.uint8).reshape(nframes, -1)).to(dv); d_n = torch.from_numpy(hn).to(dv)
         d_ur = torch.from_numpy(np.ascontiguousarray(u_right, np.float32)).to(dv) if u_right is not None else None
         o1 = self._dev_out((nframes, max_np), torch.int32, dev, -1)
         o2 = self._dev_out((nframes,) if fuse else (nframes, max_np), torch.int32, dev, 0 if fuse else np.iinfo(np.int32).max)
@@ -760,6 +801,85 @@ class ORBmatcher:
                                                     float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)),
                                                     float(th_far_points), c_void_p(d_w.data_ptr()), c_void_p(d_n.data_ptr()), max_np,
                                                     c_void_p(d_out.data_ptr())), "orbx_project_points_frames")
+        return d_out, d_n, max_np
+
+    def ProjectInFrustumFisheye(self, Rcw, tcw, Ow, Rrl, trl, tlr, Rwc, cam1, cam2, bounds, viewing_cos_limit: float, log_scale_factor: float,
+                                nlevels: int, points, far_points: bool = False, th_far_points: float = 0.0):
+        """orbx_project_in_frustum_fisheye: Frame::isInFrustum of a fisheye rig (reference src/Frame.cc:604-614, 1198-1272) -> (left, right)
+        PROJECTION_DTYPE records."""
+        f32 = lambda a, n: np.ascontiguousarray(a, np.float32).reshape(n)
+        arrs = [f32(Rcw, 9), f32(tcw, 3), f32(Ow, 3), f32(Rrl, 9), f32(trl, 3), f32(tlr, 3), f32(Rwc, 9)]
+        c1 = np.zeros(8, np.float32); c1[:len(cam1)] = cam1
+        c2 = np.zeros(8, np.float32); c2[:len(cam2)] = cam2
+        b = np.ascontiguousarray(bounds, np.float32)
+        pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+        ol = np.zeros(len(pts), PROJECTION_DTYPE); orr = np.zeros(len(pts), PROJECTION_DTYPE)
+        _check(self._lib.orbx_project_in_frustum_fisheye(self._h, *[a.ctypes.data for a in arrs], c1.ctypes.data, c2.ctypes.data, b.ctypes.data,
+                                                         float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)),
+                                                         float(th_far_points), pts.ctypes.data, len(pts), ol.ctypes.data, orr.ctypes.data),
+               "orbx_project_in_frustum_fisheye")
+        return ol, orr
+
+    def ProjectInFrustumFisheyeFrames(self, poses40, cam1, cam2, bounds, viewing_cos_limit: float, log_scale_factor: float, nlevels: int, points,
+                                      device: int, far_points: bool = False, th_far_points: float = 0.0):
+        """Batch form, device-resident: poses40 [P, 40] (Rcw[9] tcw[3] Ow[3] Rrl[9] trl[3] tlr[3] Rwc[9] + pad), points = list of P arrays.
+        Returns (d_left, d_right [P, max_np, 24] uint8 device tensors, d_np, max_np)."""
+        import torch
+        P = len(points)
+        max_np = max(1, max(len(p) for p in points))
+        hw = np.zeros((P, max_np), WORLD_POINT_DTYPE); hn = np.zeros(P, np.int32)
+        for f in range(P):
+            hn[f] = len(points[f]); hw[f, : hn[f]] = points[f]
+        hpose = np.zeros((P, 40), np.float32); hpose[:, : np.asarray(poses40).shape[1]] = np.asarray(poses40, np.float32)
+        dv = f"cuda:{device}"
+        d_w = torch.from_numpy(hw.view(np.uint8).reshape(P, -1)).to(dv); d_n = torch.from_numpy(hn).to(dv); d_pose = torch.from_numpy(hpose).to(dv)
+        d_l = torch.zeros((P, max_np, PROJECTION_DTYPE.itemsize), dtype=torch.uint8, device=dv)
+        d_r = torch.zeros((P, max_np, PROJECTION_DTYPE.itemsize), dtype=torch.uint8, device=dv)
+        c1 = np.zeros(8, np.float32); c1[:len(cam1)] = cam1
+        c2 = np.zeros(8, np.float32); c2[:len(cam2)] = cam2
+        b = np.ascontiguousarray(bounds, np.float32)
+        self._launch_fence(d_w, d_n, d_pose, d_l, d_r)
+        _check(self._lib.orbx_project_in_frustum_fisheye_frames(self._h, P, c_void_p(d_pose.data_ptr()), c1.ctypes.data, c2.ctypes.data, b.ctypes.data,
+                                                                float(viewing_cos_limit), float(log_scale_factor), int(nlevels), int(bool(far_points)),
+                                                                float(th_far_points), c_void_p(d_w.data_ptr()), c_void_p(d_n.data_ptr()), max_np,
+                                                                c_void_p(d_l.data_ptr()), c_void_p(d_r.data_ptr())), "orbx_project_in_frustum_fisheye_frames")
+        return d_l, d_r, d_n, max_np
+
+    def ProjectWindowPoints(self, q_xyzw, t, Ow, cam_type: int, cam, bounds, bf: float, th: float, scale_factors, log_scale_factor: float, tests: int,
+                            points):
+        """orbx_project_window_points: the head of Fuse / SearchByProjection(KeyFrame, Sim3) / SearchByProjection(Frame, KeyFrame) (reference
+        src/ORBmatcher2.cc:446-520, src/ORBmatcher1.cc:451-494, src/ORBmatcher3.cc:486-519) -> WINDOW_POINT_DTYPE records."""
+        q = np.ascontiguousarray(q_xyzw, np.float32); tt = np.ascontiguousarray(t, np.float32); ow = np.ascontiguousarray(Ow, np.float32)
+        b = np.ascontiguousarray(bounds, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+        pts = np.ascontiguousarray(points, WORLD_POINT_DTYPE)
+        out = np.zeros(len(pts), WINDOW_POINT_DTYPE)
+        c = _camera(cam_type, cam)
+        _check(self._lib.orbx_project_window_points(self._h, q.ctypes.data, tt.ctypes.data, ow.ctypes.data, ctypes.byref(c), b.ctypes.data, float(bf),
+                                                    float(th), sf.ctypes.data, float(log_scale_factor), len(sf), int(tests), pts.ctypes.data, len(pts),
+                                                    out.ctypes.data), "orbx_project_window_points")
+        return out
+
+    def ProjectWindowPointsFrames(self, poses, cam_type: int, cam, bounds, bf: float, th: float, scale_factors, log_scale_factor: float, tests: int,
+                                  points, device: int):
+        """Batch form, device-resident: poses [P, 10] (q xyzw, t, Ow), points = list of P arrays.  Returns (d_points [P, max_np, 24] uint8 device
+        tensor of orbx_window_point records - what FuseFrames / SearchKeyframeWindowsFrames take -, d_np, max_np)."""
+        import torch
+        P = len(points)
+        max_np = max(1, max(len(p) for p in points))
+        hw = np.zeros((P, max_np), WORLD_POINT_DTYPE); hn = np.zeros(P, np.int32)
+        for f in range(P):
+            hn[f] = len(points[f]); hw[f, : hn[f]] = points[f]
+        hpose = np.zeros((P, 16), np.float32); hpose[:, : np.asarray(poses).shape[1]] = np.asarray(poses, np.float32)
+        dv = f"cuda:{device}"
+        d_w = torch.from_numpy(hw.view(np.uint8).reshape(P, -1)).to(dv); d_n = torch.from_numpy(hn).to(dv); d_pose = torch.from_numpy(hpose).to(dv)
+        d_out = torch.zeros((P, max_np, WINDOW_POINT_DTYPE.itemsize), dtype=torch.uint8, device=dv)
+        b = np.ascontiguousarray(bounds, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+        c = _camera(cam_type, cam)
+        self._launch_fence(d_w, d_n, d_pose, d_out)
+        _check(self._lib.orbx_project_window_points_frames(self._h, P, c_void_p(d_pose.data_ptr()), ctypes.byref(c), b.ctypes.data, float(bf), float(th),
+                                                           sf.ctypes.data, float(log_scale_factor), len(sf), int(tests), c_void_p(d_w.data_ptr()),
+                                                           c_void_p(d_n.data_ptr()), max_np, c_void_p(d_out.data_ptr())),
+               "orbx_project_window_points_frames")
         return d_out, d_n, max_np
 
     def SearchByProjectionFrames(self, ex: "ORBextractor", nframes: int, k4, dist, bounds, mbf: float, proj, proj_desc, th: float,

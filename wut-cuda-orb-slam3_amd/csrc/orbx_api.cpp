@@ -167,6 +167,7 @@ struct orbx_extractor {
 
     // level-0 source of the last batch (for orbx_get_pyramid_level)
     const uint8_t *lastSrc = nullptr; int lastSrcPitch = 0; long long lastSrcFrameStride = 0; int lastFrames = 0;
+    struct PendingBatch *pending = nullptr;   // a batch submitted with orbx_extract_batch_submit and not yet waited for
     unsigned long long batchSerial = 0;   // unique over all handles of the process: names the batch whose outputs the device buffers hold (stale-consumer checks)
 };
 
@@ -358,12 +359,14 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     return ORBX_OK;
 }
 
+static void dropPending(orbx_extractor *ex);
 extern "C" void orbx_destroy(orbx_extractor *ex)
 {
     ORBX_API_ENTRY;
     ORBX_SETUP_LOCK;
     if (!ex) return;
     (void)hipSetDevice(ex->prm.device);
+    dropPending(ex);   // a submitted batch nobody waited for: nothing of it may still copy into the caller's arrays
     if (ex->streamCopy) { (void)hipStreamSynchronize(ex->streamCopy); (void)hipStreamDestroy(ex->streamCopy); }
     if (ex->streamOut) { (void)hipStreamSynchronize(ex->streamOut); (void)hipStreamDestroy(ex->streamOut); }
     if (ex->stream3) { (void)hipStreamSynchronize(ex->stream3); (void)hipStreamDestroy(ex->stream3); }
@@ -982,6 +985,24 @@ struct HostPipe {
     ~HostPipe() { if (thread.joinable()) thread.join(); }
 };
 
+// orbx_extract_batch_submit .. orbx_extract_batch_wait: what the wait needs of the call - the pipe and the frame mapping live here, not on
+// the submitting call's stack
+struct PendingBatch {
+    HostPipe pipe;
+    HostFrames hf;
+    bool small = false;   // a batch of the small-batch schedule: the results are fetched by the wait (one round trip)
+    int nframes = 0, capacity = 0;
+    orbx_keypoint *kps = nullptr; uint8_t *desc = nullptr; int32_t *nOut = nullptr, *monoOut = nullptr;
+};
+static HostPipe *pendingPipeOf(orbx_extractor *ex) { return ex->pending ? &ex->pending->pipe : nullptr; }
+static void dropPending(orbx_extractor *ex)
+{
+    if (!ex->pending) return;
+    drainHandle(ex);
+    delete ex->pending;
+    ex->pending = nullptr;
+}
+
 static int ensureStage(orbx_extractor *ex)
 {
     const size_t B = (size_t)ex->prm.max_batch, cap = (size_t)ex->maxKeypoints;
@@ -1306,6 +1327,7 @@ static int runSmallBatch(orbx_extractor *ex, const uint8_t *src0, int nf, int w,
     return ORBX_OK;
 }
 
+static HostPipe *pendingPipeOf(orbx_extractor *ex);
 static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int lap0,
                     int lap1, const HostFrames *host);
 
@@ -1320,6 +1342,8 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
                     int lap1, const HostFrames *host)
 {
     if (!ex || !d_imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: null argument");
+    if (ex->pending && !(host && host->pipe == pendingPipeOf(ex)))
+        return setError(ORBX_ERR_INVALID_ARG, "a batch submitted with orbx_extract_batch_submit is still pending on this handle: call orbx_extract_batch_wait first");
     if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
     // max_width / max_height are the largest image the handle will see: the per-level capacities of the selection and output buffers
@@ -1673,9 +1697,10 @@ static int downloadSmall(orbx_extractor *ex, const HostFrames *host, int nframes
 
 // One handle's share of a host batch: frames and results at the run mapping of `hf` (see HostFrames).
 static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int w, int h, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc,
-                            int capacity, int32_t *n_out, int32_t *mono_out)
+                            int capacity, int32_t *n_out, int32_t *mono_out, bool submit = false)
 {
     if (!ex || !hf.imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: null argument");
+    if (ex->pending) return setError(ORBX_ERR_INVALID_ARG, "a batch submitted with orbx_extract_batch_submit is still pending on this handle: call orbx_extract_batch_wait first");
     if (nframes <= 0 || w <= 0 || h <= 0 || hf.stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
     if (w > ex->prm.max_width || h > ex->prm.max_height)
@@ -1688,11 +1713,24 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
         hf.pipe = nullptr;
         rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
         if (rc != ORBX_OK) return rc;
+        if (submit) {  // the launches are queued; the wait fetches the results
+            PendingBatch *pb = new (std::nothrow) PendingBatch();
+            if (!pb) { drainHandle(ex); return setError(ORBX_ERR_OUT_OF_MEMORY, "orbx_extract_batch_submit: host allocation failed"); }
+            pb->small = true; pb->hf = hf; pb->nframes = nframes; pb->capacity = capacity; pb->kps = kps; pb->desc = desc; pb->nOut = n_out; pb->monoOut = mono_out;
+            ex->pending = pb;
+            return ORBX_OK;
+        }
         return downloadSmall(ex, &hf, nframes, kps, desc, capacity, n_out, mono_out);
     }
     if ((rc = ensureStage(ex)) != ORBX_OK) return rc;
     // H2D staging and the D2H of the results happen inside the launch sequence, sub-batch by sub-batch
-    HostPipe pipe;
+    PendingBatch *pb = nullptr;
+    if (submit) {
+        pb = new (std::nothrow) PendingBatch();
+        if (!pb) return setError(ORBX_ERR_OUT_OF_MEMORY, "orbx_extract_batch_submit: host allocation failed");
+    }
+    HostPipe localPipe;
+    HostPipe &pipe = pb ? pb->pipe : localPipe;
     pipe.kps = kps; pipe.desc = desc; pipe.capacity = capacity; pipe.nOut = n_out; pipe.monoOut = mono_out;
     static const int feederEnv = [] { const char *e = getenv("ORBX_HOST_FEEDER"); return e ? atoi(e) : -1; }();  // A/B: 0 no helper thread, 1 always
     // (first to last byte this handle reads: its last frame sits at host index hostIndex(nframes - 1))
@@ -1701,6 +1739,16 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
     pipe.direct = capacity == ex->maxKeypoints && hf.run >= nframes && (!kps || isPageLockedRange(kps, (size_t)nframes * capacity * sizeof(orbx_keypoint))) &&
                   (!desc || isPageLockedRange(desc, (size_t)nframes * capacity * 32));
     hf.pipe = &pipe;
+    if (pb) {
+        // submitted: every copy and launch of the batch is queued by this call and nothing of it is waited for - which only page-locked
+        // frames allow (pageable ones cross the link in blocking copies on a helper thread that the call has to stay with)
+        if (pipe.feeder) { delete pb; return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_submit: the frames must lie in page-locked memory (orbx_host_alloc / orbx_host_register), consecutive frames at a positive frame_stride"); }
+        pb->hf = hf; pb->hf.pipe = &pb->pipe; pb->nframes = nframes; pb->capacity = capacity; pb->kps = kps; pb->desc = desc; pb->nOut = n_out; pb->monoOut = mono_out;
+        ex->pending = pb;
+        rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &pb->hf);
+        if (rc != ORBX_OK) { drainHandle(ex); ex->pending = nullptr; delete pb; }
+        return rc;
+    }
     rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
     if (rc == ORBX_OK) rc = pipeDrain(ex, &hf, true, pipe.nsub);
     if (rc != ORBX_OK) drainHandle(ex);  // nothing of this call may still be running, or copying out of / into the caller's arrays
@@ -1721,6 +1769,36 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
     ORBX_API_ENTRY;
     const HostFrames hf = {imgs, stride, frame_stride, std::max(nframes, 1), std::max(nframes, 1), nullptr};
     return extractBatchHost(ex, hf, nframes, w, h, lap0, lap1, kps, desc, capacity, n_out, mono_out);
+}
+
+// Submit / wait: the same batch call in two halves.  A host-pointer call ends in a tail that no other work of the SAME call can cover - the
+// kernels of its last sub-batch and the copy-out of their results, ~0.9 of the 6.7 ms of a 1024-frame VGA call whose eight input copies
+// take 5.5 ms of link time (profiles/r03_host_batch_timeline.txt).  With the call split, one thread feeds two handles in turn - submit A,
+// submit B, wait A, submit A, wait B .. - and B's input copies cross the link under A's tail: the reference's two extractor objects driven
+// side by side (src/Frame.cc:124-127), without the second thread.
+extern "C" int orbx_extract_batch_submit(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
+                                         ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
+                                         int32_t *n_out, int32_t *mono_out)
+{
+    ORBX_API_ENTRY;
+    const HostFrames hf = {imgs, stride, frame_stride, std::max(nframes, 1), std::max(nframes, 1), nullptr};
+    return extractBatchHost(ex, hf, nframes, w, h, lap0, lap1, kps, desc, capacity, n_out, mono_out, true);
+}
+
+extern "C" int orbx_extract_batch_wait(orbx_extractor *ex)
+{
+    ORBX_API_ENTRY;
+    if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_wait: null handle");
+    PendingBatch *pb = ex->pending;
+    if (!pb) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_wait: no submitted batch on this handle");
+    HIP_TRY(hipSetDevice(ex->prm.device));
+    ex->pending = nullptr;
+    int rc;
+    if (pb->small) rc = downloadSmall(ex, &pb->hf, pb->nframes, pb->kps, pb->desc, pb->capacity, pb->nOut, pb->monoOut);
+    else rc = pipeDrain(ex, &pb->hf, true, pb->pipe.nsub);
+    if (rc != ORBX_OK) drainHandle(ex);
+    delete pb;
+    return rc;
 }
 
 // The C++-side sharding entry (frames shard over the GPUs, no data-path collective): block b of `block` consecutive
@@ -2701,7 +2779,7 @@ static int projectArgs(OrbxProjectArgs &a, const char *fn, int mode, const orbx_
     if (mode != 0 && mode != 1) return setError(ORBX_ERR_INVALID_ARG, "%s: mode must be 0 (motion model) or 1 (in frustum)", fn);
     if (!cam || (cam->type != 0 && cam->type != 1)) return setError(ORBX_ERR_INVALID_ARG, "%s: camera type must be 0 (Pinhole) or 1 (KannalaBrandt8)", fn);
     memset(&a, 0, sizeof a);
-    a.mode = mode; a.camType = cam->type;
+    a.mode = mode; a.camType = cam->type; a.poseStride = 16;
     memcpy(a.cam, cam->p, sizeof a.cam);
     if (mode == 1) {
         if (!bounds || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(logScaleFactor > 0.f))
@@ -2712,23 +2790,26 @@ static int projectArgs(OrbxProjectArgs &a, const char *fn, int mode, const orbx_
     return ORBX_OK;
 }
 
-static int projectHost(const char *fn, orbx_matcher *m, OrbxProjectArgs &a, const float *pose16, const orbx_world_point *points, int np,
-                       orbx_projection *out)
+// out2: the right camera's records of mode 2 (the device buffer holds both halves, maxQ records apart)
+static int projectHost(const char *fn, orbx_matcher *m, OrbxProjectArgs &a, const float *pose, const orbx_world_point *points, int np,
+                       void *out, void *out2 = nullptr)
 {
-    if (!m || np < 0 || (np > 0 && (!points || !out))) return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
+    static_assert(sizeof(orbx_projection) == sizeof(orbx_window_point), "the projection heads share one device buffer");
+    if (!m || np < 0 || (np > 0 && (!points || !out || (a.mode == 2 && !out2)))) return setError(ORBX_ERR_INVALID_ARG, "%s: bad argument", fn);
     if (np == 0) return ORBX_OK;
     if (np > m->maxQ) return setError(ORBX_ERR_CAPACITY, "%s: %d points exceed the matcher capacity %d", fn, np, m->maxQ);
     HIP_TRY(hipSetDevice(m->device));
-    int rc = m->d_proj.ensure((size_t)m->maxQ);
+    int rc = m->d_proj.ensure(2 * (size_t)m->maxQ);
     if (rc != ORBX_OK) return rc;
     HostPack in(m);
-    const size_t oP = in.add(pose16, 16 * sizeof(float)), oW = in.add(points, (size_t)np * sizeof(orbx_world_point));
+    const size_t oP = in.add(pose, (size_t)a.poseStride * sizeof(float)), oW = in.add(points, (size_t)np * sizeof(orbx_world_point));
     if ((rc = in.send()) != ORBX_OK) return rc;
     a.nframes = 1; a.maxNp = np; a.np = np; a.npDev = nullptr;
-    a.pose = in.dev<float>(oP); a.points = in.dev<uint8_t>(oW); a.out = m->d_proj.p;
+    a.pose = in.dev<float>(oP); a.points = in.dev<uint8_t>(oW); a.out = m->d_proj.p; a.out2 = m->d_proj.p + m->maxQ;
     HIP_TRY(orbxLaunchProjectPoints(m->stream, &a));
     HostFetch res(m);
     res.add(out, m->d_proj.p, (size_t)np * sizeof(orbx_projection));
+    if (a.mode == 2) res.add(out2, m->d_proj.p + m->maxQ, (size_t)np * sizeof(orbx_projection));
     return res.finish();
 }
 
@@ -2773,6 +2854,104 @@ extern "C" int orbx_project_points_frames(orbx_matcher *m, int mode, int nframes
     HIP_TRY(hipSetDevice(m->device));
     a.nframes = nframes; a.maxNp = max_np; a.np = max_np; a.npDev = d_np;
     a.pose = d_pose; a.points = d_points; a.out = d_proj_out;
+    HIP_TRY(orbxLaunchProjectPoints(m->stream, &a));
+    return ORBX_OK;
+}
+
+// Frame::isInFrustum of a fisheye rig: both cameras' records (mode 2 of k_project_points).
+static int fisheyeFrustumArgs(OrbxProjectArgs &a, const char *fn, const float *cam1, const float *cam2, const float *bounds, float viewCosLimit,
+                              float logScaleFactor, int nlevels, int farPoints, float thFar)
+{
+    if (!cam1 || !cam2 || !bounds || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(logScaleFactor > 0.f))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: needs both cameras, bounds, 0 < nlevels <= %d and log_scale_factor > 0", fn, ORBX_MAX_LEVELS);
+    memset(&a, 0, sizeof a);
+    a.mode = 2; a.camType = 1; a.poseStride = 40;
+    memcpy(a.cam, cam1, sizeof a.cam); memcpy(a.cam2, cam2, sizeof a.cam2);
+    a.minX = bounds[0]; a.maxX = bounds[1]; a.minY = bounds[2]; a.maxY = bounds[3];
+    a.viewCosLimit = viewCosLimit; a.logScaleFactor = logScaleFactor; a.nlevels = nlevels; a.farPoints = farPoints; a.thFar = thFar;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_project_in_frustum_fisheye(orbx_matcher *m, const float *Rcw, const float *tcw, const float *Ow, const float *Rrl,
+                                               const float *trl, const float *tlr, const float *Rwc, const float *cam1, const float *cam2,
+                                               const float *bounds, float viewing_cos_limit, float log_scale_factor, int nlevels, int far_points,
+                                               float th_far_points, const orbx_world_point *points, int np, orbx_projection *proj_left_out,
+                                               orbx_projection *proj_right_out)
+{
+    ORBX_API_ENTRY;
+    if (!Rcw || !tcw || !Ow || !Rrl || !trl || !tlr || !Rwc) return setError(ORBX_ERR_INVALID_ARG, "orbx_project_in_frustum_fisheye: null pose");
+    OrbxProjectArgs a;
+    int rc = fisheyeFrustumArgs(a, "orbx_project_in_frustum_fisheye", cam1, cam2, bounds, viewing_cos_limit, log_scale_factor, nlevels, far_points, th_far_points);
+    if (rc != ORBX_OK) return rc;
+    float pose[40] = {0};
+    memcpy(pose, Rcw, 36); memcpy(pose + 9, tcw, 12); memcpy(pose + 12, Ow, 12); memcpy(pose + 15, Rrl, 36); memcpy(pose + 24, trl, 12);
+    memcpy(pose + 27, tlr, 12); memcpy(pose + 30, Rwc, 36);
+    return projectHost("orbx_project_in_frustum_fisheye", m, a, pose, points, np, proj_left_out, proj_right_out);
+}
+
+extern "C" int orbx_project_in_frustum_fisheye_frames(orbx_matcher *m, int nframes, const float *d_pose, const float *cam1, const float *cam2,
+                                                      const float *bounds, float viewing_cos_limit, float log_scale_factor, int nlevels,
+                                                      int far_points, float th_far_points, const orbx_world_point *d_points, const int32_t *d_np,
+                                                      int max_np, orbx_projection *d_proj_left_out, orbx_projection *d_proj_right_out)
+{
+    ORBX_API_ENTRY;
+    if (!m || nframes < 0 || max_np < 0 || (nframes > 0 && max_np > 0 && (!d_pose || !d_points || !d_np || !d_proj_left_out || !d_proj_right_out)))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_project_in_frustum_fisheye_frames: bad argument");
+    OrbxProjectArgs a;
+    int rc = fisheyeFrustumArgs(a, "orbx_project_in_frustum_fisheye_frames", cam1, cam2, bounds, viewing_cos_limit, log_scale_factor, nlevels, far_points, th_far_points);
+    if (rc != ORBX_OK) return rc;
+    if (nframes == 0 || max_np == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    a.nframes = nframes; a.maxNp = max_np; a.np = max_np; a.npDev = d_np;
+    a.pose = d_pose; a.points = d_points; a.out = d_proj_left_out; a.out2 = d_proj_right_out;
+    HIP_TRY(orbxLaunchProjectPoints(m->stream, &a));
+    return ORBX_OK;
+}
+
+// The head of Fuse / SearchByProjection(KeyFrame, Sim3) / SearchByProjection(Frame, KeyFrame): orbx_window_point records (mode 3).
+static int windowPointArgs(OrbxProjectArgs &a, const char *fn, const orbx_camera *cam, const float *bounds, float bf, float th,
+                           const float *scaleFactors, float logScaleFactor, int nlevels, int tests)
+{
+    if (!cam || (cam->type != 0 && cam->type != 1)) return setError(ORBX_ERR_INVALID_ARG, "%s: camera type must be 0 (Pinhole) or 1 (KannalaBrandt8)", fn);
+    if (!bounds || !scaleFactors || nlevels <= 0 || nlevels > ORBX_MAX_LEVELS || !(logScaleFactor > 0.f) || (tests & ~7))
+        return setError(ORBX_ERR_INVALID_ARG, "%s: needs bounds, scale factors, 0 < nlevels <= %d, log_scale_factor > 0 and tests in 0..7", fn, ORBX_MAX_LEVELS);
+    memset(&a, 0, sizeof a);
+    a.mode = 3; a.camType = cam->type; a.poseStride = 16;
+    memcpy(a.cam, cam->p, sizeof a.cam);
+    a.minX = bounds[0]; a.maxX = bounds[1]; a.minY = bounds[2]; a.maxY = bounds[3];
+    a.mbf = bf; a.th = th; a.logScaleFactor = logScaleFactor; a.nlevels = nlevels; a.tests = tests;
+    for (int l = 0; l < nlevels; ++l) a.scaleFactors[l] = scaleFactors[l];
+    return ORBX_OK;
+}
+
+extern "C" int orbx_project_window_points(orbx_matcher *m, const float *q_xyzw, const float *t, const float *Ow, const orbx_camera *cam,
+                                          const float *bounds, float bf, float th, const float *scale_factors, float log_scale_factor, int nlevels,
+                                          int tests, const orbx_world_point *points, int np, struct orbx_window_point_s *points_out)
+{
+    ORBX_API_ENTRY;
+    if (!q_xyzw || !t || !Ow) return setError(ORBX_ERR_INVALID_ARG, "orbx_project_window_points: null pose");
+    OrbxProjectArgs a;
+    int rc = windowPointArgs(a, "orbx_project_window_points", cam, bounds, bf, th, scale_factors, log_scale_factor, nlevels, tests);
+    if (rc != ORBX_OK) return rc;
+    float pose[16] = {0};
+    memcpy(pose, q_xyzw, 16); memcpy(pose + 4, t, 12); memcpy(pose + 7, Ow, 12);
+    return projectHost("orbx_project_window_points", m, a, pose, points, np, points_out);
+}
+
+extern "C" int orbx_project_window_points_frames(orbx_matcher *m, int nframes, const float *d_pose, const orbx_camera *cam, const float *bounds,
+                                                 float bf, float th, const float *scale_factors, float log_scale_factor, int nlevels, int tests,
+                                                 const orbx_world_point *d_points, const int32_t *d_np, int max_np, struct orbx_window_point_s *d_points_out)
+{
+    ORBX_API_ENTRY;
+    if (!m || nframes < 0 || max_np < 0 || (nframes > 0 && max_np > 0 && (!d_pose || !d_points || !d_np || !d_points_out)))
+        return setError(ORBX_ERR_INVALID_ARG, "orbx_project_window_points_frames: bad argument");
+    OrbxProjectArgs a;
+    int rc = windowPointArgs(a, "orbx_project_window_points_frames", cam, bounds, bf, th, scale_factors, log_scale_factor, nlevels, tests);
+    if (rc != ORBX_OK) return rc;
+    if (nframes == 0 || max_np == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    a.nframes = nframes; a.maxNp = max_np; a.np = max_np; a.npDev = d_np;
+    a.pose = d_pose; a.points = d_points; a.out = d_points_out;
     HIP_TRY(orbxLaunchProjectPoints(m->stream, &a));
     return ORBX_OK;
 }

@@ -283,9 +283,13 @@ struct OrbxKfwFrames {
 hipError_t orbxLaunchKeyframeWindowSearchFrames(hipStream_t st, const OrbxKfwFrames *b);
 // projection head of the tracking searches (orbx_project_points_frames): scalar parameters of the in-frustum mode
 struct OrbxProjectArgs {
-    int mode, nframes, maxNp;          // mode 0 motion model (Sophus SE3f * point), 1 Frame::isInFrustum
-    const float *pose;                 // [nframes][16] device (or the one pose of a single call, also device)
-    int camType; float cam[8];
+    int mode, nframes, maxNp;          // mode 0 motion model (Sophus SE3f * point), 1 Frame::isInFrustum, 2 the same for a fisheye rig (both
+                                       // cameras), 3 the head of the keyframe-side window searches (orbx_window_point records)
+    const float *pose;                 // [nframes][poseStride] device (or the one pose of a single call, also device)
+    int poseStride;                    // floats per frame: 16 (modes 0, 1, 3), 40 (mode 2)
+    int camType; float cam[8], cam2[8];  // cam2: the right camera of mode 2
+    float th, scaleFactors[ORBX_MAX_LEVELS]; int tests;   // mode 3: radius = th * mvScaleFactors[level]; tests bit 0 depth, 1 viewing angle, 2 Frame bounds
+    void *out2;                        // mode 2: the right camera's records
     float minX, maxX, minY, maxY, mbf, viewCosLimit, logScaleFactor, thFar;
     int nlevels, farPoints;
     const void *points; const int *npDev; int np;  // npDev NULL: np points in every frame

@@ -3173,60 +3173,134 @@ __device__ __forceinline__ void pp_camera_project(int type, const float *P, cons
     } else fe_project(P, v, uv);  // KannalaBrandt8::project, src/CameraModels/KannalaBrandt8.cpp:67-84
 }
 
+// MapPoint::PredictScale (src/MapPoint.cc:514-546): ceil(log(ratio) / mfLogScaleFactor) in FLOAT - std::log(float) is glibc's logf
+// (include/orbx_libm.h, pinned), a float division, std::ceil(float); the int conversion of a NaN / out-of-range value gives INT_MIN on
+// x86-64 (cvttss2si), which the first clamp turns into level 0
+__device__ __forceinline__ int pp_predict_scale(float maxD, float dist, float logScaleFactor, int nlevels)
+{
+    const float ratio = __fdiv_rn(maxD, dist);
+    const float lv = ceilf(__fdiv_rn(orbx_glibc_logf(ratio), logScaleFactor));
+    int nScale = (lv >= -2147483648.0f && lv < 2147483648.0f) ? (int)lv : INT_MIN;
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nlevels) nScale = nlevels - 1;
+    return nScale;
+}
+
+// one camera of Frame::isInFrustum / isInFrustumChecks (src/Frame.cc:549-599, 1198-1272): R (row-major), t = that camera's pose, twc its centre
+struct PpSide { bool in; float u, v, invz, viewCos, PcDist; int level; };
+__device__ PpSide pp_frustum_side(const float *R, const float *t, const float *twc, int camType, const float *cam, const OrbxProjectArgs &a,
+                                  const ProjPointIn &pt)
+{
+    PpSide o;
+    const float *p = pt.pos;
+    float Pc[3];
+    for (int k = 0; k < 3; ++k)
+        Pc[k] = __fadd_rn(pp_sum3(__fmul_rn(R[3 * k], p[0]), __fmul_rn(R[3 * k + 1], p[1]), __fmul_rn(R[3 * k + 2], p[2])), t[k]);
+    o.PcDist = fe_sqrtf(pp_sum3(__fmul_rn(Pc[0], Pc[0]), __fmul_rn(Pc[1], Pc[1]), __fmul_rn(Pc[2], Pc[2])));
+    o.invz = __fdiv_rn(1.0f, Pc[2]);
+    bool in = !(Pc[2] < 0.0f);
+    float w[2];
+    pp_camera_project(camType, cam, Pc, w);
+    if (w[0] < a.minX || w[0] > a.maxX) in = false;
+    if (w[1] < a.minY || w[1] > a.maxY) in = false;
+    const float maxDistance = __fmul_rn(1.2f, pt.maxD), minDistance = __fmul_rn(0.8f, pt.minD);
+    const float PO[3] = {__fsub_rn(p[0], twc[0]), __fsub_rn(p[1], twc[1]), __fsub_rn(p[2], twc[2])};
+    const float dist = fe_sqrtf(pp_sum3(__fmul_rn(PO[0], PO[0]), __fmul_rn(PO[1], PO[1]), __fmul_rn(PO[2], PO[2])));
+    if (dist < minDistance || dist > maxDistance) in = false;
+    o.viewCos = __fdiv_rn(pp_sum3(__fmul_rn(PO[0], pt.normal[0]), __fmul_rn(PO[1], pt.normal[1]), __fmul_rn(PO[2], pt.normal[2])), dist);
+    if (o.viewCos < a.viewCosLimit) in = false;
+    o.level = pp_predict_scale(pt.maxD, dist, a.logScaleFactor, a.nlevels);
+    o.u = w[0]; o.v = w[1]; o.in = in;
+    return o;
+}
+
+// x3Dc = Tcw * x3Dw with Tcw a Sophus::SE3f: q = x y z w, t (Thirdparty/Sophus/sophus/so3.hpp:358-367, se3.hpp)
+__device__ __forceinline__ void pp_se3_apply(const float *q, const float *t, const float *p, float *x)
+{
+    float uv[3], c2[3];
+    pp_cross(q, p, uv);
+    for (int k = 0; k < 3; ++k) uv[k] = __fadd_rn(uv[k], uv[k]);
+    pp_cross(q, uv, c2);
+    for (int k = 0; k < 3; ++k) x[k] = __fadd_rn(__fadd_rn(__fadd_rn(p[k], __fmul_rn(q[3], uv[k])), c2[k]), t[k]);
+}
+
+struct WindowPointOut { float u, v, ur, radius; int level, search; };   // orbx_window_point
+
 __global__ __launch_bounds__(256) void k_project_points(OrbxProjectArgs a)
 {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int np = a.npDev ? min(a.npDev[f], a.maxNp) : a.np;
     if (i >= np) return;
     const ProjPointIn pt = ((const ProjPointIn *)a.points)[(size_t)f * a.maxNp + i];
-    const float *T = a.pose + (size_t)f * 16;
+    const float *T = a.pose + (size_t)f * a.poseStride;
     SbpProj o;
     o.angle = pt.angle; o.octave = pt.octave; o.flags = pt.flags;
     const float *p = pt.pos;
     if (a.mode == 0) {
         // x3Dc = Tcw * x3Dw (src/ORBmatcher3.cc:283-284)
-        const float *q = T, *t = T + 4;  // q = x y z w
-        float uv[3], c2[3], x[3];
-        pp_cross(q, p, uv);
-        for (int k = 0; k < 3; ++k) uv[k] = __fadd_rn(uv[k], uv[k]);
-        pp_cross(q, uv, c2);
-        for (int k = 0; k < 3; ++k) x[k] = __fadd_rn(__fadd_rn(__fadd_rn(p[k], __fmul_rn(q[3], uv[k])), c2[k]), t[k]);
+        float x[3];
+        pp_se3_apply(T, T + 4, p, x);
         o.invz = (float)__ddiv_rn(1.0, (double)x[2]);   // const float invzc = 1.0 / x3Dc(2) (:288)
         float w[2];
         pp_camera_project(a.camType, a.cam, x, w);       // (:293)
         o.u = w[0]; o.v = w[1];
-    } else {
+    } else if (a.mode == 1) {
         // Frame::isInFrustum, src/Frame.cc:549-599
-        const float *R = T, *t = T + 9, *Ow = T + 12;
-        float Pc[3];
-        for (int k = 0; k < 3; ++k)
-            Pc[k] = __fadd_rn(pp_sum3(__fmul_rn(R[3 * k], p[0]), __fmul_rn(R[3 * k + 1], p[1]), __fmul_rn(R[3 * k + 2], p[2])), t[k]);
-        const float PcDist = fe_sqrtf(pp_sum3(__fmul_rn(Pc[0], Pc[0]), __fmul_rn(Pc[1], Pc[1]), __fmul_rn(Pc[2], Pc[2])));
-        const float invz = __fdiv_rn(1.0f, Pc[2]);
-        bool in = !(Pc[2] < 0.0f);
+        const PpSide sd = pp_frustum_side(T, T + 9, T + 12, a.camType, a.cam, a, pt);
+        bool in = sd.in;
+        if (a.farPoints && sd.PcDist > a.thFar) in = false;   // src/ORBmatcher1.cc:57-58 (mTrackDepth = Pc_dist)
+        o.u = sd.u; o.v = sd.v;
+        o.invz = __fsub_rn(sd.u, __fmul_rn(a.mbf, sd.invz));   // mTrackProjXR
+        o.angle = sd.viewCos; o.octave = sd.level;
+        o.flags = (pt.flags & ~1) | ((pt.flags & 1) && in ? 1 : 0);
+    } else if (a.mode == 2) {
+        // Frame::isInFrustum of a fisheye rig (src/Frame.cc:604-614): isInFrustumChecks for both cameras (:1198-1272).  Pose block: Rcw[9] tcw[3]
+        // Ow[3] Rrl[9] trl[3] tlr[3] Rwc[9]; the right camera's pose as the reference forms it per call (:1204-1210), coefficient by coefficient
+        const float *Rcw = T, *tcw = T + 9, *Ow = T + 12, *Rrl = T + 15, *trl = T + 24, *tlr = T + 27, *Rwc = T + 30;
+        float mR[9], mt[3], twc[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c)
+                mR[3 * r + c] = pp_sum3(__fmul_rn(Rrl[3 * r], Rcw[c]), __fmul_rn(Rrl[3 * r + 1], Rcw[3 + c]), __fmul_rn(Rrl[3 * r + 2], Rcw[6 + c]));
+            mt[r] = __fadd_rn(pp_sum3(__fmul_rn(Rrl[3 * r], tcw[0]), __fmul_rn(Rrl[3 * r + 1], tcw[1]), __fmul_rn(Rrl[3 * r + 2], tcw[2])), trl[r]);
+            twc[r] = __fadd_rn(pp_sum3(__fmul_rn(Rwc[3 * r], tlr[0]), __fmul_rn(Rwc[3 * r + 1], tlr[1]), __fmul_rn(Rwc[3 * r + 2], tlr[2])), Ow[r]);
+        }
+        const PpSide l = pp_frustum_side(Rcw, tcw, Ow, 1, a.cam, a, pt);
+        const PpSide r = pp_frustum_side(mR, mt, twc, 1, a.cam2, a, pt);
+        const bool live = (pt.flags & 1) && !(a.farPoints && l.PcDist > a.thFar);   // the far-point test reads the LEFT camera's depth for both sides
+        o.u = l.u; o.v = l.v; o.invz = l.PcDist; o.angle = l.viewCos; o.octave = l.level;
+        o.flags = (pt.flags & ~1) | (live && l.in ? 1 : 0);
+        ((SbpProj *)a.out)[(size_t)f * a.maxNp + i] = o;
+        o.u = r.u; o.v = r.v; o.invz = r.PcDist; o.angle = r.viewCos; o.octave = r.level;
+        o.flags = (pt.flags & ~1) | (live && r.in ? 1 : 0);
+        ((SbpProj *)a.out2)[(size_t)f * a.maxNp + i] = o;
+        return;
+    } else {
+        // the head of Fuse / SearchByProjection(KeyFrame, Sim3) / SearchByProjection(Frame, KeyFrame): src/ORBmatcher2.cc:469-520,
+        // src/ORBmatcher1.cc:459-494, src/ORBmatcher3.cc:492-519.  Pose block: q[4] t[3] Ow[3]
+        const float *Ow = T + 7;
+        float x[3];
+        pp_se3_apply(T, T + 4, p, x);
+        bool ok = (pt.flags & 1) != 0;
+        if ((a.tests & 1) && x[2] < 0.0f) ok = false;
+        const float invz = __fdiv_rn(1.0f, x[2]);
         float w[2];
-        pp_camera_project(a.camType, a.cam, Pc, w);
-        if (w[0] < a.minX || w[0] > a.maxX) in = false;
-        if (w[1] < a.minY || w[1] > a.maxY) in = false;
+        pp_camera_project(a.camType, a.cam, x, w);
+        if (a.tests & 4) { if (w[0] < a.minX || w[0] > a.maxX || w[1] < a.minY || w[1] > a.maxY) ok = false; }   // Frame: mnMinX .. bounds, inclusive
+        else if (!(w[0] >= a.minX && w[0] < a.maxX && w[1] >= a.minY && w[1] < a.maxY)) ok = false;            // KeyFrame::IsInImage
         const float maxDistance = __fmul_rn(1.2f, pt.maxD), minDistance = __fmul_rn(0.8f, pt.minD);
         const float PO[3] = {__fsub_rn(p[0], Ow[0]), __fsub_rn(p[1], Ow[1]), __fsub_rn(p[2], Ow[2])};
         const float dist = fe_sqrtf(pp_sum3(__fmul_rn(PO[0], PO[0]), __fmul_rn(PO[1], PO[1]), __fmul_rn(PO[2], PO[2])));
-        if (dist < minDistance || dist > maxDistance) in = false;
-        const float viewCos = __fdiv_rn(pp_sum3(__fmul_rn(PO[0], pt.normal[0]), __fmul_rn(PO[1], pt.normal[1]), __fmul_rn(PO[2], pt.normal[2])), dist);
-        if (viewCos < a.viewCosLimit) in = false;
-        // MapPoint::PredictScale (src/MapPoint.cc:531-546): ceil(log(ratio) / mfLogScaleFactor) in FLOAT - std::log(float) is glibc's logf
-        // (include/orbx_libm.h, pinned), a float division, std::ceil(float); the int conversion of a NaN / out-of-range value gives INT_MIN
-        // on x86-64 (cvttss2si), which the first clamp turns into level 0
-        const float ratio = __fdiv_rn(pt.maxD, dist);
-        const float lv = ceilf(__fdiv_rn(orbx_glibc_logf(ratio), a.logScaleFactor));
-        int nScale = (lv >= -2147483648.0f && lv < 2147483648.0f) ? (int)lv : INT_MIN;
-        if (nScale < 0) nScale = 0;
-        else if (nScale >= a.nlevels) nScale = a.nlevels - 1;
-        if (a.farPoints && PcDist > a.thFar) in = false;   // src/ORBmatcher1.cc:57-58 (mTrackDepth = Pc_dist)
-        o.u = w[0]; o.v = w[1];
-        o.invz = __fsub_rn(w[0], __fmul_rn(a.mbf, invz));   // mTrackProjXR
-        o.angle = viewCos; o.octave = nScale;
-        o.flags = (pt.flags & ~1) | ((pt.flags & 1) && in ? 1 : 0);
+        if (dist < minDistance || dist > maxDistance) ok = false;
+        // `PO.dot(Pn) < 0.5 * dist3D`: the right side is a double product, the float dot product is promoted
+        if ((a.tests & 2) &&
+            (double)pp_sum3(__fmul_rn(PO[0], pt.normal[0]), __fmul_rn(PO[1], pt.normal[1]), __fmul_rn(PO[2], pt.normal[2])) < __dmul_rn(0.5, (double)dist))
+            ok = false;
+        const int level = pp_predict_scale(pt.maxD, dist, a.logScaleFactor, a.nlevels);
+        WindowPointOut wo;
+        wo.u = w[0]; wo.v = w[1]; wo.ur = __fsub_rn(w[0], __fmul_rn(a.mbf, invz)); wo.radius = __fmul_rn(a.th, a.scaleFactors[level]);
+        wo.level = level; wo.search = ok ? 1 : 0;
+        ((WindowPointOut *)a.out)[(size_t)f * a.maxNp + i] = wo;
+        return;
     }
     ((SbpProj *)a.out)[(size_t)f * a.maxNp + i] = o;
 }
