@@ -7,7 +7,7 @@ synthetic 640x480 mono frames, nFeatures=1000, 8 levels, scale 1.2, per GPU - ov
 (18,432 frames, 5.7 GB of the 288 GB of HBM), so the timed region covers 360 batches / 1.1 s at the default 20 steps.  `value` = frames/s with the inputs resident in HBM before
 the timed region and the results left in HBM (`value_definition` in the line says so).  SURVEY §8(d)'s metric - the PCIe-inclusive
 rate of the host-pointer API orbx_extract_batch, H2D of the frames and D2H of keypoints + descriptors inside the call, page-locked
-caller buffers - is the top-level `metric_8d_frames_per_s` (two batches in flight through orbx_extract_batch_submit / _wait; `pcie_inclusive_*` per kind of
+caller buffers - is the top-level `metric_8d_frames_per_s` (two batches in flight on the handle through orbx_extract_batch_submit / _wait; `pcie_inclusive_*` per kind of
 caller memory and for one call at a time), measured on EVERY rank
 at every N (each rank its own host buffers, barrier on both sides, aggregate = all ranks' frames / slowest rank's wall time) - never `value`.
 
@@ -484,31 +484,34 @@ def main() -> None:
             pcie[tag] = {"rank_frames_per_s": reps * np_units * fpu / wall,
                          "frames_per_s": all_reduce(reps * np_units * fpu, "sum") / all_reduce(wall, "max")}
 
-        # the same API with two batches in flight (orbx_extract_batch_submit / _wait): ONE host thread feeds two handles in turn, so that one
-        # call's frames cross the link under the other call's tail (its last sub-batch's kernels and results) - the reference's two extractor
-        # objects side by side (src/Frame.cc:124-127).  Mono: a second handle of the same parameters; stereo: the left and the right handle.
-        ex2 = exr if stereo else pkg.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank, max_width=W, max_height=H, max_batch=B)
-        lanes = [(exl, pl, outs[True][0]), (ex2, pr if stereo else pl, outs[True][1] if stereo else ex2.output_arrays(np_units, page_locked=True))]
-        for ex_, fr_, out_ in lanes:                      # warm-up: one synchronous call each
-            ex_.extract_batch(fr_, cfg["lap"], out=out_)
+        # the same API with two batches in flight per handle (orbx_extract_batch_submit / _wait): the frames of a batch cross the link - into the
+        # handle's second staging buffer - under the kernels and the copy-out of the batch before, so the link never waits for the GPU.  One
+        # host thread; stereo: the left and the right handle in turn, two batches in flight on each.
+        lanes = [(exl, pl)] + ([(exr, pr)] if stereo else [])
+        lane_outs = [[ex_.output_arrays(np_units, page_locked=True) for _ in range(2)] for ex_, _ in lanes]
+        for (ex_, fr_), oo in zip(lanes, lane_outs):        # warm-up: one synchronous call each (allocates nothing inside the timed part
+            ex_.extract_batch(fr_, cfg["lap"], out=oo[0])     # but the second staging buffer, which the first double submit below creates)
+        for (ex_, fr_), oo in zip(lanes, lane_outs):
+            ex_.extract_batch_submit(fr_, cfg["lap"], out=oo[0]); ex_.extract_batch_submit(fr_, cfg["lap"], out=oo[1])
+        for (ex_, fr_), oo in zip(lanes, lane_outs):
+            ex_.extract_batch_wait(); ex_.extract_batch_wait()
         if world > 1:
             dist.barrier()
+        calls = 2 * reps
         t1 = time.perf_counter()
-        for ex_, fr_, out_ in lanes:
-            ex_.extract_batch_submit(fr_, cfg["lap"], out=out_)
-        for _ in range(reps - 1):
-            for ex_, fr_, out_ in lanes:
+        for (ex_, fr_), oo in zip(lanes, lane_outs):
+            ex_.extract_batch_submit(fr_, cfg["lap"], out=oo[0]); ex_.extract_batch_submit(fr_, cfg["lap"], out=oo[1])
+        for k in range(2, calls):
+            for (ex_, fr_), oo in zip(lanes, lane_outs):
                 ex_.extract_batch_wait()
-                ex_.extract_batch_submit(fr_, cfg["lap"], out=out_)
-        for ex_, fr_, out_ in lanes:
-            ex_.extract_batch_wait()
+                ex_.extract_batch_submit(fr_, cfg["lap"], out=oo[k & 1])
+        for (ex_, fr_), oo in zip(lanes, lane_outs):
+            ex_.extract_batch_wait(); ex_.extract_batch_wait()
         wall = time.perf_counter() - t1
         if world > 1:
             dist.barrier()
-        pcie["page_locked_pipelined"] = {"rank_frames_per_s": 2 * reps * np_units / wall,
-                                         "frames_per_s": all_reduce(2 * reps * np_units, "sum") / all_reduce(wall, "max")}
-        if not stereo:
-            ex2.close()
+        pcie["page_locked_pipelined"] = {"rank_frames_per_s": calls * np_units * fpu / wall,
+                                         "frames_per_s": all_reduce(calls * np_units * fpu, "sum") / all_reduce(wall, "max")}
 
     if rank != 0:
         if world > 1:
@@ -623,8 +626,8 @@ def main() -> None:
         res = {tag: v["frames_per_s"] for tag, v in pcie.items()}
         out["metric_8d_frames_per_s"] = round(res["page_locked_pipelined"], 1)
         out["metric_8d_definition"] = ("SURVEY 8(d): the host-pointer batch API, host frames in (H2D) and keypoints + descriptors out (D2H) inside the calls, page-locked "
-                                       "caller buffers, two batches in flight from one host thread (orbx_extract_batch_submit / _wait on two handles: one call's frames "
-                                       "cross the link under the other's tail); one call at a time = pcie_inclusive_page_locked_frames_per_s; all ranks at the same "
+                                       "caller buffers, two batches in flight on the handle from one host thread (orbx_extract_batch_submit / _wait: a batch's frames "
+                                       "cross the link under the kernels and the copy-out of the one before); one call at a time = pcie_inclusive_page_locked_frames_per_s; all ranks at the same "
                                        "time, all ranks' frames / slowest rank's wall time")
         out["pcie_inclusive_frames_per_s"] = round(res["pageable"], 1)
         out["pcie_inclusive_pinned_input_frames_per_s"] = round(res["pinned_input"], 1)

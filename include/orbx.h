@@ -128,14 +128,19 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int
                        int32_t *n_out, int32_t *mono_out);
 
 /* orbx_extract_batch in two halves, for callers that keep the link busy across calls.  submit queues every copy and launch of the batch
- * and returns without waiting; wait blocks until the results are in the caller's arrays (n_out / mono_out included) and returns the
- * call's status.  A host-pointer call ends in a tail nothing of the same call can cover (the last sub-batch's kernels and its results,
- * ~0.9 of 6.7 ms for 1024 VGA frames): one thread that feeds TWO handles in turn - submit(A), submit(B), wait(A), submit(A), wait(B) ..
- * - has B's frames cross the link under A's tail, as the reference's two extractor objects run side by side on two threads
- * (src/Frame.cc:124-127, 1089-1092).  Requirements: the frames in page-locked memory (orbx_host_alloc / orbx_host_register; pageable
- * frames need the calling thread: ORBX_ERR_INVALID_ARG); frames and result arrays stay valid and untouched until the wait returns; one
- * batch pending per handle - until its wait every other extraction call on the handle is refused, and the handle's device outputs
- * (orbx_device_outputs, the *_frames matcher calls) belong to the pending batch.  orbx_destroy drains a batch nobody waited for. */
+ * and returns without waiting; wait blocks until the results of the OLDEST submitted batch are in the caller's arrays (n_out / mono_out
+ * included) and returns that call's status.  TWO batches may be pending on a handle: a host-pointer call ends in a tail nothing of the
+ * same call can cover (the last sub-batch's kernels and its results, ~0.9 of 6.7 ms for 1024 VGA frames), and with
+ *     submit(b0); submit(b1); for (;;) { wait(); submit(next); }
+ * the frames of the following batch cross the link - into a second staging buffer - under the kernels and the copy-out of the one before:
+ * the link never waits for the GPU (the reference keeps two extractor objects busy side by side for the same reason, src/Frame.cc:124-127,
+ * 1089-1092).  Two HANDLES in flight from one process do not reach this: their streams share the runtime's four hardware queues and
+ * serialise behind each other's barrier packets (profiles/r05_submit_wait.txt).  Requirements: the frames in page-locked memory
+ * (orbx_host_alloc / orbx_host_register; pageable frames need the calling thread: ORBX_ERR_INVALID_ARG); frames and result arrays stay
+ * valid and untouched until the batch's wait returns; while a batch is pending every other extraction call on the handle is refused
+ * (a second submit of a batch of more than 16 frames excepted), and the handle's device outputs (orbx_device_outputs, the *_frames
+ * matcher calls) belong to the newest pending batch.  A batch of <= 16 frames (the single-frame schedule) can be submitted only alone.
+ * An error of a wait drops the other pending batch too.  orbx_destroy drains batches nobody waited for. */
 int orbx_extract_batch_submit(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
                               ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
                               int32_t *n_out, int32_t *mono_out);

@@ -318,11 +318,11 @@ def test_host_batch_page_locked_and_reused_arrays(pkg):
 
 
 def test_submit_wait_two_batches_in_flight(pkg):
-    """orbx_extract_batch_submit / _wait (round 5): one thread keeps TWO handles busy - submit A, submit B, wait A, submit A, wait B .. - so
-    that one call's input copies cross the link under the other's tail.  Every frame's result is its own, byte for byte what the
-    synchronous call gives: through staging (pageable result arrays) and written by the device (page-locked ones), for different batches
-    in flight at the same time, and for a small (graph-schedule) batch.  A second submit on a busy handle, any other extraction call on it,
-    pageable frames and a wait with nothing pending are refused."""
+    """orbx_extract_batch_submit / _wait (round 5): two batches in flight on ONE handle - submit b0, submit b1, then wait / submit in turn -
+    so that a batch's frames cross the link (into the second staging buffer) under the kernels and the copy-out of the one before.  Every
+    frame's result is its own, byte for byte what the synchronous call gives: through staging (pageable result arrays) and written by
+    the device (page-locked ones), different batches in flight, different batch sizes, a small (graph-schedule) batch, two handles.  A
+    third submit, any other extraction call on a busy handle, pageable frames and a wait with nothing pending are refused."""
     B, w, h = 160, 640, 480
     batches = [np.stack([pkg.synth_frame(9000 + 1000 * k + i, w, h) for i in range(B)]) for k in range(3)]
     a = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
@@ -331,10 +331,10 @@ def test_submit_wait_two_batches_in_flight(pkg):
     pims = []
     for img in batches:
         p_ = pkg.host_array(img.shape, np.uint8); p_[...] = img; pims.append(p_)
-    outs = [a.output_arrays(B, page_locked=True), b.output_arrays(B), a.output_arrays(B, page_locked=True)]
+    outs = [a.output_arrays(B, page_locked=True), a.output_arrays(B), a.output_arrays(B, page_locked=True)]
     a.extract_batch_submit(pims[0], (0, 0), out=outs[0])
-    b.extract_batch_submit(pims[1], (0, 0), out=outs[1])
-    with pytest.raises(pkg.OrbxError, match="pending"):
+    a.extract_batch_submit(pims[1], (0, 0), out=outs[1])
+    with pytest.raises(pkg.OrbxError, match="two submitted batches"):
         a.extract_batch_submit(pims[2], (0, 0), out=outs[2])
     with pytest.raises(pkg.OrbxError, match="pending"):
         a.extract_batch(batches[2], (0, 0))
@@ -342,23 +342,42 @@ def test_submit_wait_two_batches_in_flight(pkg):
         a(batches[2][0], None, (0, 0))
     _same_valid_rows(refs[0], a.extract_batch_wait())
     a.extract_batch_submit(pims[2], (0, 0), out=outs[2])
-    _same_valid_rows(refs[1], b.extract_batch_wait())
+    _same_valid_rows(refs[1], a.extract_batch_wait())
     _same_valid_rows(refs[2], a.extract_batch_wait())
-    for rounds in range(3):                     # steady state: the same arrays reused, results still each call's own
-        a.extract_batch_submit(pims[rounds % 3], (0, 0), out=outs[0])
-        b.extract_batch_submit(pims[(rounds + 1) % 3], (0, 0), out=outs[1])
-        _same_valid_rows(refs[rounds % 3], a.extract_batch_wait())
-        _same_valid_rows(refs[(rounds + 1) % 3], b.extract_batch_wait())
+    # steady state: wait / submit in turn, the arrays reused; every other batch is shorter (other sub-batch sizes) and starts inside its arrays
+    queue = []
+    for k in range(9):
+        if len(queue) == 2:
+            _same_valid_rows(queue.pop(0), a.extract_batch_wait())
+        lo = 8 if k & 1 else 0
+        a.extract_batch_submit(pims[k % 3][lo:], (0, 0), out=tuple(x[lo:] for x in outs[k % 3]))
+        queue.append([x[lo:] for x in refs[k % 3]])
+    while queue:
+        _same_valid_rows(queue.pop(0), a.extract_batch_wait())
     with pytest.raises(pkg.OrbxError, match="no submitted batch"):
         a.extract_batch_wait()
     with pytest.raises(pkg.OrbxError, match="page-locked"):
         a.extract_batch_submit(batches[0], (0, 0), out=outs[0])          # pageable frames need the calling thread
     _same_valid_rows(refs[0], a.extract_batch(batches[0], (0, 0)))        # the handle is usable after the refusals
+    # two handles, each with batches in flight, from one thread
+    outb = [b.output_arrays(B, page_locked=True), b.output_arrays(B)]
+    a.extract_batch_submit(pims[0], (0, 0), out=outs[0]); b.extract_batch_submit(pims[1], (0, 0), out=outb[0])
+    a.extract_batch_submit(pims[2], (0, 0), out=outs[2]); b.extract_batch_submit(pims[0], (0, 0), out=outb[1])
+    _same_valid_rows(refs[1], b.extract_batch_wait()); _same_valid_rows(refs[0], a.extract_batch_wait())
+    _same_valid_rows(refs[2], a.extract_batch_wait()); _same_valid_rows(refs[0], b.extract_batch_wait())
+    # a small batch: alone only
     small = pims[0][:5]
     sref = [x.copy() for x in a.extract_batch(np.ascontiguousarray(small), (0, 0))]
     a.extract_batch_submit(small, (0, 0), out=a.output_arrays(5))
+    with pytest.raises(pkg.OrbxError, match="pending"):
+        a.extract_batch_submit(pims[1], (0, 0), out=outs[1])
     _same_valid_rows(sref, a.extract_batch_wait())
-    b.extract_batch_submit(pims[1], (0, 0), out=outs[1])                  # a batch nobody waits for: close() drains it
+    a.extract_batch_submit(pims[1], (0, 0), out=outs[1])
+    with pytest.raises(pkg.OrbxError, match="pending"):
+        a.extract_batch_submit(small, (0, 0), out=a.output_arrays(5))
+    _same_valid_rows(refs[1], a.extract_batch_wait())
+    b.extract_batch_submit(pims[1], (0, 0), out=outb[0])                  # batches nobody waits for: close() drains them
+    b.extract_batch_submit(pims[2], (0, 0), out=outb[1])
     b.close(); a.close()
 
 

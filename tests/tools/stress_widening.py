@@ -83,6 +83,16 @@ for c in range(cases):
     thf = float(rng.uniform(2, 12))
     a5 = m.ProjectInFrustum(*args, far_points=farp, th_far_points=thf); r5 = orc.project_in_frustum(*args, far_points=farp, th_far_points=thf)
     ok4 = a4.tobytes() == r4.tobytes() and a5.tobytes() == r5.tobytes()
+    # round 5: the keyframe-side head (orbx_window_point records; any combination of its three tests) and the fisheye-rig head (both cameras)
+    sfl = (np.float32(rng.uniform(1.1, 2.0)) ** np.arange(nlev, dtype=np.float32)).astype(np.float32); tests = int(rng.integers(0, 8))
+    wargs = (q, t, Ow, cam[0], cam[1], bounds, float(rng.uniform(0, 60)), float(rng.uniform(1, 8)), sfl, lsf, tests, pts)
+    a6 = m.ProjectWindowPoints(*wargs); r6 = orc.project_window_points(*wargs)
+    Rrl = scene3d.rotation_matrix(scene3d.quat_from_axis_angle(rng.normal(size=3), float(rng.uniform(0, 0.6)))); trl = rng.normal(0, 0.1, 3).astype(np.float32)
+    tlr = (-(Rrl.astype(np.float64).T @ trl.astype(np.float64))).astype(np.float32)
+    kb1 = tuple(float(v) * float(rng.uniform(0.9, 1.1)) for v in scene3d.KB8[1]); kb2 = tuple(float(v) * float(rng.uniform(0.9, 1.1)) for v in scene3d.KB8[1])
+    fargs = (R, t, Ow, Rrl, trl, tlr, np.ascontiguousarray(R.T), kb1, kb2, bounds, float(rng.uniform(0.2, 0.8)), lsf, nlev, pts)
+    a7 = m.ProjectInFrustumFisheye(*fargs, far_points=farp, th_far_points=thf); r7 = orc.project_in_frustum_fisheye(*fargs, far_points=farp, th_far_points=thf)
+    ok4 = ok4 and a6.tobytes() == r6.tobytes() and a7[0].tobytes() == r7[0].tobytes() and a7[1].tobytes() == r7[1].tobytes()
     if not (ok0 and ok1 and ok2 and ok3 and ok4):
         bad += 1
         print("case %d MISMATCH: frame search %s, map-point search %s, undistort %s, vocabulary %s, projection head %s (k=%d L=%d scoring=%d weighting=%d n=%d levelsup=%d)" % (c, ok0, ok1, ok2, ok3, ok4, kk, LL, sc, wt, len(f), lu), flush=True)

@@ -19,19 +19,23 @@ for _ in range(6):
     exs[0].extract_batch(fr, (0, 1000), out=outs[0])
 sync_ms = (time.perf_counter() - t) / 6 * 1e3
 print(f"synchronous call: {sync_ms:.2f} ms per {B} frames = {B / sync_ms * 1e3:.0f} frames/s")
-for lanes in (1, 2):
-    ts, tw = [], []
-    t0 = time.perf_counter()
-    for k in range(lanes):
-        a = time.perf_counter(); exs[k].extract_batch_submit(fr, (0, 1000), out=outs[k]); ts.append(time.perf_counter() - a)
-    reps = 6
-    for _ in range(reps - 1):
+for depth in (1, 2):
+    for lanes in (1, 2):
+        ts, tw = [], []
+        oo = [[e.output_arrays(B, page_locked=True) for _ in range(depth)] for e in exs[:lanes]]
+        t0 = time.perf_counter()
         for k in range(lanes):
-            a = time.perf_counter(); exs[k].extract_batch_wait(); tw.append(time.perf_counter() - a)
-            a = time.perf_counter(); exs[k].extract_batch_submit(fr, (0, 1000), out=outs[k]); ts.append(time.perf_counter() - a)
-    for k in range(lanes):
-        a = time.perf_counter(); exs[k].extract_batch_wait(); tw.append(time.perf_counter() - a)
-    wall = time.perf_counter() - t0
-    print(f"{lanes} handle(s) in flight: {lanes * reps * B / wall:.0f} frames/s; host time in submit {np.mean(ts) * 1e3:.2f} ms (max {np.max(ts) * 1e3:.2f}), in wait {np.mean(tw) * 1e3:.2f} ms")
-    print("   submit ms:", " ".join(f"{x * 1e3:.2f}" for x in ts))
-    print("   wait   ms:", " ".join(f"{x * 1e3:.2f}" for x in tw))
+            for d in range(depth):
+                a = time.perf_counter(); exs[k].extract_batch_submit(fr, (0, 1000), out=oo[k][d]); ts.append(time.perf_counter() - a)
+        reps = 8
+        for r in range(reps - 1):
+            for d in range(depth):
+                for k in range(lanes):
+                    a = time.perf_counter(); exs[k].extract_batch_wait(); tw.append(time.perf_counter() - a)
+                    a = time.perf_counter(); exs[k].extract_batch_submit(fr, (0, 1000), out=oo[k][d]); ts.append(time.perf_counter() - a)
+        for k in range(lanes):
+            for d in range(depth):
+                a = time.perf_counter(); exs[k].extract_batch_wait(); tw.append(time.perf_counter() - a)
+        wall = time.perf_counter() - t0
+        print(f"{lanes} handle(s) x {depth} batch(es) in flight: {lanes * depth * reps * B / wall:.0f} frames/s; host time in submit {np.mean(ts) * 1e3:.2f} ms "
+              f"(max {np.max(ts) * 1e3:.2f}), in wait {np.mean(tw) * 1e3:.2f} ms")

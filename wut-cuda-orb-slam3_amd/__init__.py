@@ -488,7 +488,7 @@ class ORBextractor:
 
     def extract_batch_submit(self, images: np.ndarray, vLappingArea=(0, 0), out=None):
         """orbx_extract_batch_submit: queues the batch and returns at once; `images` (page-locked: host_array) and `out` must stay alive and
-        untouched until extract_batch_wait(), which returns the same (n, mono, kps, desc)."""
+        untouched until the extract_batch_wait() that returns the same (n, mono, kps, desc).  Two batches may be pending on a handle."""
         assert images.dtype == np.uint8 and images.flags.c_contiguous and images.ndim == 3
         b, h, w = images.shape
         n, mono, kps, desc = out if out is not None else self.output_arrays(b)
@@ -496,13 +496,14 @@ class ORBextractor:
         _check(self._lib.orbx_extract_batch_submit(self._h, images.ctypes.data, b, w, h, images.strides[1], images.strides[0],
                                                    int(vLappingArea[0]), int(vLappingArea[1]), kps.ctypes.data, desc.ctypes.data,
                                                    self.capacity, n.ctypes.data, mono.ctypes.data), "orbx_extract_batch_submit")
-        self._submitted = (images, (n, mono, kps, desc))
+        if not hasattr(self, "_submitted"):
+            self._submitted = []
+        self._submitted.append((images, (n, mono, kps, desc)))   # (keeps the arrays alive; up to two batches may be pending)
 
     def extract_batch_wait(self):
-        """orbx_extract_batch_wait: blocks until the submitted batch's results are in the arrays given to extract_batch_submit."""
+        """orbx_extract_batch_wait: blocks until the OLDEST submitted batch's results are in the arrays given to its extract_batch_submit."""
         _check(self._lib.orbx_extract_batch_wait(self._h), "orbx_extract_batch_wait")
-        _, out = self._submitted
-        self._submitted = None
+        _, out = self._submitted.pop(0)
         return out
 
     def output_arrays(self, b: int, page_locked: bool = False):

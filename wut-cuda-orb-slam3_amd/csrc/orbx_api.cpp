@@ -108,11 +108,17 @@ struct orbx_extractor {
     hipEvent_t evJoin = nullptr;
     hipEvent_t evFront[8] = {}, evBlur[8] = {};  // per sub-batch hand-offs between the streams
     hipStream_t streamCopy = nullptr;       // host-pointer API: H2D of sub-batch i + 1 under the kernels of sub-batch i
-    hipEvent_t evCopy[8] = {};
     hipStream_t streamOut = nullptr;        // host-pointer API: D2H of sub-batch i's results under the kernels / H2D of the following ones
-    hipEvent_t evBack[8] = {}, evOut[8] = {}, evIn = nullptr;
-    hipEvent_t evCopy0[8] = {};             // ORBX_HOST_TIMELINE: start of sub-batch i's input copy
-    uint8_t *h_stage = nullptr; size_t h_stageBytes = 0;  // page-locked staging of a whole batch's results (counts, keypoints, descriptors)
+    hipEvent_t evIn = nullptr;
+    // What ONE host batch in flight owns (two slots: orbx_extract_batch_submit keeps two batches in flight on one handle): the events of
+    // its sub-batches, the page-locked staging of its results, its device staging buffer (slot 1's: allocated by the first second submit)
+    struct PipeSlot {
+        hipEvent_t evCopy[8] = {}, evBack[8] = {}, evOut[8] = {};
+        hipEvent_t evCopy0[8] = {};             // ORBX_HOST_TIMELINE: start of sub-batch i's input copy
+        uint8_t *h_stage = nullptr; size_t h_stageBytes = 0;  // page-locked staging of a whole batch's results (counts, keypoints, descriptors)
+        DevBuf<uint8_t> d_in1;                  // slot 1's staging for the input frames (slot 0 uses d_in)
+    } slots[2];
+    int curSlot = 0;                        // the slot of the host batch runBatch is queueing
     hipEvent_t evLevel[ORBX_MAX_LEVELS] = {};    // level l of the pyramid is complete (recorded after pyr_fast(l-1))
 
     // geometry of the current image size
@@ -167,7 +173,8 @@ struct orbx_extractor {
 
     // level-0 source of the last batch (for orbx_get_pyramid_level)
     const uint8_t *lastSrc = nullptr; int lastSrcPitch = 0; long long lastSrcFrameStride = 0; int lastFrames = 0;
-    struct PendingBatch *pending = nullptr;   // a batch submitted with orbx_extract_batch_submit and not yet waited for
+    struct PendingBatch *pending[2] = {nullptr, nullptr};   // batches submitted with orbx_extract_batch_submit and not yet waited for, oldest first
+    int nPending = 0;
     unsigned long long batchSerial = 0;   // unique over all handles of the process: names the batch whose outputs the device buffers hold (stale-consumer checks)
 };
 
@@ -340,10 +347,12 @@ extern "C" int orbx_create(const orbx_params *p, orbx_extractor **out)
     for (int i = 0; i < 8 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&ex->evFront[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBlur[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evCopy[i], pipeFlags);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evCopy0[i], pipeFlags);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evBack[i], pipeFlags);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evOut[i], pipeFlags);
+        for (auto &sl : ex->slots) {
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.evCopy[i], pipeFlags);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.evCopy0[i], pipeFlags);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.evBack[i], pipeFlags);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.evOut[i], pipeFlags);
+        }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ex->evIn, pipeFlags);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ex->streamCopy, hipStreamNonBlocking);
@@ -376,13 +385,15 @@ extern "C" void orbx_destroy(orbx_extractor *ex)
     for (int i = 0; i < 8; ++i) {
         if (ex->evFront[i]) (void)hipEventDestroy(ex->evFront[i]);
         if (ex->evBlur[i]) (void)hipEventDestroy(ex->evBlur[i]);
-        if (ex->evCopy[i]) (void)hipEventDestroy(ex->evCopy[i]);
-        if (ex->evCopy0[i]) (void)hipEventDestroy(ex->evCopy0[i]);
-        if (ex->evBack[i]) (void)hipEventDestroy(ex->evBack[i]);
-        if (ex->evOut[i]) (void)hipEventDestroy(ex->evOut[i]);
+        for (auto &sl : ex->slots) {
+            if (sl.evCopy[i]) (void)hipEventDestroy(sl.evCopy[i]);
+            if (sl.evCopy0[i]) (void)hipEventDestroy(sl.evCopy0[i]);
+            if (sl.evBack[i]) (void)hipEventDestroy(sl.evBack[i]);
+            if (sl.evOut[i]) (void)hipEventDestroy(sl.evOut[i]);
+        }
     }
     if (ex->evIn) (void)hipEventDestroy(ex->evIn);
-    if (ex->h_stage) (void)hipHostFree(ex->h_stage);
+    for (auto &sl : ex->slots) { if (sl.h_stage) (void)hipHostFree(sl.h_stage); sl.d_in1.release(); }
     for (int i = 0; i < ORBX_MAX_LEVELS; ++i)
         if (ex->evLevel[i]) (void)hipEventDestroy(ex->evLevel[i]);
     for (auto &e : ex->events) (void)hipEventDestroy(e);
@@ -979,6 +990,7 @@ static int stageHostFrames(orbx_extractor *ex, uint8_t *dst, ptrdiff_t dstPitch,
 struct HostPipe {
     orbx_keypoint *kps; uint8_t *desc; int capacity; int32_t *nOut, *monoOut;
     bool feeder = false, direct = false;
+    int slot = 0;   // orbx_extractor::slots[slot]: this batch's events and staging
     int nsub = 0, f0[ORBX_MAX_SUB], nf[ORBX_MAX_SUB], drained = 0;
     std::mutex mu; std::condition_variable cv; int staged = 0, feederRc = ORBX_OK; std::string feederErr;
     std::thread thread;
@@ -994,45 +1006,47 @@ struct PendingBatch {
     int nframes = 0, capacity = 0;
     orbx_keypoint *kps = nullptr; uint8_t *desc = nullptr; int32_t *nOut = nullptr, *monoOut = nullptr;
 };
-static HostPipe *pendingPipeOf(orbx_extractor *ex) { return ex->pending ? &ex->pending->pipe : nullptr; }
+// (the pipe of the NEWEST pending batch: the one a running submit is queueing)
+static HostPipe *pendingPipeOf(orbx_extractor *ex) { return ex->nPending > 0 ? &ex->pending[ex->nPending - 1]->pipe : nullptr; }
 static void dropPending(orbx_extractor *ex)
 {
-    if (!ex->pending) return;
+    if (ex->nPending == 0) return;
     drainHandle(ex);
-    delete ex->pending;
-    ex->pending = nullptr;
+    for (int k = 0; k < ex->nPending; ++k) { delete ex->pending[k]; ex->pending[k] = nullptr; }
+    ex->nPending = 0;
 }
 
-static int ensureStage(orbx_extractor *ex)
+static int ensureStage(orbx_extractor *ex, int slot)
 {
+    orbx_extractor::PipeSlot &sl = ex->slots[slot];
     const size_t B = (size_t)ex->prm.max_batch, cap = (size_t)ex->maxKeypoints;
     const size_t need = ((2 * B * sizeof(int32_t) + 63) & ~(size_t)63) + B * cap * (sizeof(orbx_keypoint) + 32) + 64;
-    if (ex->h_stageBytes >= need) return ORBX_OK;
+    if (sl.h_stageBytes >= need) return ORBX_OK;
     ORBX_SETUP_LOCK;
-    if (ex->h_stage) { (void)hipHostFree(ex->h_stage); ex->h_stage = nullptr; ex->h_stageBytes = 0; }
-    HIP_TRY(hipHostMalloc((void **)&ex->h_stage, need, hipHostMallocDefault));
-    ex->h_stageBytes = need;
+    if (sl.h_stage) { (void)hipHostFree(sl.h_stage); sl.h_stage = nullptr; sl.h_stageBytes = 0; }
+    HIP_TRY(hipHostMalloc((void **)&sl.h_stage, need, hipHostMallocDefault));
+    sl.h_stageBytes = need;
     return ORBX_OK;
 }
-static inline int32_t *stageN(orbx_extractor *ex) { return (int32_t *)ex->h_stage; }
-static inline int32_t *stageMono(orbx_extractor *ex) { return (int32_t *)ex->h_stage + ex->prm.max_batch; }
-static inline orbx_keypoint *stageKps(orbx_extractor *ex) { return (orbx_keypoint *)(ex->h_stage + ((2 * (size_t)ex->prm.max_batch * sizeof(int32_t) + 63) & ~(size_t)63)); }
-static inline uint8_t *stageDesc(orbx_extractor *ex) { return (uint8_t *)(stageKps(ex) + (size_t)ex->prm.max_batch * ex->maxKeypoints); }
+static inline int32_t *stageN(orbx_extractor *ex, int slot) { return (int32_t *)ex->slots[slot].h_stage; }
+static inline int32_t *stageMono(orbx_extractor *ex, int slot) { return (int32_t *)ex->slots[slot].h_stage + ex->prm.max_batch; }
+static inline orbx_keypoint *stageKps(orbx_extractor *ex, int slot) { return (orbx_keypoint *)(ex->slots[slot].h_stage + ((2 * (size_t)ex->prm.max_batch * sizeof(int32_t) + 63) & ~(size_t)63)); }
+static inline uint8_t *stageDesc(orbx_extractor *ex, int slot) { return (uint8_t *)(stageKps(ex, slot) + (size_t)ex->prm.max_batch * ex->maxKeypoints); }
 
 // results of sub-batch sb: D2H on the output stream behind the back stream's last kernel of that sub-batch
 static int pipeSendResults(orbx_extractor *ex, HostPipe *pp, int sb)
 {
     const int f0 = pp->f0[sb], nf = pp->nf[sb];
     const size_t cap = (size_t)ex->maxKeypoints;
-    HIP_TRY(hipEventRecord(ex->evBack[sb], ex->stream3));
-    HIP_TRY(hipStreamWaitEvent(ex->streamOut, ex->evBack[sb], 0));
-    HIP_TRY(hipMemcpyAsync(stageN(ex) + f0, ex->d_n.p + f0, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, ex->streamOut));
-    HIP_TRY(hipMemcpyAsync(stageMono(ex) + f0, ex->d_mono.p + f0, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, ex->streamOut));
-    orbx_keypoint *hk = pp->direct ? pp->kps : stageKps(ex);
-    uint8_t *hd = pp->direct ? pp->desc : stageDesc(ex);
+    HIP_TRY(hipEventRecord(ex->slots[pp->slot].evBack[sb], ex->stream3));
+    HIP_TRY(hipStreamWaitEvent(ex->streamOut, ex->slots[pp->slot].evBack[sb], 0));
+    HIP_TRY(hipMemcpyAsync(stageN(ex, pp->slot) + f0, ex->d_n.p + f0, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, ex->streamOut));
+    HIP_TRY(hipMemcpyAsync(stageMono(ex, pp->slot) + f0, ex->d_mono.p + f0, (size_t)nf * sizeof(int32_t), hipMemcpyDeviceToHost, ex->streamOut));
+    orbx_keypoint *hk = pp->direct ? pp->kps : stageKps(ex, pp->slot);
+    uint8_t *hd = pp->direct ? pp->desc : stageDesc(ex, pp->slot);
     if (pp->kps) HIP_TRY(hipMemcpyAsync(hk + (size_t)f0 * cap, ex->d_kps.p + (size_t)f0 * cap, (size_t)nf * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->streamOut));
     if (pp->desc) HIP_TRY(hipMemcpyAsync(hd + (size_t)f0 * cap * 32, ex->d_desc.p + (size_t)f0 * cap * 32, (size_t)nf * cap * 32, hipMemcpyDeviceToHost, ex->streamOut));
-    HIP_TRY(hipEventRecord(ex->evOut[sb], ex->streamOut));
+    HIP_TRY(hipEventRecord(ex->slots[pp->slot].evOut[sb], ex->streamOut));
     return ORBX_OK;
 }
 
@@ -1043,19 +1057,19 @@ static int pipeDrain(orbx_extractor *ex, const HostFrames *host, bool wait, int 
     const size_t cap = (size_t)ex->maxKeypoints;
     while (pp->drained < upTo) {
         const int sb = pp->drained;
-        if (wait) HIP_TRY(hipEventSynchronize(ex->evOut[sb]));
+        if (wait) HIP_TRY(hipEventSynchronize(ex->slots[pp->slot].evOut[sb]));
         else {
-            const hipError_t q = hipEventQuery(ex->evOut[sb]);
+            const hipError_t q = hipEventQuery(ex->slots[pp->slot].evOut[sb]);
             if (q == hipErrorNotReady) { (void)hipGetLastError(); return ORBX_OK; }
             if (q != hipSuccess) return setError(ORBX_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
         }
-        const int32_t *hn = stageN(ex), *hm = stageMono(ex);
+        const int32_t *hn = stageN(ex, pp->slot), *hm = stageMono(ex, pp->slot);
         for (int f = pp->f0[sb]; f < pp->f0[sb] + pp->nf[sb]; ++f) {
             if (hn[f] > pp->capacity) return setError(ORBX_ERR_CAPACITY, "frame %d has %d keypoints, output capacity is %d", f, hn[f], pp->capacity);
             const size_t o = host->hostIndex(f);
             if (!pp->direct && hn[f] > 0) {
-                if (pp->kps) memcpy(pp->kps + o * pp->capacity, stageKps(ex) + (size_t)f * cap, (size_t)hn[f] * sizeof(orbx_keypoint));
-                if (pp->desc) memcpy(pp->desc + o * pp->capacity * 32, stageDesc(ex) + (size_t)f * cap * 32, (size_t)hn[f] * 32);
+                if (pp->kps) memcpy(pp->kps + o * pp->capacity, stageKps(ex, pp->slot) + (size_t)f * cap, (size_t)hn[f] * sizeof(orbx_keypoint));
+                if (pp->desc) memcpy(pp->desc + o * pp->capacity * 32, stageDesc(ex, pp->slot) + (size_t)f * cap * 32, (size_t)hn[f] * 32);
             }
             if (pp->nOut) pp->nOut[o] = hn[f];
             if (pp->monoOut) pp->monoOut[o] = hm[f];
@@ -1342,7 +1356,7 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
                     int lap1, const HostFrames *host)
 {
     if (!ex || !d_imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: null argument");
-    if (ex->pending && !(host && host->pipe == pendingPipeOf(ex)))
+    if (ex->nPending > 0 && !(host && host->pipe && host->pipe == pendingPipeOf(ex)))
         return setError(ORBX_ERR_INVALID_ARG, "a batch submitted with orbx_extract_batch_submit is still pending on this handle: call orbx_extract_batch_wait first");
     if (nframes <= 0 || w <= 0 || h <= 0 || stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_device: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
@@ -1382,7 +1396,11 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
     // frames arriving from the host: sub-batches of >= 128 frames, so that the copy of the next one runs under this one's kernels
     // (up to 8 sub-batches of at least 16 MB of pixels and 8 frames: what is not hidden is the first sub-batch's copy and the last one's
     // kernels and results)
-    static const int hostSub = [] { const char *e = getenv("ORBX_HOST_SUBBATCHES"); int v = e ? atoi(e) : 8; return std::min(std::max(v, 1), ORBX_MAX_SUB); }();
+    // Round 5 (profiles/r05_submit_wait.txt, 1024 VGA frames): one call at a time 5 sub-batches (6.84 ms; 8: 7.4 - a 128-frame sub-batch keeps the
+    // GPU busy for 0.65 ms, eight of them 5.2 ms against 3.0 ms for the batch in one piece); a SUBMITTED batch 4 (its head and tail run under
+    // the neighbouring batches: 2 - 5 sub-batches 174 - 176 k frames/s, 6: 167 k, 8: 137 k).
+    static const int hostSubEnv = [] { const char *e = getenv("ORBX_HOST_SUBBATCHES"); return e ? std::min(std::max(atoi(e), 1), ORBX_MAX_SUB) : 0; }();
+    const int hostSub = hostSubEnv ? hostSubEnv : (host && host->pipe && host->pipe == pendingPipeOf(ex) ? 4 : 5);
     if (host) nsub = std::max(nsub, std::min(hostSub, std::max(1, (int)std::min((long long)nframes / 8, (long long)nframes * w * h / (16 << 20)))));
     const int subSize = ((nframes + nsub - 1) / nsub + 7) / 8 * 8;
     nsub = (nframes + subSize - 1) / subSize;
@@ -1418,16 +1436,18 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
             uint8_t *dIn = (uint8_t *)const_cast<void *>(d_imgs);
             if (sb == 0) {  // the staging buffer is free once everything ordered before this call on the front stream is done
                 HIP_TRY(hipEventRecord(ex->evIn, sFront));
-                HIP_TRY(hipStreamWaitEvent(ex->streamCopy, ex->evIn, 0));
+                // (a second batch in flight - orbx_extract_batch_submit with one pending - stages into the OTHER slot's buffer, whose last
+                // user has been waited for: its copies start at once, under the pending batch's kernels)
+                if (!(ex->nPending == 2 && pipe && pipe == pendingPipeOf(ex))) HIP_TRY(hipStreamWaitEvent(ex->streamCopy, ex->evIn, 0));
                 if (pipe && pipe->feeder) {
                     // pageable frames: the blocking copies run on a helper thread, one sub-batch after the other (joined by ~HostPipe)
                     pipe->thread = std::thread([=]() {
                         ORBX_API_ENTRY;
                         int rcf = hipSetDevice(ex->prm.device) == hipSuccess ? ORBX_OK : setError(ORBX_ERR_HIP, "hipSetDevice failed in the copy thread");
                         for (int k = 0; k < nsub; ++k) {
-                            if (rcf == ORBX_OK && hostTimeline()) (void)hipEventRecord(ex->evCopy0[k], ex->streamCopy);
+                            if (rcf == ORBX_OK && hostTimeline()) (void)hipEventRecord(ex->slots[ex->curSlot].evCopy0[k], ex->streamCopy);
                             if (rcf == ORBX_OK) rcf = stageHostFrames(ex, dIn, stride, frame_stride, host, pipe->f0[k], pipe->nf[k], nframes, w, h, ex->streamCopy);
-                            if (rcf == ORBX_OK && hipEventRecord(ex->evCopy[k], ex->streamCopy) != hipSuccess) rcf = setError(ORBX_ERR_HIP, "hipEventRecord failed in the copy thread");
+                            if (rcf == ORBX_OK && hipEventRecord(ex->slots[ex->curSlot].evCopy[k], ex->streamCopy) != hipSuccess) rcf = setError(ORBX_ERR_HIP, "hipEventRecord failed in the copy thread");
                             std::lock_guard<std::mutex> lk(pipe->mu);
                             if (rcf != ORBX_OK && pipe->feederRc == ORBX_OK) { pipe->feederRc = rcf; pipe->feederErr = g_lastError; }
                             pipe->staged = k + 1;
@@ -1441,13 +1461,13 @@ static int runBatch(orbx_extractor *ex, const void *d_imgs, int nframes, int w, 
                 pipe->cv.wait(lk, [&] { return pipe->staged > sb; });
                 if (pipe->feederRc != ORBX_OK) { g_lastError = pipe->feederErr; return pipe->feederRc; }
             } else {
-                if (hostTimeline()) (void)hipEventRecord(ex->evCopy0[sb], ex->streamCopy);
+                if (hostTimeline()) (void)hipEventRecord(ex->slots[ex->curSlot].evCopy0[sb], ex->streamCopy);
                 const int rcs = stageHostFrames(ex, dIn, stride, frame_stride, host, f0, nf, nframes, w, h, ex->streamCopy);
                 if (rcs != ORBX_OK) return rcs;
-                HIP_TRY(hipEventRecord(ex->evCopy[sb], ex->streamCopy));
+                HIP_TRY(hipEventRecord(ex->slots[ex->curSlot].evCopy[sb], ex->streamCopy));
             }
-            HIP_TRY(hipStreamWaitEvent(sFront, ex->evCopy[sb], 0));
-            HIP_TRY(hipStreamWaitEvent(sBlur, ex->evCopy[sb], 0));
+            HIP_TRY(hipStreamWaitEvent(sFront, ex->slots[ex->curSlot].evCopy[sb], 0));
+            HIP_TRY(hipStreamWaitEvent(sBlur, ex->slots[ex->curSlot].evCopy[sb], 0));
         }
         // ---- front: fused pyramid + FAST, one launch per level -----------------------------------------------
         if (prof) HIP_TRY(hipEventRecord(prof[(sb * ORBX_NUM_STAGES + 0) * 2], sFront));
@@ -1700,7 +1720,11 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
                             int capacity, int32_t *n_out, int32_t *mono_out, bool submit = false)
 {
     if (!ex || !hf.imgs) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: null argument");
-    if (ex->pending) return setError(ORBX_ERR_INVALID_ARG, "a batch submitted with orbx_extract_batch_submit is still pending on this handle: call orbx_extract_batch_wait first");
+    const bool small = nframes <= ORBX_GRAPH_MAX_FRAMES;
+    // one submitted batch may be pending when another one of the pipelined (large-batch) kind is SUBMITTED; every other call waits first
+    if (ex->nPending > 0 && !(submit && !small && ex->nPending == 1 && !ex->pending[0]->small))
+        return setError(ORBX_ERR_INVALID_ARG, ex->nPending == 2 && submit ? "two submitted batches are pending on this handle: call orbx_extract_batch_wait first"
+                        : "a batch submitted with orbx_extract_batch_submit is still pending on this handle: call orbx_extract_batch_wait first");
     if (nframes <= 0 || w <= 0 || h <= 0 || hf.stride < w) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch: bad shape");
     if (nframes > ex->prm.max_batch) return setError(ORBX_ERR_CAPACITY, "batch %d exceeds max_batch %d", nframes, ex->prm.max_batch);
     if (w > ex->prm.max_width || h > ex->prm.max_height)
@@ -1709,7 +1733,7 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
     int rc = computeGeometry(ex, w, h);
     if (rc != ORBX_OK) return rc;
     if ((rc = ensureBuffers(ex)) != ORBX_OK) return rc;
-    if (nframes <= ORBX_GRAPH_MAX_FRAMES) {  // small batches: one replayed graph, one round trip for the results
+    if (small) {  // small batches: one replayed graph, one round trip for the results
         hf.pipe = nullptr;
         rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
         if (rc != ORBX_OK) return rc;
@@ -1717,12 +1741,19 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
             PendingBatch *pb = new (std::nothrow) PendingBatch();
             if (!pb) { drainHandle(ex); return setError(ORBX_ERR_OUT_OF_MEMORY, "orbx_extract_batch_submit: host allocation failed"); }
             pb->small = true; pb->hf = hf; pb->nframes = nframes; pb->capacity = capacity; pb->kps = kps; pb->desc = desc; pb->nOut = n_out; pb->monoOut = mono_out;
-            ex->pending = pb;
+            ex->pending[0] = pb; ex->nPending = 1;
             return ORBX_OK;
         }
         return downloadSmall(ex, &hf, nframes, kps, desc, capacity, n_out, mono_out);
     }
-    if ((rc = ensureStage(ex)) != ORBX_OK) return rc;
+    // the slot of this batch: the one the pending batch (if any) does not hold
+    const int slot = ex->nPending == 1 ? 1 - ex->pending[0]->pipe.slot : 0;
+    if ((rc = ensureStage(ex, slot)) != ORBX_OK) return rc;
+    uint8_t *dIn = ex->d_in.p;
+    if (slot == 1) {
+        if ((rc = ex->slots[1].d_in1.ensure((size_t)ex->prm.max_batch * ex->inFrameStride + 64)) != ORBX_OK) return rc;
+        dIn = ex->slots[1].d_in1.p;
+    }
     // H2D staging and the D2H of the results happen inside the launch sequence, sub-batch by sub-batch
     PendingBatch *pb = nullptr;
     if (submit) {
@@ -1731,7 +1762,7 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
     }
     HostPipe localPipe;
     HostPipe &pipe = pb ? pb->pipe : localPipe;
-    pipe.kps = kps; pipe.desc = desc; pipe.capacity = capacity; pipe.nOut = n_out; pipe.monoOut = mono_out;
+    pipe.kps = kps; pipe.desc = desc; pipe.capacity = capacity; pipe.nOut = n_out; pipe.monoOut = mono_out; pipe.slot = slot;
     static const int feederEnv = [] { const char *e = getenv("ORBX_HOST_FEEDER"); return e ? atoi(e) : -1; }();  // A/B: 0 no helper thread, 1 always
     // (first to last byte this handle reads: its last frame sits at host index hostIndex(nframes - 1))
     const size_t imgBytes = hf.hostIndex(nframes - 1) * (size_t)hf.frameStride + (size_t)(h - 1) * (size_t)hf.stride + (size_t)w;
@@ -1744,11 +1775,18 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
         // frames allow (pageable ones cross the link in blocking copies on a helper thread that the call has to stay with)
         if (pipe.feeder) { delete pb; return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_submit: the frames must lie in page-locked memory (orbx_host_alloc / orbx_host_register), consecutive frames at a positive frame_stride"); }
         pb->hf = hf; pb->hf.pipe = &pb->pipe; pb->nframes = nframes; pb->capacity = capacity; pb->kps = kps; pb->desc = desc; pb->nOut = n_out; pb->monoOut = mono_out;
-        ex->pending = pb;
-        rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &pb->hf);
-        if (rc != ORBX_OK) { drainHandle(ex); ex->pending = nullptr; delete pb; }
+        ex->pending[ex->nPending++] = pb;
+        ex->curSlot = slot;
+        // the results of the batch in flight leave the device buffers this batch's back stream writes: behind its last copy-out
+        if (ex->nPending == 2) {
+            const PendingBatch *prev = ex->pending[0];
+            HIP_TRY(hipStreamWaitEvent(ex->stream3, ex->slots[prev->pipe.slot].evOut[prev->pipe.nsub - 1], 0));
+        }
+        rc = runBatch(ex, dIn, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &pb->hf);
+        if (rc != ORBX_OK) { dropPending(ex); }   // (nothing of either batch may still run: both are dropped, the call reports the error)
         return rc;
     }
+    ex->curSlot = 0;
     rc = runBatch(ex, ex->d_in.p, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &hf);
     if (rc == ORBX_OK) rc = pipeDrain(ex, &hf, true, pipe.nsub);
     if (rc != ORBX_OK) drainHandle(ex);  // nothing of this call may still be running, or copying out of / into the caller's arrays
@@ -1757,7 +1795,7 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
         fprintf(stderr, "[orbx] host batch of %d frames in %d sub-batches (ms since the call's first event):\n", nframes, pipe.nsub);
         for (int k = 0; k < pipe.nsub; ++k)
             fprintf(stderr, "[orbx]   sub-batch %d (%4d frames): copy in %6.3f - %6.3f | kernels done %6.3f | results out %6.3f\n", k, pipe.nf[k],
-                    at(ex->evCopy0[k]), at(ex->evCopy[k]), at(ex->evBack[k]), at(ex->evOut[k]));
+                    at(ex->slots[0].evCopy0[k]), at(ex->slots[0].evCopy[k]), at(ex->slots[0].evBack[k]), at(ex->slots[0].evOut[k]));
     }
     return rc;  // (~HostPipe joins the copy thread)
 }
@@ -1789,14 +1827,14 @@ extern "C" int orbx_extract_batch_wait(orbx_extractor *ex)
 {
     ORBX_API_ENTRY;
     if (!ex) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_wait: null handle");
-    PendingBatch *pb = ex->pending;
-    if (!pb) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_wait: no submitted batch on this handle");
+    if (ex->nPending == 0) return setError(ORBX_ERR_INVALID_ARG, "orbx_extract_batch_wait: no submitted batch on this handle");
+    PendingBatch *pb = ex->pending[0];   // the oldest
     HIP_TRY(hipSetDevice(ex->prm.device));
-    ex->pending = nullptr;
+    ex->pending[0] = ex->pending[1]; ex->pending[1] = nullptr; --ex->nPending;
     int rc;
     if (pb->small) rc = downloadSmall(ex, &pb->hf, pb->nframes, pb->kps, pb->desc, pb->capacity, pb->nOut, pb->monoOut);
     else rc = pipeDrain(ex, &pb->hf, true, pb->pipe.nsub);
-    if (rc != ORBX_OK) drainHandle(ex);
+    if (rc != ORBX_OK) dropPending(ex);   // (with everything drained; a second pending batch is dropped with it)
     delete pb;
     return rc;
 }
