@@ -189,6 +189,23 @@ def test_compute_stereo_matches_frames_batch(pkg, orc):
     m.close(); exl.close(); exr.close()
 
 
+@pytest.mark.parametrize("bound", ["0", "1"])
+def test_knn2_insert_bound_variants_in_subprocess(pkg, bound):
+    """k_knn2_scan_mfma's insert bound: default (round 5) the bound shared by a query's four lane groups, refreshed once per block of four
+    tiles; ORBX_KNN_SHARED_BOUND=0 every lane group's own bound (rounds 2 - 4), =1 the shared bound refreshed at every insert event (round 4's
+    A/B).  All exact: the kNN tests once more under each switch."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ORBX_KNN_SHARED_BOUND") or os.environ.get("ORBX_KNN_MFMA"):
+        pytest.skip("already a forced run")
+    env = dict(os.environ, ORBX_KNN_SHARED_BOUND=bound)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "knn2 and not subprocess"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
 @pytest.mark.parametrize("variant", ["0", "2"])
 def test_knn2_other_scans_in_subprocess(pkg, variant):
     """The kNN-2 scan runs on the matrix cores (k_knn2_scan_mfma: +-1 bytes, q . t = 256 - 2 Hamming, 16 x 16 x 64 products); ORBX_KNN_MFMA

@@ -284,17 +284,18 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
                         kn_insert(k0[qt], k1[qt], key);
                     }
                     // (Round 4, measured and dropped: the bound shared by the four lane groups of a query - the smallest of their second
-                    // keys, exact because each group's pair alone holds two keys below its own second key.  It cuts the insert events of an
-                    // unsplit 4000-row scan from 85 % to ~40 % of the tile x query-tile steps, but the two ds_bpermute round trips per event
-                    // cost more than the events saved: 2.01 against 1.87 ms per 512 pairs, 0.61 against 0.52 ms for c5's 128 split pairs.)
-                    if (a.sharedBound) {   // A/B (ORBX_KNN_SHARED_BOUND=1): the query-wide bound through v_permlane32/16_swap (no LDS round trip)
+                    // keys, exact because each group's pair alone holds two keys below its own second key - refreshed at EVERY insert event.
+                    // It cuts the events of an unsplit 4000-row scan from 85 % to ~40 % of the tile x query-tile steps, but the exchange per
+                    // event cost more than the events saved: 2.01 against 1.87 ms per 512 pairs.  ORBX_KNN_SHARED_BOUND=1 keeps that form;
+                    // round 5 refreshes the shared bound once per BLOCK of four tiles instead, below.)
+                    if (a.sharedBound == 1) {   // the query-wide bound through v_permlane32/16_swap (no LDS round trip)
                         int t = (int)(k1[qt] >> 22);
                         auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false);
                         t = min((int)s32[0], (int)s32[1]);
                         auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false);
                         thr[qt] = min((int)s16[0], (int)s16[1]);
                     } else
-                    thr[qt] = (int)(k1[qt] >> 22);
+                    thr[qt] = min(thr[qt], (int)(k1[qt] >> 22));   // (the shared bound of the last refresh is never above the lane's own)
                 }
             }
         };
@@ -308,6 +309,20 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
                 for (int u = 0; u < 4 && jb + 16 * u < j1; ++u) {
                     if (jb + 16 * u + 16 <= j1) tile(jb + 16 * u, u, std::false_type{});
                     else tile(jb + 16 * u, u, std::true_type{});
+                }
+            }
+            // Round 5: the insert bound SHARED by the four lane groups of a query (train rows 4 g .. 4 g + 3 of every tile), refreshed once per
+            // block of four tiles: thr = the smallest of the groups' second keys.  Exact - the final pair lies below every group's second key,
+            // and a bound only falls, so a stale one costs extra inserts, never a miss - and it cuts the insert events (taken for the whole
+            // wave when ONE of its 64 lanes has a candidate) from 85 - 100 % of the steps to what a four times longer scan would see.
+            if (a.sharedBound == 2) {
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    int t = thr[qt];
+                    auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)t, (unsigned)t, false, false);
+                    t = min((int)s32[0], (int)s32[1]);
+                    auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)t, (unsigned)t, false, false);
+                    thr[qt] = min((int)s16[0], (int)s16[1]);
                 }
             }
             __syncthreads();
@@ -555,7 +570,7 @@ hipError_t orbxLaunchKnn2Batch(hipStream_t st, int npairs, const uint8_t *q, lon
     // quarter of the vector instructions per descriptor pair and a 23 % lower matrix floor (34 cycles per 32768 products against 22 per
     // 16384, tools/experiments/mfma_i8_rate.hip), but 202 VGPRs = two waves per SIMD: 2.06 against 1.80 ms per 512 pairs of 4000 x 4000
     static const int mfma = [] { const char *e = getenv("ORBX_KNN_MFMA"); return e ? atoi(e) : 1; }();
-    static const int sharedBound = [] { const char *e = getenv("ORBX_KNN_SHARED_BOUND"); return e ? atoi(e) : 0; }();
+    static const int sharedBound = [] { const char *e = getenv("ORBX_KNN_SHARED_BOUND"); return e ? atoi(e) : 2; }();   // 0 off, 1 per event (round 4), 2 per block
     a.sharedBound = sharedBound;
     if (mfma == 2) hipLaunchKernelGGL(k_knn2_scan_mfma32, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
     else if (mfma) hipLaunchKernelGGL(k_knn2_scan_mfma, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
