@@ -126,6 +126,17 @@ public:
     }
     orbx_extractor *handle() { return h_; }
 
+    // A batch of frames with the link kept busy across calls (round 5): SubmitBatch queues the batch and returns, WaitBatch returns when the
+    // OLDEST submitted batch's results are in the arrays it was given; two may be pending.  Frames and result arrays page-locked
+    // (orbx_host_alloc / orbx_host_register) and untouched until their WaitBatch.  The reference keeps its two extractor objects busy side by
+    // side for the same reason (src/Frame.cc:124-127).
+    void SubmitBatch(const uint8_t *frames, int nframes, int cols, int rows, std::ptrdiff_t step, std::ptrdiff_t frameStep, int lap0, int lap1,
+                     orbx_keypoint *kps, uint8_t *desc, int capacity, int32_t *n, int32_t *monoIndex)
+    {
+        check(orbx_extract_batch_submit(h_, frames, nframes, cols, rows, step, frameStep, lap0, lap1, kps, desc, capacity, n, monoIndex), "SubmitBatch");
+    }
+    void WaitBatch() { check(orbx_extract_batch_wait(h_), "WaitBatch"); }
+
 private:
     std::vector<float> table(int (*fn)(const orbx_extractor *, float *))
     {
