@@ -189,17 +189,34 @@ def test_compute_stereo_matches_frames_batch(pkg, orc):
     m.close(); exl.close(); exr.close()
 
 
-@pytest.mark.parametrize("bound", ["0", "1"])
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_knn2_other_pipelines_in_subprocess(pkg, pipeline):
+    """k_knn2_scan_mfma issues the products of tile t + 1 before it handles the keys of tile t and interleaves the (unguarded) key inserts
+    with them (round 5, ORBX_KNN_PIPELINE=2); 1 = pipelined with the insert guard, 0 = the tile-by-tile scan of rounds 2 - 4.  Same results:
+    the kNN tests once more under each switch."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ORBX_KNN_PIPELINE") or os.environ.get("ORBX_KNN_SHARED_BOUND") or os.environ.get("ORBX_KNN_MFMA"):
+        pytest.skip("already a forced run")
+    env = dict(os.environ, ORBX_KNN_PIPELINE=pipeline)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "knn2 and not subprocess"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
+@pytest.mark.parametrize("bound", ["0", "1", "2"])
 def test_knn2_insert_bound_variants_in_subprocess(pkg, bound):
-    """k_knn2_scan_mfma's insert bound: default (round 5) the bound shared by a query's four lane groups, refreshed once per block of four
-    tiles; ORBX_KNN_SHARED_BOUND=0 every lane group's own bound (rounds 2 - 4), =1 the shared bound refreshed at every insert event (round 4's
-    A/B).  All exact: the kNN tests once more under each switch."""
+    """The insert guard of the guarded scans (ORBX_KNN_PIPELINE=1 here; the default scan has none in its whole blocks): ORBX_KNN_SHARED_BOUND=2
+    the bound shared by a query's four lane groups, refreshed once per block of four tiles; 0 every lane group's own bound (rounds 2 - 4); 1
+    the shared bound refreshed at every insert event (round 4's A/B).  All exact: the kNN tests once more under each switch."""
     import os
     import subprocess
     import sys
     if os.environ.get("ORBX_KNN_SHARED_BOUND") or os.environ.get("ORBX_KNN_MFMA"):
         pytest.skip("already a forced run")
-    env = dict(os.environ, ORBX_KNN_SHARED_BOUND=bound)
+    env = dict(os.environ, ORBX_KNN_SHARED_BOUND=bound, ORBX_KNN_PIPELINE="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "knn2 and not subprocess"], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

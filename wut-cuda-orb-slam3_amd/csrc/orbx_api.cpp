@@ -219,7 +219,7 @@ static bool hostTimeline()
 // ORBX_BENCH_BACKEND / ORBX_COMMIT belong to the Python side and the tooling.)
 static const char *const kKnownSwitches[] = {
     "ORBX_BLUR_KERNEL", "ORBX_BLUR_SEG", "ORBX_BLUR_WAVES", "ORBX_CHAIN_TILE", "ORBX_DEBUG", "ORBX_EARLY_BLUR", "ORBX_FRONT_PARTS", "ORBX_FRONT_STAGGER",
-    "ORBX_GRAPH", "ORBX_HOST_FEEDER", "ORBX_HOST_SUBBATCHES", "ORBX_HOST_TIMELINE", "ORBX_KNN_MFMA", "ORBX_KNN_SHARED_BOUND", "ORBX_KNN_SPLIT", "ORBX_NO_BLUR",
+    "ORBX_GRAPH", "ORBX_HOST_FEEDER", "ORBX_HOST_SUBBATCHES", "ORBX_HOST_TIMELINE", "ORBX_KNN_MFMA", "ORBX_KNN_PIPELINE", "ORBX_KNN_SHARED_BOUND", "ORBX_KNN_SPLIT", "ORBX_NO_BLUR",
     "ORBX_PF_CLCAP", "ORBX_PF_KERNEL", "ORBX_PF_LANE_ALLOC", "ORBX_PF_LDS_FIT", "ORBX_PF_LDS_PAD", "ORBX_PF_PHASES", "ORBX_PROJECTION_HOST_ROUNDS", "ORBX_QT_KCH",
     "ORBX_QT_KERNEL", "ORBX_QT_LDS_KEYS", "ORBX_QT_MAX_KEYS", "ORBX_QT_MAX_KEYS2", "ORBX_QT_MW", "ORBX_QT_MW_LDS_KEYS", "ORBX_QT_PER_LEVEL", "ORBX_QT_POOL_SLACK",
     "ORBX_QT_STOP", "ORBX_QT_STREAMS", "ORBX_SBP_LIST_LDS", "ORBX_SBP_RESOLVE_GLOBAL", "ORBX_SEARCH_INIT_GENERIC", "ORBX_SI_BLOCK", "ORBX_SI_ROUNDS", "ORBX_SI_ROUNDS_CAP", "ORBX_SI_TOPK",

@@ -74,6 +74,7 @@ struct Knn2Args {
     uint32_t *part;                       // [pair][split][nq][2] partial keys (nSplit > 1)
     int *idx, *dist;                      // [pair][nq][2]
     int sharedBound;                      // k_knn2_scan_mfma: the insert bound shared by the four lane groups of a query (ORBX_KNN_SHARED_BOUND)
+    int pipeline;                         // k_knn2_scan_mfma: products of tile t + 1 issued before the keys of tile t are handled (ORBX_KNN_PIPELINE)
 };
 
 __device__ __forceinline__ void kn_insert(uint32_t &k0, uint32_t &k1, uint32_t key)
@@ -250,9 +251,8 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
         loadBits(j0 + KNM_BLK, wNext);
         __syncthreads();
         int buf = 0;
-        auto tile = [&](int jt, int u, auto tailTag) {
-            constexpr bool TAIL = decltype(tailTag)::value;
-            kn_v4i acc[4];
+        // the 16 products of tile u of the current buffer into acc (train row n of the tile x the wave's four query tiles)
+        auto issueTile = [&](int u, kn_v4i (&acc)[4]) {
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) acc[qt] = kn_v4i{0, 0, 0, 0};
             kn_v4i A[4];  // train row n of the tile, all four k-steps requested before the first product
@@ -265,6 +265,10 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt) acc[qt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[sK], B[qt][sK], acc[qt], 0, 0, 0);
             }
+        };
+        // the keys of one finished tile: guard, insert (rows jt .. jt + 15)
+        auto processTile = [&](kn_v4i (&acc)[4], int jt, auto tailTag) {
+            constexpr bool TAIL = decltype(tailTag)::value;
             // lane: query n of every tile qt, train rows jt + 4 g + r; acc = 2 * Hamming - 256
             const int jr = jt + 4 * g;
             uint32_t base[4];  // 256 << 22 | row: one add per row and tile, then a shift-add per key
@@ -299,18 +303,35 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
                 }
             }
         };
-        for (int jb = j0; jb < j1; jb += KNM_BLK) {
-            if (jb + KNM_BLK < j1) expandTo(buf ^ 1, wNext);  // the next block into the other buffer
-            loadBits(jb + 2 * KNM_BLK, wNext);
-            if (jb + KNM_BLK <= j1) {  // four whole tiles
+        auto tile = [&](int jt, int u, auto tailTag) {
+            kn_v4i acc[4];
+            issueTile(u, acc);
+            processTile(acc, jt, tailTag);
+        };
+        // the same without the guard: every key is formed and inserted (3 vector instructions each, 52 per tile, no branch), so that the
+        // whole tile is ONE scheduling region together with the next tile's 16 products and can be interleaved with them instruction by
+        // instruction (ORBX_KNN_PIPELINE=2)
+        auto processTileAll = [&](kn_v4i (&acc)[4], int jt) {
+            const int jr = jt + 4 * g;
+            uint32_t base[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) tile(jb + 16 * u, u, std::false_type{});
-            } else {                   // the last rows of the split: keys of rows beyond it are masked
-                for (int u = 0; u < 4 && jb + 16 * u < j1; ++u) {
-                    if (jb + 16 * u + 16 <= j1) tile(jb + 16 * u, u, std::false_type{});
-                    else tile(jb + 16 * u, u, std::true_type{});
-                }
+            for (int r = 0; r < 4; ++r) base[r] = (uint32_t)((1 << 30) + jr + r);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kn_insert(k0[qt], k1[qt], ((uint32_t)acc[qt][r] << 22) + base[r]);
             }
+        };
+        // in-order issue: a wave that has 16 products queued issues nothing else until the last one is accepted (16 x 22 cycles) - unless the
+        // vector instructions stand BETWEEN the products in program order: one product, three vector instructions, 16 times
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+        };
+        auto refreshBound = [&]() {
             // Round 5: the insert bound SHARED by the four lane groups of a query (train rows 4 g .. 4 g + 3 of every tile), refreshed once per
             // block of four tiles: thr = the smallest of the groups' second keys.  Exact - the final pair lies below every group's second key,
             // and a bound only falls, so a stale one costs extra inserts, never a miss - and it cuts the insert events (taken for the whole
@@ -325,6 +346,71 @@ __global__ __launch_bounds__(256) void k_knn2_scan_mfma(Knn2Args a)
                     thr[qt] = min((int)s16[0], (int)s16[1]);
                 }
             }
+        };
+        if (a.pipeline) {
+            // Round 5 (ORBX_KNN_PIPELINE=1; 2, the default, drops the guard and interleaves - above): software-pipelined tiles.  A wave that reads its accumulators right behind its 16
+            // products waits for the matrix core (~350 cycles per tile) and only then runs its ~60 vector instructions; with the products
+            // of tile t + 1 ISSUED before the keys of tile t are handled (a second accumulator set), the vector work of every wave runs in
+            // the shadow of its own products - not only beside another wave's.  The pending tile crosses the block barrier; the last,
+            // partial block of a split runs unpipelined (its rows beyond the split are masked).
+            kn_v4i accA[4], accB[4];
+            bool pend = false;   // accB holds tile 3 of the previous block (rows jbPrev + 48 ..), not yet handled
+            int jtPend = 0;
+            int jb = j0;
+            if (a.pipeline == 2) {
+                for (; jb + KNM_BLK <= j1; jb += KNM_BLK) {   // whole blocks, unguarded keys interleaved with the next tile's products
+                    if (jb + KNM_BLK < j1) expandTo(buf ^ 1, wNext);
+                    loadBits(jb + 2 * KNM_BLK, wNext);
+                    if (pend) { issueTile(0, accA); processTileAll(accB, jtPend); interleave(); }
+                    else issueTile(0, accA);
+                    issueTile(1, accB); processTileAll(accA, jb); interleave();
+                    issueTile(2, accA); processTileAll(accB, jb + 16); interleave();
+                    issueTile(3, accB); processTileAll(accA, jb + 32); interleave();
+                    pend = true; jtPend = jb + 48;
+                    __syncthreads();
+                    buf ^= 1;
+                }
+                if (pend) { processTileAll(accB, jtPend); pend = false; }
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) thr[qt] = (int)(k1[qt] >> 22);
+            }
+            for (; jb + KNM_BLK <= j1; jb += KNM_BLK) {   // whole blocks
+                if (jb + KNM_BLK < j1) expandTo(buf ^ 1, wNext);
+                loadBits(jb + 2 * KNM_BLK, wNext);
+                issueTile(0, accA);
+                if (pend) processTile(accB, jtPend, std::false_type{});
+                issueTile(1, accB);
+                processTile(accA, jb, std::false_type{});
+                issueTile(2, accA);
+                processTile(accB, jb + 16, std::false_type{});
+                issueTile(3, accB);
+                processTile(accA, jb + 32, std::false_type{});
+                pend = true; jtPend = jb + 48;
+                refreshBound();
+                __syncthreads();
+                buf ^= 1;
+            }
+            if (pend) processTile(accB, jtPend, std::false_type{});
+            if (jb < j1) {                                 // the last rows of the split
+                for (int u = 0; u < 4 && jb + 16 * u < j1; ++u) {
+                    if (jb + 16 * u + 16 <= j1) tile(jb + 16 * u, u, std::false_type{});
+                    else tile(jb + 16 * u, u, std::true_type{});
+                }
+            }
+        } else
+        for (int jb = j0; jb < j1; jb += KNM_BLK) {
+            if (jb + KNM_BLK < j1) expandTo(buf ^ 1, wNext);  // the next block into the other buffer
+            loadBits(jb + 2 * KNM_BLK, wNext);
+            if (jb + KNM_BLK <= j1) {  // four whole tiles
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tile(jb + 16 * u, u, std::false_type{});
+            } else {                   // the last rows of the split: keys of rows beyond it are masked
+                for (int u = 0; u < 4 && jb + 16 * u < j1; ++u) {
+                    if (jb + 16 * u + 16 <= j1) tile(jb + 16 * u, u, std::false_type{});
+                    else tile(jb + 16 * u, u, std::true_type{});
+                }
+            }
+            refreshBound();
             __syncthreads();
             buf ^= 1;
         }
@@ -572,6 +658,8 @@ hipError_t orbxLaunchKnn2Batch(hipStream_t st, int npairs, const uint8_t *q, lon
     static const int mfma = [] { const char *e = getenv("ORBX_KNN_MFMA"); return e ? atoi(e) : 1; }();
     static const int sharedBound = [] { const char *e = getenv("ORBX_KNN_SHARED_BOUND"); return e ? atoi(e) : 2; }();   // 0 off, 1 per event (round 4), 2 per block
     a.sharedBound = sharedBound;
+    static const int pipeline = [] { const char *e = getenv("ORBX_KNN_PIPELINE"); return e ? atoi(e) : 2; }();   // 0 tile by tile, 1 pipelined + guard, 2 pipelined, unguarded, interleaved
+    a.pipeline = pipeline;
     if (mfma == 2) hipLaunchKernelGGL(k_knn2_scan_mfma32, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
     else if (mfma) hipLaunchKernelGGL(k_knn2_scan_mfma, dim3((nq + 255) / 256, a.nSplit, npairs), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_knn2_scan, dim3((nq + 63) / 64, a.nSplit, npairs), dim3(64), 0, st, a);
