@@ -499,6 +499,53 @@ static int runShardedBatch()
     return 0;
 }
 
+// two batches in flight on one handle through the C++ mirror (round 5: orbx_extract_batch_submit / _wait): page-locked frames and result
+// arrays, every frame against the oracle
+static int runSubmitWait()
+{
+    const int w = 640, h = 480, B = 40, NB = 3;
+    orbx::ORBextractor extractor(1000, 1.2f, 8, 20, 7, 0, w, h, ORBX_BLUR_OPENCV_450, ORBX_TRIG_DOUBLE, B);
+    const int cap = orbx_max_keypoints(extractor.handle());
+    uint8_t *frames[NB]; orbx_keypoint *kps[2]; uint8_t *desc[2]; int32_t *n[2], *mono[2];
+    for (int b = 0; b < NB; ++b) {
+        frames[b] = (uint8_t *)orbx_host_alloc((size_t)B * w * h);
+        ASSERT_TRUE(frames[b] != nullptr);
+        for (int f = 0; f < B; ++f) orbx_synth_frame_impl(7000 + 100 * b + f, w, h, frames[b] + (size_t)f * w * h, w);
+    }
+    for (int s = 0; s < 2; ++s) {
+        kps[s] = (orbx_keypoint *)orbx_host_alloc((size_t)B * cap * sizeof(orbx_keypoint)); desc[s] = (uint8_t *)orbx_host_alloc((size_t)B * cap * 32);
+        n[s] = (int32_t *)orbx_host_alloc(B * sizeof(int32_t)); mono[s] = (int32_t *)orbx_host_alloc(B * sizeof(int32_t));
+    }
+    oracle_handle *ref = oracle_create(1000, 1.2f, 8, 20, 7, 0, 0);
+    std::vector<oracle_keypoint> rk(oracle_max_keypoints(ref) + 64);
+    std::vector<uint8_t> rd(rk.size() * 32);
+    auto check = [&](int b, int s) {
+        for (int f = 0; f < B; f += 7) {
+            int rn = 0;
+            const int rmono = oracle_extract(ref, frames[b] + (size_t)f * w * h, w, h, w, 0, 1000, rk.data(), rd.data(), &rn);
+            if (mono[s][f] != rmono || n[s][f] != rn || memcmp(kps[s] + (size_t)f * cap, rk.data(), (size_t)rn * 28) != 0 ||
+                memcmp(desc[s] + (size_t)f * cap * 32, rd.data(), (size_t)rn * 32) != 0) return 1;
+        }
+        return 0;
+    };
+    extractor.SubmitBatch(frames[0], B, w, h, w, (std::ptrdiff_t)w * h, 0, 1000, kps[0], desc[0], cap, n[0], mono[0]);
+    for (int k = 1; k < 6; ++k) {
+        extractor.SubmitBatch(frames[k % NB], B, w, h, w, (std::ptrdiff_t)w * h, 0, 1000, kps[k & 1], desc[k & 1], cap, n[k & 1], mono[k & 1]);
+        extractor.WaitBatch();                       // batch k - 1
+        ASSERT_EQ(check((k - 1) % NB, (k - 1) & 1), 0);
+    }
+    extractor.WaitBatch();
+    ASSERT_EQ(check(5 % NB, 5 & 1), 0);
+    bool thrown = false;
+    try { extractor.WaitBatch(); } catch (const std::runtime_error &) { thrown = true; }   // nothing pending
+    ASSERT_TRUE(thrown);
+    oracle_destroy(ref);
+    for (int b = 0; b < NB; ++b) orbx_host_free(frames[b]);
+    for (int s = 0; s < 2; ++s) { orbx_host_free(kps[s]); orbx_host_free(desc[s]); orbx_host_free(n[s]); orbx_host_free(mono[s]); }
+    printf("submit / wait: 6 batches of %d frames, two in flight\n", B);
+    return 0;
+}
+
 int main()
 {
     // empty image -> -1 (reference src/ORBextractor.cc:1231-1232)
@@ -523,6 +570,7 @@ int main()
     if (runShardedBatch()) return 1;                                 // SURVEY 8(e), one process
     if (runKeyframeSearches()) return 1;                             // Fuse + ComputeDistinctiveDescriptors through the C++ mirror
     if (runCvShapedAdaptor()) return 1;                              // the operator() adaptor of the OpenCV build, on stand-in types
+    if (runSubmitWait()) return 1;                                   // two host batches in flight on one handle
     printf("OK host mirror\n");
     return 0;
 }

@@ -76,13 +76,13 @@ public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0, int maxWidth = 1920,
-                 int maxHeight = 1080, int blurVariant = ORBX_BLUR_OPENCV_450, int trigMode = ORBX_TRIG_DOUBLE)
+                 int maxHeight = 1080, int blurVariant = ORBX_BLUR_OPENCV_450, int trigMode = ORBX_TRIG_DOUBLE, int maxBatch = 1)
     {
         orbx_params p;
         orbx_default_params(&p);
         p.nfeatures = nfeatures; p.scale_factor = scaleFactor; p.nlevels = nlevels;
         p.ini_th_fast = iniThFAST; p.min_th_fast = minThFAST;
-        p.device = device; p.max_width = maxWidth; p.max_height = maxHeight; p.max_batch = 1;
+        p.device = device; p.max_width = maxWidth; p.max_height = maxHeight; p.max_batch = maxBatch;   // (> 1: SubmitBatch / WaitBatch below)
         p.blur_variant = blurVariant; p.trig_mode = trigMode;
         check(orbx_create(&p, &h_), "ORBextractor");
     }
