@@ -140,7 +140,8 @@ int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int nframes, int
  * valid and untouched until the batch's wait returns; while a batch is pending every other extraction call on the handle is refused
  * (a second submit of a batch of more than 16 frames excepted), and the handle's device outputs (orbx_device_outputs, the *_frames
  * matcher calls) belong to the newest pending batch.  A batch of <= 16 frames (the single-frame schedule) can be submitted only alone.
- * An error of a wait drops the other pending batch too.  orbx_destroy drains batches nobody waited for. */
+ * An error of a submit or a wait drops every pending batch (nothing of them still runs when the call returns).  orbx_destroy drains
+ * batches nobody waited for.  One thread per handle, as for every other call. */
 int orbx_extract_batch_submit(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
                               ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
                               int32_t *n_out, int32_t *mono_out);
