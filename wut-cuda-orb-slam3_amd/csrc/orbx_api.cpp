@@ -1778,11 +1778,13 @@ static int extractBatchHost(orbx_extractor *ex, HostFrames hf, int nframes, int 
         ex->pending[ex->nPending++] = pb;
         ex->curSlot = slot;
         // the results of the batch in flight leave the device buffers this batch's back stream writes: behind its last copy-out
+        rc = ORBX_OK;
         if (ex->nPending == 2) {
             const PendingBatch *prev = ex->pending[0];
-            HIP_TRY(hipStreamWaitEvent(ex->stream3, ex->slots[prev->pipe.slot].evOut[prev->pipe.nsub - 1], 0));
+            const hipError_t he = hipStreamWaitEvent(ex->stream3, ex->slots[prev->pipe.slot].evOut[prev->pipe.nsub - 1], 0);
+            if (he != hipSuccess) rc = setError(ORBX_ERR_HIP, "orbx_extract_batch_submit: hipStreamWaitEvent: %s", hipGetErrorString(he));
         }
-        rc = runBatch(ex, dIn, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &pb->hf);
+        if (rc == ORBX_OK) rc = runBatch(ex, dIn, nframes, w, h, ex->inPitch, ex->inFrameStride, lap0, lap1, &pb->hf);
         if (rc != ORBX_OK) { dropPending(ex); }   // (nothing of either batch may still run: both are dropped, the call reports the error)
         return rc;
     }
@@ -1810,10 +1812,11 @@ extern "C" int orbx_extract_batch(orbx_extractor *ex, const uint8_t *imgs, int n
 }
 
 // Submit / wait: the same batch call in two halves.  A host-pointer call ends in a tail that no other work of the SAME call can cover - the
-// kernels of its last sub-batch and the copy-out of their results, ~0.9 of the 6.7 ms of a 1024-frame VGA call whose eight input copies
-// take 5.5 ms of link time (profiles/r03_host_batch_timeline.txt).  With the call split, one thread feeds two handles in turn - submit A,
-// submit B, wait A, submit A, wait B .. - and B's input copies cross the link under A's tail: the reference's two extractor objects driven
-// side by side (src/Frame.cc:124-127), without the second thread.
+// kernels of its last sub-batch and the copy-out of their results, ~0.9 of the 6.7 ms of a 1024-frame VGA call whose input copies take
+// 5.5 ms of link time (profiles/r03_host_batch_timeline.txt).  With the call split, two batches are in flight on the handle: the second
+// one's frames cross the link into the second staging buffer (PipeSlot::d_in1) under the first one's kernels and copy-out; its kernels
+// queue behind the first one's on the same streams (extractBatchHost, `submit`).  Two HANDLES fed in turn do not get there - their
+// streams serialise in the runtime's hardware queues (profiles/r05_submit_wait.txt).
 extern "C" int orbx_extract_batch_submit(orbx_extractor *ex, const uint8_t *imgs, int nframes, int w, int h, ptrdiff_t stride,
                                          ptrdiff_t frame_stride, int lap0, int lap1, orbx_keypoint *kps, uint8_t *desc, int capacity,
                                          int32_t *n_out, int32_t *mono_out)
