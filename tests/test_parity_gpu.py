@@ -537,6 +537,21 @@ def test_pyr_fast_wave_per_cell_kernel(pkg, clcap):
                           (["640", "480", "1000", "2"], ["752", "480", "1200", "1"], ["512", "512", "1500", "20"]))
 
 
+@pytest.mark.parametrize("env", [{"ORBX_PF_GQCAP": "64"}, {"ORBX_PF_GQCAP": "64", "ORBX_PF_LANE_ALLOC": "0"}, {}])
+def test_pyr_fast_group_queue_overflow(pkg, env):
+    """The pre-test's group queue of k_pyr_fast may hold fewer entries than the tile has groups (what keeps a fourth workgroup per
+    CU resident at VGA); a round that queues more runs the ring test over every group of the tile.  ORBX_PF_GQCAP=64 sends nearly
+    every tile down that path (also with the ballot-prefix queue slots of the profiling instance); the noise frames overflow the
+    corner queue as well (NMS over every scored pixel) - with the default capacity too, on a batch handle.  Bytes equal the oracle."""
+    _gpu_check_subprocess(env, (["640", "480", "1000", "40"], ["752", "480", "1200", "34", "noise"], ["370", "278", "800", "33", "saturated"]))
+
+
+def test_pyr_fast_classic_tile_layout(pkg):
+    """Edge tiles stage the image rows beyond their 3-px halo as margin bands in the score tile's bytes; a level whose bands do not
+    fit keeps them in the pixel tile.  Tall cells over narrow tiles (few cells per group: small score tile) take that layout."""
+    _gpu_check_subprocess({"ORBX_TILE_W": "40"}, (["640", "480", "1000", "40"], ["400", "500", "600", "33"]))
+
+
 def test_quadtree_pool_compaction_path(pkg):
     """The serial quadtree formulation (k_quadtree_serial) recycles node ids by compacting its tombstoned list when the node
     pool runs low.  With the default pool (2 * quota + 64) that path is rare; force the serial kernel with a tiny pool in a

@@ -1,5 +1,5 @@
 """Stage-by-stage GPU-vs-oracle comparison for development (prints the first divergence per stage).
-Usage: python tests/tools/gpu_check.py [w h nfeatures nframes]"""
+Usage: python tests/tools/gpu_check.py [w h nfeatures nframes [content]]   (content: synth (default) | noise | saturated)"""
 import os
 import sys
 import time
@@ -16,9 +16,16 @@ w = int(sys.argv[1]) if len(sys.argv) > 1 else 640
 h = int(sys.argv[2]) if len(sys.argv) > 2 else 480
 nf = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 nframes = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+content = sys.argv[5] if len(sys.argv) > 5 else "synth"
 lap = (0, 1000)
 
-imgs = np.stack([pkg.synth_frame(i, w, h) for i in range(nframes)])
+if content == "synth":
+    imgs = np.stack([pkg.synth_frame(i, w, h) for i in range(nframes)])
+else:  # corners everywhere: the queue-overflow paths of k_pyr_fast
+    rng = np.random.default_rng(7)
+    imgs = rng.integers(0, 256, (nframes, h, w), dtype=np.uint8)
+    if content == "saturated":
+        imgs = np.where(imgs < 128, 0, 255).astype(np.uint8)
 ex = pkg.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=nframes)
 t = time.time()
 n, mono, kps, desc = ex.extract_batch(imgs, lap)

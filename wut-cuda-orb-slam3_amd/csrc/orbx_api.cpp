@@ -220,7 +220,7 @@ static bool hostTimeline()
 static const char *const kKnownSwitches[] = {
     "ORBX_BLUR_KERNEL", "ORBX_BLUR_SEG", "ORBX_BLUR_WAVES", "ORBX_CHAIN_TILE", "ORBX_DEBUG", "ORBX_EARLY_BLUR", "ORBX_FRONT_PARTS", "ORBX_FRONT_STAGGER",
     "ORBX_GRAPH", "ORBX_HOST_FEEDER", "ORBX_HOST_SUBBATCHES", "ORBX_HOST_TIMELINE", "ORBX_KNN_MFMA", "ORBX_KNN_PIPELINE", "ORBX_KNN_SHARED_BOUND", "ORBX_KNN_SPLIT", "ORBX_NO_BLUR",
-    "ORBX_PF_CLCAP", "ORBX_PF_KERNEL", "ORBX_PF_LANE_ALLOC", "ORBX_PF_LDS_FIT", "ORBX_PF_LDS_PAD", "ORBX_PF_PHASES", "ORBX_PROJECTION_HOST_ROUNDS", "ORBX_QT_KCH",
+    "ORBX_PF_CLCAP", "ORBX_PF_GQCAP", "ORBX_PF_KERNEL", "ORBX_PF_LANE_ALLOC", "ORBX_PF_LDS_FIT", "ORBX_PF_LDS_PAD", "ORBX_PF_PHASES", "ORBX_PROJECTION_HOST_ROUNDS", "ORBX_QT_KCH",
     "ORBX_QT_KERNEL", "ORBX_QT_LDS_KEYS", "ORBX_QT_MAX_KEYS", "ORBX_QT_MAX_KEYS2", "ORBX_QT_MW", "ORBX_QT_MW_LDS_KEYS", "ORBX_QT_PER_LEVEL", "ORBX_QT_POOL_SLACK",
     "ORBX_QT_STOP", "ORBX_QT_STREAMS", "ORBX_SBP_LIST_LDS", "ORBX_SBP_RESOLVE_GLOBAL", "ORBX_SEARCH_INIT_GENERIC", "ORBX_SI_BLOCK", "ORBX_SI_ROUNDS", "ORBX_SI_ROUNDS_CAP", "ORBX_SI_TOPK",
     "ORBX_SMALL_BLUR_LEVELS", "ORBX_SMALL_PYR_CHAIN", "ORBX_SMALL_QT_BRANCHES", "ORBX_SMALL_SPLIT", "ORBX_STREAM_PRIO", "ORBX_SUBBATCHES", "ORBX_TILE_W",
@@ -541,12 +541,6 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         g.quota = ex->quota[l];
         g.selBase = selOff; selOff += ex->levelCap[l];
         // LDS layout of k_pyr_fast
-        int maxRows = 0;
-        for (int c = 0; c < g.ncy; ++c) {
-            int ty0 = ORBX_FAST_MARGIN + c * g.hCell, ty1 = std::min(ty0 + g.hCell, g.h - ORBX_FAST_MARGIN);
-            int ly0 = c == 0 ? 0 : ty0 - 3, ly1 = c == g.ncy - 1 ? g.h : ty1 + 3;
-            maxRows = std::max(maxRows, ly1 - ly0);
-        }
         int maxCols = 0;
         for (int gi = 0; gi < g.nGroups; ++gi) {
             int c0 = gi * g.groupCells, c1 = std::min(c0 + g.groupCells, g.ncx);
@@ -554,11 +548,30 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
             int lx0 = gi == 0 ? 0 : tx0 - 3, lx1 = gi == g.nGroups - 1 ? g.w : tx1 + rightHalo;
             maxCols = std::max(maxCols, lx1 - (lx0 & ~15));
         }
-        g.tileRows = maxRows;
         // LDS column 16 holds image column ax0; strip windows / 16-byte loads may overshoot by up to 16 bytes
         g.tilePitch = (int)roundUp(maxCols + 32, 16);  // XO (16) + widest overshoot of strip windows (24) / 16-byte loads (31 - 16)
         g.scorePitch = (int)roundUp((size_t)g.groupCells * g.wCell, 16);  // scores exist for interior columns only (cell-local NMS)
         g.wpc = (g.wCell + 31) / 32;
+        // Rows of the pixel tile.  The first and the last cell-row also own the image rows beyond their 3-px halo (up to the border: sources
+        // of the next level only, 16 rows at the top).  Held in the pixel tile they cost EVERY workgroup of the launch those 16 LDS rows -
+        // and, with 360-px tiles, the fourth resident workgroup per CU; so an edge tile stages them as "margin bands" in the bytes of the
+        // score tile + bitmaps (OrbxPfTile::bandTop / bandBot) whenever they fit there.  The last level has no next level: no extension.
+        // (k_pyr_fast_cw keeps the classic layout: its resize tables are not aliased and its score tile is zeroed in the prologue.)
+        {
+            static const bool cwKernel = [] { const char *e = getenv("ORBX_PF_KERNEL"); return e && atoi(e) == 2; }();
+            const int lastTy0 = ORBX_FAST_MARGIN + (g.ncy - 1) * g.hCell, lastTy1 = std::min(lastTy0 + g.hCell, g.h - ORBX_FAST_MARGIN);
+            const int topBand = ORBX_FAST_MARGIN - 3, botBand = g.h - std::min(lastTy1 + 3, g.h);
+            const size_t scoreBytes = (size_t)(g.hCell + 2) * g.scorePitch + roundUp((size_t)g.groupCells * g.hCell * g.wpc * 4, 16);
+            g.bands = (l + 1 < nl && !cwKernel && (size_t)(topBand + botBand) * g.tilePitch <= scoreBytes) ? 1 : 0;
+            int maxRows = 0;
+            for (int c = 0; c < g.ncy; ++c) {
+                int ty0 = ORBX_FAST_MARGIN + c * g.hCell, ty1 = std::min(ty0 + g.hCell, g.h - ORBX_FAST_MARGIN);
+                const bool extend = l + 1 < nl && !g.bands;
+                int ly0 = c == 0 && extend ? 0 : ty0 - 3, ly1 = c == g.ncy - 1 && extend ? g.h : std::min(ty1 + 3, g.h);
+                maxRows = std::max(maxRows, ly1 - ly0);
+            }
+            g.tileRows = maxRows;
+        }
         g.rsMaxDx = g.rsMaxDy = 0;  // filled in with the resize tables below
     }
     // resize coefficient tables + tile ownership of destination rows / columns, per level transition
@@ -643,7 +656,8 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         g.rsMaxDx = (int)roundUp(g.rsMaxDx + 1, 2);
         g.rsMaxDy = (int)roundUp(g.rsMaxDy + 1, 2);
         // strips cover [8s + 4, 8s + 12): at most (interior width + 7) / 8 + 1 strips per row, 2 groups each
-        g.gqCap = (int)roundUp((size_t)2 * ((g.groupCells * g.wCell + 7) / 8 + 1) * g.hCell, 8);
+        const int gqFull = (int)roundUp((size_t)2 * ((g.groupCells * g.wCell + 7) / 8 + 1) * g.hCell, 8);
+        g.gqCap = gqFull;
         // LDS sub-buffers: pixel tile | score tile | NMS bitmaps (zeroed together with the score tile: 16-byte multiple) | resize
         // tables | group queue | corner queue (1024 entries) | group masks | per-column cell info
         g.oScore = g.tileRows * g.tilePitch;
@@ -655,12 +669,27 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
         g.oCq = g.oXt;
         g.oGq = g.oXt + (int)roundUp(std::max((size_t)(g.rsMaxDx + g.rsMaxDy) * 8, (size_t)1024 * 2), 16);
         g.oGqm = 0;
-        g.oColInfo = g.oGq + g.gqCap * 2;
+        {
+            // A queue for EVERY group of the tile is 6 KB at VGA and fills to 11 - 22 % at iniThFAST: where the full queue is what pushes the
+            // workgroup beyond a quarter of the CU's LDS (160 KB: 40960 B per workgroup, static LDS and the 1280-byte allocation granule
+            // included), it holds what is left - at least half of the groups and 1024 entries, otherwise the level stays at three workgroups
+            // per CU.  A round that queues more runs the dense path (k_pyr_fast (B)).  ORBX_PF_GQCAP: a fixed capacity (tests of that path).
+            static const int gqCapEnv = [] { const char *e = getenv("ORBX_PF_GQCAP"); return e ? atoi(e) : 0; }();
+            const int colBytes = (int)roundUp(g.groupCells * g.wCell, 16);
+            const int rest = g.oGq + 16 + colBytes;   // everything but the queue's entries (16: the dump slot, rounded)
+            const int limit4 = 160 * 1024 / 4 - 160;
+            if (rest + 2 * gqFull > limit4) {
+                const int fit = ((limit4 - rest) / 2) & ~7;
+                if (fit >= std::max(1024, gqFull / 2)) g.gqCap = fit;
+            }
+            if (gqCapEnv > 0) g.gqCap = std::min(gqFull, std::max(8, gqCapEnv & ~7));
+        }
+        g.oColInfo = g.oGq + (int)roundUp((size_t)(g.gqCap + 1) * 2, 16);   // (+ 1: the dump slot behind the queue)
         g.ldsBytes = (int)roundUp((size_t)g.oColInfo + roundUp(g.groupCells * g.wCell, 16), 16);
         if (getenv("ORBX_DEBUG"))
             fprintf(stderr, "[orbx] level %d LDS layout: tile %d x %d = %d | score %d x %d | bits %d | tables %d + %d / corner queue | group queue %d x 2 | "
-                            "columns %d -> %d B\n", l, g.tileRows, g.tilePitch, g.oScore, g.hCell + 2, g.scorePitch, g.oXt - g.oBits, g.rsMaxDx * 8,
-                    g.rsMaxDy * 8, g.gqCap, g.groupCells * g.wCell, g.ldsBytes);
+                            "columns %d -> %d B%s\n", l, g.tileRows, g.tilePitch, g.oScore, g.hCell + 2, g.scorePitch, g.oXt - g.oBits, g.rsMaxDx * 8,
+                    g.rsMaxDy * 8, g.gqCap, g.groupCells * g.wCell, g.ldsBytes, g.bands ? " (margin bands in the score tile)" : "");
         if (g.ldsBytes > 64 * 1024)
             return setError(ORBX_ERR_CAPACITY, "level %d: fused pyramid+FAST tile needs %d B of LDS (> 64 KiB)", l, g.ldsBytes);
         // k_pyr_fast_cw: 8 rings of 128 u16 (one per wave), a list of cwClCap u16 per cell (ring-test survivors in raster order, compacted in
@@ -691,11 +720,16 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                 const int c0 = grp * g.groupCells, c1 = std::min(c0 + g.groupCells, g.ncx);
                 const int tx0 = ORBX_FAST_MARGIN + c0 * g.wCell, tx1 = std::min(ORBX_FAST_MARGIN + c1 * g.wCell, g.w - ORBX_FAST_MARGIN);
                 // rows / columns staged in LDS: interior + 3-px ring halo; edge tiles extend to the image border so that the tile also
-                // owns the source pixels of the next pyramid level there
-                const int ly0 = crow == 0 ? 0 : ty0 - 3, ly1 = crow == g.ncy - 1 ? g.h : ty1 + 3;
+                // owns the source pixels of the next pyramid level there - in x inside the pixel tile, in y as margin bands in the score
+                // tile's bytes (g.bands) or, where those do not fit, inside the pixel tile as well
+                const bool extend = l + 1 < nl && !g.bands;
+                const int ly0 = crow == 0 && extend ? 0 : ty0 - 3, ly1 = crow == g.ncy - 1 && extend ? g.h : std::min(ty1 + 3, g.h);
                 const int lx0 = grp == 0 ? 0 : tx0 - 3, lx1 = grp == g.nGroups - 1 ? g.w : tx1 + g.rightHalo;
                 t.ty0 = ty0; t.THi = ty1 - ty0; t.ly0 = ly0; t.nRowsL = ly1 - ly0; t.rowOff = ty0 - ly0;
-                t.ax0 = lx0 & ~15; t.lx1 = lx1; t.nV = (lx1 - t.ax0 + 15) >> 4; t.nVec = t.nRowsL * t.nV;
+                t.bandTop = g.bands && crow == 0 ? ly0 : 0; t.bandBot = g.bands && crow == g.ncy - 1 ? g.h - ly1 : 0;
+                t.ax0 = lx0 & ~15; t.lx1 = lx1; t.nV = (lx1 - t.ax0 + 15) >> 4; t.nVec = (t.bandTop + t.nRowsL + t.bandBot) * t.nV;
+                if (t.nRowsL > g.tileRows || (size_t)(t.bandTop + t.bandBot) * g.tilePitch > (size_t)(g.oXt - g.oScore))
+                    return setError(ORBX_ERR_INVALID_ARG, "internal: level %d: tile rows %d (+ %d + %d) exceed the LDS layout", l, t.nRowsL, t.bandTop, t.bandBot);
                 auto magic20 = [](int n, int range) {  // ceil(2^20 / n) if it divides every i <= range exactly, else 0
                     if (n <= 0) return 0;
                     const unsigned m = ((1u << 20) + (unsigned)n - 1) / (unsigned)n;

@@ -35,10 +35,12 @@ struct OrbxLevelGeom {
     int tilePitch;         // bytes per LDS tile row of the pixel tile (multiple of 16)
     int scorePitch;        // bytes per row of the score tile: interior columns only (multiple of 16)
     int tileRows;          // max rows held in LDS
+    int bands;             // 1: edge tiles stage the rows beyond their 3-px halo as margin bands in the score tile's bytes (OrbxPfTile::bandTop)
     int wpc;               // 32-bit words per cell row in the NMS bitmaps
     int rsMaxDx, rsMaxDy;  // max destination columns / rows of the next level produced by one tile
     int rightHalo;         // columns staged beyond a tile's last interior column when another column group follows (3 = FAST ring; resize: more)
-    int gqCap;             // capacity of the pre-test group queue (2 groups per strip, all strips of the tile)
+    int gqCap;             // capacity of the pre-test group queue: 2 groups per strip x all strips of the tile, or fewer where that keeps
+                           // a fourth workgroup resident per CU (a round that queues more takes the dense path over every group of the tile)
     int ldsBytes;
     // byte offsets of the LDS sub-buffers (the pixel tile starts at 0): score tile, NMS bitmaps (directly behind the score tile: one
     // zeroing loop), resize x / y tables and - in the same bytes, first written after the barrier behind the pre-test - the corner
@@ -69,7 +71,13 @@ struct OrbxPfTile {
     // 20-bit reciprocals, ceil(2^20 / n): i / n = (i * magic) >> 20, checked by the host for the range the kernel uses them on
     int nVMagic;           // nV, i < 1024 (the first two staging passes)
     int nqMagic;           // nq, i < 512 (a thread's row class in the resize phase); 0 when nq >= 512
-    int pad[7];
+    // Margin bands (round 5): the image rows above the first / below the last cell-row's 3-px halo are sources of the next level only.
+    // Edge tiles stage them into the bytes of the score tile + NMS bitmaps (free until the FAST rounds; the resize tables hold LDS row
+    // ADDRESSES, so a source row may live anywhere) instead of the pixel tile: the pixel tile of EVERY workgroup of the launch is
+    // hCell + 6 rows instead of up to hCell + 22, which is what keeps a fourth workgroup resident per CU with 360-px tiles.
+    // Staged image rows: [ly0 - bandTop, ly0 + nRowsL + bandBot); nVec counts all of them.
+    int bandTop, bandBot;
+    int pad[5];
 };
 static_assert(sizeof(OrbxPfTile) == 128, "OrbxPfTile is read with aligned scalar loads");
 

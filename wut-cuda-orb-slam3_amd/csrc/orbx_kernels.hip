@@ -524,7 +524,18 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
         KArgs &a = K();
         TileK &t = T();
         const int tp = a.g.tilePitch;
-        const int ly0 = t.ly0, nRowsL = t.nRowsL, ax0 = t.ax0, nV = t.nV, nVec = t.nVec;
+        const int ax0 = t.ax0, nV = t.nV, nVec = t.nVec;
+        // Staged image rows [lyFirst, lyFirst + nRowsAll): the tile's own rows [ly0, ly0 + nRowsL) go to the pixel tile; the margin bands
+        // of an edge tile (OrbxPfTile::bandTop / bandBot: rows beyond the 3-px halo, sources of the next level only) go to the bytes
+        // of the score tile + bitmaps, which are first used - and for such tiles first zeroed - in the FAST rounds.
+        const int bandTop = t.bandTop, nRowsL = t.nRowsL, nRowsAll = bandTop + nRowsL + t.bandBot, lyFirst = t.ly0 - bandTop;
+        const bool hasBands = nRowsAll != nRowsL;  // (wave-uniform)
+        const uint32_t oBand = (uint32_t)a.g.oScore;
+        auto ldsRowOff = [&](uint32_t r) -> uint32_t {  // byte offset of staged row r in LDS
+            if (!hasBands) return __umul24(r, (uint32_t)tp);
+            const uint32_t rr = r - (uint32_t)bandTop;
+            return rr < (uint32_t)nRowsL ? __umul24(rr, (uint32_t)tp) : oBand + __umul24(r < (uint32_t)bandTop ? r : r - (uint32_t)nRowsL, (uint32_t)tp);
+        };
         const uint8_t *srcF = a.src + (size_t)f * a.srcFrameStride;
         const bool doResize = a.dst && (!DBG || (a.phases & 1));
         const int ndx = doResize ? t.dx1 - t.dx0 : 0, ndy = doResize ? t.dy1 - t.dy0 : 0, dx0 = t.dx0, dy0 = t.dy0;
@@ -536,16 +547,16 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
             // multiplier, and a 32-bit offset from the frame's uniform base (a frame is < 2 GB): converted through float with 32-bit
             // multiplies and a 64-bit address per lane this was ~60 issue cycles per load, in front of the kernel's first memory access
             const int it0 = otid(), it1 = it0 + PF_NT;
-            const uint32_t nVM = (uint32_t)t.nVMagic, rowBase = (uint32_t)(ly0 * a.srcPitch + ax0);
+            const uint32_t nVM = (uint32_t)t.nVMagic, rowBase = (uint32_t)(lyFirst * a.srcPitch + ax0);
             if (it0 < nVec) {
                 const uint32_t r = __umul24((uint32_t)it0, nVM) >> 20, c = (uint32_t)it0 - __umul24(r, (uint32_t)nV);
                 tv0 = *(const uint4 *)(srcF + (rowBase + __umul24(r, (uint32_t)a.srcPitch) + c * 16));
-                tvOff0 = (int)(__umul24(r, (uint32_t)tp) + PF_XO + c * 16);
+                tvOff0 = (int)(ldsRowOff(r) + PF_XO + c * 16);
             }
             if (it1 < nVec) {
                 const uint32_t r = __umul24((uint32_t)it1, nVM) >> 20, c = (uint32_t)it1 - __umul24(r, (uint32_t)nV);
                 tv1 = *(const uint4 *)(srcF + (rowBase + __umul24(r, (uint32_t)a.srcPitch) + c * 16));
-                tvOff1 = (int)(__umul24(r, (uint32_t)tp) + PF_XO + c * 16);
+                tvOff1 = (int)(ldsRowOff(r) + PF_XO + c * 16);
             }
         }
         int xo_ = 0, xw_ = 0, yo_ = 0, yw_ = 0;  // first table entries of this thread
@@ -554,8 +565,9 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
             if (i < ndx) { xo_ = a.tabs.xofs[dx0 + i]; xw_ = a.tabs.xab[dx0 + i]; }
             if (i < ndy) { yo_ = a.tabs.yofs[dy0 + i]; yw_ = a.tabs.yab[dy0 + i]; }
         }
-        // zero the score tile and the per-cell NMS bitmaps (16-byte stores; the bitmaps follow the score tile)
-        {
+        // zero the score tile and the per-cell NMS bitmaps (16-byte stores; the bitmaps follow the score tile) - unless margin bands are
+        // about to be staged there (edge tiles: zeroed at the head of the FAST rounds instead)
+        if (!hasBands) {
             uint4 z = make_uint4(0, 0, 0, 0);
             uint4 *zs = (uint4 *)(lds + a.g.oScore);
             const int nz = (a.g.oXt - a.g.oScore) >> 4;
@@ -586,24 +598,24 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
             for (int it = otid() + 2 * PF_NT; it < nVec; it += PF_NT) {  // tiles of more than 1024 vectors
                 const int r = (int)(((float)it + 0.5f) * invNV);
                 const int c = it - r * nV;
-                const uint4 v = *(const uint4 *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0 + c * 16);
-                *(uint4 *)(tile + r * tp + PF_XO + c * 16) = v;
+                const uint4 v = *(const uint4 *)(srcF + (size_t)(lyFirst + r) * a.srcPitch + ax0 + c * 16);
+                *(uint4 *)(tile + ldsRowOff((uint32_t)r) + PF_XO + c * 16) = v;
             }
         } else if (a.srcAlign == 4) {
             const int nDw = (t.lx1 - ax0 + 3) >> 2;
 #pragma nounroll
-            for (int r = wave; r < nRowsL; r += PF_NW) {
-                const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(ly0 + r) * a.srcPitch + ax0);
-                uint32_t *trow = (uint32_t *)(tile + r * tp + PF_XO);
+            for (int r = wave; r < nRowsAll; r += PF_NW) {
+                const uint32_t *srow = (const uint32_t *)(srcF + (size_t)(lyFirst + r) * a.srcPitch + ax0);
+                uint32_t *trow = (uint32_t *)(tile + ldsRowOff((uint32_t)r) + PF_XO);
 #pragma nounroll
                 for (int c = otid() & 63; c < nDw; c += 64) trow[c] = srow[c];
             }
         } else {
             const int nB = t.lx1 - ax0;
 #pragma nounroll
-            for (int r = wave; r < nRowsL; r += PF_NW) {
-                const uint8_t *srow = srcF + (size_t)(ly0 + r) * a.srcPitch + ax0;
-                uint8_t *trow = tile + r * tp + PF_XO;
+            for (int r = wave; r < nRowsAll; r += PF_NW) {
+                const uint8_t *srow = srcF + (size_t)(lyFirst + r) * a.srcPitch + ax0;
+                uint8_t *trow = tile + ldsRowOff((uint32_t)r) + PF_XO;
 #pragma nounroll
                 for (int c = otid() & 63; c < nB; c += 64) trow[c] = srow[c];
             }
@@ -618,10 +630,10 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
             auto xEntry = [&](int sx, int w2) { return make_int2(sx + colOf0, w2); };  // the right tap is always the next LDS column: where
                                                                                       // cv::resize clamps sx to w - 1 its weight is 0
             auto yEntry = [&](int sy, int w2) {
-                const int sy0 = min(max(sy, 0), hm1) - ly0, sy1 = min(max(sy + 1, 0), hm1) - ly0;
-                // .x = the LDS addresses of the two rows (16 bits each), .y = the first row's weight b0 << 8, ready for v_mul_hi_u32_u24
-                // (phase 1); b1 = 2048 - b0 (cv::resize: the two sum to 2048)
-                return make_int2((int)((tileLdsA + sy0 * tp) | ((tileLdsA + sy1 * tp) << 16)), (w2 & 0xFFFF) << 8);
+                const int sy0 = min(max(sy, 0), hm1) - lyFirst, sy1 = min(max(sy + 1, 0), hm1) - lyFirst;
+                // .x = the LDS addresses of the two rows (16 bits each; a margin band's rows lie in the score tile's bytes), .y = the first
+                // row's weight b0 << 8, ready for v_mul_hi_u32_u24 (phase 1); b1 = 2048 - b0 (cv::resize: the two sum to 2048)
+                return make_int2((int)((tileLdsA + ldsRowOff((uint32_t)sy0)) | ((tileLdsA + ldsRowOff((uint32_t)sy1)) << 16)), (w2 & 0xFFFF) << 8);
             };
             const int i0 = otid();
             if (i0 < ndx) xt[i0] = xEntry(xo_, xw_);
@@ -788,6 +800,20 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
         const int minTh = min(max(a.minTh, 0), 255), iniTh = min(max(a.iniTh, 0), 255);
         const int cInt0 = t.cInt0, cInt1 = t.cInt1, nCells = t.nCells, THi = t.THi, rowOff = t.rowOff;
         const int s0 = t.s0, NS = t.NS;  // strips cover LDS columns [8s + 4, 8s + 12)
+        // The group queue may hold fewer entries than the tile has groups (OrbxLevelGeom::gqCap: what keeps a fourth workgroup resident
+        // per CU): entries beyond it land in the dump slot gq[gqCap], and a round whose count exceeds the capacity runs the ring
+        // test over EVERY group of the tile instead of the queued ones (pathological corner density only).
+        const unsigned gqCap = (unsigned)a.g.gqCap;
+        if (t.bandTop + t.bandBot) {
+            // an edge tile staged its margin bands where the score tile and the bitmaps live: once every wave is through the resize,
+            // zero them here (the other tiles did under the latency of their tile load)
+            __syncthreads();
+            uint4 z = make_uint4(0, 0, 0, 0);
+            uint4 *zs = (uint4 *)(lds + a.g.oScore);
+            const int nz = (a.g.oXt - a.g.oScore) >> 4;
+#pragma nounroll
+            for (int i = otid(); i < nz; i += PF_NT) zs[i] = z;
+        }
         // (1 / NS is formed where it is used, from a copy of NS the optimiser cannot see through: hoisted out of the round loop it stayed
         // live - and spilled - through both rounds)
         const int nItems = NS * THi;
@@ -825,8 +851,8 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
                     if (g0 | g1) {
                         unsigned pos = lane_queue_alloc(&gqCountR[round], (unsigned)g0 + (unsigned)g1);
                         const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
-                        if (g0) gq[pos++] = (uint16_t)e;
-                        if (g1) gq[pos] = (uint16_t)(e | 1u);
+                        if (g0) { gq[min(pos, gqCap)] = (uint16_t)e; ++pos; }
+                        if (g1) gq[min(pos, gqCap)] = (uint16_t)(e | 1u);
                     }
                     return;
                 }
@@ -834,8 +860,8 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
                 if (bg0 | bg1) {
                     unsigned pos = wave_queue_alloc(&gqCountR[round], (unsigned)(__popcll(bg0) + __popcll(bg1))) + mbcnt64(bg0) + mbcnt64(bg1);
                     const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
-                    if (g0) gq[pos++] = (uint16_t)e;
-                    if (g1) gq[pos] = (uint16_t)(e | 1u);
+                    if (g0) { gq[min(pos, gqCap)] = (uint16_t)e; ++pos; }
+                    if (g1) gq[min(pos, gqCap)] = (uint16_t)(e | 1u);
                 }
             };
             if (!(phases & 2)) {
@@ -884,8 +910,20 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
 
             // (B) full ring test of the queued groups -> corner queue
             const unsigned gn = gqCountR[round];
-            for (unsigned i = otid(); i < gn; i += PF_NT) {
-                const unsigned e = gq[i];
+            // (queue overflow: every group of the tile, i -> (row, 2 * strip + half) in raster order - the same loop, so that the ring
+            // test exists once in the kernel)
+            const bool dense = gn > gqCap;
+            const unsigned gnEff = dense ? (unsigned)(2 * nItems) : gn;
+            for (unsigned i = otid(); i < gnEff; i += PF_NT) {
+                unsigned e;
+                if (dense) {
+                    int ns2 = 2 * NS;
+                    asm volatile("" : "+s"(ns2));
+                    const unsigned rr = (unsigned)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)ns2));
+                    e = (rr << 9) | (i - rr * (unsigned)ns2);
+                } else {
+                    e = gq[i];
+                }
                 const int r = e >> 9, sg = e & 511;
                 const int cb = 8 * s0 + 4 * sg;                       // window start: the group's pixels are bytes 4..7
                 const uint32_t fl = fast_group_flags_lds(tile + (rowOff + r - 3) * tp + cb, tp, T4, C4);
@@ -960,9 +998,18 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
                     pf_nms_one(score, colInfo, bits, cnt, sp, e >> 9, (int)(e & 511) + cInt0, cInt0, wCell, hCell, wpc);
                 }
             } else {
-                // corner queue overflow (pathological corner density): NMS over every scored pixel of the queued groups
-                for (unsigned i = otid(); i < gn; i += PF_NT) {
-                    const unsigned e = gq[i];
+                // corner queue overflow (pathological corner density): NMS over every scored pixel of the queued groups (of every group
+                // when the group queue overflowed too)
+                for (unsigned i = otid(); i < gnEff; i += PF_NT) {
+                    unsigned e;
+                    if (dense) {
+                        int ns2 = 2 * NS;
+                        asm volatile("" : "+s"(ns2));
+                        const unsigned rr = (unsigned)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)ns2));
+                        e = (rr << 9) | (i - rr * (unsigned)ns2);
+                    } else {
+                        e = gq[i];
+                    }
                     const int r = e >> 9, c4 = 8 * s0 + 4 * (int)(e & 511) + 4;
                     for (int k = 0; k < 4; ++k)
                         if (c4 + k >= cInt0 && c4 + k < cInt1)
