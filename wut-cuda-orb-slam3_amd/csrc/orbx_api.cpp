@@ -682,7 +682,7 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                 const int fit = ((limit4 - rest) / 2) & ~7;
                 if (fit >= std::max(1024, gqFull / 2)) g.gqCap = fit;
             }
-            if (gqCapEnv > 0) g.gqCap = std::min(gqFull, std::max(8, gqCapEnv & ~7));
+            if (gqCapEnv > 0) g.gqCap = std::min(gqFull, std::max(32, gqCapEnv & ~7));   // (>= 64 B: the emission phase keeps its wave totals there)
         }
         g.oColInfo = g.oGq + (int)roundUp((size_t)(g.gqCap + 1) * 2, 16);   // (+ 1: the dump slot behind the queue)
         g.ldsBytes = (int)roundUp((size_t)g.oColInfo + roundUp(g.groupCells * g.wCell, 16), 16);
@@ -742,6 +742,8 @@ static int computeGeometry(orbx_extractor *ex, int w, int h)
                 t.cInt0 = tx0 + t.colOf0; t.cInt1 = tx1 + t.colOf0;
                 t.nCells = c1 - c0; t.TWi = tx1 - tx0;
                 t.s0 = (t.cInt0 - 4) >> 3; t.NS = ((t.cInt1 - 1 - 4) >> 3) - t.s0 + 1;
+                if (t.NS >= orbxPyrFastThreads())  // (the pre-test deals its lanes over (row class, strip): at least one row class)
+                    return setError(ORBX_ERR_CAPACITY, "level %d: %d 8-pixel strips per tile row exceed the workgroup's %d lanes", l, t.NS, orbxPyrFastThreads());
                 t.nVMagic = magic20(t.nV, 1023);
                 if (!t.nVMagic) return setError(ORBX_ERR_INVALID_ARG, "internal: level %d: no 20-bit reciprocal for %d vectors per tile row", l, t.nV);
                 t.RC = 1;

@@ -844,18 +844,21 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
                 const uint32_t f1 = fast_group_pretest<1>(w0, w3, w6, T4, C4);
                 // (pixels outside the interior columns / the still-empty cells are not masked here: the ring test clips its result to
                 // both anyway, and the mask cost every strip ~15 instructions to keep a few edge groups out of the queue)
-                const bool g0 = f0 != 0, g1 = f1 != 0;
                 // queue slots: one LDS atomic per wave and ballot prefix counts (a per-lane atomicAdd on one address is expanded by
                 // the compiler into a readlane loop over the active lanes: ~9 scalar instructions per passing strip)
                 if (laneAlloc) {
-                    if (g0 | g1) {
-                        unsigned pos = lane_queue_alloc(&gqCountR[round], (unsigned)g0 + (unsigned)g1);
+                    // (one test of both flag words in front of the block, the first entry stored unconditionally inside it: two compares,
+                    // two selects and an exec round trip less per strip than "g0 = f0 != 0, g1 = f1 != 0; if (g0 | g1) ... if (g0) ... if (g1)")
+                    if ((f0 | f1) != 0) {
+                        const unsigned n0 = f0 != 0 ? 1u : 0u, n1 = f1 != 0 ? 1u : 0u;
+                        const unsigned pos = lane_queue_alloc(&gqCountR[round], n0 + n1);
                         const unsigned e = ((unsigned)r << 9) | (unsigned)(2 * sI);
-                        if (g0) { gq[min(pos, gqCap)] = (uint16_t)e; ++pos; }
-                        if (g1) gq[min(pos, gqCap)] = (uint16_t)(e | 1u);
+                        gq[min(pos, gqCap)] = (uint16_t)(e | (n0 ^ 1u));           // the first passing group of the strip
+                        if (n0 & n1) gq[min(pos + 1u, gqCap)] = (uint16_t)(e | 1u);
                     }
                     return;
                 }
+                const bool g0 = f0 != 0, g1 = f1 != 0;
                 const unsigned long long bg0 = __ballot(g0), bg1 = __ballot(g1);
                 if (bg0 | bg1) {
                     unsigned pos = wave_queue_alloc(&gqCountR[round], (unsigned)(__popcll(bg0) + __popcll(bg1))) + mbcnt64(bg0) + mbcnt64(bg1);
@@ -866,22 +869,22 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
             };
             if (!(phases & 2)) {
             } else if (round == 0) {
-                // item it = r * NS + sI; the walk keeps (r, sI, window address) as induction variables: a step of PF_NT items is dR rows and
-                // dS strips (+ one row when the strip index wraps).  Dividing every item by NS through a float reciprocal cost two
-                // v_cvt, four v_mul_lo_u32 (~8 issue cycles each on gfx950) and a dozen adds per strip - a fifth of the pre-test's issue time.
-                int it = otid();
+                // One strip COLUMN per lane for the whole round: the 512 lanes are dealt over (row class, strip) - lane t -> strip t mod NS,
+                // rows t / NS, + dR, + 2 dR ... with dR = 512 / NS row classes (NS < 512: checked by the host) - like the resize phase.
+                // The walk is a row step and an address step; as item it = r * NS + sI with (r, sI, address) as induction variables it
+                // carried a wrap test with two selects per strip (11 against 3 vector instructions), and divided by NS through a
+                // float reciprocal per item, as it first was, two v_cvt, four v_mul_lo_u32 and a dozen adds.
+                const int it = otid();
                 int nsO = NS;
                 asm volatile("" : "+s"(nsO));
                 const float invNS = __builtin_amdgcn_rcpf((float)nsO);
-                int r = (int)(((float)it + 0.5f) * invNS), sI = it - r * NS;
-                const int dR = (int)(((float)PF_NT + 0.5f) * invNS), dS = PF_NT - dR * NS;   // wave-uniform
+                int r = (int)(((float)it + 0.5f) * invNS);
+                const int sI = it - r * NS;
+                const int dR = (int)(((float)PF_NT + 0.5f) * invNS);   // wave-uniform
                 const uint8_t *wp = tile + (rowOff + r - 3) * tp + 8 * (s0 + sI);
-                const int stepW = dR * tp + 8 * dS, wrapW = tp - 8 * NS;
-                for (; it < nItems; it += PF_NT) {
-                    preTest(r, sI, wp);
-                    sI += dS; r += dR; wp += stepW;
-                    if (sI >= NS) { sI -= NS; ++r; wp += wrapW; }
-                }
+                const int stepW = dR * tp;
+                if (r < dR)
+                    for (; r < THi; r += dR, wp += stepW) preTest(r, sI, wp);
             } else {
                 // only the strips of still-empty cells, one cell at a time (cell geometry in SGPRs).  A strip that straddles two
                 // empty cells is tested once, with the left one.
@@ -1027,41 +1030,58 @@ __global__ __launch_bounds__(PF_NT, PF_MIN_WAVES) void k_pyr_fast(typename PyrFa
     {
         KArgs &a = K();
         TileK &t = T();
-        const int sp = a.g.scorePitch, wCell = a.g.wCell, wpc = a.g.wpc, cellWords = a.g.hCell * wpc;
+        const int sp = a.g.scorePitch, wCell = a.g.wCell, wpc = a.g.wpc;
         const uint8_t *score = lds + a.g.oScore - t.cInt0;
         const uint32_t *bits = (const uint32_t *)(lds + a.g.oBits);
         const int nCells = t.nCells, THi = t.THi, cInt0 = t.cInt0;
         const int xBias = t.colOf0 + ORBX_BORDER, yBias = t.ty0 - ORBX_BORDER;
         uint32_t *slot = a.cand + (size_t)f * a.candFrameStride + a.g.candBase + (size_t)tileId * a.g.slotCap;
-        // keypoints of the cells before cell c: a wave scan over the per-cell counts (lane = cell)
-        int tot;
-        const int cellBase = wave_excl_scan(lane < nCells ? cnt[otid() & (PF_MAX_GROUP_CELLS - 1)] : 0, tot);
-        if (tid == 0) a.tileCount[(size_t)f * a.tilesPerFrame + a.g.tileBase + tileId] = tot;
-        for (int c = wave; c < nCells; c += PF_NW) {
-            const uint32_t *cbits = bits + (size_t)c * cellWords;
-            int base = __builtin_amdgcn_readlane(cellBase, c);
-            const int cellC0 = cInt0 + c * wCell;
-            for (int rb = 0; rb < THi; rb += 64) {
-                const int r = rb + lane;
-                int n = 0;
-                if (r < THi)
-                    for (int k = 0; k < wpc; ++k) n += __popc(cbits[r * wpc + k]);
-                int total;
-                int o = base + wave_excl_scan(n, total);
-                if (r < THi) {
-                    for (int k = 0; k < wpc; ++k) {
-                        uint32_t wd = cbits[r * wpc + k];
-                        while (wd) {
-                            const int b = __ffs(wd) - 1;
-                            wd &= wd - 1;
-                            const int cc = cellC0 + k * 32 + b;
-                            slot[o++] = ORBX_PACK(cc - xBias, yBias + r, score[(r + 1) * sp + cc]);
-                        }
+        // One (cell, row) pair per lane, pairs in emission order (cell-major): the exclusive prefix of the rows' keypoint counts over the
+        // workgroup - a DPP scan per wave, the eight wave totals through LDS - is each row's offset in the slot.  (A wave per cell with a
+        // scan per cell left one wave with two of a tile's nine cells and the others idle: the emission was 2 - 3 k of a workgroup's
+        // 32 k cycles.)  The wave totals go where the group queue was (dead since the barrier behind the last NMS).
+        const int hCell = a.g.hCell, nPairs = nCells * THi;
+        int *wtot = (int *)(lds + a.g.oGq);
+        int thO = THi;
+        asm volatile("" : "+s"(thO));
+        const float invTH = __builtin_amdgcn_rcpf((float)thO);
+        int base = 0, chunk = 0;
+#pragma nounroll
+        for (int p0 = 0; p0 < nPairs; p0 += PF_NT, chunk ^= 1) {   // (one turn unless a tile has more than 512 cell rows)
+            const int p = p0 + otid();
+            const bool live = p < nPairs;
+            const int c = live ? (int)(((float)p + 0.5f) * invTH) : 0, r = live ? p - c * THi : 0;
+            const uint32_t *rbits = bits + (size_t)(c * hCell + r) * wpc;
+            int n = 0;
+            if (live)
+                for (int k = 0; k < wpc; ++k) n += __popc(rbits[k]);
+            int wsum;
+            int o = wave_excl_scan(n, wsum);
+            if (lane == 0) wtot[chunk * PF_NW + wave] = wsum;
+            __syncthreads();
+            int before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < PF_NW; ++w) {
+                const int v = wtot[chunk * PF_NW + w];
+                all += v;
+                before += w < wave ? v : 0;
+            }
+            o += base + before;
+            if (n) {
+                const int cellC0 = cInt0 + c * wCell;
+                for (int k = 0; k < wpc; ++k) {
+                    uint32_t wd = rbits[k];
+                    while (wd) {
+                        const int b = __ffs(wd) - 1;
+                        wd &= wd - 1;
+                        const int cc = cellC0 + k * 32 + b;
+                        slot[o++] = ORBX_PACK(cc - xBias, yBias + r, score[(r + 1) * sp + cc]);
                     }
                 }
-                base += total;
             }
+            base += all;
         }
+        if (tid == 0) a.tileCount[(size_t)f * a.tilesPerFrame + a.g.tileBase + tileId] = base;
     }
     PF_STAMP(12);
 }
