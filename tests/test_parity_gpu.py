@@ -167,6 +167,24 @@ def test_level_quota_beyond_lds(pkg, orc):
         ex.close()
 
 
+def test_batch_handle_with_large_level_quota(pkg, orc):
+    """A batch of 17 .. 128 quadtree instances takes the multi-wave kernel, whose 16 KB LDS key buffer once leaked into the serial
+    kernel's launch behind it: with ~2700 features per level (few levels, many features) that launch went beyond 160 KB of LDS with no
+    node scratch allocated and the call failed with "invalid argument" (found by STRESS_BATCH=20 tests/tools/stress_parity.py)."""
+    rng = np.random.default_rng(68)
+    for (w, h, nf, nlev, scale, ini, mn) in [(761, 541, 5457, 3, 1.25, 19, 10), (625, 727, 4543, 4, 2.0, 30, 23)]:
+        img = np.kron(rng.integers(0, 256, (h // 16 + 1, w // 16 + 1), dtype=np.uint8), np.ones((16, 16), np.uint8))[:h, :w].copy()
+        imgs = np.stack([np.roll(img, 17 * i, axis=1) for i in range(20)])
+        ex = pkg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w, max_height=h, max_batch=20)
+        n, mono, kps, desc = ex.extract_batch(imgs, (0, 0))
+        ref = orc.Oracle(nf, scale, nlev, ini, mn)
+        for i in (0, 19):
+            rmono, rk, rd = ref.extract(imgs[i], (0, 0))
+            assert mono[i] == rmono
+            _assert_same(pkg, kps[i][: n[i]], desc[i][: n[i]], rk, rd, f"{w}x{h} nf={nf} frame {i}")
+        ex.close()
+
+
 def test_strided_and_unaligned_input(pkg, orc):
     base = np.zeros((480, 643 + 5), np.uint8)
     img = pkg.synth_frame(8, 640, 480)

@@ -1,5 +1,7 @@
 """Randomised end-to-end parity sweep (development tool, not part of the test suite): random image sizes, feature counts, level
-counts, scale factors, thresholds and image content against the CPU oracle.  Usage: python tests/tools/stress_parity.py [n] [seed]"""
+counts, scale factors, thresholds and image content against the CPU oracle.  Usage: python tests/tools/stress_parity.py [n] [seed]
+STRESS_BATCH=N: every case runs N frames on a BATCH handle (max_batch > 16: the 360-px tiles, margin bands and the capped group queue of
+k_pyr_fast; the oracle checks the first, one in the middle and the last frame), image sizes capped at 1300 x 800."""
 import os
 import sys
 
@@ -15,8 +17,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # skip the cases before this one (same random stream)
 bad = 0
 for case in range(n_cases):
-    w = int(rng.integers(120, 2000))
-    h = int(rng.integers(100, 1300))
+    big = int(os.environ.get("STRESS_BATCH", "0"))
+    w = int(rng.integers(120, 1300 if big else 2000))
+    h = int(rng.integers(100, 800 if big else 1300))
     nlev = int(rng.integers(1, 9))
     scale = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
     while min(w, h) / scale ** (nlev - 1) < 70:  # every level must hold one 35-px FAST cell + borders
@@ -47,6 +50,8 @@ for case in range(n_cases):
     bv = bv if "bv" in dims else 0
     am = am if "am" in dims else 0
     nb = nb if "nb" in dims else 1
+    if big:
+        nb = big
     pad_w, pad_h = (pad_w, pad_h) if "pad" in dims else (0, 0)
     try:
         ex = pkg.ORBextractor(nf, scale, nlev, ini, mn, max_width=w + pad_w, max_height=h + pad_h,
@@ -55,7 +60,7 @@ for case in range(n_cases):
         n, mono, kps, desc = ex.extract_batch(imgs, lap)
         ok = True
         ref = orc.Oracle(nf, scale, nlev, ini, mn, blur_variant=bv, trig_mode=am)
-        for i in range(nb):
+        for i in (sorted({0, nb // 2, nb - 1}) if big else range(nb)):
             rmono, rk, rd = ref.extract(imgs[i], lap)
             ok = ok and mono[i] == rmono and n[i] == len(rk) and np.array_equal(kps[i][: n[i]].view(np.uint8), rk.view(np.uint8)) \
                 and np.array_equal(desc[i][: n[i]], rd)

@@ -19,6 +19,7 @@ run() {  # name, cases, seed, script
   cat $f
 }
 run parity 150 11 tests/tools/stress_parity.py
+STRESS_BATCH=20 run parity_batch 60 21 tests/tools/stress_parity.py   # batch handles: 360-px tiles, margin bands, capped group queue, multi-wave quadtree
 run matcher 120 12 tests/tools/stress_matcher.py
 run search_init 60 13 tests/tools/stress_search_init.py
 run widening 80 14 tests/tools/stress_widening.py

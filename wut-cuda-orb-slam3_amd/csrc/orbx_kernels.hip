@@ -3769,7 +3769,9 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
         if (slack >= 8) a.pool = (maxQuota + slack + 3) & ~3;
     }
     if (a.pool > 32767 || a.listCap > 32767) return hipErrorInvalidValue;  // node ids / list positions are 15-bit
-    { static int lk = -1; if (lk < 0) { const char *e = getenv("ORBX_QT_LDS_KEYS"); lk = e ? atoi(e) : QT_LDS_KEYS; } a.ldsKeys = lk; }  // measured: 0 (13 KB per instance, 12 per CU) beats 2048 (21 KB)
+    static int lk = -1;
+    if (lk < 0) { const char *e = getenv("ORBX_QT_LDS_KEYS"); lk = e ? atoi(e) : QT_LDS_KEYS; }
+    a.ldsKeys = lk;  // measured: 0 (13 KB per instance, 12 per CU) beats 2048 (21 KB)
     { static int v = -1; if (v < 0) { const char *e = getenv("ORBX_QT_KERNEL"); v = e ? atoi(e) : 3; } a.variant = v; }
     static int mk = -1, mk2 = -1;
     if (mk < 0) { const char *e = getenv("ORBX_QT_MAX_KEYS"); mk = e ? std::min(std::max(atoi(e), 0), QT3_MAX_KEYS) : QT3_MAX_KEYS; }
@@ -3850,6 +3852,10 @@ hipError_t orbxLaunchQuadtree(hipStream_t st, int nframes, int nlevels, const Or
         a.pass2 = 0;
     }
     if ((which & ORBX_QT_SERIAL) || a.variant != 3) {   // candidate sets beyond QT3_MAX_KEYS2 (deferred above), or everything in the A/B variant
+        // (its own LDS key buffer: the multi-wave launch above may have set 16 KB of keys, which orbxQuadtreeScratchBytes does not count -
+        // with a quota of ~2700 per level that pushed this launch beyond 160 KB with no node scratch allocated: "invalid argument" on a
+        // batch of 17 .. 128 instances, found by the batch sweep of tests/tools/stress_parity.py)
+        a.ldsKeys = lk;
         a.nodeBytes = (int)std::max(qtNodeBytes(a.pool, a.listCap), tileOffBytes);
         size_t lds = (size_t)a.nodeBytes + (size_t)a.ldsKeys * sizeof(uint32_t);
         a.nodeScratch = nullptr;
