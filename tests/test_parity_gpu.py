@@ -185,6 +185,30 @@ def test_batch_handle_with_large_level_quota(pkg, orc):
         ex.close()
 
 
+@pytest.mark.parametrize("pitch_pad,offset", [(4, 0), (7, 0), (0, 3), (20, 4)])
+def test_device_batch_with_unaligned_rows(pkg, orc, pitch_pad, offset):
+    """orbx_extract_batch_device on frames whose rows are not 16-byte aligned (a caller's padded or offset device images): k_pyr_fast
+    stages level 0 with 4-byte or single-byte loads - on a batch handle also the margin bands of the edge tiles.  Bytes equal the oracle."""
+    import torch
+    B, w, h = 20, 640, 480
+    pitch = w + pitch_pad
+    frames = np.stack([pkg.synth_frame(300 + i, w, h) for i in range(B)])
+    host = np.zeros((B * h * pitch + 64,), np.uint8)
+    view = host[offset: offset + B * h * pitch].reshape(B, h, pitch)
+    view[:, :, :w] = frames
+    view[:, :, w:] = 255  # (the padding must not leak into the result)
+    dev = torch.from_numpy(host).cuda()
+    ex = pkg.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    ex.extract_batch_device(dev.data_ptr() + offset, B, w, h, pitch, pitch * h, (0, 1000))
+    n, mono, kps, desc = ex.download_outputs(B)
+    ref = orc.Oracle(1000, 1.2, 8, 20, 7)
+    for f in (0, 7, B - 1):
+        rmono, rk, rd = ref.extract(frames[f], (0, 1000))
+        assert mono[f] == rmono
+        _assert_same(pkg, kps[f][: n[f]], desc[f][: n[f]], rk, rd, f"pitch {pitch} offset {offset} frame {f}")
+    ex.close()
+
+
 def test_strided_and_unaligned_input(pkg, orc):
     base = np.zeros((480, 643 + 5), np.uint8)
     img = pkg.synth_frame(8, 640, 480)
