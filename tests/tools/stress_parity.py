@@ -1,7 +1,8 @@
 """Randomised end-to-end parity sweep (development tool, not part of the test suite): random image sizes, feature counts, level
 counts, scale factors, thresholds and image content against the CPU oracle.  Usage: python tests/tools/stress_parity.py [n] [seed]
 STRESS_BATCH=N: every case runs N frames on a BATCH handle (max_batch > 16: the 360-px tiles, margin bands and the capped group queue of
-k_pyr_fast; the oracle checks the first, one in the middle and the last frame), image sizes capped at 1300 x 800."""
+k_pyr_fast; the oracle checks the first, one in the middle and the last frame), image sizes capped at 1300 x 800; STRESS_BATCH=-1: a
+batch size next to one of the schedule's thresholds per case (17 .. 700 frames)."""
 import os
 import sys
 
@@ -18,8 +19,10 @@ first = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # skip the cases before th
 bad = 0
 for case in range(n_cases):
     big = int(os.environ.get("STRESS_BATCH", "0"))
-    w = int(rng.integers(120, 1300 if big else 2000))
-    h = int(rng.integers(100, 800 if big else 1300))
+    if big < 0:  # a batch size next to one of the schedule's thresholds (graph / batch schedule, multi-wave / one-wave quadtree, LDS key buffer, launch groups)
+        big = int(rng.choice([17, 31, 64, 127, 128, 129, 200, 640, 700]))
+    w = int(rng.integers(120, (560 if big >= 600 else 1300) if big else 2000))
+    h = int(rng.integers(100, (420 if big >= 600 else 800) if big else 1300))
     nlev = int(rng.integers(1, 9))
     scale = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
     while min(w, h) / scale ** (nlev - 1) < 70:  # every level must hold one 35-px FAST cell + borders
@@ -41,7 +44,7 @@ for case in range(n_cases):
     lap = (int(rng.integers(-10, w)), int(rng.integers(0, 2 * w)))
     if case < first:
         continue
-    print(f"case {case}: {w}x{h} nf={nf} levels={nlev} scale={scale} th={ini}/{mn} kind={kind} lap={lap}", end=" ", flush=True)
+    print(f"case {case}: {'B=%d ' % big if big else ''}{w}x{h} nf={nf} levels={nlev} scale={scale} th={ini}/{mn} kind={kind} lap={lap}", end=" ", flush=True)
     bv, am = int(rng.integers(0, 2)), int(rng.integers(0, 2))
     nb = int(rng.integers(1, 4))
     pad_w, pad_h = int(rng.integers(0, 40)), int(rng.integers(0, 40))
