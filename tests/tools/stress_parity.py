@@ -20,7 +20,7 @@ bad = 0
 for case in range(n_cases):
     big = int(os.environ.get("STRESS_BATCH", "0"))
     if big < 0:  # a batch size next to one of the schedule's thresholds (graph / batch schedule, multi-wave / one-wave quadtree, LDS key buffer, launch groups)
-        big = int(rng.choice([17, 31, 64, 127, 128, 129, 200, 640, 700]))
+        big = int(rng.choice([17, 31, 64, 127, 128, 129, 200, 640, 700] if big == -1 else [4, 7, 8, 15, 16]))   # (-2: the graph schedule's batch sizes)
     w = int(rng.integers(120, (560 if big >= 600 else 1300) if big else 2000))
     h = int(rng.integers(100, (420 if big >= 600 else 800) if big else 1300))
     nlev = int(rng.integers(1, 9))
