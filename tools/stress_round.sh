@@ -21,6 +21,7 @@ run() {  # name, cases, seed, script
 run parity 150 11 tests/tools/stress_parity.py
 STRESS_BATCH=20 run parity_batch 60 21 tests/tools/stress_parity.py   # batch handles: 360-px tiles, margin bands, capped group queue, multi-wave quadtree
 run matcher 120 12 tests/tools/stress_matcher.py
+run stereo_frames 30 16 tests/tools/stress_stereo_frames.py   # the batch forms behind a stereo rig over 1 .. 129 pairs
 run search_init 60 13 tests/tools/stress_search_init.py
 run widening 80 14 tests/tools/stress_widening.py
 run keyframe 60 15 tests/tools/stress_keyframe.py
