@@ -38,7 +38,7 @@ for c in range(cases):
         m = pkg.ORBmatcher(ex.capacity, ex.capacity)
         bounds = m.ComputeImageBounds(w, h, k4, dist)
         check = sorted({0, P // 2, P - 1})
-        ok = True
+        ok, tot = True, 0
         if points:
             th, ratio = float(rng.choice([1.0, 3.0, 5.0])), float(rng.choice([0.8, 0.9]))
             mps = [_map_points(pkg, kl[p, : nl[p]], rng, int(shifts[p][0]), int(shifts[p][1])) for p in range(P)]
@@ -48,6 +48,7 @@ for c in range(cases):
                 state = np.full(nc[p], -1, np.int8)
                 rn, rassign = orc.search_by_projection_points(kc[p, : nc[p]], dc[p, : nc[p]], state, bounds, sf, mps[p], descs[p], th, ratio)
                 ok = ok and kun[p, : nc[p]].tobytes() == kc[p, : nc[p]].tobytes() and nm[p] == rn and np.array_equal(assign[p, : nc[p]], rassign)
+                tot += int(rn)
         else:
             th, mbf = (float(rng.choice([7.0, 10.0])), float(rng.uniform(20, 80))) if stereo else (float(rng.choice([15.0, 30.0, 4.0])), 0.0)
             proj, pdesc, ur_all = [], [], np.full((P, ex.capacity), -1, np.float32)
@@ -63,7 +64,9 @@ for c in range(cases):
                 rn, rassign = orc.search_by_projection(rk, dc[p, : nc[p]], state, bounds, sf, proj[p], pdesc[p], th, ur_all[p, : nc[p]] if stereo else None,
                                                        mbf, False, False, True)
                 ok = ok and kun[p, : nc[p]].tobytes() == rk.tobytes() and nm[p] == rn and np.array_equal(assign[p, : nc[p]], rassign)
+                tot += int(rn)
         m.close(); ex.close()
+        print(f"matches={tot}", end=" ")
     except Exception as e:  # noqa: BLE001
         ok = False
         print("   exception:", e)

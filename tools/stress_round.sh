@@ -23,6 +23,7 @@ STRESS_BATCH=20 run parity_batch 60 21 tests/tools/stress_parity.py   # batch ha
 run matcher 120 12 tests/tools/stress_matcher.py
 run stereo_frames 30 16 tests/tools/stress_stereo_frames.py   # the batch forms behind a stereo rig over 1 .. 129 pairs
 run search_init 60 13 tests/tools/stress_search_init.py
+run tracking_frames 30 17 tests/tools/stress_tracking_frames.py   # SearchByProjection frame / map-point batch forms over 1 .. 260 frames
 run widening 80 14 tests/tools/stress_widening.py
 run keyframe 60 15 tests/tools/stress_keyframe.py
 if [ $fail -ne 0 ]; then echo "stress_round: AT LEAST ONE SWEEP FAILED"; exit 1; fi
