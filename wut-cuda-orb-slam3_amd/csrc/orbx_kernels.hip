@@ -57,6 +57,18 @@ static inline XcdMagic xcd_magic(int units)
     x.m = (x.per & (x.per - 1)) == 0 ? 0u : (unsigned)((((unsigned long long)1 << (32 + l)) / x.per) + 1ull);   // 0: power of two, shift only
     return x;
 }
+// floor(b / d) for b < 2^31 by the same construction, any divisor d >= 1
+static inline XcdMagic div_magic(unsigned d)
+{
+    XcdMagic x;
+    x.per = std::max(d, 1u);
+    int l = 0;
+    while ((2u << l) <= x.per) ++l;
+    x.l = l;
+    x.m = (x.per & (x.per - 1)) == 0 ? 0u : (unsigned)((((unsigned long long)1 << (32 + l)) / x.per) + 1ull);
+    return x;
+}
+__device__ __forceinline__ unsigned div_by_magic(unsigned b, unsigned m, int l) { return m ? __umulhi(b, m) >> l : b >> l; }
 __device__ __forceinline__ bool xcd_decode_magic(int nframes, unsigned m, int l, unsigned per, int &frame, int &unit)
 {
     const unsigned b = blockIdx.x;
@@ -1760,6 +1772,9 @@ struct BlurArgs {
     int nframes, tilesX, tilesY;
     int srcAligned;  // k_blur3: source rows may be staged with aligned 16-byte loads
     uint32_t biasH, biasL, biasHi;  // k_blur3: constant-term operand bytes (bl3_bias_bytes)
+    // k_blur3: workgroup -> (frame, unit) and unit -> (segment, column strip) without the two integer divisions a wave of ~600
+    // instructions otherwise starts with (xcd_magic(tilesX * tilesY), div_magic(tilesX))
+    unsigned xcdM; int xcdL; unsigned xcdPer; unsigned txM; int txL;
 };
 
 __global__ __launch_bounds__(256) void k_blur(BlurArgs a)
@@ -1972,7 +1987,7 @@ __device__ __forceinline__ void blur3_body(const BlurArgs &a, BlurLaneTabK *tab,
     constexpr int TW = 16 * NW, NVEC = NW + 2, LP = 16 * (NW + 3), NT = 64 * NW, ROWS = 16 * (SEG + 1);
     constexpr int RPP = NT / NVEC, NIT = (ROWS + RPP - 1) / RPP;  // rows per staging pass (NVEC threads per row), passes
     __shared__ __attribute__((aligned(16))) uint8_t tile[ROWS * LP];  // image columns [tx0, tx0 + TW + 32), REFLECT_101 rows
-    const int sgx = unit % a.tilesX, seg = unit / a.tilesX;
+    const int seg = (int)div_by_magic((unsigned)unit, a.txM, a.txL), sgx = unit - seg * a.tilesX;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx0 = sgx * TW - 16;
     const int x0 = sgx * TW + wv * 16;
@@ -2082,7 +2097,7 @@ template <int NW, int SEG>
 __global__ __launch_bounds__(NW * 64) void k_blur3(Blur3KArgs ka)
 {
     int f, unit;
-    if (!xcd_decode(ka.a.nframes, ka.a.tilesX * ka.a.tilesY, f, unit)) return;
+    if (!xcd_decode_magic(ka.a.nframes, ka.a.xcdM, ka.a.xcdL, ka.a.xcdPer, f, unit)) return;
     const __attribute__((address_space(4))) char *kp = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
     blur3_body<NW, SEG>(ka.a, (BlurLaneTabK *)(kp + offsetof(Blur3KArgs, t)), f, unit);
 }
@@ -2130,6 +2145,8 @@ static void fillBlur3Args(BlurArgs &a, int nframes, int w, int h, const uint8_t 
     a.biasHi = bl3_bias_bytes(128 * S + 128);
     a.nframes = nframes; a.tilesY = ((h + 15) / 16 + BL3_SEG - 1) / BL3_SEG;
     a.tilesX = (w + 63) / 64;
+    const XcdMagic xm = xcd_magic(a.tilesX * a.tilesY), tm = div_magic((unsigned)a.tilesX);
+    a.xcdM = xm.m; a.xcdL = xm.l; a.xcdPer = xm.per; a.txM = tm.m; a.txL = tm.l;
 }
 
 // GaussianBlur of `nlevels` levels in one launch (k_blur3, 4 waves); hipErrorNotSupported when a level needs another kernel
@@ -2156,6 +2173,7 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
                           const int taps[7])
 {
     BlurArgs a;
+    memset(&a, 0, sizeof a);
     a.src = src; a.srcPitch = srcPitch; a.srcFrameStride = srcFrameStride;
     a.dst = dst; a.dstPitch = dstPitch; a.dstFrameStride = dstFrameStride;
     a.w = w; a.h = h;
@@ -2184,6 +2202,10 @@ hipError_t orbxLaunchBlur(hipStream_t st, int nframes, int w, int h, const uint8
         fillBlurLaneTab(ka.t, taps);
         ka.a.nframes = nframes; ka.a.tilesY = ((h + 15) / 16 + seg - 1) / seg;
         ka.a.tilesX = nw == 8 ? (w + 127) / 128 : (w + 63) / 64;
+        {
+            const XcdMagic xm = xcd_magic(ka.a.tilesX * ka.a.tilesY), tm = div_magic((unsigned)ka.a.tilesX);
+            ka.a.xcdM = xm.m; ka.a.xcdL = xm.l; ka.a.xcdPer = xm.per; ka.a.txM = tm.m; ka.a.txL = tm.l;
+        }
         const dim3 grid(xcd_grid(nframes, ka.a.tilesX * ka.a.tilesY));
         if (nw == 8 && seg == 8) hipLaunchKernelGGL((k_blur3<8, 8>), grid, dim3(512), 0, st, ka);
         else if (nw == 8) hipLaunchKernelGGL((k_blur3<8, 4>), grid, dim3(512), 0, st, ka);
@@ -4021,11 +4043,12 @@ extern "C" int orbx_debug_od_timing(unsigned long long *out) { return (int)hipMe
 #endif
 __global__ __launch_bounds__(64 * OD_WPB) void k_orient_desc(OrbxTables tb, OrbxLevelPtrs lv, const uint32_t *workKey,
                                                      const int *workPos, const int *nOut, OrbxKp *kps, uint8_t *desc,
-                                                     int cap, int nframes, int chunks)
+                                                     int cap, int nframes, int chunks, unsigned xcdM, int xcdL, unsigned xcdPer)
 {
     int f, chunk;
     OD_STAMP(0);
-    if (!xcd_decode(nframes, chunks, f, chunk)) return;
+    (void)chunks;
+    if (!xcd_decode_magic(nframes, xcdM, xcdL, xcdPer, f, chunk)) return;   // (xcd_magic(chunks): no integer division in front of a wave's first load)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = nOut[f];
     const int base = (chunk * OD_WPB + wave) * OD_KPW;
@@ -4247,7 +4270,8 @@ hipError_t orbxLaunchOrientDesc(hipStream_t st, int nframes, OrbxTables tabs, Or
         if (e != hipSuccess) return e;
     }
     const int chunks = (cap + OD_WPB * OD_KPW - 1) / (OD_WPB * OD_KPW);
+    const XcdMagic xm = xcd_magic(chunks);
     hipLaunchKernelGGL(k_orient_desc, dim3(xcd_grid(nframes, chunks)), dim3(64 * OD_WPB), 0, st, tabs, lv, workKey, workPos, nOut, (OrbxKp *)kps, desc, cap,
-                       nframes, chunks);
+                       nframes, chunks, xm.m, xm.l, xm.per);
     return hipGetLastError();
 }
