@@ -2004,11 +2004,13 @@ __device__ __forceinline__ void blur3_body(const BlurArgs &a, BlurLaneTabK *tab,
         const int r0 = tid / NVEC, v = tid - r0 * NVEC;
         const int col = tx0 + 16 * v;
         const bool colOk = tid < RPP * NVEC && col >= 0 && col + 16 <= a.srcPitch;
-        const uint8_t *colPtr = srcF + min(max(col, 0), a.srcPitch - 16);
+        // (the frame's wave-uniform base + a 32-bit lane offset is one addressing mode of the load: a frame is < 2^31 bytes and rows x pitch
+        // < 2^24; as a per-lane 64-bit pointer every load cost two v_mad_u64_u32 and a v_lshl_add_u64 - in a wave of ~600 instructions)
+        const uint32_t colOff = (uint32_t)min(max(col, 0), a.srcPitch - 16);
         uint4 stage[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
-            stage[k] = *(const uint4 *)(colPtr + (size_t)bl3_reflect(16 * b0 - 3 + min(r0 + RPP * k, nRows - 1), a.h) * a.srcPitch);
+            stage[k] = *(const uint4 *)(srcF + (colOff + __umul24((uint32_t)bl3_reflect(16 * b0 - 3 + min(r0 + RPP * k, nRows - 1), a.h), (uint32_t)a.srcPitch)));
 #pragma unroll
         for (int k = 0; k < NIT; ++k)  // (keeps the compiler from sinking each load into the predicated block of its LDS write)
             asm volatile("" : "+v"(stage[k].x), "+v"(stage[k].y), "+v"(stage[k].z), "+v"(stage[k].w));
@@ -2054,8 +2056,9 @@ __device__ __forceinline__ void blur3_body(const BlurArgs &a, BlurLaneTabK *tab,
     const bl3_v4i zero = {0, 0, 0, 0};
     const int xo = x0 + 4 * g;
     // output row n of block c lies 2 c tile rows below row n of block 0: one address per lane, a scalar step per block
-    const size_t blockBytes = (size_t)a.dstPitch * 256;
-    uint8_t *dstLane = dstF + orbx_blur_tiled_offset(xo, n, a.dstPitch) + (size_t)b0 * blockBytes;
+    // (the frame's base + a 32-bit lane offset: the blurred frame is < 2^31 bytes)
+    const uint32_t blockBytes = (uint32_t)a.dstPitch * 256u;
+    const uint32_t dstLaneOff = ((uint32_t)(n >> 3) * (uint32_t)a.dstPitch + (uint32_t)(xo >> 4)) * 128u + (uint32_t)((n & 7) * 16 + (xo & 15)) + (uint32_t)b0 * blockBytes;
     const bool xOk = xo < a.w;
     // Straight-line code over the chunks (no early exit: blocks beyond the image compute on stale LDS rows and fail the `y < a.h` test
     // of the store), so that the LDS reads of all chunks are in flight before the first product and the products of a chunk overlap
@@ -2084,7 +2087,7 @@ __device__ __forceinline__ void blur3_body(const BlurArgs &a, BlurLaneTabK *tab,
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     packed |= min((uint32_t)((Dh[r] << 8) + Dl[r]) >> 16, 255u) << (8 * r);  // (the 4.5.0 taps sum to 257: 255 needs the clamp)
-                *(uint32_t *)(dstLane + (size_t)(i - 1) * blockBytes) = packed;  // (a tile row holds all 4 pixels)
+                *(uint32_t *)(dstF + (dstLaneOff + (uint32_t)(i - 1) * blockBytes)) = packed;  // (a tile row holds all 4 pixels)
             }
         }
         loPrev = lo; hiPrev = hi;
