@@ -9,4 +9,4 @@ if [ -n "$2" ]; then
 fi
 run() { ORBX_LIB=$PWD/wut-cuda-orb-slam3_amd/$1 python3 bench.py --config ${2:-c2} --batches-per-step 2 --steps 10 --warmup 2 --no-cpu-baseline --no-pcie 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 ${2:-c2}', d['stages_ms'], d['ms_per_step']/2, d['value'])"; }
 for i in 1 2 3; do run liborbx_prev.so; run liborbx.so; done 2>&1 | tee $o/ab.txt
-for c in c4 c5; do run liborbx_prev.so $c; run liborbx.so $c; done 2>&1 | tee -a $o/ab.txt
+for c in c4 c5 c3; do run liborbx_prev.so $c; run liborbx.so $c; done 2>&1 | tee -a $o/ab.txt

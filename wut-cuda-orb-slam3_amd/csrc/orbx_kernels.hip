@@ -2614,9 +2614,10 @@ struct Qt3 {
 __host__ __device__ static inline size_t qt3NodeBytes(int L, int maxKeys = QT3_MAX_KEYS2) { return (((size_t)L * 46 + 8 + 216 * 4 + (size_t)(maxKeys / 32 + 2) * 4) + 15) & ~(size_t)15; }
 
 // A / B: key buffers.  With M <= QT3_KCH * 64 they are the same (LDS) buffer, larger sets ping-pong between two global ones.
-template <bool NG, int QT3_KCH>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS;
+typedef __attribute__((address_space(1))) uint32_t *QtGlobalKeys;  // the key buffers A / B in global scratch, typed: global_load / global_store
+template <bool NG, int QT3_KCH, class KP = uint32_t *>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS;
                                  // QT3_KCH: 64-key chunks held in registers
-__device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int f, uint8_t *qlds, uint32_t *A, uint32_t *B, int M,
+__device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int f, uint8_t *qlds, KP A, KP B, int M,
                          const int *tc, uint32_t *selOut, int *selCnt)
 {
     const int lane = threadIdx.x;
@@ -2679,7 +2680,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
     int cur = 0, size = 0;
     bool kkValid = inRegs;  // kk holds A[0 .. M)
     {
-        uint32_t *R = inRegs ? a.scratchB + (size_t)f * a.candFrameStride + g.candBase : B;  // grouping target
+        KP R = inRegs ? (KP)(a.scratchB + (size_t)f * a.candFrameStride + g.candBase) : B;  // grouping target
         int off = 0;
         for (int r = 0; r < nIni; ++r) {
             int cnt;
@@ -2706,7 +2707,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
         if (nIni > 1) {
             qt_sync<false>();
             if (inRegs) { for (int i = lane; i < M; i += WAVE) A[i] = R[i]; kkValid = false; }
-            else { uint32_t *t = A; A = B; B = t; }
+            else { KP t = A; A = B; B = t; }
         }
     }
     qt_sync<false>();
@@ -2716,10 +2717,14 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
     // one pass / one sorted round.  nSorted < 0: divide every node with more than one key, in list order; otherwise divide
     // V[nSorted - 1], V[nSorted - 2], ... while the list holds fewer than N nodes.
     auto pass = [&](int nSorted) {
-        uint32_t *gx = S.gx[cur], *gy = S.gy[cur];
-        uint16_t *cn = S.cnt[cur], *bg = S.beg[cur];
-        uint32_t *gx2 = S.gx[cur ^ 1], *gy2 = S.gy[cur ^ 1];
-        uint16_t *cn2 = S.cnt[cur ^ 1], *bg2 = S.beg[cur ^ 1];
+        // (the two generations of an array lie behind each other: generation c = base + c * length.  Indexing the pointer PAIRS with `cur`
+        // made them generic pointers - the compiler no longer saw that they point into LDS -, and every access to them a flat load / store
+        // that counts against both wait counters)
+        const int nxt = cur ^ 1;
+        uint32_t *gx = S.gx[0] + cur * L, *gy = S.gy[0] + cur * L;
+        uint16_t *cn = S.cnt[0] + cur * L, *bg = S.beg[0] + cur * (L + 2);
+        uint32_t *gx2 = S.gx[0] + nxt * L, *gy2 = S.gy[0] + nxt * L;
+        uint16_t *cn2 = S.cnt[0] + nxt * L, *bg2 = S.beg[0] + nxt * (L + 2);
         // (a) run starts: exclusive prefix of the counts, bitmap of first keys; child counters to zero
         for (int i = lane; i < ((M + 63) >> 6) * 2 + 2; i += WAVE) S.starts[i] = 0;
         {
@@ -2962,7 +2967,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
             if (div && lane == k.lo) addSlots(k, m);  // (LDS operations of a wave complete in order: every lane has read its cursor)
             if (k.act) B[dest] = k.key;
         });
-        if (!inRegs) { uint32_t *t = A; A = B; B = t; }
+        if (!inRegs) { KP t = A; A = B; B = t; }
         kkValid = false;
         cur ^= 1;
         size = size2;
@@ -2990,7 +2995,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
 
     // ---- retain the best (first strictly greatest response) key of every node, in list order (:755-771) --
     {
-        const uint16_t *cn = S.cnt[cur];
+        const uint16_t *cn = S.cnt[0] + cur * L;
         int base = 0;
         for (int pb = 0; pb < size; pb += WAVE) {
             const int p = pb + lane;
@@ -3058,13 +3063,16 @@ __global__ __launch_bounds__(64) void k_quadtree(QtArgs)
     const bool inRegs = M <= KCH * WAVE;
     if (a.nodeScratch) {  // list capacity beyond LDS: node arrays (and keys) in global memory
         uint8_t *nodes = a.nodeScratch + ((size_t)f * a.levelsRun + (level - a.levelBase)) * (size_t)a.nodeBytes;
-        qt3_body<true, KCH>(a, g, f, nodes, gA, inRegs ? gA : gB, M, tc, selOut, selCnt);
+        qt3_body<true, KCH, QtGlobalKeys>(a, g, f, nodes, (QtGlobalKeys)gA, (QtGlobalKeys)(inRegs ? gA : gB), M, tc, selOut, selCnt);
         return;
     }
     // all keys in registers for a pass + one LDS buffer behind the node arrays; larger sets ping-pong in global scratch
-    uint32_t *lK = (uint32_t *)(qlds + a.nodeBytes);
-    uint32_t *kA = inRegs && M <= a.ldsKeys ? lK : gA;
-    qt3_body<false, KCH>(a, g, f, qlds, kA, inRegs ? kA : gB, M, tc, selOut, selCnt);
+    // The key buffers as GLOBAL pointers (the default: ORBX_QT_LDS_KEYS = 0).  As one generic pointer that is either the LDS buffer or the
+    // global scratch, every key access was a flat load / store - which counts against BOTH wait counters, so that the next wait for an LDS
+    // read of the node arrays also waited for the keys in flight, and back: in a kernel that is nothing but dependent latencies.
+    // (ORBX_QT_LDS_KEYS - small key sets in an LDS buffer behind the node arrays, measured slower than the global scratch in round 3 - is
+    // no longer an option of this kernel: its generic-pointer instance cost the kernel 46 more VGPRs)
+    qt3_body<false, KCH, QtGlobalKeys>(a, g, f, qlds, (QtGlobalKeys)gA, (QtGlobalKeys)(inRegs ? gA : gB), M, tc, selOut, selCnt);
 }
 
 // =====================================================================================================
@@ -3247,10 +3255,13 @@ __device__ __forceinline__ void qt4_body(QtArgsK &a, const OrbxLevelGeom &g, int
     bool kkValid = false;
     int nV = 0;  // entries of V after a pass
     auto pass = [&](int nSorted) {
-        uint32_t *gx = S.gx[cur], *gy = S.gy[cur];
-        uint16_t *cn = S.cnt[cur], *bg = S.beg[cur];
-        uint32_t *gx2 = S.gx[cur ^ 1], *gy2 = S.gy[cur ^ 1];
-        uint16_t *cn2 = S.cnt[cur ^ 1], *bg2 = S.beg[cur ^ 1];
+        // (generation c of an array = base + c * length: indexing the pointer pairs with `cur` made them generic pointers and their
+        // accesses flat loads / stores - see qt3_body)
+        const int nxt = cur ^ 1;
+        uint32_t *gx = S.gx[0] + cur * L, *gy = S.gy[0] + cur * L;
+        uint16_t *cn = S.cnt[0] + cur * L, *bg = S.beg[0] + cur * (L + 2);
+        uint32_t *gx2 = S.gx[0] + nxt * L, *gy2 = S.gy[0] + nxt * L;
+        uint16_t *cn2 = S.cnt[0] + nxt * L, *bg2 = S.beg[0] + nxt * (L + 2);
         for (int i = tid; i < nChunks * 2 + 2; i += QT4_NT) S.starts[i] = 0;
         sync();
         if (wv == 0) {
@@ -3558,7 +3569,7 @@ __device__ __forceinline__ void qt4_body(QtArgsK &a, const OrbxLevelGeom &g, int
     auto sortV = [&](int n) {
         if (n <= 1) return;
         const QtSizedLess less;
-        uint16_t *LP = S.proc, *RP = S.beg[cur ^ 1];  // free between two passes
+        uint16_t *LP = S.proc, *RP = S.beg[0] + (cur ^ 1) * (L + 2);  // free between two passes
         if (wv == 0) {
             int *stFirst = S.sortStack, *stLast = stFirst + 72, *stDepth = stFirst + 144;
             int sp = 1;
@@ -3669,7 +3680,7 @@ __device__ __forceinline__ void qt4_body(QtArgsK &a, const OrbxLevelGeom &g, int
 
     // ---- retain the best (first strictly greatest response) key of every node, in list order (:755-771) --
     {
-        const uint16_t *cn = S.cnt[cur], *bg = S.beg[cur];
+        const uint16_t *cn = S.cnt[0] + cur * L, *bg = S.beg[0] + cur * (L + 2);
         for (int p = tid; p < size; p += QT4_NT) {
             const int n = (int)cn[p], b = (int)bg[p];
             uint32_t best = A[b];
