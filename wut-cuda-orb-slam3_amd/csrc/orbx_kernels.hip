@@ -2615,6 +2615,15 @@ __host__ __device__ static inline size_t qt3NodeBytes(int L, int maxKeys = QT3_M
 
 // A / B: key buffers.  With M <= QT3_KCH * 64 they are the same (LDS) buffer, larger sets ping-pong between two global ones.
 typedef __attribute__((address_space(1))) uint32_t *QtGlobalKeys;  // the key buffers A / B in global scratch, typed: global_load / global_store
+// key `i` of a buffer: for the typed global buffers a wave-uniform base + an UNSIGNED 32-bit byte offset (one addressing mode of the
+// load / store; with a signed index the compiler forms a per-lane 64-bit address: a shift, a sign extension and a 64-bit add in
+// front of every access of a kernel that is nothing but dependent latencies)
+__device__ __forceinline__ __attribute__((address_space(1))) uint32_t &qt_key(QtGlobalKeys base, int i)
+{
+    typedef __attribute__((address_space(1))) char *gbytes_t;
+    return *(QtGlobalKeys)((gbytes_t)base + ((uint32_t)i << 2));
+}
+__device__ __forceinline__ uint32_t &qt_key(uint32_t *base, int i) { return base[i]; }
 template <bool NG, int QT3_KCH, class KP = uint32_t *>  // NG: the node arrays live in global scratch (quotas too large for LDS), not in LDS;
                                  // QT3_KCH: 64-key chunks held in registers
 __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int f, uint8_t *qlds, KP A, KP B, int M,
@@ -2665,7 +2674,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
 #pragma unroll
             for (int u = 0; u < QT3_KCH; ++u) {
                 const int e = e0 + u * WAVE + lane;
-                if (e < M) A[e] = kk[u];
+                if (e < M) qt_key(A, e) = kk[u];
             }
         }
     }
@@ -2689,10 +2698,10 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
                 cnt = 0;
                 for (int base = 0; base < M; base += WAVE) {
                     const bool act = base + lane < M;
-                    const uint32_t key = act ? A[base + lane] : 0u;
+                    const uint32_t key = act ? qt_key(A, base + lane) : 0u;
                     const bool mine = act && (int)__fdiv_rn((float)(key & 0xFFF), hX) == r;
                     const unsigned long long m = __ballot(mine);
-                    if (mine) R[off + cnt + __popcll(m & lt)] = key;
+                    if (mine) qt_key(R, off + cnt + __popcll(m & lt)) = key;
                     cnt += __popcll(m);
                 }
             }
@@ -2706,7 +2715,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
         }
         if (nIni > 1) {
             qt_sync<false>();
-            if (inRegs) { for (int i = lane; i < M; i += WAVE) A[i] = R[i]; kkValid = false; }
+            if (inRegs) { for (int i = lane; i < M; i += WAVE) qt_key(A, i) = qt_key(R, i); kkValid = false; }
             else { KP t = A; A = B; B = t; }
         }
     }
@@ -2776,7 +2785,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
 #pragma unroll
                     for (int u = 0; u < QT3_KCH; ++u) {
                         const int e = b0 + u * WAVE + lane;
-                        if (b0 + u * WAVE < M) kk[u] = e < M ? A[e] : 0u;
+                        if (b0 + u * WAVE < M) kk[u] = e < M ? qt_key(A, e) : 0u;
                     }
                 }
 #pragma unroll
@@ -2965,7 +2974,7 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
             const uint32_t cursor = k.act ? (S.cc[2 * k.p + (sl >> 1)] >> (16 * (sl & 1))) & 0xFFFFu : 0u;
             const uint32_t dest = div ? cursor + (uint32_t)__popcll(mq & k.R & lt) : cursor + (uint32_t)k.e0;
             if (div && lane == k.lo) addSlots(k, m);  // (LDS operations of a wave complete in order: every lane has read its cursor)
-            if (k.act) B[dest] = k.key;
+            if (k.act) qt_key(B, dest) = k.key;
         });
         if (!inRegs) { KP t = A; A = B; B = t; }
         kkValid = false;
@@ -3003,9 +3012,9 @@ __device__ __forceinline__ void qt3_body(QtArgsK &a, const OrbxLevelGeom &g, int
             int total;
             const int b = base + wave_excl_scan(n, total);
             if (p < size) {
-                uint32_t best = A[b];
+                uint32_t best = qt_key(A, b);
                 for (int i = 1; i < n; ++i) {
-                    const uint32_t key = A[b + i];
+                    const uint32_t key = qt_key(A, b + i);
                     if ((key >> 24) > (best >> 24)) best = key;
                 }
                 selOut[p] = best;
@@ -3039,6 +3048,9 @@ __device__ __forceinline__ bool qt_instance(QtArgsK &a, int &f, int &level, int 
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         M += v;
     }
+    // (the same value in every lane - say so: as a per-lane value it made `inRegs`, and with it every choice between the key buffers,
+    // divergent in the compiler's eyes, and the key pointers per-lane 64-bit addresses instead of a scalar base + a 32-bit offset)
+    M = __builtin_amdgcn_readfirstlane(M);
     return true;
 }
 
@@ -3711,6 +3723,7 @@ __global__ __launch_bounds__(QT4_NT) void k_quadtree_mw(QtArgs)
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         M += v;
     }
+    M = __builtin_amdgcn_readfirstlane(M);  // (wave-uniform: see qt_instance)
     uint32_t *selOut = a.sel + (size_t)f * a.selFrameStride + g.selBase;
     int *selCnt = a.selCount + (size_t)f * a.nlevels + level;
     if (M == 0 || M > a.maxKeys) { if (threadIdx.x == 0) *selCnt = M == 0 ? 0 : QT_DEFERRED; return; }
